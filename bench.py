@@ -1,0 +1,220 @@
+#!/usr/bin/env python3
+"""Benchmark of the DDPM sampling hot path on MI355X (BASELINE.json metric: images/sec, T=1000 sampling).
+
+Workload (N=1 and per GPU for N>1): cfg4 = CelebAMask-HQ 256x256 dDDPM-x3 -- batch 32 latents of 8x32x32,
+full-width UNet (unet_chan 128, dims (1,2,2,2)), linear schedule T=1000, then the x3 ConvResNet decoder +
+tanh to 3x256x256.  A "step" is one reverse step (UNet forward + fused x update) over the batch, run by the
+native hipGraph sampler; images/sec = B*N / (T * t_step + t_decode), with t_decode measured in the same run.
+Synthetic: closed-form weights (utils/synthetic.py), x_T and per-step noise from the in-kernel Philox stream.
+
+    python bench.py --gpus 1 --steps 200 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line on stdout; diagnostics go to stderr.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (os.path.join(ROOT, "downsampled-diffusion_amd"), ROOT):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+
+FP32_PEAK_TFLOPS = 157.3      # MI355X fp32 matrix = vector peak (MI355X_MICROARCH.md, chip-level parameters)
+T_STEPS = 1000
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def cfg4():
+    return dict(unet_chan=128, unet_in=8, unet_dims=(1, 2, 2, 2), unet_dropout=0.1, image_size=256, T=T_STEPS,
+                loss_type="simple", beta_schedule="linear", loss_flat="sum", d_mode="convolutional_res",
+                u_mode="convolutional_res", d_dropout=0, d_chans=64, d_n_blocks=3, u_n_blocks=3, ae_loss=True,
+                t_rec_max=100, force_latent=True, n_downsamples=3, dataset="celeba_hq", model="dddpm")
+
+
+def broadcast_model(model, rank, world):
+    """C1 of SURVEY.md section 2.1: rank 0's parameters + buffers go to every rank as ONE flat fp32 bucket over RCCL."""
+    import torch.distributed as dist
+    tensors = [t for t in model.state_dict().values() if t.dtype == torch.float32]
+    flat = torch.cat([t.reshape(-1) for t in tensors])
+    dist.broadcast(flat, src=0)
+    off = 0
+    with torch.no_grad():
+        for t in tensors:
+            t.copy_(flat[off:off + t.numel()].view_as(t))
+            off += t.numel()
+    return flat.numel() * 4
+
+
+def time_conv_roofline(device):
+    """Dominant kernel: the 3x3 conv 128->128 @32x32, batch 32 (igemm 128x128 tile).  Average launch duration from
+    HIP events on the launch stream; algorithmic FLOPs = 2*B*H*W*9*Cin*Cout."""
+    from ddk import ops
+    B, H, W, C, N = 32, 32, 32, 128, 128
+    g = torch.Generator(device="cpu").manual_seed(0)
+    x = torch.randn(B, H, W, C, generator=g).to(device)
+    w = (torch.randn(N, C, 3, 3, generator=g) * (C * 9) ** -0.5).to(device)
+    b = torch.zeros(N, device=device)
+    wp = ops.pack_conv_weight(w)
+    for _ in range(5):
+        ops.conv(ops.CONV3X3_S1, x, wp, b)
+    torch.cuda.synchronize()
+    n = 50
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        ops.conv(ops.CONV3X3_S1, x, wp, b)
+    e1.record()
+    torch.cuda.synchronize()
+    sec = e0.elapsed_time(e1) / 1e3 / n
+    flops = 2.0 * B * H * W * 9 * C * N
+    bytes_alg = 4.0 * (B * H * W * C + B * H * W * N + N * 9 * C)
+    return dict(kernel="igemm_kernel<128,128,2,2> conv3x3 128->128 @32x32 B=32", bound="mfma",
+                achieved=flops / sec / 1e12, peak=FP32_PEAK_TFLOPS, unit="TFLOP/s", frac=flops / sec / 1e12 / FP32_PEAK_TFLOPS,
+                traffic=None, launch_us=sec * 1e6, algorithmic_gflop=flops / 1e9, algorithmic_mbytes=bytes_alg / 1e6,
+                algorithmic_hbm_gbps=bytes_alg / sec / 1e9)
+
+
+def cpu_baseline(cfg, state_dict):
+    """The CPU oracle (torch-CPU restatement, pinned to the reference by tests/golden) timed on the host cores:
+    1 warm + 3 timed UNet steps of the cfg4 shape at a reduced batch, extrapolated to T=1000."""
+    from oracle import unet_ref as U
+    from utils import synthetic as syn
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    bcpu = 8
+    sd = {k[len("latent_model."):]: v.detach().cpu() for k, v in state_dict.items() if k.startswith("latent_model.")}
+    x = syn.synthetic_normal((bcpu, 8, 32, 32), "bench.cpu.x")
+    t = torch.full((bcpu,), 500, dtype=torch.long)
+    with torch.no_grad():
+        U.unet_forward(sd, cfg, x, t)
+        t0 = time.perf_counter()
+        reps = 3
+        for _ in range(reps):
+            U.unet_forward(sd, cfg, x, t)
+        dt = (time.perf_counter() - t0) / reps
+    return dict(value=bcpu / (T_STEPS * dt), unit="images/sec", cores=torch.get_num_threads(), kind="port",
+                sample=f"1 warm-up + {reps} timed UNet steps (8x32x32 latents, batch {bcpu}, {dt * 1e3:.0f} ms/step) "
+                       f"extrapolated to T={T_STEPS}; decoder excluded")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=32, help="latents per GPU (cfg4: 32)")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        log(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}; using WORLD_SIZE")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    from ddk import lib, ops
+    assert lib.load().ddk_device_ok() == 1, lib.last_error()
+    from models import DownsampleDDPM, Unet
+    from utils import synthetic as syn
+
+    cfg = cfg4()
+    model = DownsampleDDPM(cfg, Unet(cfg), "cuda", 3)
+    if rank == 0:
+        model.load_state_dict(syn.fill_state_dict(model.state_dict(), skip=syn.SCHEDULE_KEYS))
+    model = model.to(device).eval()
+    bcast_bytes = broadcast_model(model, rank, world) if world > 1 else 0
+    model.rng_stream_id = rank
+    model.use_graph = not args.no_graph
+
+    B, C, S = args.batch, 8, 32
+    unet = model.latent_model
+    plan = unet.plan()
+    tables = model._tables()
+    x = ops.randn((B, S, S, C), device, seed=1234, step=T_STEPS, stream_id=rank)
+
+    def run_steps(k):
+        done = 0
+        while done < k:
+            n = min(T_STEPS, k - done)
+            plan.sample_nhwc(x, tables, T_STEPS - 1, T_STEPS - n, seed=1234, stream_id=rank, use_graph=model.use_graph)
+            done += n
+
+    def decode():
+        return model.rescaled_upsample(ops.nhwc_to_nchw(x))
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        run_steps(max(args.warmup, 1))
+        decode()
+        fence()
+        t0 = time.perf_counter()
+        run_steps(args.steps)
+        fence()
+        elapsed = time.perf_counter() - t0
+        dec = []
+        for _ in range(3):
+            fence()
+            t1 = time.perf_counter()
+            img = decode()
+            fence()
+            dec.append(time.perf_counter() - t1)
+        t_decode = min(dec)
+        assert torch.isfinite(img).all() and img.shape == (B, 3, 256, 256)
+
+    if world > 1:
+        tmax = torch.tensor([elapsed, t_decode], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        elapsed, t_decode = float(tmax[0]), float(tmax[1])
+
+    t_step = elapsed / args.steps
+    images_per_sec = B * world / (T_STEPS * t_step + t_decode)
+    flops_step = unet.flops(B, S, S)
+
+    if rank == 0:
+        roof = time_conv_roofline(device)
+        out = {
+            "metric": "images/sec (T=1000 sampling), 256x256 dDDPM-x3",
+            "value": images_per_sec, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": t_step * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "cfg4: CelebAMask-HQ 256x256 dDDPM -downsample 3, 32 latents (8x32x32) per GPU, T=1000, "
+                                   "UNet chan 128 dims (1,2,2,2) + x3 ConvResNet decoder; batch-sharded, no collective in the loop",
+                       "batch_per_gpu": B, "global_batch": B * world, "T": T_STEPS, "unet_step_ms": t_step * 1e3,
+                       "decode_ms": t_decode * 1e3, "hip_graph": model.use_graph,
+                       "unet_gflop_per_step": flops_step / 1e9, "unet_tflops_achieved": flops_step / t_step / 1e12,
+                       "unet_frac_of_fp32_peak": flops_step / t_step / 1e12 / FP32_PEAK_TFLOPS,
+                       "weights_broadcast_bytes": bcast_bytes},
+            "roofline": roof,
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, model.state_dict())
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,147 @@
+// attention.hip -- LinearAttention core (reference models/unet/blocks.py:126-134).
+//
+//   q, k, v = split(to_qkv(x));  k = softmax over the n = H*W pixels;
+//   ctx[d][e] = sum_n k[d][n] v[e][n]   (32 x 32 per (sample, head));   out[e][n] = sum_d ctx[d][e] q[d][n]
+//
+// There is no n x n matrix: per (sample, head) the state is 32x32, so the work is two streaming passes
+// over the [n][3*heads*32] projection (NHWC: a pixel's q|k|v are contiguous).  The 1x1 projections
+// to_qkv / to_out run on the MFMA implicit-GEMM kernel (conv_igemm.hip); this file is the part between.
+#include "ddk_internal.h"
+
+namespace ddk {
+
+constexpr int DH = 32;  // dim_head (blocks.py:119)
+
+// One workgroup per (b, head).  Pass 1: column max of k over n.  Pass 2: tiles of 64 pixels -> LDS
+// (exp(k - max), v), each thread accumulates a 1x4 strip of ctx plus the softmax denominator of its row.
+__global__ __launch_bounds__(256) void linattn_context_kernel(const float* __restrict__ qkv, float* __restrict__ ctx, int HW, int heads) {
+    __shared__ __attribute__((aligned(16))) float kexp[64 * DH];
+    __shared__ __attribute__((aligned(16))) float vs[64 * DH];
+    __shared__ float smax[8 * DH];
+    const int b = blockIdx.x / heads, h = blockIdx.x % heads;
+    const int HC = heads * DH, RS = 3 * HC;
+    const float* base = qkv + (long long)b * HW * RS;
+    const float* kp = base + HC + h * DH;
+    const float* vp = base + 2 * HC + h * DH;
+    const int tid = threadIdx.x;
+
+    {   // pass 1: max_n k[n][d]
+        const int d = tid & 31, ng = tid >> 5;
+        float m = -INFINITY;
+        for (int n = ng; n < HW; n += 8) m = fmaxf(m, kp[(long long)n * RS + d]);
+        smax[ng * DH + d] = m;
+        __syncthreads();
+        if (tid < DH) {
+            float mm = smax[tid];
+#pragma unroll
+            for (int j = 1; j < 8; ++j) mm = fmaxf(mm, smax[j * DH + tid]);
+            smax[tid] = mm;
+        }
+        __syncthreads();
+    }
+
+    const int d = tid >> 3, e0 = (tid & 7) * 4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float den = 0.f;
+    for (int n0 = 0; n0 < HW; n0 += 64) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int idx4 = tid + j * 256;
+            const int row = idx4 >> 3, c = (idx4 & 7) * 4;
+            float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
+            if (n0 + row < HW) {
+                kv = *reinterpret_cast<const float4*>(kp + (long long)(n0 + row) * RS + c);
+                vv = *reinterpret_cast<const float4*>(vp + (long long)(n0 + row) * RS + c);
+                kv.x = expf(kv.x - smax[c]);
+                kv.y = expf(kv.y - smax[c + 1]);
+                kv.z = expf(kv.z - smax[c + 2]);
+                kv.w = expf(kv.w - smax[c + 3]);
+            }
+            *reinterpret_cast<float4*>(kexp + row * DH + c) = kv;
+            *reinterpret_cast<float4*>(vs + row * DH + c) = vv;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int n = 0; n < 64; ++n) {
+            const float kd = kexp[n * DH + d];
+            const float4 v4 = *reinterpret_cast<const float4*>(vs + n * DH + e0);
+            acc.x += kd * v4.x; acc.y += kd * v4.y; acc.z += kd * v4.z; acc.w += kd * v4.w;
+            den += kd;
+        }
+        __syncthreads();
+    }
+    const float inv = 1.0f / den;
+    acc.x *= inv; acc.y *= inv; acc.z *= inv; acc.w *= inv;
+    *reinterpret_cast<float4*>(ctx + (((long long)b * heads + h) * DH + d) * DH + e0) = acc;
+}
+
+// 64 pixels x `heads` threads per workgroup; the sample's ctx (heads x 32 x 32) sits in LDS with a
+// 16-byte skew per head so the `heads` distinct addresses of a wave fall on distinct bank slots.
+__global__ __launch_bounds__(512) void linattn_apply_kernel(const float* __restrict__ qkv, const float* __restrict__ ctx,
+                                                            float* __restrict__ out, int HW, int heads, int tiles_per_sample) {
+    extern __shared__ __attribute__((aligned(16))) float cs[];
+    constexpr int HP = DH * DH + 4;  // per-head pitch
+    const int b = blockIdx.x / tiles_per_sample, tile = blockIdx.x % tiles_per_sample;
+    const int HC = heads * DH, RS = 3 * HC;
+    const int nthreads = 64 * heads;
+    for (int i = threadIdx.x; i < heads * DH * DH / 4; i += nthreads) {
+        const int hh = (i * 4) / (DH * DH), r = (i * 4) % (DH * DH);
+        *reinterpret_cast<float4*>(cs + hh * HP + r) =
+            *reinterpret_cast<const float4*>(ctx + ((long long)b * heads + hh) * DH * DH + r);
+    }
+    __syncthreads();
+    const int h = threadIdx.x % heads, pl = threadIdx.x / heads;
+    const int n = tile * 64 + pl;
+    if (n >= HW) return;
+    const float* qp = qkv + ((long long)b * HW + n) * RS + h * DH;
+    float q[DH];
+#pragma unroll
+    for (int i = 0; i < DH / 4; ++i) {
+        const float4 t = *reinterpret_cast<const float4*>(qp + i * 4);
+        q[4 * i] = t.x; q[4 * i + 1] = t.y; q[4 * i + 2] = t.z; q[4 * i + 3] = t.w;
+    }
+    float4 acc[DH / 4];
+#pragma unroll
+    for (int i = 0; i < DH / 4; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* ch = cs + h * HP;
+#pragma unroll
+    for (int d = 0; d < DH; ++d) {
+        const float qd = q[d];
+#pragma unroll
+        for (int i = 0; i < DH / 4; ++i) {
+            const float4 c4 = *reinterpret_cast<const float4*>(ch + d * DH + i * 4);
+            acc[i].x += qd * c4.x; acc[i].y += qd * c4.y; acc[i].z += qd * c4.z; acc[i].w += qd * c4.w;
+        }
+    }
+    float* op = out + ((long long)b * HW + n) * HC + h * DH;
+#pragma unroll
+    for (int i = 0; i < DH / 4; ++i) *reinterpret_cast<float4*>(op + i * 4) = acc[i];
+}
+
+int linattn_context(const float* qkv, float* ctx, int B, int HW, int heads, hipStream_t st) {
+    DDK_REQUIRE(qkv && ctx && B > 0 && HW > 0 && heads > 0, "linattn_context: arguments");
+    DDK_REQUIRE(aligned16(qkv) && aligned16(ctx), "linattn_context: alignment");
+    hipLaunchKernelGGL(linattn_context_kernel, dim3(B * heads), dim3(256), 0, st, qkv, ctx, HW, heads);
+    return check_launch("linattn_context_kernel");
+}
+
+int linattn_apply(const float* qkv, const float* ctx, float* out, int B, int HW, int heads, hipStream_t st) {
+    DDK_REQUIRE(qkv && ctx && out && B > 0 && HW > 0, "linattn_apply: arguments");
+    DDK_REQUIRE(heads >= 1 && heads <= 8, "linattn_apply: heads must be in 1..8");
+    DDK_REQUIRE(aligned16(qkv) && aligned16(ctx) && aligned16(out), "linattn_apply: alignment");
+    const int tiles = (int)ceil_div(HW, 64);
+    const size_t lds = (size_t)heads * (DH * DH + 4) * sizeof(float);
+    hipLaunchKernelGGL(linattn_apply_kernel, dim3(B * tiles), dim3(64 * heads), lds, st, qkv, ctx, out, HW, heads, tiles);
+    return check_launch("linattn_apply_kernel");
+}
+
+}  // namespace ddk
+
+extern "C" {
+int ddk_linattn_context(const float* qkv, float* ctx, int B, int HW, int heads, ddk_stream_t s) {
+    return ddk::linattn_context(qkv, ctx, B, HW, heads, ddk::as_stream(s));
+}
+int ddk_linattn_apply(const float* qkv, const float* ctx, float* out, int B, int HW, int heads, ddk_stream_t s) {
+    return ddk::linattn_apply(qkv, ctx, out, B, HW, heads, ddk::as_stream(s));
+}
+}

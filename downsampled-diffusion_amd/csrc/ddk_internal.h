@@ -1,0 +1,131 @@
+// Internal helpers shared by the libddk.so translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "ddk.h"
+
+namespace ddk {
+
+void set_error(const char* fmt, ...);
+
+inline int fail_arg(const char* what) {
+    set_error("bad argument: %s", what);
+    return DDK_ERR_ARG;
+}
+
+// Checks the launch that was just enqueued (no sync: only catches configuration errors).
+inline int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: %s", what, hipGetErrorString(e));
+        return DDK_ERR_HIP;
+    }
+    return DDK_OK;
+}
+
+#define DDK_REQUIRE(cond, msg)              \
+    do {                                    \
+        if (!(cond)) return ddk::fail_arg(msg); \
+    } while (0)
+
+#define DDK_HIP(call)                                                    \
+    do {                                                                 \
+        hipError_t e_ = (call);                                          \
+        if (e_ != hipSuccess) {                                          \
+            ddk::set_error("%s: %s", #call, hipGetErrorString(e_));      \
+            return DDK_ERR_HIP;                                          \
+        }                                                                \
+    } while (0)
+
+#define DDK_TRY(expr)              \
+    do {                           \
+        int rc_ = (expr);          \
+        if (rc_ != DDK_OK) return rc_; \
+    } while (0)
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+inline hipStream_t as_stream(ddk_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+inline long long ceil_div(long long a, long long b) { return (a + b - 1) / b; }
+
+// ---- device helpers -------------------------------------------------------------------------
+// Mish(x) = x * tanh(softplus(x)).  With n = e^x (e^x + 2): tanh(ln(1+e^x)) = n / (n + 2), which has
+// no cancellation for x << 0 and one exp + one divide.  For x > 20 softplus(x) == x in torch
+// (threshold 20) and tanh(x) rounds to 1 in fp32, so Mish(x) == x.
+__device__ __forceinline__ float mish_f(float x) {
+    if (x > 20.0f) return x;
+    float e = expf(x);
+    float n = e * (e + 2.0f);
+    return x * (n / (n + 2.0f));
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// Sum over the whole workgroup (blockDim.x a multiple of 64, <= 1024); result valid in every thread.
+// `red` is at least 17 floats of LDS.
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();  // protect `red` from a previous use
+    if (lane == 0) red[wid] = v;
+    __syncthreads();
+    float t = (lane < nw) ? red[lane] : 0.0f;
+    t = wave_sum(t);
+    return t;
+}
+
+__device__ __forceinline__ float block_max(float v, float* red) {
+    v = wave_max(v);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[wid] = v;
+    __syncthreads();
+    float t = (lane < nw) ? red[lane] : -INFINITY;
+    t = wave_max(t);
+    return t;
+}
+
+// ---- internal launchers used by the UNet plan (same arithmetic as the public entry points) ----
+// conv_igemm.hip
+size_t conv_workspace_bytes(int kind, int B, int H, int W, int cin, int N);
+int conv_forward(const ddk_conv_args& a, hipStream_t st);
+double conv_flops(int kind, int B, int H, int W, int cin, int N);
+// norm_act.hip
+size_t groupnorm_workspace_bytes(int B, int HW, int C, int groups);
+int groupnorm_mish(const float* x, const float* gamma, const float* beta, const float* temb, int temb_stride,
+                   const float* addend, float* out, int B, int HW, int C, int groups, float eps, void* ws, size_t ws_bytes,
+                   hipStream_t st);
+int chan_layernorm(const float* x, const float* g, const float* b, float* out, long long M, int C, float eps, hipStream_t st);
+int unary(int op, const float* x, float* out, long long n, hipStream_t st);
+int add(const float* a, const float* b, float* out, long long n, hipStream_t st);
+int avgpool2(const float* x, float* out, int B, int H, int W, int C, hipStream_t st);
+int upsample_nearest2(const float* x, float* out, int B, int H, int W, int C, hipStream_t st);
+// attention.hip
+int linattn_context(const float* qkv, float* ctx, int B, int HW, int heads, hipStream_t st);
+int linattn_apply(const float* qkv, const float* ctx, float* out, int B, int HW, int heads, hipStream_t st);
+// time_embed.hip
+int time_mlp(const int64_t* t, const float* freqs, const float* w1t, const float* b1, const float* w2t, const float* b2,
+             float* act, float* raw, int B, int dim, hipStream_t st);
+int time_proj(const float* act, const float* wt, const float* bias, float* out, int B, int dim, int n_out, hipStream_t st);
+// layout_pack.hip
+int conv1x1_small_n(const float* x, const float* w, const float* bias, float* out, long long M, int C, int n_out, hipStream_t st);
+// diffusion.hip
+int p_sample_update(float* x, const float* eps_hat, const float* noise, long long noise_step_stride, int t_first,
+                    const int64_t* t, const float* c_recip, const float* c_recipm1, const float* c1, const float* c2,
+                    const float* sigma, int B, long long per, uint64_t seed, uint32_t stream_id, hipStream_t st);
+int randn(float* out, long long n, uint64_t seed, uint32_t step, uint32_t stream_id, hipStream_t st);
+
+}  // namespace ddk

@@ -1,0 +1,178 @@
+// diffusion.hip -- noise-schedule arithmetic of the DDPM (HBM-bound elementwise kernels).
+//
+// Reference: models/diffusion/ddpm.py:256-273 (q_sample), :149-158 (predict_x_from_eps, clamp),
+// :177-185 (q_posterior mean), :203-227 (p_sample), :241 (x_T ~ N(0,1)), :279 + utils/utils.py:34-40
+// (per-sample squared-error sum); models/utils/helpers.py:31-40 (extract, noise_like).
+//
+// The coefficient tables are the module's [T] fp32 buffers; each sample gathers its own t.  Products and
+// sums use __fmul_rn/__fadd_rn in the reference's evaluation order (no FMA contraction), so given the
+// same eps_hat and noise the update is bit-identical to the torch expression.
+#include "ddk_internal.h"
+
+namespace ddk {
+
+// ---- Philox4x32-10 (Salmon et al. SC'11; Random123 philox4x32_R(10)) -----------------------------
+struct U4 { uint32_t x, y, z, w; };
+
+__device__ __forceinline__ U4 philox4x32_10(U4 c, uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        if (r > 0) { k0 += 0x9E3779B9u; k1 += 0xBB67AE85u; }
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
+        c = U4{hi1 ^ c.y ^ k0, lo1, hi0 ^ c.w ^ k1, lo0};
+    }
+    return c;
+}
+
+__device__ __forceinline__ float u01(uint32_t r) { return ((float)(r >> 8) + 0.5f) * 5.9604644775390625e-8f; }  // 2^-24
+
+__device__ __forceinline__ float4 philox_normal4(unsigned long long idx4, uint32_t step, uint32_t stream, uint64_t seed) {
+    const U4 r = philox4x32_10(U4{(uint32_t)idx4, (uint32_t)(idx4 >> 32), step, stream}, (uint32_t)seed, (uint32_t)(seed >> 32));
+    const float two_pi = 6.283185307179586f;
+    float4 z;
+    float sn, cs;
+    float rad = sqrtf(-2.0f * logf(u01(r.x)));
+    sincosf(two_pi * u01(r.y), &sn, &cs);
+    z.x = rad * cs; z.y = rad * sn;
+    rad = sqrtf(-2.0f * logf(u01(r.z)));
+    sincosf(two_pi * u01(r.w), &sn, &cs);
+    z.z = rad * cs; z.w = rad * sn;
+    return z;
+}
+
+static int grid1d(long long n) {
+    const long long b = ceil_div(n > 0 ? n : 1, 256);
+    return (int)(b < 2048 ? b : 2048);
+}
+
+__global__ __launch_bounds__(256) void randn_kernel(float* __restrict__ out, long long n4, long long n, uint64_t seed, uint32_t step,
+                                                    uint32_t stream) {
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const float4 z = philox_normal4((unsigned long long)i, step, stream, seed);
+        if (i * 4 + 3 < n) {
+            reinterpret_cast<float4*>(out)[i] = z;
+        } else {
+            const float zz[4] = {z.x, z.y, z.z, z.w};
+            for (int j = 0; j < 4 && i * 4 + j < n; ++j) out[i * 4 + j] = zz[j];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void q_sample_kernel(const float* __restrict__ x, const float* __restrict__ eps,
+                                                       const int64_t* __restrict__ t, const float* __restrict__ ca,
+                                                       const float* __restrict__ cb, float* __restrict__ out, long long per4,
+                                                       long long total4) {
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total4; i += (long long)gridDim.x * 256) {
+        const int64_t tb = t[i / per4];
+        const float a = ca[tb], b = cb[tb];
+        const float4 xv = reinterpret_cast<const float4*>(x)[i], ev = reinterpret_cast<const float4*>(eps)[i];
+        float4 o;
+        o.x = __fadd_rn(__fmul_rn(a, xv.x), __fmul_rn(b, ev.x));
+        o.y = __fadd_rn(__fmul_rn(a, xv.y), __fmul_rn(b, ev.y));
+        o.z = __fadd_rn(__fmul_rn(a, xv.z), __fmul_rn(b, ev.z));
+        o.w = __fadd_rn(__fmul_rn(a, xv.w), __fmul_rn(b, ev.w));
+        reinterpret_cast<float4*>(out)[i] = o;
+    }
+}
+
+__device__ __forceinline__ float p_step(float x, float e, float z, float cr, float crm1, float c1, float c2, float sg) {
+    float x0 = __fsub_rn(__fmul_rn(cr, x), __fmul_rn(crm1, e));     // ddpm.py:152-155
+    x0 = fminf(fmaxf(x0, -1.0f), 1.0f);                             // ddpm.py:157 clamp_(-1, 1)
+    const float mean = __fadd_rn(__fmul_rn(c1, x0), __fmul_rn(c2, x));  // ddpm.py:177-180
+    return __fadd_rn(mean, __fmul_rn(sg, z));                       // ddpm.py:227 (sg already carries the t>0 mask)
+}
+
+__global__ __launch_bounds__(256) void p_sample_kernel(float* __restrict__ x, const float* __restrict__ eps_hat,
+                                                       const float* __restrict__ noise, long long noise_step_stride, int t_first,
+                                                       const int64_t* __restrict__ t,
+                                                       const float* __restrict__ c_recip, const float* __restrict__ c_recipm1,
+                                                       const float* __restrict__ c1, const float* __restrict__ c2,
+                                                       const float* __restrict__ sigma, long long per4, long long total4,
+                                                       uint64_t seed, uint32_t stream) {
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total4; i += (long long)gridDim.x * 256) {
+        const int64_t tb = t[i / per4];
+        const float cr = c_recip[tb], crm1 = c_recipm1[tb], a1 = c1[tb], a2 = c2[tb];
+        const float sg = tb > 0 ? sigma[tb] : 0.0f;  // nonzero_mask * exp(0.5 logvar), ddpm.py:220-227
+        const float4 xv = reinterpret_cast<const float4*>(x)[i], ev = reinterpret_cast<const float4*>(eps_hat)[i];
+        // injected noise: draw k = t_first - t of a [n_steps][...] array (stride 0: a single tensor)
+        const float4 zv = noise ? reinterpret_cast<const float4*>(noise + (long long)(t_first - tb) * noise_step_stride)[i]
+                                : philox_normal4((unsigned long long)i, (uint32_t)tb, stream, seed);
+        float4 o;
+        o.x = p_step(xv.x, ev.x, zv.x, cr, crm1, a1, a2, sg);
+        o.y = p_step(xv.y, ev.y, zv.y, cr, crm1, a1, a2, sg);
+        o.z = p_step(xv.z, ev.z, zv.z, cr, crm1, a1, a2, sg);
+        o.w = p_step(xv.w, ev.w, zv.w, cr, crm1, a1, a2, sg);
+        reinterpret_cast<float4*>(x)[i] = o;
+    }
+}
+
+// one workgroup per sample: fixed summation tree -> run-to-run deterministic
+__global__ __launch_bounds__(1024) void sq_err_sum_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                          float* __restrict__ per_sample, long long per4) {
+    __shared__ float red[32];
+    const float4* ap = reinterpret_cast<const float4*>(a) + blockIdx.x * per4;
+    const float4* bp = reinterpret_cast<const float4*>(b) + blockIdx.x * per4;
+    float s = 0.f;
+    for (long long i = threadIdx.x; i < per4; i += blockDim.x) {
+        const float4 u = ap[i], v = bp[i];
+        const float d0 = u.x - v.x, d1 = u.y - v.y, d2 = u.z - v.z, d3 = u.w - v.w;
+        s += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+    }
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) per_sample[blockIdx.x] = s;
+}
+
+int p_sample_update(float* x, const float* eps_hat, const float* noise, long long noise_step_stride, int t_first,
+                    const int64_t* t, const float* c_recip, const float* c_recipm1, const float* c1, const float* c2,
+                    const float* sigma, int B, long long per, uint64_t seed, uint32_t stream_id, hipStream_t st) {
+    DDK_REQUIRE(x && eps_hat && t && c_recip && c_recipm1 && c1 && c2 && sigma, "p_sample_update: null pointer");
+    DDK_REQUIRE(B > 0 && per > 0 && per % 4 == 0, "p_sample_update: per-sample element count must be a multiple of 4");
+    DDK_REQUIRE(aligned16(x) && aligned16(eps_hat) && aligned16(noise) && noise_step_stride % 4 == 0, "p_sample_update: alignment");
+    const long long total4 = B * per / 4;
+    hipLaunchKernelGGL(p_sample_kernel, dim3(grid1d(total4)), dim3(256), 0, st, x, eps_hat, noise, noise_step_stride, t_first, t,
+                       c_recip, c_recipm1, c1, c2, sigma, per / 4, total4, seed, stream_id);
+    return check_launch("p_sample_kernel");
+}
+
+int randn(float* out, long long n, uint64_t seed, uint32_t step, uint32_t stream_id, hipStream_t st) {
+    DDK_REQUIRE(out && n > 0 && aligned16(out), "randn: arguments");
+    const long long n4 = (n + 3) / 4;
+    hipLaunchKernelGGL(randn_kernel, dim3(grid1d(n4)), dim3(256), 0, st, out, n4, n, seed, step, stream_id);
+    return check_launch("randn_kernel");
+}
+
+}  // namespace ddk
+
+using namespace ddk;
+
+extern "C" {
+
+int ddk_q_sample(const float* x, const float* eps, const int64_t* t, const float* sqrt_acp, const float* sqrt_1m_acp, float* out,
+                 int B, long long per, ddk_stream_t s) {
+    DDK_REQUIRE(x && eps && t && sqrt_acp && sqrt_1m_acp && out, "q_sample: null pointer");
+    DDK_REQUIRE(B > 0 && per > 0 && per % 4 == 0, "q_sample: per-sample element count must be a multiple of 4");
+    DDK_REQUIRE(aligned16(x) && aligned16(eps) && aligned16(out), "q_sample: alignment");
+    const long long total4 = B * per / 4;
+    hipLaunchKernelGGL(q_sample_kernel, dim3(grid1d(total4)), dim3(256), 0, as_stream(s), x, eps, t, sqrt_acp, sqrt_1m_acp, out,
+                       per / 4, total4);
+    return check_launch("q_sample_kernel");
+}
+
+int ddk_p_sample_update(float* x, const float* eps_hat, const float* noise, const int64_t* t, const float* c_recip,
+                        const float* c_recipm1, const float* c1, const float* c2, const float* sigma, int B, long long per,
+                        uint64_t seed, uint32_t stream_id, ddk_stream_t s) {
+    return p_sample_update(x, eps_hat, noise, 0, 0, t, c_recip, c_recipm1, c1, c2, sigma, B, per, seed, stream_id, as_stream(s));
+}
+
+int ddk_randn(float* out, long long n, uint64_t seed, uint32_t step, uint32_t stream_id, ddk_stream_t s) {
+    return randn(out, n, seed, step, stream_id, as_stream(s));
+}
+
+int ddk_sq_err_sum(const float* a, const float* b, float* per_sample, int B, long long per, ddk_stream_t s) {
+    DDK_REQUIRE(a && b && per_sample && B > 0 && per > 0 && per % 4 == 0, "sq_err_sum: arguments (per % 4 == 0)");
+    DDK_REQUIRE(aligned16(a) && aligned16(b), "sq_err_sum: alignment");
+    hipLaunchKernelGGL(sq_err_sum_kernel, dim3(B), dim3(1024), 0, as_stream(s), a, b, per_sample, per / 4);
+    return check_launch("sq_err_sum_kernel");
+}
+}

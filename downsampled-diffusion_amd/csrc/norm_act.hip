@@ -1,0 +1,409 @@
+// norm_act.hip -- GroupNorm+Mish(+time shift)(+residual), channel LayerNorm, and the small elementwise /
+// resampling kernels of the dDDPM ConvResNet.  All HBM/L2-bound: 16-byte accesses, wavefront-shuffle
+// reductions, one read + one write per element.
+//
+// Reference sites: models/unet/blocks.py:57-60 (LayerNorm), :79-80 (GroupNorm, Mish), :106-115 (time
+// shift + residual), models/downsampled/convblocks.py:110-130 (Mish, avg_pool2d, nearest x2),
+// models/diffusion/dddpm.py:99,110 (tanh).
+#include "ddk_internal.h"
+
+namespace ddk {
+
+// ------------------------------------------------------------------------------------------------
+// GroupNorm(groups, eps, affine) -> Mish -> (+ temb[b][c]) -> (+ addend), NHWC.
+// One workgroup per (b, group): the group's HW x cpg slab (<= 256 * 4 * VPT floats) is read once into
+// registers, mean and biased variance are two block reductions over the registers (two-pass, like
+// torch's native_group_norm), and the result is written once.
+template <int VPT>
+__global__ __launch_bounds__(256) void gn_mish_resident_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, const float* __restrict__ temb,
+                                                               int temb_stride, const float* __restrict__ addend,
+                                                               float* __restrict__ out, int HW, int C, int groups, float eps) {
+    __shared__ float red[32];
+    const int b = blockIdx.x / groups, g = blockIdx.x % groups;
+    const int cpg = C / groups;
+    const int upr = cpg >> 2;                 // float4 units per pixel row of this group
+    const int units = HW * upr;
+    const long long base = (long long)b * HW * C + g * cpg;
+
+    float4 v[VPT];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+        const int u = threadIdx.x + i * 256;
+        if (u < units) {
+            const int row = u / upr, cu = u - row * upr;
+            v[i] = *reinterpret_cast<const float4*>(x + base + (long long)row * C + cu * 4);
+            s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        } else {
+            v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    const float inv_n = 1.0f / (float)(HW * cpg);
+    const float mean = block_sum(s, red) * inv_n;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+        const int u = threadIdx.x + i * 256;
+        if (u < units) {
+            const float a = v[i].x - mean, bb = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+            q += (a * a + bb * bb) + (c * c + d * d);
+        }
+    }
+    const float var = block_sum(q, red) * inv_n;
+    const float rstd = 1.0f / sqrtf(var + eps);
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+        const int u = threadIdx.x + i * 256;
+        if (u < units) {
+            const int row = u / upr, cu = u - row * upr;
+            const int c0 = g * cpg + cu * 4;
+            const float4 ga = *reinterpret_cast<const float4*>(gamma + c0);
+            const float4 be = *reinterpret_cast<const float4*>(beta + c0);
+            float4 y;
+            y.x = mish_f((v[i].x - mean) * rstd * ga.x + be.x);
+            y.y = mish_f((v[i].y - mean) * rstd * ga.y + be.y);
+            y.z = mish_f((v[i].z - mean) * rstd * ga.z + be.z);
+            y.w = mish_f((v[i].w - mean) * rstd * ga.w + be.w);
+            if (temb) {
+                const float4 t = *reinterpret_cast<const float4*>(temb + (long long)b * temb_stride + c0);
+                y.x += t.x; y.y += t.y; y.z += t.z; y.w += t.w;
+            }
+            const long long o = base + (long long)row * C + cu * 4;
+            if (addend) {
+                const float4 r = *reinterpret_cast<const float4*>(addend + o);
+                y.x += r.x; y.y += r.y; y.z += r.z; y.w += r.w;
+            }
+            *reinterpret_cast<float4*>(out + o) = y;
+        }
+    }
+}
+
+// Large slabs (full-resolution DDPM, 256x256): stats by `nsplit` workgroups per (b, group) as Welford
+// partials (count, mean, M2) combined in a fixed order, then a grid-wide apply pass.
+__global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict__ x, float* __restrict__ part, int HW, int C,
+                                                         int groups, int nsplit) {
+    __shared__ float red[32];
+    const int bg = blockIdx.x, sp = blockIdx.y;
+    const int b = bg / groups, g = bg % groups;
+    const int cpg = C / groups, upr = cpg >> 2;
+    const long long units = (long long)HW * upr;
+    const long long per = (units + nsplit - 1) / nsplit;
+    const long long u0 = sp * per, u1 = (u0 + per < units) ? u0 + per : units;
+    const long long base = (long long)b * HW * C + g * cpg;
+    float s = 0.f;
+    for (long long u = u0 + threadIdx.x; u < u1; u += 256) {
+        const long long row = u / upr;
+        const int cu = (int)(u - row * upr);
+        const float4 v = *reinterpret_cast<const float4*>(x + base + row * C + cu * 4);
+        s += (v.x + v.y) + (v.z + v.w);
+    }
+    const float cnt = (float)((u1 > u0 ? u1 - u0 : 0) * 4);
+    const float mean = cnt > 0 ? block_sum(s, red) / cnt : 0.f;
+    float q = 0.f;
+    for (long long u = u0 + threadIdx.x; u < u1; u += 256) {
+        const long long row = u / upr;
+        const int cu = (int)(u - row * upr);
+        const float4 v = *reinterpret_cast<const float4*>(x + base + row * C + cu * 4);
+        const float a = v.x - mean, bb = v.y - mean, c = v.z - mean, d = v.w - mean;
+        q += (a * a + bb * bb) + (c * c + d * d);
+    }
+    const float m2 = block_sum(q, red);
+    if (threadIdx.x == 0) {
+        float* o = part + ((long long)bg * nsplit + sp) * 3;
+        o[0] = cnt; o[1] = mean; o[2] = m2;
+    }
+}
+
+__global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x, const float* __restrict__ part, int nsplit,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       const float* __restrict__ temb, int temb_stride,
+                                                       const float* __restrict__ addend, float* __restrict__ out, int HW, int C,
+                                                       int groups, float eps, long long total4) {
+    const int c4 = C >> 2, cpg = C / groups;
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total4; i += (long long)gridDim.x * 256) {
+        const int cq = (int)(i % c4);
+        const long long pix = i / c4;
+        const int b = (int)(pix / HW);
+        const int c0 = cq * 4, g = c0 / cpg;
+        // Chan et al. parallel combination of the Welford partials, fixed order
+        const float* pp = part + ((long long)(b * groups + g) * nsplit) * 3;
+        float n = pp[0], mean = pp[1], m2 = pp[2];
+        for (int s = 1; s < nsplit; ++s) {
+            const float nb = pp[3 * s], mb = pp[3 * s + 1], qb = pp[3 * s + 2];
+            if (nb > 0) {
+                const float tot = n + nb, delta = mb - mean;
+                mean += delta * (nb / tot);
+                m2 += qb + delta * delta * (n * nb / tot);
+                n = tot;
+            }
+        }
+        const float rstd = 1.0f / sqrtf(m2 / n + eps);
+        const float4 v = reinterpret_cast<const float4*>(x)[i];
+        const float4 ga = *reinterpret_cast<const float4*>(gamma + c0);
+        const float4 be = *reinterpret_cast<const float4*>(beta + c0);
+        float4 y;
+        y.x = mish_f((v.x - mean) * rstd * ga.x + be.x);
+        y.y = mish_f((v.y - mean) * rstd * ga.y + be.y);
+        y.z = mish_f((v.z - mean) * rstd * ga.z + be.z);
+        y.w = mish_f((v.w - mean) * rstd * ga.w + be.w);
+        if (temb) {
+            const float4 t = *reinterpret_cast<const float4*>(temb + (long long)b * temb_stride + c0);
+            y.x += t.x; y.y += t.y; y.z += t.z; y.w += t.w;
+        }
+        if (addend) {
+            const float4 r = reinterpret_cast<const float4*>(addend)[i];
+            y.x += r.x; y.y += r.y; y.z += r.z; y.w += r.w;
+        }
+        reinterpret_cast<float4*>(out)[i] = y;
+    }
+}
+
+static int gn_nsplit(int HW, int cpg) {
+    const long long n = (long long)HW * cpg;
+    if (n <= 256LL * 4 * 16) return 0;  // resident path
+    long long s = n / (256LL * 4 * 16);
+    return (int)(s > 64 ? 64 : (s < 2 ? 2 : s));
+}
+
+size_t groupnorm_workspace_bytes(int B, int HW, int C, int groups) {
+    if (groups <= 0 || C % groups) return 0;
+    const int ns = gn_nsplit(HW, C / groups);
+    return (size_t)B * groups * ns * 3 * sizeof(float);
+}
+
+int groupnorm_mish(const float* x, const float* gamma, const float* beta, const float* temb, int temb_stride,
+                   const float* addend, float* out, int B, int HW, int C, int groups, float eps, void* ws, size_t ws_bytes,
+                   hipStream_t st) {
+    DDK_REQUIRE(x && gamma && beta && out, "groupnorm: null pointer");
+    DDK_REQUIRE(B > 0 && HW > 0 && groups > 0 && C % groups == 0 && (C / groups) % 4 == 0,
+                "groupnorm: C/groups must be a multiple of 4");
+    DDK_REQUIRE(aligned16(x) && aligned16(out) && aligned16(gamma) && aligned16(beta) && aligned16(temb) && aligned16(addend),
+                "groupnorm: alignment");
+    DDK_REQUIRE(temb == nullptr || temb_stride % 4 == 0, "groupnorm: temb_stride % 4");
+    const int cpg = C / groups;
+    const int ns = gn_nsplit(HW, cpg);
+    if (ns == 0) {
+        const int units = HW * (cpg / 4);
+        const int vpt = (int)ceil_div(units, 256);
+        dim3 grid(B * groups), block(256);
+#define GN_CASE(V)                                                                                                        \
+    hipLaunchKernelGGL((gn_mish_resident_kernel<V>), grid, block, 0, st, x, gamma, beta, temb, temb_stride, addend, out, \
+                       HW, C, groups, eps)
+        if (vpt <= 1) GN_CASE(1);
+        else if (vpt <= 2) GN_CASE(2);
+        else if (vpt <= 4) GN_CASE(4);
+        else if (vpt <= 8) GN_CASE(8);
+        else GN_CASE(16);
+#undef GN_CASE
+        return check_launch("gn_mish_resident_kernel");
+    }
+    const size_t need = (size_t)B * groups * ns * 3 * sizeof(float);
+    if (!ws || ws_bytes < need) {
+        set_error("groupnorm: workspace too small (%zu < %zu)", ws_bytes, need);
+        return DDK_ERR_WORKSPACE;
+    }
+    float* part = static_cast<float*>(ws);
+    hipLaunchKernelGGL(gn_partial_kernel, dim3(B * groups, ns), dim3(256), 0, st, x, part, HW, C, groups, ns);
+    DDK_TRY(check_launch("gn_partial_kernel"));
+    const long long total4 = (long long)B * HW * C / 4;
+    const int blocks = (int)(ceil_div(total4, 256) < 4096 ? ceil_div(total4, 256) : 4096);
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(blocks), dim3(256), 0, st, x, part, ns, gamma, beta, temb, temb_stride, addend, out,
+                       HW, C, groups, eps, total4);
+    return check_launch("gn_apply_kernel");
+}
+
+// ------------------------------------------------------------------------------------------------
+// Channel LayerNorm: LPP lanes per pixel (C/4 capped at 64), 64/LPP pixels per wave, the pixel's C
+// floats live in registers, mean and biased variance by xor-shuffles inside the lane group.
+template <int LPP, int VPL>
+__global__ __launch_bounds__(256) void chan_layernorm_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                             const float* __restrict__ bta, float* __restrict__ out,
+                                                             long long M, int C, float eps) {
+    constexpr int PPW = 64 / LPP;
+    const int lane = threadIdx.x & 63;
+    const long long wave = blockIdx.x * 4LL + (threadIdx.x >> 6);
+    const long long pix = wave * PPW + lane / LPP;
+    const int sub = lane % LPP;
+    const bool ok = pix < M;
+    float4 v[VPL];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        v[i] = ok ? *reinterpret_cast<const float4*>(x + pix * C + (sub + i * LPP) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+#pragma unroll
+    for (int o = LPP / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    const float mean = s / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+        q += (a * a + b * b) + (c * c + d * d);
+    }
+#pragma unroll
+    for (int o = LPP / 2; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+    const float inv = 1.0f / (sqrtf(q / (float)C) + eps);  // eps on the std (blocks.py:58-60)
+    if (!ok) return;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const int c0 = (sub + i * LPP) * 4;
+        const float4 ga = *reinterpret_cast<const float4*>(g + c0);
+        const float4 be = *reinterpret_cast<const float4*>(bta + c0);
+        float4 y;
+        y.x = (v[i].x - mean) * inv * ga.x + be.x;
+        y.y = (v[i].y - mean) * inv * ga.y + be.y;
+        y.z = (v[i].z - mean) * inv * ga.z + be.z;
+        y.w = (v[i].w - mean) * inv * ga.w + be.w;
+        *reinterpret_cast<float4*>(out + pix * C + c0) = y;
+    }
+}
+
+int chan_layernorm(const float* x, const float* g, const float* b, float* out, long long M, int C, float eps, hipStream_t st) {
+    DDK_REQUIRE(x && g && b && out && M > 0, "layernorm: null pointer / M");
+    DDK_REQUIRE(aligned16(x) && aligned16(g) && aligned16(b) && aligned16(out), "layernorm: alignment");
+#define LN_CASE(LPP, VPL)                                                                                                   \
+    do {                                                                                                                    \
+        const long long waves = ceil_div(M, 64 / LPP);                                                                      \
+        hipLaunchKernelGGL((chan_layernorm_kernel<LPP, VPL>), dim3((unsigned)ceil_div(waves, 4)), dim3(256), 0, st, x, g, b, out, M, \
+                           C, eps);                                                                                         \
+        return check_launch("chan_layernorm_kernel");                                                                       \
+    } while (0)
+    switch (C) {
+        case 32: LN_CASE(8, 1);
+        case 64: LN_CASE(16, 1);
+        case 96: LN_CASE(8, 3);
+        case 128: LN_CASE(32, 1);
+        case 192: LN_CASE(16, 3);
+        case 256: LN_CASE(64, 1);
+        case 384: LN_CASE(32, 3);
+        case 512: LN_CASE(64, 2);
+        case 768: LN_CASE(64, 3);
+        case 1024: LN_CASE(64, 4);
+        default: break;
+    }
+#undef LN_CASE
+    return fail_arg("layernorm: unsupported channel count (supported: 32,64,96,128,192,256,384,512,768,1024)");
+}
+
+// ------------------------------------------------------------------------------------------------
+template <int OP>  // 0 mish, 1 tanh
+__global__ __launch_bounds__(256) void unary_kernel(const float* __restrict__ x, float* __restrict__ out, long long n4, long long n) {
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        float4 v = reinterpret_cast<const float4*>(x)[i];
+        if (OP == 0) { v.x = mish_f(v.x); v.y = mish_f(v.y); v.z = mish_f(v.z); v.w = mish_f(v.w); }
+        else { v.x = tanhf(v.x); v.y = tanhf(v.y); v.z = tanhf(v.z); v.w = tanhf(v.w); }
+        reinterpret_cast<float4*>(out)[i] = v;
+    }
+    // tail (n not a multiple of 4)
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const long long i = (n4 << 2) + threadIdx.x;
+        out[i] = OP == 0 ? mish_f(x[i]) : tanhf(x[i]);
+    }
+}
+
+static int grid_for(long long n4) {
+    const long long b = ceil_div(n4 > 0 ? n4 : 1, 256);
+    return (int)(b < 2048 ? b : 2048);
+}
+
+int unary(int op, const float* x, float* out, long long n, hipStream_t st) {
+    DDK_REQUIRE(x && out && n > 0, "unary: null pointer / n");
+    DDK_REQUIRE(aligned16(x) && aligned16(out), "unary: alignment");
+    const long long n4 = n >> 2;
+    if (op == 0) hipLaunchKernelGGL(unary_kernel<0>, dim3(grid_for(n4)), dim3(256), 0, st, x, out, n4, n);
+    else hipLaunchKernelGGL(unary_kernel<1>, dim3(grid_for(n4)), dim3(256), 0, st, x, out, n4, n);
+    return check_launch("unary_kernel");
+}
+
+__global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
+                                                  long long n4) {
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const float4 u = reinterpret_cast<const float4*>(a)[i], v = reinterpret_cast<const float4*>(b)[i];
+        reinterpret_cast<float4*>(out)[i] = make_float4(u.x + v.x, u.y + v.y, u.z + v.z, u.w + v.w);
+    }
+}
+
+int add(const float* a, const float* b, float* out, long long n, hipStream_t st) {
+    DDK_REQUIRE(a && b && out && n > 0 && n % 4 == 0, "add: null pointer / n % 4");
+    DDK_REQUIRE(aligned16(a) && aligned16(b) && aligned16(out), "add: alignment");
+    hipLaunchKernelGGL(add_kernel, dim3(grid_for(n / 4)), dim3(256), 0, st, a, b, out, n / 4);
+    return check_launch("add_kernel");
+}
+
+// avg_pool2d(2): out[b][y][x][c] = ((x00 + x01) + (x10 + x11)) * 0.25
+__global__ __launch_bounds__(256) void avgpool2_kernel(const float* __restrict__ x, float* __restrict__ out, int H, int W, int C,
+                                                       long long total4) {
+    const int c4 = C >> 2, Ho = H >> 1, Wo = W >> 1;
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total4; i += (long long)gridDim.x * 256) {
+        const int cq = (int)(i % c4);
+        long long p = i / c4;
+        const int xo = (int)(p % Wo); p /= Wo;
+        const int yo = (int)(p % Ho);
+        const long long b = p / Ho;
+        const float* s = x + ((b * H + 2 * yo) * W + 2 * xo) * C + cq * 4;
+        const float4 a = *reinterpret_cast<const float4*>(s), bb = *reinterpret_cast<const float4*>(s + C);
+        const float4 c = *reinterpret_cast<const float4*>(s + (long long)W * C), d = *reinterpret_cast<const float4*>(s + (long long)W * C + C);
+        float4 r;
+        r.x = ((a.x + bb.x) + (c.x + d.x)) * 0.25f;
+        r.y = ((a.y + bb.y) + (c.y + d.y)) * 0.25f;
+        r.z = ((a.z + bb.z) + (c.z + d.z)) * 0.25f;
+        r.w = ((a.w + bb.w) + (c.w + d.w)) * 0.25f;
+        reinterpret_cast<float4*>(out)[i] = r;
+    }
+}
+
+int avgpool2(const float* x, float* out, int B, int H, int W, int C, hipStream_t st) {
+    DDK_REQUIRE(x && out && B > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && C % 4 == 0, "avgpool2: shape");
+    DDK_REQUIRE(aligned16(x) && aligned16(out), "avgpool2: alignment");
+    const long long total4 = (long long)B * (H / 2) * (W / 2) * (C / 4);
+    hipLaunchKernelGGL(avgpool2_kernel, dim3(grid_for(total4)), dim3(256), 0, st, x, out, H, W, C, total4);
+    return check_launch("avgpool2_kernel");
+}
+
+__global__ __launch_bounds__(256) void upnearest2_kernel(const float* __restrict__ x, float* __restrict__ out, int H, int W, int C,
+                                                         long long total4) {
+    const int c4 = C >> 2, Ho = H * 2, Wo = W * 2;
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total4; i += (long long)gridDim.x * 256) {
+        const int cq = (int)(i % c4);
+        long long p = i / c4;
+        const int xo = (int)(p % Wo); p /= Wo;
+        const int yo = (int)(p % Ho);
+        const long long b = p / Ho;
+        reinterpret_cast<float4*>(out)[i] =
+            *reinterpret_cast<const float4*>(x + ((b * H + (yo >> 1)) * W + (xo >> 1)) * C + cq * 4);
+    }
+}
+
+int upsample_nearest2(const float* x, float* out, int B, int H, int W, int C, hipStream_t st) {
+    DDK_REQUIRE(x && out && B > 0 && H > 0 && W > 0 && C % 4 == 0, "upsample_nearest2: shape");
+    DDK_REQUIRE(aligned16(x) && aligned16(out), "upsample_nearest2: alignment");
+    const long long total4 = (long long)B * (H * 2) * (W * 2) * (C / 4);
+    hipLaunchKernelGGL(upnearest2_kernel, dim3(grid_for(total4)), dim3(256), 0, st, x, out, H, W, C, total4);
+    return check_launch("upnearest2_kernel");
+}
+
+}  // namespace ddk
+
+extern "C" {
+int ddk_groupnorm_mish(const float* x, const float* gamma, const float* beta, const float* temb, int temb_stride,
+                       const float* addend, float* out, int B, int HW, int C, int groups, float eps, void* workspace,
+                       size_t workspace_bytes, ddk_stream_t s) {
+    return ddk::groupnorm_mish(x, gamma, beta, temb, temb_stride, addend, out, B, HW, C, groups, eps, workspace, workspace_bytes,
+                               ddk::as_stream(s));
+}
+size_t ddk_groupnorm_workspace_bytes(int B, int HW, int C, int groups) { return ddk::groupnorm_workspace_bytes(B, HW, C, groups); }
+int ddk_chan_layernorm(const float* x, const float* g, const float* b, float* out, long long M, int C, float eps, ddk_stream_t s) {
+    return ddk::chan_layernorm(x, g, b, out, M, C, eps, ddk::as_stream(s));
+}
+int ddk_mish(const float* x, float* out, long long n, ddk_stream_t s) { return ddk::unary(0, x, out, n, ddk::as_stream(s)); }
+int ddk_tanh(const float* x, float* out, long long n, ddk_stream_t s) { return ddk::unary(1, x, out, n, ddk::as_stream(s)); }
+int ddk_add(const float* a, const float* b, float* out, long long n, ddk_stream_t s) { return ddk::add(a, b, out, n, ddk::as_stream(s)); }
+int ddk_avgpool2(const float* x, float* out, int B, int H, int W, int C, ddk_stream_t s) {
+    return ddk::avgpool2(x, out, B, H, W, C, ddk::as_stream(s));
+}
+int ddk_upsample_nearest2(const float* x, float* out, int B, int H, int W, int C, ddk_stream_t s) {
+    return ddk::upsample_nearest2(x, out, B, H, W, C, ddk::as_stream(s));
+}
+}

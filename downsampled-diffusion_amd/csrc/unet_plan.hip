@@ -1,0 +1,618 @@
+// unet_plan.hip -- native sequencing of the eval-mode UNet forward and of the T-step sampler loop.
+//
+// Reference: models/unet/unet.py:10-72 (module tree), :74-104 (forward), models/unet/blocks.py:105-115
+// (ResnetBlock), :8-14,63-71,126-134 (Residual(PreNorm(LinearAttention))), models/diffusion/ddpm.py:203-249
+// (p_sample, p_sample_loop).
+//
+// The plan owns (a) the list of weight slots -- one per state_dict tensor, with the packed layout each
+// kernel wants -- and (b) the order of kernel launches for one forward.  Nothing here computes: every
+// arithmetic step is a HIP kernel from the other translation units.  The sampler captures one reverse step
+// (t bookkeeping + UNet + x update) into a hipGraph and replays it, so the T-step loop costs one
+// hipGraphLaunch per step on the host.
+#include <string>
+#include <vector>
+
+#include "ddk_internal.h"
+
+namespace ddk {
+
+constexpr int HEADS = 4;
+constexpr int HIDDEN = HEADS * 32;  // LinearAttention hidden width is 128 whatever unet_chan is (blocks.py:119-122)
+constexpr int GROUPS = 8;
+constexpr float GN_EPS = 1e-5f, LN_EPS = 1e-5f;
+
+static inline int pad32(int c) { return (c + 31) / 32 * 32; }
+
+enum PackKind { PK_COPY = 0, PK_CONV = 1, PK_CONVT = 2, PK_LINEAR_T = 3 };
+
+struct Slot {
+    std::string name;
+    long long numel;
+    int kind;
+    size_t off;  // float offset into the packed arena
+    int O, I, KH, KW, i_pad, ld, col0;
+};
+
+struct ConvW {
+    size_t w = 0, b = 0;
+    bool has_bias = false;
+    int cin = 0, cin_pad = 0, cout = 0;
+};
+struct NormW { size_t g = 0, b = 0; };
+struct ResW {
+    int ci = 0, ci_pad = 0, co = 0, temb_off = 0;
+    ConvW c1, c2, res;
+    NormW n1, n2;
+    bool has_res = false;
+};
+struct AttnW {
+    int c = 0;
+    NormW ln;
+    ConvW qkv, out;
+};
+
+}  // namespace ddk
+
+using namespace ddk;
+
+struct ddk_unet {
+    ddk_unet_config cfg;
+    std::vector<Slot> slots;
+    size_t packed_floats = 0;
+    int L = 0;
+    std::vector<int> dims;  // [in, chan*m0, ...]
+    int time_dim = 0, temb_total = 0;
+    size_t freqs = 0, w1t = 0, b1 = 0, w2t = 0, b2 = 0, temb_wt = 0, temb_bias = 0;
+    std::vector<ResW> down_res, up_res;  // 2 per level
+    std::vector<AttnW> down_attn, up_attn;
+    std::vector<ConvW> down_conv, up_conv;
+    ResW mid1, mid2;
+    AttnW mid_attn;
+    ConvW final_conv;
+    NormW final_norm;
+    size_t final_w = 0, final_b = 0;
+
+    size_t alloc(size_t n) {
+        const size_t o = packed_floats;
+        packed_floats += (n + 3) / 4 * 4;
+        return o;
+    }
+    size_t add_copy(const std::string& name, long long n) {
+        const size_t o = alloc((size_t)n);
+        slots.push_back(Slot{name, n, PK_COPY, o, 0, 0, 0, 0, 0, 0, 0});
+        return o;
+    }
+    void add_copy_at(const std::string& name, long long n, size_t off) {
+        slots.push_back(Slot{name, n, PK_COPY, off, 0, 0, 0, 0, 0, 0, 0});
+    }
+    ConvW add_conv(const std::string& prefix, int cout, int cin, int k, bool bias) {
+        ConvW c;
+        c.cin = cin; c.cin_pad = pad32(cin); c.cout = cout;
+        c.w = alloc((size_t)cout * k * k * c.cin_pad);
+        slots.push_back(Slot{prefix + "weight", (long long)cout * cin * k * k, PK_CONV, c.w, cout, cin, k, k, c.cin_pad, 0, 0});
+        c.has_bias = bias;
+        if (bias) c.b = add_copy(prefix + "bias", cout);
+        return c;
+    }
+    ConvW add_convT(const std::string& prefix, int ch) {
+        ConvW c;
+        c.cin = ch; c.cin_pad = ch; c.cout = ch;
+        c.w = alloc((size_t)16 * ch * ch);
+        slots.push_back(Slot{prefix + "weight", (long long)16 * ch * ch, PK_CONVT, c.w, ch, ch, 4, 4, ch, 0, 0});
+        c.has_bias = true;
+        c.b = add_copy(prefix + "bias", ch);
+        return c;
+    }
+    NormW add_norm(const std::string& wname, const std::string& bname, int c) {
+        NormW n;
+        n.g = add_copy(wname, c);
+        n.b = add_copy(bname, c);
+        return n;
+    }
+    ResW add_res(const std::string& p, int ci, int co, int& temb_cursor) {
+        ResW r;
+        r.ci = ci; r.ci_pad = pad32(ci); r.co = co;
+        r.temb_off = temb_cursor;
+        temb_cursor += co;
+        slots.push_back(Slot{p + "mlp.1.weight", (long long)co * time_dim, PK_LINEAR_T, temb_wt, co, time_dim, 0, 0, 0, temb_total, r.temb_off});
+        add_copy_at(p + "mlp.1.bias", co, temb_bias + r.temb_off);
+        r.c1 = add_conv(p + "block1.block.0.", co, ci, 3, true);
+        r.n1 = add_norm(p + "block1.block.1.weight", p + "block1.block.1.bias", co);
+        r.c2 = add_conv(p + "block2.block.0.", co, co, 3, true);
+        r.n2 = add_norm(p + "block2.block.1.weight", p + "block2.block.1.bias", co);
+        r.has_res = ci != co;
+        if (r.has_res) r.res = add_conv(p + "res_conv.", co, ci, 1, true);
+        return r;
+    }
+    AttnW add_attn(const std::string& p, int c) {
+        AttnW a;
+        a.c = c;
+        a.qkv = add_conv(p + "fn.fn.to_qkv.", 3 * HIDDEN, c, 1, false);
+        a.out = add_conv(p + "fn.fn.to_out.", c, HIDDEN, 1, true);
+        a.ln = add_norm(p + "fn.norm.g", p + "fn.norm.b", c);
+        return a;
+    }
+};
+
+static int total_temb(const ddk_unet& u) {
+    // 2 ResnetBlocks per down level, 2 mid, 2 per up level; C_out per unet.py:43-66
+    int tot = 0;
+    for (int l = 0; l < u.L; ++l) tot += 2 * u.dims[l + 1];
+    tot += 2 * u.dims[u.L];
+    for (int i = 0; i < u.L - 1; ++i) tot += 2 * u.dims[u.L - 1 - i];
+    return tot;
+}
+
+extern "C" ddk_unet* ddk_unet_create(const ddk_unet_config* cfg) {
+    if (!cfg || cfg->n_levels < 1 || cfg->n_levels > 8 || cfg->in_ch < 1 || cfg->chan < 32 || cfg->chan % 32) {
+        set_error("unet_create: need 1 <= n_levels <= 8, in_ch >= 1, unet_chan a positive multiple of 32");
+        return nullptr;
+    }
+    for (int i = 0; i < cfg->n_levels; ++i)
+        if (cfg->mults[i] < 1) { set_error("unet_create: unet_dims entries must be >= 1"); return nullptr; }
+    if (cfg->mults[0] != 1) {
+        // final_conv is Block(dim, dim) on the last up level's dims[1] channels (unet.py:69-72): only consistent for mult 1
+        set_error("unet_create: unet_dims[0] must be 1 (final Block(dim, dim), unet.py:69)");
+        return nullptr;
+    }
+    ddk_unet* u = new ddk_unet();
+    u->cfg = *cfg;
+    u->L = cfg->n_levels;
+    u->dims.push_back(cfg->in_ch);
+    for (int i = 0; i < u->L; ++i) u->dims.push_back(cfg->chan * cfg->mults[i]);
+    u->time_dim = cfg->chan;
+    u->temb_total = total_temb(*u);
+    const int td = u->time_dim;
+
+    u->freqs = u->add_copy("@sinusoidal_freqs", td / 2);
+    u->w1t = u->alloc((size_t)td * 4 * td);
+    u->slots.push_back(Slot{"time_mlp.1.weight", (long long)4 * td * td, PK_LINEAR_T, u->w1t, 4 * td, td, 0, 0, 0, 4 * td, 0});
+    u->b1 = u->add_copy("time_mlp.1.bias", 4 * td);
+    u->w2t = u->alloc((size_t)4 * td * td);
+    u->slots.push_back(Slot{"time_mlp.3.weight", (long long)4 * td * td, PK_LINEAR_T, u->w2t, td, 4 * td, 0, 0, 0, td, 0});
+    u->b2 = u->add_copy("time_mlp.3.bias", td);
+    u->temb_wt = u->alloc((size_t)td * u->temb_total);
+    u->temb_bias = u->alloc((size_t)u->temb_total);
+
+    int cur = 0;
+    for (int l = 0; l < u->L; ++l) {
+        const std::string p = "downs." + std::to_string(l) + ".";
+        const int ci = u->dims[l], co = u->dims[l + 1];
+        u->down_res.push_back(u->add_res(p + "0.", ci, co, cur));
+        u->down_res.push_back(u->add_res(p + "1.", co, co, cur));
+        u->down_attn.push_back(u->add_attn(p + "2.", co));
+        if (l < u->L - 1) u->down_conv.push_back(u->add_conv(p + "3.conv.", co, co, 3, true));
+    }
+    const int mid = u->dims[u->L];
+    u->mid1 = u->add_res("mid_block1.", mid, mid, cur);
+    u->mid_attn = u->add_attn("mid_attn.", mid);
+    u->mid2 = u->add_res("mid_block2.", mid, mid, cur);
+    for (int i = 0; i < u->L - 1; ++i) {
+        const std::string p = "ups." + std::to_string(i) + ".";
+        const int din = u->dims[u->L - 1 - i], dout = u->dims[u->L - i];  // reversed(in_out[1:])[i]
+        u->up_res.push_back(u->add_res(p + "0.", 2 * dout, din, cur));
+        u->up_res.push_back(u->add_res(p + "1.", din, din, cur));
+        u->up_attn.push_back(u->add_attn(p + "2.", din));
+        u->up_conv.push_back(u->add_convT(p + "3.conv.", din));
+    }
+    u->final_conv = u->add_conv("final_conv.0.block.0.", cfg->chan, cfg->chan, 3, true);
+    u->final_norm = u->add_norm("final_conv.0.block.1.weight", "final_conv.0.block.1.bias", cfg->chan);
+    u->final_w = u->add_copy("final_conv.1.weight", (long long)cfg->in_ch * cfg->chan);
+    u->final_b = u->add_copy("final_conv.1.bias", cfg->in_ch);
+    if (cur != u->temb_total) {
+        set_error("unet_create: internal temb accounting mismatch");
+        delete u;
+        return nullptr;
+    }
+    return u;
+}
+
+extern "C" void ddk_unet_destroy(ddk_unet* u) { delete u; }
+extern "C" int ddk_unet_num_slots(const ddk_unet* u) { return u ? (int)u->slots.size() : 0; }
+extern "C" const char* ddk_unet_slot_name(const ddk_unet* u, int slot) {
+    return (u && slot >= 0 && slot < (int)u->slots.size()) ? u->slots[slot].name.c_str() : nullptr;
+}
+extern "C" long long ddk_unet_slot_numel(const ddk_unet* u, int slot) {
+    return (u && slot >= 0 && slot < (int)u->slots.size()) ? u->slots[slot].numel : -1;
+}
+extern "C" size_t ddk_unet_packed_bytes(const ddk_unet* u) { return u ? u->packed_floats * sizeof(float) : 0; }
+
+extern "C" int ddk_unet_pack_slot(const ddk_unet* u, int slot, const float* canonical, void* packed, ddk_stream_t s) {
+    DDK_REQUIRE(u && canonical && packed && slot >= 0 && slot < (int)u->slots.size(), "unet_pack_slot: arguments");
+    const Slot& sl = u->slots[slot];
+    float* dst = static_cast<float*>(packed) + sl.off;
+    switch (sl.kind) {
+        case PK_COPY:
+            DDK_HIP(hipMemcpyAsync(dst, canonical, (size_t)sl.numel * sizeof(float), hipMemcpyDeviceToDevice, as_stream(s)));
+            return DDK_OK;
+        case PK_CONV: return ddk_pack_conv_weight(canonical, dst, sl.O, sl.I, sl.KH, sl.KW, sl.i_pad, s);
+        case PK_CONVT: return ddk_pack_convT_weight(canonical, dst, sl.I, sl.O, s);
+        case PK_LINEAR_T: return ddk_pack_linear_T(canonical, dst, sl.O, sl.I, sl.ld, sl.col0, s);
+        default: return fail_arg("unet_pack_slot: slot kind");
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+namespace ddk {
+
+// Workspace carve-up (all offsets in floats, 16-byte aligned).
+struct Layout {
+    size_t act = 0;      // one general activation buffer (max over layers of M*C)
+    size_t qkv = 0, o = 0, ctx = 0, splitk = 0, gn_ws = 0;
+    std::vector<size_t> skip;  // per level
+    size_t xpad = 0, temb = 0, tact = 0;
+    // offsets
+    size_t off_A = 0, off_B = 0, off_C = 0, off_raw = 0, off_a1 = 0, off_res = 0, off_xn = 0, off_qkv = 0, off_o = 0, off_ctx = 0,
+           off_splitk = 0, off_gn = 0, off_xpad = 0, off_temb = 0, off_tact = 0;
+    std::vector<size_t> off_skip;
+    size_t total = 0;
+};
+
+static size_t al4(size_t n) { return (n + 3) / 4 * 4; }
+
+static void upd(size_t& m, size_t v) { if (v > m) m = v; }
+
+static void res_sizes(const ResW& r, int B, int H, int W, Layout& ly) {
+    const size_t M = (size_t)B * H * W;
+    upd(ly.act, M * r.co);
+    upd(ly.splitk, conv_workspace_bytes(DDK_CONV3X3_S1, B, H, W, r.ci_pad, r.co) / 4);
+    upd(ly.splitk, conv_workspace_bytes(DDK_CONV3X3_S1, B, H, W, r.co, r.co) / 4);
+    if (r.has_res) upd(ly.splitk, conv_workspace_bytes(DDK_CONV1X1, B, H, W, r.ci_pad, r.co) / 4);
+    upd(ly.gn_ws, groupnorm_workspace_bytes(B, H * W, r.co, GROUPS) / 4);
+}
+
+static void attn_sizes(const AttnW& a, int B, int H, int W, Layout& ly) {
+    const size_t M = (size_t)B * H * W;
+    upd(ly.act, M * a.c);
+    upd(ly.qkv, M * 3 * HIDDEN);
+    upd(ly.o, M * HIDDEN);
+    upd(ly.ctx, (size_t)B * HEADS * 32 * 32);
+    upd(ly.splitk, conv_workspace_bytes(DDK_CONV1X1, B, H, W, a.c, 3 * HIDDEN) / 4);
+    upd(ly.splitk, conv_workspace_bytes(DDK_CONV1X1, B, H, W, HIDDEN, a.c) / 4);
+}
+
+static Layout make_layout(const ddk_unet& u, int B, int H0, int W0) {
+    Layout ly;
+    int H = H0, W = W0;
+    ly.skip.resize(u.L);
+    for (int l = 0; l < u.L; ++l) {
+        res_sizes(u.down_res[2 * l], B, H, W, ly);
+        res_sizes(u.down_res[2 * l + 1], B, H, W, ly);
+        attn_sizes(u.down_attn[l], B, H, W, ly);
+        ly.skip[l] = al4((size_t)B * H * W * u.dims[l + 1]);
+        if (l < u.L - 1) {
+            upd(ly.splitk, conv_workspace_bytes(DDK_CONV3X3_S2, B, H, W, u.dims[l + 1], u.dims[l + 1]) / 4);
+            H /= 2; W /= 2;
+            upd(ly.act, (size_t)B * H * W * u.dims[l + 1]);
+        }
+    }
+    res_sizes(u.mid1, B, H, W, ly);
+    attn_sizes(u.mid_attn, B, H, W, ly);
+    res_sizes(u.mid2, B, H, W, ly);
+    for (int i = 0; i < u.L - 1; ++i) {
+        res_sizes(u.up_res[2 * i], B, H, W, ly);
+        res_sizes(u.up_res[2 * i + 1], B, H, W, ly);
+        attn_sizes(u.up_attn[i], B, H, W, ly);
+        const int c = u.up_conv[i].cout;
+        upd(ly.splitk, conv_workspace_bytes(DDK_CONVT4X4_S2, B, H, W, c, c) / 4);
+        H *= 2; W *= 2;
+        upd(ly.act, (size_t)B * H * W * c);
+    }
+    upd(ly.act, (size_t)B * H * W * u.cfg.chan);
+    upd(ly.splitk, conv_workspace_bytes(DDK_CONV3X3_S1, B, H, W, u.cfg.chan, u.cfg.chan) / 4);
+    upd(ly.gn_ws, groupnorm_workspace_bytes(B, H * W, u.cfg.chan, GROUPS) / 4);
+    ly.xpad = al4((size_t)B * H0 * W0 * pad32(u.cfg.in_ch));
+    ly.temb = al4((size_t)B * u.temb_total);
+    ly.tact = al4((size_t)B * u.time_dim);
+    ly.act = al4(ly.act); ly.qkv = al4(ly.qkv); ly.o = al4(ly.o); ly.ctx = al4(ly.ctx);
+    ly.splitk = al4(ly.splitk); ly.gn_ws = al4(ly.gn_ws);
+
+    size_t off = 0;
+    auto take = [&](size_t n) { const size_t o = off; off += n; return o; };
+    ly.off_A = take(ly.act); ly.off_B = take(ly.act); ly.off_C = take(ly.act);
+    ly.off_raw = take(ly.act); ly.off_a1 = take(ly.act); ly.off_res = take(ly.act); ly.off_xn = take(ly.act);
+    ly.off_qkv = take(ly.qkv); ly.off_o = take(ly.o); ly.off_ctx = take(ly.ctx);
+    ly.off_splitk = take(ly.splitk); ly.off_gn = take(ly.gn_ws);
+    ly.off_xpad = take(ly.xpad); ly.off_temb = take(ly.temb); ly.off_tact = take(ly.tact);
+    ly.off_skip.resize(u.L);
+    for (int l = 0; l < u.L; ++l) ly.off_skip[l] = take(ly.skip[l]);
+    ly.total = off;
+    return ly;
+}
+
+struct Ctx {
+    const ddk_unet& u;
+    const float* P;  // packed weights
+    float* W;        // workspace base
+    const Layout& ly;
+    int B;
+    hipStream_t st;
+    const float* temb;  // [B][temb_total]
+};
+
+static int run_conv(Ctx& c, int kind, const ConvW& cw, const float* src0, int c0, const float* src1, int c1, const float* resid,
+                    float* out, int H, int W, int N) {
+    ddk_conv_args a{};
+    a.kind = kind;
+    a.src0 = src0; a.src1 = src1; a.c0 = c0; a.c1 = c1;
+    a.weight = c.P + cw.w;
+    a.bias = cw.has_bias ? c.P + cw.b : nullptr;
+    a.resid = resid;
+    a.out = out;
+    a.B = c.B; a.H = H; a.W = W; a.N = N;
+    a.pre_mish = 0;
+    a.post_mish = 0;
+    a.workspace = c.W + c.ly.off_splitk;
+    a.workspace_bytes = c.ly.splitk * sizeof(float);
+    return conv_forward(a, c.st);
+}
+
+static int run_gn(Ctx& c, const float* x, const NormW& n, const float* temb, const float* addend, float* out, int HW, int C) {
+    return groupnorm_mish(x, c.P + n.g, c.P + n.b, temb, c.u.temb_total, addend, out, c.B, HW, C, GROUPS, GN_EPS,
+                          c.W + c.ly.off_gn, c.ly.gn_ws * sizeof(float), c.st);
+}
+
+// blocks.py:105-115 (eval): out = Mish(GN(conv2(Mish(GN(conv1(x))) + temb))) + res(x)
+static int run_res(Ctx& c, const ResW& r, const float* src0, int c0, const float* src1, int c1, float* out, int H, int W) {
+    float* raw = c.W + c.ly.off_raw;
+    float* a1 = c.W + c.ly.off_a1;
+    float* res = c.W + c.ly.off_res;
+    const int HW = H * W;
+    DDK_TRY(run_conv(c, DDK_CONV3X3_S1, r.c1, src0, c0, src1, c1, nullptr, raw, H, W, r.co));
+    DDK_TRY(run_gn(c, raw, r.n1, c.temb + r.temb_off, nullptr, a1, HW, r.co));
+    DDK_TRY(run_conv(c, DDK_CONV3X3_S1, r.c2, a1, r.co, nullptr, 0, nullptr, raw, H, W, r.co));
+    const float* addend = src0;
+    if (r.has_res) {
+        DDK_TRY(run_conv(c, DDK_CONV1X1, r.res, src0, c0, src1, c1, nullptr, res, H, W, r.co));
+        addend = res;
+    }
+    return run_gn(c, raw, r.n2, nullptr, addend, out, HW, r.co);
+}
+
+// blocks.py:8-14,63-71,126-134: out = to_out(attn(to_qkv(LN(x)))) + x
+static int run_attn(Ctx& c, const AttnW& a, const float* x, float* out, int H, int W) {
+    float* xn = c.W + c.ly.off_xn;
+    float* qkv = c.W + c.ly.off_qkv;
+    float* ctx = c.W + c.ly.off_ctx;
+    float* o = c.W + c.ly.off_o;
+    const long long M = (long long)c.B * H * W;
+    DDK_TRY(chan_layernorm(x, c.P + a.ln.g, c.P + a.ln.b, xn, M, a.c, LN_EPS, c.st));
+    DDK_TRY(run_conv(c, DDK_CONV1X1, a.qkv, xn, a.c, nullptr, 0, nullptr, qkv, H, W, 3 * HIDDEN));
+    DDK_TRY(linattn_context(qkv, ctx, c.B, H * W, HEADS, c.st));
+    DDK_TRY(linattn_apply(qkv, ctx, o, c.B, H * W, HEADS, c.st));
+    return run_conv(c, DDK_CONV1X1, a.out, o, HIDDEN, nullptr, 0, x, out, H, W, a.c);
+}
+
+// xpad: NHWC input already zero-padded to pad32(in_ch) channels.
+static int forward_core(const ddk_unet& u, const float* P, const float* xpad, const int64_t* t, float* out, int B, int H0, int W0,
+                        float* ws, const Layout& ly, hipStream_t st) {
+    float* tact = ws + ly.off_tact;
+    float* temb = ws + ly.off_temb;
+    DDK_TRY(time_mlp(t, P + u.freqs, P + u.w1t, P + u.b1, P + u.w2t, P + u.b2, tact, nullptr, B, u.time_dim, st));
+    DDK_TRY(time_proj(tact, P + u.temb_wt, P + u.temb_bias, temb, B, u.time_dim, u.temb_total, st));
+    Ctx c{u, P, ws, ly, B, st, temb};
+    float* bufA = ws + ly.off_A;
+    float* bufB = ws + ly.off_B;
+    float* bufC = ws + ly.off_C;
+
+    int H = H0, W = W0;
+    const float* cur = xpad;
+    int cur_c = pad32(u.cfg.in_ch);
+    for (int l = 0; l < u.L; ++l) {
+        float* skip = ws + ly.off_skip[l];
+        const int co = u.dims[l + 1];
+        DDK_TRY(run_res(c, u.down_res[2 * l], cur, cur_c, nullptr, 0, bufB, H, W));
+        DDK_TRY(run_res(c, u.down_res[2 * l + 1], bufB, co, nullptr, 0, bufC, H, W));
+        DDK_TRY(run_attn(c, u.down_attn[l], bufC, skip, H, W));
+        if (l < u.L - 1) {
+            DDK_TRY(run_conv(c, DDK_CONV3X3_S2, u.down_conv[l], skip, co, nullptr, 0, nullptr, bufA, H, W, co));
+            H /= 2; W /= 2;
+            cur = bufA;
+        } else {
+            cur = skip;
+        }
+        cur_c = co;
+    }
+    DDK_TRY(run_res(c, u.mid1, cur, cur_c, nullptr, 0, bufB, H, W));
+    DDK_TRY(run_attn(c, u.mid_attn, bufB, bufC, H, W));
+    DDK_TRY(run_res(c, u.mid2, bufC, cur_c, nullptr, 0, bufA, H, W));
+    cur = bufA;
+    for (int i = 0; i < u.L - 1; ++i) {
+        const int lvl = u.L - 1 - i;  // skips.pop(): the most recent skip first (unet.py:97)
+        const float* skip = ws + ly.off_skip[lvl];
+        const int dout = u.dims[lvl + 1], din = u.dims[lvl];
+        DDK_TRY(run_res(c, u.up_res[2 * i], cur, cur_c, skip, dout, bufB, H, W));
+        DDK_TRY(run_res(c, u.up_res[2 * i + 1], bufB, din, nullptr, 0, bufC, H, W));
+        DDK_TRY(run_attn(c, u.up_attn[i], bufC, bufB, H, W));
+        DDK_TRY(run_conv(c, DDK_CONVT4X4_S2, u.up_conv[i], bufB, din, nullptr, 0, nullptr, bufA, H, W, din));
+        H *= 2; W *= 2;
+        cur = bufA;
+        cur_c = din;
+    }
+    // final_conv: Block(dim, dim) then 1x1 to in_ch (unet.py:69-72)
+    float* raw = ws + ly.off_raw;
+    float* a1 = ws + ly.off_a1;
+    DDK_TRY(run_conv(c, DDK_CONV3X3_S1, u.final_conv, cur, cur_c, nullptr, 0, nullptr, raw, H, W, u.cfg.chan));
+    DDK_TRY(run_gn(c, raw, u.final_norm, nullptr, nullptr, a1, H * W, u.cfg.chan));
+    return conv1x1_small_n(a1, P + u.final_w, P + u.final_b, out, (long long)B * H * W, u.cfg.chan, u.cfg.in_ch, st);
+}
+
+static int check_shape(const ddk_unet* u, int B, int H, int W) {
+    DDK_REQUIRE(u, "unet: null plan");
+    DDK_REQUIRE(B > 0 && H > 0 && W > 0, "unet: B/H/W must be positive");
+    const int f = 1 << (u->L - 1);
+    if (H % f || W % f) {
+        set_error("unet: spatial size %dx%d must be divisible by %d (%d stride-2 stages, unet.py:43-50)", H, W, f, u->L - 1);
+        return DDK_ERR_ARG;
+    }
+    return DDK_OK;
+}
+
+// sampler bookkeeping kernels ----------------------------------------------------------------------
+__global__ void set_counter_kernel(int64_t* counter, int64_t v) { *counter = v; }
+
+// t_cur[b] = counter for every sample, then counter -= 1; also zero-pads x into xpad.  First kernel of a
+// step: the previous step's kernels have all completed (stream order), nobody else reads the counter.
+__global__ __launch_bounds__(256) void step_prepare_kernel(const float* __restrict__ x, float* __restrict__ xpad, long long total,
+                                                           int C, int c_pad, int64_t* __restrict__ counter,
+                                                           int64_t* __restrict__ t_cur, int B) {
+    if (blockIdx.x == 0) {
+        const int64_t v = *counter;
+        for (int b = threadIdx.x; b < B; b += blockDim.x) t_cur[b] = v;
+        __syncthreads();
+        if (threadIdx.x == 0) *counter = v - 1;
+    }
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int ch = (int)(i % c_pad);
+        const long long m = i / c_pad;
+        xpad[i] = ch < C ? x[m * C + ch] : 0.f;
+    }
+}
+
+}  // namespace ddk
+
+extern "C" size_t ddk_unet_workspace_bytes(const ddk_unet* u, int B, int H, int W) {
+    if (check_shape(u, B, H, W) != DDK_OK) return 0;
+    return make_layout(*u, B, H, W).total * sizeof(float);
+}
+
+extern "C" int ddk_unet_forward(const ddk_unet* u, const void* packed, const float* x, const int64_t* t, float* out, int B, int H,
+                                int W, void* workspace, size_t workspace_bytes, ddk_stream_t s) {
+    DDK_TRY(check_shape(u, B, H, W));
+    DDK_REQUIRE(packed && x && t && out && workspace, "unet_forward: null pointer");
+    DDK_REQUIRE(aligned16(packed) && aligned16(workspace) && aligned16(x) && aligned16(out), "unet_forward: alignment");
+    const Layout ly = make_layout(*u, B, H, W);
+    if (workspace_bytes < ly.total * sizeof(float)) {
+        set_error("unet_forward: workspace too small (%zu < %zu)", workspace_bytes, ly.total * sizeof(float));
+        return DDK_ERR_WORKSPACE;
+    }
+    float* ws = static_cast<float*>(workspace);
+    float* xpad = ws + ly.off_xpad;
+    DDK_TRY(ddk_pad_channels(x, xpad, (long long)B * H * W, u->cfg.in_ch, pad32(u->cfg.in_ch), s));
+    return forward_core(*u, static_cast<const float*>(packed), xpad, t, out, B, H, W, ws, ly, as_stream(s));
+}
+
+extern "C" double ddk_unet_flops(const ddk_unet* u, int B, int H0, int W0) {
+    if (check_shape(u, B, H0, W0) != DDK_OK) return 0;
+    double f = 0;
+    auto res = [&](const ResW& r, int H, int W) {
+        f += conv_flops(DDK_CONV3X3_S1, B, H, W, r.ci, r.co) + conv_flops(DDK_CONV3X3_S1, B, H, W, r.co, r.co);
+        if (r.has_res) f += conv_flops(DDK_CONV1X1, B, H, W, r.ci, r.co);
+        f += 2.0 * B * u->time_dim * r.co;  // mlp Linear
+    };
+    auto attn = [&](const AttnW& a, int H, int W) {
+        f += conv_flops(DDK_CONV1X1, B, H, W, a.c, 3 * HIDDEN) + conv_flops(DDK_CONV1X1, B, H, W, HIDDEN, a.c);
+        f += 2.0 * 2.0 * B * HEADS * 32.0 * 32.0 * H * W;  // the two einsums
+    };
+    int H = H0, W = W0;
+    f += 2.0 * B * (u->time_dim * 4.0 * u->time_dim) * 2;  // time_mlp Linears
+    for (int l = 0; l < u->L; ++l) {
+        res(u->down_res[2 * l], H, W); res(u->down_res[2 * l + 1], H, W); attn(u->down_attn[l], H, W);
+        if (l < u->L - 1) { f += conv_flops(DDK_CONV3X3_S2, B, H, W, u->dims[l + 1], u->dims[l + 1]); H /= 2; W /= 2; }
+    }
+    res(u->mid1, H, W); attn(u->mid_attn, H, W); res(u->mid2, H, W);
+    for (int i = 0; i < u->L - 1; ++i) {
+        res(u->up_res[2 * i], H, W); res(u->up_res[2 * i + 1], H, W); attn(u->up_attn[i], H, W);
+        f += conv_flops(DDK_CONVT4X4_S2, B, H, W, u->up_conv[i].cin, u->up_conv[i].cout);
+        H *= 2; W *= 2;
+    }
+    f += conv_flops(DDK_CONV3X3_S1, B, H, W, u->cfg.chan, u->cfg.chan) + conv_flops(DDK_CONV1X1, B, H, W, u->cfg.chan, u->cfg.in_ch);
+    return f;
+}
+
+// ------------------------------------------------------------------------------------------------ sampler
+namespace ddk {
+struct SamplerLayout {
+    size_t unet_floats, off_eps, off_t, total;
+};
+static SamplerLayout sampler_layout(const ddk_unet& u, int B, int H, int W) {
+    SamplerLayout s;
+    s.unet_floats = make_layout(u, B, H, W).total;
+    s.off_eps = s.unet_floats;
+    s.off_t = s.off_eps + al4((size_t)B * H * W * u.cfg.in_ch);
+    s.total = s.off_t + al4(2 * (size_t)(B + 1));  // int64 t_cur[B] + counter, in float units
+    return s;
+}
+}  // namespace ddk
+
+extern "C" size_t ddk_sampler_workspace_bytes(const ddk_unet* u, int B, int H, int W) {
+    if (check_shape(u, B, H, W) != DDK_OK) return 0;
+    return sampler_layout(*u, B, H, W).total * sizeof(float);
+}
+
+extern "C" int ddk_sampler_run(const ddk_sampler_args* a, ddk_stream_t s) {
+    DDK_REQUIRE(a && a->unet && a->packed && a->x && a->workspace, "sampler: null pointer");
+    DDK_REQUIRE(a->c_recip && a->c_recipm1 && a->c1 && a->c2 && a->sigma, "sampler: null schedule table");
+    const ddk_unet& u = *a->unet;
+    DDK_TRY(check_shape(&u, a->B, a->H, a->W));
+    DDK_REQUIRE(a->t_start >= a->t_end && a->t_end >= 0, "sampler: need t_start >= t_end >= 0");
+    DDK_REQUIRE(aligned16(a->packed) && aligned16(a->workspace) && aligned16(a->x) && aligned16(a->noise), "sampler: alignment");
+    const int B = a->B, H = a->H, W = a->W, C = u.cfg.in_ch, cp = pad32(C);
+    const long long per = (long long)H * W * C;
+    DDK_REQUIRE(per % 4 == 0, "sampler: H*W*in_ch must be a multiple of 4");
+    const SamplerLayout sl = sampler_layout(u, B, H, W);
+    if (a->workspace_bytes < sl.total * sizeof(float)) {
+        set_error("sampler: workspace too small (%zu < %zu)", a->workspace_bytes, sl.total * sizeof(float));
+        return DDK_ERR_WORKSPACE;
+    }
+    const Layout ly = make_layout(u, B, H, W);
+    hipStream_t st = as_stream(s);
+    float* ws = static_cast<float*>(a->workspace);
+    float* eps_hat = ws + sl.off_eps;
+    int64_t* t_cur = reinterpret_cast<int64_t*>(ws + sl.off_t);
+    int64_t* counter = t_cur + B;
+    float* xpad = ws + ly.off_xpad;
+    const float* P = static_cast<const float*>(a->packed);
+    const long long padded = (long long)B * H * W * cp;
+    const int prep_blocks = (int)(ceil_div(padded, 256) < 1024 ? ceil_div(padded, 256) : 1024);
+
+    auto one_step = [&]() -> int {
+        hipLaunchKernelGGL(step_prepare_kernel, dim3(prep_blocks), dim3(256), 0, st, a->x, xpad, padded, C, cp, counter, t_cur, B);
+        DDK_TRY(check_launch("step_prepare_kernel"));
+        DDK_TRY(forward_core(u, P, xpad, t_cur, eps_hat, B, H, W, ws, ly, st));
+        return p_sample_update(a->x, eps_hat, a->noise, a->noise ? B * per : 0, a->t_start, t_cur, a->c_recip, a->c_recipm1, a->c1,
+                               a->c2, a->sigma, B, per, a->seed, a->stream_id, st);
+    };
+
+    hipLaunchKernelGGL(set_counter_kernel, dim3(1), dim3(1), 0, st, counter, (int64_t)a->t_start);
+    DDK_TRY(check_launch("set_counter_kernel"));
+    const int n_steps = a->t_start - a->t_end + 1;
+    // first step eagerly: it also performs the one-time per-kernel attribute setup that must not run under capture
+    DDK_TRY(one_step());
+    if (n_steps == 1) return DDK_OK;
+    if (!a->use_graph) {
+        for (int k = 1; k < n_steps; ++k) DDK_TRY(one_step());
+        return DDK_OK;
+    }
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+    if (e != hipSuccess) {
+        set_error("sampler: hipStreamBeginCapture failed (%s); the legacy NULL stream cannot be captured -- pass a created stream",
+                  hipGetErrorString(e));
+        return DDK_ERR_HIP;
+    }
+    int rc = one_step();
+    e = hipStreamEndCapture(st, &graph);
+    if (rc != DDK_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+    if (e != hipSuccess) { set_error("sampler: hipStreamEndCapture: %s", hipGetErrorString(e)); return DDK_ERR_HIP; }
+    e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    if (e != hipSuccess) {
+        (void)hipGraphDestroy(graph);
+        set_error("sampler: hipGraphInstantiate: %s", hipGetErrorString(e));
+        return DDK_ERR_HIP;
+    }
+    rc = DDK_OK;
+    for (int k = 1; k < n_steps; ++k) {
+        e = hipGraphLaunch(exec, st);
+        if (e != hipSuccess) { set_error("sampler: hipGraphLaunch: %s", hipGetErrorString(e)); rc = DDK_ERR_HIP; break; }
+    }
+    // The exec object must outlive its in-flight launches: wait for this stream's work only.
+    if (rc == DDK_OK) {
+        e = hipStreamSynchronize(st);
+        if (e != hipSuccess) { set_error("sampler: hipStreamSynchronize: %s", hipGetErrorString(e)); rc = DDK_ERR_HIP; }
+    }
+    (void)hipGraphExecDestroy(exec);
+    (void)hipGraphDestroy(graph);
+    return rc;
+}

@@ -1,0 +1,132 @@
+"""ctypes binding of libddk.so (include/ddk.h) -- the only route from Python to the HIP kernels.
+
+There is NO fallback: if the library is missing, or a kernel is asked to run on anything but a
+ROCm device tensor, this module raises.  (plain ``extern "C"`` functions, device
+pointers + sizes, the caller's stream.)
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get("DDK_LIB", os.path.join(os.path.dirname(_HERE), "csrc", "libddk.so"))
+
+
+class DDKError(RuntimeError):
+    pass
+
+
+class ConvArgs(C.Structure):
+    _fields_ = [
+        ("kind", C.c_int), ("src0", C.c_void_p), ("src1", C.c_void_p), ("c0", C.c_int), ("c1", C.c_int),
+        ("weight", C.c_void_p), ("bias", C.c_void_p), ("resid", C.c_void_p), ("out", C.c_void_p),
+        ("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("N", C.c_int), ("pre_mish", C.c_int), ("post_mish", C.c_int),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+    ]
+
+
+class UnetConfig(C.Structure):
+    _fields_ = [("in_ch", C.c_int), ("chan", C.c_int), ("n_levels", C.c_int), ("mults", C.c_int * 8)]
+
+
+class SamplerArgs(C.Structure):
+    _fields_ = [
+        ("unet", C.c_void_p), ("packed", C.c_void_p), ("x", C.c_void_p), ("noise", C.c_void_p),
+        ("c_recip", C.c_void_p), ("c_recipm1", C.c_void_p), ("c1", C.c_void_p), ("c2", C.c_void_p),
+        ("sigma", C.c_void_p), ("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("t_start", C.c_int),
+        ("t_end", C.c_int), ("seed", C.c_uint64), ("stream_id", C.c_uint32), ("use_graph", C.c_int),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+    ]
+
+
+_P, _I, _LL, _F, _SZ = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_size_t
+
+# name -> (restype, argtypes); every symbol include/ddk.h declares
+SIGNATURES = {
+    "ddk_version": (_I, []),
+    "ddk_last_error": (C.c_char_p, []),
+    "ddk_device_ok": (_I, []),
+    "ddk_nchw_to_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "ddk_nhwc_to_nchw": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "ddk_pad_channels": (_I, [_P, _P, _LL, _I, _I, _P]),
+    "ddk_pack_conv_weight": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "ddk_pack_convT_weight": (_I, [_P, _P, _I, _I, _P]),
+    "ddk_pack_linear_T": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "ddk_conv_workspace_bytes": (_SZ, [_I, _I, _I, _I, _I, _I]),
+    "ddk_conv_forward": (_I, [C.POINTER(ConvArgs), _P]),
+    "ddk_groupnorm_mish": (_I, [_P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _F, _P, _SZ, _P]),
+    "ddk_groupnorm_workspace_bytes": (_SZ, [_I, _I, _I, _I]),
+    "ddk_chan_layernorm": (_I, [_P, _P, _P, _P, _LL, _I, _F, _P]),
+    "ddk_mish": (_I, [_P, _P, _LL, _P]),
+    "ddk_tanh": (_I, [_P, _P, _LL, _P]),
+    "ddk_avgpool2": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "ddk_upsample_nearest2": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "ddk_add": (_I, [_P, _P, _P, _LL, _P]),
+    "ddk_linattn_context": (_I, [_P, _P, _I, _I, _I, _P]),
+    "ddk_linattn_apply": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "ddk_time_mlp": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
+    "ddk_time_proj": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
+    "ddk_conv1x1_small_n": (_I, [_P, _P, _P, _P, _LL, _I, _I, _P]),
+    "ddk_q_sample": (_I, [_P, _P, _P, _P, _P, _P, _I, _LL, _P]),
+    "ddk_p_sample_update": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _LL, C.c_uint64, C.c_uint32, _P]),
+    "ddk_randn": (_I, [_P, _LL, C.c_uint64, C.c_uint32, C.c_uint32, _P]),
+    "ddk_sq_err_sum": (_I, [_P, _P, _P, _I, _LL, _P]),
+    "ddk_unet_create": (_P, [C.POINTER(UnetConfig)]),
+    "ddk_unet_destroy": (None, [_P]),
+    "ddk_unet_num_slots": (_I, [_P]),
+    "ddk_unet_slot_name": (C.c_char_p, [_P, _I]),
+    "ddk_unet_slot_numel": (_LL, [_P, _I]),
+    "ddk_unet_packed_bytes": (_SZ, [_P]),
+    "ddk_unet_pack_slot": (_I, [_P, _I, _P, _P, _P]),
+    "ddk_unet_workspace_bytes": (_SZ, [_P, _I, _I, _I]),
+    "ddk_unet_forward": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P, _SZ, _P]),
+    "ddk_unet_flops": (C.c_double, [_P, _I, _I, _I]),
+    "ddk_sampler_workspace_bytes": (_SZ, [_P, _I, _I, _I]),
+    "ddk_sampler_run": (_I, [C.POINTER(SamplerArgs), _P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libddk.so once; raises DDKError with a build hint when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DDKError(
+            f"HIP kernel library not found at {LIB_PATH}. Build it with `make -C {os.path.dirname(LIB_PATH)}` "
+            "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so is stale
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def last_error():
+    return load().ddk_last_error().decode()
+
+
+def check(rc, what=""):
+    if rc != 0:
+        raise DDKError(f"{what or 'ddk call'} failed ({rc}): {last_error()}")
+
+
+def ptr(t):
+    """Device pointer of a contiguous fp32/int64 ROCm tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise DDKError("HIP kernels need a ROCm device tensor (got a CPU tensor); there is no CPU fallback")
+    if not t.is_contiguous():
+        raise DDKError("HIP kernels need contiguous tensors")
+    return t.data_ptr()
+
+
+def stream():
+    """The caller's current HIP stream as an opaque pointer."""
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,217 @@
+"""NHWC functional wrappers over the C ABI: one Python function per HIP kernel family.
+
+Tensors are fp32, contiguous, on a ROCm device; activations are [B, H, W, C].  torch is used
+only to allocate outputs / workspaces and to supply the current stream.
+"""
+import ctypes as C
+
+import torch
+
+from . import lib as L
+
+CONV3X3_S1, CONV3X3_S2, CONV1X1, CONVT4X4_S2 = 0, 1, 2, 3
+GN_GROUPS, GN_EPS, LN_EPS = 8, 1e-5, 1e-5
+
+
+def pad32(c):
+    return (c + 31) // 32 * 32
+
+
+def _f32(t):
+    if t.dtype != torch.float32:
+        raise L.DDKError(f"expected float32, got {t.dtype}")
+    return t
+
+
+# ------------------------------------------------------------------ layout / packing
+def nchw_to_nhwc(x, c_pad=None):
+    b, c, h, w = x.shape
+    c_pad = c if c_pad is None else c_pad
+    out = torch.empty((b, h, w, c_pad), device=x.device, dtype=torch.float32)
+    L.check(L.load().ddk_nchw_to_nhwc(L.ptr(_f32(x)), L.ptr(out), b, c, h, w, c_pad, L.stream()), "nchw_to_nhwc")
+    return out
+
+
+def nhwc_to_nchw(x, c=None):
+    b, h, w, cs = x.shape
+    c = cs if c is None else c
+    out = torch.empty((b, c, h, w), device=x.device, dtype=torch.float32)
+    L.check(L.load().ddk_nhwc_to_nchw(L.ptr(_f32(x)), L.ptr(out), b, c, h, w, cs, L.stream()), "nhwc_to_nchw")
+    return out
+
+
+def pad_channels(x, c_pad):
+    c = x.shape[-1]
+    out = torch.empty((*x.shape[:-1], c_pad), device=x.device, dtype=torch.float32)
+    L.check(L.load().ddk_pad_channels(L.ptr(_f32(x)), L.ptr(out), x.numel() // c, c, c_pad, L.stream()), "pad_channels")
+    return out
+
+
+def pack_conv_weight(w):
+    """OIHW -> [O][KH*KW][pad32(I)]"""
+    o, i, kh, kw = w.shape
+    out = torch.empty((o, kh * kw, pad32(i)), device=w.device, dtype=torch.float32)
+    L.check(L.load().ddk_pack_conv_weight(L.ptr(_f32(w.contiguous())), L.ptr(out), o, i, kh, kw, pad32(i), L.stream()),
+            "pack_conv_weight")
+    return out
+
+
+def pack_convT_weight(w):
+    """ConvTranspose2d (I,O,4,4) -> [4 phases][O][4 taps][I]"""
+    i, o, kh, kw = w.shape
+    if (kh, kw) != (4, 4):
+        raise L.DDKError("pack_convT_weight: kernel must be 4x4")
+    out = torch.empty((4, o, 4, i), device=w.device, dtype=torch.float32)
+    L.check(L.load().ddk_pack_convT_weight(L.ptr(_f32(w.contiguous())), L.ptr(out), i, o, L.stream()), "pack_convT_weight")
+    return out
+
+
+# ------------------------------------------------------------------ conv family
+def conv(kind, x, w_packed, bias=None, n_out=None, x2=None, resid=None, pre_mish=False, post_mish=False):
+    """Implicit-GEMM conv on NHWC x (optionally channel-concatenated with x2 without materialising it)."""
+    b, h, w_, c0 = x.shape
+    c1 = 0 if x2 is None else x2.shape[-1]
+    n = n_out if n_out is not None else (w_packed.shape[1] if kind == CONVT4X4_S2 else w_packed.shape[0])
+    if kind == CONV3X3_S2:
+        ho, wo = (h - 1) // 2 + 1, (w_ - 1) // 2 + 1
+    elif kind == CONVT4X4_S2:
+        ho, wo = 2 * h, 2 * w_
+    else:
+        ho, wo = h, w_
+    out = torch.empty((b, ho, wo, n), device=x.device, dtype=torch.float32)
+    lib = L.load()
+    ws_bytes = lib.ddk_conv_workspace_bytes(kind, b, h, w_, c0 + c1, n)
+    ws = torch.empty(max(ws_bytes, 16) // 4, device=x.device, dtype=torch.float32) if ws_bytes else None
+    a = L.ConvArgs(kind, L.ptr(_f32(x)), L.ptr(x2), c0, c1, L.ptr(w_packed), L.ptr(bias), L.ptr(resid), L.ptr(out),
+                   b, h, w_, n, int(pre_mish), int(post_mish), L.ptr(ws), ws_bytes)
+    L.check(lib.ddk_conv_forward(C.byref(a), L.stream()), "conv_forward")
+    return out
+
+
+# ------------------------------------------------------------------ norms / activations
+def groupnorm_mish(x, gamma, beta, temb=None, addend=None, groups=GN_GROUPS, eps=GN_EPS):
+    b, h, w, c = x.shape
+    out = torch.empty_like(x)
+    lib = L.load()
+    ws_bytes = lib.ddk_groupnorm_workspace_bytes(b, h * w, c, groups)
+    ws = torch.empty(max(ws_bytes, 16) // 4, device=x.device, dtype=torch.float32) if ws_bytes else None
+    stride = temb.stride(0) if temb is not None else 0
+    L.check(lib.ddk_groupnorm_mish(L.ptr(_f32(x)), L.ptr(gamma), L.ptr(beta),
+                                   temb.data_ptr() if temb is not None else None, stride, L.ptr(addend), L.ptr(out),
+                                   b, h * w, c, groups, eps, L.ptr(ws), ws_bytes, L.stream()), "groupnorm_mish")
+    return out
+
+
+def chan_layernorm(x, g, b, eps=LN_EPS):
+    c = x.shape[-1]
+    out = torch.empty_like(x)
+    L.check(L.load().ddk_chan_layernorm(L.ptr(_f32(x)), L.ptr(g.reshape(-1)), L.ptr(b.reshape(-1)), L.ptr(out),
+                                        x.numel() // c, c, eps, L.stream()), "chan_layernorm")
+    return out
+
+
+def mish(x):
+    out = torch.empty_like(x)
+    L.check(L.load().ddk_mish(L.ptr(_f32(x)), L.ptr(out), x.numel(), L.stream()), "mish")
+    return out
+
+
+def tanh(x):
+    out = torch.empty_like(x)
+    L.check(L.load().ddk_tanh(L.ptr(_f32(x)), L.ptr(out), x.numel(), L.stream()), "tanh")
+    return out
+
+
+def add(a, b):
+    out = torch.empty_like(a)
+    L.check(L.load().ddk_add(L.ptr(_f32(a)), L.ptr(_f32(b)), L.ptr(out), a.numel(), L.stream()), "add")
+    return out
+
+
+def avgpool2(x):
+    b, h, w, c = x.shape
+    out = torch.empty((b, h // 2, w // 2, c), device=x.device, dtype=torch.float32)
+    L.check(L.load().ddk_avgpool2(L.ptr(_f32(x)), L.ptr(out), b, h, w, c, L.stream()), "avgpool2")
+    return out
+
+
+def upsample_nearest2(x):
+    b, h, w, c = x.shape
+    out = torch.empty((b, 2 * h, 2 * w, c), device=x.device, dtype=torch.float32)
+    L.check(L.load().ddk_upsample_nearest2(L.ptr(_f32(x)), L.ptr(out), b, h, w, c, L.stream()), "upsample_nearest2")
+    return out
+
+
+# ------------------------------------------------------------------ linear attention core
+def linattn(qkv, heads=4):
+    """qkv [B,H,W,3*heads*32] -> attention output [B,H,W,heads*32] (before to_out)."""
+    b, h, w, c3 = qkv.shape
+    ctx = torch.empty((b, heads, 32, 32), device=qkv.device, dtype=torch.float32)
+    out = torch.empty((b, h, w, c3 // 3), device=qkv.device, dtype=torch.float32)
+    lib = L.load()
+    L.check(lib.ddk_linattn_context(L.ptr(_f32(qkv)), L.ptr(ctx), b, h * w, heads, L.stream()), "linattn_context")
+    L.check(lib.ddk_linattn_apply(L.ptr(qkv), L.ptr(ctx), L.ptr(out), b, h * w, heads, L.stream()), "linattn_apply")
+    return out, ctx
+
+
+# ------------------------------------------------------------------ time embedding
+def time_mlp(t, freqs, w1t, b1, w2t, b2):
+    """t int64 [B] -> (Mish(time_mlp(t)) [B,dim], time_mlp(t) [B,dim])"""
+    bsz, dim = t.shape[0], w2t.shape[1]
+    act = torch.empty((bsz, dim), device=t.device, dtype=torch.float32)
+    raw = torch.empty((bsz, dim), device=t.device, dtype=torch.float32)
+    if t.dtype != torch.int64:
+        raise L.DDKError("time_mlp: t must be int64")
+    L.check(L.load().ddk_time_mlp(L.ptr(t), L.ptr(freqs), L.ptr(w1t), L.ptr(b1), L.ptr(w2t), L.ptr(b2), L.ptr(act),
+                                  L.ptr(raw), bsz, dim, L.stream()), "time_mlp")
+    return act, raw
+
+
+def time_proj(act, wt, bias):
+    bsz, dim = act.shape
+    n_out = wt.shape[1]
+    out = torch.empty((bsz, n_out), device=act.device, dtype=torch.float32)
+    L.check(L.load().ddk_time_proj(L.ptr(_f32(act)), L.ptr(wt), L.ptr(bias), L.ptr(out), bsz, dim, n_out, L.stream()),
+            "time_proj")
+    return out
+
+
+def conv1x1_small_n(x, w, bias):
+    c = x.shape[-1]
+    n_out = w.shape[0]
+    out = torch.empty((*x.shape[:-1], n_out), device=x.device, dtype=torch.float32)
+    L.check(L.load().ddk_conv1x1_small_n(L.ptr(_f32(x)), L.ptr(w.reshape(n_out, c)), L.ptr(bias), L.ptr(out),
+                                         x.numel() // c, c, n_out, L.stream()), "conv1x1_small_n")
+    return out
+
+
+# ------------------------------------------------------------------ noise-schedule arithmetic
+def q_sample(x, eps, t, sqrt_acp, sqrt_1m_acp):
+    out = torch.empty_like(x)
+    b = x.shape[0]
+    L.check(L.load().ddk_q_sample(L.ptr(_f32(x)), L.ptr(_f32(eps)), L.ptr(t), L.ptr(sqrt_acp), L.ptr(sqrt_1m_acp),
+                                  L.ptr(out), b, x.numel() // b, L.stream()), "q_sample")
+    return out
+
+
+def p_sample_update_(x, eps_hat, t, c_recip, c_recipm1, c1, c2, sigma, noise=None, seed=0, stream_id=0):
+    """In-place reverse-step update of x (any layout, as long as x / eps_hat / noise agree)."""
+    b = x.shape[0]
+    L.check(L.load().ddk_p_sample_update(L.ptr(_f32(x)), L.ptr(_f32(eps_hat)), L.ptr(noise), L.ptr(t), L.ptr(c_recip),
+                                         L.ptr(c_recipm1), L.ptr(c1), L.ptr(c2), L.ptr(sigma), b, x.numel() // b,
+                                         seed, stream_id, L.stream()), "p_sample_update")
+    return x
+
+
+def randn(shape, device, seed, step, stream_id=0):
+    out = torch.empty(shape, device=device, dtype=torch.float32)
+    L.check(L.load().ddk_randn(L.ptr(out), out.numel(), seed, step, stream_id, L.stream()), "randn")
+    return out
+
+
+def sq_err_sum(a, b):
+    bsz = a.shape[0]
+    out = torch.empty((bsz,), device=a.device, dtype=torch.float32)
+    L.check(L.load().ddk_sq_err_sum(L.ptr(_f32(a)), L.ptr(_f32(b)), L.ptr(out), bsz, a.numel() // bsz, L.stream()),
+            "sq_err_sum")
+    return out

@@ -1,0 +1,144 @@
+"""Python handle on the native UNet plan / sampler of libddk.so (csrc/unet_plan.hip).
+
+The plan is created from the reference config keys (models/unet/unet.py:19-22), tells us which
+state_dict tensors it needs (names = reference keys), repacks them into one device arena and then
+runs a whole forward -- or the whole T-step sampling loop -- from a single C call.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import lib as L
+
+
+def sinusoidal_freqs(dim):
+    """The fp32 frequency table of SinusoidalPosEmb (blocks.py:24-26), computed with the same torch
+    CPU expression as the reference so the table is bit-identical to its CPU path."""
+    half = dim // 2
+    step = math.log(10000) / (half - 1)
+    return torch.exp(torch.arange(half) * -step)
+
+
+class UnetPlan:
+    def __init__(self, in_ch, chan, mults):
+        lib = L.load()
+        cfg = L.UnetConfig(in_ch, chan, len(mults), (C.c_int * 8)(*list(mults) + [0] * (8 - len(mults))))
+        self._lib = lib
+        self.handle = lib.ddk_unet_create(C.byref(cfg))
+        if not self.handle:
+            raise L.DDKError(f"ddk_unet_create failed: {L.last_error()}")
+        self.in_ch, self.chan, self.mults = in_ch, chan, tuple(mults)
+        self.slot_names = [lib.ddk_unet_slot_name(self.handle, i).decode() for i in range(lib.ddk_unet_num_slots(self.handle))]
+        self.slot_numel = [lib.ddk_unet_slot_numel(self.handle, i) for i in range(len(self.slot_names))]
+        self.packed = None
+        self._ws = None
+        self._ws_key = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self._lib.ddk_unet_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    # ---------------------------------------------------------------- weights
+    def pack(self, tensors, device):
+        """tensors: mapping reference-key -> fp32 tensor (any device).  Builds the packed arena."""
+        lib = self._lib
+        nbytes = lib.ddk_unet_packed_bytes(self.handle)
+        packed = torch.zeros(nbytes // 4, device=device, dtype=torch.float32)
+        keep = []
+        for i, name in enumerate(self.slot_names):
+            if name == "@sinusoidal_freqs":
+                src = sinusoidal_freqs(self.chan)
+            else:
+                if name not in tensors:
+                    raise L.DDKError(f"UNet weight '{name}' missing from the state dict")
+                src = tensors[name]
+            src = src.detach().to(device=device, dtype=torch.float32).contiguous()
+            if src.numel() != self.slot_numel[i]:
+                raise L.DDKError(f"UNet weight '{name}': expected {self.slot_numel[i]} elements, got {src.numel()}")
+            keep.append(src)
+            L.check(lib.ddk_unet_pack_slot(self.handle, i, L.ptr(src), L.ptr(packed), L.stream()), f"pack {name}")
+        torch.cuda.current_stream().synchronize()  # sources may be temporaries
+        self.packed = packed
+        return packed
+
+    # ---------------------------------------------------------------- forward
+    def _workspace(self, kind, nbytes, device):
+        key = (kind, nbytes, str(device))
+        if self._ws_key != key:
+            self._ws = torch.empty(max(nbytes, 16) // 4 + 4, device=device, dtype=torch.float32)
+            self._ws_key = key
+        return self._ws
+
+    def flops(self, b, h, w):
+        return self._lib.ddk_unet_flops(self.handle, b, h, w)
+
+    def forward_nhwc(self, x, t):
+        """x [B,H,W,in_ch] fp32, t [B] int64 -> eps_hat [B,H,W,in_ch]."""
+        if self.packed is None:
+            raise L.DDKError("UnetPlan.forward before pack()")
+        b, h, w, c = x.shape
+        if c != self.in_ch:
+            raise L.DDKError(f"expected {self.in_ch} input channels, got {c}")
+        if t.dtype != torch.int64:
+            raise L.DDKError("timesteps must be int64")
+        lib = self._lib
+        nbytes = lib.ddk_unet_workspace_bytes(self.handle, b, h, w)
+        if nbytes == 0:
+            raise L.DDKError(f"unet workspace query failed: {L.last_error()}")
+        ws = self._workspace("fwd", nbytes, x.device)
+        out = torch.empty_like(x)
+        L.check(lib.ddk_unet_forward(self.handle, L.ptr(self.packed), L.ptr(x), L.ptr(t), L.ptr(out), b, h, w,
+                                     L.ptr(ws), nbytes, L.stream()), "unet_forward")
+        return out
+
+    # ---------------------------------------------------------------- sampler
+    def sample_nhwc(self, x, tables, t_start, t_end=0, noise=None, seed=0, stream_id=0, use_graph=True):
+        """Run steps t_start .. t_end (inclusive) of the reverse chain in place on x [B,H,W,in_ch].
+
+        tables: dict with c_recip, c_recipm1, c1, c2, sigma ([T] fp32 device tensors).
+        noise: optional [n_steps,B,H,W,in_ch] injected draws (parity tests); else in-kernel Philox.
+        """
+        if self.packed is None:
+            raise L.DDKError("UnetPlan.sample before pack()")
+        b, h, w, c = x.shape
+        lib = self._lib
+        nbytes = lib.ddk_sampler_workspace_bytes(self.handle, b, h, w)
+        if nbytes == 0:
+            raise L.DDKError(f"sampler workspace query failed: {L.last_error()}")
+        ws = self._workspace("smp", nbytes, x.device)
+        n_steps = t_start - t_end + 1
+        if noise is not None and tuple(noise.shape) != (n_steps, b, h, w, c):
+            raise L.DDKError(f"injected noise must be {(n_steps, b, h, w, c)}, got {tuple(noise.shape)}")
+
+        def call(stream_ptr):
+            a = L.SamplerArgs(self.handle, L.ptr(self.packed), L.ptr(x), L.ptr(noise), L.ptr(tables["c_recip"]),
+                              L.ptr(tables["c_recipm1"]), L.ptr(tables["c1"]), L.ptr(tables["c2"]), L.ptr(tables["sigma"]),
+                              b, h, w, t_start, t_end, seed, stream_id, int(use_graph), L.ptr(ws), nbytes)
+            L.check(lib.ddk_sampler_run(C.byref(a), stream_ptr), "sampler_run")
+
+        if use_graph and n_steps > 1:
+            # hipGraph capture is illegal on the legacy NULL stream: run on a side stream ordered after the current one
+            cur = torch.cuda.current_stream()
+            side = _side_stream(x.device)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                call(side.cuda_stream)
+            cur.wait_stream(side)
+        else:
+            call(L.stream())
+        return x
+
+
+_side_streams = {}
+
+
+def _side_stream(device):
+    key = str(device)
+    if key not in _side_streams:
+        _side_streams[key] = torch.cuda.Stream(device=device)
+    return _side_streams[key]

@@ -1,0 +1,194 @@
+/*
+ * ddk.h -- C ABI of libddk.so, the MI355X (gfx950) HIP kernels for the DDPM / dDDPM denoising path.
+ *
+ * The reference (simonamtoft/downsampled-diffusion) has no FFI: the path sits behind Python
+ * nn.Modules (models/unet/unet.py:9-104, models/diffusion/ddpm.py:22-457).  This header is the
+ * boundary the new host code (downsampled-diffusion_amd/ddk/lib.py, ctypes) binds instead of
+ * dispatching ATen ops; every entry cites the reference site whose arithmetic it replaces.
+ *
+ * Conventions
+ *   - plain C: pointers are DEVICE pointers (16-byte aligned, dense), sizes are ints; no torch types.
+ *   - activations are NHWC fp32 ("pixel-major": [B][H][W][C]); channel counts on the conv/GEMM
+ *     kernels are multiples of 32 (pad with ddk_nchw_to_nhwc / ddk_pad_channels).
+ *   - every call is asynchronous on `stream` (a hipStream_t), allocates nothing, never syncs;
+ *     the caller owns all buffers including workspaces (sizes from the *_workspace_bytes calls).
+ *   - return 0 on success, negative on error; ddk_last_error() gives the message (thread local).
+ */
+#ifndef DDK_H
+#define DDK_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* ddk_stream_t; /* hipStream_t */
+
+#define DDK_OK 0
+#define DDK_ERR_ARG (-1)     /* shape / alignment / null pointer */
+#define DDK_ERR_HIP (-2)     /* a HIP runtime call failed */
+#define DDK_ERR_WORKSPACE (-3)
+
+int ddk_version(void);
+const char* ddk_last_error(void);
+/* 1 when a gfx950 device is visible to this process. */
+int ddk_device_ok(void);
+
+/* ------------------------------------------------------------------ layout / packing */
+/* NCHW -> NHWC with the channel dim zero-padded to c_pad (>= C).  Unet.forward entry (unet.py:74). */
+int ddk_nchw_to_nhwc(const float* src, float* dst, int B, int C, int H, int W, int c_pad, ddk_stream_t s);
+/* NHWC (row stride c_stride >= C) -> NCHW, first C channels. */
+int ddk_nhwc_to_nchw(const float* src, float* dst, int B, int C, int H, int W, int c_stride, ddk_stream_t s);
+/* [M][C] -> [M][c_pad], zero fill. */
+int ddk_pad_channels(const float* src, float* dst, long long M, int C, int c_pad, ddk_stream_t s);
+/* Conv2d weight OIHW -> [O][KH*KW][I_pad] (zero padded input channels). */
+int ddk_pack_conv_weight(const float* w_oihw, float* dst, int O, int I, int KH, int KW, int i_pad, ddk_stream_t s);
+/* ConvTranspose2d(k4,s2,p1) weight (I,O,4,4) -> [phase 4][O][tap 4][I]; phase = py*2+px, tap = a*2+b
+ * with input offset (dy,dx) = (py - a, px - b) and kernel index ky = 1 - py + 2a, kx = 1 - px + 2b. */
+int ddk_pack_convT_weight(const float* w_iohw, float* dst, int I, int O, ddk_stream_t s);
+/* Linear weight [O][I] -> transposed [I][O] at column offset col0 of a [I][ld] matrix. */
+int ddk_pack_linear_T(const float* w_oi, float* dst, int O, int I, int ld, int col0, ddk_stream_t s);
+
+/* ------------------------------------------------------------------ conv family (fp32 MFMA implicit GEMM) */
+enum ddk_conv_kind {
+    DDK_CONV3X3_S1 = 0, /* Block conv, blocks.py:78 */
+    DDK_CONV3X3_S2 = 1, /* Downsample, blocks.py:44 */
+    DDK_CONV1X1 = 2,    /* res_conv / to_qkv / to_out, blocks.py:103,123-124 */
+    DDK_CONVT4X4_S2 = 3 /* Upsample, blocks.py:35 */
+};
+
+typedef struct ddk_conv_args {
+    int kind;            /* enum ddk_conv_kind */
+    const float* src0;   /* NHWC [B][H][W][c0] */
+    const float* src1;   /* optional second source (channel concat without materialising it, unet.py:97) */
+    int c0, c1;          /* channels of each source, multiples of 32 (c1 = 0 when src1 is NULL) */
+    const float* weight; /* packed by ddk_pack_conv_weight / ddk_pack_convT_weight, I = c0 + c1 */
+    const float* bias;   /* [N] or NULL */
+    const float* resid;  /* optional [B][Ho][Wo][N] added in the epilogue (Residual, blocks.py:13-14) */
+    float* out;          /* NHWC [B][Ho][Wo][N] */
+    int B, H, W;         /* input spatial size */
+    int N;               /* output channels, multiple of 32 */
+    int pre_mish;        /* 1: apply Mish to the input while staging it (convblocks.py:114) */
+    int post_mish;       /* 1: write Mish(out): the next conv's input activation, applied once (convblocks.py:115-117) */
+    void* workspace;     /* split-K slabs; may be NULL when ddk_conv_workspace_bytes() == 0 */
+    size_t workspace_bytes;
+} ddk_conv_args;
+
+size_t ddk_conv_workspace_bytes(int kind, int B, int H, int W, int cin, int N);
+int ddk_conv_forward(const ddk_conv_args* a, ddk_stream_t s);
+
+/* ------------------------------------------------------------------ normalisation / activation */
+/* out = Mish(GroupNorm_g(x)) [+ temb[b*temb_stride + c]] [+ addend]   (blocks.py:79-80,106-115)
+ * x, addend, out: [B][HW][C]; gamma/beta [C]; stats per (b, group), biased variance, eps inside sqrt. */
+int ddk_groupnorm_mish(const float* x, const float* gamma, const float* beta, const float* temb,
+                       int temb_stride, const float* addend, float* out, int B, int HW, int C, int groups,
+                       float eps, void* workspace, size_t workspace_bytes, ddk_stream_t s);
+size_t ddk_groupnorm_workspace_bytes(int B, int HW, int C, int groups);
+/* per-pixel channel LayerNorm, (x-mean)/(sqrt(var)+eps)*g+b, biased var (blocks.py:57-60). */
+int ddk_chan_layernorm(const float* x, const float* g, const float* b, float* out, long long M, int C,
+                       float eps, ddk_stream_t s);
+/* elementwise Mish / tanh (convblocks.py:110, dddpm.py:99,110). */
+int ddk_mish(const float* x, float* out, long long n, ddk_stream_t s);
+int ddk_tanh(const float* x, float* out, long long n, ddk_stream_t s);
+/* out[b][y][x][c] = mean of the 2x2 window (F.avg_pool2d(2), convblocks.py:129). */
+int ddk_avgpool2(const float* x, float* out, int B, int H, int W, int C, ddk_stream_t s);
+/* nearest-neighbour x2 (F.interpolate(scale_factor=2), convblocks.py:127). */
+int ddk_upsample_nearest2(const float* x, float* out, int B, int H, int W, int C, ddk_stream_t s);
+/* out = a + b */
+int ddk_add(const float* a, const float* b, float* out, long long n, ddk_stream_t s);
+
+/* ------------------------------------------------------------------ linear attention (blocks.py:126-134) */
+/* qkv: [B][HW][3*heads*32], channel = (qkv, head, c).  ctx[b][h][d][e] = sum_n softmax_n(k[d,:])[n] v[e,n]. */
+int ddk_linattn_context(const float* qkv, float* ctx, int B, int HW, int heads, ddk_stream_t s);
+/* out[b][n][h*32+e] = sum_d ctx[b][h][d][e] * q[b][n][h*32+d]. */
+int ddk_linattn_apply(const float* qkv, const float* ctx, float* out, int B, int HW, int heads, ddk_stream_t s);
+
+/* ------------------------------------------------------------------ time embedding (blocks.py:22-29, unet.py:30-35, blocks.py:92-95) */
+/* act[b][:] = Mish(Linear2(Mish(Linear1(sincos(t[b] * freqs)))))  -- the vector every ResnetBlock's
+ * Linear consumes.  w1t [dim][4dim], w2t [4dim][dim] are transposed Linear weights; scratch none. */
+int ddk_time_mlp(const int64_t* t, const float* freqs, const float* w1t, const float* b1, const float* w2t,
+                 const float* b2, float* act, float* raw, int B, int dim, ddk_stream_t s);
+/* out[b][j] = sum_k act[b][k] * wt[k][j] + bias[j], j < n_out (all 17 ResnetBlock mlps at once). */
+int ddk_time_proj(const float* act, const float* wt, const float* bias, float* out, int B, int dim, int n_out,
+                  ddk_stream_t s);
+
+/* ------------------------------------------------------------------ small-N 1x1 (final_conv.1, unet.py:71) */
+/* out[m][co] = sum_c x[m][c] w[co][c] + b[co]; x [M][C], w [n_out][C] (the OIHW tensor as is), out [M][n_out]. */
+int ddk_conv1x1_small_n(const float* x, const float* w, const float* bias, float* out, long long M, int C,
+                        int n_out, ddk_stream_t s);
+
+/* ------------------------------------------------------------------ noise-schedule arithmetic */
+/* x_t = sqrt_acp[t_b] * x + sqrt_1m_acp[t_b] * eps     (ddpm.py:256-273); per = elements per sample. */
+int ddk_q_sample(const float* x, const float* eps, const int64_t* t, const float* sqrt_acp,
+                 const float* sqrt_1m_acp, float* out, int B, long long per, ddk_stream_t s);
+/* One reverse step after the UNet call (ddpm.py:149-158,177-185,216-227), in place on x:
+ *   x0 = clamp(c_recip[t] x - c_recipm1[t] eps_hat, -1, 1); mean = c1[t] x0 + c2[t] x;
+ *   x <- mean + [t > 0] sigma[t] z,  sigma = exp(0.5 posterior_log_variance_clipped).
+ * z comes from `noise` when non-NULL, else from Philox4x32-10 keyed (seed, t_b, stream_id). */
+int ddk_p_sample_update(float* x, const float* eps_hat, const float* noise, const int64_t* t,
+                        const float* c_recip, const float* c_recipm1, const float* c1, const float* c2,
+                        const float* sigma, int B, long long per, uint64_t seed, uint32_t stream_id,
+                        ddk_stream_t s);
+/* out[i] ~ N(0,1): Philox4x32-10 + Box-Muller, counter (i/4, step, stream_id)  (ddpm.py:241). */
+int ddk_randn(float* out, long long n, uint64_t seed, uint32_t step, uint32_t stream_id, ddk_stream_t s);
+/* per_sample[b] = sum_i (a - b)^2 over the sample's `per` elements (ddpm.py:279, utils/utils.py:34-40). */
+int ddk_sq_err_sum(const float* a, const float* b, float* per_sample, int B, long long per, ddk_stream_t s);
+
+/* ------------------------------------------------------------------ whole-UNet plan (unet.py:74-104, eval mode) */
+typedef struct ddk_unet_config {
+    int in_ch;      /* config['unet_in'] */
+    int chan;       /* config['unet_chan'], multiple of 32 */
+    int n_levels;   /* len(config['unet_dims']) */
+    int mults[8];   /* config['unet_dims'] */
+} ddk_unet_config;
+
+typedef struct ddk_unet ddk_unet; /* opaque */
+
+ddk_unet* ddk_unet_create(const ddk_unet_config* cfg);
+void ddk_unet_destroy(ddk_unet* u);
+/* Weight slots: the plan lists every state_dict tensor it needs (name = reference key, Appendix B of
+ * SURVEY.md; the synthetic slot "@sinusoidal_freqs" is the fp32 table of blocks.py:24-26). */
+int ddk_unet_num_slots(const ddk_unet* u);
+const char* ddk_unet_slot_name(const ddk_unet* u, int slot);
+long long ddk_unet_slot_numel(const ddk_unet* u, int slot);
+/* bytes of the packed weight arena the caller allocates once per model */
+size_t ddk_unet_packed_bytes(const ddk_unet* u);
+/* repack one canonical (state_dict layout) tensor into the arena */
+int ddk_unet_pack_slot(const ddk_unet* u, int slot, const float* canonical, void* packed, ddk_stream_t s);
+size_t ddk_unet_workspace_bytes(const ddk_unet* u, int B, int H, int W);
+/* eps_hat = Unet(x, t).  x: NHWC [B][H][W][in_ch] (unpadded), out same shape. */
+int ddk_unet_forward(const ddk_unet* u, const void* packed, const float* x, const int64_t* t, float* out,
+                     int B, int H, int W, void* workspace, size_t workspace_bytes, ddk_stream_t s);
+/* FLOPs (2*MAC) of one forward for B samples at HxW: the algorithmic work bench.py prices. */
+double ddk_unet_flops(const ddk_unet* u, int B, int H, int W);
+
+/* ------------------------------------------------------------------ T-step sampler (ddpm.py:229-249) */
+typedef struct ddk_sampler_args {
+    const ddk_unet* unet;
+    const void* packed;
+    float* x;                 /* NHWC [B][H][W][in_ch]: x_T in, x_{t_end} out */
+    const float* noise;       /* NULL -> in-kernel Philox; else [n_steps][B][H][W][in_ch], k-th draw for step k */
+    const float* c_recip;     /* sqrt_recip_alphas_cumprod [T] */
+    const float* c_recipm1;   /* sqrt_recipm1_alphas_cumprod [T] */
+    const float* c1;          /* posterior_mean_coef1 [T] */
+    const float* c2;          /* posterior_mean_coef2 [T] */
+    const float* sigma;       /* exp(0.5 * posterior_log_variance_clipped) [T] */
+    int B, H, W;
+    int t_start;              /* first timestep (T-1) */
+    int t_end;                /* last timestep inclusive (0, or early_stop) */
+    uint64_t seed;
+    uint32_t stream_id;       /* rank / shard id: independent Philox stream per GPU */
+    int use_graph;            /* capture one step into a hipGraph and replay it */
+    void* workspace;
+    size_t workspace_bytes;
+} ddk_sampler_args;
+
+size_t ddk_sampler_workspace_bytes(const ddk_unet* u, int B, int H, int W);
+int ddk_sampler_run(const ddk_sampler_args* a, ddk_stream_t s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DDK_H */

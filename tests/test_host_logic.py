@@ -1,0 +1,143 @@
+"""CPU-side checks of the product package: state_dict layout, schedule buffers, C-ABI symbols, loud failure
+without a device, CLI surface.  No kernel is launched here."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import ddpm_cfg, dddpm_cfg, golden, golden_keys
+from conftest import ROOT
+
+import models
+from models import DDPM, DownsampleDDPM, DownsampleDDPMAutoencoder, Unet
+from ddk import lib as L
+
+
+def _shapes(m):
+    return {k: list(v.shape) for k, v in m.state_dict().items()}
+
+
+def test_state_dict_layout_matches_reference():
+    ks = golden_keys()
+    cfg = ddpm_cfg(128, 3, 32)
+    got = _shapes(DDPM(cfg, Unet(cfg), "cpu", 3))
+    assert got == ks["ddpm_c3"] and list(got) == list(ks["ddpm_c3"])          # same keys, shapes AND order
+    cfgd = dddpm_cfg(128, 256, 3)
+    got = _shapes(DownsampleDDPM(cfgd, Unet(cfgd), "cpu", 3))
+    assert got == ks["dddpm_x3"] and list(got) == list(ks["dddpm_x3"])
+    cfgt = dddpm_cfg(32, 32, 2)
+    got = _shapes(DownsampleDDPMAutoencoder(cfgt, Unet(cfgt), "cpu", 3))
+    assert got == ks["dddpm_tiny_x2"] and list(got) == list(ks["dddpm_tiny_x2"])
+
+
+def test_param_counts():
+    cfg = dddpm_cfg(128, 256, 3)
+    u = Unet(cfg)
+    assert sum(p.numel() for p in u.parameters()) == 22261768
+    assert sum(p.numel() for p in DownsampleDDPM(cfg, u, "cpu", 3).parameters()) == 22671699
+    cfg3 = ddpm_cfg(128, 3, 32)
+    assert sum(p.numel() for p in Unet(cfg3).parameters()) == 22254723
+
+
+@pytest.mark.parametrize("kind,T", [("linear", 1000), ("linear", 200), ("cosine", 1000)])
+def test_schedule_buffers_bit_exact(kind, T):
+    g = golden("g1_schedule")
+    m = DDPM(ddpm_cfg(32, 3, 16, T, kind), torch.nn.Identity(), "cpu", 3)
+    sd = m.state_dict()
+    from utils.synthetic import SCHEDULE_KEYS
+    for k in SCHEDULE_KEYS:
+        assert np.array_equal(sd[k].numpy(), g[f"{kind}_{T}_{k}"]), k
+    assert np.array_equal(m.vlb_weights.numpy(), g[f"{kind}_{T}_vlb_weights"])
+    assert "vlb_weights" not in sd and "posterior_sigma" not in sd           # non-persistent (ddpm.py:105)
+    want = (0.5 * torch.tensor(g[f"{kind}_{T}_posterior_log_variance_clipped"])).exp()    # ddpm.py:227
+    assert torch.equal(m.posterior_sigma, want)
+
+
+def test_sample_shapes_and_attrs():
+    cfg = dddpm_cfg(128, 256, 3)
+    m = DownsampleDDPM(cfg, Unet(cfg), "cpu", 3)
+    assert m.sample_shape == [8, 32, 32] and m.x_shape == [3, 256, 256] and m.timesteps == 1000
+    assert m.t_rec_max == 100 and m.force_latent is True
+    with pytest.raises(ValueError):
+        c = ddpm_cfg(32, 3, 16); c["loss_flat"] = "max"; DDPM(c, torch.nn.Identity(), "cpu", 3)
+    with pytest.raises(ValueError):
+        c = ddpm_cfg(32, 3, 16); c["beta_schedule"] = "sqrt"; DDPM(c, torch.nn.Identity(), "cpu", 3)
+    with pytest.raises(AssertionError):
+        c = ddpm_cfg(32, 3, 16); c["loss_type"] = "l1"; DDPM(c, torch.nn.Identity(), "cpu", 3)
+
+
+def test_unet_rejects_unsupported_width():
+    with pytest.raises(L.DDKError):
+        Unet(dict(unet_chan=16, unet_in=3, unet_dims=(1, 2), unet_dropout=0.0))
+
+
+def test_c_abi_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "ddk.h")).read()
+    declared = set(re.findall(r"\b(ddk_[a-zA-Z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 40
+    assert declared == set(L.SIGNATURES), declared ^ set(L.SIGNATURES)
+    lib = ctypes.CDLL(L.LIB_PATH)
+    for name in declared:
+        assert getattr(lib, name) is not None
+    assert L.load().ddk_version() == 100
+
+
+def test_plan_slots_cover_state_dict():
+    cfg = ddpm_cfg(128, 8, 32)
+    u = Unet(cfg)
+    u.flops(1, 32, 32)                                   # creates the plan (host only)
+    names = set(u._plan.slot_names)
+    assert names - {"@sinusoidal_freqs"} == set(u.state_dict())
+    assert abs(u.flops(1, 32, 32) / 1e9 - 4.5947) < 1e-3
+    assert abs(Unet(ddpm_cfg(128, 3, 32)).flops(1, 32, 32) / 1e9 - 4.5803) < 1e-3   # cfg2
+    assert abs(Unet(ddpm_cfg(128, 1, 32)).flops(1, 32, 32) / 1e9 - 4.5745) < 1e-3   # cfg1
+    assert abs(u.flops(1, 16, 16) / 1e9 - 1.1496) < 1e-3                            # cfg3
+
+
+def test_no_cpu_fallback():
+    cfg = ddpm_cfg(32, 3, 16)
+    u = Unet(cfg).eval()
+    with pytest.raises(L.DDKError):
+        with torch.no_grad():
+            u(torch.zeros(1, 3, 16, 16), torch.zeros(1, dtype=torch.long))
+    m = DDPM(cfg, u, "cpu", 3)
+    with pytest.raises(L.DDKError):
+        m.sample(2)
+    with pytest.raises(L.DDKError):
+        m.q_sample(torch.zeros(1, 3, 16, 16), torch.zeros(1, dtype=torch.long), torch.zeros(1, 3, 16, 16))
+    from ddk import ops
+    with pytest.raises(L.DDKError):
+        ops.mish(torch.zeros(8))
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "downsampled-diffusion_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dp, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src, os.path.join(dp, f)
+
+
+def test_cli_args_surface():
+    from utils import DATASETS, get_args
+    cfg, mute = get_args({"lr": 1e-3}, DATASETS, models.MODEL_NAMES,
+                         ["-m", "ddpm", "-d", "celeba_hq", "-e", "7", "-bs", "32", "-is", "256", "-downsample", "3", "-mute"])
+    assert mute and cfg["dataset"] == "celeba_hq" and cfg["n_steps"] == 7 and cfg["batch_size"] == 32
+    assert cfg["image_size"] == 256 and cfg["n_downsamples"] == 3 and cfg["model"] == "ddpm"
+    cfg, mute = get_args({}, DATASETS, models.MODEL_NAMES, [])
+    assert not mute and cfg["image_size"] == 32 and cfg["batch_size"] == 32 and cfg["n_steps"] == 500
+    for d in ("celeba_hq_65", "celeba_hq_64", "mnist"):
+        assert d in DATASETS
+
+
+def test_fix_samples_format():
+    from utils import fix_samples
+    from oracle.diffusion_ref import fix_samples as ref_fix
+    x = torch.randn(3, 3, 8, 8)
+    out = fix_samples(x)
+    assert out.shape == (3, 8, 8, 3) and out.dtype == np.float32
+    assert np.allclose(out, ref_fix(x), atol=1e-4) and out.min() == 0 and abs(out.max() - 255) < 1e-3

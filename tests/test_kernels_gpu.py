@@ -1,0 +1,259 @@
+"""Per-kernel parity: every HIP kernel family (called through the C ABI via ddk.ops) against the CPU oracle /
+plain torch-CPU fp32 on the same seeded inputs.  fp32 tolerance: max|diff| / max|ref| <= 2e-5 for contractions
+(summation order differs), tighter for elementwise; bit-exact where the kernel pins the evaluation order."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import rel_err, to_nchw, to_nhwc
+from oracle import diffusion_ref as D
+from oracle import philox_ref
+from oracle import unet_ref as U
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from ddk import ops as o
+    from ddk import lib
+    assert lib.load().ddk_device_ok() == 1, lib.last_error()
+    return o
+
+
+# ---------------------------------------------------------------- conv family
+CONV_CASES = [
+    # kind, B, H, W, c0, c1, N
+    ("s1", 2, 8, 8, 32, 0, 64),          # small-M: split-K path, 64x64 tile
+    ("s1", 2, 32, 32, 128, 0, 128),      # split-K on 128-wide
+    ("s1", 32, 32, 32, 128, 0, 128),     # cfg4 level-0 conv: 128x128 tile, direct epilogue
+    ("s1", 32, 16, 16, 128, 0, 256),     # 128x64 tile
+    ("s1", 4, 8, 8, 256, 256, 256),      # dual source (concat-free skip), K = 4608
+    ("s1", 3, 5, 7, 32, 0, 32),          # ragged M, N = 32 tile
+    ("s1", 2, 16, 16, 64, 0, 64),        # N = 64 tile
+    ("s2", 4, 16, 16, 64, 0, 64),
+    ("s2", 32, 32, 32, 128, 0, 128),
+    ("s2", 2, 7, 9, 32, 0, 32),          # odd spatial size
+    ("1x1", 8, 16, 16, 128, 0, 384),     # to_qkv shape
+    ("1x1", 2, 4, 4, 256, 256, 256),     # res_conv over a dual source
+    ("T", 4, 4, 4, 64, 0, 64),
+    ("T", 32, 16, 16, 128, 0, 128),      # ups.2.3 at cfg4
+]
+
+
+@pytest.mark.parametrize("kind,B,H,W,c0,c1,N", CONV_CASES)
+def test_conv(ops, kind, B, H, W, c0, c1, N):
+    cin = c0 + c1
+    x = rnd(B, cin, H, W, seed=1)
+    k = {"s1": 3, "s2": 3, "1x1": 1, "T": 4}[kind]
+    bias = rnd(N, seed=3, scale=0.1)
+    if kind == "T":
+        w = rnd(cin, N, 4, 4, seed=2, scale=(cin * 4) ** -0.5)
+        ref = F.conv_transpose2d(x, w, bias, stride=2, padding=1)
+        wp = ops.pack_convT_weight(w.to(DEV))
+        code = ops.CONVT4X4_S2
+    else:
+        w = rnd(N, cin, k, k, seed=2, scale=(cin * k * k) ** -0.5)
+        ref = F.conv2d(x, w, bias, stride=2 if kind == "s2" else 1, padding=k // 2)
+        wp = ops.pack_conv_weight(w.to(DEV))
+        code = {"s1": ops.CONV3X3_S1, "s2": ops.CONV3X3_S2, "1x1": ops.CONV1X1}[kind]
+    xh = to_nhwc(x).to(DEV)
+    x0 = xh[..., :c0].contiguous()
+    x1 = xh[..., c0:].contiguous() if c1 else None
+    resid = rnd(*ref.shape, seed=4)
+    out = ops.conv(code, x0, wp, bias.to(DEV), x2=x1)
+    assert rel_err(to_nchw(out.cpu()), ref) < 2e-5
+    out_r = ops.conv(code, x0, wp, bias.to(DEV), x2=x1, resid=to_nhwc(resid).to(DEV))
+    assert rel_err(to_nchw(out_r.cpu()), ref + resid) < 2e-5
+    # run-to-run determinism (fixed-order split-K reduction, no float atomics)
+    assert torch.equal(out, ops.conv(code, x0, wp, bias.to(DEV), x2=x1))
+
+
+def test_conv_pre_post_mish(ops):
+    x = rnd(2, 64, 16, 16, seed=5)
+    w = rnd(32, 64, 1, 1, seed=6, scale=0.125)
+    b = rnd(32, seed=7, scale=0.1)
+    ref = U.mish(F.conv2d(U.mish(x), w, b))
+    out = ops.conv(ops.CONV1X1, to_nhwc(x).to(DEV), ops.pack_conv_weight(w.to(DEV)), b.to(DEV), pre_mish=True, post_mish=True)
+    assert rel_err(to_nchw(out.cpu()), ref) < 2e-5
+    w3 = rnd(32, 32, 3, 3, seed=8, scale=(32 * 9) ** -0.5)
+    x3 = rnd(2, 32, 8, 8, seed=9)          # split-K path: post_mish applied by the reduce kernel
+    ref3 = U.mish(F.conv2d(x3, w3, b, padding=1))
+    out3 = ops.conv(ops.CONV3X3_S1, to_nhwc(x3).to(DEV), ops.pack_conv_weight(w3.to(DEV)), b.to(DEV), post_mish=True)
+    assert rel_err(to_nchw(out3.cpu()), ref3) < 2e-5
+
+
+def test_conv_small_cin_padding(ops):
+    """C_in in {1,3,8}: channels zero-padded to 32 on both operands (first UNet conv / res_conv)."""
+    for cin in (1, 3, 8):
+        x = rnd(2, cin, 16, 16, seed=10 + cin)
+        w = rnd(64, cin, 3, 3, seed=20 + cin, scale=(cin * 9) ** -0.5)
+        ref = F.conv2d(x, w, None, padding=1)
+        out = ops.conv(ops.CONV3X3_S1, ops.nchw_to_nhwc(x.to(DEV), 32), ops.pack_conv_weight(w.to(DEV)))
+        assert rel_err(to_nchw(out.cpu()), ref) < 2e-5
+
+
+def test_conv_argument_errors(ops):
+    from ddk.lib import DDKError
+    x = torch.zeros(1, 4, 4, 48, device=DEV)
+    with pytest.raises(DDKError):
+        ops.conv(ops.CONV1X1, x, torch.zeros(32, 1, 64, device=DEV))      # c0 not a multiple of 32
+
+
+# ---------------------------------------------------------------- norms
+@pytest.mark.parametrize("B,H,W,C", [(2, 8, 8, 32), (32, 32, 32, 128), (32, 16, 16, 256), (4, 4, 4, 256), (3, 5, 7, 64),
+                                     (2, 128, 128, 32), (1, 256, 256, 128)])
+def test_groupnorm_mish(ops, B, H, W, C):
+    x = rnd(B, C, H, W, seed=30, scale=2.0) + 0.5
+    g, b = 1 + 0.1 * rnd(C, seed=31), 0.1 * rnd(C, seed=32)
+    temb = rnd(B, C + 8, seed=33)[:, 4:4 + C]            # strided view, like a slice of the [B][3584] table
+    add = rnd(B, C, H, W, seed=34)
+    ref0 = U.mish(F.group_norm(x, 8, g, b, 1e-5))
+    xh = to_nhwc(x).to(DEV)
+    out0 = ops.groupnorm_mish(xh, g.to(DEV), b.to(DEV))
+    assert rel_err(to_nchw(out0.cpu()), ref0) < 5e-6
+    tb = rnd(B, C + 8, seed=33).to(DEV)
+    out1 = ops.groupnorm_mish(xh, g.to(DEV), b.to(DEV), temb=tb[:, 4:4 + C], addend=to_nhwc(add).to(DEV))
+    assert rel_err(to_nchw(out1.cpu()), ref0 + temb[:, :, None, None] + add) < 5e-6
+
+
+@pytest.mark.parametrize("C", [32, 64, 128, 256, 512])
+def test_chan_layernorm(ops, C):
+    x = rnd(3, C, 6, 5, seed=40, scale=3.0) + 1.0
+    g, b = 1 + 0.1 * rnd(1, C, 1, 1, seed=41), 0.1 * rnd(1, C, 1, 1, seed=42)
+    out = ops.chan_layernorm(to_nhwc(x).to(DEV), g.to(DEV), b.to(DEV))
+    assert rel_err(to_nchw(out.cpu()), U.chan_layernorm(x, g, b)) < 5e-6
+
+
+def test_mish_matches_torch(ops):
+    x = torch.cat([torch.linspace(-30, 30, 4097), torch.tensor([-100.0, 100.0, 0.0, 20.0, 20.000002, -20.0])])
+    out = ops.mish(x.to(DEV)).cpu()
+    ref = F.mish(x)
+    assert (out - ref).abs().max() < 2e-6 and rel_err(out, ref) < 1e-6
+    assert rel_err(ops.tanh(x.to(DEV)).cpu(), torch.tanh(x)) < 1e-6
+
+
+def test_pool_upsample_add(ops):
+    x = rnd(2, 64, 8, 12, seed=50)
+    xh = to_nhwc(x).to(DEV)
+    assert torch.equal(to_nchw(ops.upsample_nearest2(xh).cpu()), F.interpolate(x, scale_factor=2))
+    assert rel_err(to_nchw(ops.avgpool2(xh).cpu()), F.avg_pool2d(x, 2, 2)) < 1e-6
+    y = rnd(2, 64, 8, 12, seed=51)
+    assert torch.equal(ops.add(xh, to_nhwc(y).to(DEV)).cpu(), to_nhwc(x + y))
+
+
+# ---------------------------------------------------------------- attention
+@pytest.mark.parametrize("B,H,W", [(2, 4, 4), (3, 8, 8), (2, 32, 32), (1, 10, 13)])
+def test_linattn(ops, B, H, W):
+    qkv = rnd(B, 384, H, W, seed=60, scale=1.5)
+    q, k, v = qkv.reshape(B, 3, 4, 32, H * W).unbind(1)
+    ks = k.softmax(dim=-1)
+    ctx_ref = torch.einsum("bhdn,bhen->bhde", ks, v)
+    out_ref = torch.einsum("bhde,bhdn->bhen", ctx_ref, q).reshape(B, 128, H, W)
+    out, ctx = ops.linattn(to_nhwc(qkv).to(DEV), 4)
+    assert rel_err(ctx.cpu(), ctx_ref) < 1e-5
+    assert rel_err(to_nchw(out.cpu()), out_ref) < 1e-5
+
+
+def test_linattn_softmax_extremes(ops):
+    """a dominant key (softmax ~ one-hot) and large negative logits must not overflow / lose the max"""
+    B, H, W = 1, 8, 8
+    qkv = rnd(B, 384, H, W, seed=61)
+    qkv[:, 128:256, 3, 5] += 60.0
+    qkv[:, 128:256, 0, 0] -= 80.0
+    q, k, v = qkv.reshape(B, 3, 4, 32, H * W).unbind(1)
+    ctx_ref = torch.einsum("bhdn,bhen->bhde", k.softmax(dim=-1), v)
+    _, ctx = ops.linattn(to_nhwc(qkv).to(DEV), 4)
+    assert torch.isfinite(ctx).all() and rel_err(ctx.cpu(), ctx_ref) < 1e-5
+
+
+# ---------------------------------------------------------------- time embedding
+@pytest.mark.parametrize("dim", [32, 128])
+def test_time_embedding(ops, dim):
+    from ddk.plan import sinusoidal_freqs
+    t = torch.tensor([0, 1, 17, 500, 999, 3, 3, 250, 731])
+    w1, b1 = rnd(4 * dim, dim, seed=70, scale=dim ** -0.5), rnd(4 * dim, seed=71, scale=0.1)
+    w2, b2 = rnd(dim, 4 * dim, seed=72, scale=(4 * dim) ** -0.5), rnd(dim, seed=73, scale=0.1)
+    wp, bp = rnd(200, dim, seed=74, scale=dim ** -0.5), rnd(200, seed=75, scale=0.1)
+    e = U.sinusoidal_embedding(t, dim)
+    raw_ref = F.linear(U.mish(F.linear(e, w1, b1)), w2, b2)
+    act, raw = ops.time_mlp(t.to(DEV), sinusoidal_freqs(dim).to(DEV), w1.t().contiguous().to(DEV), b1.to(DEV),
+                            w2.t().contiguous().to(DEV), b2.to(DEV))
+    assert rel_err(raw.cpu(), raw_ref) < 2e-5
+    assert rel_err(act.cpu(), U.mish(raw_ref)) < 2e-5
+    out = ops.time_proj(act, wp.t().contiguous().to(DEV), bp.to(DEV))
+    assert rel_err(out.cpu(), F.linear(U.mish(raw_ref), wp, bp)) < 2e-5
+
+
+def test_conv1x1_small_n(ops):
+    for C, n_out in ((128, 8), (128, 3), (32, 1), (64, 3), (64, 8)):
+        x = rnd(2, C, 9, 7, seed=80)
+        w, b = rnd(n_out, C, 1, 1, seed=81, scale=C ** -0.5), rnd(n_out, seed=82)
+        out = ops.conv1x1_small_n(to_nhwc(x).to(DEV), w.to(DEV), b.to(DEV))
+        assert rel_err(to_nchw(out.cpu()), F.conv2d(x, w, b)) < 1e-5
+
+
+def test_layout_roundtrip(ops):
+    x = rnd(3, 5, 6, 7, seed=90)
+    xh = ops.nchw_to_nhwc(x.to(DEV), 32)
+    assert xh.shape == (3, 6, 7, 32) and torch.equal(xh[..., :5].cpu(), to_nhwc(x)) and (xh[..., 5:] == 0).all()
+    assert torch.equal(ops.nhwc_to_nchw(xh, 5).cpu(), x)
+    assert torch.equal(ops.pad_channels(to_nhwc(x).to(DEV), 32).cpu(), xh.cpu())
+
+
+# ---------------------------------------------------------------- noise-schedule arithmetic
+def _tables():
+    buf = D.schedule_buffers("linear", 1000)
+    sigma = (0.5 * buf["posterior_log_variance_clipped"]).exp()
+    return buf, sigma
+
+
+def test_q_sample_bit_exact(ops):
+    buf, _ = _tables()
+    x, eps = rnd(5, 3, 16, 16, seed=100), rnd(5, 3, 16, 16, seed=101)
+    t = torch.tensor([0, 1, 499, 998, 999])
+    out = ops.q_sample(x.to(DEV), eps.to(DEV), t.to(DEV), buf["sqrt_alphas_cumprod"].to(DEV),
+                       buf["sqrt_one_minus_alphas_cumprod"].to(DEV))
+    assert torch.equal(out.cpu(), D.q_sample(buf, x, t, eps))
+
+
+def test_p_sample_update_bit_exact(ops):
+    buf, sigma = _tables()
+    x, eh, z = rnd(6, 8, 8, 8, seed=110, scale=1.5), rnd(6, 8, 8, 8, seed=111), rnd(6, 8, 8, 8, seed=112)
+    t = torch.tensor([0, 1, 2, 500, 998, 999])
+    ref = D.p_sample_update(buf, x, t, eh, z)
+    tb = {k: buf[v].to(DEV) for k, v in (("c_recip", "sqrt_recip_alphas_cumprod"), ("c_recipm1", "sqrt_recipm1_alphas_cumprod"),
+                                         ("c1", "posterior_mean_coef1"), ("c2", "posterior_mean_coef2"))}
+    out = ops.p_sample_update_(x.to(DEV).clone(), eh.to(DEV), t.to(DEV), sigma=sigma.to(DEV), noise=z.to(DEV), **tb)
+    assert torch.equal(out.cpu(), ref)
+    assert torch.equal(out[0].cpu(), ref[0]) and (ref[0] - D.p_sample_update(buf, x, t, eh, 0 * z)[0]).abs().max() == 0  # t==0: no noise
+    # in-kernel Philox noise == oracle Philox + the same update
+    seed, stream = 0x1234567887654321, 5
+    out_p = ops.p_sample_update_(x.to(DEV).clone(), eh.to(DEV), torch.full((6,), 321, dtype=torch.long, device=DEV),
+                                 sigma=sigma.to(DEV), seed=seed, stream_id=stream, **tb)
+    zp = torch.from_numpy(philox_ref.philox_normal(x.numel(), seed, 321, stream)).reshape(x.shape)
+    ref_p = D.p_sample_update(buf, x, torch.full((6,), 321), eh, zp)
+    assert (out_p.cpu() - ref_p).abs().max() < 2e-6
+
+
+def test_randn_matches_philox_oracle(ops):
+    n = 4096 * 3 + 2
+    z = ops.randn((n,), DEV, seed=42, step=7, stream_id=1).cpu().numpy()
+    ref = philox_ref.philox_normal(n, 42, 7, 1)
+    assert np.abs(z - ref).max() < 2e-6
+    big = ops.randn((1 << 22,), DEV, seed=1, step=0).cpu().double()
+    assert abs(big.mean()) < 3e-3 and abs(big.std() - 1) < 3e-3
+
+
+def test_sq_err_sum(ops):
+    a, b = rnd(4, 8, 32, 32, seed=120), rnd(4, 8, 32, 32, seed=121)
+    out = ops.sq_err_sum(a.to(DEV), b.to(DEV)).cpu()
+    ref = ((a - b).double() ** 2).sum(dim=(1, 2, 3))
+    assert rel_err(out, ref) < 2e-6
