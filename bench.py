@@ -84,12 +84,26 @@ def time_conv_roofline(device):
                 algorithmic_hbm_gbps=bytes_alg / sec / 1e9)
 
 
+def usable_cores():
+    """Host cores this process may actually use: affinity mask capped by the cgroup CPU quota (a 1-GPU box
+    shows all 256 hardware threads in os.cpu_count() but grants a 16-core share)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, int(os.environ.get("DDK_CPU_THREADS", "32"))))
+
+
 def cpu_baseline(cfg, state_dict):
     """The CPU oracle (torch-CPU restatement, pinned to the reference by tests/golden) timed on the host cores:
     1 warm + 3 timed UNet steps of the cfg4 shape at a reduced batch, extrapolated to T=1000."""
     from oracle import unet_ref as U
     from utils import synthetic as syn
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
     bcpu = 8
     sd = {k[len("latent_model."):]: v.detach().cpu() for k, v in state_dict.items() if k.startswith("latent_model.")}

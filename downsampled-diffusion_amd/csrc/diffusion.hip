@@ -9,6 +9,10 @@
 // same eps_hat and noise the update is bit-identical to the torch expression.
 #include "ddk_internal.h"
 
+// hipcc contracts a*b+c into an FMA by default (-ffp-contract=fast), even through __fmul_rn/__fadd_rn; the
+// schedule arithmetic below must round every product like the reference's separate torch ops do, so this
+// file is compiled with -ffp-contract=off (see Makefile).
+
 namespace ddk {
 
 // ---- Philox4x32-10 (Salmon et al. SC'11; Random123 philox4x32_R(10)) -----------------------------

@@ -90,7 +90,8 @@ def test_dddpm_sample_and_decode():
     x_T, noise = injected((2, 8, 8, 8), "g4.dd", 50)
     z = m.p_sample_loop((2, 8, 8, 8), early_stop=950, x_T=x_T, noise=noise)
     assert np.abs(z.cpu().numpy() - g["dd_z"]).max() < 1e-4
-    x = m.rescaled_upsample(z)
+    with torch.no_grad():
+        x = m.rescaled_upsample(z)
     assert np.abs(x.cpu().numpy() - g["dd_x"]).max() < 1e-4
     from utils import fix_samples
     assert (np.round(fix_samples(x)) != np.round(g["dd_x_fixed"])).mean() < 2e-3
@@ -130,13 +131,13 @@ def test_philox_sampler_reproducible_and_sharded():
 
 
 def test_sample_api_shapes():
-    m = make_ddpm(32, 3, 16, T=20)
+    m = make_ddpm(32, 3, 16, T=100)
     torch.manual_seed(0)
     x = m.sample(3)
     assert x.shape == (3, 3, 16, 16) and torch.isfinite(x).all()
     torch.manual_seed(0)
     assert torch.equal(x, m.sample(3))        # reproducible under torch.manual_seed
-    assert m.sample(2, early_stop=19).shape == (2, 3, 16, 16)
+    assert m.sample(2, early_stop=99).shape == (2, 3, 16, 16)
 
 
 def test_losses_forward_no_grad():
