@@ -15,6 +15,8 @@
 // A second source pointer lets the up-path read (x, skip) without materialising the concat.  Small-M
 // layers (8x8, 4x4 latents) are split along k across workgroups into fp32 slabs and reduced by a second
 // tiny kernel in a fixed order, so results are run-to-run deterministic (no float atomics).
+#include <cstdlib>
+
 #include "ddk_internal.h"
 
 namespace ddk {
@@ -38,9 +40,25 @@ struct IgemmParams {
     int splits, kiters, kiters_per_split;
     long long slab_stride;
     int pre_mish, post_mish;
-    signed char dy[4][9];
-    signed char dx[4][9];
+    int debug;    // tuning only (DDK_DEBUG): 1 skip in-loop DMA, 2 skip barrier, 4 skip output stores
+    int tapmode;  // 0: single tap (1x1); 1: 3x3, (dy,dx) = (tap/3-1, tap%3-1); 2: transpose-conv phase taps (py-a, px-b)
 };
+
+// Input offset of a tap: pure scalar arithmetic on wave-uniform values (a lookup table in the kernel
+// arguments costs a dependent memory load per k-chunk in front of the staging loads).
+__device__ __forceinline__ void tap_offset(int tapmode, int phase, int tap, int& dy, int& dx) {
+    if (tapmode == 1) {
+        const int ty = (tap * 11) >> 5;  // tap / 3 for tap in 0..8
+        dy = ty - 1;
+        dx = tap - 3 * ty - 1;
+    } else if (tapmode == 2) {
+        dy = (phase >> 1) - (tap >> 1);
+        dx = (phase & 1) - (tap & 1);
+    } else {
+        dy = 0;
+        dx = 0;
+    }
+}
 
 constexpr int LDK = 36;  // LDS row pitch in floats (32 k + one 16-byte pad)
 
@@ -91,7 +109,8 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmParams p)
 
     float4 ra[A_PASS], rb[B_PASS];
     auto gload = [&]() {
-        const int dy = p.dy[phase][tap], dx = p.dx[phase][tap];
+        int dy, dx;
+        tap_offset(p.tapmode, phase, tap, dy, dx);
         const float* src;
         int cs, coff;
         if (cc < p.c0) {
@@ -206,6 +225,243 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmParams p)
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// LDS-DMA variant (used whenever no Mish has to be applied while staging): operand tiles go global -> LDS
+// directly with global_load_lds_dwordx4 (no VGPR staging, no ds_write), two stages, the DMA of chunk i+1 in
+// flight under the MFMAs of chunk i.  An LDS-DMA writes wave-base + lane*16, so a stage is the plain
+// [row][32 k] image (128-byte rows, 8 rows per wave-instruction) and bank conflicts are avoided by an XOR
+// swizzle applied to the per-lane SOURCE address: position p of row r holds k-chunk p ^ ((r >> 1) & 7), and the
+// fragment read applies the same involution.  Out-of-image taps (zero padding) and rows past M / N read a
+// 128-byte zero page instead, so every lane always loads and there is no branch in the staging code.
+//
+// The DMA is issued from inline asm on purpose: hipcc (ROCm 7.2) puts an s_waitcnt vmcnt(0) in front of the first
+// ds_read after a __builtin_amdgcn_global_load_lds (it cannot prove the DMA's target stage differs from the
+// stage being read), which would drain the prefetch before the MFMAs instead of under them.  With the asm form
+// the compiler does not see the load; the wait is placed by hand: vmcnt(0) + barrier at the top of each k-chunk,
+// which orders every wave's DMA into stage s before any wave's reads of stage s, and every wave's reads of
+// stage s^1 (finished: their MFMAs consumed them) before the next DMA into it.
+__device__ __attribute__((aligned(128))) float g_zero_page[32];
+
+// one 1-KiB piece: LDS[m0 + lane*16 .. +16) <- 16 bytes at this lane's global address
+__device__ __forceinline__ void lds_dma16(const float* g, unsigned lds_byte_addr) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_byte_addr), "v"(g) : "memory", "m0");
+}
+
+// STAGES = 2: the pieces of chunk k+1 are all issued right after the barrier of chunk k (small LDS footprint, so
+// 2-5 workgroups share a CU and cover each other's barrier / issue phases -- the faster choice measured);
+// STAGES = 3: chunk k+2 is issued piece by piece between the MFMAs of chunk k (one workgroup per CU).
+template <int BM, int BN, int WM, int WN, int STAGES>
+__global__ __launch_bounds__(WM* WN * 64) void igemm_dma_kernel(const IgemmParams p) {
+    constexpr int NW = WM * WN;
+    constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
+    constexpr int A_PW = BM / 8 / NW, B_PW = BN / 8 / NW;  // 1-KiB DMA pieces per wave per stage
+    constexpr int PW = A_PW + B_PW;
+    constexpr int STAGE = (BM + BN) * 32;                  // floats
+    constexpr int NMFMA = 16 * TM * TN;                    // MFMAs per wave per k-chunk
+    constexpr int PIECE_EVERY = (NMFMA / 2 / PW) > 0 ? (NMFMA / 2 / PW) : 1;  // pieces go out over the first half
+    static_assert(PW * PIECE_EVERY <= NMFMA, "not enough MFMA slots to issue the DMA pieces");
+    static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile rows must split into 8-row pieces per wave");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / WN, wn = wid % WN;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int phase = blockIdx.z / p.splits, split = blockIdx.z % p.splits;
+    const int prow = lane >> 3, ppos = lane & 7;
+    const int wid_u = __builtin_amdgcn_readfirstlane(wid);  // wave-uniform, lives in an SGPR (feeds m0)
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) float*)smem;
+
+    // ---- DMA bookkeeping: piece j of this wave covers tile rows (wid*PW + j)*8 + prow.
+    // Per lane and piece, computed once: the linear index of the pixel under the CENTRE tap, the swizzled
+    // k-chunk offset, and a bit mask of the taps that fall inside the image.  Per k-chunk the tap / channel
+    // offset is wave-uniform scalar arithmetic, so a piece costs a bit test, one 64-bit mad and a select.
+    // (Plain int arrays on purpose: a `cond ? ptrA[j] : ptrB[j]` select of two pointer arrays defeats SROA and
+    // sends the arrays to scratch, whose reloads wait vmcnt(0) and serialise the DMA.)
+    int a_pix[A_PW], a_sw[A_PW];
+    unsigned a_mask[A_PW];
+#pragma unroll
+    for (int j = 0; j < A_PW; ++j) {
+        const int r = (wid * A_PW + j) * 8 + prow;
+        const int gm = m0 + r;
+        const int xm = gm % p.Wm, tmp = gm / p.Wm;
+        const int ym = tmp % p.Hm, b = tmp / p.Hm;
+        const int iy0 = ym * p.in_stride, ix0 = xm * p.in_stride;
+        a_sw[j] = (ppos ^ ((r >> 1) & 7)) * 4;  // float offset of the k-chunk this lane fetches
+        a_pix[j] = (b * p.H + iy0) * p.W + ix0;
+        unsigned m = 0;
+        if (p.debug & 16) m = 0x1ffu;
+        else
+        for (int t = 0; t < p.ntaps; ++t) {
+            int dy, dx;
+            tap_offset(p.tapmode, phase, t, dy, dx);
+            if ((unsigned)(iy0 + dy) < (unsigned)p.H && (unsigned)(ix0 + dx) < (unsigned)p.W) m |= 1u << t;
+        }
+        a_mask[j] = gm < p.M ? m : 0u;
+    }
+    long long b_off[B_PW];
+    bool b_ok[B_PW];
+#pragma unroll
+    for (int j = 0; j < B_PW; ++j) {
+        const int r = (wid * B_PW + j) * 8 + prow;
+        const int n = n0 + r;
+        b_ok[j] = n < p.N;
+        b_off[j] = ((long long)(phase * p.N + (b_ok[j] ? n : 0)) * p.ntaps) * p.cin + (ppos ^ ((r >> 1) & 7)) * 4;
+    }
+    const float* zero = g_zero_page + ppos * 4;
+
+    const int it_begin = split * p.kiters_per_split;
+    const int it_end = min(p.kiters, it_begin + p.kiters_per_split);
+    const int cpt = p.cin >> 5;
+    int tap = it_begin / cpt, cc = (it_begin % cpt) << 5;
+
+    // wave-uniform state of the k-chunk whose pieces are being issued
+    const float* i_src = nullptr;
+    int i_cs = 0, i_coff = 0, i_dpix = 0, i_tap = 0;
+    long long i_woff = 0;
+    unsigned i_st = 0;
+    auto issue_begin = [&](int stage) {
+        int dy, dx;
+        tap_offset(p.tapmode, phase, tap, dy, dx);
+        const bool first = cc < p.c0;
+        i_src = first ? p.src0 : p.src1;
+        i_cs = first ? p.c0 : p.c1;
+        i_coff = first ? cc : cc - p.c0;
+        i_dpix = dy * p.W + dx;
+        i_woff = (long long)tap * p.cin + cc;
+        i_tap = tap;
+        i_st = lds_base + (unsigned)(stage * STAGE * 4);
+        cc += 32;
+        if (cc == p.cin) { cc = 0; ++tap; }
+    };
+    auto issue_piece = [&](int j) {  // j is a compile-time constant after unrolling
+        if (j < A_PW) {
+            const long long off = (long long)(a_pix[j] + i_dpix) * i_cs + (i_coff + a_sw[j]);
+            const float* g = ((a_mask[j] >> i_tap) & 1u) ? i_src + off : zero;
+            lds_dma16(g, i_st + (unsigned)((wid_u * A_PW + j) * 1024));
+        } else {
+            const int jb = j - A_PW;
+            const float* g = b_ok[jb] ? p.w + (b_off[jb] + i_woff) : zero;
+            lds_dma16(g, i_st + (unsigned)(BM * 128 + (wid_u * B_PW + jb) * 1024));
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // fragment addressing: row = tile base + (lane & 31); k-chunk 2q + (lane >> 5) sits at position chunk ^ f(row)
+    const int fsw = ((lane & 31) >> 1) & 7, fh = lane >> 5;
+    int foff[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) foff[q] = (lane & 31) * 32 + (((2 * q + fh) ^ fsw) << 2);
+    const int a_base = wm * TM * 32 * 32;
+    const int b_base = BM * 32 + wn * TN * 32 * 32;
+
+    // ---- ring of STAGES buffers: chunk k+STAGES-1 is DMA'd while chunk k is multiplied.
+    constexpr int AHEAD = STAGES - 1;
+    const int n_it = (p.debug & 8) ? 0 : it_end - it_begin;
+#pragma unroll
+    for (int pre = 0; pre < AHEAD; ++pre) {
+        if (pre < n_it) {
+            issue_begin(pre);
+#pragma unroll
+            for (int j = 0; j < PW; ++j) issue_piece(j);
+        }
+    }
+    int stage = 0;
+    for (int k = 0; k < n_it; ++k) {
+        // pieces of chunk k must have landed; with 3 stages those of chunk k+1 (the PW youngest) may stay in flight
+        if (STAGES == 3 && k + 1 < n_it) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!(p.debug & 2)) __syncthreads();  // everyone's pieces of chunk k landed; everyone finished reading chunk k-1's stage
+        const bool more = k + AHEAD < n_it && !(p.debug & 1);
+        int wr = stage + AHEAD;
+        if (wr >= STAGES) wr -= STAGES;
+        if (more) {
+            issue_begin(wr);
+            if (STAGES == 2) {
+#pragma unroll
+                for (int j = 0; j < PW; ++j) issue_piece(j);
+            }
+        }
+        const float* As = smem + stage * STAGE + a_base;
+        const float* Bs = smem + stage * STAGE + b_base;
+        float4 a[2][TM], b[2][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[0][i] = *reinterpret_cast<const float4*>(As + i * 1024 + foff[0]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[0][j] = *reinterpret_cast<const float4*>(Bs + j * 1024 + foff[0]);
+        int mf = 0;  // MFMA counter: folds to constants once the loops below are unrolled
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int cur = q & 1, nxt = cur ^ 1;
+            if (q < 3) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[nxt][i] = *reinterpret_cast<const float4*>(As + i * 1024 + foff[q + 1]);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[nxt][j] = *reinterpret_cast<const float4*>(Bs + j * 1024 + foff[q + 1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);  // keep the prefetch above the MFMAs (hipcc otherwise sinks it to first use)
+            // e outermost: consecutive MFMAs go to different accumulators (round-robin over the TM*TN tiles)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        const float av = e == 0 ? a[cur][i].x : e == 1 ? a[cur][i].y : e == 2 ? a[cur][i].z : a[cur][i].w;
+                        const float bv = e == 0 ? b[cur][j].x : e == 1 ? b[cur][j].y : e == 2 ? b[cur][j].z : b[cur][j].w;
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
+                        ++mf;
+                        if (STAGES == 3 && mf % PIECE_EVERY == 0 && mf / PIECE_EVERY <= PW) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (more) issue_piece(mf / PIECE_EVERY - 1);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+        }
+        stage = stage + 1 == STAGES ? 0 : stage + 1;
+    }
+
+    const bool direct = p.splits == 1;
+    float* outp = direct ? p.out : p.out + (long long)split * p.slab_stride;
+    const int py = phase >> 1, px = phase & 1;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const int gm = m0 + row;
+            if (gm >= p.M) continue;
+            long long opix = gm;
+            if (p.out_scale != 1) {
+                const int xm = gm % p.Wm, tmp = gm / p.Wm;
+                const int ym = tmp % p.Hm, b = tmp / p.Hm;
+                opix = ((long long)b * p.Ho + ym * p.out_scale + py) * p.Wo + xm * p.out_scale + px;
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int gn = n0 + (wn * TN + j) * 32 + (lane & 31);
+                if (gn >= p.N) continue;
+                float v = acc[i][j][r];
+                const long long o = opix * p.N + gn;
+                if (direct) {
+                    if (p.bias) v += p.bias[gn];
+                    if (p.resid) v += p.resid[o];
+                    if (p.post_mish) v = mish_f(v);
+                }
+                if (!(p.debug & 4)) outp[o] = v;
+            }
+        }
+    }
+}
+
 // out[i] = sum_s slab[s][i] (fixed order) + bias[i % N] + resid[i]
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slabs, int splits,
                                                             long long slab_stride, const float* __restrict__ bias,
@@ -267,7 +523,22 @@ static void tile_dims(TileId t, int& bm, int& bn) {
 // Pick the largest tile that still gives the 256 CUs about a full wave of workgroups; when even the
 // smallest does not, split k across workgroups (at least 4 k-chunks per split).
 static Choice choose_tile(long long M, int N, int nphase, int kiters) {
-    const long long target = 200;
+    // tuning knob for tools/conv_bench.py only: DDK_FORCE_TILE="<tile id>[,<splits>]"
+    if (const char* f = getenv("DDK_FORCE_TILE")) {
+        int t = 0, s = 1;
+        if (sscanf(f, "%d,%d", &t, &s) >= 1 && t >= 0 && t <= 4) {
+            int bm, bn;
+            tile_dims((TileId)t, bm, bn);
+            if (N % 32 == 0 && (bn <= N || bn == 32)) {
+                if (s < 1) s = 1;
+                if (s > kiters) s = kiters;
+                Choice c{(TileId)t, 1, kiters};
+                c.kps = (int)ceil_div(kiters, s);
+                c.splits = (int)ceil_div(kiters, c.kps);
+                return c;
+            }
+        }
+    }
     TileId order_wide[] = {T128x128, T128x64, T64x64};
     TileId order_n64[] = {T128x64, T64x64};
     TileId order_n32[] = {T128x32, T64x32};
@@ -276,28 +547,52 @@ static Choice choose_tile(long long M, int N, int nphase, int kiters) {
     if (N % 64 != 0) { order = order_n32; n_order = 2; }
     else if (N % 128 != 0 && N < 128) { order = order_n64; n_order = 2; }
     else { order = order_wide; n_order = 3; }
-    Choice c{order[n_order - 1], 1, kiters};
-    long long tiles = 0;
-    for (int i = 0; i < n_order; ++i) {
+    auto n_tiles = [&](TileId t) {
         int bm, bn;
-        tile_dims(order[i], bm, bn);
-        tiles = ceil_div(M, bm) * ceil_div(N, bn) * nphase;
-        if (tiles >= target || i == n_order - 1) { c.tile = order[i]; break; }
-    }
-    if (tiles < target) {
-        long long want = ceil_div(256, tiles);
-        long long max_by_k = kiters / 4 > 0 ? kiters / 4 : 1;
-        long long s = want < max_by_k ? want : max_by_k;
-        if (s > 16) s = 16;
-        if (s < 1) s = 1;
+        tile_dims(t, bm, bn);
+        return ceil_div(M, bm) * ceil_div(N, bn) * nphase;
+    };
+    auto with_splits = [&](TileId t, long long s) {
+        Choice c{t, 1, kiters};
         c.kps = (int)ceil_div(kiters, s);
         c.splits = (int)ceil_div(kiters, c.kps);
+        return c;
+    };
+    // Rules fitted to tools/conv_bench.py sweeps on MI355X (profiles/r01_conv_sweep.txt).  The kernel runs best
+    // with 2+ workgroups per CU (~512 workgroups) and at least ~18 k-chunks per workgroup:
+    // 1. short contractions (1x1 convs, <= 8 k-chunks): smallest tile, no split -- prologue/epilogue bound;
+    if (kiters <= 8) return with_splits(order[n_order - 1], 1);
+    // 2. the largest tile that gives >= 512 workgroups without splitting k;
+    for (int i = 0; i < n_order; ++i)
+        if (n_tiles(order[i]) >= 512) return with_splits(order[i], 1);
+    // 3. else the largest tile that reaches ~512 workgroups by splitting k with >= 18 chunks left per workgroup;
+    for (int i = 0; i < n_order; ++i) {
+        long long s = 1;
+        while (n_tiles(order[i]) * s < 512 && s < 16) s *= 2;
+        if (kiters / s >= 18) return with_splits(order[i], s);
     }
-    return c;
+    // 4. else the smallest tile with the deepest split that keeps >= 9 chunks per workgroup.
+    long long s = 16;
+    while (s > 1 && (kiters / s < 9 || n_tiles(order[n_order - 1]) * s > 1024)) s /= 2;
+    return with_splits(order[n_order - 1], s);
 }
 
 template <int BM, int BN, int WM, int WN>
 static int launch_tile(const IgemmParams& p, hipStream_t st) {
+    static const bool no_dma = getenv("DDK_NO_DMA") != nullptr;  // A/B knob for tools/conv_bench.py
+    dim3 grid((unsigned)ceil_div(p.M, BM), (unsigned)ceil_div(p.N, BN), (unsigned)(p.nphase * p.splits));
+    if (!p.pre_mish && !no_dma) {
+        constexpr int STAGES = 2;
+        constexpr size_t lds = STAGES * (size_t)(BM + BN) * 32 * sizeof(float);
+        static bool attr_set = false;
+        if (!attr_set) {
+            DDK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_dma_kernel<BM, BN, WM, WN, STAGES>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, STAGES>), grid, dim3(WM * WN * 64), lds, st, p);
+        return check_launch("igemm_dma_kernel");
+    }
     constexpr size_t lds = 2 * (size_t)(BM + BN) * LDK * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
@@ -305,7 +600,6 @@ static int launch_tile(const IgemmParams& p, hipStream_t st) {
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    dim3 grid((unsigned)ceil_div(p.M, BM), (unsigned)ceil_div(p.N, BN), (unsigned)(p.nphase * p.splits));
     hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN>), grid, dim3(WM * WN * 64), lds, st, p);
     return check_launch("igemm_kernel");
 }
@@ -343,17 +637,13 @@ int conv_forward(const ddk_conv_args& a, hipStream_t st) {
     p.ntaps = g.ntaps; p.nphase = g.nphase;
     p.kiters = g.ntaps * (p.cin / 32);
     p.pre_mish = a.pre_mish;
+    {
+        static const int dbg = getenv("DDK_DEBUG") ? atoi(getenv("DDK_DEBUG")) : 0;
+        p.debug = dbg;
+    }
     p.post_mish = a.post_mish;
     p.slab_stride = (long long)a.B * g.Ho * g.Wo * a.N;
-    if (a.kind == DDK_CONV3X3_S1 || a.kind == DDK_CONV3X3_S2) {
-        for (int t = 0; t < 9; ++t) { p.dy[0][t] = (signed char)(t / 3 - 1); p.dx[0][t] = (signed char)(t % 3 - 1); }
-    } else if (a.kind == DDK_CONVT4X4_S2) {
-        for (int ph = 0; ph < 4; ++ph)
-            for (int t = 0; t < 4; ++t) {
-                p.dy[ph][t] = (signed char)((ph >> 1) - (t >> 1));
-                p.dx[ph][t] = (signed char)((ph & 1) - (t & 1));
-            }
-    }
+    p.tapmode = (a.kind == DDK_CONV1X1) ? 0 : (a.kind == DDK_CONVT4X4_S2 ? 2 : 1);
     const Choice c = choose_tile(p.M, p.N, p.nphase, p.kiters);
     p.splits = c.splits;
     p.kiters_per_split = c.kps;
