@@ -645,6 +645,16 @@ int conv_forward(const ddk_conv_args& a, hipStream_t st) {
     p.slab_stride = (long long)a.B * g.Ho * g.Wo * a.N;
     p.tapmode = (a.kind == DDK_CONV1X1) ? 0 : (a.kind == DDK_CONVT4X4_S2 ? 2 : 1);
     const Choice c = choose_tile(p.M, p.N, p.nphase, p.kiters);
+    {
+        static const bool trace = getenv("DDK_TRACE") != nullptr;  // tuning aid: one line per conv launch
+        if (trace) {
+            int bm, bn;
+            tile_dims(c.tile, bm, bn);
+            fprintf(stderr, "[ddk] conv kind=%d B=%d %dx%d cin=%d N=%d M=%d kiters=%d -> tile %dx%d splits=%d (kps %d) wgs=%lld\n", a.kind,
+                    a.B, a.H, a.W, p.cin, p.N, p.M, p.kiters, bm, bn, c.splits, c.kps,
+                    ceil_div(p.M, bm) * ceil_div(p.N, bn) * p.nphase * c.splits);
+        }
+    }
     p.splits = c.splits;
     p.kiters_per_split = c.kps;
     float* final_out = a.out;
@@ -666,7 +676,7 @@ int conv_forward(const ddk_conv_args& a, hipStream_t st) {
         default: rc = launch_tile<64, 32, 2, 1>(p, st); break;
     }
     DDK_TRY(rc);
-    if (c.splits > 1) {
+    if (c.splits > 1 && !a.defer_reduce) {
         const long long n4 = p.slab_stride / 4;
         const int blocks = (int)(ceil_div(n4, 256) < 2048 ? ceil_div(n4, 256) : 2048);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, static_cast<const float*>(a.workspace),
@@ -674,6 +684,12 @@ int conv_forward(const ddk_conv_args& a, hipStream_t st) {
         DDK_TRY(check_launch("splitk_reduce_kernel"));
     }
     return DDK_OK;
+}
+
+int conv_splits(int kind, int B, int H, int W, int cin, int N) {
+    Geometry g;
+    if (!conv_geometry(kind, H, W, g) || cin <= 0 || cin % 32) return 1;
+    return choose_tile((long long)B * g.Hm * g.Wm, N, g.nphase, g.ntaps * (cin / 32)).splits;
 }
 
 double conv_flops(int kind, int B, int H, int W, int cin, int N) {
@@ -687,6 +703,8 @@ double conv_flops(int kind, int B, int H, int W, int cin, int N) {
 extern "C" size_t ddk_conv_workspace_bytes(int kind, int B, int H, int W, int cin, int N) {
     return ddk::conv_workspace_bytes(kind, B, H, W, cin, N);
 }
+
+extern "C" int ddk_conv_splits(int kind, int B, int H, int W, int cin, int N) { return ddk::conv_splits(kind, B, H, W, cin, N); }
 
 extern "C" int ddk_conv_forward(const ddk_conv_args* a, ddk_stream_t s) {
     if (!a) return ddk::fail_arg("conv: null args");

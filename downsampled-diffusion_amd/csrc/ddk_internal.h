@@ -102,12 +102,16 @@ __device__ __forceinline__ float block_max(float v, float* red) {
 // conv_igemm.hip
 size_t conv_workspace_bytes(int kind, int B, int H, int W, int cin, int N);
 int conv_forward(const ddk_conv_args& a, hipStream_t st);
+int conv_splits(int kind, int B, int H, int W, int cin, int N);
 double conv_flops(int kind, int B, int H, int W, int cin, int N);
 // norm_act.hip
 size_t groupnorm_workspace_bytes(int B, int HW, int C, int groups);
 int groupnorm_mish(const float* x, const float* gamma, const float* beta, const float* temb, int temb_stride,
                    const float* addend, float* out, int B, int HW, int C, int groups, float eps, void* ws, size_t ws_bytes,
                    hipStream_t st);
+int groupnorm_mish_ex(const float* x, int nslab, long long slab_stride, const float* cbias, const float* gamma,
+                      const float* beta, const float* temb, int temb_stride, const float* addend, float* out, int B, int HW, int C,
+                      int groups, float eps, void* ws, size_t ws_bytes, hipStream_t st);
 int chan_layernorm(const float* x, const float* g, const float* b, float* out, long long M, int C, float eps, hipStream_t st);
 int unary(int op, const float* x, float* out, long long n, hipStream_t st);
 int add(const float* a, const float* b, float* out, long long n, hipStream_t st);

@@ -11,14 +11,18 @@ namespace ddk {
 
 // ------------------------------------------------------------------------------------------------
 // GroupNorm(groups, eps, affine) -> Mish -> (+ temb[b][c]) -> (+ addend), NHWC.
-// One workgroup per (b, group): the group's HW x cpg slab (<= 256 * 4 * VPT floats) is read once into
-// registers, mean and biased variance are two block reductions over the registers (two-pass, like
+// One workgroup of NT threads per (b, group): the group's HW x cpg slab (<= NT * 4 * VPT floats) is read once
+// into registers, mean and biased variance are two block reductions over the registers (two-pass, like
 // torch's native_group_norm), and the result is written once.
-template <int VPT>
-__global__ __launch_bounds__(256) void gn_mish_resident_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
-                                                               const float* __restrict__ beta, const float* __restrict__ temb,
-                                                               int temb_stride, const float* __restrict__ addend,
-                                                               float* __restrict__ out, int HW, int C, int groups, float eps) {
+// The input may still be in split-K form: `nslab` fp32 slabs (stride `slab_stride`) whose fixed-order sum plus
+// the conv bias `cbias` is the tensor -- the conv's reduce pass is then folded into this load (no extra
+// kernel, no extra round trip).
+template <int VPT, int NT>
+__global__ __launch_bounds__(NT) void gn_mish_resident_kernel(const float* __restrict__ x, int nslab, long long slab_stride,
+                                                              const float* __restrict__ cbias, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, const float* __restrict__ temb,
+                                                              int temb_stride, const float* __restrict__ addend,
+                                                              float* __restrict__ out, int HW, int C, int groups, float eps) {
     __shared__ float red[32];
     const int b = blockIdx.x / groups, g = blockIdx.x % groups;
     const int cpg = C / groups;
@@ -30,11 +34,21 @@ __global__ __launch_bounds__(256) void gn_mish_resident_kernel(const float* __re
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < VPT; ++i) {
-        const int u = threadIdx.x + i * 256;
+        const int u = threadIdx.x + i * NT;
         if (u < units) {
             const int row = u / upr, cu = u - row * upr;
-            v[i] = *reinterpret_cast<const float4*>(x + base + (long long)row * C + cu * 4);
-            s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+            const long long o = base + (long long)row * C + cu * 4;
+            float4 a = *reinterpret_cast<const float4*>(x + o);
+            for (int k = 1; k < nslab; ++k) {
+                const float4 t = *reinterpret_cast<const float4*>(x + k * slab_stride + o);
+                a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
+            }
+            if (cbias) {
+                const float4 t = *reinterpret_cast<const float4*>(cbias + g * cpg + cu * 4);
+                a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
+            }
+            v[i] = a;
+            s += (a.x + a.y) + (a.z + a.w);
         } else {
             v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
@@ -44,7 +58,7 @@ __global__ __launch_bounds__(256) void gn_mish_resident_kernel(const float* __re
     float q = 0.f;
 #pragma unroll
     for (int i = 0; i < VPT; ++i) {
-        const int u = threadIdx.x + i * 256;
+        const int u = threadIdx.x + i * NT;
         if (u < units) {
             const float a = v[i].x - mean, bb = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
             q += (a * a + bb * bb) + (c * c + d * d);
@@ -54,7 +68,7 @@ __global__ __launch_bounds__(256) void gn_mish_resident_kernel(const float* __re
     const float rstd = 1.0f / sqrtf(var + eps);
 #pragma unroll
     for (int i = 0; i < VPT; ++i) {
-        const int u = threadIdx.x + i * 256;
+        const int u = threadIdx.x + i * NT;
         if (u < units) {
             const int row = u / upr, cu = u - row * upr;
             const int c0 = g * cpg + cu * 4;
@@ -172,32 +186,35 @@ size_t groupnorm_workspace_bytes(int B, int HW, int C, int groups) {
     return (size_t)B * groups * ns * 3 * sizeof(float);
 }
 
-int groupnorm_mish(const float* x, const float* gamma, const float* beta, const float* temb, int temb_stride,
-                   const float* addend, float* out, int B, int HW, int C, int groups, float eps, void* ws, size_t ws_bytes,
-                   hipStream_t st) {
+int groupnorm_mish_ex(const float* x, int nslab, long long slab_stride, const float* cbias, const float* gamma,
+                      const float* beta, const float* temb, int temb_stride, const float* addend, float* out, int B, int HW, int C,
+                      int groups, float eps, void* ws, size_t ws_bytes, hipStream_t st) {
     DDK_REQUIRE(x && gamma && beta && out, "groupnorm: null pointer");
     DDK_REQUIRE(B > 0 && HW > 0 && groups > 0 && C % groups == 0 && (C / groups) % 4 == 0,
                 "groupnorm: C/groups must be a multiple of 4");
-    DDK_REQUIRE(aligned16(x) && aligned16(out) && aligned16(gamma) && aligned16(beta) && aligned16(temb) && aligned16(addend),
+    DDK_REQUIRE(aligned16(x) && aligned16(out) && aligned16(gamma) && aligned16(beta) && aligned16(temb) && aligned16(addend) &&
+                    aligned16(cbias),
                 "groupnorm: alignment");
     DDK_REQUIRE(temb == nullptr || temb_stride % 4 == 0, "groupnorm: temb_stride % 4");
+    DDK_REQUIRE(nslab >= 1 && (nslab == 1 || slab_stride % 4 == 0), "groupnorm: slabs");
     const int cpg = C / groups;
     const int ns = gn_nsplit(HW, cpg);
     if (ns == 0) {
         const int units = HW * (cpg / 4);
-        const int vpt = (int)ceil_div(units, 256);
-        dim3 grid(B * groups), block(256);
-#define GN_CASE(V)                                                                                                        \
-    hipLaunchKernelGGL((gn_mish_resident_kernel<V>), grid, block, 0, st, x, gamma, beta, temb, temb_stride, addend, out, \
-                       HW, C, groups, eps)
-        if (vpt <= 1) GN_CASE(1);
-        else if (vpt <= 2) GN_CASE(2);
-        else if (vpt <= 4) GN_CASE(4);
-        else if (vpt <= 8) GN_CASE(8);
-        else GN_CASE(16);
+        dim3 grid(B * groups);
+#define GN_CASE(V, NT)                                                                                                  \
+    hipLaunchKernelGGL((gn_mish_resident_kernel<V, NT>), grid, dim3(NT), 0, st, x, nslab, slab_stride, cbias, gamma, beta, temb, \
+                       temb_stride, addend, out, HW, C, groups, eps)
+        // big slabs: 1024 threads (16 waves per CU keep enough loads in flight); small ones: 256
+        if (units <= 256) GN_CASE(1, 256);
+        else if (units <= 512) GN_CASE(2, 256);
+        else if (units <= 1024) GN_CASE(1, 1024);
+        else if (units <= 2048) GN_CASE(2, 1024);
+        else GN_CASE(4, 1024);
 #undef GN_CASE
         return check_launch("gn_mish_resident_kernel");
     }
+    DDK_REQUIRE(nslab == 1 && cbias == nullptr, "groupnorm: split-K input is only supported on the register-resident path");
     const size_t need = (size_t)B * groups * ns * 3 * sizeof(float);
     if (!ws || ws_bytes < need) {
         set_error("groupnorm: workspace too small (%zu < %zu)", ws_bytes, need);
@@ -211,6 +228,12 @@ int groupnorm_mish(const float* x, const float* gamma, const float* beta, const 
     hipLaunchKernelGGL(gn_apply_kernel, dim3(blocks), dim3(256), 0, st, x, part, ns, gamma, beta, temb, temb_stride, addend, out,
                        HW, C, groups, eps, total4);
     return check_launch("gn_apply_kernel");
+}
+
+int groupnorm_mish(const float* x, const float* gamma, const float* beta, const float* temb, int temb_stride,
+                   const float* addend, float* out, int B, int HW, int C, int groups, float eps, void* ws, size_t ws_bytes,
+                   hipStream_t st) {
+    return groupnorm_mish_ex(x, 1, 0, nullptr, gamma, beta, temb, temb_stride, addend, out, B, HW, C, groups, eps, ws, ws_bytes, st);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -394,6 +417,12 @@ int ddk_groupnorm_mish(const float* x, const float* gamma, const float* beta, co
                                ddk::as_stream(s));
 }
 size_t ddk_groupnorm_workspace_bytes(int B, int HW, int C, int groups) { return ddk::groupnorm_workspace_bytes(B, HW, C, groups); }
+int ddk_groupnorm_mish_slabs(const float* slabs, int nslab, long long slab_stride, const float* conv_bias, const float* gamma,
+                             const float* beta, const float* temb, int temb_stride, const float* addend, float* out, int B, int HW,
+                             int C, int groups, float eps, ddk_stream_t s) {
+    return ddk::groupnorm_mish_ex(slabs, nslab, slab_stride, conv_bias, gamma, beta, temb, temb_stride, addend, out, B, HW, C, groups,
+                                  eps, nullptr, 0, ddk::as_stream(s));
+}
 int ddk_chan_layernorm(const float* x, const float* g, const float* b, float* out, long long M, int C, float eps, ddk_stream_t s) {
     return ddk::chan_layernorm(x, g, b, out, M, C, eps, ddk::as_stream(s));
 }

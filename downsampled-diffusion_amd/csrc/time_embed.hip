@@ -10,32 +10,71 @@
 
 namespace ddk {
 
+// One workgroup per sample.  Both matrix-vector products split k over thread groups so that every thread
+// streams a short run of independent 16-byte weight loads (a single thread walking a whole 128..512-long
+// column is a chain of dependent-latency loads: 80 us instead of a few).
 __global__ __launch_bounds__(256) void time_mlp_kernel(const int64_t* __restrict__ t, const float* __restrict__ freqs,
                                                        const float* __restrict__ w1t, const float* __restrict__ b1,
                                                        const float* __restrict__ w2t, const float* __restrict__ b2,
                                                        float* __restrict__ act, float* __restrict__ raw, int dim) {
-    extern __shared__ float sm[];
-    float* e = sm;          // [dim]
-    float* h1 = sm + dim;   // [4 dim]
-    const int b = blockIdx.x, half = dim >> 1, hid = dim * 4;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* e = sm;              // [dim]
+    float* h1 = sm + dim;       // [4 dim]
+    float* part = sm + 5 * dim; // [2048] partial sums
+    const int b = blockIdx.x, half = dim >> 1, hid = dim * 4, tid = threadIdx.x;
     const float tf = (float)t[b];  // int64 * fp32 promotes to fp32 in torch (blocks.py:27)
-    for (int j = threadIdx.x; j < dim; j += blockDim.x) {
+    for (int j = tid; j < dim; j += 256) {
         const float a = tf * freqs[j < half ? j : j - half];
         e[j] = j < half ? sinf(a) : cosf(a);
     }
     __syncthreads();
-    for (int j = threadIdx.x; j < hid; j += blockDim.x) {
-        float s = 0.f;
-        for (int k = 0; k < dim; ++k) s += e[k] * w1t[(long long)k * hid + j];
-        h1[j] = mish_f(s + b1[j]);
+    {   // h1 = Mish(W1 e + b1): thread = (k-group, 8 consecutive outputs)
+        const int nj = hid >> 3, nkg = 256 / nj, kper = (dim + nkg - 1) / nkg;
+        const int kg = tid / nj, jl = tid - kg * nj;
+        float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (kg < nkg) {
+            const int k1 = min(dim, (kg + 1) * kper);
+#pragma unroll 4
+            for (int k = kg * kper; k < k1; ++k) {
+                const float4 u = *reinterpret_cast<const float4*>(w1t + (long long)k * hid + jl * 8);
+                const float4 v = *reinterpret_cast<const float4*>(w1t + (long long)k * hid + jl * 8 + 4);
+                const float ek = e[k];
+                s[0] += ek * u.x; s[1] += ek * u.y; s[2] += ek * u.z; s[3] += ek * u.w;
+                s[4] += ek * v.x; s[5] += ek * v.y; s[6] += ek * v.z; s[7] += ek * v.w;
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) part[kg * hid + jl * 8 + i] = s[i];
+        }
+        __syncthreads();
+        for (int j = tid; j < hid; j += 256) {
+            float a = b1[j];
+            for (int g = 0; g < nkg; ++g) a += part[g * hid + j];
+            h1[j] = mish_f(a);
+        }
+        __syncthreads();
     }
-    __syncthreads();
-    for (int i = threadIdx.x; i < dim; i += blockDim.x) {
-        float s = 0.f;
-        for (int j = 0; j < hid; ++j) s += h1[j] * w2t[(long long)j * dim + i];
-        s += b2[i];
-        if (raw) raw[(long long)b * dim + i] = s;
-        act[(long long)b * dim + i] = mish_f(s);
+    {   // tv = W2 h1 + b2: thread = (k-group, 4 consecutive outputs)
+        const int ni = dim >> 2, nkg = 256 / ni, kper = (hid + nkg - 1) / nkg;
+        const int kg = tid / ni, il = tid - kg * ni;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        if (kg < nkg) {
+            const int k1 = min(hid, (kg + 1) * kper);
+#pragma unroll 8
+            for (int k = kg * kper; k < k1; ++k) {
+                const float4 u = *reinterpret_cast<const float4*>(w2t + (long long)k * dim + il * 4);
+                const float hk = h1[k];
+                s0 += hk * u.x; s1 += hk * u.y; s2 += hk * u.z; s3 += hk * u.w;
+            }
+            float* pp = part + kg * dim + il * 4;
+            pp[0] = s0; pp[1] = s1; pp[2] = s2; pp[3] = s3;
+        }
+        __syncthreads();
+        for (int i = tid; i < dim; i += 256) {
+            float a = b2[i];
+            for (int g = 0; g < nkg; ++g) a += part[g * dim + i];
+            if (raw) raw[(long long)b * dim + i] = a;
+            act[(long long)b * dim + i] = mish_f(a);
+        }
     }
 }
 
@@ -68,9 +107,10 @@ __global__ __launch_bounds__(256) void time_proj_kernel(const float* __restrict_
 int time_mlp(const int64_t* t, const float* freqs, const float* w1t, const float* b1, const float* w2t, const float* b2,
              float* act, float* raw, int B, int dim, hipStream_t st) {
     DDK_REQUIRE(t && freqs && w1t && b1 && w2t && b2 && act, "time_mlp: null pointer");
-    DDK_REQUIRE(B > 0 && dim > 0 && dim % 2 == 0 && dim <= 2048, "time_mlp: B / dim");
-    hipLaunchKernelGGL(time_mlp_kernel, dim3(B), dim3(256), (size_t)dim * 5 * sizeof(float), st, t, freqs, w1t, b1, w2t, b2, act,
-                       raw, dim);
+    DDK_REQUIRE(B > 0 && dim >= 8 && dim % 8 == 0 && dim <= 512, "time_mlp: dim (= unet_chan) must be a multiple of 8, <= 512");
+    DDK_REQUIRE(aligned16(w1t) && aligned16(w2t), "time_mlp: weight alignment");
+    hipLaunchKernelGGL(time_mlp_kernel, dim3(B), dim3(256), ((size_t)dim * 5 + 2048) * sizeof(float), st, t, freqs, w1t, b1, w2t,
+                       b2, act, raw, dim);
     return check_launch("time_mlp_kernel");
 }
 

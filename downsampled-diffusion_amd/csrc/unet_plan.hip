@@ -144,8 +144,9 @@ static int total_temb(const ddk_unet& u) {
 }
 
 extern "C" ddk_unet* ddk_unet_create(const ddk_unet_config* cfg) {
-    if (!cfg || cfg->n_levels < 1 || cfg->n_levels > 8 || cfg->in_ch < 1 || cfg->chan < 32 || cfg->chan % 32) {
-        set_error("unet_create: need 1 <= n_levels <= 8, in_ch >= 1, unet_chan a positive multiple of 32");
+    if (!cfg || cfg->n_levels < 1 || cfg->n_levels > 8 || cfg->in_ch < 1 || cfg->chan < 32 || cfg->chan % 32 ||
+        cfg->chan > 512) {
+        set_error("unet_create: need 1 <= n_levels <= 8, in_ch >= 1, unet_chan a multiple of 32 in [32, 512]");
         return nullptr;
     }
     for (int i = 0; i < cfg->n_levels; ++i)
@@ -342,9 +343,36 @@ static int run_conv(Ctx& c, int kind, const ConvW& cw, const float* src0, int c0
     a.B = c.B; a.H = H; a.W = W; a.N = N;
     a.pre_mish = 0;
     a.post_mish = 0;
+    a.defer_reduce = 0;
     a.workspace = c.W + c.ly.off_splitk;
     a.workspace_bytes = c.ly.splitk * sizeof(float);
     return conv_forward(a, c.st);
+}
+
+// conv3x3 -> GroupNorm+Mish(+shift)(+residual).  When the conv splits k, its slabs stay in the workspace and the
+// GroupNorm kernel sums them (plus the conv bias) while loading: one kernel and one HBM round trip fewer.
+static int run_conv_gn(Ctx& c, const ConvW& cw, const float* src0, int c0, const float* src1, int c1, float* raw, const NormW& n,
+                       const float* temb, const float* addend, float* out, int H, int W, int N) {
+    const int splits = conv_splits(DDK_CONV3X3_S1, c.B, H, W, c0 + c1, N);
+    const bool resident = groupnorm_workspace_bytes(c.B, H * W, N, GROUPS) == 0;
+    if (splits > 1 && resident) {
+        ddk_conv_args a{};
+        a.kind = DDK_CONV3X3_S1;
+        a.src0 = src0; a.src1 = src1; a.c0 = c0; a.c1 = c1;
+        a.weight = c.P + cw.w;
+        a.out = raw;  // unused: the slabs are the result
+        a.B = c.B; a.H = H; a.W = W; a.N = N;
+        a.defer_reduce = 1;
+        a.workspace = c.W + c.ly.off_splitk;
+        a.workspace_bytes = c.ly.splitk * sizeof(float);
+        DDK_TRY(conv_forward(a, c.st));
+        return groupnorm_mish_ex(c.W + c.ly.off_splitk, splits, (long long)c.B * H * W * N, cw.has_bias ? c.P + cw.b : nullptr,
+                                 c.P + n.g, c.P + n.b, temb, c.u.temb_total, addend, out, c.B, H * W, N, GROUPS, GN_EPS, nullptr, 0,
+                                 c.st);
+    }
+    DDK_TRY(run_conv(c, DDK_CONV3X3_S1, cw, src0, c0, src1, c1, nullptr, raw, H, W, N));
+    return groupnorm_mish(raw, c.P + n.g, c.P + n.b, temb, c.u.temb_total, addend, out, c.B, H * W, N, GROUPS, GN_EPS,
+                          c.W + c.ly.off_gn, c.ly.gn_ws * sizeof(float), c.st);
 }
 
 static int run_gn(Ctx& c, const float* x, const NormW& n, const float* temb, const float* addend, float* out, int HW, int C) {
@@ -358,15 +386,14 @@ static int run_res(Ctx& c, const ResW& r, const float* src0, int c0, const float
     float* a1 = c.W + c.ly.off_a1;
     float* res = c.W + c.ly.off_res;
     const int HW = H * W;
-    DDK_TRY(run_conv(c, DDK_CONV3X3_S1, r.c1, src0, c0, src1, c1, nullptr, raw, H, W, r.co));
-    DDK_TRY(run_gn(c, raw, r.n1, c.temb + r.temb_off, nullptr, a1, HW, r.co));
-    DDK_TRY(run_conv(c, DDK_CONV3X3_S1, r.c2, a1, r.co, nullptr, 0, nullptr, raw, H, W, r.co));
+    // the 1x1 skip first: the second conv's split-K slabs and the skip conv's would otherwise share the workspace
     const float* addend = src0;
     if (r.has_res) {
         DDK_TRY(run_conv(c, DDK_CONV1X1, r.res, src0, c0, src1, c1, nullptr, res, H, W, r.co));
         addend = res;
     }
-    return run_gn(c, raw, r.n2, nullptr, addend, out, HW, r.co);
+    DDK_TRY(run_conv_gn(c, r.c1, src0, c0, src1, c1, raw, r.n1, c.temb + r.temb_off, nullptr, a1, H, W, r.co));
+    return run_conv_gn(c, r.c2, a1, r.co, nullptr, 0, raw, r.n2, nullptr, addend, out, H, W, r.co);
 }
 
 // blocks.py:8-14,63-71,126-134: out = to_out(attn(to_qkv(LN(x)))) + x
@@ -432,8 +459,7 @@ static int forward_core(const ddk_unet& u, const float* P, const float* xpad, co
     // final_conv: Block(dim, dim) then 1x1 to in_ch (unet.py:69-72)
     float* raw = ws + ly.off_raw;
     float* a1 = ws + ly.off_a1;
-    DDK_TRY(run_conv(c, DDK_CONV3X3_S1, u.final_conv, cur, cur_c, nullptr, 0, nullptr, raw, H, W, u.cfg.chan));
-    DDK_TRY(run_gn(c, raw, u.final_norm, nullptr, nullptr, a1, H * W, u.cfg.chan));
+    DDK_TRY(run_conv_gn(c, u.final_conv, cur, cur_c, nullptr, 0, raw, u.final_norm, nullptr, nullptr, a1, H, W, u.cfg.chan));
     return conv1x1_small_n(a1, P + u.final_w, P + u.final_b, out, (long long)B * H * W, u.cfg.chan, u.cfg.in_ch, st);
 }
 

@@ -21,7 +21,7 @@ class ConvArgs(C.Structure):
     _fields_ = [
         ("kind", C.c_int), ("src0", C.c_void_p), ("src1", C.c_void_p), ("c0", C.c_int), ("c1", C.c_int),
         ("weight", C.c_void_p), ("bias", C.c_void_p), ("resid", C.c_void_p), ("out", C.c_void_p),
-        ("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("N", C.c_int), ("pre_mish", C.c_int), ("post_mish", C.c_int),
+        ("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("N", C.c_int), ("pre_mish", C.c_int), ("post_mish", C.c_int), ("defer_reduce", C.c_int),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
     ]
 
@@ -54,9 +54,11 @@ SIGNATURES = {
     "ddk_pack_convT_weight": (_I, [_P, _P, _I, _I, _P]),
     "ddk_pack_linear_T": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "ddk_conv_workspace_bytes": (_SZ, [_I, _I, _I, _I, _I, _I]),
+    "ddk_conv_splits": (_I, [_I, _I, _I, _I, _I, _I]),
     "ddk_conv_forward": (_I, [C.POINTER(ConvArgs), _P]),
     "ddk_groupnorm_mish": (_I, [_P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _F, _P, _SZ, _P]),
     "ddk_groupnorm_workspace_bytes": (_SZ, [_I, _I, _I, _I]),
+    "ddk_groupnorm_mish_slabs": (_I, [_P, _I, _LL, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _F, _P]),
     "ddk_chan_layernorm": (_I, [_P, _P, _P, _P, _LL, _I, _F, _P]),
     "ddk_mish": (_I, [_P, _P, _LL, _P]),
     "ddk_tanh": (_I, [_P, _P, _LL, _P]),

@@ -83,8 +83,31 @@ def conv(kind, x, w_packed, bias=None, n_out=None, x2=None, resid=None, pre_mish
     ws_bytes = lib.ddk_conv_workspace_bytes(kind, b, h, w_, c0 + c1, n)
     ws = torch.empty(max(ws_bytes, 16) // 4, device=x.device, dtype=torch.float32) if ws_bytes else None
     a = L.ConvArgs(kind, L.ptr(_f32(x)), L.ptr(x2), c0, c1, L.ptr(w_packed), L.ptr(bias), L.ptr(resid), L.ptr(out),
-                   b, h, w_, n, int(pre_mish), int(post_mish), L.ptr(ws), ws_bytes)
+                   b, h, w_, n, int(pre_mish), int(post_mish), 0, L.ptr(ws), ws_bytes)
     L.check(lib.ddk_conv_forward(C.byref(a), L.stream()), "conv_forward")
+    return out
+
+
+def conv3x3_groupnorm_mish(x, w_packed, bias, gamma, beta, x2=None, temb=None, addend=None, groups=GN_GROUPS, eps=GN_EPS):
+    """conv3x3(pad 1) -> GroupNorm -> Mish (+temb)(+addend).  When the conv splits k its partial slabs are summed by the
+    GroupNorm kernel's load (ddk_groupnorm_mish_slabs) instead of a separate reduce pass."""
+    b, h, w_, c0 = x.shape
+    c1 = 0 if x2 is None else x2.shape[-1]
+    n = w_packed.shape[0]
+    lib = L.load()
+    splits = lib.ddk_conv_splits(CONV3X3_S1, b, h, w_, c0 + c1, n)
+    if splits == 1 or lib.ddk_groupnorm_workspace_bytes(b, h * w_, n, groups) != 0:
+        return groupnorm_mish(conv(CONV3X3_S1, x, w_packed, bias, x2=x2), gamma, beta, temb=temb, addend=addend, groups=groups, eps=eps)
+    ws_bytes = lib.ddk_conv_workspace_bytes(CONV3X3_S1, b, h, w_, c0 + c1, n)
+    ws = torch.empty(ws_bytes // 4, device=x.device, dtype=torch.float32)
+    out = torch.empty((b, h, w_, n), device=x.device, dtype=torch.float32)
+    a = L.ConvArgs(CONV3X3_S1, L.ptr(_f32(x)), L.ptr(x2), c0, c1, L.ptr(w_packed), None, None, L.ptr(out), b, h, w_, n, 0, 0, 1,
+                   L.ptr(ws), ws_bytes)
+    L.check(lib.ddk_conv_forward(C.byref(a), L.stream()), "conv_forward(defer)")
+    stride = temb.stride(0) if temb is not None else 0
+    L.check(lib.ddk_groupnorm_mish_slabs(L.ptr(ws), splits, b * h * w_ * n, L.ptr(bias), L.ptr(gamma), L.ptr(beta),
+                                         temb.data_ptr() if temb is not None else None, stride, L.ptr(addend), L.ptr(out),
+                                         b, h * w_, n, groups, eps, L.stream()), "groupnorm_mish_slabs")
     return out
 
 

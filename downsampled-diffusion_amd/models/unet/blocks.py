@@ -149,9 +149,8 @@ class Block(nn.Module):
     def forward_nhwc(self, x, x2=None, temb=None, addend=None):
         conv, norm = self.block[0], self.block[1]
         w = self._packed.get("w", conv.weight, ops.pack_conv_weight)
-        raw = ops.conv(ops.CONV3X3_S1, x, w, conv.bias.detach(), x2=x2)
-        return ops.groupnorm_mish(raw, norm.weight.detach(), norm.bias.detach(), temb=temb, addend=addend,
-                                  groups=self.groups, eps=norm.eps)
+        return ops.conv3x3_groupnorm_mish(x, w, conv.bias.detach(), norm.weight.detach(), norm.bias.detach(), x2=x2,
+                                          temb=temb, addend=addend, groups=self.groups, eps=norm.eps)
 
     def forward(self, x):
         return ops.nhwc_to_nchw(self.forward_nhwc(_to_nhwc(x)))

@@ -72,11 +72,15 @@ typedef struct ddk_conv_args {
     int N;               /* output channels, multiple of 32 */
     int pre_mish;        /* 1: apply Mish to the input while staging it (convblocks.py:114) */
     int post_mish;       /* 1: write Mish(out): the next conv's input activation, applied once (convblocks.py:115-117) */
+    int defer_reduce;    /* 1: when the launch splits k (ddk_conv_splits() > 1) leave the partial slabs in `workspace`
+                          *    (no bias / resid / Mish applied) for ddk_groupnorm_mish_slabs to sum while it loads */
     void* workspace;     /* split-K slabs; may be NULL when ddk_conv_workspace_bytes() == 0 */
     size_t workspace_bytes;
 } ddk_conv_args;
 
 size_t ddk_conv_workspace_bytes(int kind, int B, int H, int W, int cin, int N);
+/* number of k-splits (partial slabs) the launch for this shape uses; 1 = written directly */
+int ddk_conv_splits(int kind, int B, int H, int W, int cin, int N);
 int ddk_conv_forward(const ddk_conv_args* a, ddk_stream_t s);
 
 /* ------------------------------------------------------------------ normalisation / activation */
@@ -86,6 +90,13 @@ int ddk_groupnorm_mish(const float* x, const float* gamma, const float* beta, co
                        int temb_stride, const float* addend, float* out, int B, int HW, int C, int groups,
                        float eps, void* workspace, size_t workspace_bytes, ddk_stream_t s);
 size_t ddk_groupnorm_workspace_bytes(int B, int HW, int C, int groups);
+/* Same, reading the conv output still as `nslab` split-K slabs (stride slab_stride floats) + conv_bias: the
+ * conv's reduction is folded into this kernel's load.  Only for slabs that fit the register-resident path
+ * (ddk_groupnorm_workspace_bytes() == 0). */
+int ddk_groupnorm_mish_slabs(const float* slabs, int nslab, long long slab_stride, const float* conv_bias,
+                             const float* gamma, const float* beta, const float* temb, int temb_stride,
+                             const float* addend, float* out, int B, int HW, int C, int groups, float eps,
+                             ddk_stream_t s);
 /* per-pixel channel LayerNorm, (x-mean)/(sqrt(var)+eps)*g+b, biased var (blocks.py:57-60). */
 int ddk_chan_layernorm(const float* x, const float* g, const float* b, float* out, long long M, int C,
                        float eps, ddk_stream_t s);

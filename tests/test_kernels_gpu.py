@@ -124,6 +124,19 @@ def test_groupnorm_mish(ops, B, H, W, C):
     assert rel_err(to_nchw(out1.cpu()), ref0 + temb[:, :, None, None] + add) < 5e-6
 
 
+@pytest.mark.parametrize("B,H,W,cin,N", [(2, 8, 8, 64, 64), (32, 4, 4, 256, 256), (4, 16, 16, 128, 128), (32, 32, 32, 128, 128)])
+def test_conv_groupnorm_fused_reduce(ops, B, H, W, cin, N):
+    """conv3x3 -> GN+Mish with the split-K reduction folded into the GroupNorm load == the two-kernel form"""
+    x = rnd(B, cin, H, W, seed=35)
+    w = rnd(N, cin, 3, 3, seed=36, scale=(cin * 9) ** -0.5)
+    bias, g, b = rnd(N, seed=37, scale=0.1), 1 + 0.1 * rnd(N, seed=38), 0.1 * rnd(N, seed=39)
+    temb, add = rnd(B, N, seed=40), rnd(B, N, H, W, seed=41)
+    ref = U.mish(F.group_norm(F.conv2d(x, w, bias, padding=1), 8, g, b, 1e-5)) + temb[:, :, None, None] + add
+    out = ops.conv3x3_groupnorm_mish(to_nhwc(x).to(DEV), ops.pack_conv_weight(w.to(DEV)), bias.to(DEV), g.to(DEV), b.to(DEV),
+                                     temb=temb.to(DEV), addend=to_nhwc(add).to(DEV))
+    assert rel_err(to_nchw(out.cpu()), ref) < 2e-5
+
+
 @pytest.mark.parametrize("C", [32, 64, 128, 256, 512])
 def test_chan_layernorm(ops, C):
     x = rnd(3, C, 6, 5, seed=40, scale=3.0) + 1.0
