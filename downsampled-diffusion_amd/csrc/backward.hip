@@ -1,0 +1,883 @@
+// backward.hip -- backward kernels of the non-conv ops on the training path, plus train-mode forward variants.
+//
+// Reference: the autograd graph torch builds for models/unet/blocks.py (GroupNorm+Mish+shift+Dropout, channel
+// LayerNorm, LinearAttention, time MLP), models/unet/unet.py:71 (final 1x1), models/diffusion/ddpm.py:275-288 (loss),
+// models/downsampled/convblocks.py:110-130 (Mish, avg_pool2d, nearest x2), dddpm.py:99,110 (tanh), driven by
+// trainers/trainer_ddpm.py:124-128 (objective.backward()).
+//
+// Per-channel parameter gradients are produced as per-workgroup partial rows ([parts][C]) in a workspace and folded
+// by ddk_rows_sum_accum in a fixed order: deterministic, and they ACCUMULATE into the gradient tensors so the
+// reference's 2-micro-batch accumulation needs no extra pass.
+#include "ddk_internal.h"
+
+namespace ddk {
+
+// d/du [u * tanh(softplus(u))]: with e = exp(u), n = e(e+2), t = n/(n+2):  t + u * 4 e (e+1) / (n+2)^2
+__device__ __forceinline__ float mish_grad_f(float u) {
+    if (u > 20.0f) return 1.0f;
+    const float e = expf(u);
+    const float n = e * (e + 2.0f);
+    const float d = n + 2.0f;
+    return n / d + u * (4.0f * e * (e + 1.0f)) / (d * d);
+}
+
+// Philox-based keep mask for Dropout(p): one 32-bit draw per element (4 per call)
+struct U4b { uint32_t x, y, z, w; };
+__device__ __forceinline__ U4b philox_u4(unsigned long long idx4, uint32_t a, uint32_t b, uint64_t seed) {
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    U4b c{(uint32_t)idx4, (uint32_t)(idx4 >> 32), a, b};
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        if (r > 0) { k0 += 0x9E3779B9u; k1 += 0xBB67AE85u; }
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
+        c = U4b{hi1 ^ c.y ^ k0, lo1, hi0 ^ c.w ^ k1, lo0};
+    }
+    return c;
+}
+__device__ __forceinline__ float4 dropout_scale4(long long elem4, float p, uint64_t seed, uint32_t layer) {
+    // keep with probability 1-p, scale kept values by 1/(1-p)  (nn.Dropout semantics)
+    const U4b r = philox_u4((unsigned long long)elem4, layer, 0x44524F50u /* 'DROP' */, seed);
+    const uint32_t thr = (uint32_t)((double)p * 4294967296.0);
+    const float s = 1.0f / (1.0f - p);
+    return make_float4(r.x >= thr ? s : 0.f, r.y >= thr ? s : 0.f, r.z >= thr ? s : 0.f, r.w >= thr ? s : 0.f);
+}
+
+// ------------------------------------------------------------------------------------------------
+// GroupNorm+Mish(+temb)(+dropout)(+addend): train-mode forward and backward, register-resident per (b, group).
+//   u = gn(x) * gamma + beta;  y = drop(mish(u) + temb) + addend
+// backward (x recomputed from the saved conv output, nothing else is stored):
+//   g1 = dy * dropmask;  dtemb[b][c] = sum_hw g1;  du = g1 * mish'(u);  dbeta += sum du;  dgamma += sum du * xhat
+//   dx = rstd * (du*gamma - mean_g(du*gamma) - xhat * mean_g(du*gamma*xhat))
+template <int VPT, int NT, bool BWD>
+__global__ __launch_bounds__(NT) void gn_train_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, const float* __restrict__ temb,
+                                                      int temb_stride, const float* __restrict__ addend, float drop_p,
+                                                      uint64_t seed, uint32_t layer, const float* __restrict__ dy,
+                                                      float* __restrict__ out /* fwd: y; bwd: dx */,
+                                                      float* __restrict__ part /* bwd: [3][B][C] dtemb, dgamma, dbeta */, int B, int HW,
+                                                      int C, int groups, float eps) {
+    __shared__ float red[32];
+    __shared__ float csum[16][8][12];  // [wave][cu][4 ch x {dtemb, dgamma, dbeta}]
+    const int b = blockIdx.x / groups, g = blockIdx.x % groups;
+    const int cpg = C / groups;
+    const int upr = cpg >> 2;
+    const int units = HW * upr;
+    const long long base = (long long)b * HW * C + g * cpg;
+
+    float4 v[VPT];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+        const int u = threadIdx.x + i * NT;
+        if (u < units) {
+            const int row = u / upr, cu = u - row * upr;
+            v[i] = *reinterpret_cast<const float4*>(x + base + (long long)row * C + cu * 4);
+            s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        } else {
+            v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    const float inv_n = 1.0f / (float)(HW * cpg);
+    const float mean = block_sum(s, red) * inv_n;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+        const int u = threadIdx.x + i * NT;
+        if (u < units) {
+            const float a = v[i].x - mean, bb = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+            q += (a * a + bb * bb) + (c * c + d * d);
+        }
+    }
+    const float var = block_sum(q, red) * inv_n;
+    const float rstd = 1.0f / sqrtf(var + eps);
+    const int cu_t = threadIdx.x % upr;  // NT % upr == 0: every unit of this thread has the same channel quad
+    const int c0 = g * cpg + cu_t * 4;
+    const float4 ga = *reinterpret_cast<const float4*>(gamma + c0);
+    const float4 be = *reinterpret_cast<const float4*>(beta + c0);
+
+    if (!BWD) {
+        float4 tb = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (temb) tb = *reinterpret_cast<const float4*>(temb + (long long)b * temb_stride + c0);
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+            const int u = threadIdx.x + i * NT;
+            if (u < units) {
+                const int row = u / upr;
+                const long long o = base + (long long)row * C + cu_t * 4;
+                float4 y;
+                y.x = mish_f((v[i].x - mean) * rstd * ga.x + be.x) + tb.x;
+                y.y = mish_f((v[i].y - mean) * rstd * ga.y + be.y) + tb.y;
+                y.z = mish_f((v[i].z - mean) * rstd * ga.z + be.z) + tb.z;
+                y.w = mish_f((v[i].w - mean) * rstd * ga.w + be.w) + tb.w;
+                if (drop_p > 0.f) {
+                    const float4 m = dropout_scale4(o >> 2, drop_p, seed, layer);
+                    y.x *= m.x; y.y *= m.y; y.z *= m.z; y.w *= m.w;
+                }
+                if (addend) {
+                    const float4 r = *reinterpret_cast<const float4*>(addend + o);
+                    y.x += r.x; y.y += r.y; y.z += r.z; y.w += r.w;
+                }
+                *reinterpret_cast<float4*>(out + o) = y;
+            }
+        }
+        return;
+    }
+
+    // ---- backward
+    float4 du[VPT];
+    float4 st = make_float4(0.f, 0.f, 0.f, 0.f), sg = st, sb = st;  // per-channel sums: dtemb, dgamma, dbeta
+    float s1 = 0.f, s2 = 0.f;                                        // group sums of du*gamma and du*gamma*xhat
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+        const int u = threadIdx.x + i * NT;
+        du[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (u < units) {
+            const int row = u / upr;
+            const long long o = base + (long long)row * C + cu_t * 4;
+            float4 g1 = *reinterpret_cast<const float4*>(dy + o);
+            if (drop_p > 0.f) {
+                const float4 m = dropout_scale4(o >> 2, drop_p, seed, layer);
+                g1.x *= m.x; g1.y *= m.y; g1.z *= m.z; g1.w *= m.w;
+            }
+            st.x += g1.x; st.y += g1.y; st.z += g1.z; st.w += g1.w;
+            const float xh0 = (v[i].x - mean) * rstd, xh1 = (v[i].y - mean) * rstd, xh2 = (v[i].z - mean) * rstd,
+                        xh3 = (v[i].w - mean) * rstd;
+            float4 d;
+            d.x = g1.x * mish_grad_f(xh0 * ga.x + be.x);
+            d.y = g1.y * mish_grad_f(xh1 * ga.y + be.y);
+            d.z = g1.z * mish_grad_f(xh2 * ga.z + be.z);
+            d.w = g1.w * mish_grad_f(xh3 * ga.w + be.w);
+            sb.x += d.x; sb.y += d.y; sb.z += d.z; sb.w += d.w;
+            sg.x += d.x * xh0; sg.y += d.y * xh1; sg.z += d.z * xh2; sg.w += d.w * xh3;
+            d.x *= ga.x; d.y *= ga.y; d.z *= ga.z; d.w *= ga.w;  // d xhat
+            s1 += (d.x + d.y) + (d.z + d.w);
+            s2 += (d.x * xh0 + d.y * xh1) + (d.z * xh2 + d.w * xh3);
+            du[i] = d;
+            v[i] = make_float4(xh0, xh1, xh2, xh3);
+        }
+    }
+    const float m1 = block_sum(s1, red) * inv_n;
+    const float m2 = block_sum(s2, red) * inv_n;
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+        const int u = threadIdx.x + i * NT;
+        if (u < units) {
+            const int row = u / upr;
+            const long long o = base + (long long)row * C + cu_t * 4;
+            float4 r;
+            r.x = rstd * (du[i].x - m1 - v[i].x * m2);
+            r.y = rstd * (du[i].y - m1 - v[i].y * m2);
+            r.z = rstd * (du[i].z - m1 - v[i].z * m2);
+            r.w = rstd * (du[i].w - m1 - v[i].w * m2);
+            *reinterpret_cast<float4*>(out + o) = r;
+        }
+    }
+    // per-channel sums: lanes with equal (lane % upr) hold the same channel quad -> xor-reduce over the others
+    float vals[12] = {st.x, st.y, st.z, st.w, sg.x, sg.y, sg.z, sg.w, sb.x, sb.y, sb.z, sb.w};
+#pragma unroll
+    for (int k = 0; k < 12; ++k)
+        for (int o = upr; o < 64; o <<= 1) vals[k] += __shfl_xor(vals[k], o, 64);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane < upr)
+#pragma unroll
+        for (int k = 0; k < 12; ++k) csum[wid][lane][k] = vals[k];
+    __syncthreads();
+    if (threadIdx.x < upr * 12) {
+        const int cu = threadIdx.x / 12, k = threadIdx.x % 12;
+        float t = 0.f;
+        for (int w = 0; w < NT / 64; ++w) t += csum[w][cu][k];
+        const int which = k >> 2, ch = g * cpg + cu * 4 + (k & 3);
+        part[((long long)which * B + b) * C + ch] = t;
+    }
+}
+
+// out[n] (+)= sum_r rows[r][n]  (fixed order)
+__global__ __launch_bounds__(256) void rows_sum_kernel(const float* __restrict__ rows, int nrows, long long row_stride,
+                                                       float* __restrict__ out, int n, int accumulate) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int r = 0; r < nrows; ++r) s += rows[r * row_stride + i];
+    out[i] = accumulate ? out[i] + s : s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Channel LayerNorm backward.  y = d/s*g + b, d = x - mean, s = sqrt(var) + eps:
+//   dx = dyg/s - mean(dyg)/s - d * sum(dyg*d) / (C * sigma * s^2),  dyg = dy*g;  dg = sum_pix dy*d/s;  db = sum_pix dy
+// Grid-stride over pixel groups; each lane keeps per-channel partial sums, one partial row per workgroup.
+template <int LPP, int VPL>
+__global__ __launch_bounds__(256) void chan_layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                                 const float* __restrict__ dy, float* __restrict__ dx,
+                                                                 float* __restrict__ part /* [2][gridDim][C] */, long long M, int C,
+                                                                 float eps) {
+    constexpr int PPW = 64 / LPP;
+    __shared__ float acc_s[4][64][VPL * 8];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, sub = lane % LPP;
+    float4 ga[VPL], sgm[VPL], sbt[VPL];
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        ga[i] = *reinterpret_cast<const float4*>(g + (sub + i * LPP) * 4);
+        sgm[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        sbt[i] = sgm[i];
+    }
+    const long long waves_total = (long long)gridDim.x * 4;
+    for (long long wv = blockIdx.x * 4LL + wid;; wv += waves_total) {
+        const long long pix0 = wv * PPW;
+        if (pix0 >= M) break;
+        const long long pix = pix0 + lane / LPP;
+        const bool ok = pix < M;
+        float4 v[VPL], d4[VPL];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            v[i] = ok ? *reinterpret_cast<const float4*>(x + pix * C + (sub + i * LPP) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            d4[i] = ok ? *reinterpret_cast<const float4*>(dy + pix * C + (sub + i * LPP) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        }
+#pragma unroll
+        for (int o = LPP / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        const float mean = s / (float)C;
+        float q = 0.f, t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
+            q += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+            const float a0 = d4[i].x * ga[i].x, a1 = d4[i].y * ga[i].y, a2 = d4[i].z * ga[i].z, a3 = d4[i].w * ga[i].w;
+            t1 += (a0 + a1) + (a2 + a3);
+            t2 += (a0 * v[i].x + a1 * v[i].y) + (a2 * v[i].z + a3 * v[i].w);
+        }
+#pragma unroll
+        for (int o = LPP / 2; o > 0; o >>= 1) {
+            q += __shfl_xor(q, o, 64);
+            t1 += __shfl_xor(t1, o, 64);
+            t2 += __shfl_xor(t2, o, 64);
+        }
+        const float sigma = sqrtf(q / (float)C), sden = sigma + eps;
+        const float inv_s = 1.0f / sden;
+        const float k1 = t1 / (float)C * inv_s;
+        const float k2 = t2 / ((float)C * sigma * sden * sden);
+        if (ok) {
+#pragma unroll
+            for (int i = 0; i < VPL; ++i) {
+                float4 r;
+                r.x = d4[i].x * ga[i].x * inv_s - k1 - v[i].x * k2;
+                r.y = d4[i].y * ga[i].y * inv_s - k1 - v[i].y * k2;
+                r.z = d4[i].z * ga[i].z * inv_s - k1 - v[i].z * k2;
+                r.w = d4[i].w * ga[i].w * inv_s - k1 - v[i].w * k2;
+                *reinterpret_cast<float4*>(dx + pix * C + (sub + i * LPP) * 4) = r;
+                sgm[i].x += d4[i].x * v[i].x * inv_s; sgm[i].y += d4[i].y * v[i].y * inv_s;
+                sgm[i].z += d4[i].z * v[i].z * inv_s; sgm[i].w += d4[i].w * v[i].w * inv_s;
+                sbt[i].x += d4[i].x; sbt[i].y += d4[i].y; sbt[i].z += d4[i].z; sbt[i].w += d4[i].w;
+            }
+        }
+    }
+    // fold the PPW pixel slots of a wave, then the 4 waves
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        float* a = acc_s[wid][lane] + i * 8;
+        a[0] = sgm[i].x; a[1] = sgm[i].y; a[2] = sgm[i].z; a[3] = sgm[i].w;
+        a[4] = sbt[i].x; a[5] = sbt[i].y; a[6] = sbt[i].z; a[7] = sbt[i].w;
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < C * 2; idx += 256) {
+        const int which = idx / C, c = idx % C;
+        const int cq = c >> 2, ssub = cq % LPP, i = cq / LPP;
+        float t = 0.f;
+        for (int w = 0; w < 4; ++w)
+            for (int pslot = 0; pslot < PPW; ++pslot) t += acc_s[w][pslot * LPP + ssub][i * 8 + which * 4 + (c & 3)];
+        part[((long long)which * gridDim.x + blockIdx.x) * C + c] = t;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Linear attention backward.  Forward: ks = softmax_n(k); ctx = ks^T v; out = q ctx.
+//   dctx[d][e] = sum_n q[n][d] dout[n][e]                      (linattn_dctx_kernel)
+//   dq = dout ctx^T;  dv = ks dctx;  dks = v dctx^T;  dk = ks * (dks - S),  S[d] = sum_e dctx[d][e] ctx[d][e]
+// ks is recomputed from k with the forward's column max / sum (stats[b][h][0][d] = max, [1][d] = sum of exp).
+constexpr int DHB = 32;
+
+__global__ __launch_bounds__(256) void linattn_stats_kernel(const float* __restrict__ qkv, float* __restrict__ stats, int HW, int heads) {
+    __shared__ float sm[8 * DHB];
+    const int b = blockIdx.x / heads, h = blockIdx.x % heads;
+    const int HC = heads * DHB, RS = 3 * HC;
+    const float* kp = qkv + (long long)b * HW * RS + HC + h * DHB;
+    const int d = threadIdx.x & 31, ng = threadIdx.x >> 5;
+    float m = -INFINITY;
+    for (int n = ng; n < HW; n += 8) m = fmaxf(m, kp[(long long)n * RS + d]);
+    sm[ng * DHB + d] = m;
+    __syncthreads();
+    float mm = sm[d];
+#pragma unroll
+    for (int j = 1; j < 8; ++j) mm = fmaxf(mm, sm[j * DHB + d]);
+    __syncthreads();
+    float s = 0.f;
+    for (int n = ng; n < HW; n += 8) s += expf(kp[(long long)n * RS + d] - mm);
+    sm[ng * DHB + d] = s;
+    __syncthreads();
+    if (threadIdx.x < DHB) {
+        float t = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t += sm[j * DHB + threadIdx.x];
+        float* o = stats + ((long long)b * heads + h) * 2 * DHB;
+        o[threadIdx.x] = mm;
+        o[DHB + threadIdx.x] = t;
+    }
+}
+
+// dctx[b][h][d][e] = sum_n q[n][h*32+d] * dout[n][h*32+e]
+__global__ __launch_bounds__(256) void linattn_dctx_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
+                                                           float* __restrict__ dctx, int HW, int heads) {
+    __shared__ __attribute__((aligned(16))) float qs[64 * DHB];
+    __shared__ __attribute__((aligned(16))) float ds[64 * DHB];
+    const int b = blockIdx.x / heads, h = blockIdx.x % heads;
+    const int HC = heads * DHB, RS = 3 * HC, tid = threadIdx.x;
+    const float* qp = qkv + (long long)b * HW * RS + h * DHB;
+    const float* dp = dout + (long long)b * HW * HC + h * DHB;
+    const int d = tid >> 3, e0 = (tid & 7) * 4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int n0 = 0; n0 < HW; n0 += 64) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int idx4 = tid + j * 256, row = idx4 >> 3, c = (idx4 & 7) * 4;
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f), bb = a;
+            if (n0 + row < HW) {
+                a = *reinterpret_cast<const float4*>(qp + (long long)(n0 + row) * RS + c);
+                bb = *reinterpret_cast<const float4*>(dp + (long long)(n0 + row) * HC + c);
+            }
+            *reinterpret_cast<float4*>(qs + row * DHB + c) = a;
+            *reinterpret_cast<float4*>(ds + row * DHB + c) = bb;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int n = 0; n < 64; ++n) {
+            const float qd = qs[n * DHB + d];
+            const float4 v4 = *reinterpret_cast<const float4*>(ds + n * DHB + e0);
+            acc.x += qd * v4.x; acc.y += qd * v4.y; acc.z += qd * v4.z; acc.w += qd * v4.w;
+        }
+        __syncthreads();
+    }
+    *reinterpret_cast<float4*>(dctx + (((long long)b * heads + h) * DHB + d) * DHB + e0) = acc;
+}
+
+// per (pixel, head): dq, dk, dv -> dqkv [B][HW][3*heads*32]
+__global__ __launch_bounds__(256) void linattn_bwd_apply_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
+                                                                const float* __restrict__ ctx, const float* __restrict__ dctx,
+                                                                const float* __restrict__ stats, float* __restrict__ dqkv, int HW,
+                                                                int heads, int tiles_per_sample) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    constexpr int HP = DHB * DHB + 4;
+    float* cs = sm;                      // ctx   [heads][HP]
+    float* dcs = sm + heads * HP;        // dctx  [heads][HP]
+    float* S = sm + 2 * heads * HP;      // [heads][32]
+    const int b = blockIdx.x / tiles_per_sample, tile = blockIdx.x % tiles_per_sample;
+    const int HC = heads * DHB, RS = 3 * HC, nthreads = 64 * heads;
+    for (int i = threadIdx.x; i < heads * DHB * DHB / 4; i += nthreads) {
+        const int hh = (i * 4) / (DHB * DHB), r = (i * 4) % (DHB * DHB);
+        *reinterpret_cast<float4*>(cs + hh * HP + r) = *reinterpret_cast<const float4*>(ctx + ((long long)b * heads + hh) * DHB * DHB + r);
+        *reinterpret_cast<float4*>(dcs + hh * HP + r) = *reinterpret_cast<const float4*>(dctx + ((long long)b * heads + hh) * DHB * DHB + r);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < heads * DHB; i += nthreads) {
+        const int hh = i / DHB, d = i % DHB;
+        float t = 0.f;
+        for (int e = 0; e < DHB; ++e) t += dcs[hh * HP + d * DHB + e] * cs[hh * HP + d * DHB + e];
+        S[i] = t;
+    }
+    __syncthreads();
+    const int h = threadIdx.x % heads, pl = threadIdx.x / heads;
+    const int n = tile * 64 + pl;
+    if (n >= HW) return;
+    const float* base = qkv + ((long long)b * HW + n) * RS;
+    const float* dop = dout + ((long long)b * HW + n) * HC + h * DHB;
+    const float* st = stats + ((long long)b * heads + h) * 2 * DHB;
+    const float* ch = cs + h * HP;
+    const float* dch = dcs + h * HP;
+    float* outp = dqkv + ((long long)b * HW + n) * RS;
+    float ks[DHB];
+    {   // pass 1 (over d): dq[d] = dout . ctx[d][:],  dks[d] = v . dctx[d][:],  dk[d] = ks[d] (dks[d] - S[d])
+        float dO[DHB], vv[DHB];
+#pragma unroll
+        for (int i = 0; i < DHB / 4; ++i) {
+            const float4 a = *reinterpret_cast<const float4*>(dop + i * 4);
+            const float4 k4 = *reinterpret_cast<const float4*>(base + HC + h * DHB + i * 4);
+            const float4 v4 = *reinterpret_cast<const float4*>(base + 2 * HC + h * DHB + i * 4);
+            dO[4 * i] = a.x; dO[4 * i + 1] = a.y; dO[4 * i + 2] = a.z; dO[4 * i + 3] = a.w;
+            ks[4 * i] = k4.x; ks[4 * i + 1] = k4.y; ks[4 * i + 2] = k4.z; ks[4 * i + 3] = k4.w;
+            vv[4 * i] = v4.x; vv[4 * i + 1] = v4.y; vv[4 * i + 2] = v4.z; vv[4 * i + 3] = v4.w;
+        }
+#pragma unroll
+        for (int d = 0; d < DHB; ++d) {
+            float dq = 0.f, dks = 0.f;
+            ks[d] = expf(ks[d] - st[d]) / st[DHB + d];
+#pragma unroll
+            for (int i = 0; i < DHB / 4; ++i) {
+                const float4 c4 = *reinterpret_cast<const float4*>(ch + d * DHB + i * 4);
+                const float4 g4 = *reinterpret_cast<const float4*>(dch + d * DHB + i * 4);
+                dq += (dO[4 * i] * c4.x + dO[4 * i + 1] * c4.y) + (dO[4 * i + 2] * c4.z + dO[4 * i + 3] * c4.w);
+                dks += (vv[4 * i] * g4.x + vv[4 * i + 1] * g4.y) + (vv[4 * i + 2] * g4.z + vv[4 * i + 3] * g4.w);
+            }
+            outp[h * DHB + d] = dq;
+            outp[HC + h * DHB + d] = ks[d] * (dks - S[h * DHB + d]);
+        }
+    }
+    // pass 2 (over e): dv[e] = sum_d ks[d] dctx[d][e]
+#pragma unroll
+    for (int i = 0; i < DHB / 4; ++i) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int d = 0; d < DHB; ++d) {
+            const float4 g4 = *reinterpret_cast<const float4*>(dch + d * DHB + i * 4);
+            acc.x += ks[d] * g4.x; acc.y += ks[d] * g4.y; acc.z += ks[d] * g4.z; acc.w += ks[d] * g4.w;
+        }
+        *reinterpret_cast<float4*>(outp + 2 * HC + h * DHB + i * 4) = acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ elementwise backward
+template <int OP>  // 0: dx = dy * mish'(x)   1: dx = dy * (1 - y^2) (y = tanh output)   2: out = a * s (scale)
+__global__ __launch_bounds__(256) void unary_bwd_kernel(const float* __restrict__ xy, const float* __restrict__ dy, float* __restrict__ dx,
+                                                        long long n4) {
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const float4 a = reinterpret_cast<const float4*>(xy)[i], g = reinterpret_cast<const float4*>(dy)[i];
+        float4 r;
+        if (OP == 0) { r.x = g.x * mish_grad_f(a.x); r.y = g.y * mish_grad_f(a.y); r.z = g.z * mish_grad_f(a.z); r.w = g.w * mish_grad_f(a.w); }
+        else { r.x = g.x * (1.f - a.x * a.x); r.y = g.y * (1.f - a.y * a.y); r.z = g.z * (1.f - a.z * a.z); r.w = g.w * (1.f - a.w * a.w); }
+        reinterpret_cast<float4*>(dx)[i] = r;
+    }
+}
+
+// avg_pool2d(2) backward: dx[b][y][x][c] = 0.25 * dy[b][y/2][x/2][c];   nearest x2 backward: dx[b][y][x] = sum of the 2x2 block of dy
+__global__ __launch_bounds__(256) void avgpool2_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int H, int W, int C,
+                                                           long long total4) {
+    const int c4 = C >> 2;
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total4; i += (long long)gridDim.x * 256) {
+        const int cq = (int)(i % c4);
+        long long p = i / c4;
+        const int x = (int)(p % W); p /= W;
+        const int y = (int)(p % H);
+        const long long b = p / H;
+        const float4 g = *reinterpret_cast<const float4*>(dy + ((b * (H >> 1) + (y >> 1)) * (W >> 1) + (x >> 1)) * C + cq * 4);
+        reinterpret_cast<float4*>(dx)[i] = make_float4(0.25f * g.x, 0.25f * g.y, 0.25f * g.z, 0.25f * g.w);
+    }
+}
+__global__ __launch_bounds__(256) void upnearest2_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int H, int W, int C,
+                                                             long long total4) {
+    const int c4 = C >> 2;
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total4; i += (long long)gridDim.x * 256) {
+        const int cq = (int)(i % c4);
+        long long p = i / c4;
+        const int x = (int)(p % W); p /= W;
+        const int y = (int)(p % H);
+        const long long b = p / H;
+        const float* s = dy + ((b * 2 * H + 2 * y) * 2 * W + 2 * x) * C + cq * 4;
+        const float4 a = *reinterpret_cast<const float4*>(s), bb = *reinterpret_cast<const float4*>(s + C);
+        const float4 c = *reinterpret_cast<const float4*>(s + 2LL * W * C), d = *reinterpret_cast<const float4*>(s + 2LL * W * C + C);
+        reinterpret_cast<float4*>(dx)[i] = make_float4((a.x + bb.x) + (c.x + d.x), (a.y + bb.y) + (c.y + d.y), (a.z + bb.z) + (c.z + d.z),
+                                                       (a.w + bb.w) + (c.w + d.w));
+    }
+}
+
+// loss backward: d eps_hat = -2 (eps - eps_hat) * scale[b]
+__global__ __launch_bounds__(256) void sq_err_grad_kernel(const float* __restrict__ a, const float* __restrict__ bh, const float* __restrict__ scale,
+                                                          float* __restrict__ out, long long per4, long long total4) {
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total4; i += (long long)gridDim.x * 256) {
+        const float sc = -2.0f * scale[i / per4];
+        const float4 u = reinterpret_cast<const float4*>(a)[i], v = reinterpret_cast<const float4*>(bh)[i];
+        reinterpret_cast<float4*>(out)[i] = make_float4(sc * (u.x - v.x), sc * (u.y - v.y), sc * (u.z - v.z), sc * (u.w - v.w));
+    }
+}
+
+// out[i] = x[i] * scale[i / per]   (q_sample backward wrt x: sqrt_acp[t_b] * dy; also generic per-sample scaling)
+__global__ __launch_bounds__(256) void scale_per_sample_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                               float* __restrict__ out, long long per4, long long total4) {
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total4; i += (long long)gridDim.x * 256) {
+        const float sc = scale[i / per4];
+        const float4 u = reinterpret_cast<const float4*>(x)[i];
+        reinterpret_cast<float4*>(out)[i] = make_float4(sc * u.x, sc * u.y, sc * u.z, sc * u.w);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// small-N 1x1 conv backward (final_conv.1): da[m][c] = sum_co dy[m][co] w[co][c];  dw[co][c] += sum_m dy[m][co] a[m][c];
+// db[co] += sum_m dy[m][co].  Partial rows per workgroup: part[blk][n_out*C + n_out].
+template <int LPP, int VPL, int NOUT_MAX>
+__global__ __launch_bounds__(256) void conv1x1_small_n_bwd_kernel(const float* __restrict__ a, const float* __restrict__ w,
+                                                                  const float* __restrict__ dy, float* __restrict__ da,
+                                                                  float* __restrict__ part, long long M, int C, int n_out) {
+    constexpr int PPW = 64 / LPP;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, sub = lane % LPP;
+    float4 dw[NOUT_MAX][VPL];
+    float dbv[NOUT_MAX];
+#pragma unroll
+    for (int co = 0; co < NOUT_MAX; ++co) {
+        dbv[co] = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) dw[co][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const long long waves_total = (long long)gridDim.x * 4;
+    for (long long wv = blockIdx.x * 4LL + wid;; wv += waves_total) {
+        const long long pix0 = wv * PPW;
+        if (pix0 >= M) break;
+        const long long pix = pix0 + lane / LPP;
+        const bool ok = pix < M;
+        float4 av[VPL], r[VPL];
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            av[i] = ok ? *reinterpret_cast<const float4*>(a + pix * C + (sub + i * LPP) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            r[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int co = 0; co < NOUT_MAX; ++co) {
+            if (co < n_out) {
+                const float g = ok ? dy[pix * n_out + co] : 0.f;
+                if (sub == 0) dbv[co] += g;
+#pragma unroll
+                for (int i = 0; i < VPL; ++i) {
+                    const float4 ww = *reinterpret_cast<const float4*>(w + (long long)co * C + (sub + i * LPP) * 4);
+                    r[i].x += g * ww.x; r[i].y += g * ww.y; r[i].z += g * ww.z; r[i].w += g * ww.w;
+                    dw[co][i].x += g * av[i].x; dw[co][i].y += g * av[i].y; dw[co][i].z += g * av[i].z; dw[co][i].w += g * av[i].w;
+                }
+            }
+        }
+        if (ok)
+#pragma unroll
+            for (int i = 0; i < VPL; ++i) *reinterpret_cast<float4*>(da + pix * C + (sub + i * LPP) * 4) = r[i];
+    }
+    // fold the PPW pixel slots of the wave by xor shuffles over lane bits >= log2(LPP); one partial row per wave
+    const int row = blockIdx.x * 4 + wid;
+    float* prow = part + (long long)row * (n_out * C + n_out);
+#pragma unroll
+    for (int co = 0; co < NOUT_MAX; ++co) {
+        if (co < n_out) {
+#pragma unroll
+            for (int i = 0; i < VPL; ++i) {
+                float4 t = dw[co][i];
+                for (int o = LPP; o < 64; o <<= 1) {
+                    t.x += __shfl_xor(t.x, o, 64); t.y += __shfl_xor(t.y, o, 64); t.z += __shfl_xor(t.z, o, 64); t.w += __shfl_xor(t.w, o, 64);
+                }
+                if (lane < LPP) *reinterpret_cast<float4*>(prow + (long long)co * C + (sub + i * LPP) * 4) = t;
+            }
+            float tb = dbv[co];
+            for (int o = 1; o < 64; o <<= 1) tb += __shfl_xor(tb, o, 64);
+            if (lane == 0) prow[(long long)n_out * C + co] = tb;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Tiny dense helpers for the time-embedding path (B <= a few hundred rows):  C = op(A) op(B), one thread per output.
+//   mode 0: C[M][N]  = A[M][K]   B[K][N]            mode 1: C[M][N] = A[M][K] B[N][K]^T
+//   mode 2: C[M][N] (+)= A[K][M]^T B[K][N]   (accumulating, for weight gradients)
+__global__ __launch_bounds__(256) void small_gemm_kernel(int mode, const float* __restrict__ A, const float* __restrict__ Bm,
+                                                         float* __restrict__ Cm, int M, int N, int K, int lda, int ldb, int ldc,
+                                                         int accumulate) {
+    const long long idx = blockIdx.x * 256LL + threadIdx.x;
+    if (idx >= (long long)M * N) return;
+    const int m = (int)(idx / N), n = (int)(idx % N);
+    float s0 = 0.f, s1 = 0.f;
+    int k = 0;
+    if (mode == 0) {
+        for (; k + 1 < K; k += 2) { s0 += A[(long long)m * lda + k] * Bm[(long long)k * ldb + n]; s1 += A[(long long)m * lda + k + 1] * Bm[(long long)(k + 1) * ldb + n]; }
+        if (k < K) s0 += A[(long long)m * lda + k] * Bm[(long long)k * ldb + n];
+    } else if (mode == 1) {
+        for (; k + 1 < K; k += 2) { s0 += A[(long long)m * lda + k] * Bm[(long long)n * ldb + k]; s1 += A[(long long)m * lda + k + 1] * Bm[(long long)n * ldb + k + 1]; }
+        if (k < K) s0 += A[(long long)m * lda + k] * Bm[(long long)n * ldb + k];
+    } else {
+        for (; k + 1 < K; k += 2) { s0 += A[(long long)k * lda + m] * Bm[(long long)k * ldb + n]; s1 += A[(long long)(k + 1) * lda + m] * Bm[(long long)(k + 1) * ldb + n]; }
+        if (k < K) s0 += A[(long long)k * lda + m] * Bm[(long long)k * ldb + n];
+    }
+    const float r = s0 + s1;
+    Cm[(long long)m * ldc + n] = accumulate ? Cm[(long long)m * ldc + n] + r : r;
+}
+
+// sinusoidal embedding + pre-activations of the time MLP, saved for its backward: e [B][dim], u1 [B][4dim] (pre-Mish), tv [B][dim]
+__global__ __launch_bounds__(256) void sincos_kernel(const int64_t* __restrict__ t, const float* __restrict__ freqs, float* __restrict__ e,
+                                                     int B, int dim) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * dim) return;
+    const int b = i / dim, j = i % dim, half = dim >> 1;
+    const float a = (float)t[b] * freqs[j < half ? j : j - half];
+    e[i] = j < half ? sinf(a) : cosf(a);
+}
+// y = x + bias[col];  optionally act = mish(y)
+__global__ __launch_bounds__(256) void bias_act_kernel(float* __restrict__ y, const float* __restrict__ bias, float* __restrict__ act,
+                                                       long long total, int N) {
+    const long long i = blockIdx.x * 256LL + threadIdx.x;
+    if (i >= total) return;
+    const float v = y[i] + bias[i % N];
+    y[i] = v;
+    if (act) act[i] = mish_f(v);
+}
+
+// ------------------------------------------------------------------------------------------------ optimiser (flat fp32 buffers)
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ x, long long n, float* __restrict__ part) {
+    __shared__ float red[32];
+    float s = 0.f;
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n; i += (long long)gridDim.x * 256) s += x[i] * x[i];
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+// norm = sqrt(sum part); coef = min(1, max_norm / (norm + 1e-6))  (torch.nn.utils.clip_grad_norm_)
+__global__ void clip_coef_kernel(const float* __restrict__ part, int nparts, float max_norm, float* __restrict__ out /* [norm, coef] */) {
+    __shared__ float red[32];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < nparts; i += blockDim.x) s += part[i];
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) {
+        const float norm = sqrtf(s);
+        out[0] = norm;
+        out[1] = fminf(1.0f, max_norm / (norm + 1e-6f));
+    }
+}
+// torch.optim.Adam (no amsgrad / weight decay) on flat buffers; the clip coefficient is read from device memory
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, long long n, float step_size, float b2, float omb1,
+                                                   float omb2, float eps, float bc2_sqrt, const float* __restrict__ clip) {
+    const float coef = clip ? clip[1] : 1.0f;
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float gi = g[i] * coef;
+        const float mi = m[i] + (gi - m[i]) * omb1;            // exp_avg.lerp_(grad, 1 - beta1)
+        const float vi = v[i] * b2 + omb2 * gi * gi;           // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] = p[i] - step_size * (mi / denom);                // addcdiv_(exp_avg, denom, value=-lr/bc1)
+    }
+}
+// p_ema = p_ema * decay + (1 - decay) * p   (trainers/ema.py:41-44)
+__global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ pe, const float* __restrict__ p, long long n, float decay) {
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+        pe[i] = pe[i] * decay + (1.0f - decay) * p[i];
+}
+
+static int grid_for(long long n) {
+    const long long b = ceil_div(n > 0 ? n : 1, 256);
+    return (int)(b < 4096 ? b : 4096);
+}
+
+}  // namespace ddk
+
+using namespace ddk;
+
+extern "C" {
+
+/* Train-mode forward of GroupNorm+Mish: y = dropout_p(mish(gn(x)) + temb) + addend (blocks.py:106-111). */
+int ddk_groupnorm_mish_train_fwd(const float* x, const float* gamma, const float* beta, const float* temb, int temb_stride,
+                                 const float* addend, float drop_p, uint64_t seed, uint32_t layer, float* out, int B, int HW, int C,
+                                 int groups, float eps, ddk_stream_t s);
+/* Backward of the same: dx, and partial rows part[3][B][C] = (dtemb, dgamma, dbeta) per sample. */
+int ddk_groupnorm_mish_bwd(const float* x, const float* gamma, const float* beta, float drop_p, uint64_t seed, uint32_t layer,
+                           const float* dy, float* dx, float* part, int B, int HW, int C, int groups, float eps, ddk_stream_t s);
+
+static int gn_train_launch(bool bwd, const float* x, const float* gamma, const float* beta, const float* temb, int temb_stride,
+                           const float* addend, float drop_p, uint64_t seed, uint32_t layer, const float* dy, float* out, float* part,
+                           int B, int HW, int C, int groups, float eps, hipStream_t st) {
+    DDK_REQUIRE(x && gamma && beta && out, "groupnorm_train: null pointer");
+    DDK_REQUIRE(B > 0 && HW > 0 && groups > 0 && C % groups == 0 && (C / groups) % 4 == 0, "groupnorm_train: C/groups % 4");
+    DDK_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "groupnorm_train: dropout p");
+    const int cpg = C / groups, upr = cpg / 4;
+    DDK_REQUIRE(upr <= 8 && (upr & (upr - 1)) == 0, "groupnorm_train: channels per group must be 4, 8, 16 or 32");
+    const long long units = (long long)HW * upr;
+    DDK_REQUIRE(units <= 4096, "groupnorm_train: group slab too large for the register-resident kernel (HW * C/groups <= 16384)");
+    dim3 grid(B * groups);
+#define GT(V, NT)                                                                                                                 \
+    do {                                                                                                                          \
+        if (bwd) hipLaunchKernelGGL((gn_train_kernel<V, NT, true>), grid, dim3(NT), 0, st, x, gamma, beta, temb, temb_stride, addend, \
+                                    drop_p, seed, layer, dy, out, part, B, HW, C, groups, eps);                                  \
+        else hipLaunchKernelGGL((gn_train_kernel<V, NT, false>), grid, dim3(NT), 0, st, x, gamma, beta, temb, temb_stride, addend,   \
+                                drop_p, seed, layer, dy, out, part, B, HW, C, groups, eps);                                      \
+    } while (0)
+    if (units <= 256) GT(1, 256);
+    else if (units <= 512) GT(2, 256);
+    else if (units <= 1024) GT(1, 1024);
+    else if (units <= 2048) GT(2, 1024);
+    else GT(4, 1024);
+#undef GT
+    return check_launch("gn_train_kernel");
+}
+
+int ddk_groupnorm_mish_train_fwd(const float* x, const float* gamma, const float* beta, const float* temb, int temb_stride,
+                                 const float* addend, float drop_p, uint64_t seed, uint32_t layer, float* out, int B, int HW, int C,
+                                 int groups, float eps, ddk_stream_t s) {
+    return gn_train_launch(false, x, gamma, beta, temb, temb_stride, addend, drop_p, seed, layer, nullptr, out, nullptr, B, HW, C, groups,
+                           eps, as_stream(s));
+}
+
+int ddk_groupnorm_mish_bwd(const float* x, const float* gamma, const float* beta, float drop_p, uint64_t seed, uint32_t layer,
+                           const float* dy, float* dx, float* part, int B, int HW, int C, int groups, float eps, ddk_stream_t s) {
+    DDK_REQUIRE(dy && part, "groupnorm_bwd: null pointer");
+    return gn_train_launch(true, x, gamma, beta, nullptr, 0, nullptr, drop_p, seed, layer, dy, dx, part, B, HW, C, groups, eps,
+                           as_stream(s));
+}
+
+/* out[n] (+)= sum_r rows[r*row_stride + n] */
+int ddk_rows_sum(const float* rows, int nrows, long long row_stride, float* out, int n, int accumulate, ddk_stream_t s) {
+    DDK_REQUIRE(rows && out && nrows > 0 && n > 0, "rows_sum: arguments");
+    hipLaunchKernelGGL(rows_sum_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, as_stream(s), rows, nrows, row_stride, out, n,
+                       accumulate);
+    return check_launch("rows_sum_kernel");
+}
+
+/* Channel LayerNorm backward: dx and partial rows part[2][nparts][C] (dg, db); returns nparts via *nparts_out. */
+int ddk_chan_layernorm_bwd(const float* x, const float* g, const float* dy, float* dx, float* part, int max_parts, int* nparts_out,
+                           long long M, int C, float eps, ddk_stream_t s) {
+    DDK_REQUIRE(x && g && dy && dx && part && nparts_out && M > 0 && max_parts > 0, "layernorm_bwd: arguments");
+    DDK_REQUIRE(aligned16(x) && aligned16(g) && aligned16(dy) && aligned16(dx), "layernorm_bwd: alignment");
+    hipStream_t st = as_stream(s);
+#define LB(LPP, VPL)                                                                                                     \
+    do {                                                                                                                 \
+        long long blocks = ceil_div(ceil_div(M, 64 / LPP), 4);                                                           \
+        if (blocks > max_parts) blocks = max_parts;                                                                      \
+        if (blocks > 512) blocks = 512;                                                                                  \
+        *nparts_out = (int)blocks;                                                                                       \
+        hipLaunchKernelGGL((chan_layernorm_bwd_kernel<LPP, VPL>), dim3((unsigned)blocks), dim3(256), 0, st, x, g, dy, dx, part, M, C, eps); \
+        return check_launch("chan_layernorm_bwd_kernel");                                                                \
+    } while (0)
+    switch (C) {
+        case 32: LB(8, 1);
+        case 64: LB(16, 1);
+        case 128: LB(32, 1);
+        case 256: LB(64, 1);
+        case 512: LB(64, 2);
+        default: break;
+    }
+#undef LB
+    return fail_arg("layernorm_bwd: unsupported channel count (32, 64, 128, 256, 512)");
+}
+
+/* softmax statistics of k saved by the training forward: stats[b][h][2][32] = (column max, sum of exp) */
+int ddk_linattn_stats(const float* qkv, float* stats, int B, int HW, int heads, ddk_stream_t s) {
+    DDK_REQUIRE(qkv && stats && B > 0 && HW > 0 && heads > 0, "linattn_stats: arguments");
+    hipLaunchKernelGGL(linattn_stats_kernel, dim3(B * heads), dim3(256), 0, as_stream(s), qkv, stats, HW, heads);
+    return check_launch("linattn_stats_kernel");
+}
+
+/* dqkv from dout (grad of the attention output before to_out); dctx is scratch [B][heads][32][32] */
+int ddk_linattn_bwd(const float* qkv, const float* dout, const float* ctx, const float* stats, float* dctx, float* dqkv, int B, int HW,
+                    int heads, ddk_stream_t s) {
+    DDK_REQUIRE(qkv && dout && ctx && stats && dctx && dqkv && B > 0 && HW > 0 && heads >= 1 && heads <= 4, "linattn_bwd: arguments (heads <= 4)");
+    DDK_REQUIRE(aligned16(qkv) && aligned16(dout) && aligned16(ctx) && aligned16(dctx) && aligned16(dqkv), "linattn_bwd: alignment");
+    hipStream_t st = as_stream(s);
+    hipLaunchKernelGGL(linattn_dctx_kernel, dim3(B * heads), dim3(256), 0, st, qkv, dout, dctx, HW, heads);
+    DDK_TRY(check_launch("linattn_dctx_kernel"));
+    const int tiles = (int)ceil_div(HW, 64);
+    const size_t lds = ((size_t)2 * heads * (DHB * DHB + 4) + heads * DHB) * sizeof(float);
+    hipLaunchKernelGGL(linattn_bwd_apply_kernel, dim3(B * tiles), dim3(64 * heads), lds, st, qkv, dout, ctx, dctx, stats, dqkv, HW, heads,
+                       tiles);
+    return check_launch("linattn_bwd_apply_kernel");
+}
+
+int ddk_mish_bwd(const float* x, const float* dy, float* dx, long long n, ddk_stream_t s) {
+    DDK_REQUIRE(x && dy && dx && n > 0 && n % 4 == 0 && aligned16(x) && aligned16(dy) && aligned16(dx), "mish_bwd: arguments (n % 4)");
+    hipLaunchKernelGGL(unary_bwd_kernel<0>, dim3(grid_for(n / 4)), dim3(256), 0, as_stream(s), x, dy, dx, n / 4);
+    return check_launch("mish_bwd");
+}
+int ddk_tanh_bwd(const float* y, const float* dy, float* dx, long long n, ddk_stream_t s) {
+    DDK_REQUIRE(y && dy && dx && n > 0 && n % 4 == 0 && aligned16(y) && aligned16(dy) && aligned16(dx), "tanh_bwd: arguments (n % 4)");
+    hipLaunchKernelGGL(unary_bwd_kernel<1>, dim3(grid_for(n / 4)), dim3(256), 0, as_stream(s), y, dy, dx, n / 4);
+    return check_launch("tanh_bwd");
+}
+/* dy [B][H/2][W/2][C] -> dx [B][H][W][C] */
+int ddk_avgpool2_bwd(const float* dy, float* dx, int B, int H, int W, int C, ddk_stream_t s) {
+    DDK_REQUIRE(dy && dx && B > 0 && H % 2 == 0 && W % 2 == 0 && C % 4 == 0, "avgpool2_bwd: shape");
+    const long long total4 = (long long)B * H * W * (C / 4);
+    hipLaunchKernelGGL(avgpool2_bwd_kernel, dim3(grid_for(total4)), dim3(256), 0, as_stream(s), dy, dx, H, W, C, total4);
+    return check_launch("avgpool2_bwd");
+}
+/* dy [B][2H][2W][C] -> dx [B][H][W][C] */
+int ddk_upsample_nearest2_bwd(const float* dy, float* dx, int B, int H, int W, int C, ddk_stream_t s) {
+    DDK_REQUIRE(dy && dx && B > 0 && H > 0 && W > 0 && C % 4 == 0, "upsample_nearest2_bwd: shape");
+    const long long total4 = (long long)B * H * W * (C / 4);
+    hipLaunchKernelGGL(upnearest2_bwd_kernel, dim3(grid_for(total4)), dim3(256), 0, as_stream(s), dy, dx, H, W, C, total4);
+    return check_launch("upnearest2_bwd");
+}
+/* out = -2 (a - b) * scale[sample]: gradient of sum((a-b)^2) wrt b times an upstream per-sample factor */
+int ddk_sq_err_grad(const float* a, const float* b, const float* scale, float* out, int B, long long per, ddk_stream_t s) {
+    DDK_REQUIRE(a && b && scale && out && B > 0 && per > 0 && per % 4 == 0, "sq_err_grad: arguments");
+    const long long total4 = B * per / 4;
+    hipLaunchKernelGGL(sq_err_grad_kernel, dim3(grid_for(total4)), dim3(256), 0, as_stream(s), a, b, scale, out, per / 4, total4);
+    return check_launch("sq_err_grad");
+}
+int ddk_scale_per_sample(const float* x, const float* scale, float* out, int B, long long per, ddk_stream_t s) {
+    DDK_REQUIRE(x && scale && out && B > 0 && per > 0 && per % 4 == 0, "scale_per_sample: arguments");
+    const long long total4 = B * per / 4;
+    hipLaunchKernelGGL(scale_per_sample_kernel, dim3(grid_for(total4)), dim3(256), 0, as_stream(s), x, scale, out, per / 4, total4);
+    return check_launch("scale_per_sample");
+}
+
+/* final 1x1 backward; part: [max_rows][n_out*C + n_out] partial rows, *nrows_out of them are written */
+int ddk_conv1x1_small_n_bwd(const float* a, const float* w, const float* dy, float* da, float* part, int max_rows, int* nrows_out,
+                            long long M, int C, int n_out, ddk_stream_t s) {
+    DDK_REQUIRE(a && w && dy && da && part && nrows_out && M > 0 && n_out > 0 && n_out <= 8, "conv1x1_small_n_bwd: arguments (n_out <= 8)");
+    DDK_REQUIRE(aligned16(a) && aligned16(w) && aligned16(da), "conv1x1_small_n_bwd: alignment");
+    hipStream_t st = as_stream(s);
+#define CB(LPP, VPL)                                                                                                          \
+    do {                                                                                                                      \
+        long long blocks = ceil_div(ceil_div(M, 64 / LPP), 4);                                                                \
+        if (blocks > max_rows / 4) blocks = max_rows / 4;                                                                     \
+        if (blocks > 256) blocks = 256;                                                                                       \
+        if (blocks < 1) return fail_arg("conv1x1_small_n_bwd: max_rows < 4");                                                 \
+        *nrows_out = (int)blocks * 4;                                                                                         \
+        hipLaunchKernelGGL((conv1x1_small_n_bwd_kernel<LPP, VPL, 8>), dim3((unsigned)blocks), dim3(256), 0, st, a, w, dy, da, part, M, C, \
+                           n_out);                                                                                            \
+        return check_launch("conv1x1_small_n_bwd_kernel");                                                                    \
+    } while (0)
+    switch (C) {
+        case 32: CB(8, 1);
+        case 64: CB(16, 1);
+        case 128: CB(32, 1);
+        case 256: CB(64, 1);
+        default: break;
+    }
+#undef CB
+    return fail_arg("conv1x1_small_n_bwd: unsupported channel count (32, 64, 128, 256)");
+}
+
+/* C = op(A) op(B) for the tiny time-embedding matrices; see small_gemm_kernel for the modes */
+int ddk_small_gemm(int mode, const float* A, const float* Bm, float* Cm, int M, int N, int K, int lda, int ldb, int ldc, int accumulate,
+                   ddk_stream_t s) {
+    DDK_REQUIRE(A && Bm && Cm && M > 0 && N > 0 && K > 0 && mode >= 0 && mode <= 2, "small_gemm: arguments");
+    hipLaunchKernelGGL(small_gemm_kernel, dim3((unsigned)ceil_div((long long)M * N, 256)), dim3(256), 0, as_stream(s), mode, A, Bm, Cm, M, N,
+                       K, lda, ldb, ldc, accumulate);
+    return check_launch("small_gemm_kernel");
+}
+int ddk_sincos_embed(const int64_t* t, const float* freqs, float* e, int B, int dim, ddk_stream_t s) {
+    DDK_REQUIRE(t && freqs && e && B > 0 && dim > 0 && dim % 2 == 0, "sincos_embed: arguments");
+    hipLaunchKernelGGL(sincos_kernel, dim3((unsigned)ceil_div((long long)B * dim, 256)), dim3(256), 0, as_stream(s), t, freqs, e, B, dim);
+    return check_launch("sincos_kernel");
+}
+/* y[m][n] += bias[n] in place; act = mish(y) when act != NULL */
+int ddk_bias_act(float* y, const float* bias, float* act, long long M, int N, ddk_stream_t s) {
+    DDK_REQUIRE(y && bias && M > 0 && N > 0, "bias_act: arguments");
+    hipLaunchKernelGGL(bias_act_kernel, dim3((unsigned)ceil_div(M * N, 256)), dim3(256), 0, as_stream(s), y, bias, act, M * N, N);
+    return check_launch("bias_act_kernel");
+}
+
+/* global gradient norm + clip coefficient: out2 = [norm, min(1, max_norm/(norm+1e-6))]; workspace >= 1024 floats */
+int ddk_grad_norm_clip(const float* g, long long n, float max_norm, float* out2, void* workspace, size_t workspace_bytes, ddk_stream_t s) {
+    DDK_REQUIRE(g && out2 && workspace && n > 0 && workspace_bytes >= 1024 * sizeof(float), "grad_norm_clip: arguments");
+    const int blocks = (int)(ceil_div(n, 256 * 16) < 1024 ? ceil_div(n, 256 * 16) : 1024);
+    float* part = static_cast<float*>(workspace);
+    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(blocks), dim3(256), 0, as_stream(s), g, n, part);
+    DDK_TRY(check_launch("sumsq_partial_kernel"));
+    hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(256), 0, as_stream(s), part, blocks, max_norm, out2);
+    return check_launch("clip_coef_kernel");
+}
+/* one Adam step on flat buffers; step counts from 1; clip2 (device [norm, coef]) may be NULL */
+int ddk_adam_step(float* p, const float* g, float* m, float* v, long long n, double lr, double beta1, double beta2, double eps, int step,
+                  const float* clip2, ddk_stream_t s) {
+    DDK_REQUIRE(p && g && m && v && n > 0 && step >= 1, "adam_step: arguments");
+    const double bc1 = 1.0 - pow(beta1, (double)step);
+    const double bc2s = sqrt(1.0 - pow(beta2, (double)step));
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, as_stream(s), p, g, m, v, n, (float)(lr / bc1), (float)beta2,
+                       (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, (float)bc2s, clip2);
+    return check_launch("adam_kernel");
+}
+int ddk_ema_update(float* p_ema, const float* p, long long n, float decay, ddk_stream_t s) {
+    DDK_REQUIRE(p_ema && p && n > 0, "ema_update: arguments");
+    hipLaunchKernelGGL(ema_kernel, dim3(grid_for(n)), dim3(256), 0, as_stream(s), p_ema, p, n, decay);
+    return check_launch("ema_kernel");
+}
+}

@@ -41,7 +41,8 @@ struct IgemmParams {
     long long slab_stride;
     int pre_mish, post_mish;
     int debug;    // tuning only (DDK_DEBUG): 1 skip in-loop DMA, 2 skip barrier, 4 skip output stores
-    int tapmode;  // 0: single tap (1x1); 1: 3x3, (dy,dx) = (tap/3-1, tap%3-1); 2: transpose-conv phase taps (py-a, px-b)
+    int tapmode;  // 0: single tap (1x1); 1: 3x3, (dy,dx) = (tap/3-1, tap%3-1); 2: transpose-conv phase taps (py-a, px-b);
+                  // 3: 4x4, (dy,dx) = (tap/4-1, tap%4-1)
 };
 
 // Input offset of a tap: pure scalar arithmetic on wave-uniform values (a lookup table in the kernel
@@ -54,6 +55,9 @@ __device__ __forceinline__ void tap_offset(int tapmode, int phase, int tap, int&
     } else if (tapmode == 2) {
         dy = (phase >> 1) - (tap >> 1);
         dx = (phase & 1) - (tap & 1);
+    } else if (tapmode == 3) {
+        dy = (tap >> 2) - 1;
+        dx = (tap & 3) - 1;
     } else {
         dy = 0;
         dx = 0;
@@ -291,7 +295,7 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_dma_kernel(const IgemmParam
         a_sw[j] = (ppos ^ ((r >> 1) & 7)) * 4;  // float offset of the k-chunk this lane fetches
         a_pix[j] = (b * p.H + iy0) * p.W + ix0;
         unsigned m = 0;
-        if (p.debug & 16) m = 0x1ffu;
+        if (p.debug & 16) m = 0xffffu;
         else
         for (int t = 0; t < p.ntaps; ++t) {
             int dy, dx;
@@ -506,6 +510,7 @@ static bool conv_geometry(int kind, int H, int W, Geometry& g) {
         case DDK_CONV3X3_S2: g = {(H - 1) / 2 + 1, (W - 1) / 2 + 1, (H - 1) / 2 + 1, (W - 1) / 2 + 1, 2, 1, 9, 1}; return true;
         case DDK_CONV1X1: g = {H, W, H, W, 1, 1, 1, 1}; return true;
         case DDK_CONVT4X4_S2: g = {H, W, 2 * H, 2 * W, 1, 2, 4, 4}; return true;
+        case DDK_CONV4X4_S2: g = {H / 2, W / 2, H / 2, W / 2, 2, 1, 16, 1}; return H % 2 == 0 && W % 2 == 0;
         default: return false;
     }
 }
@@ -643,7 +648,7 @@ int conv_forward(const ddk_conv_args& a, hipStream_t st) {
     }
     p.post_mish = a.post_mish;
     p.slab_stride = (long long)a.B * g.Ho * g.Wo * a.N;
-    p.tapmode = (a.kind == DDK_CONV1X1) ? 0 : (a.kind == DDK_CONVT4X4_S2 ? 2 : 1);
+    p.tapmode = (a.kind == DDK_CONV1X1) ? 0 : (a.kind == DDK_CONVT4X4_S2 ? 2 : (a.kind == DDK_CONV4X4_S2 ? 3 : 1));
     const Choice c = choose_tile(p.M, p.N, p.nphase, p.kiters);
     {
         static const bool trace = getenv("DDK_TRACE") != nullptr;  // tuning aid: one line per conv launch

@@ -1,0 +1,313 @@
+"""torch.autograd.Function wrappers: HIP forward + HIP backward for every op of the training path.
+
+torch's autograd engine only ORDERS the backward calls and accumulates ``.grad``; every tensor it passes around is
+produced by a kernel of libddk.so (csrc/conv_igemm.hip, conv_wgrad.hip, backward.hip).  Activations are NHWC.
+Counterpart of the graph torch records for reference models/unet/blocks.py + models/diffusion/ddpm.py:275-315 when
+trainers/trainer_ddpm.py:124-128 calls ``objective.backward()``.
+"""
+import torch
+
+from . import ops
+
+
+def _c(t):
+    return t if t is None or t.is_contiguous() else t.contiguous()
+
+
+class ConvFn(torch.autograd.Function):
+    """conv family on NHWC x (optionally channel-concatenated with x2), canonical (OIHW / (I,O,4,4)) weight."""
+
+    @staticmethod
+    def forward(ctx, kind, x, x2, weight, bias, resid):
+        if kind == ops.CONVT4X4_S2:
+            wp = ops.pack_convT_weight(weight.detach())
+            n = weight.shape[1]
+        else:
+            wp = ops.pack_conv_weight(weight.detach())
+            n = weight.shape[0]
+        out = ops.conv(kind, x, wp, None if bias is None else bias.detach(), n_out=n, x2=x2, resid=resid)
+        ctx.kind = kind
+        ctx.save_for_backward(x, x2, weight)
+        ctx.has_bias = bias is not None
+        ctx.has_resid = resid is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        kind = ctx.kind
+        x, x2, weight = ctx.saved_tensors
+        dy = _c(dy)
+        need_x, need_x2, need_w = ctx.needs_input_grad[1], ctx.needs_input_grad[2], ctx.needs_input_grad[3]
+        c0 = x.shape[-1]
+        c1 = 0 if x2 is None else x2.shape[-1]
+        dx = dx2 = gw = gb = None
+        if need_w:
+            gw = torch.zeros_like(weight, memory_format=torch.contiguous_format)
+            if kind == ops.CONVT4X4_S2:
+                # dW[i][o][ky][kx] = sum X[i] * dY[o] shifted: wgrad of the 4x4 stride-2 conv with the roles swapped
+                ops.conv_wgrad_(ops.CONV4X4_S2, dy, x, gw, c_real=dy.shape[-1], cw=dy.shape[-1], c_off=0)
+            else:
+                cin = weight.shape[1]
+                ops.conv_wgrad_(kind, x, dy, gw, c_real=min(c0, cin), cw=cin, c_off=0)
+                if x2 is not None:
+                    ops.conv_wgrad_(kind, x2, dy, gw, c_real=c1, cw=cin, c_off=c0)
+        if ctx.has_bias and ctx.needs_input_grad[4]:
+            gb = ops.bias_grad(dy)
+        if need_x or need_x2:
+            if kind == ops.CONVT4X4_S2:
+                dx = ops.conv(ops.CONV4X4_S2, dy, ops.pack_conv_weight(weight.detach()))   # (I,O,4,4) read as OIHW
+            else:
+                wd = ops.pack_conv_weight_dgrad(weight.detach(), i_pad=c0 + c1)            # [c0+c1][taps][N]
+                src = dy
+                k = ops.CONV1X1 if kind == ops.CONV1X1 else ops.CONV3X3_S1
+                if kind == ops.CONV3X3_S2:
+                    src = ops.zero_stuff2(dy, x.shape[1], x.shape[2])
+                if need_x:
+                    dx = ops.conv(k, src, wd[:c0], n_out=c0)
+                if need_x2:
+                    dx2 = ops.conv(k, src, wd[c0:], n_out=c1)
+        return None, dx, dx2, gw, gb, (dy if ctx.has_resid else None)
+
+
+def conv(kind, x, weight, bias=None, x2=None, resid=None):
+    return ConvFn.apply(kind, x, x2, weight, bias, resid)
+
+
+class GNMishFn(torch.autograd.Function):
+    """y = dropout_p(mish(groupnorm(x)) + temb) + addend  (blocks.py:79-80,106-111)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, temb, addend, drop_p, seed, layer, groups, eps):
+        ctx.save_for_backward(x, gamma, beta)
+        ctx.cfg = (drop_p, seed, layer, groups, eps, temb is not None, addend is not None)
+        return ops.groupnorm_mish_train(x, gamma.detach(), beta.detach(), temb=temb, addend=addend, drop_p=drop_p, seed=seed,
+                                        layer=layer, groups=groups, eps=eps)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, beta = ctx.saved_tensors
+        drop_p, seed, layer, groups, eps, has_temb, has_add = ctx.cfg
+        dy = _c(dy)
+        dx, dtemb, dg, db = ops.groupnorm_mish_bwd(x, gamma.detach(), beta.detach(), dy, drop_p, seed, layer, groups, eps)
+        return dx, dg, db, (dtemb if has_temb else None), (dy if has_add else None), None, None, None, None, None
+
+
+def groupnorm_mish(x, gamma, beta, temb=None, addend=None, drop_p=0.0, seed=0, layer=0, groups=8, eps=1e-5):
+    return GNMishFn.apply(x, gamma, beta, temb, addend, float(drop_p), int(seed), int(layer), groups, eps)
+
+
+class ChanLayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, g, b, eps):
+        ctx.save_for_backward(x, g)
+        ctx.eps = eps
+        return ops.chan_layernorm(x, g.detach(), b.detach(), eps)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, g = ctx.saved_tensors
+        dx, dg, db = ops.chan_layernorm_bwd(x, g.detach(), _c(dy), ctx.eps)
+        return dx, dg.reshape(g.shape), db.reshape(g.shape), None
+
+
+class LinAttnFn(torch.autograd.Function):
+    """qkv [B,H,W,384] -> attention output [B,H,W,128] (blocks.py:128-133)."""
+
+    @staticmethod
+    def forward(ctx, qkv, heads):
+        out, cx, stats = ops.linattn_train(qkv, heads)
+        ctx.save_for_backward(qkv, cx, stats)
+        ctx.heads = heads
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, cx, stats = ctx.saved_tensors
+        return ops.linattn_bwd(qkv, _c(dout), cx, stats, ctx.heads), None
+
+
+class SmallNConvFn(torch.autograd.Function):
+    """final 1x1 to in_channels (unet.py:71) and the resamplers' last 1x1."""
+
+    @staticmethod
+    def forward(ctx, a, weight, bias):
+        ctx.save_for_backward(a, weight)
+        return ops.conv1x1_small_n(a, weight.detach(), bias.detach())
+
+    @staticmethod
+    def backward(ctx, dy):
+        a, weight = ctx.saved_tensors
+        da, dw, db = ops.conv1x1_small_n_bwd(a, weight.detach(), _c(dy))
+        return da, dw.reshape(weight.shape), db
+
+
+class SqErrSumFn(torch.autograd.Function):
+    """per-sample sum((a - b)^2); gradient flows to b (the model output)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        ctx.save_for_backward(a, b)
+        return ops.sq_err_sum(a, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        gb = ops.sq_err_grad(a, b, _c(g)) if ctx.needs_input_grad[1] else None
+        ga = None
+        if ctx.needs_input_grad[0]:
+            ga = ops.sq_err_grad(b, a, _c(g))
+        return ga, gb
+
+
+class MishFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        return ops.mish(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.mish_bwd(ctx.saved_tensors[0], _c(dy))
+
+
+class TanhFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        y = ops.tanh(x)
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.tanh_bwd(ctx.saved_tensors[0], _c(dy))
+
+
+class AvgPool2Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return ops.avgpool2(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.avgpool2_bwd(_c(dy))
+
+
+class UpNearest2Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return ops.upsample_nearest2(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.upsample_nearest2_bwd(_c(dy))
+
+
+class AddFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        return ops.add(a, b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, dy
+
+
+class NchwToNhwcFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, c_pad):
+        ctx.c = x.shape[1]
+        return ops.nchw_to_nhwc(x, c_pad)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.nhwc_to_nchw(_c(dy), ctx.c), None
+
+
+class NhwcToNchwFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, c):
+        ctx.cs = x.shape[-1]
+        return ops.nhwc_to_nchw(x, c)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.nchw_to_nhwc(_c(dy), ctx.cs), None
+
+
+class QSampleFn(torch.autograd.Function):
+    """x_t = sqrt_acp[t] x + sqrt(1-acp)[t] eps; gradient to x only (needed by the non-autoencoder dDDPM loss)."""
+
+    @staticmethod
+    def forward(ctx, x, eps, t, sqrt_acp, sqrt_1m_acp):
+        ctx.save_for_backward(t, sqrt_acp)
+        return ops.q_sample(x, eps, t, sqrt_acp, sqrt_1m_acp)
+
+    @staticmethod
+    def backward(ctx, dy):
+        t, sqrt_acp = ctx.saved_tensors
+        return ops.scale_per_sample(_c(dy), sqrt_acp[t].contiguous()), None, None, None, None
+
+
+class TimeEmbedFn(torch.autograd.Function):
+    """t -> [B, sum C_out] time shifts of every ResnetBlock (blocks.py:22-29,92-95; unet.py:30-35).
+
+    inputs: t, freqs, W1 [4d,d], b1, W2 [d,4d], b2, then the blocks' (weight [Co,d], bias [Co]) pairs.
+    """
+
+    @staticmethod
+    def forward(ctx, t, freqs, w1, b1, w2, b2, *mlps):
+        bsz, d = t.shape[0], w2.shape[0]
+        dev = t.device
+        e = ops.sincos_embed(t, freqs)
+        u1 = torch.empty((bsz, 4 * d), device=dev, dtype=torch.float32)
+        ops.small_gemm(1, e, w1.detach(), u1, bsz, 4 * d, d, d, d, 4 * d)
+        h1 = ops.bias_act_(u1, b1.detach(), True)
+        tv = torch.empty((bsz, d), device=dev, dtype=torch.float32)
+        ops.small_gemm(1, h1, w2.detach(), tv, bsz, d, 4 * d, 4 * d, 4 * d, d)
+        act = ops.bias_act_(tv, b2.detach(), True)
+        ws, bs = mlps[0::2], mlps[1::2]
+        ctot = sum(w.shape[0] for w in ws)
+        out = torch.empty((bsz, ctot), device=dev, dtype=torch.float32)
+        off = 0
+        for w, b in zip(ws, bs):
+            co = w.shape[0]
+            ops.small_gemm(1, act, w.detach(), out[:, off:off + co], bsz, co, d, d, d, ctot)
+            off += co
+        bcat = torch.cat([b.detach() for b in bs])
+        ops.bias_act_(out, bcat, False)
+        ctx.save_for_backward(e, u1, h1, tv, act, w1, w2, *ws)
+        ctx.n_mlp = len(ws)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        saved = ctx.saved_tensors
+        e, u1, h1, tv, act, w1, w2 = saved[:7]
+        ws = saved[7:]
+        dout = _c(dout)
+        bsz, ctot = dout.shape
+        d = w2.shape[0]
+        dev = dout.device
+        dact = torch.zeros((bsz, d), device=dev, dtype=torch.float32)
+        grads = []
+        off = 0
+        for w in ws:
+            co = w.shape[0]
+            sl = dout[:, off:off + co]
+            gw = torch.empty_like(w)
+            ops.small_gemm(2, sl, act, gw, co, d, bsz, ctot, d, d)               # dW[co][d] = dout^T act
+            gb = ops.rows_sum(sl, bsz, ctot, co)
+            ops.small_gemm(0, sl, w.detach(), dact, bsz, d, co, ctot, d, d, accumulate=True)
+            grads += [gw, gb]
+            off += co
+        dtv = ops.mish_bwd(tv, dact)
+        gw2 = torch.empty_like(w2)
+        ops.small_gemm(2, dtv, h1, gw2, d, 4 * d, bsz, d, 4 * d, 4 * d)
+        gb2 = ops.rows_sum(dtv, bsz, d, d)
+        dh1 = torch.empty((bsz, 4 * d), device=dev, dtype=torch.float32)
+        ops.small_gemm(0, dtv, w2.detach(), dh1, bsz, 4 * d, d, d, 4 * d, 4 * d)
+        du1 = ops.mish_bwd(u1, dh1)
+        gw1 = torch.empty_like(w1)
+        ops.small_gemm(2, du1, e, gw1, 4 * d, d, bsz, 4 * d, d, d)
+        gb1 = ops.rows_sum(du1, bsz, 4 * d, 4 * d)
+        return (None, None, gw1, gb1, gw2, gb2, *grads)

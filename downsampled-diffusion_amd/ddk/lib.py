@@ -86,6 +86,30 @@ SIGNATURES = {
     "ddk_unet_flops": (C.c_double, [_P, _I, _I, _I]),
     "ddk_sampler_workspace_bytes": (_SZ, [_P, _I, _I, _I]),
     "ddk_sampler_run": (_I, [C.POINTER(SamplerArgs), _P]),
+    "ddk_pack_conv_weight_dgrad": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "ddk_zero_stuff2": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "ddk_conv_wgrad_workspace_bytes": (_SZ, [_I, _I, _I, _I, _I, _I]),
+    "ddk_conv_wgrad": (_I, [_I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _SZ, _P]),
+    "ddk_bias_grad": (_I, [_P, _P, _LL, _I, _I, _P, _SZ, _P]),
+    "ddk_groupnorm_mish_train_fwd": (_I, [_P, _P, _P, _P, _I, _P, _F, C.c_uint64, C.c_uint32, _P, _I, _I, _I, _I, _F, _P]),
+    "ddk_groupnorm_mish_bwd": (_I, [_P, _P, _P, _F, C.c_uint64, C.c_uint32, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
+    "ddk_rows_sum": (_I, [_P, _I, _LL, _P, _I, _I, _P]),
+    "ddk_chan_layernorm_bwd": (_I, [_P, _P, _P, _P, _P, _I, C.POINTER(C.c_int), _LL, _I, _F, _P]),
+    "ddk_linattn_stats": (_I, [_P, _P, _I, _I, _I, _P]),
+    "ddk_linattn_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "ddk_mish_bwd": (_I, [_P, _P, _P, _LL, _P]),
+    "ddk_tanh_bwd": (_I, [_P, _P, _P, _LL, _P]),
+    "ddk_avgpool2_bwd": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "ddk_upsample_nearest2_bwd": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "ddk_sq_err_grad": (_I, [_P, _P, _P, _P, _I, _LL, _P]),
+    "ddk_scale_per_sample": (_I, [_P, _P, _P, _I, _LL, _P]),
+    "ddk_conv1x1_small_n_bwd": (_I, [_P, _P, _P, _P, _P, _I, C.POINTER(C.c_int), _LL, _I, _I, _P]),
+    "ddk_small_gemm": (_I, [_I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "ddk_sincos_embed": (_I, [_P, _P, _P, _I, _I, _P]),
+    "ddk_bias_act": (_I, [_P, _P, _P, _LL, _I, _P]),
+    "ddk_grad_norm_clip": (_I, [_P, _LL, _F, _P, _P, _SZ, _P]),
+    "ddk_adam_step": (_I, [_P, _P, _P, _P, _LL, C.c_double, C.c_double, C.c_double, C.c_double, _I, _P, _P]),
+    "ddk_ema_update": (_I, [_P, _P, _LL, _F, _P]),
 }
 
 _lib = None

@@ -76,6 +76,8 @@ def conv(kind, x, w_packed, bias=None, n_out=None, x2=None, resid=None, pre_mish
         ho, wo = (h - 1) // 2 + 1, (w_ - 1) // 2 + 1
     elif kind == CONVT4X4_S2:
         ho, wo = 2 * h, 2 * w_
+    elif kind == 4:   # CONV4X4_S2
+        ho, wo = h // 2, w_ // 2
     else:
         ho, wo = h, w_
     out = torch.empty((b, ho, wo, n), device=x.device, dtype=torch.float32)
@@ -238,3 +240,220 @@ def sq_err_sum(a, b):
     L.check(L.load().ddk_sq_err_sum(L.ptr(_f32(a)), L.ptr(_f32(b)), L.ptr(out), bsz, a.numel() // bsz, L.stream()),
             "sq_err_sum")
     return out
+
+
+# ================================================================== training path (backward kernels)
+CONV4X4_S2 = 4
+_scratch = {}
+
+
+def _ws(device, nbytes, tag="ws"):
+    """Reusable scratch buffer per (device, tag): backward kernels need short-lived workspaces."""
+    key = (str(device), tag)
+    buf = _scratch.get(key)
+    n = max(nbytes, 16) // 4 + 4
+    if buf is None or buf.numel() < n:
+        buf = torch.empty(n, device=device, dtype=torch.float32)
+        _scratch[key] = buf
+    return buf
+
+
+def pack_conv_weight_dgrad(w, i_pad=None, o_pad=None):
+    """OIHW -> [I_pad][KH*KW][O_pad] with flipped taps: operand of the input-gradient conv."""
+    o, i, kh, kw = w.shape
+    i_pad = pad32(i) if i_pad is None else i_pad
+    o_pad = o if o_pad is None else o_pad
+    out = torch.empty((i_pad, kh * kw, o_pad), device=w.device, dtype=torch.float32)
+    L.check(L.load().ddk_pack_conv_weight_dgrad(L.ptr(_f32(w.contiguous())), L.ptr(out), o, i, kh, kw, i_pad, o_pad, L.stream()),
+            "pack_conv_weight_dgrad")
+    return out
+
+
+def zero_stuff2(dy, h_out, w_out):
+    b, h, w, c = dy.shape
+    out = torch.empty((b, h_out, w_out, c), device=dy.device, dtype=torch.float32)
+    L.check(L.load().ddk_zero_stuff2(L.ptr(_f32(dy)), L.ptr(out), b, h, w, h_out, w_out, c, L.stream()), "zero_stuff2")
+    return out
+
+
+def conv_wgrad_(kind, x, dy, grad_w, c_real, cw, c_off):
+    """grad_w (canonical layout, contiguous) += weight gradient of `kind` for the source x (see csrc/conv_wgrad.hip)."""
+    b, h, w, cx = x.shape
+    n = dy.shape[-1]
+    lib = L.load()
+    nbytes = lib.ddk_conv_wgrad_workspace_bytes(kind, b, h, w, cx, n)
+    ws = _ws(x.device, nbytes, "wgrad")
+    L.check(lib.ddk_conv_wgrad(kind, L.ptr(_f32(x)), L.ptr(_f32(dy)), L.ptr(grad_w), b, h, w, cx, c_real, cw, c_off, n,
+                               L.ptr(ws), nbytes, L.stream()), "conv_wgrad")
+    return grad_w
+
+
+def bias_grad(dy, accumulate_into=None):
+    n = dy.shape[-1]
+    out = accumulate_into if accumulate_into is not None else torch.empty(n, device=dy.device, dtype=torch.float32)
+    ws = _ws(dy.device, 64 * n * 4, "bias")
+    L.check(L.load().ddk_bias_grad(L.ptr(_f32(dy)), L.ptr(out), dy.numel() // n, n, int(accumulate_into is not None), L.ptr(ws),
+                                   64 * n * 4, L.stream()), "bias_grad")
+    return out
+
+
+def groupnorm_mish_train(x, gamma, beta, temb=None, addend=None, drop_p=0.0, seed=0, layer=0, groups=GN_GROUPS, eps=GN_EPS):
+    b, h, w, c = x.shape
+    out = torch.empty_like(x)
+    stride = temb.stride(0) if temb is not None else 0
+    L.check(L.load().ddk_groupnorm_mish_train_fwd(L.ptr(_f32(x)), L.ptr(gamma), L.ptr(beta),
+                                                  temb.data_ptr() if temb is not None else None, stride, L.ptr(addend),
+                                                  float(drop_p), seed, layer, L.ptr(out), b, h * w, c, groups, eps, L.stream()),
+            "groupnorm_mish_train_fwd")
+    return out
+
+
+def groupnorm_mish_bwd(x, gamma, beta, dy, drop_p=0.0, seed=0, layer=0, groups=GN_GROUPS, eps=GN_EPS):
+    """-> dx, dtemb [B,C], dgamma [C], dbeta [C]"""
+    b, h, w, c = x.shape
+    dx = torch.empty_like(x)
+    part = torch.empty((3, b, c), device=x.device, dtype=torch.float32)
+    lib = L.load()
+    L.check(lib.ddk_groupnorm_mish_bwd(L.ptr(_f32(x)), L.ptr(gamma), L.ptr(beta), float(drop_p), seed, layer, L.ptr(_f32(dy)),
+                                       L.ptr(dx), L.ptr(part), b, h * w, c, groups, eps, L.stream()), "groupnorm_mish_bwd")
+    dg = torch.empty(c, device=x.device, dtype=torch.float32)
+    db = torch.empty(c, device=x.device, dtype=torch.float32)
+    L.check(lib.ddk_rows_sum(L.ptr(part[1]), b, c, L.ptr(dg), c, 0, L.stream()), "rows_sum")
+    L.check(lib.ddk_rows_sum(L.ptr(part[2]), b, c, L.ptr(db), c, 0, L.stream()), "rows_sum")
+    return dx, part[0], dg, db
+
+
+def rows_sum(rows, nrows, row_stride, n):
+    out = torch.empty(n, device=rows.device, dtype=torch.float32)
+    L.check(L.load().ddk_rows_sum(rows.data_ptr(), nrows, row_stride, L.ptr(out), n, 0, L.stream()), "rows_sum")
+    return out
+
+
+def chan_layernorm_bwd(x, g, dy, eps=LN_EPS):
+    c = x.shape[-1]
+    m = x.numel() // c
+    dx = torch.empty_like(x)
+    max_parts = 512
+    part = torch.empty((2, max_parts, c), device=x.device, dtype=torch.float32)
+    n = C.c_int(0)
+    lib = L.load()
+    L.check(lib.ddk_chan_layernorm_bwd(L.ptr(_f32(x)), L.ptr(g.reshape(-1)), L.ptr(_f32(dy)), L.ptr(dx), L.ptr(part), max_parts,
+                                       C.byref(n), m, c, eps, L.stream()), "chan_layernorm_bwd")
+    # the kernel laid the rows out as [2][nparts][C] with nparts = n.value
+    flat = part.reshape(-1)
+    dg = rows_sum(flat[:n.value * c], n.value, c, c)
+    db = rows_sum(flat[n.value * c:2 * n.value * c], n.value, c, c)
+    return dx, dg, db
+
+
+def linattn_train(qkv, heads=4):
+    out, ctx = linattn(qkv, heads)
+    b, h, w, _ = qkv.shape
+    stats = torch.empty((b, heads, 2, 32), device=qkv.device, dtype=torch.float32)
+    L.check(L.load().ddk_linattn_stats(L.ptr(qkv), L.ptr(stats), b, h * w, heads, L.stream()), "linattn_stats")
+    return out, ctx, stats
+
+
+def linattn_bwd(qkv, dout, ctx, stats, heads=4):
+    b, h, w, _ = qkv.shape
+    dctx = torch.empty_like(ctx)
+    dqkv = torch.empty_like(qkv)
+    L.check(L.load().ddk_linattn_bwd(L.ptr(qkv), L.ptr(_f32(dout)), L.ptr(ctx), L.ptr(stats), L.ptr(dctx), L.ptr(dqkv), b, h * w,
+                                     heads, L.stream()), "linattn_bwd")
+    return dqkv
+
+
+def mish_bwd(x, dy):
+    dx = torch.empty_like(x)
+    L.check(L.load().ddk_mish_bwd(L.ptr(_f32(x)), L.ptr(_f32(dy)), L.ptr(dx), x.numel(), L.stream()), "mish_bwd")
+    return dx
+
+
+def tanh_bwd(y, dy):
+    dx = torch.empty_like(y)
+    L.check(L.load().ddk_tanh_bwd(L.ptr(_f32(y)), L.ptr(_f32(dy)), L.ptr(dx), y.numel(), L.stream()), "tanh_bwd")
+    return dx
+
+
+def avgpool2_bwd(dy):
+    b, h2, w2, c = dy.shape
+    dx = torch.empty((b, 2 * h2, 2 * w2, c), device=dy.device, dtype=torch.float32)
+    L.check(L.load().ddk_avgpool2_bwd(L.ptr(_f32(dy)), L.ptr(dx), b, 2 * h2, 2 * w2, c, L.stream()), "avgpool2_bwd")
+    return dx
+
+
+def upsample_nearest2_bwd(dy):
+    b, h2, w2, c = dy.shape
+    dx = torch.empty((b, h2 // 2, w2 // 2, c), device=dy.device, dtype=torch.float32)
+    L.check(L.load().ddk_upsample_nearest2_bwd(L.ptr(_f32(dy)), L.ptr(dx), b, h2 // 2, w2 // 2, c, L.stream()), "upsample_nearest2_bwd")
+    return dx
+
+
+def sq_err_grad(a, b, scale):
+    out = torch.empty_like(b)
+    bsz = a.shape[0]
+    L.check(L.load().ddk_sq_err_grad(L.ptr(_f32(a)), L.ptr(_f32(b)), L.ptr(_f32(scale)), L.ptr(out), bsz, a.numel() // bsz, L.stream()),
+            "sq_err_grad")
+    return out
+
+
+def scale_per_sample(x, scale):
+    out = torch.empty_like(x)
+    bsz = x.shape[0]
+    L.check(L.load().ddk_scale_per_sample(L.ptr(_f32(x)), L.ptr(_f32(scale)), L.ptr(out), bsz, x.numel() // bsz, L.stream()),
+            "scale_per_sample")
+    return out
+
+
+def conv1x1_small_n_bwd(a, w, dy):
+    """-> da, dw [n_out, C], db [n_out]"""
+    c = a.shape[-1]
+    n_out = w.shape[0]
+    m = a.numel() // c
+    da = torch.empty_like(a)
+    max_rows = 1024
+    rowlen = n_out * c + n_out
+    part = torch.empty((max_rows, rowlen), device=a.device, dtype=torch.float32)
+    n = C.c_int(0)
+    L.check(L.load().ddk_conv1x1_small_n_bwd(L.ptr(_f32(a)), L.ptr(w.reshape(n_out, c).contiguous()), L.ptr(_f32(dy)), L.ptr(da),
+                                             L.ptr(part), max_rows, C.byref(n), m, c, n_out, L.stream()), "conv1x1_small_n_bwd")
+    tot = rows_sum(part, n.value, rowlen, rowlen)
+    return da, tot[:n_out * c].reshape(n_out, c), tot[n_out * c:]
+
+
+def small_gemm(mode, a, b, out, m, n, k, lda, ldb, ldc, accumulate=False):
+    L.check(L.load().ddk_small_gemm(mode, a.data_ptr(), b.data_ptr(), out.data_ptr(), m, n, k, lda, ldb, ldc, int(accumulate), L.stream()),
+            "small_gemm")
+    return out
+
+
+def sincos_embed(t, freqs):
+    bsz, dim = t.shape[0], freqs.numel() * 2
+    e = torch.empty((bsz, dim), device=t.device, dtype=torch.float32)
+    L.check(L.load().ddk_sincos_embed(L.ptr(t), L.ptr(freqs), L.ptr(e), bsz, dim, L.stream()), "sincos_embed")
+    return e
+
+
+def bias_act_(y, bias, want_act):
+    act = torch.empty_like(y) if want_act else None
+    L.check(L.load().ddk_bias_act(L.ptr(y), L.ptr(bias), L.ptr(act), y.shape[0], y.shape[1], L.stream()), "bias_act")
+    return act
+
+
+# ------------------------------------------------------------------ optimiser (flat buffers)
+def grad_norm_clip(flat_grad, max_norm):
+    """-> device tensor [norm, clip_coef] (no host sync)"""
+    out = torch.empty(2, device=flat_grad.device, dtype=torch.float32)
+    ws = _ws(flat_grad.device, 4096, "norm")
+    L.check(L.load().ddk_grad_norm_clip(L.ptr(flat_grad), flat_grad.numel(), float(max_norm), L.ptr(out), L.ptr(ws), 4096, L.stream()),
+            "grad_norm_clip")
+    return out
+
+
+def adam_step_(p, g, m, v, lr, step, clip=None, betas=(0.9, 0.999), eps=1e-8):
+    L.check(L.load().ddk_adam_step(L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), p.numel(), float(lr), float(betas[0]), float(betas[1]),
+                                   float(eps), int(step), L.ptr(clip), L.stream()), "adam_step")
+
+
+def ema_update_(p_ema, p, decay):
+    L.check(L.load().ddk_ema_update(L.ptr(p_ema), L.ptr(p), p.numel(), float(decay), L.stream()), "ema_update")

@@ -107,6 +107,10 @@ class DDPM(nn.Module):
         """x_t = sqrt(abar_t) x + sqrt(1 - abar_t) eps (ddpm.py:256-273), one fused kernel."""
         assert x.shape == eps.shape
         self._check_device(x)
+        if torch.is_grad_enabled() and x.requires_grad:      # only the non-autoencoder dDDPM loss differentiates through z_t
+            from ddk import autograd as AG
+            return AG.QSampleFn.apply(x.contiguous(), eps.contiguous(), t.contiguous(), self.sqrt_alphas_cumprod,
+                                      self.sqrt_one_minus_alphas_cumprod)
         return ops.q_sample(x.contiguous(), eps.contiguous(), t.contiguous(), self.sqrt_alphas_cumprod,
                             self.sqrt_one_minus_alphas_cumprod)
 

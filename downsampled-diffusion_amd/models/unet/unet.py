@@ -83,10 +83,13 @@ class Unet(nn.Module):
         return self._plan.flops(batch, height, width)
 
     # ------------------------------------------------------------------ forward
+    def _wants_grad(self, x):
+        return torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))
+
     def forward_nhwc(self, x, time):
         """x [B,H,W,C_in] fp32 on the device, time [B] integer -> eps_hat [B,H,W,C_in]."""
-        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
-            from trainers.autograd_unet import unet_forward_autograd   # training path (HIP forward + backward)
+        if self._wants_grad(x):
+            from trainers.autograd_unet import unet_forward_autograd   # training path: HIP forward + backward kernels
             return unet_forward_autograd(self, x, time)
         if self.training and self.downs[0][0].dropout.p > 0:
             raise DDKError("Unet in train() mode with dropout > 0 outside autograd: call model.eval() for inference")
@@ -98,5 +101,9 @@ class Unet(nn.Module):
             raise DDKError("Unet.forward: input is on the CPU; the HIP path needs ROCm device tensors (no CPU fallback)")
         if x.dim() != 4 or x.shape[1] != self.in_channels:
             raise DDKError(f"Unet.forward: expected B x {self.in_channels} x H x W, got {tuple(x.shape)}")
+        if self._wants_grad(x):
+            from ddk import autograd as AG
+            y = self.forward_nhwc(AG.NchwToNhwcFn.apply(x.contiguous().float(), x.shape[1]), time)
+            return AG.NhwcToNchwFn.apply(y, y.shape[-1])
         y = self.forward_nhwc(ops.nchw_to_nhwc(x.contiguous().float()), time)
         return ops.nhwc_to_nchw(y)

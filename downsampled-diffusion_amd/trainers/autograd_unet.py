@@ -1,18 +1,152 @@
-"""Differentiable (forward + backward HIP kernels) path for training.  Placeholder entry points: the
-backward kernel set is not built yet, so these fail loudly rather than fall back."""
-from ddk.lib import DDKError
+"""Differentiable forward of the UNet / resamplers / loss for TRAINING: the same arithmetic as the native inference plan,
+composed from ddk.autograd Functions (HIP forward + HIP backward kernels) so ``objective.backward()`` of
+reference trainers/trainer_ddpm.py:124-128 works unchanged on the drop-in modules.
 
-_MSG = ("the training (autograd) path needs the HIP backward kernels, which are not built yet; "
-        "wrap inference in torch.no_grad() / call .eval()")
+Follows reference models/unet/unet.py:74-104 (train mode: Dropout(p) between the two Blocks of the down-path
+ResnetBlocks, unet.py:46-47 vs :54-63) and models/downsampled/convblocks.py:112-159.
+"""
+import torch
+from torch import nn
+
+from ddk import autograd as AG
+from ddk import ops
+from ddk.plan import sinusoidal_freqs
+
+HEADS = 4
+
+
+class _Seeds:
+    """Dropout seeds: one 62-bit seed per forward (from torch's CPU generator: reproducible under manual_seed),
+    a distinct layer id per dropout site."""
+
+    def __init__(self, training):
+        self.seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if training else 0
+        self.layer = 0
+
+    def next(self):
+        self.layer += 1
+        return self.seed, self.layer
+
+
+def _block(blk, x, x2=None, temb=None, addend=None, drop_p=0.0, seeds=None):
+    conv, norm = blk.block[0], blk.block[1]
+    raw = AG.conv(ops.CONV3X3_S1, x, conv.weight, conv.bias, x2=x2)
+    seed, layer = seeds.next() if (seeds is not None and drop_p > 0) else (0, 0)
+    return AG.groupnorm_mish(raw, norm.weight, norm.bias, temb=temb, addend=addend, drop_p=drop_p, seed=seed, layer=layer,
+                             groups=blk.groups, eps=norm.eps)
+
+
+def _resnet(rb, x, temb_slice, x2=None, seeds=None):
+    """blocks.py:105-115: h = drop(Block1(x) + shift); out = Block2(h) + res(x)"""
+    p = rb.dropout.p if rb.training else 0.0
+    h = _block(rb.block1, x, x2=x2, temb=temb_slice, drop_p=p, seeds=seeds)
+    if isinstance(rb.res_conv, nn.Identity):
+        res = x
+    else:
+        res = AG.conv(ops.CONV1X1, x, rb.res_conv.weight, rb.res_conv.bias, x2=x2)
+    return _block(rb.block2, h, addend=res)
+
+
+def _attention(res_mod, x):
+    """Residual(PreNorm(LinearAttention)): blocks.py:8-14,63-71,126-134"""
+    pre = res_mod.fn
+    att = pre.fn
+    xn = AG.ChanLayerNormFn.apply(x, pre.norm.g, pre.norm.b, pre.norm.eps)
+    qkv = AG.conv(ops.CONV1X1, xn, att.to_qkv.weight)
+    o = AG.LinAttnFn.apply(qkv, att.heads)
+    return AG.conv(ops.CONV1X1, o, att.to_out.weight, att.to_out.bias, resid=x)
+
+
+def _resnet_blocks(unet):
+    """All ResnetBlocks in forward order (the order of the time-shift table's column blocks)."""
+    blocks = []
+    for lvl in unet.downs:
+        blocks += [lvl[0], lvl[1]]
+    blocks += [unet.mid_block1, unet.mid_block2]
+    for lvl in unet.ups:
+        blocks += [lvl[0], lvl[1]]
+    return blocks
 
 
 def unet_forward_autograd(unet, x, time):
-    raise DDKError("Unet: " + _MSG)
+    """x [B,H,W,C_in] (NHWC, unpadded), time [B] -> eps_hat [B,H,W,C_in], differentiable w.r.t. x and every parameter."""
+    dev = x.device
+    seeds = _Seeds(unet.training)
+    rbs = _resnet_blocks(unet)
+    freqs = getattr(unet, "_freqs_dev", None)
+    if freqs is None or freqs.device != dev:
+        freqs = sinusoidal_freqs(unet.dim).to(dev)
+        unet._freqs_dev = freqs
+    mlp_args = []
+    for rb in rbs:
+        mlp_args += [rb.mlp[1].weight, rb.mlp[1].bias]
+    temb_all = AG.TimeEmbedFn.apply(time.to(torch.int64).contiguous(), freqs, unet.time_mlp[1].weight, unet.time_mlp[1].bias,
+                                    unet.time_mlp[3].weight, unet.time_mlp[3].bias, *mlp_args)
+    offs, o = {}, 0
+    for rb in rbs:
+        co = rb.mlp[1].weight.shape[0]
+        offs[id(rb)] = (o, co)
+        o += co
+
+    def shift(rb):
+        a, co = offs[id(rb)]
+        return temb_all[:, a:a + co]
+
+    c_in = x.shape[-1]
+    if c_in % 32:
+        h = AG.NhwcToNchwFn.apply(x, c_in)                   # pad channels through the layout kernels (differentiable)
+        h = AG.NchwToNhwcFn.apply(h, ops.pad32(c_in))
+    else:
+        h = x
+    skips = []
+    for lvl in unet.downs:
+        rb1, rb2, attn, down = lvl
+        h = _resnet(rb1, h, shift(rb1), seeds=seeds)
+        h = _resnet(rb2, h, shift(rb2), seeds=seeds)
+        h = _attention(attn, h)
+        skips.append(h)
+        if not isinstance(down, nn.Identity):
+            h = AG.conv(ops.CONV3X3_S2, h, down.conv.weight, down.conv.bias)
+    h = _resnet(unet.mid_block1, h, shift(unet.mid_block1), seeds=seeds)
+    h = _attention(unet.mid_attn, h)
+    h = _resnet(unet.mid_block2, h, shift(unet.mid_block2), seeds=seeds)
+    for lvl in unet.ups:
+        rb1, rb2, attn, up = lvl
+        h = _resnet(rb1, h, shift(rb1), x2=skips.pop(), seeds=seeds)
+        h = _resnet(rb2, h, shift(rb2), seeds=seeds)
+        h = _attention(attn, h)
+        h = AG.conv(ops.CONVT4X4_S2, h, up.conv.weight, up.conv.bias)
+    h = _block(unet.final_conv[0], h)
+    last = unet.final_conv[1]
+    return AG.SmallNConvFn.apply(h, last.weight, last.bias)
 
 
-def sq_err_sum_autograd(eps, eps_hat):
-    raise DDKError("loss: " + _MSG)
+def sq_err_sum_autograd(a, b):
+    """per-sample sum over C,H,W of (a-b)^2 (ddpm.py:279 + utils/utils.py:34-40)"""
+    return AG.SqErrSumFn.apply(a.contiguous(), b.contiguous())
 
 
-def resnet_forward_autograd(net, x, final_tanh):
-    raise DDKError("ConvResNet: " + _MSG)
+def _conv_res_block(blk, x):
+    """convblocks.py:112-130 with the pre-activations kept for the backward (no fused post-Mish in training)."""
+    h = AG.conv(ops.CONV1X1, AG.MishFn.apply(x), blk.c1.weight, blk.c1.bias)
+    h = AG.conv(ops.CONV3X3_S1, AG.MishFn.apply(h), blk.c2.weight, blk.c2.bias)
+    h = AG.conv(ops.CONV3X3_S1, AG.MishFn.apply(h), blk.c3.weight, blk.c3.bias)
+    out = AG.conv(ops.CONV1X1, AG.MishFn.apply(h), blk.c4.weight, blk.c4.bias, resid=x if blk.residual else None)
+    if blk.upsample:
+        out = AG.UpNearest2Fn.apply(out)
+    elif blk.downsample:
+        out = AG.AvgPool2Fn.apply(out)
+    return out
+
+
+def resnet_forward_autograd(net, x_nchw, final_tanh):
+    """ConvResNet (dDDPM encoder / decoder) on an NCHW tensor -> NCHW, differentiable."""
+    h = AG.NchwToNhwcFn.apply(x_nchw.contiguous().float(), ops.pad32(x_nchw.shape[1]))
+    first, last = net.conv[0], net.conv[-1]
+    h = AG.conv(ops.CONV1X1, h, first.weight, first.bias)
+    for blk in list(net.conv)[1:-1]:
+        h = _conv_res_block(blk, h)
+    out = AG.SmallNConvFn.apply(h, last.weight, last.bias)
+    if final_tanh:
+        out = AG.TanhFn.apply(out)
+    return AG.NhwcToNchwFn.apply(out, out.shape[-1])

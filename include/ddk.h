@@ -56,7 +56,8 @@ enum ddk_conv_kind {
     DDK_CONV3X3_S1 = 0, /* Block conv, blocks.py:78 */
     DDK_CONV3X3_S2 = 1, /* Downsample, blocks.py:44 */
     DDK_CONV1X1 = 2,    /* res_conv / to_qkv / to_out, blocks.py:103,123-124 */
-    DDK_CONVT4X4_S2 = 3 /* Upsample, blocks.py:35 */
+    DDK_CONVT4X4_S2 = 3, /* Upsample, blocks.py:35 */
+    DDK_CONV4X4_S2 = 4   /* Conv2d k4 s2 p1: the input gradient of Upsample (weights: its (I,O,4,4) tensor read as OIHW) */
 };
 
 typedef struct ddk_conv_args {
@@ -198,6 +199,58 @@ typedef struct ddk_sampler_args {
 
 size_t ddk_sampler_workspace_bytes(const ddk_unet* u, int B, int H, int W);
 int ddk_sampler_run(const ddk_sampler_args* a, ddk_stream_t s);
+
+
+/* ================================================================== training path (backward kernels) ==
+ * Autograd counterparts of the ops above, driven by objective.backward() in trainers/trainer_ddpm.py:124-128.
+ * Parameter gradients ACCUMULATE into the caller's (canonical-layout) gradient tensors. */
+
+/* input gradient of conv3x3 s1 / 1x1: run ddk_conv_forward on dY with this operand; [I_pad][taps][O_pad], taps flipped */
+int ddk_pack_conv_weight_dgrad(const float* w_oihw, float* dst, int O, int I, int KH, int KW, int i_pad, int o_pad,
+                               ddk_stream_t s);
+/* [B][H][W][C] -> [B][Ho][Wo][C], values on the even grid, zeros elsewhere (input gradient of the stride-2 conv) */
+int ddk_zero_stuff2(const float* in, float* out, int B, int H, int W, int Ho, int Wo, int C, ddk_stream_t s);
+size_t ddk_conv_wgrad_workspace_bytes(int kind, int B, int H, int W, int cx, int N);
+/* grad_w[(n*cw + c_off + c)*taps + tap] += sum_m dy[m][n] x[pix(m)+tap][c], c < c_real (see csrc/conv_wgrad.hip) */
+int ddk_conv_wgrad(int kind, const float* x, const float* dy, float* grad_w, int B, int H, int W, int cx, int c_real,
+                   int cw, int c_off, int N, void* workspace, size_t workspace_bytes, ddk_stream_t s);
+/* grad_b[n] (+)= sum_m dy[m][n]; workspace >= 64*N floats */
+int ddk_bias_grad(const float* dy, float* grad_b, long long M, int N, int accumulate, void* workspace,
+                  size_t workspace_bytes, ddk_stream_t s);
+/* y = dropout_p(mish(gn(x)) + temb) + addend; the keep mask is a pure function of (seed, layer, element) */
+int ddk_groupnorm_mish_train_fwd(const float* x, const float* gamma, const float* beta, const float* temb,
+                                 int temb_stride, const float* addend, float drop_p, uint64_t seed, uint32_t layer,
+                                 float* out, int B, int HW, int C, int groups, float eps, ddk_stream_t s);
+/* dx and per-sample partial rows part[3][B][C] = (dtemb, dgamma, dbeta); d(addend) is dy itself */
+int ddk_groupnorm_mish_bwd(const float* x, const float* gamma, const float* beta, float drop_p, uint64_t seed,
+                           uint32_t layer, const float* dy, float* dx, float* part, int B, int HW, int C, int groups,
+                           float eps, ddk_stream_t s);
+int ddk_rows_sum(const float* rows, int nrows, long long row_stride, float* out, int n, int accumulate, ddk_stream_t s);
+int ddk_chan_layernorm_bwd(const float* x, const float* g, const float* dy, float* dx, float* part, int max_parts,
+                           int* nparts_out, long long M, int C, float eps, ddk_stream_t s);
+int ddk_linattn_stats(const float* qkv, float* stats, int B, int HW, int heads, ddk_stream_t s);
+int ddk_linattn_bwd(const float* qkv, const float* dout, const float* ctx, const float* stats, float* dctx,
+                    float* dqkv, int B, int HW, int heads, ddk_stream_t s);
+int ddk_mish_bwd(const float* x, const float* dy, float* dx, long long n, ddk_stream_t s);
+int ddk_tanh_bwd(const float* y, const float* dy, float* dx, long long n, ddk_stream_t s);
+int ddk_avgpool2_bwd(const float* dy, float* dx, int B, int H, int W, int C, ddk_stream_t s);
+int ddk_upsample_nearest2_bwd(const float* dy, float* dx, int B, int H, int W, int C, ddk_stream_t s);
+int ddk_sq_err_grad(const float* a, const float* b, const float* scale, float* out, int B, long long per,
+                    ddk_stream_t s);
+int ddk_scale_per_sample(const float* x, const float* scale, float* out, int B, long long per, ddk_stream_t s);
+int ddk_conv1x1_small_n_bwd(const float* a, const float* w, const float* dy, float* da, float* part, int max_rows,
+                            int* nrows_out, long long M, int C, int n_out, ddk_stream_t s);
+int ddk_small_gemm(int mode, const float* A, const float* Bm, float* Cm, int M, int N, int K, int lda, int ldb,
+                   int ldc, int accumulate, ddk_stream_t s);
+int ddk_sincos_embed(const int64_t* t, const float* freqs, float* e, int B, int dim, ddk_stream_t s);
+int ddk_bias_act(float* y, const float* bias, float* act, long long M, int N, ddk_stream_t s);
+/* optimiser on flat fp32 buffers (trainer_ddpm.py:142-148, trainers/ema.py:36-44) */
+int ddk_grad_norm_clip(const float* g, long long n, float max_norm, float* out2, void* workspace,
+                       size_t workspace_bytes, ddk_stream_t s);
+/* scalars are doubles: torch derives 1-beta, the bias corrections and lr/bc1 in double before rounding to fp32 */
+int ddk_adam_step(float* p, const float* g, float* m, float* v, long long n, double lr, double beta1, double beta2,
+                  double eps, int step, const float* clip2, ddk_stream_t s);
+int ddk_ema_update(float* p_ema, const float* p, long long n, float decay, ddk_stream_t s);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,259 @@
+"""Backward-kernel parity on the GPU: every HIP backward op (through ddk.autograd) against torch-CPU autograd of the
+oracle's functional ops on the same inputs, then a whole training objective against the reference goldens (G6)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import ddpm_cfg, dddpm_cfg, det_load, golden, rel_err, to_nchw, to_nhwc
+from oracle import unet_ref as U
+from utils import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+@pytest.fixture(scope="module")
+def AG():
+    from ddk import autograd as ag
+    return ag
+
+
+def grads_cpu(fn, *tensors):
+    leaves = [t.clone().requires_grad_(True) for t in tensors]
+    out = fn(*leaves)
+    g = rnd(*out.shape, seed=999)
+    gs = torch.autograd.grad(out, leaves, g, allow_unused=True)
+    return out.detach(), g, gs
+
+
+CONV_BWD = [
+    ("s1", 2, 8, 8, 32, 0, 64), ("s1", 4, 16, 16, 128, 0, 128), ("s1", 2, 8, 8, 64, 64, 64), ("s1", 3, 5, 7, 32, 0, 32),
+    ("s1", 32, 4, 4, 256, 0, 256), ("s2", 4, 16, 16, 64, 0, 64), ("s2", 2, 8, 8, 128, 0, 128),
+    ("1x1", 4, 8, 8, 128, 0, 384), ("1x1", 2, 4, 4, 64, 64, 128), ("T", 4, 4, 4, 64, 0, 64), ("T", 2, 8, 8, 128, 0, 128),
+]
+
+
+@pytest.mark.parametrize("kind,B,H,W,c0,c1,N", CONV_BWD)
+def test_conv_backward(AG, kind, B, H, W, c0, c1, N):
+    from ddk import ops
+    cin = c0 + c1
+    x = rnd(B, cin, H, W, seed=1)
+    bias = rnd(N, seed=3, scale=0.1)
+    if kind == "T":
+        w = rnd(cin, N, 4, 4, seed=2, scale=(cin * 4) ** -0.5)
+        f = lambda xx, ww, bb: F.conv_transpose2d(xx, ww, bb, stride=2, padding=1)
+        code = ops.CONVT4X4_S2
+    else:
+        k = 1 if kind == "1x1" else 3
+        w = rnd(N, cin, k, k, seed=2, scale=(cin * k * k) ** -0.5)
+        f = lambda xx, ww, bb: F.conv2d(xx, ww, bb, stride=2 if kind == "s2" else 1, padding=k // 2)
+        code = {"s1": ops.CONV3X3_S1, "s2": ops.CONV3X3_S2, "1x1": ops.CONV1X1}[kind]
+    out_ref, g, (gx, gw, gb) = grads_cpu(f, x, w, bias)
+    xh = to_nhwc(x).to(DEV)
+    x0 = xh[..., :c0].contiguous().requires_grad_(True)
+    x1 = xh[..., c0:].contiguous().requires_grad_(True) if c1 else None
+    wd, bd = w.to(DEV).requires_grad_(True), bias.to(DEV).requires_grad_(True)
+    out = AG.conv(code, x0, wd, bd, x2=x1)
+    assert rel_err(to_nchw(out.detach().cpu()), out_ref) < 2e-5
+    out.backward(to_nhwc(g).to(DEV))
+    gxh = to_nhwc(gx)
+    assert rel_err(x0.grad.cpu(), gxh[..., :c0]) < 3e-5
+    if c1:
+        assert rel_err(x1.grad.cpu(), gxh[..., c0:]) < 3e-5
+    assert rel_err(wd.grad.cpu(), gw) < 3e-5
+    assert rel_err(bd.grad.cpu(), gb) < 3e-5
+
+
+def test_conv_backward_padded_input_and_residual(AG):
+    """first UNet conv: 8 real channels inside a 32-channel padded tensor; to_out-style fused residual"""
+    from ddk import ops
+    x, w, b = rnd(2, 8, 8, 8, seed=4), rnd(64, 8, 3, 3, seed=5, scale=0.1), rnd(64, seed=6, scale=0.1)
+    r = rnd(2, 64, 8, 8, seed=7)
+    out_ref, g, (gx, gw, gb, gr) = grads_cpu(lambda a, ww, bb, rr: F.conv2d(a, ww, bb, padding=1) + rr, x, w, b, r)
+    xp = ops.nchw_to_nhwc(x.to(DEV), 32).requires_grad_(True)
+    wd, bd, rd = w.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True), to_nhwc(r).to(DEV).requires_grad_(True)
+    out = AG.conv(ops.CONV3X3_S1, xp, wd, bd, resid=rd)
+    out.backward(to_nhwc(g).to(DEV))
+    assert rel_err(to_nchw(out.detach().cpu()), out_ref) < 2e-5
+    assert rel_err(xp.grad[..., :8].cpu(), to_nhwc(gx)) < 3e-5 and float(xp.grad[..., 8:].abs().max()) == 0.0
+    assert rel_err(wd.grad.cpu(), gw) < 3e-5 and rel_err(bd.grad.cpu(), gb) < 3e-5 and rel_err(rd.grad.cpu(), to_nhwc(gr)) < 1e-6
+
+
+@pytest.mark.parametrize("B,H,W,C", [(2, 8, 8, 32), (4, 16, 16, 128), (8, 32, 32, 128), (3, 4, 4, 256), (2, 16, 16, 256)])
+def test_groupnorm_mish_backward(AG, B, H, W, C):
+    x = rnd(B, C, H, W, seed=10, scale=2.0) + 0.3
+    g, b = 1 + 0.1 * rnd(C, seed=11), 0.1 * rnd(C, seed=12)
+    temb, add = rnd(B, C, seed=13), rnd(B, C, H, W, seed=14)
+    f = lambda xx, gg, bb, tt, aa: U.mish(F.group_norm(xx, 8, gg, bb, 1e-5)) + tt[:, :, None, None] + aa
+    out_ref, go, (gx, gg, gb, gt, ga) = grads_cpu(f, x, g, b, temb, add)
+    xd = to_nhwc(x).to(DEV).requires_grad_(True)
+    gd, bd = g.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+    td, ad = temb.to(DEV).requires_grad_(True), to_nhwc(add).to(DEV).requires_grad_(True)
+    out = AG.groupnorm_mish(xd, gd, bd, temb=td, addend=ad)
+    assert rel_err(to_nchw(out.detach().cpu()), out_ref) < 5e-6
+    out.backward(to_nhwc(go).to(DEV))
+    assert rel_err(xd.grad.cpu(), to_nhwc(gx)) < 3e-5
+    assert rel_err(gd.grad.cpu(), gg) < 3e-5 and rel_err(bd.grad.cpu(), gb) < 3e-5
+    assert rel_err(td.grad.cpu(), gt) < 3e-5 and rel_err(ad.grad.cpu(), to_nhwc(ga)) < 1e-6
+
+
+def test_groupnorm_dropout_consistency(AG):
+    """Dropout(p): ~p of the outputs are zeroed and scaled by 1/(1-p); the backward uses the identical mask."""
+    B, H, W, C, p = 4, 16, 16, 128, 0.1
+    x = (rnd(B, H, W, C, seed=20) + 3.0).to(DEV).requires_grad_(True)      # mish(gn)+temb is never exactly 0 here
+    g, b = torch.ones(C, device=DEV), torch.zeros(C, device=DEV)
+    temb = torch.full((B, C), 5.0, device=DEV).requires_grad_(True)
+    y = AG.groupnorm_mish(x, g, b, temb=temb, drop_p=p, seed=1234, layer=3)
+    y0 = AG.groupnorm_mish(x.detach(), g, b, temb=temb.detach(), drop_p=0.0)
+    dropped = (y == 0)
+    frac = float(dropped.float().mean())
+    assert abs(frac - p) < 0.01
+    assert torch.allclose(y[~dropped], y0[~dropped] / (1 - p), rtol=1e-6)
+    assert torch.equal(y, AG.groupnorm_mish(x, g, b, temb=temb, drop_p=p, seed=1234, layer=3))          # deterministic
+    assert not torch.equal(dropped, AG.groupnorm_mish(x, g, b, temb=temb, drop_p=p, seed=1234, layer=4) == 0)
+    y.sum().backward()
+    # dtemb[b][c] = sum_hw mask/(1-p)
+    want = (~dropped).float().sum(dim=(1, 2)) / (1 - p)
+    assert torch.allclose(temb.grad, want, rtol=1e-5)
+
+
+@pytest.mark.parametrize("C", [32, 64, 128, 256])
+def test_chan_layernorm_backward(AG, C):
+    x = rnd(3, C, 6, 5, seed=30, scale=2.0) + 0.5
+    g, b = 1 + 0.1 * rnd(1, C, 1, 1, seed=31), 0.1 * rnd(1, C, 1, 1, seed=32)
+    out_ref, go, (gx, gg, gb) = grads_cpu(lambda a, gg_, bb_: U.chan_layernorm(a, gg_, bb_), x, g, b)
+    xd = to_nhwc(x).to(DEV).requires_grad_(True)
+    gd, bd = g.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+    out = AG.ChanLayerNormFn.apply(xd, gd, bd, 1e-5)
+    out.backward(to_nhwc(go).to(DEV))
+    assert rel_err(xd.grad.cpu(), to_nhwc(gx)) < 3e-5
+    assert rel_err(gd.grad.cpu(), gg) < 3e-5 and rel_err(bd.grad.cpu(), gb) < 3e-5
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 4, 4), (3, 8, 8), (2, 16, 16), (1, 10, 13)])
+def test_linattn_backward(AG, B, H, W):
+    qkv = rnd(B, 384, H, W, seed=40, scale=1.2)
+
+    def f(t):
+        q, k, v = t.reshape(B, 3, 4, 32, H * W).unbind(1)
+        ctx = torch.einsum("bhdn,bhen->bhde", k.softmax(dim=-1), v)
+        return torch.einsum("bhde,bhdn->bhen", ctx, q).reshape(B, 128, H, W)
+    out_ref, go, (gq,) = grads_cpu(f, qkv)
+    qd = to_nhwc(qkv).to(DEV).requires_grad_(True)
+    out = AG.LinAttnFn.apply(qd, 4)
+    out.backward(to_nhwc(go).to(DEV))
+    assert rel_err(to_nchw(out.detach().cpu()), out_ref) < 1e-5
+    assert rel_err(qd.grad.cpu(), to_nhwc(gq)) < 3e-5
+
+
+def test_small_n_conv_and_elementwise_backward(AG):
+    for C, n_out in ((128, 8), (128, 3), (32, 1), (64, 3)):
+        a, w, b = rnd(2, C, 9, 7, seed=50), rnd(n_out, C, 1, 1, seed=51, scale=C ** -0.5), rnd(n_out, seed=52)
+        out_ref, go, (ga, gw, gb) = grads_cpu(lambda x, ww, bb: F.conv2d(x, ww, bb), a, w, b)
+        ad = to_nhwc(a).to(DEV).requires_grad_(True)
+        wd, bd = w.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+        out = AG.SmallNConvFn.apply(ad, wd, bd)
+        out.backward(to_nhwc(go).to(DEV))
+        assert rel_err(ad.grad.cpu(), to_nhwc(ga)) < 3e-5 and rel_err(wd.grad.cpu(), gw) < 3e-5 and rel_err(bd.grad.cpu(), gb) < 3e-5
+    x = rnd(2, 64, 8, 12, seed=53, scale=3.0)
+    for fn_gpu, fn_cpu in ((AG.MishFn.apply, U.mish), (AG.TanhFn.apply, torch.tanh),
+                           (AG.AvgPool2Fn.apply, lambda t: F.avg_pool2d(t, 2, 2)),
+                           (AG.UpNearest2Fn.apply, lambda t: F.interpolate(t, scale_factor=2))):
+        out_ref, go, (gx,) = grads_cpu(fn_cpu, x)
+        xd = to_nhwc(x).to(DEV).requires_grad_(True)
+        out = fn_gpu(xd)
+        out.backward(to_nhwc(go).to(DEV))
+        assert rel_err(xd.grad.cpu(), to_nhwc(gx)) < 1e-5
+
+
+def test_time_embedding_backward(AG):
+    from ddk.plan import sinusoidal_freqs
+    dim, B = 32, 5
+    t = torch.tensor([0, 3, 250, 731, 999])
+    w1, b1 = rnd(4 * dim, dim, seed=60, scale=dim ** -0.5), rnd(4 * dim, seed=61, scale=0.1)
+    w2, b2 = rnd(dim, 4 * dim, seed=62, scale=(4 * dim) ** -0.5), rnd(dim, seed=63, scale=0.1)
+    mlps = [(rnd(co, dim, seed=64 + i, scale=dim ** -0.5), rnd(co, seed=70 + i, scale=0.1)) for i, co in enumerate((32, 64, 64))]
+
+    def f(w1_, b1_, w2_, b2_, *m):
+        tv = F.linear(U.mish(F.linear(U.sinusoidal_embedding(t, dim), w1_, b1_)), w2_, b2_)
+        a = U.mish(tv)
+        return torch.cat([F.linear(a, m[2 * i], m[2 * i + 1]) for i in range(3)], dim=1)
+    flat = [w1, b1, w2, b2] + [p for pair in mlps for p in pair]
+    out_ref, go, gs = grads_cpu(f, *flat)
+    dev = [p.to(DEV).requires_grad_(True) for p in flat]
+    out = AG.TimeEmbedFn.apply(t.to(DEV), sinusoidal_freqs(dim).to(DEV), *dev)
+    assert rel_err(out.detach().cpu(), out_ref) < 2e-5
+    out.backward(go.to(DEV))
+    for p, g in zip(dev, gs):
+        assert rel_err(p.grad.cpu(), g) < 3e-5
+
+
+def test_optimizer_kernels_match_oracle():
+    from ddk import ops
+    from oracle import train_ref as TR
+    n = 100003
+    p, g = rnd(n, seed=80), rnd(n, seed=81, scale=3.0)
+    m, v = torch.zeros(n), torch.zeros(n)
+    pd, gd, md, vd = p.to(DEV), g.to(DEV), m.to(DEV), v.to(DEV)
+    grads = {"a": g[:5000].clone(), "b": g[5000:].clone()}
+    clipped, total = TR.clip_grads(grads)
+    nc = ops.grad_norm_clip(gd, 1.0).cpu()
+    assert abs(float(nc[0]) / float(total) - 1) < 1e-5
+    gc = torch.cat([clipped["a"], clipped["b"]])
+    for step in (1, 2, 3):
+        p, m, v = TR.adam_step(p, gc, m, v, step, 2e-4)
+        ops.adam_step_(pd, gd, md, vd, 2e-4, step, clip=nc.to(DEV))
+        assert (pd.cpu() - p).abs().max() < 2e-7 and rel_err(md.cpu(), m) < 1e-5 and rel_err(vd.cpu(), v) < 1e-5
+    e = rnd(n, seed=82)
+    ed = e.to(DEV)
+    ops.ema_update_(ed, pd, 0.995)
+    assert (ed.cpu() - (e * 0.995 + (1 - 0.995) * pd.cpu())).abs().max() < 1e-6
+
+
+# ---------------------------------------------------------------- whole objective vs the reference goldens (G6)
+def _g6_model(tag):
+    from models import DDPM, DownsampleDDPM, DownsampleDDPMAutoencoder, Unet
+    if tag == "ddpm":
+        cfg = ddpm_cfg(32, 3, 16)
+        m = DDPM(cfg, Unet(cfg), DEV, 3)
+        return det_load(m).to(DEV).train(), (4, 3, 16, 16), (4, 3, 16, 16)
+    cfg = dddpm_cfg(32, 32, 2)
+    cls = DownsampleDDPMAutoencoder if tag == "dddpm_ae" else DownsampleDDPM
+    return det_load(cls(cfg, Unet(cfg), DEV, 3)).to(DEV).train(), (4, 3, 32, 32), (4, 8, 8, 8)
+
+
+@pytest.mark.parametrize("tag", ["ddpm", "dddpm_ae"])
+def test_objective_and_grads_vs_reference(tag):
+    g = golden("g6_train")
+    model, xshape, eshape = _g6_model(tag)
+    probe = [str(n) for n in g[f"{tag}_probe_names"]]
+    params = dict(model.named_parameters())
+    objs = []
+    for mb in range(2):
+        x = syn.synthetic_input(xshape, f"g6.{tag}.x0{mb}").to(DEV)
+        tt = torch.tensor([0, 40, 500, 999 - mb], device=DEV)
+        eps = syn.synthetic_normal(eshape, f"g6.{tag}.eps0{mb}").to(DEV)
+        model.t_sample = lambda n, tt=tt: tt
+        orig = torch.randn_like
+        torch.randn_like = lambda z, eps=eps: eps
+        try:
+            res = model(x)
+        finally:
+            torch.randn_like = orig
+        obj = res[0] if isinstance(res, tuple) else res
+        if isinstance(res, tuple):
+            assert abs(float(res[1]["latent"]) / float(g[f"{tag}_latent{mb}"]) - 1) < 1e-4
+            assert abs(float(res[1]["recon"]) / float(g[f"{tag}_recon{mb}"]) - 1) < 1e-4
+        (obj / 2).backward()
+        objs.append(float(obj))
+    assert np.allclose(objs, g[f"{tag}_obj0"], rtol=1e-4), (objs, g[f"{tag}_obj0"])
+    for n in probe:
+        assert rel_err(params[n].grad.cpu(), g[f"{tag}_grad_{n}"]) < 1e-3, n
+    total = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in model.parameters() if p.grad is not None))
+    assert abs(float(total) / float(g[f"{tag}_gradnorm0"]) - 1) < 1e-3
