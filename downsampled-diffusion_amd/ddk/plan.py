@@ -35,6 +35,9 @@ class UnetPlan:
         self._ws = None
         self._ws_key = None
 
+    def __deepcopy__(self, memo):
+        return None     # a copied module (EMA) builds its own native plan on first use
+
     def __del__(self):
         try:
             if getattr(self, "handle", None):

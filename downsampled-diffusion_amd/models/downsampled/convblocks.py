@@ -73,6 +73,13 @@ class ConvResNet(nn.Module):
         self.in_channels, self.out_channels, self.dim = in_channels, out_channels, dim
         self._packed = _Packed()
 
+    def invalidate_plan(self):
+        self._packed._store.clear()
+        for m in self.conv:
+            pk = getattr(m, "_packed", None)
+            if pk is not None:
+                pk._store.clear()
+
     def forward_nhwc(self, x, final_tanh=False):
         """x [B,H,W,pad32(in_channels)] -> [B,H',W',out_channels]; optional fused-after tanh (dddpm.py:99,110)."""
         first, last = self.conv[0], self.conv[-1]

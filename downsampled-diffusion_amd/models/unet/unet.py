@@ -76,6 +76,15 @@ class Unet(nn.Module):
             self._plan_tag = tag
         return self._plan
 
+    def invalidate_plan(self):
+        """Force a re-pack of the weights at the next forward (used after in-place optimiser / EMA kernels, which
+        update the parameters behind torch's version counters)."""
+        self._plan_tag = None
+        for m in self.modules():
+            pk = getattr(m, "_packed", None)
+            if pk is not None:
+                pk._store.clear()
+
     def flops(self, batch, height, width):
         """Algorithmic FLOPs (2*MAC) of one forward."""
         if self._plan is None:

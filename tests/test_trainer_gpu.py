@@ -1,0 +1,132 @@
+"""Training harness on the GPU: two optimiser steps (2 micro-batches each, clip 1.0, Adam, EMA reset + lerp) against
+the reference goldens (G6), the trainer loop end to end on the synthetic loader, checkpoint schema + resume."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import ddpm_cfg, dddpm_cfg, det_load, golden
+from utils import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _run_micro_batch(model, tag, step, mb, xshape, eshape):
+    x = syn.synthetic_input(xshape, f"g6.{tag}.x{step}{mb}").to(DEV)
+    tt = torch.tensor([0, 40 + step, 500, 999 - mb], device=DEV)
+    eps = syn.synthetic_normal(eshape, f"g6.{tag}.eps{step}{mb}").to(DEV)
+    model.t_sample = lambda n, tt=tt: tt
+    orig = torch.randn_like
+    torch.randn_like = lambda z, eps=eps: eps
+    try:
+        res = model(x)
+    finally:
+        torch.randn_like = orig
+    obj = res[0] if isinstance(res, tuple) else res
+    (obj / 2).backward()
+    return float(obj)
+
+
+@pytest.mark.parametrize("tag", ["ddpm", "dddpm_ae"])
+def test_two_optimizer_steps_vs_reference(tag):
+    from models import DDPM, DownsampleDDPMAutoencoder, Unet
+    from trainers.ema import EMA
+    from trainers.optim import FusedAdam
+    g = golden("g6_train")
+    if tag == "ddpm":
+        cfg = ddpm_cfg(32, 3, 16)
+        model = det_load(DDPM(cfg, Unet(cfg), DEV, 3)).to(DEV)
+        xshape, eshape = (4, 3, 16, 16), (4, 3, 16, 16)
+    else:
+        cfg = dddpm_cfg(32, 32, 2)
+        model = det_load(DownsampleDDPMAutoencoder(cfg, Unet(cfg), DEV, 3)).to(DEV)
+        xshape, eshape = (4, 3, 32, 32), (4, 8, 8, 8)
+    model.train()
+    ema = EMA(model, 0.995)
+    lr = 2e-4
+    opt = FusedAdam(model, lr=lr, max_grad_norm=1.0)
+    model._flat_params = opt.fp
+    probe = [str(n) for n in g[f"{tag}_probe_names"]]
+    params = dict(model.named_parameters())
+    for step in range(2):
+        objs = [_run_micro_batch(model, tag, step, mb, xshape, eshape) for mb in range(2)]
+        assert np.allclose(objs, g[f"{tag}_obj{step}"], rtol=2e-4), (step, objs, g[f"{tag}_obj{step}"])
+        norm = opt.step()
+        opt.zero_grad()
+        assert abs(float(norm[0]) / float(g[f"{tag}_gradnorm{step}"]) - 1) < 1e-3
+        for n in probe:
+            d = np.abs(params[n].detach().cpu().numpy() - g[f"{tag}_param{step}_{n}"])
+            assert d.max() < 0.25 * lr and d.mean() < 3e-3 * lr, (step, n, d.max(), d.mean())
+        if step == 0:
+            ema.reset(model)
+        else:
+            ema.update(model)
+            eparams = dict(ema.ema_model.named_parameters())
+            for n in probe:
+                d = np.abs(eparams[n].detach().cpu().numpy() - g[f"{tag}_ema_{n}"])
+                assert d.max() < 0.25 * lr and d.mean() < 3e-3 * lr, (n, d.max(), d.mean())
+    # the inference plan must see the updated weights after invalidate_plan()
+    model.eval()
+    model.latent_model.invalidate_plan()
+    with torch.no_grad():
+        zshape = (2, 3, 16, 16) if tag == "ddpm" else (2, 8, 8, 8)
+        y = model.latent_model(syn.synthetic_normal(zshape, "post.x").to(DEV), torch.tensor([5, 600], device=DEV))
+    assert torch.isfinite(y).all()
+
+
+def test_trainer_loop_checkpoint_and_resume(tmp_path, monkeypatch):
+    import utils
+    import trainers.trainer as T
+    import trainers.trainer_ddpm as TD
+    for mod in (T, TD):
+        monkeypatch.setattr(mod, "LOGGING_DIR", str(tmp_path) + "/", raising=True)
+    from trainers import setup_trainer
+    config = dict(model="ddpm", dataset="cifar10", n_steps=3, batch_size=4, image_size=16, n_downsamples=0, lr=2e-4, unet_chan=32,
+                  unet_dims=(1, 2, 2, 2), unet_dropout=0.1, T=100, loss_type="simple", beta_schedule="linear", ema_decay=0.995,
+                  loss_flat="sum", val_split=0, n_samples=4)
+    trainer, config = setup_trainer(config, True, str(tmp_path), "unit", seed=0)
+    assert config["unet_in"] == 3 and config["model_size"] == sum(p.numel() for p in trainer.model.parameters())
+    p0 = trainer.opt.fp.flat.clone()
+    losses = trainer.train()
+    assert len(losses) == 3 and all(np.isfinite(losses)) and trainer.step == 3
+    assert not torch.equal(p0, trainer.opt.fp.flat)
+    # EMA was reset to the live weights on every step (step < 2000): identical flats
+    assert torch.equal(trainer.ema._flat_ema().flat, trainer.opt.fp.flat)
+    ck = torch.load(trainer.checkpoint_name, map_location="cpu", weights_only=False)
+    assert set(ck) == {"optimizer", "model", "config", "train_losses", "step", "ema_model"}          # trainer_ddpm.py:51-59
+    assert ck["step"] == 3 and len(ck["train_losses"]) == 3
+    assert set(ck["optimizer"]) == {"state", "param_groups"} and len(ck["optimizer"]["state"]) == len(list(trainer.model.parameters()))
+    assert list(ck["model"].keys()) == list(trainer.model.state_dict().keys())
+    # resume into a fresh trainer: parameters, Adam moments and step come back
+    config2 = dict(ck["config"])
+    config2["n_steps"] = 4
+    trainer2, _ = setup_trainer(config2, True, str(tmp_path), "unit", seed=0)
+    trainer2.load_checkpoint(ck)
+    assert trainer2.step == 3 and trainer2.opt.step_count == trainer.opt.step_count
+    assert torch.equal(trainer2.opt.fp.flat.cpu(), trainer.opt.fp.flat.cpu())
+    assert torch.equal(trainer2.opt.exp_avg.cpu(), trainer.opt.exp_avg.cpu())
+    trainer2.n_steps = 4
+    trainer2.train()
+    assert trainer2.step == 4 and len(trainer2.train_losses) == 4
+    # the EMA model samples through the native sampler after training
+    x = trainer2.sample()
+    assert x.shape == (4, 3, 16, 16) and torch.isfinite(x).all()
+
+
+def test_dddpm_trainer_smoke(tmp_path, monkeypatch):
+    import trainers.trainer as T
+    import trainers.trainer_ddpm as TD
+    for mod in (T, TD):
+        monkeypatch.setattr(mod, "LOGGING_DIR", str(tmp_path) + "/", raising=True)
+    from trainers import setup_trainer
+    config = dict(model="dddpm", dataset="celeba", n_steps=2, batch_size=4, image_size=32, n_downsamples=2, lr=2e-4, unet_chan=32,
+                  unet_dims=(1, 2, 2, 2), unet_dropout=0.1, T=1000, loss_type="simple", beta_schedule="linear", ema_decay=0.995,
+                  loss_flat="sum", val_split=0, n_samples=4, d_mode="convolutional_res", u_mode="convolutional_res", d_dropout=0,
+                  d_chans=64, d_n_blocks=3, u_n_blocks=3, unet_in=8, ae_loss=True, t_rec_max=100, force_latent=True)
+    trainer, config = setup_trainer(config, True, str(tmp_path), "unit", seed=0)
+    losses = trainer.train()
+    assert len(losses) == 2 and all(np.isfinite(losses))
+    xs, zs = trainer.sample()
+    assert xs.shape == (4, 3, 32, 32) and zs.shape == (4, 8, 8, 8)
