@@ -78,9 +78,17 @@ def time_conv_roofline(device):
     sec = e0.elapsed_time(e1) / 1e3 / n
     flops = 2.0 * B * H * W * 9 * C * N
     bytes_alg = 4.0 * (B * H * W * C + B * H * W * N + N * 9 * C)
-    return dict(kernel="igemm_kernel<128,128,2,2> conv3x3 128->128 @32x32 B=32", bound="mfma",
+    # HBM/fabric bytes per launch come from a separate rocprofv3 --pmc run (FETCH_SIZE x2 + WRITE_SIZE, see
+    # profiles/r01_conv_pmc_traffic.json); a PMC pass cannot run inside this timing loop.
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_conv_pmc_traffic.json")) as f:
+            traffic = json.load(f)["traffic_bytes_per_launch"]
+    except Exception:
+        pass
+    return dict(kernel="igemm_dma_kernel conv3x3 128->128 @32x32 B=32 (fp32 MFMA implicit GEMM)", bound="mfma",
                 achieved=flops / sec / 1e12, peak=FP32_PEAK_TFLOPS, unit="TFLOP/s", frac=flops / sec / 1e12 / FP32_PEAK_TFLOPS,
-                traffic=None, launch_us=sec * 1e6, algorithmic_gflop=flops / 1e9, algorithmic_mbytes=bytes_alg / 1e6,
+                traffic=traffic, launch_us=sec * 1e6, algorithmic_gflop=flops / 1e9, algorithmic_mbytes=bytes_alg / 1e6,
                 algorithmic_hbm_gbps=bytes_alg / sec / 1e9)
 
 
@@ -136,12 +144,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         log(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}; using WORLD_SIZE")
+    if os.environ.get("DDK_BENCH_SAME_DEVICE"):       # rehearsal of the N>1 path on a 1-GPU box (gloo, all ranks on cuda:0)
+        local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        backend = os.environ.get("DDK_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from ddk import lib, ops
     assert lib.load().ddk_device_ok() == 1, lib.last_error()

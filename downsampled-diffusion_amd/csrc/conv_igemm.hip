@@ -271,8 +271,22 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_dma_kernel(const IgemmParam
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WN, wn = wid % WN;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-    const int phase = blockIdx.z / p.splits, split = blockIdx.z % p.splits;
+    // XCD-aware tile order (speed only): workgroups are dealt round-robin over the 8 XCDs, each with its own L2.
+    // Give every XCD a CONTIGUOUS run of logical tiles, ordered (n-tile fastest, then m-tile, then split / phase), so
+    // the workgroups sharing an L2 are the ones that re-read the same input rows (9 taps, halo rows, all n-tiles).
+    int tile_m, tile_n, tile_z;
+    {
+        const int nwg = gridDim.x * gridDim.y * gridDim.z;
+        const int bid = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        tile_n = logical % gridDim.y;
+        const int rest = logical / gridDim.y;
+        tile_m = rest % gridDim.x;
+        tile_z = rest / gridDim.x;
+    }
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int phase = tile_z / p.splits, split = tile_z % p.splits;
     const int prow = lane >> 3, ppos = lane & 7;
     const int wid_u = __builtin_amdgcn_readfirstlane(wid);  // wave-uniform, lives in an SGPR (feeds m0)
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) float*)smem;

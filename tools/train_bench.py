@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Training-step timing (cfg3: CelebA 64x64 dDDPM x2, batch 64; cfg2-like plain DDPM 32x32) and a full-resolution
+(cfg5 shape, 256x256) UNet forward check against the CPU oracle.  GPU-box tool: python tools/train_bench.py"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(ROOT, "downsampled-diffusion_amd"), ROOT]
+import torch
+from models import DDPM, DownsampleDDPMAutoencoder, Unet
+from trainers.optim import FusedAdam
+from utils import synthetic as syn
+
+DEV = "cuda"
+
+
+def cfg(chan, cin, size, down=0):
+    c = dict(unet_chan=chan, unet_in=cin, unet_dims=(1, 2, 2, 2), unet_dropout=0.1, image_size=size, T=1000, loss_type="simple",
+             beta_schedule="linear", loss_flat="sum", ema_decay=0.995)
+    if down:
+        c.update(d_mode="convolutional_res", u_mode="convolutional_res", d_dropout=0, d_chans=64, d_n_blocks=3, u_n_blocks=3, unet_in=8,
+                 ae_loss=True, t_rec_max=100, force_latent=True, n_downsamples=down)
+    return c
+
+
+def time_train(name, model, xshape, steps=5):
+    model = model.to(DEV).train()
+    model.load_state_dict(syn.fill_state_dict(model.state_dict(), skip=syn.SCHEDULE_KEYS))
+    opt = FusedAdam(model, lr=2e-4)
+    x = (torch.rand(xshape, device=DEV) * 2 - 1)
+
+    def step():
+        for _ in range(2):
+            out = model(x)
+            obj = out[0] if isinstance(out, tuple) else out
+            (obj / 2).backward()
+        opt.step(); opt.zero_grad()
+        return obj
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(steps):
+        obj = step()
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
+    print(f"{name}: {dt * 1e3:8.1f} ms / optimiser step (2 micro-batches of {xshape[0]}), objective {float(obj):.3f}", flush=True)
+
+
+if __name__ == "__main__":
+    c = cfg(128, 8, 64, down=2)
+    time_train("cfg3 dDDPM-x2 64x64 bs64", DownsampleDDPMAutoencoder(c, Unet(c), DEV, 3), (64, 3, 64, 64))
+    c = cfg(128, 3, 32)
+    time_train("cfg2 DDPM 32x32 bs64    ", DDPM(c, Unet(c), DEV, 3), (64, 3, 32, 32))
+    # cfg5 shape: full-resolution forward, B=1, vs the CPU oracle
+    from oracle import unet_ref as U
+    c = cfg(128, 3, 256)
+    u = Unet(c)
+    u.load_state_dict(syn.fill_state_dict(u.state_dict()))
+    sd = {k: v.clone() for k, v in u.state_dict().items()}
+    u = u.to(DEV).eval()
+    x = syn.synthetic_normal((1, 3, 256, 256), "cfg5.x")
+    t = torch.tensor([421])
+    with torch.no_grad():
+        y = u(x.to(DEV), t.to(DEV)).cpu()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(3):
+            u(x.to(DEV), t.to(DEV))
+        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 3
+    ref = U.unet_forward(sd, c, x, t)
+    err = float((y - ref).abs().max() / ref.abs().max())
+    print(f"cfg5 256x256 B=1 forward: {dt * 1e3:.1f} ms, rel err vs oracle {err:.2e} ({u.flops(1, 256, 256) / dt / 1e12:.1f} TFLOP/s)")
