@@ -247,6 +247,10 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmParams p)
 // stage s^1 (finished: their MFMAs consumed them) before the next DMA into it.
 __device__ __attribute__((aligned(128))) float g_zero_page[32];
 
+// Diagnostic only (DDK_DEBUG & 32): shader-clock and 100 MHz real-time stamps around the k-loop of each workgroup,
+// written to a buffer of their own, never read by any kernel (MI355X_MICROARCH.md, DVFS give-back item 6).
+__device__ unsigned long long g_stamps[6 * 4096];
+
 // one 1-KiB piece: LDS[m0 + lane*16 .. +16) <- 16 bytes at this lane's global address
 __device__ __forceinline__ void lds_dma16(const float* g, unsigned lds_byte_addr) {
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_byte_addr), "v"(g) : "memory", "m0");
@@ -268,6 +272,7 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_dma_kernel(const IgemmParam
     static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile rows must split into 8-row pieces per wave");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    const unsigned long long r_entry = (p.debug & 32) ? __builtin_amdgcn_s_memrealtime() : 0ull;
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WN, wn = wid % WN;
@@ -392,12 +397,25 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_dma_kernel(const IgemmParam
             for (int j = 0; j < PW; ++j) issue_piece(j);
         }
     }
+    unsigned long long t0 = 0, r0 = 0;
+    if (p.debug & 32) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
     int stage = 0;
+    unsigned long long seg_wait = 0, seg_issue = 0, seg_mfma = 0;  // DDK_DEBUG & 64: where a k-chunk's cycles go
+    auto stamp = [&]() -> unsigned long long {
+        unsigned long long t;
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+        __builtin_amdgcn_sched_barrier(0);
+        return t;
+    };
     for (int k = 0; k < n_it; ++k) {
+        unsigned long long ta = 0, tb = 0, tc = 0;
+        if (p.debug & 64) ta = stamp();
         // pieces of chunk k must have landed; with 3 stages those of chunk k+1 (the PW youngest) may stay in flight
         if (STAGES == 3 && k + 1 < n_it) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (!(p.debug & 2)) __syncthreads();  // everyone's pieces of chunk k landed; everyone finished reading chunk k-1's stage
+        if (p.debug & 64) tb = stamp();
         const bool more = k + AHEAD < n_it && !(p.debug & 1);
         int wr = stage + AHEAD;
         if (wr >= STAGES) wr -= STAGES;
@@ -408,6 +426,7 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_dma_kernel(const IgemmParam
                 for (int j = 0; j < PW; ++j) issue_piece(j);
             }
         }
+        if (p.debug & 64) tc = stamp();
         const float* As = smem + stage * STAGE + a_base;
         const float* Bs = smem + stage * STAGE + b_base;
         float4 a[2][TM], b[2][TN];
@@ -445,6 +464,31 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_dma_kernel(const IgemmParam
                     }
         }
         stage = stage + 1 == STAGES ? 0 : stage + 1;
+        if (p.debug & 64) {
+            const unsigned long long td = stamp();
+            seg_wait += tb - ta; seg_issue += tc - tb; seg_mfma += td - tc;
+        }
+    }
+    if ((p.debug & 64) && lane == 0) {
+        const int wg = (blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) & 511;
+        g_stamps[2048 * 8 + (wg * 4 + wid) * 4 + 0] = seg_wait;
+        g_stamps[2048 * 8 + (wg * 4 + wid) * 4 + 1] = seg_issue;
+        g_stamps[2048 * 8 + (wg * 4 + wid) * 4 + 2] = seg_mfma;
+        g_stamps[2048 * 8 + (wg * 4 + wid) * 4 + 3] = (unsigned long long)n_it;
+    }
+    unsigned long long r1 = 0;
+    if (p.debug & 32) {
+        r1 = __builtin_amdgcn_s_memrealtime();
+        if (tid == 0) {
+            const int wg = (blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) & 2047;
+            g_stamps[wg * 8 + 0] = __builtin_amdgcn_s_memtime() - t0;  // shader cycles in the k-loop
+            g_stamps[wg * 8 + 1] = r1 - r0;                             // 100 MHz ticks in the k-loop
+            g_stamps[wg * 8 + 2] = (unsigned long long)n_it;
+            g_stamps[wg * 8 + 3] = 1;
+            g_stamps[wg * 8 + 4] = r_entry;                             // absolute: kernel entry
+            g_stamps[wg * 8 + 5] = r0;                                  // absolute: loop start
+            g_stamps[wg * 8 + 6] = r1;                                  // absolute: loop end
+        }
     }
 
     const bool direct = p.splits == 1;
@@ -476,6 +520,666 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_dma_kernel(const IgemmParam
                 }
                 if (!(p.debug & 4)) outp[o] = v;
             }
+        }
+    }
+    if ((p.debug & 32) && tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int wg = (blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) & 2047;
+        g_stamps[wg * 8 + 7] = __builtin_amdgcn_s_memrealtime();       // absolute: this wave's stores drained
+    }
+}
+
+
+
+// ------------------------------------------------------------------------------------------------
+// Wave-specialised variant (the default): WM*WN "matrix" waves + 4 "loader" waves per workgroup.
+// In-kernel stamps of igemm_dma_kernel (tools/conv_clock.py) showed where a k-chunk's cycles go on a 128x128 tile:
+// 4096 in the MFMAs, ~140 in the barrier, ~240 waiting for the first fragments -- and ~800 ISSUING the 8 LDS-DMA
+// pieces (each ~100 cycles of address math + TA issue, 370 when three workgroups share a CU), during which that
+// wave's matrix pipe idles.  Here the matrix waves never touch global memory: their instruction stream is
+// ds_read_b128 + MFMA only.  The loader waves (one per SIMD, next to a matrix wave) own the 3-stage LDS ring:
+//   loader, chunk k:  wait until its pieces of chunk k landed (vmcnt, chunk k+1 may stay in flight) -> barrier ->
+//                     issue chunk k+2 into the stage the matrix waves finished reading before that barrier
+//   matrix, chunk k:  barrier -> fragments + MFMAs on stage k % 3
+// Every wave executes exactly n_it barriers; the epilogue is done by the matrix waves alone.
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__((WM * WN + 4) * 64) void igemm_ws_kernel(const IgemmParams p) {
+    constexpr int NMW = WM * WN;   // matrix waves
+    constexpr int NLW = 4;         // loader waves
+    constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
+    constexpr int A_PW = BM / 8 / NLW, B_PW = BN / 8 / NLW;  // 1-KiB pieces per loader wave per stage
+    constexpr int PW = A_PW + B_PW;
+    constexpr int STAGES = 3;
+    constexpr int STAGE = (BM + BN) * 32;  // floats
+    static_assert(BM % (8 * NLW) == 0 && BN % (8 * NLW) == 0, "tile rows must split into 8-row pieces per loader wave");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int tile_m, tile_n, tile_z;
+    {   // XCD-aware tile order (see igemm_dma_kernel)
+        const int nwg = gridDim.x * gridDim.y * gridDim.z;
+        const int bid = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        tile_n = logical % gridDim.y;
+        const int rest = logical / gridDim.y;
+        tile_m = rest % gridDim.x;
+        tile_z = rest / gridDim.x;
+    }
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int phase = tile_z / p.splits, split = tile_z % p.splits;
+    const int it_begin = split * p.kiters_per_split;
+    const int it_end = min(p.kiters, it_begin + p.kiters_per_split);
+    const int n_it = it_end - it_begin;
+
+    if (wid >= NMW) {
+        // ================================================================ loader wave
+        const int lw = wid - NMW;
+        const int prow = lane >> 3, ppos = lane & 7;
+        const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) float*)smem;
+        int a_pix[A_PW], a_sw[A_PW];
+        unsigned a_mask[A_PW];
+#pragma unroll
+        for (int j = 0; j < A_PW; ++j) {
+            const int r = (lw * A_PW + j) * 8 + prow;
+            const int gm = m0 + r;
+            const int xm = gm % p.Wm, tmp = gm / p.Wm;
+            const int ym = tmp % p.Hm, b = tmp / p.Hm;
+            const int iy0 = ym * p.in_stride, ix0 = xm * p.in_stride;
+            a_sw[j] = (ppos ^ ((r >> 1) & 7)) * 4;
+            a_pix[j] = (b * p.H + iy0) * p.W + ix0;
+            unsigned m = 0;
+            for (int t = 0; t < p.ntaps; ++t) {
+                int dy, dx;
+                tap_offset(p.tapmode, phase, t, dy, dx);
+                if ((unsigned)(iy0 + dy) < (unsigned)p.H && (unsigned)(ix0 + dx) < (unsigned)p.W) m |= 1u << t;
+            }
+            a_mask[j] = gm < p.M ? m : 0u;
+        }
+        long long b_off[B_PW];
+        bool b_ok[B_PW];
+#pragma unroll
+        for (int j = 0; j < B_PW; ++j) {
+            const int r = (lw * B_PW + j) * 8 + prow;
+            const int n = n0 + r;
+            b_ok[j] = n < p.N;
+            b_off[j] = ((long long)(phase * p.N + (b_ok[j] ? n : 0)) * p.ntaps) * p.cin + (ppos ^ ((r >> 1) & 7)) * 4;
+        }
+        const float* zero = g_zero_page + ppos * 4;
+        const int cpt = p.cin >> 5;
+        int tap = it_begin / cpt, cc = (it_begin % cpt) << 5;
+
+        auto issue = [&](int stage) {
+            int dy, dx;
+            tap_offset(p.tapmode, phase, tap, dy, dx);
+            const bool first = cc < p.c0;  // all wave-uniform
+            const float* src = first ? p.src0 : p.src1;
+            const int cs = first ? p.c0 : p.c1;
+            const int coff = first ? cc : cc - p.c0;
+            const int dpix = dy * p.W + dx;
+            const long long woff = (long long)tap * p.cin + cc;
+            const unsigned st = lds_base + (unsigned)(stage * STAGE * 4);
+#pragma unroll
+            for (int j = 0; j < A_PW; ++j) {
+                const long long off = (long long)(a_pix[j] + dpix) * cs + (coff + a_sw[j]);
+                const float* g = ((a_mask[j] >> tap) & 1u) ? src + off : zero;
+                lds_dma16(g, st + (unsigned)((lw * A_PW + j) * 1024));
+            }
+#pragma unroll
+            for (int j = 0; j < B_PW; ++j) {
+                const float* g = b_ok[j] ? p.w + (b_off[j] + woff) : zero;
+                lds_dma16(g, st + (unsigned)(BM * 128 + (lw * B_PW + j) * 1024));
+            }
+            cc += 32;
+            if (cc == p.cin) { cc = 0; ++tap; }
+        };
+
+        if (n_it > 0) issue(0);
+        if (n_it > 1) issue(1);
+        int wr = 2;
+        unsigned long long l_vm = 0, l_bar = 0, l_iss = 0;  // DDK_DEBUG & 128: loader-side segment cycles
+        for (int k = 0; k < n_it; ++k) {
+            unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+            if (p.debug & 128) t0 = __builtin_amdgcn_s_memtime();
+            if (k + 1 < n_it) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW) : "memory");  // chunk k landed, k+1 may fly
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (p.debug & 128) t1 = __builtin_amdgcn_s_memtime();
+            __builtin_amdgcn_s_barrier();
+            if (p.debug & 128) t2 = __builtin_amdgcn_s_memtime();
+            if (k + 2 < n_it) {
+                issue(wr);
+                wr = wr == 2 ? 0 : wr + 1;
+            }
+            if (p.debug & 128) { t3 = __builtin_amdgcn_s_memtime(); l_vm += t1 - t0; l_bar += t2 - t1; l_iss += t3 - t2; }
+        }
+        if ((p.debug & 128) && lane == 0) {
+            const int wg = (blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) & 511;
+            g_stamps[2048 * 8 + (wg * 4 + lw) * 4 + 0] = l_vm;
+            g_stamps[2048 * 8 + (wg * 4 + lw) * 4 + 1] = l_bar;
+            g_stamps[2048 * 8 + (wg * 4 + lw) * 4 + 2] = l_iss;
+            g_stamps[2048 * 8 + (wg * 4 + lw) * 4 + 3] = (unsigned long long)n_it;
+        }
+        return;
+    }
+
+    // ==================================================================== matrix wave
+    const int wm = wid / WN, wn = wid % WN;
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int fsw = ((lane & 31) >> 1) & 7, fh = lane >> 5;
+    int foff[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) foff[q] = (lane & 31) * 32 + (((2 * q + fh) ^ fsw) << 2);
+    const int a_base = wm * TM * 32 * 32;
+    const int b_base = BM * 32 + wn * TN * 32 * 32;
+
+    int stage = 0;
+    unsigned long long seg_wait = 0, seg_mfma = 0, t_loop0 = 0, r_loop0 = 0;
+    auto stamp = [&]() -> unsigned long long {
+        unsigned long long t;
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+        __builtin_amdgcn_sched_barrier(0);
+        return t;
+    };
+    if (p.debug & 96) { t_loop0 = __builtin_amdgcn_s_memtime(); r_loop0 = __builtin_amdgcn_s_memrealtime(); }
+    for (int k = 0; k < n_it; ++k) {
+        unsigned long long ta = 0, tb = 0;
+        if (p.debug & 64) ta = stamp();
+        __builtin_amdgcn_s_barrier();          // chunk k is in stage `stage` (the loaders waited for it before arriving)
+        __builtin_amdgcn_sched_barrier(0);
+        if (p.debug & 64) tb = stamp();
+        const float* As = smem + stage * STAGE + a_base;
+        const float* Bs = smem + stage * STAGE + b_base;
+        float4 a[2][TM], b[2][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[0][i] = *reinterpret_cast<const float4*>(As + i * 1024 + foff[0]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[0][j] = *reinterpret_cast<const float4*>(Bs + j * 1024 + foff[0]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int cur = q & 1, nxt = cur ^ 1;
+            if (q < 3) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[nxt][i] = *reinterpret_cast<const float4*>(As + i * 1024 + foff[q + 1]);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[nxt][j] = *reinterpret_cast<const float4*>(Bs + j * 1024 + foff[q + 1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);  // keep the prefetch above the MFMAs
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        const float av = e == 0 ? a[cur][i].x : e == 1 ? a[cur][i].y : e == 2 ? a[cur][i].z : a[cur][i].w;
+                        const float bv = e == 0 ? b[cur][j].x : e == 1 ? b[cur][j].y : e == 2 ? b[cur][j].z : b[cur][j].w;
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
+                    }
+        }
+        // the reads of this stage must have returned before the next barrier lets a loader overwrite it: they
+        // have -- every fragment was consumed by an MFMA above (the compiler waited lgkmcnt for it)
+        stage = stage == 2 ? 0 : stage + 1;
+        if (p.debug & 64) {
+            const unsigned long long td = stamp();
+            seg_wait += tb - ta; seg_mfma += td - tb;
+        }
+    }
+    if ((p.debug & 96) && lane == 0) {
+        const int wg = (blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z));
+        if (wid == 0) {
+            g_stamps[(wg & 2047) * 8 + 0] = __builtin_amdgcn_s_memtime() - t_loop0;
+            g_stamps[(wg & 2047) * 8 + 1] = __builtin_amdgcn_s_memrealtime() - r_loop0;
+            g_stamps[(wg & 2047) * 8 + 2] = (unsigned long long)n_it;
+            g_stamps[(wg & 2047) * 8 + 3] = 1;
+            g_stamps[(wg & 2047) * 8 + 4] = r_loop0; g_stamps[(wg & 2047) * 8 + 5] = r_loop0;
+            g_stamps[(wg & 2047) * 8 + 6] = __builtin_amdgcn_s_memrealtime(); g_stamps[(wg & 2047) * 8 + 7] = g_stamps[(wg & 2047) * 8 + 6];
+        }
+        if (!(p.debug & 128)) {
+            g_stamps[2048 * 8 + ((wg & 511) * 4 + (wid & 3)) * 4 + 0] = seg_wait;
+            g_stamps[2048 * 8 + ((wg & 511) * 4 + (wid & 3)) * 4 + 1] = 0;
+            g_stamps[2048 * 8 + ((wg & 511) * 4 + (wid & 3)) * 4 + 2] = seg_mfma;
+            g_stamps[2048 * 8 + ((wg & 511) * 4 + (wid & 3)) * 4 + 3] = (unsigned long long)n_it;
+        }
+    }
+
+    // ---- epilogue (matrix waves only): col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+    const bool direct = p.splits == 1;
+    float* outp = direct ? p.out : p.out + (long long)split * p.slab_stride;
+    const int py = phase >> 1, px = phase & 1;
+    float bias_v[TN];
+    bool col_ok[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int gn = n0 + (wn * TN + j) * 32 + (lane & 31);
+        col_ok[j] = gn < p.N;
+        bias_v[j] = (direct && p.bias && col_ok[j]) ? p.bias[gn] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const int gm = m0 + row;
+            if (gm >= p.M) continue;
+            long long opix = gm;
+            if (p.out_scale != 1) {
+                const int xm = gm % p.Wm, tmp = gm / p.Wm;
+                const int ym = tmp % p.Hm, b = tmp / p.Hm;
+                opix = ((long long)b * p.Ho + ym * p.out_scale + py) * p.Wo + xm * p.out_scale + px;
+            }
+            float* orow = outp + opix * p.N + n0 + wn * TN * 32 + (lane & 31);
+            const float* rrow = (direct && p.resid) ? p.resid + opix * p.N + n0 + wn * TN * 32 + (lane & 31) : nullptr;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                if (!col_ok[j]) continue;
+                float v = acc[i][j][r] + bias_v[j];
+                if (rrow) v += rrow[j * 32];
+                if (direct && p.post_mish) v = mish_f(v);
+                orow[j * 32] = v;
+            }
+        }
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// 3x3 stride-1 conv with the INPUT HALO TILE staged once per channel chunk (the default for the UNet Block convs).
+//
+// Why: a CU sustains only ~6.8 B/clk of LDS-DMA traffic (1 KiB piece per ~150 cycles CU-wide, measured with
+// tools/conv_clock.py loader stamps; consistent with a bounded number of outstanding L2 requests per CU).  The
+// im2col kernels above re-fetch the activation tile for every tap: 32 KB per 4096 MFMA cycles for a 128x128 tile
+// (7.8 B/clk), so the loaders, not the matrix pipe, set their pace.  Here a workgroup's 128 output pixels are
+// whole image rows (128/W rows, or several whole images when H*W < 128); their (rows+2) x (W+2) halo of one
+// 32-channel chunk (<= 224 pixels x 128 B) is DMA'd into LDS ONCE and all 9 taps read their A fragments from it at
+// a wave-uniform row offset dy*(W+2)+dx.  Only the weights (16 KB per k-step) still stream: ~19 KB instead of 32 KB
+// per 4096 MFMA cycles.  k order is (channel chunk, tap) so one halo serves 9 consecutive k-steps.
+//
+// Waves: 4 matrix waves (ds_read_b128 + MFMA only) + 4 loader waves (LDS-DMA only), one s_barrier per k-step.
+//   weights: 4-stage ring.  Barrier s guarantees steps <= s+1 have landed, so a matrix wave prefetches the first
+//            fragments of step s+1 while it multiplies step s -- no LDS latency is exposed after a barrier.
+//   halo:    2 buffers; loader l issues piece j (8 halo rows) of chunk c+1 right after barrier 9c+j, j = 0..6;
+//            they have landed by barrier 9c+8, i.e. before the first fragments of chunk c+1 are prefetched.
+//   A loader tracks the size of its youngest issue group (4 weight pieces + 0/1 halo piece) and waits
+//   s_waitcnt vmcnt(that size): everything older has landed.
+// Epilogue: each matrix wave transposes its 64x64 accumulator block through LDS and writes rows as 256-byte
+// dwordx4 segments (4x fewer store instructions than the per-register dword stores of the im2col kernels).
+constexpr int HALO_PIECES_PER_LOADER = 7;
+constexpr int HALO_MAX_PX = HALO_PIECES_PER_LOADER * 4 * 8;  // 224: 6x34 = 204 at W=32, 10x18 = 180 at W=16, 2x10x10 = 200 at W=8
+constexpr int HALO_BN = 128;
+constexpr int HALO_LDS_FLOATS = 2 * HALO_MAX_PX * 32 + 4 * HALO_BN * 32;   // 30720 floats = 120 KB
+
+// STAMPS: s_memtime is an SMEM op (out-of-order lgkmcnt), so even a never-taken stamp branch forces lgkmcnt(0)
+// waits into the loop -- the diagnostic build is a separate instantiation.
+template <int STAMPS>   // 0: production, 1: timeline stamps outside the loop (DDK_DEBUG & 32), 2: per-step segments (64 / 128)
+__global__ __launch_bounds__(512) void conv3x3_halo_kernel(const IgemmParams p) {
+    constexpr int BM = 128, BN = HALO_BN, WN = 2;
+    constexpr int NMW = 4, NLW = 4;
+    constexpr int TM = 2, TN = 2;
+    constexpr int B_PW = BN / 8 / NLW;                       // 4 weight pieces per loader per k-step
+    constexpr int H_PW = HALO_PIECES_PER_LOADER;
+    constexpr int HALO_FLOATS = HALO_MAX_PX * 32;
+    constexpr int BST = BN * 32;                             // floats per weight stage
+    constexpr int NST = 4;
+    constexpr int EPI_PITCH = 72;                            // 64 + 8: rows +4 apart land 32 banks apart
+    static_assert(4 * 64 * EPI_PITCH <= HALO_LDS_FLOATS, "epilogue staging fits");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int tile_m, tile_n, tile_z;
+    {   // XCD-aware tile order (see igemm_dma_kernel)
+        const int nwg = gridDim.x * gridDim.y * gridDim.z;
+        const int bid = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        tile_n = logical % gridDim.y;
+        const int rest = logical / gridDim.y;
+        tile_m = rest % gridDim.x;
+        tile_z = rest / gridDim.x;
+    }
+    unsigned long long r_entry = 0;
+    if (STAMPS == 1) r_entry = __builtin_amdgcn_s_memrealtime();
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int split = tile_z;                                // nphase == 1
+    // geometry of the pixel tile: TR = 128 / W whole rows of the row-major (b, y) list; TB images when TR > H
+    const int W = p.W, H = p.H, Wp = W + 2;
+    const int TR = BM / W;
+    const int TB = TR > H ? TR / H : 1;                      // images per tile (H*W < 128)
+    const int rows_img = TB > 1 ? H : TR;                    // output rows per image inside the tile
+    const int img_px = (rows_img + 2) * Wp;                  // halo pixels per image
+    const int halo_px = TB * img_px;
+    const int R0 = m0 / W;                                   // first global row (b*H + y) of the tile
+    const int cpt = p.cin >> 5;                              // channel chunks
+    const int c_begin = split * p.kiters_per_split;          // for this kernel kiters_per_split counts CHUNKS
+    const int n_chunks = min(cpt, c_begin + p.kiters_per_split) - c_begin;
+    const int n_steps = n_chunks * 9;
+
+    if (wid >= NMW) {
+        // ================================================================ loader wave
+        const int lw = wid - NMW;
+        const int prow = lane >> 3, ppos = lane & 7;
+        const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) float*)smem;
+        if (!(p.debug & 256)) __builtin_amdgcn_s_setprio(3);   // loader instructions win issue arbitration against the MFMA stream
+        // halo piece j of this loader = halo rows (lw*7 + j)*8 + prow; its source pixel never changes with the chunk
+        int h_pix[H_PW], h_sw[H_PW];
+        unsigned h_ok = 0, h_live = 0;
+#pragma unroll
+        for (int j = 0; j < H_PW; ++j) {
+            const int piece = lw * H_PW + j;
+            const int hp = piece * 8 + prow;
+            h_sw[j] = (ppos ^ ((hp >> 1) & 7)) * 4;
+            h_pix[j] = 0;
+            if (piece * 8 < halo_px) h_live |= 1u << j;           // wave-uniform
+            if (hp < halo_px) {
+                const int img = hp / img_px, rem = hp - img * img_px;
+                const int hy = rem / Wp, hx = rem - hy * Wp;
+                const int row0 = R0 + img * rows_img;           // first output row of this image's part of the tile
+                const int b = row0 / H;
+                const int y = row0 - b * H + hy - 1, x = hx - 1;
+                if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W && b < p.B) {
+                    h_pix[j] = (b * H + y) * W + x;
+                    h_ok |= 1u << j;
+                }
+            }
+        }
+        h_live = __builtin_amdgcn_readfirstlane(h_live);
+        long long b_off[B_PW];
+        bool b_ok[B_PW];
+#pragma unroll
+        for (int j = 0; j < B_PW; ++j) {
+            const int r = (lw * B_PW + j) * 8 + prow;
+            const int n = n0 + r;
+            b_ok[j] = n < p.N;
+            b_off[j] = ((long long)(b_ok[j] ? n : 0) * 9) * p.cin + (ppos ^ ((r >> 1) & 7)) * 4;
+        }
+        const float* zero = g_zero_page + ppos * 4;
+
+        auto issue_halo_piece = [&](int chunk, int j, int buf) {   // piece j of channel chunk `chunk` into halo buffer buf
+            const int cc = chunk << 5;
+            const bool first = cc < p.c0;                          // wave-uniform
+            const float* src = first ? p.src0 : p.src1;
+            const int cs = first ? p.c0 : p.c1, coff = first ? cc : cc - p.c0;
+            const float* g = ((h_ok >> j) & 1u) ? src + ((long long)h_pix[j] * cs + (coff + h_sw[j])) : zero;
+            lds_dma16(g, lds_base + (unsigned)((buf * HALO_FLOATS + (lw * H_PW + j) * 256) * 4));
+        };
+        auto issue_b = [&](int chunk, int tap, int stage) {        // weights of k-step (chunk, tap)
+            const long long woff = (long long)tap * p.cin + (chunk << 5);
+#pragma unroll
+            for (int j = 0; j < B_PW; ++j) {
+                const float* g = b_ok[j] ? p.w + (b_off[j] + woff) : zero;
+                lds_dma16(g, lds_base + (unsigned)((2 * HALO_FLOATS + stage * BST + (lw * B_PW + j) * 256) * 4));
+            }
+        };
+
+        // prologue: the whole halo of the first chunk + weights of step 0, then the weights of steps 1 and 2
+#pragma unroll
+        for (int j = 0; j < H_PW; ++j)
+            if ((h_live >> j) & 1u) issue_halo_piece(c_begin, j, 0);
+        issue_b(c_begin, 0, 0);
+        issue_b(c_begin, 1, 1);
+        issue_b(c_begin, 2, 2);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * B_PW) : "memory");   // step 0 landed (1 and 2 may fly)
+        __builtin_amdgcn_s_barrier();                                      // "pre" barrier: matrix waves prefetch step 0
+        int wr = 3;
+        int tap = 0, ci = 0;             // position of step s
+        int tap3 = 3, ci3 = 0;           // position of step s + 3
+        int young = B_PW;                // pieces in the youngest issue group (step s+2's group, issued during step s-1)
+        unsigned long long l_vm = 0, l_bar = 0, l_iss = 0;  // DDK_DEBUG & 128: loader-side segment cycles
+        for (int s = 0; s < n_steps; ++s) {
+            unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+            if (STAMPS == 2 && (p.debug & 128)) t0 = __builtin_amdgcn_s_memtime();
+            // everything but the youngest group has landed => steps <= s+1 (and halo pieces issued before step s-1)
+            if (s + 2 < n_steps) {
+                if (young == B_PW + 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(B_PW + 1) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(B_PW) : "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            if (STAMPS == 2 && (p.debug & 128)) t1 = __builtin_amdgcn_s_memtime();
+            if (!(STAMPS == 1 && (p.debug & 2))) __builtin_amdgcn_s_barrier();
+            if (STAMPS == 2 && (p.debug & 128)) t2 = __builtin_amdgcn_s_memtime();
+            if (s + 3 < n_steps && !(STAMPS == 1 && (p.debug & 1))) {
+                issue_b(c_begin + ci3, tap3, wr);
+                wr = (wr + 1) & 3;
+                young = B_PW;
+                if (tap < H_PW && ci + 1 < n_chunks && ((h_live >> tap) & 1u)) {
+#pragma unroll
+                    for (int j = 0; j < H_PW; ++j)              // static piece index keeps h_pix/h_sw in registers
+                        if (j == tap) issue_halo_piece(c_begin + ci + 1, j, (ci + 1) & 1);
+                    young = B_PW + 1;
+                }
+            }
+            if (++tap == 9) { tap = 0; ++ci; }
+            if (++tap3 == 9) { tap3 = 0; ++ci3; }
+            if (STAMPS == 2 && (p.debug & 128)) { t3 = __builtin_amdgcn_s_memtime(); l_vm += t1 - t0; l_bar += t2 - t1; l_iss += t3 - t2; }
+        }
+        __builtin_amdgcn_s_barrier();    // matrix waves reuse the LDS for their epilogue after this one
+        if (STAMPS == 2 && (p.debug & 128) && lane == 0) {
+            const int wg = (blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) & 511;
+            g_stamps[2048 * 8 + (wg * 4 + lw) * 4 + 0] = l_vm;
+            g_stamps[2048 * 8 + (wg * 4 + lw) * 4 + 1] = l_bar;
+            g_stamps[2048 * 8 + (wg * 4 + lw) * 4 + 2] = l_iss;
+            g_stamps[2048 * 8 + (wg * 4 + lw) * 4 + 3] = (unsigned long long)n_steps;
+        }
+        return;
+    }
+
+    // ==================================================================== matrix wave
+    const int wm = wid / WN, wn = wid % WN;
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int fh = lane >> 5;
+    // A fragments: this lane's output pixel -> its halo row (centre tap), per MFMA tile i
+    int a_row[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int pm = (wm * TM + i) * 32 + (lane & 31);         // pixel inside the tile
+        const int rt = pm / W, x = pm - rt * W;
+        const int img = rt / rows_img, y = rt - img * rows_img;
+        a_row[i] = img * img_px + (y + 1) * Wp + x + 1;
+    }
+    const int bsw = ((lane & 31) >> 1) & 7;
+    int b_foff[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) b_foff[q] = (lane & 31) * 32 + (((2 * q + fh) ^ bsw) << 2);
+    const int b_base = 2 * HALO_FLOATS + wn * TN * 32 * 32;
+
+    // LDS addressing in float4 units.  For one k-step (tap t, halo buffer hb, ring stage st) this lane reads
+    //   A quarter q of MFMA tile i at  hb*HALO4 + hr_i*8 + ((2q+fh) ^ sw_i),  hr_i = a_row[i] + tap offset, sw_i = (hr_i>>1)&7
+    //   B quarter q                at  b_base4 + st*BST4 + b_f4[q]  (+ 256 per n-tile)
+    // The offsets of quarter q are recomputed for step s+1 right after quarter q of step s has been requested, a few VALU
+    // ops at a time in the shadow of an MFMA (explicit sched_barrier fences keep them there).
+    constexpr int HALO4 = HALO_FLOATS / 4, BST4 = BST / 4;
+    const float4* smem4 = reinterpret_cast<const float4*>(smem);
+    const int b_base4 = b_base / 4;
+    int b_f4[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) b_f4[q] = (lane & 31) * 8 + ((2 * q + fh) ^ bsw);
+    int cA[4][TM], cB[4];            // offsets of the quarter that will be requested next time around
+    int n_base[TM], n_sw[TM], n_soff = 0;   // step s+1: per-tile base / swizzle key, stage offset
+    auto next_bases = [&](int t, int hb, int st) {
+        const int ty = (t * 11) >> 5;
+        const int toff = (ty - 1) * Wp + (t - 3 * ty - 1);        // wave-uniform halo-row offset of this tap
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int hr = a_row[i] + toff;
+            n_base[i] = hb * HALO4 + hr * 8;
+            n_sw[i] = (hr >> 1) & 7;
+        }
+        n_soff = b_base4 + st * BST4;
+    };
+    auto next_quarter = [&](int q) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) cA[q][i] = n_base[i] + ((2 * q + fh) ^ n_sw[i]);
+        cB[q] = n_soff + b_f4[q];
+    };
+    float4 a[2][TM], b[2][TN];
+    auto load_frags = [&](int slot, int q) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[slot][i] = smem4[cA[q][i]];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[slot][j] = smem4[cB[q] + j * 256];
+    };
+    auto mfma_e = [&](int cur, int e) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const float av = e == 0 ? a[cur][i].x : e == 1 ? a[cur][i].y : e == 2 ? a[cur][i].z : a[cur][i].w;
+                const float bv = e == 0 ? b[cur][j].x : e == 1 ? b[cur][j].y : e == 2 ? b[cur][j].z : b[cur][j].w;
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
+            }
+    };
+
+    int stage = 0, tap = 0, hbuf = 0;
+    __builtin_amdgcn_s_barrier();                                  // "pre" barrier: step 0 landed
+    next_bases(0, 0, 0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) next_quarter(q);
+    load_frags(0, 0);
+    // Consume the epilogue-only kernel arguments here: a scalar load still pending at the loop header (SMEM returns out
+    // of order) makes the compiler wait lgkmcnt(0) -- i.e. for the fragments it has just requested -- in every iteration.
+    unsigned long long r_loop0 = 0, t_loop0 = 0;
+    if (STAMPS == 1) {
+        r_loop0 = __builtin_amdgcn_s_memrealtime();
+        t_loop0 = __builtin_amdgcn_s_memtime();
+        asm volatile("" ::"s"(r_loop0), "s"(t_loop0), "s"(r_entry));
+    }
+    {
+        const long long ss = p.slab_stride;
+        const int sp = p.splits, pm = p.post_mish, MM = p.M, NN = p.N;
+        asm volatile("" ::"s"(ss), "s"(sp), "s"(pm), "s"(MM), "s"(NN), "s"(p.out), "s"(p.bias), "s"(p.resid));
+    }
+    unsigned long long seg_wait = 0, seg_mma = 0;   // DDK_DEBUG & 64
+    for (int s = 0; s < n_steps; ++s) {
+        unsigned long long t0 = 0, t1 = 0;
+        if (STAMPS == 2 && (p.debug & 64)) t0 = __builtin_amdgcn_s_memtime();
+        if (!(STAMPS == 1 && (p.debug & 2))) __builtin_amdgcn_s_barrier();   // steps <= s+1 landed; stage (s+3)&3 is free for the loaders
+        __builtin_amdgcn_sched_barrier(0);
+        if (STAMPS == 2 && (p.debug & 64)) t1 = __builtin_amdgcn_s_memtime();
+        int stage_n = 0, tap_n = 0, hbuf_n = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int cur = q & 1, nxt = cur ^ 1;
+            // one ds_read_b128 behind each of the first four MFMAs (a clump of four reads holds the wave's issue longer than
+            // one MFMA runs); q == 3 requests quarter 0 of step s+1 (cA[0]/cB[0] already hold its offsets)
+            {
+                const int qn = (q + 1) & 3;
+                const float av = a[cur][0].x, av1 = a[cur][1].x, bv = b[cur][0].x, bv1 = b[cur][1].x;
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[0][0], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (!(STAMPS == 1 && (p.debug & 8))) a[nxt][0] = smem4[cA[qn][0]];
+                __builtin_amdgcn_sched_barrier(0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv1, acc[0][1], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (!(STAMPS == 1 && (p.debug & 8))) a[nxt][1] = smem4[cA[qn][1]];
+                __builtin_amdgcn_sched_barrier(0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1, bv, acc[1][0], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (!(STAMPS == 1 && (p.debug & 8))) b[nxt][0] = smem4[cB[qn]];
+                __builtin_amdgcn_sched_barrier(0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1, bv1, acc[1][1], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (!(STAMPS == 1 && (p.debug & 8))) b[nxt][1] = smem4[cB[qn] + 256];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            static_assert(TM == 2 && TN == 2, "hand-interleaved for a 64x64 wave tile");
+            if (q == 0) {
+                // position of step s+1 (the last step prefetches its own fragments again: unused, but keeps the loop branch-free)
+                const bool more = s + 1 < n_steps;
+                stage_n = more ? (stage + 1) & 3 : stage;
+                tap_n = more ? tap + 1 : tap;
+                hbuf_n = hbuf;
+                if (tap_n == 9) { tap_n = 0; hbuf_n ^= 1; }
+                stage_n = __builtin_amdgcn_readfirstlane(stage_n);
+                tap_n = __builtin_amdgcn_readfirstlane(tap_n);
+                hbuf_n = __builtin_amdgcn_readfirstlane(hbuf_n);
+                next_bases(tap_n, hbuf_n, stage_n);
+                next_quarter(0);                   // quarter 0 of step s was requested in step s-1
+            } else {
+                next_quarter(q);                   // quarter q of step s was requested in block q-1
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_e(cur, 1);
+            mfma_e(cur, 2);
+            mfma_e(cur, 3);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        stage = stage_n; tap = tap_n; hbuf = hbuf_n;
+        if (STAMPS == 2 && (p.debug & 64)) { const unsigned long long t2 = __builtin_amdgcn_s_memtime(); seg_wait += t1 - t0; seg_mma += t2 - t1; }
+    }
+    if (STAMPS == 2 && (p.debug & 64) && lane == 0) {
+        const int wg = (blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) & 511;
+        g_stamps[2048 * 8 + (wg * 4 + (wid & 3)) * 4 + 0] = seg_wait;
+        g_stamps[2048 * 8 + (wg * 4 + (wid & 3)) * 4 + 1] = 0;
+        g_stamps[2048 * 8 + (wg * 4 + (wid & 3)) * 4 + 2] = seg_mma;
+        g_stamps[2048 * 8 + (wg * 4 + (wid & 3)) * 4 + 3] = (unsigned long long)n_steps;
+    }
+    unsigned long long r_loop1 = 0, t_loop1 = 0;
+    if (STAMPS == 1) { r_loop1 = __builtin_amdgcn_s_memrealtime(); t_loop1 = __builtin_amdgcn_s_memtime(); }
+    __builtin_amdgcn_s_barrier();        // every wave is done reading the ring: the LDS is free for the epilogue
+
+    // ---- epilogue: 64x64 block of this wave -> LDS (row = pixel, pitch 72) -> float4 rows -> dwordx4 stores
+    float* Es = smem + wid * 64 * EPI_PITCH;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                Es[row * EPI_PITCH + j * 32 + (lane & 31)] = acc[i][j][r];
+            }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const bool direct = p.splits == 1;
+    float* outp = direct ? p.out : p.out + (long long)split * p.slab_stride;
+    const int col4 = (lane & 15) * 4;
+    const int gn = n0 + wn * 64 + col4;
+    if (gn < p.N) {                                               // N % 32 == 0: a float4 is all-or-nothing
+        float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (direct && p.bias) bias4 = *reinterpret_cast<const float4*>(p.bias + gn);
+#pragma unroll 4
+        for (int pass = 0; pass < 16; ++pass) {
+            const int row = pass * 4 + (lane >> 4);
+            const int gm = m0 + wm * 64 + row;
+            if (gm >= p.M) continue;
+            float4 v = *reinterpret_cast<const float4*>(Es + row * EPI_PITCH + col4);
+            v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
+            const long long o = (long long)gm * p.N + gn;
+            if (direct && p.resid) {
+                const float4 rr = *reinterpret_cast<const float4*>(p.resid + o);
+                v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+            }
+            if (direct && p.post_mish) { v.x = mish_f(v.x); v.y = mish_f(v.y); v.z = mish_f(v.z); v.w = mish_f(v.w); }
+            *reinterpret_cast<float4*>(outp + o) = v;
+        }
+    }
+    if (STAMPS == 1 && wid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) {
+            const int wg = (blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) & 2047;
+            g_stamps[wg * 8 + 0] = t_loop1 - t_loop0;   // shader cycles in the k-loop
+            g_stamps[wg * 8 + 1] = r_loop1 - r_loop0;   // 100 MHz ticks in the k-loop
+            g_stamps[wg * 8 + 2] = (unsigned long long)n_steps;
+            g_stamps[wg * 8 + 3] = 1;
+            g_stamps[wg * 8 + 4] = r_entry;
+            g_stamps[wg * 8 + 5] = r_loop0;
+            g_stamps[wg * 8 + 6] = r_loop1;
+            g_stamps[wg * 8 + 7] = __builtin_amdgcn_s_memrealtime();
         }
     }
 }
@@ -596,10 +1300,82 @@ static Choice choose_tile(long long M, int N, int nphase, int kiters) {
     return with_splits(order[n_order - 1], s);
 }
 
+// ---- halo kernel eligibility and split choice.  Tiles are whole image rows, so W must divide 128, a tile must not
+// straddle images partially, and the (rows+2) x (W+2) halo must fit HALO_MAX_PX.
+static bool halo_eligible(int kind, int B, int H, int W, int N) {
+    static const bool off = getenv("DDK_NO_HALO") != nullptr;   // A/B knob for tools/conv_bench.py
+    if (off || kind != DDK_CONV3X3_S1 || N < 128 || N % 32) return false;
+    if (W < 8 || W > 128 || 128 % W) return false;
+    const int TR = 128 / W;
+    if (TR <= H ? (H % TR != 0) : (TR % H != 0)) return false;
+    const int TB = TR > H ? TR / H : 1, rows_img = TB > 1 ? H : TR;
+    if (TB * (rows_img + 2) * (W + 2) > HALO_MAX_PX) return false;
+    static const int min_tiles = getenv("DDK_HALO_MIN_TILES") ? atoi(getenv("DDK_HALO_MIN_TILES")) : 100;
+    return ceil_div((long long)B * H * W, 128) * ceil_div(N, 128) >= min_tiles;
+}
+
+// One workgroup per CU (113 KB of LDS): split the channel chunks until ~256 workgroups exist, keeping >= 2 chunks
+// (18 k-steps) per workgroup.
+static Choice choose_halo(long long M, int N, int chunks) {
+    const long long tiles = ceil_div(M, 128) * ceil_div(N, 128);
+    long long s = 1;
+    if (const char* f = getenv("DDK_FORCE_TILE")) {
+        int t = 0, fs = 1;
+        if (sscanf(f, "%d,%d", &t, &fs) == 2 && fs >= 1) s = fs;
+    } else {
+        while (tiles * s < 208 && chunks / (s * 2) >= 2) s *= 2;
+    }
+    if (s > chunks) s = chunks;
+    Choice c{T128x128, 1, chunks};
+    c.kps = (int)ceil_div(chunks, s);
+    c.splits = (int)ceil_div(chunks, c.kps);
+    return c;
+}
+
+static int launch_halo(const IgemmParams& p, hipStream_t st) {
+    constexpr size_t lds = (size_t)HALO_LDS_FLOATS * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        DDK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<0>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        DDK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<1>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        DDK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<2>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    dim3 grid((unsigned)ceil_div(p.M, 128), (unsigned)ceil_div(p.N, HALO_BN), (unsigned)p.splits);
+    if (p.debug & (64 | 128)) hipLaunchKernelGGL(conv3x3_halo_kernel<2>, grid, dim3(512), lds, st, p);
+    else if (p.debug & 32) hipLaunchKernelGGL(conv3x3_halo_kernel<1>, grid, dim3(512), lds, st, p);
+    else hipLaunchKernelGGL(conv3x3_halo_kernel<0>, grid, dim3(512), lds, st, p);
+    return check_launch("conv3x3_halo_kernel");
+}
+
+struct ConvPlan {
+    bool halo;
+    Choice c;
+};
+static ConvPlan plan_conv(int kind, int B, int H, int W, int cin, int N, const Geometry& g, bool pre_mish = false) {
+    if (!pre_mish && halo_eligible(kind, B, H, W, N)) return {true, choose_halo((long long)B * H * W, N, cin / 32)};
+    return {false, choose_tile((long long)B * g.Hm * g.Wm, N, g.nphase, g.ntaps * (cin / 32))};
+}
+
 template <int BM, int BN, int WM, int WN>
 static int launch_tile(const IgemmParams& p, hipStream_t st) {
-    static const bool no_dma = getenv("DDK_NO_DMA") != nullptr;  // A/B knob for tools/conv_bench.py
+    static const bool no_dma = getenv("DDK_NO_DMA") != nullptr;  // A/B knobs for tools/conv_bench.py
+    static const bool no_ws = getenv("DDK_WS") == nullptr;          // warp-specialised im2col variant: opt-in (no faster)
     dim3 grid((unsigned)ceil_div(p.M, BM), (unsigned)ceil_div(p.N, BN), (unsigned)(p.nphase * p.splits));
+    if (!p.pre_mish && !no_dma && !no_ws) {
+        constexpr size_t lds = 3 * (size_t)(BM + BN) * 32 * sizeof(float);
+        static bool attr_set = false;
+        if (!attr_set) {
+            DDK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_ws_kernel<BM, BN, WM, WN>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((igemm_ws_kernel<BM, BN, WM, WN>), grid, dim3((WM * WN + 4) * 64), lds, st, p);
+        return check_launch("igemm_ws_kernel");
+    }
     if (!p.pre_mish && !no_dma) {
         constexpr int STAGES = 2;
         constexpr size_t lds = STAGES * (size_t)(BM + BN) * 32 * sizeof(float);
@@ -626,7 +1402,7 @@ static int launch_tile(const IgemmParams& p, hipStream_t st) {
 size_t conv_workspace_bytes(int kind, int B, int H, int W, int cin, int N) {
     Geometry g;
     if (!conv_geometry(kind, H, W, g) || cin <= 0 || cin % 32) return 0;
-    const Choice c = choose_tile((long long)B * g.Hm * g.Wm, N, g.nphase, g.ntaps * (cin / 32));
+    const Choice c = plan_conv(kind, B, H, W, cin, N, g).c;
     if (c.splits == 1) return 0;
     return (size_t)c.splits * B * g.Ho * g.Wo * N * sizeof(float);
 }
@@ -663,14 +1439,15 @@ int conv_forward(const ddk_conv_args& a, hipStream_t st) {
     p.post_mish = a.post_mish;
     p.slab_stride = (long long)a.B * g.Ho * g.Wo * a.N;
     p.tapmode = (a.kind == DDK_CONV1X1) ? 0 : (a.kind == DDK_CONVT4X4_S2 ? 2 : (a.kind == DDK_CONV4X4_S2 ? 3 : 1));
-    const Choice c = choose_tile(p.M, p.N, p.nphase, p.kiters);
+    const ConvPlan plan = plan_conv(a.kind, a.B, a.H, a.W, p.cin, p.N, g, a.pre_mish != 0);
+    const Choice c = plan.c;
     {
         static const bool trace = getenv("DDK_TRACE") != nullptr;  // tuning aid: one line per conv launch
         if (trace) {
             int bm, bn;
             tile_dims(c.tile, bm, bn);
-            fprintf(stderr, "[ddk] conv kind=%d B=%d %dx%d cin=%d N=%d M=%d kiters=%d -> tile %dx%d splits=%d (kps %d) wgs=%lld\n", a.kind,
-                    a.B, a.H, a.W, p.cin, p.N, p.M, p.kiters, bm, bn, c.splits, c.kps,
+            fprintf(stderr, "[ddk] conv kind=%d B=%d %dx%d cin=%d N=%d M=%d kiters=%d -> %s tile %dx%d splits=%d (kps %d) wgs=%lld\n", a.kind,
+                    a.B, a.H, a.W, p.cin, p.N, p.M, p.kiters, plan.halo ? "halo" : "igemm", bm, bn, c.splits, c.kps,
                     ceil_div(p.M, bm) * ceil_div(p.N, bn) * p.nphase * c.splits);
         }
     }
@@ -687,7 +1464,8 @@ int conv_forward(const ddk_conv_args& a, hipStream_t st) {
         p.out = static_cast<float*>(a.workspace);
     }
     int rc;
-    switch (c.tile) {
+    if (plan.halo) rc = launch_halo(p, st);
+    else switch (c.tile) {
         case T128x128: rc = launch_tile<128, 128, 2, 2>(p, st); break;
         case T128x64: rc = launch_tile<128, 64, 2, 2>(p, st); break;
         case T64x64: rc = launch_tile<64, 64, 2, 2>(p, st); break;
@@ -708,7 +1486,7 @@ int conv_forward(const ddk_conv_args& a, hipStream_t st) {
 int conv_splits(int kind, int B, int H, int W, int cin, int N) {
     Geometry g;
     if (!conv_geometry(kind, H, W, g) || cin <= 0 || cin % 32) return 1;
-    return choose_tile((long long)B * g.Hm * g.Wm, N, g.nphase, g.ntaps * (cin / 32)).splits;
+    return plan_conv(kind, B, H, W, cin, N, g).c.splits;
 }
 
 double conv_flops(int kind, int B, int H, int W, int cin, int N) {
@@ -721,6 +1499,16 @@ double conv_flops(int kind, int B, int H, int W, int cin, int N) {
 
 extern "C" size_t ddk_conv_workspace_bytes(int kind, int B, int H, int W, int cin, int N) {
     return ddk::conv_workspace_bytes(kind, B, H, W, cin, N);
+}
+
+// diagnostic: copy the stamp buffer (4 x 4096 u64) to the host and clear it
+extern "C" int ddk_debug_read_stamps(unsigned long long* host_out) {
+    if (!host_out) return ddk::fail_arg("debug_read_stamps: null");
+    DDK_HIP(hipDeviceSynchronize());
+    DDK_HIP(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(ddk::g_stamps), sizeof(unsigned long long) * 6 * 4096));
+    static unsigned long long zeros[6 * 4096];
+    DDK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(ddk::g_stamps), zeros, sizeof(zeros)));
+    return DDK_OK;
 }
 
 extern "C" int ddk_conv_splits(int kind, int B, int H, int W, int cin, int N) { return ddk::conv_splits(kind, B, H, W, cin, N); }

@@ -56,6 +56,7 @@ SIGNATURES = {
     "ddk_conv_workspace_bytes": (_SZ, [_I, _I, _I, _I, _I, _I]),
     "ddk_conv_splits": (_I, [_I, _I, _I, _I, _I, _I]),
     "ddk_conv_forward": (_I, [C.POINTER(ConvArgs), _P]),
+    "ddk_debug_read_stamps": (_I, [_P]),
     "ddk_groupnorm_mish": (_I, [_P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _F, _P, _SZ, _P]),
     "ddk_groupnorm_workspace_bytes": (_SZ, [_I, _I, _I, _I]),
     "ddk_groupnorm_mish_slabs": (_I, [_P, _I, _LL, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _F, _P]),

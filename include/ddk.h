@@ -83,6 +83,9 @@ size_t ddk_conv_workspace_bytes(int kind, int B, int H, int W, int cin, int N);
 /* number of k-splits (partial slabs) the launch for this shape uses; 1 = written directly */
 int ddk_conv_splits(int kind, int B, int H, int W, int cin, int N);
 int ddk_conv_forward(const ddk_conv_args* a, ddk_stream_t s);
+/* tuning diagnostic (env DDK_DEBUG & 32): per-workgroup {shader cycles, 100 MHz ticks, k-chunks, valid} of the conv
+ * k-loop; synchronises the device, copies 6*4096 u64 to host_out and clears the buffer.  Not used by the product. */
+int ddk_debug_read_stamps(unsigned long long* host_out);
 
 /* ------------------------------------------------------------------ normalisation / activation */
 /* out = Mish(GroupNorm_g(x)) [+ temb[b*temb_stride + c]] [+ addend]   (blocks.py:79-80,106-115)
