@@ -256,23 +256,87 @@ __device__ __forceinline__ void lds_dma16(const float* g, unsigned lds_byte_addr
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_byte_addr), "v"(g) : "memory", "m0");
 }
 
-// STAGES = 2: the pieces of chunk k+1 are all issued right after the barrier of chunk k (small LDS footprint, so
-// 2-5 workgroups share a CU and cover each other's barrier / issue phases -- the faster choice measured);
-// STAGES = 3: chunk k+2 is issued piece by piece between the MFMAs of chunk k (one workgroup per CU).
-template <int BM, int BN, int WM, int WN, int STAGES>
+// Shared epilogue of the DMA kernels: a wave's (TM*32) x (TN*32) accumulator block goes through LDS (pitch TN*32+8
+// floats: the two half-waves of an MFMA register, 4 rows apart, land 32 banks apart) and leaves as float4 rows --
+// 4x fewer store instructions than one dword store per accumulator register, and full 128/256-byte row segments.
+// `Es` is this wave's private staging area; the caller has made sure no wave still reads the LDS it overlays.
+template <int TM, int TN>
+__device__ __forceinline__ void store_block_via_lds(const IgemmParams& p, f32x16 (&acc)[TM][TN], float* Es, int lane, int m_base,
+                                                    int n_base, int split, int phase) {
+    constexpr int PITCH = TN * 32 + 8;
+    constexpr int LPR = TN * 8;          // lanes per row (one float4 each)
+    constexpr int RPP = 64 / LPR;        // rows per pass
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                Es[row * PITCH + j * 32 + (lane & 31)] = acc[i][j][r];
+            }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const bool direct = p.splits == 1;
+    float* outp = direct ? p.out : p.out + (long long)split * p.slab_stride;
+    const int col4 = (lane % LPR) * 4;
+    const int gn = n_base + col4;
+    if (gn >= p.N) return;               // N % 32 == 0: a float4 is all-or-nothing
+    float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (direct && p.bias) bias4 = *reinterpret_cast<const float4*>(p.bias + gn);
+    const int py = phase >> 1, px = phase & 1;
+#pragma unroll 4
+    for (int pass = 0; pass < TM * 32 / RPP; ++pass) {
+        const int row = pass * RPP + lane / LPR;
+        const int gm = m_base + row;
+        if (gm >= p.M) continue;
+        long long opix = gm;
+        if (p.out_scale != 1) {          // transpose conv: this phase's pixels interleave into the 2x larger output
+            const int xm = gm % p.Wm, tmp = gm / p.Wm;
+            const int ym = tmp % p.Hm, b = tmp / p.Hm;
+            opix = ((long long)b * p.Ho + ym * p.out_scale + py) * p.Wo + xm * p.out_scale + px;
+        }
+        float4 v = *reinterpret_cast<const float4*>(Es + row * PITCH + col4);
+        v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
+        const long long o = opix * p.N + gn;
+        if (direct && p.resid) {
+            const float4 rr = *reinterpret_cast<const float4*>(p.resid + o);
+            v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+        }
+        if (direct && p.post_mish) { v.x = mish_f(v.x); v.y = mish_f(v.y); v.z = mish_f(v.z); v.w = mish_f(v.w); }
+        *reinterpret_cast<float4*>(outp + o) = v;
+    }
+}
+
+// Keep SMEM out of the k-loops: a scalar load that is still pending at the loop header (kernel arguments only used by
+// the epilogue, or an s_memtime stamp behind a never-taken branch) makes hipcc wait lgkmcnt(0) -- i.e. for the LDS
+// fragments it has just requested -- in every iteration, because SMEM returns out of order.  Consuming the epilogue's
+// arguments here forces their wait in front of the loop.
+__device__ __forceinline__ void consume_epilogue_args(const IgemmParams& p) {
+    const long long ss = p.slab_stride;
+    const int sp = p.splits, pm = p.post_mish, MM = p.M, NN = p.N, os = p.out_scale, wm = p.Wm, hm = p.Hm, ho = p.Ho, wo = p.Wo;
+    asm volatile("" ::"s"(ss), "s"(sp), "s"(pm), "s"(MM), "s"(NN), "s"(os), "s"(wm), "s"(hm), "s"(ho), "s"(wo), "s"(p.out), "s"(p.bias),
+                 "s"(p.resid));
+}
+
+// im2col implicit GEMM, all waves load and multiply (every conv kind; the 3x3 stride-1 layers with enough pixels use the
+// halo kernel further down).  2-stage ring: the pieces of chunk k+1 are all issued right after the barrier of chunk k
+// (small LDS footprint, so 2-5 workgroups share a CU and cover each other's barrier / issue phases).
+// DBG = 1 is the diagnostic instantiation (DDK_DEBUG stamps / ablations, tools/conv_clock.py); production is DBG = 0.
+template <int BM, int BN, int WM, int WN, int DBG>
 __global__ __launch_bounds__(WM* WN * 64) void igemm_dma_kernel(const IgemmParams p) {
     constexpr int NW = WM * WN;
+    constexpr int STAGES = 2;
     constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
     constexpr int A_PW = BM / 8 / NW, B_PW = BN / 8 / NW;  // 1-KiB DMA pieces per wave per stage
     constexpr int PW = A_PW + B_PW;
     constexpr int STAGE = (BM + BN) * 32;                  // floats
-    constexpr int NMFMA = 16 * TM * TN;                    // MFMAs per wave per k-chunk
-    constexpr int PIECE_EVERY = (NMFMA / 2 / PW) > 0 ? (NMFMA / 2 / PW) : 1;  // pieces go out over the first half
-    static_assert(PW * PIECE_EVERY <= NMFMA, "not enough MFMA slots to issue the DMA pieces");
     static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile rows must split into 8-row pieces per wave");
+    const int dbg = DBG ? p.debug : 0;
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const unsigned long long r_entry = (p.debug & 32) ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    const unsigned long long r_entry = (dbg & 32) ? __builtin_amdgcn_s_memrealtime() : 0ull;
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WN, wn = wid % WN;
@@ -314,8 +378,6 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_dma_kernel(const IgemmParam
         a_sw[j] = (ppos ^ ((r >> 1) & 7)) * 4;  // float offset of the k-chunk this lane fetches
         a_pix[j] = (b * p.H + iy0) * p.W + ix0;
         unsigned m = 0;
-        if (p.debug & 16) m = 0xffffu;
-        else
         for (int t = 0; t < p.ntaps; ++t) {
             int dy, dx;
             tap_offset(p.tapmode, phase, t, dy, dx);
@@ -339,35 +401,28 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_dma_kernel(const IgemmParam
     const int cpt = p.cin >> 5;
     int tap = it_begin / cpt, cc = (it_begin % cpt) << 5;
 
-    // wave-uniform state of the k-chunk whose pieces are being issued
-    const float* i_src = nullptr;
-    int i_cs = 0, i_coff = 0, i_dpix = 0, i_tap = 0;
-    long long i_woff = 0;
-    unsigned i_st = 0;
-    auto issue_begin = [&](int stage) {
+    auto issue_chunk = [&](int stage) {   // all PW pieces of the next k-chunk; tap / channel state is wave-uniform
         int dy, dx;
         tap_offset(p.tapmode, phase, tap, dy, dx);
         const bool first = cc < p.c0;
-        i_src = first ? p.src0 : p.src1;
-        i_cs = first ? p.c0 : p.c1;
-        i_coff = first ? cc : cc - p.c0;
-        i_dpix = dy * p.W + dx;
-        i_woff = (long long)tap * p.cin + cc;
-        i_tap = tap;
-        i_st = lds_base + (unsigned)(stage * STAGE * 4);
+        const float* src = first ? p.src0 : p.src1;
+        const int cs = first ? p.c0 : p.c1, coff = first ? cc : cc - p.c0;
+        const int dpix = dy * p.W + dx;
+        const long long woff = (long long)tap * p.cin + cc;
+        const unsigned st = lds_base + (unsigned)(stage * STAGE * 4);
+#pragma unroll
+        for (int j = 0; j < A_PW; ++j) {
+            const long long off = (long long)(a_pix[j] + dpix) * cs + (coff + a_sw[j]);
+            const float* g = ((a_mask[j] >> tap) & 1u) ? src + off : zero;
+            lds_dma16(g, st + (unsigned)((wid_u * A_PW + j) * 1024));
+        }
+#pragma unroll
+        for (int j = 0; j < B_PW; ++j) {
+            const float* g = b_ok[j] ? p.w + (b_off[j] + woff) : zero;
+            lds_dma16(g, st + (unsigned)(BM * 128 + (wid_u * B_PW + j) * 1024));
+        }
         cc += 32;
         if (cc == p.cin) { cc = 0; ++tap; }
-    };
-    auto issue_piece = [&](int j) {  // j is a compile-time constant after unrolling
-        if (j < A_PW) {
-            const long long off = (long long)(a_pix[j] + i_dpix) * i_cs + (i_coff + a_sw[j]);
-            const float* g = ((a_mask[j] >> i_tap) & 1u) ? i_src + off : zero;
-            lds_dma16(g, i_st + (unsigned)((wid_u * A_PW + j) * 1024));
-        } else {
-            const int jb = j - A_PW;
-            const float* g = b_ok[jb] ? p.w + (b_off[jb] + i_woff) : zero;
-            lds_dma16(g, i_st + (unsigned)(BM * 128 + (wid_u * B_PW + jb) * 1024));
-        }
     };
 
     f32x16 acc[TM][TN];
@@ -386,19 +441,11 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_dma_kernel(const IgemmParam
     const int a_base = wm * TM * 32 * 32;
     const int b_base = BM * 32 + wn * TN * 32 * 32;
 
-    // ---- ring of STAGES buffers: chunk k+STAGES-1 is DMA'd while chunk k is multiplied.
-    constexpr int AHEAD = STAGES - 1;
-    const int n_it = (p.debug & 8) ? 0 : it_end - it_begin;
-#pragma unroll
-    for (int pre = 0; pre < AHEAD; ++pre) {
-        if (pre < n_it) {
-            issue_begin(pre);
-#pragma unroll
-            for (int j = 0; j < PW; ++j) issue_piece(j);
-        }
-    }
+    const int n_it = (dbg & 8) ? 0 : it_end - it_begin;
+    if (n_it > 0) issue_chunk(0);
     unsigned long long t0 = 0, r0 = 0;
-    if (p.debug & 32) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
+    if (dbg & 32) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
+    consume_epilogue_args(p);
     int stage = 0;
     unsigned long long seg_wait = 0, seg_issue = 0, seg_mfma = 0;  // DDK_DEBUG & 64: where a k-chunk's cycles go
     auto stamp = [&]() -> unsigned long long {
@@ -410,23 +457,12 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_dma_kernel(const IgemmParam
     };
     for (int k = 0; k < n_it; ++k) {
         unsigned long long ta = 0, tb = 0, tc = 0;
-        if (p.debug & 64) ta = stamp();
-        // pieces of chunk k must have landed; with 3 stages those of chunk k+1 (the PW youngest) may stay in flight
-        if (STAGES == 3 && k + 1 < n_it) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (!(p.debug & 2)) __syncthreads();  // everyone's pieces of chunk k landed; everyone finished reading chunk k-1's stage
-        if (p.debug & 64) tb = stamp();
-        const bool more = k + AHEAD < n_it && !(p.debug & 1);
-        int wr = stage + AHEAD;
-        if (wr >= STAGES) wr -= STAGES;
-        if (more) {
-            issue_begin(wr);
-            if (STAGES == 2) {
-#pragma unroll
-                for (int j = 0; j < PW; ++j) issue_piece(j);
-            }
-        }
-        if (p.debug & 64) tc = stamp();
+        if (dbg & 64) ta = stamp();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of chunk k have landed
+        if (!(dbg & 2)) __syncthreads();  // everyone's pieces of chunk k landed; everyone finished reading chunk k-1's stage
+        if (dbg & 64) tb = stamp();
+        if (k + 1 < n_it && !(dbg & 1)) issue_chunk(stage ^ 1);
+        if (dbg & 64) tc = stamp();
         const float* As = smem + stage * STAGE + a_base;
         const float* Bs = smem + stage * STAGE + b_base;
         float4 a[2][TM], b[2][TN];
@@ -434,7 +470,6 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_dma_kernel(const IgemmParam
         for (int i = 0; i < TM; ++i) a[0][i] = *reinterpret_cast<const float4*>(As + i * 1024 + foff[0]);
 #pragma unroll
         for (int j = 0; j < TN; ++j) b[0][j] = *reinterpret_cast<const float4*>(Bs + j * 1024 + foff[0]);
-        int mf = 0;  // MFMA counter: folds to constants once the loops below are unrolled
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int cur = q & 1, nxt = cur ^ 1;
@@ -455,21 +490,15 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_dma_kernel(const IgemmParam
                         const float av = e == 0 ? a[cur][i].x : e == 1 ? a[cur][i].y : e == 2 ? a[cur][i].z : a[cur][i].w;
                         const float bv = e == 0 ? b[cur][j].x : e == 1 ? b[cur][j].y : e == 2 ? b[cur][j].z : b[cur][j].w;
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
-                        ++mf;
-                        if (STAGES == 3 && mf % PIECE_EVERY == 0 && mf / PIECE_EVERY <= PW) {
-                            __builtin_amdgcn_sched_barrier(0);
-                            if (more) issue_piece(mf / PIECE_EVERY - 1);
-                            __builtin_amdgcn_sched_barrier(0);
-                        }
                     }
         }
-        stage = stage + 1 == STAGES ? 0 : stage + 1;
-        if (p.debug & 64) {
+        stage ^= 1;
+        if (dbg & 64) {
             const unsigned long long td = stamp();
             seg_wait += tb - ta; seg_issue += tc - tb; seg_mfma += td - tc;
         }
     }
-    if ((p.debug & 64) && lane == 0) {
+    if ((dbg & 64) && lane == 0) {
         const int wg = (blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) & 511;
         g_stamps[2048 * 8 + (wg * 4 + wid) * 4 + 0] = seg_wait;
         g_stamps[2048 * 8 + (wg * 4 + wid) * 4 + 1] = seg_issue;
@@ -477,7 +506,7 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_dma_kernel(const IgemmParam
         g_stamps[2048 * 8 + (wg * 4 + wid) * 4 + 3] = (unsigned long long)n_it;
     }
     unsigned long long r1 = 0;
-    if (p.debug & 32) {
+    if (dbg & 32) {
         r1 = __builtin_amdgcn_s_memrealtime();
         if (tid == 0) {
             const int wg = (blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) & 2047;
@@ -491,303 +520,15 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_dma_kernel(const IgemmParam
         }
     }
 
-    const bool direct = p.splits == 1;
-    float* outp = direct ? p.out : p.out + (long long)split * p.slab_stride;
-    const int py = phase >> 1, px = phase & 1;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            const int gm = m0 + row;
-            if (gm >= p.M) continue;
-            long long opix = gm;
-            if (p.out_scale != 1) {
-                const int xm = gm % p.Wm, tmp = gm / p.Wm;
-                const int ym = tmp % p.Hm, b = tmp / p.Hm;
-                opix = ((long long)b * p.Ho + ym * p.out_scale + py) * p.Wo + xm * p.out_scale + px;
-            }
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int gn = n0 + (wn * TN + j) * 32 + (lane & 31);
-                if (gn >= p.N) continue;
-                float v = acc[i][j][r];
-                const long long o = opix * p.N + gn;
-                if (direct) {
-                    if (p.bias) v += p.bias[gn];
-                    if (p.resid) v += p.resid[o];
-                    if (p.post_mish) v = mish_f(v);
-                }
-                if (!(p.debug & 4)) outp[o] = v;
-            }
-        }
-    }
-    if ((p.debug & 32) && tid == 0) {
+    __syncthreads();   // every wave is done reading the ring: its LDS now stages the output block
+    constexpr int EPI_FLOATS = TM * 32 * (TN * 32 + 8);
+    store_block_via_lds<TM, TN>(p, acc, smem + wid * EPI_FLOATS, lane, m0 + wm * TM * 32, n0 + wn * TN * 32, split, phase);
+    if ((dbg & 32) && tid == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const int wg = (blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) & 2047;
         g_stamps[wg * 8 + 7] = __builtin_amdgcn_s_memrealtime();       // absolute: this wave's stores drained
     }
 }
-
-
-
-// ------------------------------------------------------------------------------------------------
-// Wave-specialised variant (the default): WM*WN "matrix" waves + 4 "loader" waves per workgroup.
-// In-kernel stamps of igemm_dma_kernel (tools/conv_clock.py) showed where a k-chunk's cycles go on a 128x128 tile:
-// 4096 in the MFMAs, ~140 in the barrier, ~240 waiting for the first fragments -- and ~800 ISSUING the 8 LDS-DMA
-// pieces (each ~100 cycles of address math + TA issue, 370 when three workgroups share a CU), during which that
-// wave's matrix pipe idles.  Here the matrix waves never touch global memory: their instruction stream is
-// ds_read_b128 + MFMA only.  The loader waves (one per SIMD, next to a matrix wave) own the 3-stage LDS ring:
-//   loader, chunk k:  wait until its pieces of chunk k landed (vmcnt, chunk k+1 may stay in flight) -> barrier ->
-//                     issue chunk k+2 into the stage the matrix waves finished reading before that barrier
-//   matrix, chunk k:  barrier -> fragments + MFMAs on stage k % 3
-// Every wave executes exactly n_it barriers; the epilogue is done by the matrix waves alone.
-template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__((WM * WN + 4) * 64) void igemm_ws_kernel(const IgemmParams p) {
-    constexpr int NMW = WM * WN;   // matrix waves
-    constexpr int NLW = 4;         // loader waves
-    constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
-    constexpr int A_PW = BM / 8 / NLW, B_PW = BN / 8 / NLW;  // 1-KiB pieces per loader wave per stage
-    constexpr int PW = A_PW + B_PW;
-    constexpr int STAGES = 3;
-    constexpr int STAGE = (BM + BN) * 32;  // floats
-    static_assert(BM % (8 * NLW) == 0 && BN % (8 * NLW) == 0, "tile rows must split into 8-row pieces per loader wave");
-
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int tile_m, tile_n, tile_z;
-    {   // XCD-aware tile order (see igemm_dma_kernel)
-        const int nwg = gridDim.x * gridDim.y * gridDim.z;
-        const int bid = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-        const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-        tile_n = logical % gridDim.y;
-        const int rest = logical / gridDim.y;
-        tile_m = rest % gridDim.x;
-        tile_z = rest / gridDim.x;
-    }
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const int phase = tile_z / p.splits, split = tile_z % p.splits;
-    const int it_begin = split * p.kiters_per_split;
-    const int it_end = min(p.kiters, it_begin + p.kiters_per_split);
-    const int n_it = it_end - it_begin;
-
-    if (wid >= NMW) {
-        // ================================================================ loader wave
-        const int lw = wid - NMW;
-        const int prow = lane >> 3, ppos = lane & 7;
-        const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) float*)smem;
-        int a_pix[A_PW], a_sw[A_PW];
-        unsigned a_mask[A_PW];
-#pragma unroll
-        for (int j = 0; j < A_PW; ++j) {
-            const int r = (lw * A_PW + j) * 8 + prow;
-            const int gm = m0 + r;
-            const int xm = gm % p.Wm, tmp = gm / p.Wm;
-            const int ym = tmp % p.Hm, b = tmp / p.Hm;
-            const int iy0 = ym * p.in_stride, ix0 = xm * p.in_stride;
-            a_sw[j] = (ppos ^ ((r >> 1) & 7)) * 4;
-            a_pix[j] = (b * p.H + iy0) * p.W + ix0;
-            unsigned m = 0;
-            for (int t = 0; t < p.ntaps; ++t) {
-                int dy, dx;
-                tap_offset(p.tapmode, phase, t, dy, dx);
-                if ((unsigned)(iy0 + dy) < (unsigned)p.H && (unsigned)(ix0 + dx) < (unsigned)p.W) m |= 1u << t;
-            }
-            a_mask[j] = gm < p.M ? m : 0u;
-        }
-        long long b_off[B_PW];
-        bool b_ok[B_PW];
-#pragma unroll
-        for (int j = 0; j < B_PW; ++j) {
-            const int r = (lw * B_PW + j) * 8 + prow;
-            const int n = n0 + r;
-            b_ok[j] = n < p.N;
-            b_off[j] = ((long long)(phase * p.N + (b_ok[j] ? n : 0)) * p.ntaps) * p.cin + (ppos ^ ((r >> 1) & 7)) * 4;
-        }
-        const float* zero = g_zero_page + ppos * 4;
-        const int cpt = p.cin >> 5;
-        int tap = it_begin / cpt, cc = (it_begin % cpt) << 5;
-
-        auto issue = [&](int stage) {
-            int dy, dx;
-            tap_offset(p.tapmode, phase, tap, dy, dx);
-            const bool first = cc < p.c0;  // all wave-uniform
-            const float* src = first ? p.src0 : p.src1;
-            const int cs = first ? p.c0 : p.c1;
-            const int coff = first ? cc : cc - p.c0;
-            const int dpix = dy * p.W + dx;
-            const long long woff = (long long)tap * p.cin + cc;
-            const unsigned st = lds_base + (unsigned)(stage * STAGE * 4);
-#pragma unroll
-            for (int j = 0; j < A_PW; ++j) {
-                const long long off = (long long)(a_pix[j] + dpix) * cs + (coff + a_sw[j]);
-                const float* g = ((a_mask[j] >> tap) & 1u) ? src + off : zero;
-                lds_dma16(g, st + (unsigned)((lw * A_PW + j) * 1024));
-            }
-#pragma unroll
-            for (int j = 0; j < B_PW; ++j) {
-                const float* g = b_ok[j] ? p.w + (b_off[j] + woff) : zero;
-                lds_dma16(g, st + (unsigned)(BM * 128 + (lw * B_PW + j) * 1024));
-            }
-            cc += 32;
-            if (cc == p.cin) { cc = 0; ++tap; }
-        };
-
-        if (n_it > 0) issue(0);
-        if (n_it > 1) issue(1);
-        int wr = 2;
-        unsigned long long l_vm = 0, l_bar = 0, l_iss = 0;  // DDK_DEBUG & 128: loader-side segment cycles
-        for (int k = 0; k < n_it; ++k) {
-            unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
-            if (p.debug & 128) t0 = __builtin_amdgcn_s_memtime();
-            if (k + 1 < n_it) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW) : "memory");  // chunk k landed, k+1 may fly
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (p.debug & 128) t1 = __builtin_amdgcn_s_memtime();
-            __builtin_amdgcn_s_barrier();
-            if (p.debug & 128) t2 = __builtin_amdgcn_s_memtime();
-            if (k + 2 < n_it) {
-                issue(wr);
-                wr = wr == 2 ? 0 : wr + 1;
-            }
-            if (p.debug & 128) { t3 = __builtin_amdgcn_s_memtime(); l_vm += t1 - t0; l_bar += t2 - t1; l_iss += t3 - t2; }
-        }
-        if ((p.debug & 128) && lane == 0) {
-            const int wg = (blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) & 511;
-            g_stamps[2048 * 8 + (wg * 4 + lw) * 4 + 0] = l_vm;
-            g_stamps[2048 * 8 + (wg * 4 + lw) * 4 + 1] = l_bar;
-            g_stamps[2048 * 8 + (wg * 4 + lw) * 4 + 2] = l_iss;
-            g_stamps[2048 * 8 + (wg * 4 + lw) * 4 + 3] = (unsigned long long)n_it;
-        }
-        return;
-    }
-
-    // ==================================================================== matrix wave
-    const int wm = wid / WN, wn = wid % WN;
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    const int fsw = ((lane & 31) >> 1) & 7, fh = lane >> 5;
-    int foff[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) foff[q] = (lane & 31) * 32 + (((2 * q + fh) ^ fsw) << 2);
-    const int a_base = wm * TM * 32 * 32;
-    const int b_base = BM * 32 + wn * TN * 32 * 32;
-
-    int stage = 0;
-    unsigned long long seg_wait = 0, seg_mfma = 0, t_loop0 = 0, r_loop0 = 0;
-    auto stamp = [&]() -> unsigned long long {
-        unsigned long long t;
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
-        __builtin_amdgcn_sched_barrier(0);
-        return t;
-    };
-    if (p.debug & 96) { t_loop0 = __builtin_amdgcn_s_memtime(); r_loop0 = __builtin_amdgcn_s_memrealtime(); }
-    for (int k = 0; k < n_it; ++k) {
-        unsigned long long ta = 0, tb = 0;
-        if (p.debug & 64) ta = stamp();
-        __builtin_amdgcn_s_barrier();          // chunk k is in stage `stage` (the loaders waited for it before arriving)
-        __builtin_amdgcn_sched_barrier(0);
-        if (p.debug & 64) tb = stamp();
-        const float* As = smem + stage * STAGE + a_base;
-        const float* Bs = smem + stage * STAGE + b_base;
-        float4 a[2][TM], b[2][TN];
-#pragma unroll
-        for (int i = 0; i < TM; ++i) a[0][i] = *reinterpret_cast<const float4*>(As + i * 1024 + foff[0]);
-#pragma unroll
-        for (int j = 0; j < TN; ++j) b[0][j] = *reinterpret_cast<const float4*>(Bs + j * 1024 + foff[0]);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int cur = q & 1, nxt = cur ^ 1;
-            if (q < 3) {
-#pragma unroll
-                for (int i = 0; i < TM; ++i) a[nxt][i] = *reinterpret_cast<const float4*>(As + i * 1024 + foff[q + 1]);
-#pragma unroll
-                for (int j = 0; j < TN; ++j) b[nxt][j] = *reinterpret_cast<const float4*>(Bs + j * 1024 + foff[q + 1]);
-            }
-            __builtin_amdgcn_sched_barrier(0);  // keep the prefetch above the MFMAs
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) {
-                        const float av = e == 0 ? a[cur][i].x : e == 1 ? a[cur][i].y : e == 2 ? a[cur][i].z : a[cur][i].w;
-                        const float bv = e == 0 ? b[cur][j].x : e == 1 ? b[cur][j].y : e == 2 ? b[cur][j].z : b[cur][j].w;
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
-                    }
-        }
-        // the reads of this stage must have returned before the next barrier lets a loader overwrite it: they
-        // have -- every fragment was consumed by an MFMA above (the compiler waited lgkmcnt for it)
-        stage = stage == 2 ? 0 : stage + 1;
-        if (p.debug & 64) {
-            const unsigned long long td = stamp();
-            seg_wait += tb - ta; seg_mfma += td - tb;
-        }
-    }
-    if ((p.debug & 96) && lane == 0) {
-        const int wg = (blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z));
-        if (wid == 0) {
-            g_stamps[(wg & 2047) * 8 + 0] = __builtin_amdgcn_s_memtime() - t_loop0;
-            g_stamps[(wg & 2047) * 8 + 1] = __builtin_amdgcn_s_memrealtime() - r_loop0;
-            g_stamps[(wg & 2047) * 8 + 2] = (unsigned long long)n_it;
-            g_stamps[(wg & 2047) * 8 + 3] = 1;
-            g_stamps[(wg & 2047) * 8 + 4] = r_loop0; g_stamps[(wg & 2047) * 8 + 5] = r_loop0;
-            g_stamps[(wg & 2047) * 8 + 6] = __builtin_amdgcn_s_memrealtime(); g_stamps[(wg & 2047) * 8 + 7] = g_stamps[(wg & 2047) * 8 + 6];
-        }
-        if (!(p.debug & 128)) {
-            g_stamps[2048 * 8 + ((wg & 511) * 4 + (wid & 3)) * 4 + 0] = seg_wait;
-            g_stamps[2048 * 8 + ((wg & 511) * 4 + (wid & 3)) * 4 + 1] = 0;
-            g_stamps[2048 * 8 + ((wg & 511) * 4 + (wid & 3)) * 4 + 2] = seg_mfma;
-            g_stamps[2048 * 8 + ((wg & 511) * 4 + (wid & 3)) * 4 + 3] = (unsigned long long)n_it;
-        }
-    }
-
-    // ---- epilogue (matrix waves only): col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
-    const bool direct = p.splits == 1;
-    float* outp = direct ? p.out : p.out + (long long)split * p.slab_stride;
-    const int py = phase >> 1, px = phase & 1;
-    float bias_v[TN];
-    bool col_ok[TN];
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int gn = n0 + (wn * TN + j) * 32 + (lane & 31);
-        col_ok[j] = gn < p.N;
-        bias_v[j] = (direct && p.bias && col_ok[j]) ? p.bias[gn] : 0.f;
-    }
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            const int gm = m0 + row;
-            if (gm >= p.M) continue;
-            long long opix = gm;
-            if (p.out_scale != 1) {
-                const int xm = gm % p.Wm, tmp = gm / p.Wm;
-                const int ym = tmp % p.Hm, b = tmp / p.Hm;
-                opix = ((long long)b * p.Ho + ym * p.out_scale + py) * p.Wo + xm * p.out_scale + px;
-            }
-            float* orow = outp + opix * p.N + n0 + wn * TN * 32 + (lane & 31);
-            const float* rrow = (direct && p.resid) ? p.resid + opix * p.N + n0 + wn * TN * 32 + (lane & 31) : nullptr;
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                if (!col_ok[j]) continue;
-                float v = acc[i][j][r] + bias_v[j];
-                if (rrow) v += rrow[j * 32];
-                if (direct && p.post_mish) v = mish_f(v);
-                orow[j * 32] = v;
-            }
-        }
-    }
-}
-
 
 // ------------------------------------------------------------------------------------------------
 // 3x3 stride-1 conv with the INPUT HALO TILE staged once per channel chunk (the default for the UNet Block convs).
@@ -1049,19 +790,13 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const IgemmParams p) 
 #pragma unroll
     for (int q = 0; q < 4; ++q) next_quarter(q);
     load_frags(0, 0);
-    // Consume the epilogue-only kernel arguments here: a scalar load still pending at the loop header (SMEM returns out
-    // of order) makes the compiler wait lgkmcnt(0) -- i.e. for the fragments it has just requested -- in every iteration.
     unsigned long long r_loop0 = 0, t_loop0 = 0;
     if (STAMPS == 1) {
         r_loop0 = __builtin_amdgcn_s_memrealtime();
         t_loop0 = __builtin_amdgcn_s_memtime();
         asm volatile("" ::"s"(r_loop0), "s"(t_loop0), "s"(r_entry));
     }
-    {
-        const long long ss = p.slab_stride;
-        const int sp = p.splits, pm = p.post_mish, MM = p.M, NN = p.N;
-        asm volatile("" ::"s"(ss), "s"(sp), "s"(pm), "s"(MM), "s"(NN), "s"(p.out), "s"(p.bias), "s"(p.resid));
-    }
+    consume_epilogue_args(p);
     unsigned long long seg_wait = 0, seg_mma = 0;   // DDK_DEBUG & 64
     for (int s = 0; s < n_steps; ++s) {
         unsigned long long t0 = 0, t1 = 0;
@@ -1131,43 +866,8 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const IgemmParams p) 
     if (STAMPS == 1) { r_loop1 = __builtin_amdgcn_s_memrealtime(); t_loop1 = __builtin_amdgcn_s_memtime(); }
     __builtin_amdgcn_s_barrier();        // every wave is done reading the ring: the LDS is free for the epilogue
 
-    // ---- epilogue: 64x64 block of this wave -> LDS (row = pixel, pitch 72) -> float4 rows -> dwordx4 stores
-    float* Es = smem + wid * 64 * EPI_PITCH;
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                Es[row * EPI_PITCH + j * 32 + (lane & 31)] = acc[i][j][r];
-            }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const bool direct = p.splits == 1;
-    float* outp = direct ? p.out : p.out + (long long)split * p.slab_stride;
-    const int col4 = (lane & 15) * 4;
-    const int gn = n0 + wn * 64 + col4;
-    if (gn < p.N) {                                               // N % 32 == 0: a float4 is all-or-nothing
-        float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (direct && p.bias) bias4 = *reinterpret_cast<const float4*>(p.bias + gn);
-#pragma unroll 4
-        for (int pass = 0; pass < 16; ++pass) {
-            const int row = pass * 4 + (lane >> 4);
-            const int gm = m0 + wm * 64 + row;
-            if (gm >= p.M) continue;
-            float4 v = *reinterpret_cast<const float4*>(Es + row * EPI_PITCH + col4);
-            v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
-            const long long o = (long long)gm * p.N + gn;
-            if (direct && p.resid) {
-                const float4 rr = *reinterpret_cast<const float4*>(p.resid + o);
-                v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
-            }
-            if (direct && p.post_mish) { v.x = mish_f(v.x); v.y = mish_f(v.y); v.z = mish_f(v.z); v.w = mish_f(v.w); }
-            *reinterpret_cast<float4*>(outp + o) = v;
-        }
-    }
+    // ---- epilogue: 64x64 block of this wave -> LDS -> float4 rows -> dwordx4 stores
+    store_block_via_lds<TM, TN>(p, acc, smem + wid * 64 * EPI_PITCH, lane, m0 + wm * 64, n0 + wn * 64, split, 0);
     if (STAMPS == 1 && wid == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0) {
@@ -1301,35 +1001,34 @@ static Choice choose_tile(long long M, int N, int nphase, int kiters) {
 }
 
 // ---- halo kernel eligibility and split choice.  Tiles are whole image rows, so W must divide 128, a tile must not
-// straddle images partially, and the (rows+2) x (W+2) halo must fit HALO_MAX_PX.
-static bool halo_eligible(int kind, int B, int H, int W, int N) {
-    static const bool off = getenv("DDK_NO_HALO") != nullptr;   // A/B knob for tools/conv_bench.py
+// straddle images partially, and the (rows+2) x (W+2) halo must fit HALO_MAX_PX.  One workgroup per CU (120 KB of
+// LDS): the channel chunks are split until >= 208 workgroups exist, and the kernel is only used when that leaves
+// >= 4 chunks (36 k-steps) per workgroup -- with less, its 3 us prologue + 3 us epilogue lose to the im2col kernel's
+// smaller tiles (tools/conv_bench.py sweeps, profiles/r01_conv_sweep.txt).
+static bool choose_halo(int kind, int B, int H, int W, int cin, int N, Choice& c) {
+    static const bool off = getenv("DDK_NO_HALO") != nullptr;   // A/B knobs for tools/conv_bench.py
+    static const int min_chunks = getenv("DDK_HALO_MIN_CHUNKS") ? atoi(getenv("DDK_HALO_MIN_CHUNKS")) : 4;
     if (off || kind != DDK_CONV3X3_S1 || N < 128 || N % 32) return false;
     if (W < 8 || W > 128 || 128 % W) return false;
     const int TR = 128 / W;
     if (TR <= H ? (H % TR != 0) : (TR % H != 0)) return false;
     const int TB = TR > H ? TR / H : 1, rows_img = TB > 1 ? H : TR;
     if (TB * (rows_img + 2) * (W + 2) > HALO_MAX_PX) return false;
-    static const int min_tiles = getenv("DDK_HALO_MIN_TILES") ? atoi(getenv("DDK_HALO_MIN_TILES")) : 100;
-    return ceil_div((long long)B * H * W, 128) * ceil_div(N, 128) >= min_tiles;
-}
-
-// One workgroup per CU (113 KB of LDS): split the channel chunks until ~256 workgroups exist, keeping >= 2 chunks
-// (18 k-steps) per workgroup.
-static Choice choose_halo(long long M, int N, int chunks) {
-    const long long tiles = ceil_div(M, 128) * ceil_div(N, 128);
+    const int chunks = cin / 32;
+    const long long tiles = ceil_div((long long)B * H * W, 128) * ceil_div(N, 128);
     long long s = 1;
     if (const char* f = getenv("DDK_FORCE_TILE")) {
         int t = 0, fs = 1;
         if (sscanf(f, "%d,%d", &t, &fs) == 2 && fs >= 1) s = fs;
+        if (s > chunks) s = chunks;
     } else {
-        while (tiles * s < 208 && chunks / (s * 2) >= 2) s *= 2;
+        while (tiles * s < 208 && s < chunks) s *= 2;
+        if (tiles * s < 208 || chunks / s < min_chunks) return false;
     }
-    if (s > chunks) s = chunks;
-    Choice c{T128x128, 1, chunks};
+    c = Choice{T128x128, 1, chunks};
     c.kps = (int)ceil_div(chunks, s);
     c.splits = (int)ceil_div(chunks, c.kps);
-    return c;
+    return true;
 }
 
 static int launch_halo(const IgemmParams& p, hipStream_t st) {
@@ -1356,36 +1055,30 @@ struct ConvPlan {
     Choice c;
 };
 static ConvPlan plan_conv(int kind, int B, int H, int W, int cin, int N, const Geometry& g, bool pre_mish = false) {
-    if (!pre_mish && halo_eligible(kind, B, H, W, N)) return {true, choose_halo((long long)B * H * W, N, cin / 32)};
+    Choice c;
+    if (!pre_mish && choose_halo(kind, B, H, W, cin, N, c)) return {true, c};
     return {false, choose_tile((long long)B * g.Hm * g.Wm, N, g.nphase, g.ntaps * (cin / 32))};
 }
 
 template <int BM, int BN, int WM, int WN>
 static int launch_tile(const IgemmParams& p, hipStream_t st) {
-    static const bool no_dma = getenv("DDK_NO_DMA") != nullptr;  // A/B knobs for tools/conv_bench.py
-    static const bool no_ws = getenv("DDK_WS") == nullptr;          // warp-specialised im2col variant: opt-in (no faster)
+    static const bool no_dma = getenv("DDK_NO_DMA") != nullptr;  // A/B knob for tools/conv_bench.py
     dim3 grid((unsigned)ceil_div(p.M, BM), (unsigned)ceil_div(p.N, BN), (unsigned)(p.nphase * p.splits));
-    if (!p.pre_mish && !no_dma && !no_ws) {
-        constexpr size_t lds = 3 * (size_t)(BM + BN) * 32 * sizeof(float);
-        static bool attr_set = false;
-        if (!attr_set) {
-            DDK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_ws_kernel<BM, BN, WM, WN>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            attr_set = true;
-        }
-        hipLaunchKernelGGL((igemm_ws_kernel<BM, BN, WM, WN>), grid, dim3((WM * WN + 4) * 64), lds, st, p);
-        return check_launch("igemm_ws_kernel");
-    }
     if (!p.pre_mish && !no_dma) {
-        constexpr int STAGES = 2;
-        constexpr size_t lds = STAGES * (size_t)(BM + BN) * 32 * sizeof(float);
+        constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
+        constexpr size_t ring = 2 * (size_t)(BM + BN) * 32 * sizeof(float);
+        constexpr size_t epi = (size_t)WM * WN * TM * 32 * (TN * 32 + 8) * sizeof(float);
+        constexpr size_t lds = ring > epi ? ring : epi;
         static bool attr_set = false;
         if (!attr_set) {
-            DDK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_dma_kernel<BM, BN, WM, WN, STAGES>),
+            DDK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_dma_kernel<BM, BN, WM, WN, 0>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            DDK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_dma_kernel<BM, BN, WM, WN, 1>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             attr_set = true;
         }
-        hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, STAGES>), grid, dim3(WM * WN * 64), lds, st, p);
+        if (p.debug) hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, 1>), grid, dim3(WM * WN * 64), lds, st, p);
+        else hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, 0>), grid, dim3(WM * WN * 64), lds, st, p);
         return check_launch("igemm_dma_kernel");
     }
     constexpr size_t lds = 2 * (size_t)(BM + BN) * LDK * sizeof(float);

@@ -38,12 +38,12 @@ CONV_CASES = [
     ("s1", 4, 8, 8, 256, 256, 256),      # dual source (concat-free skip), K = 4608
     ("s1", 3, 5, 7, 32, 0, 32),          # ragged M, N = 32 tile
     ("s1", 2, 16, 16, 64, 0, 64),        # N = 64 tile
-    # halo-tile kernel (>= 100 output tiles of 128 pixels x 128 channels)
+    # halo-tile kernel (>= 208 workgroups after splitting the channel chunks, >= 4 chunks each)
     ("s1", 32, 16, 16, 256, 256, 256),   # dual source, channel-chunk split
-    ("s1", 67, 8, 8, 64, 0, 384),        # two images per tile, odd batch: last tile half empty
-    ("s1", 64, 16, 16, 32, 0, 160),      # one channel chunk (9 k-steps), ragged N tile
-    ("s1", 50, 8, 32, 32, 0, 128),       # 4-row tiles, two tiles per image
-    ("s1", 16, 32, 32, 96, 0, 128),      # odd chunk count (3): halo double-buffer parity
+    ("s1", 69, 8, 8, 256, 0, 384),       # two images per tile, odd batch: last tile half empty
+    ("s1", 64, 16, 16, 128, 0, 160),     # ragged N tile
+    ("s1", 52, 8, 32, 256, 0, 128),      # 4-row tiles, two tiles per image
+    ("s1", 32, 32, 32, 160, 0, 128),     # odd chunk count (5): halo double-buffer parity
     ("s2", 4, 16, 16, 64, 0, 64),
     ("s2", 32, 32, 32, 128, 0, 128),
     ("s2", 2, 7, 9, 32, 0, 32),          # odd spatial size

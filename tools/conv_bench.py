@@ -14,14 +14,22 @@ SHAPES = [  # name, kind, B, H, W, c0, c1, N
     ("3x3 128->128 @32", ops.CONV3X3_S1, 32, 32, 32, 128, 0, 128),
     ("3x3 256->256 @16", ops.CONV3X3_S1, 32, 16, 16, 256, 0, 256),
     ("3x3 512->128 @16", ops.CONV3X3_S1, 32, 16, 16, 256, 256, 128),
+    ("3x3 128->128 @16", ops.CONV3X3_S1, 32, 16, 16, 128, 0, 128),
+    ("3x3 128->256 @16", ops.CONV3X3_S1, 32, 16, 16, 128, 0, 256),
     ("3x3 256->256 @8", ops.CONV3X3_S1, 32, 8, 8, 256, 0, 256),
     ("3x3 512->256 @8", ops.CONV3X3_S1, 32, 8, 8, 256, 256, 256),
     ("3x3 256->256 @4", ops.CONV3X3_S1, 32, 4, 4, 256, 0, 256),
+    ("3x3 512->256 @4", ops.CONV3X3_S1, 32, 4, 4, 256, 256, 256),
     ("1x1 128->384 @32", ops.CONV1X1, 32, 32, 32, 128, 0, 384),
     ("1x1 128->128 @32", ops.CONV1X1, 32, 32, 32, 128, 0, 128),
     ("1x1 256->384 @8", ops.CONV1X1, 32, 8, 8, 256, 0, 384),
+    ("1x1 256->384 @16", ops.CONV1X1, 32, 16, 16, 256, 0, 384),
+    ("1x1 256->384 @4", ops.CONV1X1, 32, 4, 4, 256, 0, 384),
     ("s2 128->128 @32", ops.CONV3X3_S2, 32, 32, 32, 128, 0, 128),
+    ("s2 256->256 @16", ops.CONV3X3_S2, 32, 16, 16, 256, 0, 256),
+    ("s2 256->256 @8", ops.CONV3X3_S2, 32, 8, 8, 256, 0, 256),
     ("T 128->128 @16", ops.CONVT4X4_S2, 32, 16, 16, 128, 0, 128),
+    ("T 256->256 @8", ops.CONVT4X4_S2, 32, 8, 8, 256, 0, 256),
     ("T 256->256 @4", ops.CONVT4X4_S2, 32, 4, 4, 256, 0, 256),
 ]
 
@@ -68,7 +76,7 @@ def main():
         line = f"{name:18s} {fl / 1e9:6.3f} GF auto {us:6.1f}us {fl / us / 1e6:5.1f}TF |"
         if not quick:
             for t in (0, 1, 2):
-                for s in (1, 2, 4, 8):
+                for s in (1, 2, 4, 8, 16):
                     os.environ["DDK_FORCE_TILE"] = f"{t},{s}"
                     try:
                         u = timeit(lambda: ops.conv(kind, x0, wp, bias, x2=x1), n=15)
