@@ -86,7 +86,7 @@ def time_conv_roofline(device):
             traffic = json.load(f)["traffic_bytes_per_launch"]
     except Exception:
         pass
-    return dict(kernel="igemm_dma_kernel conv3x3 128->128 @32x32 B=32 (fp32 MFMA implicit GEMM)", bound="mfma",
+    return dict(kernel="conv3x3_halo_kernel conv3x3 128->128 @32x32 B=32 (fp32 MFMA, halo-tile implicit GEMM)", bound="mfma",
                 achieved=flops / sec / 1e12, peak=FP32_PEAK_TFLOPS, unit="TFLOP/s", frac=flops / sec / 1e12 / FP32_PEAK_TFLOPS,
                 traffic=traffic, launch_us=sec * 1e6, algorithmic_gflop=flops / 1e9, algorithmic_mbytes=bytes_alg / 1e6,
                 algorithmic_hbm_gbps=bytes_alg / sec / 1e9)
