@@ -12,23 +12,31 @@ namespace ddk {
 
 constexpr int DH = 32;  // dim_head (blocks.py:119)
 
-// One workgroup per (b, head).  Pass 1: column max of k over n.  Pass 2: tiles of 64 pixels -> LDS
-// (exp(k - max), v), each thread accumulates a 1x4 strip of ctx plus the softmax denominator of its row.
-__global__ __launch_bounds__(256) void linattn_context_kernel(const float* __restrict__ qkv, float* __restrict__ ctx, int HW, int heads) {
+// One workgroup per (b, head, split of the pixel range).  Pass 1: column max of k over its pixels.  Pass 2: tiles of
+// 64 pixels -> LDS (exp(k - max), v), each thread accumulates a 1x4 strip of ctx plus the softmax denominator of its
+// row.  With one split the normalised context is written directly; otherwise the split's (max, denominator,
+// unnormalised ctx) go to the workspace and linattn_merge_kernel combines them in split order (deterministic):
+// softmax is invariant to the subtracted constant, so partials rescale by exp(m_s - max_s m_s).
+constexpr int PART = DH + DH + DH * DH;  // floats per partial: max[32], den[32], acc[32][32]
+
+__global__ __launch_bounds__(256) void linattn_context_kernel(const float* __restrict__ qkv, float* __restrict__ ctx,
+                                                              float* __restrict__ part, int HW, int heads, int splits, int rows_per_split) {
     __shared__ __attribute__((aligned(16))) float kexp[64 * DH];
     __shared__ __attribute__((aligned(16))) float vs[64 * DH];
     __shared__ float smax[8 * DH];
-    const int b = blockIdx.x / heads, h = blockIdx.x % heads;
+    const int bh = blockIdx.x / splits, sp = blockIdx.x % splits;
+    const int b = bh / heads, h = bh % heads;
     const int HC = heads * DH, RS = 3 * HC;
     const float* base = qkv + (long long)b * HW * RS;
     const float* kp = base + HC + h * DH;
     const float* vp = base + 2 * HC + h * DH;
     const int tid = threadIdx.x;
+    const int n_begin = sp * rows_per_split, n_end = min(HW, n_begin + rows_per_split);
 
-    {   // pass 1: max_n k[n][d]
+    {   // pass 1: max_n k[n][d] over this split
         const int d = tid & 31, ng = tid >> 5;
         float m = -INFINITY;
-        for (int n = ng; n < HW; n += 8) m = fmaxf(m, kp[(long long)n * RS + d]);
+        for (int n = n_begin + ng; n < n_end; n += 8) m = fmaxf(m, kp[(long long)n * RS + d]);
         smax[ng * DH + d] = m;
         __syncthreads();
         if (tid < DH) {
@@ -43,13 +51,13 @@ __global__ __launch_bounds__(256) void linattn_context_kernel(const float* __res
     const int d = tid >> 3, e0 = (tid & 7) * 4;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     float den = 0.f;
-    for (int n0 = 0; n0 < HW; n0 += 64) {
+    for (int n0 = n_begin; n0 < n_end; n0 += 64) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int idx4 = tid + j * 256;
             const int row = idx4 >> 3, c = (idx4 & 7) * 4;
             float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
-            if (n0 + row < HW) {
+            if (n0 + row < n_end) {
                 kv = *reinterpret_cast<const float4*>(kp + (long long)(n0 + row) * RS + c);
                 vv = *reinterpret_cast<const float4*>(vp + (long long)(n0 + row) * RS + c);
                 kv.x = expf(kv.x - smax[c]);
@@ -70,9 +78,34 @@ __global__ __launch_bounds__(256) void linattn_context_kernel(const float* __res
         }
         __syncthreads();
     }
+    if (splits == 1) {
+        const float inv = 1.0f / den;
+        acc.x *= inv; acc.y *= inv; acc.z *= inv; acc.w *= inv;
+        *reinterpret_cast<float4*>(ctx + ((long long)bh * DH + d) * DH + e0) = acc;
+    } else {
+        float* pp = part + ((long long)bh * splits + sp) * PART;
+        if (e0 == 0) { pp[d] = smax[d]; pp[DH + d] = den; }
+        *reinterpret_cast<float4*>(pp + 2 * DH + d * DH + e0) = acc;
+    }
+}
+
+__global__ __launch_bounds__(256) void linattn_merge_kernel(const float* __restrict__ part, float* __restrict__ ctx, int splits) {
+    const int bh = blockIdx.x, tid = threadIdx.x;
+    const int d = tid >> 3, e0 = (tid & 7) * 4;
+    const float* pp = part + (long long)bh * splits * PART;
+    float M = -INFINITY;
+    for (int s = 0; s < splits; ++s) M = fmaxf(M, pp[s * PART + d]);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float den = 0.f;
+    for (int s = 0; s < splits; ++s) {
+        const float w = expf(pp[s * PART + d] - M);
+        const float4 a = *reinterpret_cast<const float4*>(pp + s * PART + 2 * DH + d * DH + e0);
+        den += pp[s * PART + DH + d] * w;
+        acc.x += a.x * w; acc.y += a.y * w; acc.z += a.z * w; acc.w += a.w * w;
+    }
     const float inv = 1.0f / den;
     acc.x *= inv; acc.y *= inv; acc.z *= inv; acc.w *= inv;
-    *reinterpret_cast<float4*>(ctx + (((long long)b * heads + h) * DH + d) * DH + e0) = acc;
+    *reinterpret_cast<float4*>(ctx + ((long long)bh * DH + d) * DH + e0) = acc;
 }
 
 // 64 pixels x `heads` threads per workgroup; the sample's ctx (heads x 32 x 32) sits in LDS with a
@@ -118,11 +151,43 @@ __global__ __launch_bounds__(512) void linattn_apply_kernel(const float* __restr
     for (int i = 0; i < DH / 4; ++i) *reinterpret_cast<float4*>(op + i * 4) = acc[i];
 }
 
-int linattn_context(const float* qkv, float* ctx, int B, int HW, int heads, hipStream_t st) {
+// Pixel-range splits: ~1024 workgroups at most, at least one 64-pixel tile each.
+static void linattn_splits(int B, int HW, int heads, int& splits, int& rows) {
+    const int max_s = (int)ceil_div(HW, 64);
+    int s = 1024 / (B * heads);
+    if (s < 1) s = 1;
+    if (s > max_s) s = max_s;
+    rows = (int)(ceil_div(ceil_div(HW, s), 64) * 64);
+    splits = (int)ceil_div(HW, rows);
+}
+
+size_t linattn_context_workspace_bytes(int B, int HW, int heads) {
+    if (B <= 0 || HW <= 0 || heads <= 0) return 0;
+    int s, rows;
+    linattn_splits(B, HW, heads, s, rows);
+    return s > 1 ? (size_t)B * heads * s * PART * sizeof(float) : 0;
+}
+
+int linattn_context(const float* qkv, float* ctx, int B, int HW, int heads, void* workspace, size_t workspace_bytes, hipStream_t st) {
     DDK_REQUIRE(qkv && ctx && B > 0 && HW > 0 && heads > 0, "linattn_context: arguments");
-    DDK_REQUIRE(aligned16(qkv) && aligned16(ctx), "linattn_context: alignment");
-    hipLaunchKernelGGL(linattn_context_kernel, dim3(B * heads), dim3(256), 0, st, qkv, ctx, HW, heads);
-    return check_launch("linattn_context_kernel");
+    DDK_REQUIRE(aligned16(qkv) && aligned16(ctx) && aligned16(workspace), "linattn_context: alignment");
+    int s, rows;
+    linattn_splits(B, HW, heads, s, rows);
+    if (s > 1 && (!workspace || workspace_bytes < (size_t)B * heads * s * PART * sizeof(float))) {
+        if (workspace) {   // a workspace that is too small is a caller bug; none at all selects the unsplit kernel
+            set_error("linattn_context: workspace too small (%zu < %zu)", workspace_bytes, (size_t)B * heads * s * PART * sizeof(float));
+            return DDK_ERR_WORKSPACE;
+        }
+        s = 1;
+        rows = HW;
+    }
+    hipLaunchKernelGGL(linattn_context_kernel, dim3(B * heads * s), dim3(256), 0, st, qkv, ctx, static_cast<float*>(workspace), HW, heads, s, rows);
+    DDK_TRY(check_launch("linattn_context_kernel"));
+    if (s > 1) {
+        hipLaunchKernelGGL(linattn_merge_kernel, dim3(B * heads), dim3(256), 0, st, static_cast<const float*>(workspace), ctx, s);
+        DDK_TRY(check_launch("linattn_merge_kernel"));
+    }
+    return DDK_OK;
 }
 
 int linattn_apply(const float* qkv, const float* ctx, float* out, int B, int HW, int heads, hipStream_t st) {
@@ -138,8 +203,9 @@ int linattn_apply(const float* qkv, const float* ctx, float* out, int B, int HW,
 }  // namespace ddk
 
 extern "C" {
-int ddk_linattn_context(const float* qkv, float* ctx, int B, int HW, int heads, ddk_stream_t s) {
-    return ddk::linattn_context(qkv, ctx, B, HW, heads, ddk::as_stream(s));
+size_t ddk_linattn_context_workspace_bytes(int B, int HW, int heads) { return ddk::linattn_context_workspace_bytes(B, HW, heads); }
+int ddk_linattn_context(const float* qkv, float* ctx, int B, int HW, int heads, void* workspace, size_t workspace_bytes, ddk_stream_t s) {
+    return ddk::linattn_context(qkv, ctx, B, HW, heads, workspace, workspace_bytes, ddk::as_stream(s));
 }
 int ddk_linattn_apply(const float* qkv, const float* ctx, float* out, int B, int HW, int heads, ddk_stream_t s) {
     return ddk::linattn_apply(qkv, ctx, out, B, HW, heads, ddk::as_stream(s));

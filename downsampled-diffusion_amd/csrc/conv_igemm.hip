@@ -327,10 +327,8 @@ __device__ __forceinline__ void consume_epilogue_args(const IgemmParams& p) {
 template <int BM, int BN, int WM, int WN, int DBG>
 __global__ __launch_bounds__(WM* WN * 64) void igemm_dma_kernel(const IgemmParams p) {
     constexpr int NW = WM * WN;
-    constexpr int STAGES = 2;
     constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
     constexpr int A_PW = BM / 8 / NW, B_PW = BN / 8 / NW;  // 1-KiB DMA pieces per wave per stage
-    constexpr int PW = A_PW + B_PW;
     constexpr int STAGE = (BM + BN) * 32;                  // floats
     static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile rows must split into 8-row pieces per wave");
     const int dbg = DBG ? p.debug : 0;
@@ -567,7 +565,6 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const IgemmParams p) 
     constexpr int H_PW = HALO_PIECES_PER_LOADER;
     constexpr int HALO_FLOATS = HALO_MAX_PX * 32;
     constexpr int BST = BN * 32;                             // floats per weight stage
-    constexpr int NST = 4;
     constexpr int EPI_PITCH = 72;                            // 64 + 8: rows +4 apart land 32 banks apart
     static_assert(4 * 64 * EPI_PITCH <= HALO_LDS_FLOATS, "epilogue staging fits");
 

@@ -118,7 +118,8 @@ int add(const float* a, const float* b, float* out, long long n, hipStream_t st)
 int avgpool2(const float* x, float* out, int B, int H, int W, int C, hipStream_t st);
 int upsample_nearest2(const float* x, float* out, int B, int H, int W, int C, hipStream_t st);
 // attention.hip
-int linattn_context(const float* qkv, float* ctx, int B, int HW, int heads, hipStream_t st);
+size_t linattn_context_workspace_bytes(int B, int HW, int heads);
+int linattn_context(const float* qkv, float* ctx, int B, int HW, int heads, void* workspace, size_t workspace_bytes, hipStream_t st);
 int linattn_apply(const float* qkv, const float* ctx, float* out, int B, int HW, int heads, hipStream_t st);
 // time_embed.hip
 int time_mlp(const int64_t* t, const float* freqs, const float* w1t, const float* b1, const float* w2t, const float* b2,

@@ -268,6 +268,7 @@ static void attn_sizes(const AttnW& a, int B, int H, int W, Layout& ly) {
     upd(ly.qkv, M * 3 * HIDDEN);
     upd(ly.o, M * HIDDEN);
     upd(ly.ctx, (size_t)B * HEADS * 32 * 32);
+    upd(ly.splitk, linattn_context_workspace_bytes(B, H * W, HEADS) / 4);   // the context partials reuse the split-K slab area
     upd(ly.splitk, conv_workspace_bytes(DDK_CONV1X1, B, H, W, a.c, 3 * HIDDEN) / 4);
     upd(ly.splitk, conv_workspace_bytes(DDK_CONV1X1, B, H, W, HIDDEN, a.c) / 4);
 }
@@ -385,7 +386,6 @@ static int run_res(Ctx& c, const ResW& r, const float* src0, int c0, const float
     float* raw = c.W + c.ly.off_raw;
     float* a1 = c.W + c.ly.off_a1;
     float* res = c.W + c.ly.off_res;
-    const int HW = H * W;
     // the 1x1 skip first: the second conv's split-K slabs and the skip conv's would otherwise share the workspace
     const float* addend = src0;
     if (r.has_res) {
@@ -405,7 +405,7 @@ static int run_attn(Ctx& c, const AttnW& a, const float* x, float* out, int H, i
     const long long M = (long long)c.B * H * W;
     DDK_TRY(chan_layernorm(x, c.P + a.ln.g, c.P + a.ln.b, xn, M, a.c, LN_EPS, c.st));
     DDK_TRY(run_conv(c, DDK_CONV1X1, a.qkv, xn, a.c, nullptr, 0, nullptr, qkv, H, W, 3 * HIDDEN));
-    DDK_TRY(linattn_context(qkv, ctx, c.B, H * W, HEADS, c.st));
+    DDK_TRY(linattn_context(qkv, ctx, c.B, H * W, HEADS, c.W + c.ly.off_splitk, c.ly.splitk * sizeof(float), c.st));
     DDK_TRY(linattn_apply(qkv, ctx, o, c.B, H * W, HEADS, c.st));
     return run_conv(c, DDK_CONV1X1, a.out, o, HIDDEN, nullptr, 0, x, out, H, W, a.c);
 }

@@ -66,7 +66,8 @@ SIGNATURES = {
     "ddk_avgpool2": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "ddk_upsample_nearest2": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "ddk_add": (_I, [_P, _P, _P, _LL, _P]),
-    "ddk_linattn_context": (_I, [_P, _P, _I, _I, _I, _P]),
+    "ddk_linattn_context_workspace_bytes": (_SZ, [_I, _I, _I]),
+    "ddk_linattn_context": (_I, [_P, _P, _I, _I, _I, _P, _SZ, _P]),
     "ddk_linattn_apply": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "ddk_time_mlp": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "ddk_time_proj": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),

@@ -115,8 +115,11 @@ int ddk_upsample_nearest2(const float* x, float* out, int B, int H, int W, int C
 int ddk_add(const float* a, const float* b, float* out, long long n, ddk_stream_t s);
 
 /* ------------------------------------------------------------------ linear attention (blocks.py:126-134) */
-/* qkv: [B][HW][3*heads*32], channel = (qkv, head, c).  ctx[b][h][d][e] = sum_n softmax_n(k[d,:])[n] v[e,n]. */
-int ddk_linattn_context(const float* qkv, float* ctx, int B, int HW, int heads, ddk_stream_t s);
+/* qkv: [B][HW][3*heads*32], channel = (qkv, head, c).  ctx[b][h][d][e] = sum_n softmax_n(k[d,:])[n] v[e,n].
+   The pixel range is split over workgroups when a workspace of ddk_linattn_context_workspace_bytes() is given
+   (partials merged in split order: deterministic); workspace == NULL runs one workgroup per (b, head). */
+size_t ddk_linattn_context_workspace_bytes(int B, int HW, int heads);
+int ddk_linattn_context(const float* qkv, float* ctx, int B, int HW, int heads, void* workspace, size_t workspace_bytes, ddk_stream_t s);
 /* out[b][n][h*32+e] = sum_d ctx[b][h][d][e] * q[b][n][h*32+d]. */
 int ddk_linattn_apply(const float* qkv, const float* ctx, float* out, int B, int HW, int heads, ddk_stream_t s);
 
