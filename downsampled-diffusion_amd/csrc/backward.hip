@@ -193,6 +193,169 @@ __global__ __launch_bounds__(NT) void gn_train_kernel(const float* __restrict__ 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Large group slabs (full-resolution DDPM: 256x256 x 16 channels = 1M elements per (b, group)): the same arithmetic
+// streamed from memory by `ns` workgroups per (b, group).
+//   stats:   gn_stats_partials (Welford partials, norm_act.hip) -> gn_big_finalize_kernel -> (mean, rstd) per (b, group)
+//   forward: gn_big_fwd_kernel, one elementwise pass
+//   backward: pass A accumulates, per split, the group sums of du*gamma and du*gamma*xhat and the per-channel
+//            (dtemb, dgamma, dbeta) rows; gn_big_finalize2 adds the splits in order; pass B recomputes du and writes dx.
+__global__ void gn_big_finalize_kernel(const float* __restrict__ part, int ns, float* __restrict__ stat, int n_bg, float eps) {
+    const int bg = blockIdx.x * blockDim.x + threadIdx.x;
+    if (bg >= n_bg) return;
+    const float* pp = part + (long long)bg * ns * 3;
+    float n = pp[0], mean = pp[1], m2 = pp[2];   // Chan et al. combination, fixed order
+    for (int s = 1; s < ns; ++s) {
+        const float nb = pp[3 * s], mb = pp[3 * s + 1], qb = pp[3 * s + 2];
+        if (nb > 0) {
+            const float tot = n + nb, delta = mb - mean;
+            mean += delta * (nb / tot);
+            m2 += qb + delta * delta * (n * nb / tot);
+            n = tot;
+        }
+    }
+    stat[2 * bg] = mean;
+    stat[2 * bg + 1] = 1.0f / sqrtf(m2 / n + eps);
+}
+
+__global__ __launch_bounds__(256) void gn_big_fwd_kernel(const float* __restrict__ x, const float* __restrict__ stat,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         const float* __restrict__ temb, int temb_stride, const float* __restrict__ addend,
+                                                         float drop_p, uint64_t seed, uint32_t layer, float* __restrict__ out, int HW, int C,
+                                                         int groups, long long total4) {
+    const int c4 = C >> 2, cpg = C / groups;
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total4; i += (long long)gridDim.x * 256) {
+        const int cq = (int)(i % c4);
+        const long long pix = i / c4;
+        const int b = (int)(pix / HW);
+        const int c0 = cq * 4, g = c0 / cpg;
+        const float mean = stat[2 * (b * groups + g)], rstd = stat[2 * (b * groups + g) + 1];
+        const float4 v = reinterpret_cast<const float4*>(x)[i];
+        const float4 ga = *reinterpret_cast<const float4*>(gamma + c0);
+        const float4 be = *reinterpret_cast<const float4*>(beta + c0);
+        float4 y;
+        y.x = mish_f((v.x - mean) * rstd * ga.x + be.x);
+        y.y = mish_f((v.y - mean) * rstd * ga.y + be.y);
+        y.z = mish_f((v.z - mean) * rstd * ga.z + be.z);
+        y.w = mish_f((v.w - mean) * rstd * ga.w + be.w);
+        if (temb) {
+            const float4 t = *reinterpret_cast<const float4*>(temb + (long long)b * temb_stride + c0);
+            y.x += t.x; y.y += t.y; y.z += t.z; y.w += t.w;
+        }
+        if (drop_p > 0.f) {
+            const float4 m = dropout_scale4(i, drop_p, seed, layer);
+            y.x *= m.x; y.y *= m.y; y.z *= m.z; y.w *= m.w;
+        }
+        if (addend) {
+            const float4 r = reinterpret_cast<const float4*>(addend)[i];
+            y.x += r.x; y.y += r.y; y.z += r.z; y.w += r.w;
+        }
+        reinterpret_cast<float4*>(out)[i] = y;
+    }
+}
+
+// PASS 0: group sums + per-channel rows of this split.  PASS 1: dx (m1, m2 read from gsum, already summed over splits).
+template <int PASS>
+__global__ __launch_bounds__(256) void gn_big_bwd_kernel(const float* __restrict__ x, const float* __restrict__ stat,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta, float drop_p,
+                                                         uint64_t seed, uint32_t layer, const float* __restrict__ dy,
+                                                         float* __restrict__ dx, float* __restrict__ gpart /* [bg][ns][2] */,
+                                                         const float* __restrict__ gsum /* [bg][2] */,
+                                                         float* __restrict__ cpart /* [ns][3][B][C] */, int B, int HW, int C, int groups,
+                                                         int ns) {
+    __shared__ float red[32];
+    __shared__ float csum[4][8][12];
+    const int bg = blockIdx.x, sp = blockIdx.y;
+    const int b = bg / groups, g = bg % groups;
+    const int cpg = C / groups, upr = cpg >> 2;
+    const long long units = (long long)HW * upr;
+    long long per = (units + ns - 1) / ns;
+    per = (per + 255) / 256 * 256;               // multiple of 256 (and of upr): a thread keeps one channel quad
+    const long long u0 = sp * per, u1 = (u0 + per < units) ? u0 + per : units;
+    const long long base = (long long)b * HW * C + g * cpg;
+    const float mean = stat[2 * bg], rstd = stat[2 * bg + 1];
+    const int cu_t = threadIdx.x % upr;
+    const int c0 = g * cpg + cu_t * 4;
+    const float4 ga = *reinterpret_cast<const float4*>(gamma + c0);
+    const float4 be = *reinterpret_cast<const float4*>(beta + c0);
+    const float inv_n = 1.0f / (float)((long long)HW * cpg);
+    float m1 = 0.f, m2 = 0.f;
+    if (PASS == 1) { m1 = gsum[2 * bg] * inv_n; m2 = gsum[2 * bg + 1] * inv_n; }
+
+    float4 st = make_float4(0.f, 0.f, 0.f, 0.f), sg = st, sb = st;
+    float s1 = 0.f, s2 = 0.f;
+    for (long long u = u0 + threadIdx.x; u < u1; u += 256) {
+        const long long row = u / upr;
+        const long long o = base + row * C + cu_t * 4;
+        const float4 v = *reinterpret_cast<const float4*>(x + o);
+        float4 g1 = *reinterpret_cast<const float4*>(dy + o);
+        if (drop_p > 0.f) {
+            const float4 m = dropout_scale4(o >> 2, drop_p, seed, layer);
+            g1.x *= m.x; g1.y *= m.y; g1.z *= m.z; g1.w *= m.w;
+        }
+        const float xh0 = (v.x - mean) * rstd, xh1 = (v.y - mean) * rstd, xh2 = (v.z - mean) * rstd, xh3 = (v.w - mean) * rstd;
+        float4 d;
+        d.x = g1.x * mish_grad_f(xh0 * ga.x + be.x);
+        d.y = g1.y * mish_grad_f(xh1 * ga.y + be.y);
+        d.z = g1.z * mish_grad_f(xh2 * ga.z + be.z);
+        d.w = g1.w * mish_grad_f(xh3 * ga.w + be.w);
+        if (PASS == 0) {
+            st.x += g1.x; st.y += g1.y; st.z += g1.z; st.w += g1.w;
+            sb.x += d.x; sb.y += d.y; sb.z += d.z; sb.w += d.w;
+            sg.x += d.x * xh0; sg.y += d.y * xh1; sg.z += d.z * xh2; sg.w += d.w * xh3;
+        }
+        d.x *= ga.x; d.y *= ga.y; d.z *= ga.z; d.w *= ga.w;
+        if (PASS == 0) {
+            s1 += (d.x + d.y) + (d.z + d.w);
+            s2 += (d.x * xh0 + d.y * xh1) + (d.z * xh2 + d.w * xh3);
+        } else {
+            float4 r;
+            r.x = rstd * (d.x - m1 - xh0 * m2);
+            r.y = rstd * (d.y - m1 - xh1 * m2);
+            r.z = rstd * (d.z - m1 - xh2 * m2);
+            r.w = rstd * (d.w - m1 - xh3 * m2);
+            *reinterpret_cast<float4*>(dx + o) = r;
+        }
+    }
+    if (PASS == 1) return;
+    const float t1 = block_sum(s1, red), t2 = block_sum(s2, red);
+    if (threadIdx.x == 0) { gpart[((long long)bg * ns + sp) * 2] = t1; gpart[((long long)bg * ns + sp) * 2 + 1] = t2; }
+    float vals[12] = {st.x, st.y, st.z, st.w, sg.x, sg.y, sg.z, sg.w, sb.x, sb.y, sb.z, sb.w};
+#pragma unroll
+    for (int k = 0; k < 12; ++k)
+        for (int o = upr; o < 64; o <<= 1) vals[k] += __shfl_xor(vals[k], o, 64);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane < upr)
+#pragma unroll
+        for (int k = 0; k < 12; ++k) csum[wid][lane][k] = vals[k];
+    __syncthreads();
+    if (threadIdx.x < upr * 12) {
+        const int cu = threadIdx.x / 12, k = threadIdx.x % 12;
+        const float t = (csum[0][cu][k] + csum[1][cu][k]) + (csum[2][cu][k] + csum[3][cu][k]);
+        const int which = k >> 2, ch = g * cpg + cu * 4 + (k & 3);
+        cpart[(((long long)sp * 3 + which) * B + b) * C + ch] = t;
+    }
+}
+
+// gsum[bg][k] = sum_s gpart[bg][s][k];  part[i] = sum_s cpart[s][i]   (fixed order)
+__global__ void gn_big_finalize2_kernel(const float* __restrict__ gpart, float* __restrict__ gsum, int n_bg, const float* __restrict__ cpart,
+                                        float* __restrict__ part, long long n_c, int ns) {
+    const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    if (i < 2LL * n_bg) {
+        const long long bg = i >> 1;
+        const int k = (int)(i & 1);
+        float t = 0.f;
+        for (int s = 0; s < ns; ++s) t += gpart[(bg * ns + s) * 2 + k];
+        gsum[i] = t;
+    }
+    if (i < n_c) {
+        float t = 0.f;
+        for (int s = 0; s < ns; ++s) t += cpart[(long long)s * n_c + i];
+        part[i] = t;
+    }
+}
+
 // out[n] (+)= sum_r rows[r][n]  (fixed order)
 __global__ __launch_bounds__(256) void rows_sum_kernel(const float* __restrict__ rows, int nrows, long long row_stride,
                                                        float* __restrict__ out, int n, int accumulate) {
@@ -666,21 +829,67 @@ extern "C" {
 /* Train-mode forward of GroupNorm+Mish: y = dropout_p(mish(gn(x)) + temb) + addend (blocks.py:106-111). */
 int ddk_groupnorm_mish_train_fwd(const float* x, const float* gamma, const float* beta, const float* temb, int temb_stride,
                                  const float* addend, float drop_p, uint64_t seed, uint32_t layer, float* out, int B, int HW, int C,
-                                 int groups, float eps, ddk_stream_t s);
+                                 int groups, float eps, void* workspace, size_t workspace_bytes, ddk_stream_t s);
 /* Backward of the same: dx, and partial rows part[3][B][C] = (dtemb, dgamma, dbeta) per sample. */
 int ddk_groupnorm_mish_bwd(const float* x, const float* gamma, const float* beta, float drop_p, uint64_t seed, uint32_t layer,
-                           const float* dy, float* dx, float* part, int B, int HW, int C, int groups, float eps, ddk_stream_t s);
+                           const float* dy, float* dx, float* part, int B, int HW, int C, int groups, float eps, void* workspace,
+                           size_t workspace_bytes, ddk_stream_t s);
+
+// Workspace of the large-slab path, in floats: [stats partials 3*ns][stat 2][gpart 2*ns][gsum 2] per (b, group), then
+// the per-channel rows [ns][3][B][C].  0 for slabs the register-resident kernel handles.
+static size_t gn_train_ws_floats(int B, int HW, int C, int groups, int& ns) {
+    ns = gn_train_nsplit(HW, C / groups);
+    if (ns == 0) return 0;
+    const size_t n_bg = (size_t)B * groups;
+    return n_bg * (3 * (size_t)ns + 2 + 2 * (size_t)ns + 2) + (size_t)ns * 3 * B * C;
+}
 
 static int gn_train_launch(bool bwd, const float* x, const float* gamma, const float* beta, const float* temb, int temb_stride,
                            const float* addend, float drop_p, uint64_t seed, uint32_t layer, const float* dy, float* out, float* part,
-                           int B, int HW, int C, int groups, float eps, hipStream_t st) {
+                           int B, int HW, int C, int groups, float eps, void* ws, size_t ws_bytes, hipStream_t st) {
     DDK_REQUIRE(x && gamma && beta && out, "groupnorm_train: null pointer");
     DDK_REQUIRE(B > 0 && HW > 0 && groups > 0 && C % groups == 0 && (C / groups) % 4 == 0, "groupnorm_train: C/groups % 4");
     DDK_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "groupnorm_train: dropout p");
     const int cpg = C / groups, upr = cpg / 4;
     DDK_REQUIRE(upr <= 8 && (upr & (upr - 1)) == 0, "groupnorm_train: channels per group must be 4, 8, 16 or 32");
     const long long units = (long long)HW * upr;
-    DDK_REQUIRE(units <= 4096, "groupnorm_train: group slab too large for the register-resident kernel (HW * C/groups <= 16384)");
+    int ns = 0;
+    const size_t need = gn_train_ws_floats(B, HW, C, groups, ns) * sizeof(float);
+    if (ns > 0) {
+        if (!ws || ws_bytes < need) {
+            set_error("groupnorm_train: workspace too small (%zu < %zu)", ws_bytes, need);
+            return DDK_ERR_WORKSPACE;
+        }
+        DDK_REQUIRE(aligned16(ws), "groupnorm_train: workspace alignment");
+        const int n_bg = B * groups;
+        float* w_part = static_cast<float*>(ws);
+        float* w_stat = w_part + (size_t)n_bg * 3 * ns;
+        float* w_gpart = w_stat + (size_t)n_bg * 2;
+        float* w_gsum = w_gpart + (size_t)n_bg * 2 * ns;
+        float* w_cpart = w_gsum + (size_t)n_bg * 2;
+        DDK_TRY(gn_stats_partials(x, w_part, B, HW, C, groups, ns, st));
+        hipLaunchKernelGGL(gn_big_finalize_kernel, dim3((unsigned)ceil_div(n_bg, 64)), dim3(64), 0, st, w_part, ns, w_stat, n_bg, eps);
+        DDK_TRY(check_launch("gn_big_finalize_kernel"));
+        const long long total4 = (long long)B * HW * C / 4;
+        if (!bwd) {
+            const int blocks = (int)(ceil_div(total4, 256) < 8192 ? ceil_div(total4, 256) : 8192);
+            hipLaunchKernelGGL(gn_big_fwd_kernel, dim3(blocks), dim3(256), 0, st, x, w_stat, gamma, beta, temb, temb_stride, addend, drop_p,
+                               seed, layer, out, HW, C, groups, total4);
+            return check_launch("gn_big_fwd_kernel");
+        }
+        hipLaunchKernelGGL(gn_big_bwd_kernel<0>, dim3(n_bg, ns), dim3(256), 0, st, x, w_stat, gamma, beta, drop_p, seed, layer, dy, out,
+                           w_gpart, w_gsum, w_cpart, B, HW, C, groups, ns);
+        DDK_TRY(check_launch("gn_big_bwd_kernel<0>"));
+        const long long n_c = 3LL * B * C;
+        const long long nthr = n_c > 2LL * n_bg ? n_c : 2LL * n_bg;
+        hipLaunchKernelGGL(gn_big_finalize2_kernel, dim3((unsigned)ceil_div(nthr, 256)), dim3(256), 0, st, w_gpart, w_gsum, n_bg, w_cpart,
+                           part, n_c, ns);
+        DDK_TRY(check_launch("gn_big_finalize2_kernel"));
+        hipLaunchKernelGGL(gn_big_bwd_kernel<1>, dim3(n_bg, ns), dim3(256), 0, st, x, w_stat, gamma, beta, drop_p, seed, layer, dy, out,
+                           w_gpart, w_gsum, w_cpart, B, HW, C, groups, ns);
+        return check_launch("gn_big_bwd_kernel<1>");
+    }
+    DDK_REQUIRE(units <= 4096, "groupnorm_train: internal: resident path selected for a large slab");
     dim3 grid(B * groups);
 #define GT(V, NT)                                                                                                                 \
     do {                                                                                                                          \
@@ -698,18 +907,25 @@ static int gn_train_launch(bool bwd, const float* x, const float* gamma, const f
     return check_launch("gn_train_kernel");
 }
 
+size_t ddk_groupnorm_train_workspace_bytes(int B, int HW, int C, int groups) {
+    if (B <= 0 || HW <= 0 || groups <= 0 || C % groups) return 0;
+    int ns;
+    return gn_train_ws_floats(B, HW, C, groups, ns) * sizeof(float);
+}
+
 int ddk_groupnorm_mish_train_fwd(const float* x, const float* gamma, const float* beta, const float* temb, int temb_stride,
                                  const float* addend, float drop_p, uint64_t seed, uint32_t layer, float* out, int B, int HW, int C,
-                                 int groups, float eps, ddk_stream_t s) {
+                                 int groups, float eps, void* workspace, size_t workspace_bytes, ddk_stream_t s) {
     return gn_train_launch(false, x, gamma, beta, temb, temb_stride, addend, drop_p, seed, layer, nullptr, out, nullptr, B, HW, C, groups,
-                           eps, as_stream(s));
+                           eps, workspace, workspace_bytes, as_stream(s));
 }
 
 int ddk_groupnorm_mish_bwd(const float* x, const float* gamma, const float* beta, float drop_p, uint64_t seed, uint32_t layer,
-                           const float* dy, float* dx, float* part, int B, int HW, int C, int groups, float eps, ddk_stream_t s) {
+                           const float* dy, float* dx, float* part, int B, int HW, int C, int groups, float eps, void* workspace,
+                           size_t workspace_bytes, ddk_stream_t s) {
     DDK_REQUIRE(dy && part, "groupnorm_bwd: null pointer");
     return gn_train_launch(true, x, gamma, beta, nullptr, 0, nullptr, drop_p, seed, layer, dy, dx, part, B, HW, C, groups, eps,
-                           as_stream(s));
+                           workspace, workspace_bytes, as_stream(s));
 }
 
 /* out[n] (+)= sum_r rows[r*row_stride + n] */

@@ -106,6 +106,8 @@ int conv_splits(int kind, int B, int H, int W, int cin, int N);
 double conv_flops(int kind, int B, int H, int W, int cin, int N);
 // norm_act.hip
 size_t groupnorm_workspace_bytes(int B, int HW, int C, int groups);
+int gn_train_nsplit(int HW, int cpg);
+int gn_stats_partials(const float* x, float* part, int B, int HW, int C, int groups, int ns, hipStream_t st);
 int groupnorm_mish(const float* x, const float* gamma, const float* beta, const float* temb, int temb_stride,
                    const float* addend, float* out, int B, int HW, int C, int groups, float eps, void* ws, size_t ws_bytes,
                    hipStream_t st);

@@ -180,6 +180,13 @@ static int gn_nsplit(int HW, int cpg) {
     return (int)(s > 64 ? 64 : (s < 2 ? 2 : s));
 }
 
+// train-mode callers (backward.hip): same split rule and the same Welford partial kernel
+int gn_train_nsplit(int HW, int cpg) { return gn_nsplit(HW, cpg); }
+int gn_stats_partials(const float* x, float* part, int B, int HW, int C, int groups, int ns, hipStream_t st) {
+    hipLaunchKernelGGL(gn_partial_kernel, dim3(B * groups, ns), dim3(256), 0, st, x, part, HW, C, groups, ns);
+    return check_launch("gn_partial_kernel");
+}
+
 size_t groupnorm_workspace_bytes(int B, int HW, int C, int groups) {
     if (groups <= 0 || C % groups) return 0;
     const int ns = gn_nsplit(HW, C / groups);

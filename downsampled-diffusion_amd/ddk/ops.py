@@ -303,9 +303,13 @@ def groupnorm_mish_train(x, gamma, beta, temb=None, addend=None, drop_p=0.0, see
     b, h, w, c = x.shape
     out = torch.empty_like(x)
     stride = temb.stride(0) if temb is not None else 0
-    L.check(L.load().ddk_groupnorm_mish_train_fwd(L.ptr(_f32(x)), L.ptr(gamma), L.ptr(beta),
-                                                  temb.data_ptr() if temb is not None else None, stride, L.ptr(addend),
-                                                  float(drop_p), seed, layer, L.ptr(out), b, h * w, c, groups, eps, L.stream()),
+    lib = L.load()
+    nbytes = lib.ddk_groupnorm_train_workspace_bytes(b, h * w, c, groups)
+    ws = _ws(x.device, nbytes, "gn_train") if nbytes else None
+    L.check(lib.ddk_groupnorm_mish_train_fwd(L.ptr(_f32(x)), L.ptr(gamma), L.ptr(beta),
+                                             temb.data_ptr() if temb is not None else None, stride, L.ptr(addend),
+                                             float(drop_p), seed, layer, L.ptr(out), b, h * w, c, groups, eps, L.ptr(ws), nbytes,
+                                             L.stream()),
             "groupnorm_mish_train_fwd")
     return out
 
@@ -316,8 +320,11 @@ def groupnorm_mish_bwd(x, gamma, beta, dy, drop_p=0.0, seed=0, layer=0, groups=G
     dx = torch.empty_like(x)
     part = torch.empty((3, b, c), device=x.device, dtype=torch.float32)
     lib = L.load()
+    nbytes = lib.ddk_groupnorm_train_workspace_bytes(b, h * w, c, groups)
+    ws = _ws(x.device, nbytes, "gn_train") if nbytes else None
     L.check(lib.ddk_groupnorm_mish_bwd(L.ptr(_f32(x)), L.ptr(gamma), L.ptr(beta), float(drop_p), seed, layer, L.ptr(_f32(dy)),
-                                       L.ptr(dx), L.ptr(part), b, h * w, c, groups, eps, L.stream()), "groupnorm_mish_bwd")
+                                       L.ptr(dx), L.ptr(part), b, h * w, c, groups, eps, L.ptr(ws), nbytes, L.stream()),
+            "groupnorm_mish_bwd")
     dg = torch.empty(c, device=x.device, dtype=torch.float32)
     db = torch.empty(c, device=x.device, dtype=torch.float32)
     L.check(lib.ddk_rows_sum(L.ptr(part[1]), b, c, L.ptr(dg), c, 0, L.stream()), "rows_sum")

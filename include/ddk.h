@@ -223,14 +223,18 @@ int ddk_conv_wgrad(int kind, const float* x, const float* dy, float* grad_w, int
 /* grad_b[n] (+)= sum_m dy[m][n]; workspace >= 64*N floats */
 int ddk_bias_grad(const float* dy, float* grad_b, long long M, int N, int accumulate, void* workspace,
                   size_t workspace_bytes, ddk_stream_t s);
-/* y = dropout_p(mish(gn(x)) + temb) + addend; the keep mask is a pure function of (seed, layer, element) */
+/* y = dropout_p(mish(gn(x)) + temb) + addend; the keep mask is a pure function of (seed, layer, element).
+   Group slabs up to 16384 elements stay in registers (workspace unused, may be NULL); larger ones (full-resolution
+   DDPM) stream through ddk_groupnorm_train_workspace_bytes() of scratch. */
+size_t ddk_groupnorm_train_workspace_bytes(int B, int HW, int C, int groups);
 int ddk_groupnorm_mish_train_fwd(const float* x, const float* gamma, const float* beta, const float* temb,
                                  int temb_stride, const float* addend, float drop_p, uint64_t seed, uint32_t layer,
-                                 float* out, int B, int HW, int C, int groups, float eps, ddk_stream_t s);
+                                 float* out, int B, int HW, int C, int groups, float eps, void* workspace,
+                                 size_t workspace_bytes, ddk_stream_t s);
 /* dx and per-sample partial rows part[3][B][C] = (dtemb, dgamma, dbeta); d(addend) is dy itself */
 int ddk_groupnorm_mish_bwd(const float* x, const float* gamma, const float* beta, float drop_p, uint64_t seed,
                            uint32_t layer, const float* dy, float* dx, float* part, int B, int HW, int C, int groups,
-                           float eps, ddk_stream_t s);
+                           float eps, void* workspace, size_t workspace_bytes, ddk_stream_t s);
 int ddk_rows_sum(const float* rows, int nrows, long long row_stride, float* out, int n, int accumulate, ddk_stream_t s);
 int ddk_chan_layernorm_bwd(const float* x, const float* g, const float* dy, float* dx, float* part, int max_parts,
                            int* nparts_out, long long M, int C, float eps, ddk_stream_t s);

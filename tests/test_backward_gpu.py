@@ -85,7 +85,9 @@ def test_conv_backward_padded_input_and_residual(AG):
     assert rel_err(wd.grad.cpu(), gw) < 3e-5 and rel_err(bd.grad.cpu(), gb) < 3e-5 and rel_err(rd.grad.cpu(), to_nhwc(gr)) < 1e-6
 
 
-@pytest.mark.parametrize("B,H,W,C", [(2, 8, 8, 32), (4, 16, 16, 128), (8, 32, 32, 128), (3, 4, 4, 256), (2, 16, 16, 256)])
+@pytest.mark.parametrize("B,H,W,C", [(2, 8, 8, 32), (4, 16, 16, 128), (8, 32, 32, 128), (3, 4, 4, 256), (2, 16, 16, 256),
+                                     (2, 48, 48, 128),     # 36864 elements per group: streamed large-slab path, 2 splits
+                                     (1, 100, 90, 64)])    # 72000 per group: 4 splits, ragged last split
 def test_groupnorm_mish_backward(AG, B, H, W, C):
     x = rnd(B, C, H, W, seed=10, scale=2.0) + 0.3
     g, b = 1 + 0.1 * rnd(C, seed=11), 0.1 * rnd(C, seed=12)
@@ -119,6 +121,22 @@ def test_groupnorm_dropout_consistency(AG):
     assert not torch.equal(dropped, AG.groupnorm_mish(x, g, b, temb=temb, drop_p=p, seed=1234, layer=4) == 0)
     y.sum().backward()
     # dtemb[b][c] = sum_hw mask/(1-p)
+    want = (~dropped).float().sum(dim=(1, 2)) / (1 - p)
+    assert torch.allclose(temb.grad, want, rtol=1e-5)
+
+
+def test_groupnorm_dropout_large_slab(AG):
+    """Same mask contract on the streamed large-slab path (64x64 x 16 channels per group = 65536 elements)."""
+    B, H, W, C, p = 2, 64, 64, 128, 0.1
+    x = (rnd(B, H, W, C, seed=21) + 3.0).to(DEV).requires_grad_(True)
+    g, b = torch.ones(C, device=DEV), torch.zeros(C, device=DEV)
+    temb = torch.full((B, C), 5.0, device=DEV).requires_grad_(True)
+    y = AG.groupnorm_mish(x, g, b, temb=temb, drop_p=p, seed=99, layer=7)
+    y0 = AG.groupnorm_mish(x.detach(), g, b, temb=temb.detach(), drop_p=0.0)
+    dropped = (y == 0)
+    assert abs(float(dropped.float().mean()) - p) < 0.005
+    assert torch.allclose(y[~dropped], y0[~dropped] / (1 - p), rtol=1e-6)
+    y.sum().backward()
     want = (~dropped).float().sum(dim=(1, 2)) / (1 - p)
     assert torch.allclose(temb.grad, want, rtol=1e-5)
 
@@ -257,3 +275,36 @@ def test_objective_and_grads_vs_reference(tag):
         assert rel_err(params[n].grad.cpu(), g[f"{tag}_grad_{n}"]) < 1e-3, n
     total = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in model.parameters() if p.grad is not None))
     assert abs(float(total) / float(g[f"{tag}_gradnorm0"]) - 1) < 1e-3
+
+
+def test_unet_grads_large_resolution_vs_oracle():
+    """Full-resolution-style training (cfg5 shape class): 64x64 maps at 64 channels put 32768 elements in a GroupNorm
+    group, i.e. the streamed large-slab kernels; 4096 pixels per sample in the linear attention.  Gradients of a
+    weighted-sum objective against torch-CPU autograd through the oracle's functional UNet."""
+    from models import Unet
+    cfg = dict(unet_chan=64, unet_in=3, unet_dims=(1, 2), unet_dropout=0.0)
+    model = Unet(cfg)
+    sd = syn.fill_state_dict(model.state_dict(), 77)
+    model.load_state_dict(sd)
+    model = model.to(DEV).train()
+    x = syn.synthetic_input((2, 3, 64, 64), "bigres.x")
+    t = torch.tensor([3, 700])
+    wgt = syn.synthetic_normal((2, 3, 64, 64), "bigres.w")
+
+    probe = ["downs.0.0.block1.block.0.weight", "downs.0.0.block1.block.1.weight", "downs.0.2.fn.fn.to_qkv.weight",
+             "ups.0.1.block2.block.0.weight", "final_conv.1.weight", "time_mlp.1.weight", "downs.0.1.mlp.1.bias"]
+    ref_sd = {k: v.clone() for k, v in sd.items()}
+    for k in probe:
+        ref_sd[k].requires_grad_(True)
+    xr = x.clone().requires_grad_(True)
+    out_ref = U.unet_forward(ref_sd, cfg, xr, t)
+    (out_ref * wgt).sum().backward()
+
+    xd = x.to(DEV).requires_grad_(True)
+    out = model(xd, t.to(DEV))
+    assert rel_err(out.detach().cpu(), out_ref.detach()) < 5e-5
+    (out * wgt.to(DEV)).sum().backward()
+    params = dict(model.named_parameters())
+    assert rel_err(xd.grad.cpu(), xr.grad) < 2e-4
+    for k in probe:
+        assert rel_err(params[k].grad.cpu(), ref_sd[k].grad) < 2e-4, k

@@ -48,6 +48,10 @@ if __name__ == "__main__":
     time_train("cfg3 dDDPM-x2 64x64 bs64", DownsampleDDPMAutoencoder(c, Unet(c), DEV, 3), (64, 3, 64, 64))
     c = cfg(128, 3, 32)
     time_train("cfg2 DDPM 32x32 bs64    ", DDPM(c, Unet(c), DEV, 3), (64, 3, 32, 32))
+    # cfg5: full-resolution DDPM, bs=8 per GPU (2 micro-batches of 4)
+    c = cfg(128, 3, 256)
+    time_train("cfg5 DDPM 256x256 bs8     ", DDPM(c, Unet(c), DEV, 3), (4, 3, 256, 256), steps=3)
+    print(f"peak HBM allocated: {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB", flush=True)
     # cfg5 shape: full-resolution forward, B=1, vs the CPU oracle
     from oracle import unet_ref as U
     c = cfg(128, 3, 256)
