@@ -35,8 +35,19 @@ __device__ __forceinline__ U4b philox_u4(unsigned long long idx4, uint32_t a, ui
     }
     return c;
 }
+// Device-resident epoch mixed into every dropout key.  Eager training passes a fresh host seed per forward and leaves
+// the epoch at 0; a captured training step (trainers/graph_step.py) has its seed baked into the graph, so it bumps the
+// epoch with a one-thread kernel at the start of each forward instead -- replays then draw fresh masks, and the backward
+// of the same forward (same epoch) regenerates the identical mask.
+__device__ unsigned long long g_drop_epoch = 0;
+__global__ void drop_epoch_kernel(unsigned long long set_to, int bump) {
+    if (bump) g_drop_epoch += 1;
+    else g_drop_epoch = set_to;
+}
+
 __device__ __forceinline__ float4 dropout_scale4(long long elem4, float p, uint64_t seed, uint32_t layer) {
     // keep with probability 1-p, scale kept values by 1/(1-p)  (nn.Dropout semantics)
+    seed += g_drop_epoch * 0x9E3779B97F4A7C15ull;
     const U4b r = philox_u4((unsigned long long)elem4, layer, 0x44524F50u /* 'DROP' */, seed);
     const uint32_t thr = (uint32_t)((double)p * 4294967296.0);
     const float s = 1.0f / (1.0f - p);
@@ -55,10 +66,10 @@ __global__ __launch_bounds__(NT) void gn_train_kernel(const float* __restrict__ 
                                                       int temb_stride, const float* __restrict__ addend, float drop_p,
                                                       uint64_t seed, uint32_t layer, const float* __restrict__ dy,
                                                       float* __restrict__ out /* fwd: y; bwd: dx */,
-                                                      float* __restrict__ part /* bwd: [3][B][C] dtemb, dgamma, dbeta */, int B, int HW,
+                                                      float* __restrict__ part /* bwd: [4][B][C] dtemb, dgamma, dbeta, sum dx */, int B, int HW,
                                                       int C, int groups, float eps) {
     __shared__ float red[32];
-    __shared__ float csum[16][8][12];  // [wave][cu][4 ch x {dtemb, dgamma, dbeta}]
+    __shared__ float csum[16][8][16];  // [wave][cu][4 ch x {dtemb, dgamma, dbeta, dx}]
     const int b = blockIdx.x / groups, g = blockIdx.x % groups;
     const int cpg = C / groups;
     const int upr = cpg >> 2;
@@ -159,6 +170,7 @@ __global__ __launch_bounds__(NT) void gn_train_kernel(const float* __restrict__ 
     }
     const float m1 = block_sum(s1, red) * inv_n;
     const float m2 = block_sum(s2, red) * inv_n;
+    float4 sx = make_float4(0.f, 0.f, 0.f, 0.f);                     // per-channel sum of dx: bias gradient of the producing conv
 #pragma unroll
     for (int i = 0; i < VPT; ++i) {
         const int u = threadIdx.x + i * NT;
@@ -170,22 +182,23 @@ __global__ __launch_bounds__(NT) void gn_train_kernel(const float* __restrict__ 
             r.y = rstd * (du[i].y - m1 - v[i].y * m2);
             r.z = rstd * (du[i].z - m1 - v[i].z * m2);
             r.w = rstd * (du[i].w - m1 - v[i].w * m2);
+            sx.x += r.x; sx.y += r.y; sx.z += r.z; sx.w += r.w;
             *reinterpret_cast<float4*>(out + o) = r;
         }
     }
     // per-channel sums: lanes with equal (lane % upr) hold the same channel quad -> xor-reduce over the others
-    float vals[12] = {st.x, st.y, st.z, st.w, sg.x, sg.y, sg.z, sg.w, sb.x, sb.y, sb.z, sb.w};
+    float vals[16] = {st.x, st.y, st.z, st.w, sg.x, sg.y, sg.z, sg.w, sb.x, sb.y, sb.z, sb.w, sx.x, sx.y, sx.z, sx.w};
 #pragma unroll
-    for (int k = 0; k < 12; ++k)
+    for (int k = 0; k < 16; ++k)
         for (int o = upr; o < 64; o <<= 1) vals[k] += __shfl_xor(vals[k], o, 64);
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     __syncthreads();
     if (lane < upr)
 #pragma unroll
-        for (int k = 0; k < 12; ++k) csum[wid][lane][k] = vals[k];
+        for (int k = 0; k < 16; ++k) csum[wid][lane][k] = vals[k];
     __syncthreads();
-    if (threadIdx.x < upr * 12) {
-        const int cu = threadIdx.x / 12, k = threadIdx.x % 12;
+    if (threadIdx.x < upr * 16) {
+        const int cu = threadIdx.x / 16, k = threadIdx.x % 16;
         float t = 0.f;
         for (int w = 0; w < NT / 64; ++w) t += csum[w][cu][k];
         const int which = k >> 2, ch = g * cpg + cu * 4 + (k & 3);
@@ -261,10 +274,11 @@ __global__ __launch_bounds__(256) void gn_big_bwd_kernel(const float* __restrict
                                                          uint64_t seed, uint32_t layer, const float* __restrict__ dy,
                                                          float* __restrict__ dx, float* __restrict__ gpart /* [bg][ns][2] */,
                                                          const float* __restrict__ gsum /* [bg][2] */,
-                                                         float* __restrict__ cpart /* [ns][3][B][C] */, int B, int HW, int C, int groups,
+                                                         float* __restrict__ cpart /* [ns][4][B][C] */, int B, int HW, int C, int groups,
                                                          int ns) {
     __shared__ float red[32];
     __shared__ float csum[4][8][12];
+    float4 sx = make_float4(0.f, 0.f, 0.f, 0.f);
     const int bg = blockIdx.x, sp = blockIdx.y;
     const int b = bg / groups, g = bg % groups;
     const int cpg = C / groups, upr = cpg >> 2;
@@ -314,10 +328,27 @@ __global__ __launch_bounds__(256) void gn_big_bwd_kernel(const float* __restrict
             r.y = rstd * (d.y - m1 - xh1 * m2);
             r.z = rstd * (d.z - m1 - xh2 * m2);
             r.w = rstd * (d.w - m1 - xh3 * m2);
+            sx.x += r.x; sx.y += r.y; sx.z += r.z; sx.w += r.w;
             *reinterpret_cast<float4*>(dx + o) = r;
         }
     }
-    if (PASS == 1) return;
+    if (PASS == 1) {   // row kind 3 of this split: per-channel sum of dx
+        float vx[4] = {sx.x, sx.y, sx.z, sx.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            for (int o = upr; o < 64; o <<= 1) vx[k] += __shfl_xor(vx[k], o, 64);
+        const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+        if (lane < upr)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) csum[wid][lane][k] = vx[k];
+        __syncthreads();
+        if (threadIdx.x < upr * 4) {
+            const int cu = threadIdx.x / 4, k = threadIdx.x % 4;
+            const float t = (csum[0][cu][k] + csum[1][cu][k]) + (csum[2][cu][k] + csum[3][cu][k]);
+            cpart[(((long long)sp * 4 + 3) * B + b) * C + g * cpg + cu * 4 + k] = t;
+        }
+        return;
+    }
     const float t1 = block_sum(s1, red), t2 = block_sum(s2, red);
     if (threadIdx.x == 0) { gpart[((long long)bg * ns + sp) * 2] = t1; gpart[((long long)bg * ns + sp) * 2 + 1] = t2; }
     float vals[12] = {st.x, st.y, st.z, st.w, sg.x, sg.y, sg.z, sg.w, sb.x, sb.y, sb.z, sb.w};
@@ -334,7 +365,7 @@ __global__ __launch_bounds__(256) void gn_big_bwd_kernel(const float* __restrict
         const int cu = threadIdx.x / 12, k = threadIdx.x % 12;
         const float t = (csum[0][cu][k] + csum[1][cu][k]) + (csum[2][cu][k] + csum[3][cu][k]);
         const int which = k >> 2, ch = g * cpg + cu * 4 + (k & 3);
-        cpart[(((long long)sp * 3 + which) * B + b) * C + ch] = t;
+        cpart[(((long long)sp * 4 + which) * B + b) * C + ch] = t;
     }
 }
 
@@ -356,14 +387,25 @@ __global__ void gn_big_finalize2_kernel(const float* __restrict__ gpart, float* 
     }
 }
 
-// out[n] (+)= sum_r rows[r][n]  (fixed order)
+// out[k][n] (+)= sum_r rows[k*batch_stride + r*row_stride + n]  (fixed order: 4 interleaved row groups, then the groups)
+// One workgroup per 64 columns of one batch entry k; 4 row groups of 64 lanes keep 4 loads in flight per column.
 __global__ __launch_bounds__(256) void rows_sum_kernel(const float* __restrict__ rows, int nrows, long long row_stride,
-                                                       float* __restrict__ out, int n, int accumulate) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
+                                                       long long batch_stride, float* __restrict__ out, int n, int accumulate) {
+    __shared__ float red[4][64];
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+    const float* base = rows + (long long)blockIdx.y * batch_stride;
     float s = 0.f;
-    for (int r = 0; r < nrows; ++r) s += rows[r * row_stride + i];
-    out[i] = accumulate ? out[i] + s : s;
+    if (col < n) {
+#pragma unroll 4
+        for (int r = rg; r < nrows; r += 4) s += base[r * row_stride + col];
+    }
+    red[rg][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (threadIdx.x < 64 && col < n) {
+        const float t = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        float* o = out + (long long)blockIdx.y * n + col;
+        *o = accumulate ? *o + t : t;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -830,7 +872,7 @@ extern "C" {
 int ddk_groupnorm_mish_train_fwd(const float* x, const float* gamma, const float* beta, const float* temb, int temb_stride,
                                  const float* addend, float drop_p, uint64_t seed, uint32_t layer, float* out, int B, int HW, int C,
                                  int groups, float eps, void* workspace, size_t workspace_bytes, ddk_stream_t s);
-/* Backward of the same: dx, and partial rows part[3][B][C] = (dtemb, dgamma, dbeta) per sample. */
+/* Backward of the same: dx, and partial rows part[4][B][C] = (dtemb, dgamma, dbeta, sum_hw dx) per sample. */
 int ddk_groupnorm_mish_bwd(const float* x, const float* gamma, const float* beta, float drop_p, uint64_t seed, uint32_t layer,
                            const float* dy, float* dx, float* part, int B, int HW, int C, int groups, float eps, void* workspace,
                            size_t workspace_bytes, ddk_stream_t s);
@@ -841,7 +883,7 @@ static size_t gn_train_ws_floats(int B, int HW, int C, int groups, int& ns) {
     ns = gn_train_nsplit(HW, C / groups);
     if (ns == 0) return 0;
     const size_t n_bg = (size_t)B * groups;
-    return n_bg * (3 * (size_t)ns + 2 + 2 * (size_t)ns + 2) + (size_t)ns * 3 * B * C;
+    return n_bg * (3 * (size_t)ns + 2 + 2 * (size_t)ns + 2) + (size_t)ns * 4 * B * C;
 }
 
 static int gn_train_launch(bool bwd, const float* x, const float* gamma, const float* beta, const float* temb, int temb_stride,
@@ -880,14 +922,17 @@ static int gn_train_launch(bool bwd, const float* x, const float* gamma, const f
         hipLaunchKernelGGL(gn_big_bwd_kernel<0>, dim3(n_bg, ns), dim3(256), 0, st, x, w_stat, gamma, beta, drop_p, seed, layer, dy, out,
                            w_gpart, w_gsum, w_cpart, B, HW, C, groups, ns);
         DDK_TRY(check_launch("gn_big_bwd_kernel<0>"));
-        const long long n_c = 3LL * B * C;
-        const long long nthr = n_c > 2LL * n_bg ? n_c : 2LL * n_bg;
-        hipLaunchKernelGGL(gn_big_finalize2_kernel, dim3((unsigned)ceil_div(nthr, 256)), dim3(256), 0, st, w_gpart, w_gsum, n_bg, w_cpart,
-                           part, n_c, ns);
+        // group sums first (pass 1 needs them), the per-channel rows of all 4 kinds after pass 1 has written kind 3
+        hipLaunchKernelGGL(gn_big_finalize2_kernel, dim3((unsigned)ceil_div(2LL * n_bg, 256)), dim3(256), 0, st, w_gpart, w_gsum, n_bg,
+                           w_cpart, part, 0LL, ns);
         DDK_TRY(check_launch("gn_big_finalize2_kernel"));
         hipLaunchKernelGGL(gn_big_bwd_kernel<1>, dim3(n_bg, ns), dim3(256), 0, st, x, w_stat, gamma, beta, drop_p, seed, layer, dy, out,
                            w_gpart, w_gsum, w_cpart, B, HW, C, groups, ns);
-        return check_launch("gn_big_bwd_kernel<1>");
+        DDK_TRY(check_launch("gn_big_bwd_kernel<1>"));
+        const long long n_c = 4LL * B * C;
+        hipLaunchKernelGGL(gn_big_finalize2_kernel, dim3((unsigned)ceil_div(n_c, 256)), dim3(256), 0, st, w_gpart, w_gsum, 0, w_cpart, part,
+                           n_c, ns);
+        return check_launch("gn_big_finalize2_kernel");
     }
     DDK_REQUIRE(units <= 4096, "groupnorm_train: internal: resident path selected for a large slab");
     dim3 grid(B * groups);
@@ -905,6 +950,11 @@ static int gn_train_launch(bool bwd, const float* x, const float* gamma, const f
     else GT(4, 1024);
 #undef GT
     return check_launch("gn_train_kernel");
+}
+
+int ddk_dropout_epoch(unsigned long long set_to, int bump, ddk_stream_t s) {
+    hipLaunchKernelGGL(drop_epoch_kernel, dim3(1), dim3(1), 0, as_stream(s), set_to, bump);
+    return check_launch("drop_epoch_kernel");
 }
 
 size_t ddk_groupnorm_train_workspace_bytes(int B, int HW, int C, int groups) {
@@ -931,8 +981,17 @@ int ddk_groupnorm_mish_bwd(const float* x, const float* gamma, const float* beta
 /* out[n] (+)= sum_r rows[r*row_stride + n] */
 int ddk_rows_sum(const float* rows, int nrows, long long row_stride, float* out, int n, int accumulate, ddk_stream_t s) {
     DDK_REQUIRE(rows && out && nrows > 0 && n > 0, "rows_sum: arguments");
-    hipLaunchKernelGGL(rows_sum_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, as_stream(s), rows, nrows, row_stride, out, n,
+    hipLaunchKernelGGL(rows_sum_kernel, dim3((unsigned)ceil_div(n, 64), 1), dim3(256), 0, as_stream(s), rows, nrows, row_stride, 0LL, out, n,
                        accumulate);
+    return check_launch("rows_sum_kernel");
+}
+
+/* out[k][n] (+)= sum_r rows[k*batch_stride + r*row_stride + n], k < nbatch: several row reductions in one launch */
+int ddk_rows_sum_batched(const float* rows, int nbatch, long long batch_stride, int nrows, long long row_stride, float* out, int n,
+                         int accumulate, ddk_stream_t s) {
+    DDK_REQUIRE(rows && out && nbatch > 0 && nrows > 0 && n > 0, "rows_sum_batched: arguments");
+    hipLaunchKernelGGL(rows_sum_kernel, dim3((unsigned)ceil_div(n, 64), (unsigned)nbatch), dim3(256), 0, as_stream(s), rows, nrows,
+                       row_stride, batch_stride, out, n, accumulate);
     return check_launch("rows_sum_kernel");
 }
 

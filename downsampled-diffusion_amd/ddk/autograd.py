@@ -14,6 +14,57 @@ def _c(t):
     return t if t is None or t.is_contiguous() else t.contiguous()
 
 
+def _grad_slot(p):
+    """The tensor a parameter gradient can be accumulated into in place: ``p.grad`` when it already exists as a dense fp32
+    buffer (trainers/optim.py gives every parameter a view of ONE flat gradient buffer).  The backward kernels then add
+    into it directly and the Function returns None for that input -- no zero-fill, no temporary, no torch add."""
+    g = getattr(p, "grad", None)
+    if p is not None and p.is_leaf and g is not None and g.dtype == torch.float32 and g.is_contiguous():
+        return g
+    return None
+
+
+def _conv_backward(kind, x, x2, weight, bias, dy, needs, gb_ready=False):
+    """Shared backward of the conv family.  needs = (x, x2, weight, bias).  Returns (dx, dx2, gw, gb); gw / gb are None
+    when they were accumulated straight into ``.grad``.  gb_ready: the bias gradient was already produced elsewhere
+    (by the GroupNorm backward that follows the conv)."""
+    need_x, need_x2, need_w, need_b = needs
+    c0 = x.shape[-1]
+    c1 = 0 if x2 is None else x2.shape[-1]
+    dx = dx2 = gw = gb = None
+    if need_w:
+        slot = _grad_slot(weight)
+        gw_t = slot if slot is not None else torch.zeros_like(weight, memory_format=torch.contiguous_format)
+        if kind == ops.CONVT4X4_S2:
+            # dW[i][o][ky][kx] = sum X[i] * dY[o] shifted: wgrad of the 4x4 stride-2 conv with the roles swapped
+            ops.conv_wgrad_(ops.CONV4X4_S2, dy, x, gw_t, c_real=dy.shape[-1], cw=dy.shape[-1], c_off=0)
+        else:
+            cin = weight.shape[1]
+            ops.conv_wgrad_(kind, x, dy, gw_t, c_real=min(c0, cin), cw=cin, c_off=0)
+            if x2 is not None:
+                ops.conv_wgrad_(kind, x2, dy, gw_t, c_real=c1, cw=cin, c_off=c0)
+        gw = None if slot is not None else gw_t
+    if bias is not None and need_b and not gb_ready:
+        slot = _grad_slot(bias)
+        gb = ops.bias_grad(dy, accumulate_into=slot)
+        if slot is not None:
+            gb = None
+    if need_x or need_x2:
+        if kind == ops.CONVT4X4_S2:
+            dx = ops.conv(ops.CONV4X4_S2, dy, ops.pack_conv_weight(weight.detach()))   # (I,O,4,4) read as OIHW
+        else:
+            wd = ops.pack_conv_weight_dgrad(weight.detach(), i_pad=c0 + c1)            # [c0+c1][taps][N]
+            src = dy
+            k = ops.CONV1X1 if kind == ops.CONV1X1 else ops.CONV3X3_S1
+            if kind == ops.CONV3X3_S2:
+                src = ops.zero_stuff2(dy, x.shape[1], x.shape[2])
+            if need_x:
+                dx = ops.conv(k, src, wd[:c0], n_out=c0)
+            if need_x2:
+                dx2 = ops.conv(k, src, wd[c0:], n_out=c1)
+    return dx, dx2, gw, gb
+
+
 class ConvFn(torch.autograd.Function):
     """conv family on NHWC x (optionally channel-concatenated with x2), canonical (OIHW / (I,O,4,4)) weight."""
 
@@ -27,45 +78,15 @@ class ConvFn(torch.autograd.Function):
             n = weight.shape[0]
         out = ops.conv(kind, x, wp, None if bias is None else bias.detach(), n_out=n, x2=x2, resid=resid)
         ctx.kind = kind
-        ctx.save_for_backward(x, x2, weight)
-        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x, x2, weight, bias)
         ctx.has_resid = resid is not None
         return out
 
     @staticmethod
     def backward(ctx, dy):
-        kind = ctx.kind
-        x, x2, weight = ctx.saved_tensors
+        x, x2, weight, bias = ctx.saved_tensors
         dy = _c(dy)
-        need_x, need_x2, need_w = ctx.needs_input_grad[1], ctx.needs_input_grad[2], ctx.needs_input_grad[3]
-        c0 = x.shape[-1]
-        c1 = 0 if x2 is None else x2.shape[-1]
-        dx = dx2 = gw = gb = None
-        if need_w:
-            gw = torch.zeros_like(weight, memory_format=torch.contiguous_format)
-            if kind == ops.CONVT4X4_S2:
-                # dW[i][o][ky][kx] = sum X[i] * dY[o] shifted: wgrad of the 4x4 stride-2 conv with the roles swapped
-                ops.conv_wgrad_(ops.CONV4X4_S2, dy, x, gw, c_real=dy.shape[-1], cw=dy.shape[-1], c_off=0)
-            else:
-                cin = weight.shape[1]
-                ops.conv_wgrad_(kind, x, dy, gw, c_real=min(c0, cin), cw=cin, c_off=0)
-                if x2 is not None:
-                    ops.conv_wgrad_(kind, x2, dy, gw, c_real=c1, cw=cin, c_off=c0)
-        if ctx.has_bias and ctx.needs_input_grad[4]:
-            gb = ops.bias_grad(dy)
-        if need_x or need_x2:
-            if kind == ops.CONVT4X4_S2:
-                dx = ops.conv(ops.CONV4X4_S2, dy, ops.pack_conv_weight(weight.detach()))   # (I,O,4,4) read as OIHW
-            else:
-                wd = ops.pack_conv_weight_dgrad(weight.detach(), i_pad=c0 + c1)            # [c0+c1][taps][N]
-                src = dy
-                k = ops.CONV1X1 if kind == ops.CONV1X1 else ops.CONV3X3_S1
-                if kind == ops.CONV3X3_S2:
-                    src = ops.zero_stuff2(dy, x.shape[1], x.shape[2])
-                if need_x:
-                    dx = ops.conv(k, src, wd[:c0], n_out=c0)
-                if need_x2:
-                    dx2 = ops.conv(k, src, wd[c0:], n_out=c1)
+        dx, dx2, gw, gb = _conv_backward(ctx.kind, x, x2, weight, bias, dy, ctx.needs_input_grad[1:5])
         return None, dx, dx2, gw, gb, (dy if ctx.has_resid else None)
 
 
@@ -88,8 +109,40 @@ class GNMishFn(torch.autograd.Function):
         x, gamma, beta = ctx.saved_tensors
         drop_p, seed, layer, groups, eps, has_temb, has_add = ctx.cfg
         dy = _c(dy)
-        dx, dtemb, dg, db = ops.groupnorm_mish_bwd(x, gamma.detach(), beta.detach(), dy, drop_p, seed, layer, groups, eps)
-        return dx, dg, db, (dtemb if has_temb else None), (dy if has_add else None), None, None, None, None, None
+        acc = (_grad_slot(gamma), _grad_slot(beta), None)
+        dx, dtemb, sums = ops.groupnorm_mish_bwd(x, gamma.detach(), beta.detach(), dy, drop_p, seed, layer, groups, eps, acc=acc)
+        return dx, sums[0], sums[1], (dtemb if has_temb else None), (dy if has_add else None), None, None, None, None, None
+
+
+class ConvGNMishFn(torch.autograd.Function):
+    """One `Block` (blocks.py:74-84): y = dropout_p(mish(groupnorm(conv3x3(cat(x, x2)) + bias)) + temb) + addend.
+    Fused so that the backward of the GroupNorm hands the conv its bias gradient (the per-channel sum of dx it already
+    has in registers) -- no column-sum pass over dY."""
+
+    @staticmethod
+    def forward(ctx, x, x2, weight, bias, gamma, beta, temb, addend, drop_p, seed, layer, groups, eps):
+        raw = ops.conv(ops.CONV3X3_S1, x, ops.pack_conv_weight(weight.detach()), bias.detach(), n_out=weight.shape[0], x2=x2)
+        ctx.save_for_backward(x, x2, weight, bias, raw, gamma, beta)
+        ctx.cfg = (drop_p, seed, layer, groups, eps, temb is not None, addend is not None)
+        return ops.groupnorm_mish_train(raw, gamma.detach(), beta.detach(), temb=temb, addend=addend, drop_p=drop_p, seed=seed,
+                                        layer=layer, groups=groups, eps=eps)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, x2, weight, bias, raw, gamma, beta = ctx.saved_tensors
+        drop_p, seed, layer, groups, eps, has_temb, has_add = ctx.cfg
+        dy = _c(dy)
+        need = ctx.needs_input_grad
+        acc = (_grad_slot(gamma), _grad_slot(beta), _grad_slot(bias) if need[3] else None)
+        draw, dtemb, sums = ops.groupnorm_mish_bwd(raw, gamma.detach(), beta.detach(), dy, drop_p, seed, layer, groups, eps, acc=acc)
+        dx, dx2, gw, _ = _conv_backward(ops.CONV3X3_S1, x, x2, weight, bias, draw, need[0:4], gb_ready=True)
+        gb = sums[2] if need[3] else None
+        return (dx, dx2, gw, gb, sums[0], sums[1], (dtemb if has_temb else None), (dy if has_add else None),
+                None, None, None, None, None)
+
+
+def conv_groupnorm_mish(x, weight, bias, gamma, beta, x2=None, temb=None, addend=None, drop_p=0.0, seed=0, layer=0, groups=8, eps=1e-5):
+    return ConvGNMishFn.apply(x, x2, weight, bias, gamma, beta, temb, addend, float(drop_p), int(seed), int(layer), groups, eps)
 
 
 def groupnorm_mish(x, gamma, beta, temb=None, addend=None, drop_p=0.0, seed=0, layer=0, groups=8, eps=1e-5):

@@ -314,22 +314,30 @@ def groupnorm_mish_train(x, gamma, beta, temb=None, addend=None, drop_p=0.0, see
     return out
 
 
-def groupnorm_mish_bwd(x, gamma, beta, dy, drop_p=0.0, seed=0, layer=0, groups=GN_GROUPS, eps=GN_EPS):
-    """-> dx, dtemb [B,C], dgamma [C], dbeta [C]"""
+def groupnorm_mish_bwd(x, gamma, beta, dy, drop_p=0.0, seed=0, layer=0, groups=GN_GROUPS, eps=GN_EPS, acc=None):
+    """-> dx, dtemb [B,C], sums [3][C] = (dgamma, dbeta, sum over all pixels of dx -- the bias gradient of the conv that
+    produced x).  `acc`: optional (gamma.grad, beta.grad, conv_bias.grad) accumulated into directly (entries may be None)."""
     b, h, w, c = x.shape
     dx = torch.empty_like(x)
-    part = torch.empty((3, b, c), device=x.device, dtype=torch.float32)
+    part = torch.empty((4, b, c), device=x.device, dtype=torch.float32)
     lib = L.load()
     nbytes = lib.ddk_groupnorm_train_workspace_bytes(b, h * w, c, groups)
     ws = _ws(x.device, nbytes, "gn_train") if nbytes else None
     L.check(lib.ddk_groupnorm_mish_bwd(L.ptr(_f32(x)), L.ptr(gamma), L.ptr(beta), float(drop_p), seed, layer, L.ptr(_f32(dy)),
                                        L.ptr(dx), L.ptr(part), b, h * w, c, groups, eps, L.ptr(ws), nbytes, L.stream()),
             "groupnorm_mish_bwd")
-    dg = torch.empty(c, device=x.device, dtype=torch.float32)
-    db = torch.empty(c, device=x.device, dtype=torch.float32)
-    L.check(lib.ddk_rows_sum(L.ptr(part[1]), b, c, L.ptr(dg), c, 0, L.stream()), "rows_sum")
-    L.check(lib.ddk_rows_sum(L.ptr(part[2]), b, c, L.ptr(db), c, 0, L.stream()), "rows_sum")
-    return dx, part[0], dg, db
+    sums = [None, None, None]
+    missing = [k for k in range(3) if acc is None or acc[k] is None]
+    if acc is not None:
+        for k, tgt in enumerate(acc):
+            if tgt is not None:                  # straight into the parameter's gradient (fixed-order row sum, then +=)
+                L.check(lib.ddk_rows_sum(L.ptr(part[1 + k]), b, c, L.ptr(tgt), c, 1, L.stream()), "rows_sum")
+    if missing:
+        out = torch.empty((3, c), device=x.device, dtype=torch.float32)
+        L.check(lib.ddk_rows_sum_batched(L.ptr(part[1]), 3, b * c, b, c, L.ptr(out), c, 0, L.stream()), "rows_sum_batched")
+        for k in missing:
+            sums[k] = out[k]
+    return dx, part[0], sums
 
 
 def rows_sum(rows, nrows, row_stride, n):

@@ -30,10 +30,9 @@ class _Seeds:
 
 def _block(blk, x, x2=None, temb=None, addend=None, drop_p=0.0, seeds=None):
     conv, norm = blk.block[0], blk.block[1]
-    raw = AG.conv(ops.CONV3X3_S1, x, conv.weight, conv.bias, x2=x2)
     seed, layer = seeds.next() if (seeds is not None and drop_p > 0) else (0, 0)
-    return AG.groupnorm_mish(raw, norm.weight, norm.bias, temb=temb, addend=addend, drop_p=drop_p, seed=seed, layer=layer,
-                             groups=blk.groups, eps=norm.eps)
+    return AG.conv_groupnorm_mish(x, conv.weight, conv.bias, norm.weight, norm.bias, x2=x2, temb=temb, addend=addend, drop_p=drop_p,
+                                  seed=seed, layer=layer, groups=blk.groups, eps=norm.eps)
 
 
 def _resnet(rb, x, temb_slice, x2=None, seeds=None):

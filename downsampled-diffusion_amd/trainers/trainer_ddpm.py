@@ -38,6 +38,7 @@ class TrainerDDPM(Trainer):
         else:
             self.val_batch = next(self.train_loader)[0][0].repeat(self.n_samples, 1, 1, 1).to(self.device)
         self.step = 0
+        self._graph = None
         self.gradient_accumulate_every = 2
         self.logging_every = 10000
         if self.use_ema:
@@ -99,13 +100,39 @@ class TrainerDDPM(Trainer):
             self.ema.update(self.model)
 
     # ------------------------------------------------------------------ one optimiser step
-    def _micro_batch(self):
-        x, _ = next(self.train_loader)
-        x = x.to(self.device, non_blocking=True)
+    def _micro_batch(self, x=None):
+        if x is None:
+            x, _ = next(self.train_loader)
+            x = x.to(self.device, non_blocking=True)
         out = self.model(x)
         obj, extra = (out[0], out[1]) if isinstance(out, tuple) else (out, None)
         (obj / self.gradient_accumulate_every).backward()
         return obj.detach(), extra
+
+    def _accumulate(self):
+        """The `gradient_accumulate_every` forward/backward passes of one step -> tensor [accumulate, 1 or 3] of
+        (objective[, latent, recon]) per micro-batch.  On the GPU the passes are captured once into a device graph
+        (trainers/graph_step.py) and replayed; config['graph_train'] = False keeps the eager sequence."""
+        batches = [next(self.train_loader)[0].to(self.device, non_blocking=True) for _ in range(self.gradient_accumulate_every)]
+        use_graph = self.config.get('graph_train', True) and str(self.device).startswith('cuda')
+        if use_graph and self._graph is None:
+            from .graph_step import GraphedAccumulation
+            try:
+                self._graph = GraphedAccumulation(self.model, self.gradient_accumulate_every).capture(batches)
+                self.opt.zero_grad()      # the warm-up / capture passes accumulated gradients of their own
+            except Exception as e:       # noqa: BLE001 -- e.g. a model whose forward synchronises with the host
+                print(f"[trainer] device-graph capture of the training step failed ({type(e).__name__}: {e}); running eagerly")
+                self._graph = False
+                torch.cuda.synchronize()
+                self.opt.zero_grad()
+        if use_graph and self._graph and all(b.shape == s.shape for b, s in zip(batches, self._graph.static_x)):
+            return self._graph.replay(batches)
+        rows = []
+        for x in batches:
+            obj, extra = self._micro_batch(x)
+            rec = [obj] if extra is None else [obj, extra['latent'].detach(), extra['recon'].detach()]
+            rows.append(torch.stack([r.reshape(()) for r in rec]))
+        return torch.stack(rows)
 
     def optimizer_step(self):
         """all-reduce (data parallel) -> clip_grad_norm_(1.0) -> Adam -> zero_grad (trainer_ddpm.py:142-144)"""
@@ -118,8 +145,7 @@ class TrainerDDPM(Trainer):
     def train_loop(self) -> None:
         while self.step < self.n_steps:
             self.model.train()
-            objs = [self._micro_batch()[0] for _ in range(self.gradient_accumulate_every)]
-            train_obj = float(torch.stack(objs).mean())          # one device->host read per step
+            train_obj = float(self._accumulate()[:, 0].mean())   # one device->host read per step
             self.train_losses.append(train_obj)
             is_log = self.step != 0 and self.step % self.logging_every == 0
             self.logger.log({'train_obj': train_obj}, commit=(not is_log))
@@ -140,13 +166,9 @@ class TrainerDownsampleDDPM(TrainerDDPM):
     def train_loop(self):
         while self.step < self.n_steps:
             self.model.train()
-            objs, lats, recs = [], [], []
-            for _ in range(self.gradient_accumulate_every):
-                obj, extra = self._micro_batch()
-                objs.append(obj / self.gradient_accumulate_every)        # the reference logs objective.item() here
-                lats.append(extra['latent'].detach())
-                recs.append(extra['recon'].detach())
-            vals = torch.stack([torch.stack(objs).mean(), torch.stack(lats).mean(), torch.stack(recs).mean()]).tolist()
+            rows = self._accumulate()                                    # [accumulate, (objective, latent, recon)]
+            # the reference logs objective.item() / accumulate per micro-batch and the means of latent / recon
+            vals = torch.stack([rows[:, 0].mean() / self.gradient_accumulate_every, rows[:, 1].mean(), rows[:, 2].mean()]).tolist()
             self.train_losses.append(vals[0])
             is_log = self.step != 0 and self.step % self.logging_every == 0
             self.logger.log({'train_obj': vals[0], 'train_latent': vals[1], 'train_recon': vals[2]}, commit=(not is_log))

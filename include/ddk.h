@@ -227,15 +227,22 @@ int ddk_bias_grad(const float* dy, float* grad_b, long long M, int N, int accumu
    Group slabs up to 16384 elements stay in registers (workspace unused, may be NULL); larger ones (full-resolution
    DDPM) stream through ddk_groupnorm_train_workspace_bytes() of scratch. */
 size_t ddk_groupnorm_train_workspace_bytes(int B, int HW, int C, int groups);
+/* Device-side dropout epoch (mixed into every mask key): bump != 0 increments it, else it is set to `set_to`.
+   Lets a captured (hipGraph) training step draw fresh masks on every replay. */
+int ddk_dropout_epoch(unsigned long long set_to, int bump, ddk_stream_t s);
 int ddk_groupnorm_mish_train_fwd(const float* x, const float* gamma, const float* beta, const float* temb,
                                  int temb_stride, const float* addend, float drop_p, uint64_t seed, uint32_t layer,
                                  float* out, int B, int HW, int C, int groups, float eps, void* workspace,
                                  size_t workspace_bytes, ddk_stream_t s);
-/* dx and per-sample partial rows part[3][B][C] = (dtemb, dgamma, dbeta); d(addend) is dy itself */
+/* dx and per-sample partial rows part[4][B][C] = (dtemb, dgamma, dbeta, sum_hw dx); d(addend) is dy itself.  The
+   last row, summed over b, is the bias gradient of the conv that produced x (blocks.py:78). */
 int ddk_groupnorm_mish_bwd(const float* x, const float* gamma, const float* beta, float drop_p, uint64_t seed,
                            uint32_t layer, const float* dy, float* dx, float* part, int B, int HW, int C, int groups,
                            float eps, void* workspace, size_t workspace_bytes, ddk_stream_t s);
 int ddk_rows_sum(const float* rows, int nrows, long long row_stride, float* out, int n, int accumulate, ddk_stream_t s);
+/* out[k][n] (+)= sum_r rows[k*batch_stride + r*row_stride + n], k < nbatch */
+int ddk_rows_sum_batched(const float* rows, int nbatch, long long batch_stride, int nrows, long long row_stride, float* out,
+                         int n, int accumulate, ddk_stream_t s);
 int ddk_chan_layernorm_bwd(const float* x, const float* g, const float* dy, float* dx, float* part, int max_parts,
                            int* nparts_out, long long M, int C, float eps, ddk_stream_t s);
 int ddk_linattn_stats(const float* qkv, float* stats, int B, int HW, int heads, ddk_stream_t s);

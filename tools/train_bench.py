@@ -22,25 +22,44 @@ def cfg(chan, cin, size, down=0):
 
 
 def time_train(name, model, xshape, steps=5):
+    """eager: Python + torch.autograd sequence the ~900 launches; graph: the 2 x (forward, backward) replayed as one device graph"""
+    from trainers.graph_step import GraphedAccumulation
     model = model.to(DEV).train()
     model.load_state_dict(syn.fill_state_dict(model.state_dict(), skip=syn.SCHEDULE_KEYS))
     opt = FusedAdam(model, lr=2e-4)
-    x = (torch.rand(xshape, device=DEV) * 2 - 1)
+    xs = [(torch.rand(xshape, device=DEV) * 2 - 1) for _ in range(2)]
+    ga = GraphedAccumulation(model, 2)
 
-    def step():
-        for _ in range(2):
-            out = model(x)
-            obj = out[0] if isinstance(out, tuple) else out
-            (obj / 2).backward()
+    def finish():
         opt.step(); opt.zero_grad()
-        return obj
-    for _ in range(2):
-        step()
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    for _ in range(steps):
-        obj = step()
-    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
-    print(f"{name}: {dt * 1e3:8.1f} ms / optimiser step (2 micro-batches of {xshape[0]}), objective {float(obj):.3f}", flush=True)
+        for m in model.modules():
+            if hasattr(m, "invalidate_plan"):
+                m.invalidate_plan()
+
+    def eager():
+        ga.static_x = xs
+        rows = ga._run()
+        finish()
+        return rows
+
+    def graphed():
+        rows = ga.replay(xs)
+        finish()
+        return rows
+
+    res = {}
+    for mode, fn in (("eager", eager), ("graph", graphed)):
+        if mode == "graph":
+            ga.capture(xs)
+            opt.zero_grad()
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(steps):
+            rows = fn()
+        torch.cuda.synchronize(); res[mode] = (time.perf_counter() - t0) / steps
+    print(f"{name}: eager {res['eager'] * 1e3:7.1f} ms, device graph {res['graph'] * 1e3:7.1f} ms per optimiser step "
+          f"(2 micro-batches of {xshape[0]}), objective {float(rows[0, 0]):.3f}", flush=True)
 
 
 if __name__ == "__main__":
