@@ -196,30 +196,51 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 }
 
 // bias gradient: partial[s][n] = sum over the s-th row range of dy[m][n]; then grad[n] += sum_s partial
+// part[blockIdx.x][n] = sum over this workgroup's row range of dy[m][n].  A thread owns one float4 column group and
+// every RG-th row (RG = 256 / (N/4) row groups), 4 independent accumulators keep loads in flight; row groups are then
+// added in fixed order through LDS.
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ dy, float* __restrict__ part, long long M, int N,
                                                              long long rows_per) {
-    __shared__ float red[8][32];
-    const int col = blockIdx.x * 32 + (threadIdx.x & 31), rg = threadIdx.x >> 5;
-    const long long m0 = blockIdx.y * rows_per, m1 = (m0 + rows_per < M) ? m0 + rows_per : M;
-    float s = 0.f;
-    if (col < N)
-        for (long long m = m0 + rg; m < m1; m += 8) s += dy[m * N + col];
-    red[rg][threadIdx.x & 31] = s;
+    __shared__ float4 red[256];
+    const int cq = N >> 2;                    // float4 column groups (<= 256)
+    const int rg_n = 256 / cq;                // row groups
+    const int c = threadIdx.x % cq, rg = threadIdx.x / cq;
+    const long long m0 = blockIdx.x * rows_per, m1 = (m0 + rows_per < M) ? m0 + rows_per : M;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (rg < rg_n) {
+        const float4* p = reinterpret_cast<const float4*>(dy) + c;
+#pragma unroll 4
+        for (long long m = m0 + rg; m < m1; m += rg_n) {
+            const float4 v = p[m * cq];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+    }
+    red[threadIdx.x] = s;
     __syncthreads();
-    if (threadIdx.x < 32 && col < N) {
-        float t = 0.f;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) t += red[i][threadIdx.x];
-        part[(long long)blockIdx.y * N + col] = t;
+    if (threadIdx.x < cq) {
+        float4 t = red[threadIdx.x];
+        for (int i = 1; i < rg_n; ++i) {
+            const float4 v = red[i * cq + threadIdx.x];
+            t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+        }
+        reinterpret_cast<float4*>(part + (long long)blockIdx.x * N)[threadIdx.x] = t;
     }
 }
 __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, int nparts, float* __restrict__ grad, int N,
                                                            int accumulate) {
-    const int n = blockIdx.x * 256 + threadIdx.x;
-    if (n >= N) return;
+    __shared__ float red[4][64];
+    const int n = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
     float s = 0.f;
-    for (int i = 0; i < nparts; ++i) s += part[(long long)i * N + n];
-    grad[n] = accumulate ? grad[n] + s : s;
+    if (n < N) {
+#pragma unroll 4
+        for (int i = rg; i < nparts; i += 4) s += part[(long long)i * N + n];
+    }
+    red[rg][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (threadIdx.x < 64 && n < N) {
+        const float t = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        grad[n] = accumulate ? grad[n] + t : t;
+    }
 }
 
 // dst[i][t][o] = w[o][i][T-1-t] (i < I), zero rows up to i_pad; o padded to o_pad with zeros
@@ -351,18 +372,20 @@ int ddk_conv_wgrad(int kind, const float* x, const float* dy, float* grad_w, int
     return check_launch("wgrad_reduce_kernel");
 }
 
-/* grad_b[n] (+)= sum_m dy[m][n]; workspace >= 64*N floats */
+/* grad_b[n] (+)= sum_m dy[m][n]; workspace >= 256*N floats */
 int ddk_bias_grad(const float* dy, float* grad_b, long long M, int N, int accumulate, void* workspace, size_t workspace_bytes,
                   ddk_stream_t s) {
     DDK_REQUIRE(dy && grad_b && workspace && M > 0 && N > 0, "bias_grad: arguments");
-    const int parts = (int)(M >= 64 * 32 ? 64 : ceil_div(M, 32));
-    DDK_REQUIRE(workspace_bytes >= (size_t)parts * N * sizeof(float), "bias_grad: workspace too small (need 64*N floats)");
+    DDK_REQUIRE(N % 4 == 0 && N <= 1024 && aligned16(dy) && aligned16(workspace), "bias_grad: N % 4 == 0, N <= 1024, 16-byte aligned dy");
+    // ~256 workgroups, each at least 64 rows
+    long long parts = ceil_div(M, 64);
+    if (parts > 256) parts = 256;
+    DDK_REQUIRE(workspace_bytes >= (size_t)parts * N * sizeof(float), "bias_grad: workspace too small (need 256*N floats)");
     const long long rows_per = ceil_div(M, parts);
     float* part = static_cast<float*>(workspace);
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)ceil_div(N, 32), (unsigned)parts), dim3(256), 0, as_stream(s), dy, part, M, N,
-                       rows_per);
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)parts), dim3(256), 0, as_stream(s), dy, part, M, N, rows_per);
     DDK_TRY(check_launch("colsum_partial_kernel"));
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, as_stream(s), part, parts, grad_b, N,
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)ceil_div(N, 64)), dim3(256), 0, as_stream(s), part, (int)parts, grad_b, N,
                        accumulate);
     return check_launch("colsum_final_kernel");
 }

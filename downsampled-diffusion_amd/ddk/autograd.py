@@ -51,9 +51,10 @@ def _conv_backward(kind, x, x2, weight, bias, dy, needs, gb_ready=False):
             gb = None
     if need_x or need_x2:
         if kind == ops.CONVT4X4_S2:
-            dx = ops.conv(ops.CONV4X4_S2, dy, ops.pack_conv_weight(weight.detach()))   # (I,O,4,4) read as OIHW
+            dx = ops.conv(ops.CONV4X4_S2, dy, ops.cached_pack("fwd", weight, ops.pack_conv_weight))   # (I,O,4,4) read as OIHW
         else:
-            wd = ops.pack_conv_weight_dgrad(weight.detach(), i_pad=c0 + c1)            # [c0+c1][taps][N]
+            wd = ops.cached_pack(("dgrad", c0 + c1), weight,
+                                 lambda w: ops.pack_conv_weight_dgrad(w, i_pad=c0 + c1))       # [c0+c1][taps][N]
             src = dy
             k = ops.CONV1X1 if kind == ops.CONV1X1 else ops.CONV3X3_S1
             if kind == ops.CONV3X3_S2:
@@ -71,10 +72,10 @@ class ConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, kind, x, x2, weight, bias, resid):
         if kind == ops.CONVT4X4_S2:
-            wp = ops.pack_convT_weight(weight.detach())
+            wp = ops.cached_pack("fwdT", weight, ops.pack_convT_weight)
             n = weight.shape[1]
         else:
-            wp = ops.pack_conv_weight(weight.detach())
+            wp = ops.cached_pack("fwd", weight, ops.pack_conv_weight)
             n = weight.shape[0]
         out = ops.conv(kind, x, wp, None if bias is None else bias.detach(), n_out=n, x2=x2, resid=resid)
         ctx.kind = kind
@@ -121,7 +122,8 @@ class ConvGNMishFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, x2, weight, bias, gamma, beta, temb, addend, drop_p, seed, layer, groups, eps):
-        raw = ops.conv(ops.CONV3X3_S1, x, ops.pack_conv_weight(weight.detach()), bias.detach(), n_out=weight.shape[0], x2=x2)
+        raw = ops.conv(ops.CONV3X3_S1, x, ops.cached_pack("fwd", weight, ops.pack_conv_weight), bias.detach(),
+                       n_out=weight.shape[0], x2=x2)
         ctx.save_for_backward(x, x2, weight, bias, raw, gamma, beta)
         ctx.cfg = (drop_p, seed, layer, groups, eps, temb is not None, addend is not None)
         return ops.groupnorm_mish_train(raw, gamma.detach(), beta.detach(), temb=temb, addend=addend, drop_p=drop_p, seed=seed,

@@ -17,6 +17,32 @@ def pad32(c):
     return (c + 31) // 32 * 32
 
 
+# ---------------------------------------------------------------- kernel-layout copies of weights (training path)
+# The autograd Functions repack a canonical weight for every conv forward / input-gradient.  Within one optimiser step the
+# weights do not change between the accumulation micro-batches, so the packed copies are cached, keyed by the parameter's
+# storage + torch version counter + an epoch that every in-place weight update done by OUR kernels bumps
+# (FusedAdam.step, EMA, load_state_dict paths call weights_changed(); torch ops bump the version counter themselves).
+_pack_cache = {}
+_weights_epoch = [0]
+
+
+def weights_changed():
+    _weights_epoch[0] += 1
+    _pack_cache.clear()
+
+
+def cached_pack(tag, w, fn):
+    """fn(w.detach()) cached per live tensor object `w` (a weakref guards against a new tensor re-using the address)."""
+    import weakref
+    key = (tag, w.data_ptr(), tuple(w.shape), w._version, _weights_epoch[0])
+    hit = _pack_cache.get(key)
+    if hit is not None and hit[0]() is w:
+        return hit[1]
+    out = fn(w.detach())
+    _pack_cache[key] = (weakref.ref(w), out)
+    return out
+
+
 def _f32(t):
     if t.dtype != torch.float32:
         raise L.DDKError(f"expected float32, got {t.dtype}")
@@ -293,9 +319,9 @@ def conv_wgrad_(kind, x, dy, grad_w, c_real, cw, c_off):
 def bias_grad(dy, accumulate_into=None):
     n = dy.shape[-1]
     out = accumulate_into if accumulate_into is not None else torch.empty(n, device=dy.device, dtype=torch.float32)
-    ws = _ws(dy.device, 64 * n * 4, "bias")
+    ws = _ws(dy.device, 256 * n * 4, "bias")
     L.check(L.load().ddk_bias_grad(L.ptr(_f32(dy)), L.ptr(out), dy.numel() // n, n, int(accumulate_into is not None), L.ptr(ws),
-                                   64 * n * 4, L.stream()), "bias_grad")
+                                   256 * n * 4, L.stream()), "bias_grad")
     return out
 
 

@@ -17,6 +17,8 @@ from ddk import lib as L
 
 
 def _invalidate(model):
+    from ddk import ops
+    ops.weights_changed()
     for m in model.modules():
         if hasattr(m, "invalidate_plan"):
             m.invalidate_plan()

@@ -64,6 +64,7 @@ class FusedAdam:
         self.step_count += 1
         ops.adam_step_(self.fp.flat, self.fp.grad, self.exp_avg, self.exp_avg_sq, self.lr, self.step_count, clip=self.last_norm,
                        betas=self.betas, eps=self.eps)
+        ops.weights_changed()      # in-place update behind torch's version counters: drop cached kernel-layout copies
         return self.last_norm
 
     # ---- torch.optim.Adam-compatible (de)serialisation, so checkpoints interchange with the reference trainer

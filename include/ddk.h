@@ -220,7 +220,7 @@ size_t ddk_conv_wgrad_workspace_bytes(int kind, int B, int H, int W, int cx, int
 /* grad_w[(n*cw + c_off + c)*taps + tap] += sum_m dy[m][n] x[pix(m)+tap][c], c < c_real (see csrc/conv_wgrad.hip) */
 int ddk_conv_wgrad(int kind, const float* x, const float* dy, float* grad_w, int B, int H, int W, int cx, int c_real,
                    int cw, int c_off, int N, void* workspace, size_t workspace_bytes, ddk_stream_t s);
-/* grad_b[n] (+)= sum_m dy[m][n]; workspace >= 64*N floats */
+/* grad_b[n] (+)= sum_m dy[m][n]; N % 4 == 0; workspace >= 256*N floats */
 int ddk_bias_grad(const float* dy, float* grad_b, long long M, int N, int accumulate, void* workspace,
                   size_t workspace_bytes, ddk_stream_t s);
 /* y = dropout_p(mish(gn(x)) + temb) + addend; the keep mask is a pure function of (seed, layer, element).
