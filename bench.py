@@ -129,6 +129,37 @@ def cpu_baseline(cfg, state_dict):
                        f"extrapolated to T={T_STEPS}; decoder excluded")
 
 
+def train_step_ms(device, steps=5):
+    """Secondary figure: one optimiser step of cfg3 (CelebA 64x64 dDDPM -downsample 2, batch 64:
+    2 accumulation micro-batches, clip, Adam) with the accumulation passes replayed as one device graph."""
+    from models import DownsampleDDPMAutoencoder, Unet
+    from trainers.graph_step import GraphedAccumulation
+    from trainers.optim import FusedAdam
+    from utils import synthetic as syn
+    c = dict(unet_chan=128, unet_in=8, unet_dims=(1, 2, 2, 2), unet_dropout=0.1, image_size=64, T=1000, loss_type="simple",
+             beta_schedule="linear", loss_flat="sum", ema_decay=0.995, d_mode="convolutional_res", u_mode="convolutional_res",
+             d_dropout=0, d_chans=64, d_n_blocks=3, u_n_blocks=3, ae_loss=True, t_rec_max=100, force_latent=True, n_downsamples=2)
+    model = DownsampleDDPMAutoencoder(c, Unet(c), "cuda", 3).to(device).train()
+    model.load_state_dict(syn.fill_state_dict(model.state_dict(), skip=syn.SCHEDULE_KEYS))
+    opt = FusedAdam(model, lr=2e-4)
+    xs = [torch.rand((64, 3, 64, 64), device=device) * 2 - 1 for _ in range(2)]
+    ga = GraphedAccumulation(model, 2).capture(xs)
+    opt.zero_grad()
+
+    def step():
+        ga.replay(xs)
+        opt.step()
+        opt.zero_grad()
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps * 1e3
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -137,6 +168,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="latents per GPU (cfg4: 32)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train", action="store_true", help="skip the secondary cfg3 training-step timing")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -236,6 +268,12 @@ def main():
                        "weights_broadcast_bytes": bcast_bytes},
             "roofline": roof,
         }
+        if world == 1 and not args.no_train:
+            try:
+                out["config"]["train_step_ms_cfg3_bs64"] = train_step_ms(device)
+            except Exception as e:   # noqa: BLE001 -- secondary figure: report the failure, keep the headline line
+                out["config"]["train_step_ms_cfg3_bs64"] = None
+                log(f"training-step timing failed: {type(e).__name__}: {e}")
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, model.state_dict())
         print(json.dumps(out), flush=True)

@@ -150,6 +150,29 @@ int randn(float* out, long long n, uint64_t seed, uint32_t step, uint32_t stream
 
 using namespace ddk;
 
+
+// Sampler output stage (utils/eval_helpers.py:37-41 + utils/utils.py:16-24): per-image min / max over C*H*W, then
+// out[b][h][w][c] = ((x[b][c][h][w] - lo) / (hi - lo)) * 255 -- the same three fp32 operations, in the same order, as
+// the reference's torch expression (this file is compiled with -ffp-contract=off), written NHWC like its np.moveaxis.
+// One workgroup per image: pass 1 reduces, pass 2 normalises and transposes.
+__global__ __launch_bounds__(1024) void fix_samples_kernel(const float* __restrict__ x, float* __restrict__ out, int C, long long HW) {
+    __shared__ float red[32];
+    const long long per = (long long)C * HW;
+    const float* xb = x + (long long)blockIdx.x * per;
+    float* ob = out + (long long)blockIdx.x * per;
+    float lo = INFINITY, hi = -INFINITY;
+    for (long long i = threadIdx.x; i < per; i += 1024) {
+        const float v = xb[i];
+        lo = fminf(lo, v);
+        hi = fmaxf(hi, v);
+    }
+    hi = block_max(hi, red);
+    lo = -block_max(-lo, red);
+    const float range = hi - lo;
+    for (long long p = threadIdx.x; p < HW; p += 1024)
+        for (int c = 0; c < C; ++c) ob[p * C + c] = ((xb[c * HW + p] - lo) / range) * 255.0f;
+}
+
 extern "C" {
 
 int ddk_q_sample(const float* x, const float* eps, const int64_t* t, const float* sqrt_acp, const float* sqrt_1m_acp, float* out,
@@ -171,6 +194,12 @@ int ddk_p_sample_update(float* x, const float* eps_hat, const float* noise, cons
 
 int ddk_randn(float* out, long long n, uint64_t seed, uint32_t step, uint32_t stream_id, ddk_stream_t s) {
     return randn(out, n, seed, step, stream_id, as_stream(s));
+}
+
+int ddk_fix_samples(const float* x_nchw, float* out_nhwc, int B, int C, int H, int W, ddk_stream_t s) {
+    DDK_REQUIRE(x_nchw && out_nhwc && B > 0 && C > 0 && H > 0 && W > 0, "fix_samples: arguments");
+    hipLaunchKernelGGL(fix_samples_kernel, dim3(B), dim3(1024), 0, as_stream(s), x_nchw, out_nhwc, C, (long long)H * W);
+    return check_launch("fix_samples_kernel");
 }
 
 int ddk_sq_err_sum(const float* a, const float* b, float* per_sample, int B, long long per, ddk_stream_t s) {

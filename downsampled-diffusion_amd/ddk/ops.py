@@ -193,6 +193,14 @@ def upsample_nearest2(x):
     return out
 
 
+def fix_samples(x):
+    """x [B,C,H,W] device fp32 -> [B,H,W,C] device fp32 in [0,255] (per-image min-max, utils/eval_helpers.py:37-41)."""
+    b, c, h, w = x.shape
+    out = torch.empty((b, h, w, c), device=x.device, dtype=torch.float32)
+    L.check(L.load().ddk_fix_samples(L.ptr(_f32(x)), L.ptr(out), b, c, h, w, L.stream()), "fix_samples")
+    return out
+
+
 # ------------------------------------------------------------------ linear attention core
 def linattn(qkv, heads=4):
     """qkv [B,H,W,3*heads*32] -> attention output [B,H,W,heads*32] (before to_out)."""

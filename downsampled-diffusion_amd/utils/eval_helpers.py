@@ -1,10 +1,22 @@
 """Sampler output stage (reference utils/eval_helpers.py:37-41)."""
 import numpy as np
+import torch
 
 from .utils import min_max_norm_image
 
 
 def fix_samples(samples):
-    """Per-image min-max -> [0,255] -> host NHWC float32: the on-disk format of generate_model_samples.py."""
+    """Per-image min-max -> [0,255] -> host NHWC float32: the on-disk format of generate_model_samples.py.
+
+    Device tensors go through ONE fused HIP kernel (min/max + normalise + NCHW->NHWC, bit-identical to the reference
+    expression) and a pinned, asynchronous device-to-host copy; host tensors (already off the device) use the plain
+    torch expression."""
+    if samples.is_cuda:
+        from ddk import ops
+        dev = ops.fix_samples(samples.contiguous().float())
+        host = torch.empty(dev.shape, dtype=torch.float32, pin_memory=True)
+        host.copy_(dev, non_blocking=True)
+        torch.cuda.current_stream(samples.device).synchronize()
+        return host.numpy()
     samples = min_max_norm_image(samples) * 255.
-    return np.moveaxis(samples.cpu().numpy(), 1, -1)
+    return np.moveaxis(samples.numpy(), 1, -1)

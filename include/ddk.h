@@ -151,6 +151,9 @@ int ddk_p_sample_update(float* x, const float* eps_hat, const float* noise, cons
                         ddk_stream_t s);
 /* out[i] ~ N(0,1): Philox4x32-10 + Box-Muller, counter (i/4, step, stream_id)  (ddpm.py:241). */
 int ddk_randn(float* out, long long n, uint64_t seed, uint32_t step, uint32_t stream_id, ddk_stream_t s);
+/* Sampler output stage (utils/eval_helpers.py:37-41): per-image min-max over C*H*W, x255, NCHW -> NHWC:
+   out[b][h][w][c] = ((x[b][c][h][w] - min_b) / (max_b - min_b)) * 255, bit-identical to the reference expression. */
+int ddk_fix_samples(const float* x_nchw, float* out_nhwc, int B, int C, int H, int W, ddk_stream_t s);
 /* per_sample[b] = sum_i (a - b)^2 over the sample's `per` elements (ddpm.py:279, utils/utils.py:34-40). */
 int ddk_sq_err_sum(const float* a, const float* b, float* per_sample, int B, long long per, ddk_stream_t s);
 

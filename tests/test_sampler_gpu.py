@@ -159,3 +159,17 @@ def test_losses_forward_no_grad():
     finally:
         torch.randn_like = orig
     assert abs(float(got) / float(ref) - 1) < 1e-4
+
+
+def test_fix_samples_kernel_bit_exact():
+    """The fused output stage (per-image min-max, x255, NCHW->NHWC) equals the reference torch expression bit for bit,
+    on the device tensor path used by generate_model_samples.py."""
+    from utils import fix_samples
+    from oracle.diffusion_ref import fix_samples as ref_fix
+    for shape in [(5, 3, 64, 64), (2, 1, 28, 28), (3, 3, 37, 53)]:
+        g = torch.Generator().manual_seed(sum(shape))
+        x = torch.randn(*shape, generator=g) * 0.7 + 0.1
+        got = fix_samples(x.to("cuda"))
+        want = ref_fix(x)
+        assert got.shape == want.shape and got.dtype == np.float32
+        assert np.array_equal(got, want)
