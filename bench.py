@@ -68,14 +68,28 @@ def time_conv_roofline(device):
     for _ in range(5):
         ops.conv(ops.CONV3X3_S1, x, wp, b)
     torch.cuda.synchronize()
+    # 50 launches replayed as one device graph, exactly how the sampler issues them (back to back, no host in between):
+    # elapsed / 50 is then the kernel's own average duration, the figure rocprofv3 --kernel-trace reports for it.
+    # (Launched one by one from the host, each launch adds a ~9 us dispatch gap that is not the kernel's.)
     n = 50
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(n):
-        ops.conv(ops.CONV3X3_S1, x, wp, b)
-    e1.record()
-    torch.cuda.synchronize()
-    sec = e0.elapsed_time(e1) / 1e3 / n
+    side = torch.cuda.Stream(device=device)
+    side.wait_stream(torch.cuda.current_stream(device))
+    with torch.cuda.stream(side):
+        y = ops.conv(ops.CONV3X3_S1, x, wp, b)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            for _ in range(n):
+                y = ops.conv(ops.CONV3X3_S1, x, wp, b)
+        graph.replay()
+        side.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 4
+        e0.record(side)
+        for _ in range(reps):
+            graph.replay()
+        e1.record(side)
+        side.synchronize()
+    sec = e0.elapsed_time(e1) / 1e3 / (n * reps)
     flops = 2.0 * B * H * W * 9 * C * N
     bytes_alg = 4.0 * (B * H * W * C + B * H * W * N + N * 9 * C)
     # HBM/fabric bytes per launch come from a separate rocprofv3 --pmc run (FETCH_SIZE x2 + WRITE_SIZE, see
