@@ -110,10 +110,10 @@ int gn_train_nsplit(int HW, int cpg);
 int gn_stats_partials(const float* x, float* part, int B, int HW, int C, int groups, int ns, hipStream_t st);
 int groupnorm_mish(const float* x, const float* gamma, const float* beta, const float* temb, int temb_stride,
                    const float* addend, float* out, int B, int HW, int C, int groups, float eps, void* ws, size_t ws_bytes,
-                   hipStream_t st);
+                   hipStream_t st, const long long* temb_rows = nullptr);
 int groupnorm_mish_ex(const float* x, int nslab, long long slab_stride, const float* cbias, const float* gamma,
                       const float* beta, const float* temb, int temb_stride, const float* addend, float* out, int B, int HW, int C,
-                      int groups, float eps, void* ws, size_t ws_bytes, hipStream_t st);
+                      int groups, float eps, void* ws, size_t ws_bytes, hipStream_t st, const long long* temb_rows = nullptr);
 int chan_layernorm(const float* x, const float* g, const float* b, float* out, long long M, int C, float eps, hipStream_t st);
 int unary(int op, const float* x, float* out, long long n, hipStream_t st);
 int add(const float* a, const float* b, float* out, long long n, hipStream_t st);

@@ -21,7 +21,8 @@ template <int VPT, int NT>
 __global__ __launch_bounds__(NT) void gn_mish_resident_kernel(const float* __restrict__ x, int nslab, long long slab_stride,
                                                               const float* __restrict__ cbias, const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, const float* __restrict__ temb,
-                                                              int temb_stride, const float* __restrict__ addend,
+                                                              int temb_stride, const long long* __restrict__ temb_rows,
+                                                              const float* __restrict__ addend,
                                                               float* __restrict__ out, int HW, int C, int groups, float eps) {
     __shared__ float red[32];
     const int b = blockIdx.x / groups, g = blockIdx.x % groups;
@@ -80,7 +81,8 @@ __global__ __launch_bounds__(NT) void gn_mish_resident_kernel(const float* __res
             y.z = mish_f((v[i].z - mean) * rstd * ga.z + be.z);
             y.w = mish_f((v[i].w - mean) * rstd * ga.w + be.w);
             if (temb) {
-                const float4 t = *reinterpret_cast<const float4*>(temb + (long long)b * temb_stride + c0);
+                const long long tr = temb_rows ? temb_rows[b] : b;   // sampler: row = timestep of sample b in the precomputed table
+                const float4 t = *reinterpret_cast<const float4*>(temb + tr * temb_stride + c0);
                 y.x += t.x; y.y += t.y; y.z += t.z; y.w += t.w;
             }
             const long long o = base + (long long)row * C + cu * 4;
@@ -132,6 +134,7 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict
 __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x, const float* __restrict__ part, int nsplit,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        const float* __restrict__ temb, int temb_stride,
+                                                       const long long* __restrict__ temb_rows,
                                                        const float* __restrict__ addend, float* __restrict__ out, int HW, int C,
                                                        int groups, float eps, long long total4) {
     const int c4 = C >> 2, cpg = C / groups;
@@ -162,7 +165,8 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
         y.z = mish_f((v.z - mean) * rstd * ga.z + be.z);
         y.w = mish_f((v.w - mean) * rstd * ga.w + be.w);
         if (temb) {
-            const float4 t = *reinterpret_cast<const float4*>(temb + (long long)b * temb_stride + c0);
+            const long long tr = temb_rows ? temb_rows[b] : b;
+            const float4 t = *reinterpret_cast<const float4*>(temb + tr * temb_stride + c0);
             y.x += t.x; y.y += t.y; y.z += t.z; y.w += t.w;
         }
         if (addend) {
@@ -195,7 +199,7 @@ size_t groupnorm_workspace_bytes(int B, int HW, int C, int groups) {
 
 int groupnorm_mish_ex(const float* x, int nslab, long long slab_stride, const float* cbias, const float* gamma,
                       const float* beta, const float* temb, int temb_stride, const float* addend, float* out, int B, int HW, int C,
-                      int groups, float eps, void* ws, size_t ws_bytes, hipStream_t st) {
+                      int groups, float eps, void* ws, size_t ws_bytes, hipStream_t st, const long long* temb_rows) {
     DDK_REQUIRE(x && gamma && beta && out, "groupnorm: null pointer");
     DDK_REQUIRE(B > 0 && HW > 0 && groups > 0 && C % groups == 0 && (C / groups) % 4 == 0,
                 "groupnorm: C/groups must be a multiple of 4");
@@ -211,7 +215,7 @@ int groupnorm_mish_ex(const float* x, int nslab, long long slab_stride, const fl
         dim3 grid(B * groups);
 #define GN_CASE(V, NT)                                                                                                  \
     hipLaunchKernelGGL((gn_mish_resident_kernel<V, NT>), grid, dim3(NT), 0, st, x, nslab, slab_stride, cbias, gamma, beta, temb, \
-                       temb_stride, addend, out, HW, C, groups, eps)
+                       temb_stride, temb_rows, addend, out, HW, C, groups, eps)
         // big slabs: 1024 threads (16 waves per CU keep enough loads in flight); small ones: 256
         if (units <= 256) GN_CASE(1, 256);
         else if (units <= 512) GN_CASE(2, 256);
@@ -232,15 +236,16 @@ int groupnorm_mish_ex(const float* x, int nslab, long long slab_stride, const fl
     DDK_TRY(check_launch("gn_partial_kernel"));
     const long long total4 = (long long)B * HW * C / 4;
     const int blocks = (int)(ceil_div(total4, 256) < 4096 ? ceil_div(total4, 256) : 4096);
-    hipLaunchKernelGGL(gn_apply_kernel, dim3(blocks), dim3(256), 0, st, x, part, ns, gamma, beta, temb, temb_stride, addend, out,
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(blocks), dim3(256), 0, st, x, part, ns, gamma, beta, temb, temb_stride, temb_rows, addend, out,
                        HW, C, groups, eps, total4);
     return check_launch("gn_apply_kernel");
 }
 
 int groupnorm_mish(const float* x, const float* gamma, const float* beta, const float* temb, int temb_stride,
                    const float* addend, float* out, int B, int HW, int C, int groups, float eps, void* ws, size_t ws_bytes,
-                   hipStream_t st) {
-    return groupnorm_mish_ex(x, 1, 0, nullptr, gamma, beta, temb, temb_stride, addend, out, B, HW, C, groups, eps, ws, ws_bytes, st);
+                   hipStream_t st, const long long* temb_rows) {
+    return groupnorm_mish_ex(x, 1, 0, nullptr, gamma, beta, temb, temb_stride, addend, out, B, HW, C, groups, eps, ws, ws_bytes, st,
+                             temb_rows);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -329,7 +329,8 @@ struct Ctx {
     const Layout& ly;
     int B;
     hipStream_t st;
-    const float* temb;  // [B][temb_total]
+    const float* temb;            // [B][temb_total], or the sampler's per-timestep table [t_start+1][temb_total]
+    const long long* temb_rows;   // nullptr: row b;  sampler: row = t_cur[b] (device), so one table serves every step
 };
 
 static int run_conv(Ctx& c, int kind, const ConvW& cw, const float* src0, int c0, const float* src1, int c1, const float* resid,
@@ -369,16 +370,16 @@ static int run_conv_gn(Ctx& c, const ConvW& cw, const float* src0, int c0, const
         DDK_TRY(conv_forward(a, c.st));
         return groupnorm_mish_ex(c.W + c.ly.off_splitk, splits, (long long)c.B * H * W * N, cw.has_bias ? c.P + cw.b : nullptr,
                                  c.P + n.g, c.P + n.b, temb, c.u.temb_total, addend, out, c.B, H * W, N, GROUPS, GN_EPS, nullptr, 0,
-                                 c.st);
+                                 c.st, c.temb_rows);
     }
     DDK_TRY(run_conv(c, DDK_CONV3X3_S1, cw, src0, c0, src1, c1, nullptr, raw, H, W, N));
     return groupnorm_mish(raw, c.P + n.g, c.P + n.b, temb, c.u.temb_total, addend, out, c.B, H * W, N, GROUPS, GN_EPS,
-                          c.W + c.ly.off_gn, c.ly.gn_ws * sizeof(float), c.st);
+                          c.W + c.ly.off_gn, c.ly.gn_ws * sizeof(float), c.st, c.temb_rows);
 }
 
 static int run_gn(Ctx& c, const float* x, const NormW& n, const float* temb, const float* addend, float* out, int HW, int C) {
     return groupnorm_mish(x, c.P + n.g, c.P + n.b, temb, c.u.temb_total, addend, out, c.B, HW, C, GROUPS, GN_EPS,
-                          c.W + c.ly.off_gn, c.ly.gn_ws * sizeof(float), c.st);
+                          c.W + c.ly.off_gn, c.ly.gn_ws * sizeof(float), c.st, c.temb_rows);
 }
 
 // blocks.py:105-115 (eval): out = Mish(GN(conv2(Mish(GN(conv1(x))) + temb))) + res(x)
@@ -411,13 +412,18 @@ static int run_attn(Ctx& c, const AttnW& a, const float* x, float* out, int H, i
 }
 
 // xpad: NHWC input already zero-padded to pad32(in_ch) channels.
+// temb_table != nullptr (sampler): the per-block time shifts of EVERY timestep were computed once up front
+// (build_temb_table); row t[b] of the table is read directly by the GroupNorm kernels and no time kernel runs per step.
 static int forward_core(const ddk_unet& u, const float* P, const float* xpad, const int64_t* t, float* out, int B, int H0, int W0,
-                        float* ws, const Layout& ly, hipStream_t st) {
+                        float* ws, const Layout& ly, hipStream_t st, const float* temb_table = nullptr) {
     float* tact = ws + ly.off_tact;
     float* temb = ws + ly.off_temb;
-    DDK_TRY(time_mlp(t, P + u.freqs, P + u.w1t, P + u.b1, P + u.w2t, P + u.b2, tact, nullptr, B, u.time_dim, st));
-    DDK_TRY(time_proj(tact, P + u.temb_wt, P + u.temb_bias, temb, B, u.time_dim, u.temb_total, st));
-    Ctx c{u, P, ws, ly, B, st, temb};
+    if (!temb_table) {
+        DDK_TRY(time_mlp(t, P + u.freqs, P + u.w1t, P + u.b1, P + u.w2t, P + u.b2, tact, nullptr, B, u.time_dim, st));
+        DDK_TRY(time_proj(tact, P + u.temb_wt, P + u.temb_bias, temb, B, u.time_dim, u.temb_total, st));
+    }
+    static_assert(sizeof(long long) == sizeof(int64_t), "timestep rows are read as long long");
+    Ctx c{u, P, ws, ly, B, st, temb_table ? temb_table : temb, temb_table ? reinterpret_cast<const long long*>(t) : nullptr};
     float* bufA = ws + ly.off_A;
     float* bufB = ws + ly.off_B;
     float* bufC = ws + ly.off_C;
@@ -549,21 +555,31 @@ extern "C" double ddk_unet_flops(const ddk_unet* u, int B, int H0, int W0) {
 // ------------------------------------------------------------------------------------------------ sampler
 namespace ddk {
 struct SamplerLayout {
-    size_t unet_floats, off_eps, off_t, total;
+    size_t unet_floats, off_eps, off_t, off_table, off_tact_all, off_tall, total;
 };
-static SamplerLayout sampler_layout(const ddk_unet& u, int B, int H, int W) {
+// rows = t_start + 1 timesteps: the time-shift table [rows][temb_total], its staging [rows][time_dim] and int64 t = 0..rows-1
+static SamplerLayout sampler_layout(const ddk_unet& u, int B, int H, int W, int t_start) {
     SamplerLayout s;
+    const size_t rows = (size_t)t_start + 1;
     s.unet_floats = make_layout(u, B, H, W).total;
     s.off_eps = s.unet_floats;
     s.off_t = s.off_eps + al4((size_t)B * H * W * u.cfg.in_ch);
-    s.total = s.off_t + al4(2 * (size_t)(B + 1));  // int64 t_cur[B] + counter, in float units
+    s.off_table = s.off_t + al4(2 * (size_t)(B + 1));  // int64 t_cur[B] + counter, in float units
+    s.off_tact_all = s.off_table + al4(rows * u.temb_total);
+    s.off_tall = s.off_tact_all + al4(rows * u.time_dim);
+    s.total = s.off_tall + al4(2 * rows);
     return s;
+}
+
+__global__ void iota64_kernel(int64_t* out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = i;
 }
 }  // namespace ddk
 
-extern "C" size_t ddk_sampler_workspace_bytes(const ddk_unet* u, int B, int H, int W) {
-    if (check_shape(u, B, H, W) != DDK_OK) return 0;
-    return sampler_layout(*u, B, H, W).total * sizeof(float);
+extern "C" size_t ddk_sampler_workspace_bytes(const ddk_unet* u, int B, int H, int W, int t_start) {
+    if (check_shape(u, B, H, W) != DDK_OK || t_start < 0) return 0;
+    return sampler_layout(*u, B, H, W, t_start).total * sizeof(float);
 }
 
 extern "C" int ddk_sampler_run(const ddk_sampler_args* a, ddk_stream_t s) {
@@ -576,7 +592,7 @@ extern "C" int ddk_sampler_run(const ddk_sampler_args* a, ddk_stream_t s) {
     const int B = a->B, H = a->H, W = a->W, C = u.cfg.in_ch, cp = pad32(C);
     const long long per = (long long)H * W * C;
     DDK_REQUIRE(per % 4 == 0, "sampler: H*W*in_ch must be a multiple of 4");
-    const SamplerLayout sl = sampler_layout(u, B, H, W);
+    const SamplerLayout sl = sampler_layout(u, B, H, W, a->t_start);
     if (a->workspace_bytes < sl.total * sizeof(float)) {
         set_error("sampler: workspace too small (%zu < %zu)", a->workspace_bytes, sl.total * sizeof(float));
         return DDK_ERR_WORKSPACE;
@@ -589,19 +605,29 @@ extern "C" int ddk_sampler_run(const ddk_sampler_args* a, ddk_stream_t s) {
     int64_t* counter = t_cur + B;
     float* xpad = ws + ly.off_xpad;
     const float* P = static_cast<const float*>(a->packed);
+    const float* temb_table = ws + sl.off_table;
     const long long padded = (long long)B * H * W * cp;
     const int prep_blocks = (int)(ceil_div(padded, 256) < 1024 ? ceil_div(padded, 256) : 1024);
 
     auto one_step = [&]() -> int {
         hipLaunchKernelGGL(step_prepare_kernel, dim3(prep_blocks), dim3(256), 0, st, a->x, xpad, padded, C, cp, counter, t_cur, B);
         DDK_TRY(check_launch("step_prepare_kernel"));
-        DDK_TRY(forward_core(u, P, xpad, t_cur, eps_hat, B, H, W, ws, ly, st));
+        DDK_TRY(forward_core(u, P, xpad, t_cur, eps_hat, B, H, W, ws, ly, st, temb_table));
         return p_sample_update(a->x, eps_hat, a->noise, a->noise ? B * per : 0, a->t_start, t_cur, a->c_recip, a->c_recipm1, a->c1,
                                a->c2, a->sigma, B, per, a->seed, a->stream_id, st);
     };
 
     hipLaunchKernelGGL(set_counter_kernel, dim3(1), dim3(1), 0, st, counter, (int64_t)a->t_start);
     DDK_TRY(check_launch("set_counter_kernel"));
+    {   // time-shift table for t = 0..t_start: the same two kernels a forward runs, once, with "batch" = all timesteps
+        const int rows = a->t_start + 1;
+        int64_t* t_all = reinterpret_cast<int64_t*>(ws + sl.off_tall);
+        float* tact_all = ws + sl.off_tact_all;
+        hipLaunchKernelGGL(iota64_kernel, dim3((unsigned)ceil_div(rows, 256)), dim3(256), 0, st, t_all, rows);
+        DDK_TRY(check_launch("iota64_kernel"));
+        DDK_TRY(time_mlp(t_all, P + u.freqs, P + u.w1t, P + u.b1, P + u.w2t, P + u.b2, tact_all, nullptr, rows, u.time_dim, st));
+        DDK_TRY(time_proj(tact_all, P + u.temb_wt, P + u.temb_bias, ws + sl.off_table, rows, u.time_dim, u.temb_total, st));
+    }
     const int n_steps = a->t_start - a->t_end + 1;
     // first step eagerly: it also performs the one-time per-kernel attribute setup that must not run under capture
     DDK_TRY(one_step());

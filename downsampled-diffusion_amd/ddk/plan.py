@@ -110,7 +110,7 @@ class UnetPlan:
             raise L.DDKError("UnetPlan.sample before pack()")
         b, h, w, c = x.shape
         lib = self._lib
-        nbytes = lib.ddk_sampler_workspace_bytes(self.handle, b, h, w)
+        nbytes = lib.ddk_sampler_workspace_bytes(self.handle, b, h, w, t_start)
         if nbytes == 0:
             raise L.DDKError(f"sampler workspace query failed: {L.last_error()}")
         ws = self._workspace("smp", nbytes, x.device)

@@ -206,7 +206,9 @@ typedef struct ddk_sampler_args {
     size_t workspace_bytes;
 } ddk_sampler_args;
 
-size_t ddk_sampler_workspace_bytes(const ddk_unet* u, int B, int H, int W);
+/* workspace of ddk_sampler_run for chains starting at t_start (it holds, besides the UNet's scratch, the per-block time
+   shifts of every timestep 0..t_start, computed once: no time-embedding kernel runs inside the loop) */
+size_t ddk_sampler_workspace_bytes(const ddk_unet* u, int B, int H, int W, int t_start);
 int ddk_sampler_run(const ddk_sampler_args* a, ddk_stream_t s);
 
 
