@@ -5,6 +5,9 @@ import torch
 from .utils import min_max_norm_image
 
 
+_staging = {}
+
+
 def fix_samples(samples):
     """Per-image min-max -> [0,255] -> host NHWC float32: the on-disk format of generate_model_samples.py.
 
@@ -14,9 +17,12 @@ def fix_samples(samples):
     if samples.is_cuda:
         from ddk import ops
         dev = ops.fix_samples(samples.contiguous().float())
-        host = torch.empty(dev.shape, dtype=torch.float32, pin_memory=True)
-        host.copy_(dev, non_blocking=True)
+        key = (tuple(dev.shape), str(dev.device))
+        stage = _staging.get(key)
+        if stage is None:                      # one pinned staging buffer per batch shape, reused for every batch
+            stage = _staging[key] = torch.empty(dev.shape, dtype=torch.float32, pin_memory=True)
+        stage.copy_(dev, non_blocking=True)
         torch.cuda.current_stream(samples.device).synchronize()
-        return host.numpy()
+        return stage.numpy().copy()            # pageable result: the caller keeps a list of all batches
     samples = min_max_norm_image(samples) * 255.
     return np.moveaxis(samples.numpy(), 1, -1)
