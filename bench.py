@@ -288,7 +288,7 @@ def main():
             except Exception as e:   # noqa: BLE001 -- secondary figure: report the failure, keep the headline line
                 out["config"]["train_step_ms_cfg3_bs64"] = None
                 log(f"training-step timing failed: {type(e).__name__}: {e}")
-        if not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline:          # reported baseline: rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(cfg, model.state_dict())
         print(json.dumps(out), flush=True)
     if world > 1:
