@@ -142,6 +142,10 @@ __global__ __launch_bounds__(WN* WC * 64) void wgrad_kernel(const WgradParams p)
     const int b_off = 32 * BN + wc * TC * 32 + (lane & 31) + (lane >> 5) * BC;
 
     if (n_it > 0) issue(0, m_begin);
+    {   // keep SMEM out of the k-loop (see conv_igemm.hip consume_epilogue_args): epilogue-only arguments are consumed here
+        const int nt = p.ntaps, NN = p.N, cxx = p.cx;
+        asm volatile("" ::"s"(p.slab), "s"(nt), "s"(NN), "s"(cxx));
+    }
     for (int k = 0; k < n_it; ++k) {
         const int stage = k & 1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -149,17 +153,27 @@ __global__ __launch_bounds__(WN* WC * 64) void wgrad_kernel(const WgradParams p)
         if (k + 1 < n_it) issue(stage ^ 1, m_begin + (k + 1) * 32);
         const float* As = smem + stage * STAGE + a_off;
         const float* Bs = smem + stage * STAGE + b_off;
+        // operands of k-pair q+2 are requested before the MFMAs of k-pair q (two pairs = 2*TN*TC MFMAs of cover for the
+        // ds_read latency); the fences keep hipcc from sinking the reads back to their first use
+        float a[3][TN], b[3][TC];
+        auto load_pair = [&](int slot, int kk) {
 #pragma unroll
-        for (int kk = 0; kk < 32; kk += 2) {
-            float a[TN], b[TC];
+            for (int i = 0; i < TN; ++i) a[slot][i] = As[kk * BN + i * 32];
 #pragma unroll
-            for (int i = 0; i < TN; ++i) a[i] = As[kk * BN + i * 32];
+            for (int j = 0; j < TC; ++j) b[slot][j] = Bs[kk * BC + j * 32];
+        };
+        load_pair(0, 0);
+        load_pair(1, 2);
 #pragma unroll
-            for (int j = 0; j < TC; ++j) b[j] = Bs[kk * BC + j * 32];
+        for (int q = 0; q < 16; ++q) {
+            const int cur = q % 3, nxt = (q + 2) % 3;
+            if (q + 2 < 16) load_pair(nxt, 2 * (q + 2));
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < TN; ++i)
 #pragma unroll
-                for (int j = 0; j < TC; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TC; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 
