@@ -108,3 +108,22 @@ def test_spatial_size_must_divide():
     with pytest.raises(DDKError):             # 28 -> 14 -> 7 -> 4: reference fails in torch.cat
         with torch.no_grad():
             u(torch.zeros(1, 1, 28, 28, device=DEV), torch.zeros(1, dtype=torch.long, device=DEV))
+
+
+def test_full_resolution_forward_vs_oracle():
+    """cfg5 shape class: the reference-width UNet (chan 128, dims (1,2,2,2), C_in 3) at 128x128 -- GroupNorm slabs of
+    262144 elements (the multi-workgroup statistics path), 16384 pixels per sample in the linear attention -- against the
+    CPU oracle.  (256x256 runs the same code paths; 128x128 keeps the oracle's CPU time to a few seconds.)"""
+    from models import Unet
+    from oracle import unet_ref as U
+    cfg = dict(unet_chan=128, unet_in=3, unet_dims=(1, 2, 2, 2), unet_dropout=0.0)
+    u = Unet(cfg)
+    u.load_state_dict(syn.fill_state_dict(u.state_dict(), 5))
+    sd = {k: v.clone() for k, v in u.state_dict().items()}
+    u = u.to(DEV).eval()
+    x = syn.synthetic_normal((1, 3, 128, 128), "cfg5.x")
+    t = torch.tensor([421])
+    with torch.no_grad():
+        y = u(x.to(DEV), t.to(DEV)).cpu()
+        ref = U.unet_forward(sd, cfg, x, t)
+    assert float((y - ref).abs().max() / ref.abs().max()) < 5e-5

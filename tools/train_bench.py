@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Training-step timing (cfg3: CelebA 64x64 dDDPM x2, batch 64; cfg2-like plain DDPM 32x32) and a full-resolution
-(cfg5 shape, 256x256) UNet forward check against the CPU oracle.  GPU-box tool: python tools/train_bench.py"""
+"""Training-step timing: cfg3 (CelebA 64x64 dDDPM x2, batch 64), cfg2-like plain DDPM 32x32, cfg5 (full-resolution DDPM
+256x256, batch 8), eager vs device-graph replay.  GPU-box tool: python tools/train_bench.py"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(ROOT, "downsampled-diffusion_amd"), ROOT]
@@ -71,21 +71,3 @@ if __name__ == "__main__":
     c = cfg(128, 3, 256)
     time_train("cfg5 DDPM 256x256 bs8     ", DDPM(c, Unet(c), DEV, 3), (4, 3, 256, 256), steps=3)
     print(f"peak HBM allocated: {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB", flush=True)
-    # cfg5 shape: full-resolution forward, B=1, vs the CPU oracle
-    from oracle import unet_ref as U
-    c = cfg(128, 3, 256)
-    u = Unet(c)
-    u.load_state_dict(syn.fill_state_dict(u.state_dict()))
-    sd = {k: v.clone() for k, v in u.state_dict().items()}
-    u = u.to(DEV).eval()
-    x = syn.synthetic_normal((1, 3, 256, 256), "cfg5.x")
-    t = torch.tensor([421])
-    with torch.no_grad():
-        y = u(x.to(DEV), t.to(DEV)).cpu()
-        torch.cuda.synchronize(); t0 = time.perf_counter()
-        for _ in range(3):
-            u(x.to(DEV), t.to(DEV))
-        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 3
-    ref = U.unet_forward(sd, c, x, t)
-    err = float((y - ref).abs().max() / ref.abs().max())
-    print(f"cfg5 256x256 B=1 forward: {dt * 1e3:.1f} ms, rel err vs oracle {err:.2e} ({u.flops(1, 256, 256) / dt / 1e12:.1f} TFLOP/s)")
