@@ -114,12 +114,14 @@ def test_no_cpu_fallback():
 
 
 def test_product_never_imports_oracle():
-    pkg = os.path.join(ROOT, "downsampled-diffusion_amd")
-    for dp, _, fs in os.walk(pkg):
-        for f in fs:
-            if f.endswith((".py", ".hip", ".h", ".cpp")):
-                src = open(os.path.join(dp, f)).read()
-                assert "import oracle" not in src and "from oracle" not in src, os.path.join(dp, f)
+    """oracle/ is test infrastructure: nothing in the package, include/ or tools/ may import it (bench.py's cpu_baseline
+    leg and __graft_entry__.smoke() are the two sanctioned users outside tests/)."""
+    for top in ("downsampled-diffusion_amd", "include", "tools"):
+        for dp, _, fs in os.walk(os.path.join(ROOT, top)):
+            for f in fs:
+                if f.endswith((".py", ".hip", ".h", ".cpp")):
+                    src = open(os.path.join(dp, f)).read()
+                    assert "import oracle" not in src and "from oracle" not in src, os.path.join(dp, f)
 
 
 def test_cli_args_surface():
