@@ -322,38 +322,33 @@ class TimeEmbedFn(torch.autograd.Function):
         act = ops.bias_act_(tv, b2.detach(), True)
         ws, bs = mlps[0::2], mlps[1::2]
         ctot = sum(w.shape[0] for w in ws)
+        # all per-block Linears as ONE product against the concatenated weight (3 launches instead of 17 + 1)
+        wcat = torch.cat([w.detach() for w in ws])                  # [ctot, d]
         out = torch.empty((bsz, ctot), device=dev, dtype=torch.float32)
-        off = 0
-        for w, b in zip(ws, bs):
-            co = w.shape[0]
-            ops.small_gemm(1, act, w.detach(), out[:, off:off + co], bsz, co, d, d, d, ctot)
-            off += co
+        ops.small_gemm(1, act, wcat, out, bsz, ctot, d, d, d, ctot)
         bcat = torch.cat([b.detach() for b in bs])
         ops.bias_act_(out, bcat, False)
-        ctx.save_for_backward(e, u1, h1, tv, act, w1, w2, *ws)
-        ctx.n_mlp = len(ws)
+        ctx.save_for_backward(e, u1, h1, tv, act, w1, w2, wcat)
+        ctx.couts = [w.shape[0] for w in ws]
         return out
 
     @staticmethod
     def backward(ctx, dout):
         saved = ctx.saved_tensors
-        e, u1, h1, tv, act, w1, w2 = saved[:7]
-        ws = saved[7:]
+        e, u1, h1, tv, act, w1, w2, wcat = saved
         dout = _c(dout)
         bsz, ctot = dout.shape
         d = w2.shape[0]
         dev = dout.device
-        dact = torch.zeros((bsz, d), device=dev, dtype=torch.float32)
+        gwcat = torch.empty_like(wcat)
+        ops.small_gemm(2, dout, act, gwcat, ctot, d, bsz, ctot, d, d)        # dWcat[ctot][d] = dout^T act
+        gbcat = ops.rows_sum(dout, bsz, ctot, ctot)
+        dact = torch.empty((bsz, d), device=dev, dtype=torch.float32)
+        ops.small_gemm(0, dout, wcat, dact, bsz, d, ctot, ctot, d, d)        # dact = dout Wcat
         grads = []
         off = 0
-        for w in ws:
-            co = w.shape[0]
-            sl = dout[:, off:off + co]
-            gw = torch.empty_like(w)
-            ops.small_gemm(2, sl, act, gw, co, d, bsz, ctot, d, d)               # dW[co][d] = dout^T act
-            gb = ops.rows_sum(sl, bsz, ctot, co)
-            ops.small_gemm(0, sl, w.detach(), dact, bsz, d, co, ctot, d, d, accumulate=True)
-            grads += [gw, gb]
+        for co in ctx.couts:                                                 # per-parameter gradients are row ranges (views)
+            grads += [gwcat[off:off + co], gbcat[off:off + co]]
             off += co
         dtv = ops.mish_bwd(tv, dact)
         gw2 = torch.empty_like(w2)
