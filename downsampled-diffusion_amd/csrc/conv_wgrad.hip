@@ -193,6 +193,147 @@ __global__ __launch_bounds__(WN* WC * 64) void wgrad_kernel(const WgradParams p)
         }
 }
 
+// ------------------------------------------------------------------------------------------------
+// 3x3 stride-1 weight gradient with the INPUT HALO staged once per 32-pixel chunk and ALL 9 TAPS accumulated by the same
+// workgroup (the per-tap kernel above re-loads dY for each of its 9 tap workgroups and streams 32 KB per 4096 MFMA
+// cycles -- the CU's LDS-DMA rate, see conv_igemm.hip).  Tile: 64 output channels (n) x 64 input channels (c) x 9 taps;
+// 4 waves (2x2), each 32 x 32 x 9 taps = 9 accumulators.  A k-chunk is 32 consecutive output pixels = R = 32/WC whole
+// rows of width WC (W <= 32), or a 32-pixel segment of one row (W > 32, WC = 32).  Per chunk the workgroup DMAs
+//   dYs[32 px][64 n]                                   8 KB
+//   Xh[R][3 rows][WC+2 cols][64 c]   (zero outside)    26-36 KB
+// and runs 16 k-pairs x 9 taps MFMAs per wave: 34-44 KB per 9216 MFMA cycles instead of 72 KB.  The X operand of tap
+// (dy, dx) for pixel k is halo pixel hb(k) + (dy+1)*(WC+2) + (dx+1): a compile-time immediate on top of a per-lane base.
+struct WgHaloParams {
+    const float* x;    // [B][H][W][cx]
+    const float* dy;   // [M][N]
+    float* slab;       // [splits][N][9][cx]
+    int cx, N, B, H, W, M;
+    int splits, chunks_per_split, n_chunks;
+    FastDiv dH_, dW_;
+};
+
+template <int WC>
+__global__ __launch_bounds__(256) void wgrad3x3_halo_kernel(const WgHaloParams p) {
+    constexpr int R = 32 / WC;                  // rows per chunk (W <= 32); 1 when WC == 32 (also covers W > 32)
+    constexpr int WP = WC + 2;
+    constexpr int HALO_PX = R * 3 * WP;
+    constexpr int X_PIECES = (HALO_PX + 3) / 4; // 1-KiB pieces of 4 halo pixels x 64 channels
+    constexpr int STAGE = 32 * 64 + X_PIECES * 4 * 64;   // floats
+    constexpr int PIECES = 8 + X_PIECES;
+    constexpr int PW = (PIECES + 3) / 4;
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wid_u = __builtin_amdgcn_readfirstlane(wid);
+    const int wn = wid >> 1, wc = wid & 1;
+    const int n0 = blockIdx.x * 64, c0 = blockIdx.y * 64, split = blockIdx.z;
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) float*)smem;
+    const int g_begin = split * p.chunks_per_split;
+    const int g_end = min(p.n_chunks, g_begin + p.chunks_per_split);
+    const int n_it = g_end - g_begin;
+    const float* zero = g_zero_page_w + (lane & 7) * 4;
+    const int ppx = lane >> 4, pc4 = (lane & 15) * 4;    // this lane's pixel inside a piece and its channel quad
+
+    auto issue = [&](int stage, int g) {
+        const unsigned st = lds_base + (unsigned)(stage * STAGE * 4);
+        const int m0 = g * 32;
+        // chunk origin: global row (b*H + y) of its first pixel and first column
+        int grow0, x0;
+        if (WC == 32) { const unsigned q = fdiv((unsigned)m0, p.dW_); grow0 = (int)q; x0 = m0 - (int)q * p.W; }
+        else { grow0 = m0 / WC; x0 = 0; }
+#pragma unroll
+        for (int jj = 0; jj < PW; ++jj) {
+            const int j = wid_u * PW + jj;            // wave-uniform piece index
+            if (j < 8) {
+                const int m = m0 + j * 4 + ppx;
+                const float* g_ = m < p.M ? p.dy + (long long)m * p.N + n0 + pc4 : zero;
+                lds_dma16_w(g_, (unsigned)__builtin_amdgcn_readfirstlane((int)(st + (unsigned)(j * 1024))));
+            } else if (j < PIECES) {
+                const int hp = (j - 8) * 4 + ppx;
+                const int r = hp / (3 * WP), rem = hp - r * (3 * WP);
+                const int dyi = rem / WP, xx = rem - dyi * WP;
+                const unsigned grow = (unsigned)(grow0 + r);
+                const unsigned b = fdiv(grow, p.dH_);
+                const int yy = (int)(grow - b * (unsigned)p.H) + dyi - 1;
+                const int xc = x0 + xx - 1;
+                const bool ok = hp < HALO_PX && (int)b < p.B && (unsigned)yy < (unsigned)p.H && (unsigned)xc < (unsigned)p.W;
+                const float* g_ = ok ? p.x + (((long long)b * p.H + yy) * p.W + xc) * p.cx + c0 + pc4 : zero;
+                lds_dma16_w(g_, (unsigned)__builtin_amdgcn_readfirstlane((int)(st + (unsigned)(32 * 64 * 4 + (j - 8) * 1024))));
+            }
+        }
+    };
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    // per-lane operand offsets (floats): k = 2*kk + (lane >> 5)
+    const int fh = lane >> 5, l31 = lane & 31;
+    const int a_off = fh * 64 + wn * 32 + l31;                      // + kk * 128
+    int hb_off[16];
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+        const int k = 2 * kk + fh;
+        const int r = k / WC, xl = k - r * WC;
+        hb_off[kk] = 32 * 64 + (r * 3 * WP + xl) * 64 + wc * 32 + l31;   // tap (dy,dx) adds ((dy+1)*WP + dx+1) * 64
+    }
+
+    if (n_it > 0) issue(0, g_begin);
+    {   // keep SMEM out of the k-loop (conv_igemm.hip consume_epilogue_args)
+        const int NN = p.N, cxx = p.cx, sp = p.splits;
+        asm volatile("" ::"s"(p.slab), "s"(NN), "s"(cxx), "s"(sp));
+    }
+    for (int it = 0; it < n_it; ++it) {
+        const int stage = it & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (it + 1 < n_it) issue(stage ^ 1, g_begin + it + 1);
+        const float* S = smem + stage * STAGE;
+        float a[2], b[2][9];
+        auto load_pair = [&](int slot, int kk) {
+            a[slot] = S[a_off + kk * 128];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) b[slot][t] = S[hb_off[kk] + ((t / 3) * WP + (t % 3)) * 64];
+        };
+        load_pair(0, 0);
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            const int cur = kk & 1;
+            if (kk + 1 < 16) load_pair(cur ^ 1, kk + 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur], b[cur][t], acc[t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+    // epilogue: per tap, this wave's 32x32 block -> LDS (pitch 40) -> float4 rows -> slab[split][n][tap][c]
+    __syncthreads();
+    float* Es = smem + wid * 32 * 40;
+    float* outp = p.slab + (long long)split * p.N * 9 * p.cx;
+    const int row_l = lane >> 3, col4 = (lane & 7) * 4;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Es[((r & 3) + 8 * (r >> 2) + 4 * fh) * 40 + l31] = acc[t][r];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            const int row = pass * 8 + row_l;
+            const int n = n0 + wn * 32 + row;
+            const float4 v = *reinterpret_cast<const float4*>(Es + row * 40 + col4);
+            if (n < p.N) *reinterpret_cast<float4*>(outp + ((long long)n * 9 + t) * p.cx + c0 + wc * 32 + col4) = v;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
 // grad[(n*cw + c_off + c)*ntaps + tap] += sum_s slab[s][n][tap][c]   (only the first c_real channels: the input may be padded)
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, int splits, long long slab_stride,
                                                            float* __restrict__ grad, int N, int ntaps, int cx, int c_real, int cw,
@@ -316,6 +457,43 @@ static bool wgrad_geometry(int kind, int H, int W, int& Hm, int& Wm, int& stride
     }
 }
 
+// halo weight-gradient kernel: eligibility and split over pixel chunks (~512 workgroups, >= 8 chunks each)
+static bool wgrad_halo_plan(int kind, int B, int H, int W, int cx, int N, int& wc, int& splits, int& cps, int& n_chunks) {
+    static const bool off = getenv("DDK_NO_WGRAD_HALO") != nullptr;   // A/B knob
+    if (off || kind != DDK_CONV3X3_S1 || N % 64 || cx % 64) return false;
+    if (W <= 32) { if (W < 4 || 32 % W) return false; wc = W; }
+    else { if (W % 32) return false; wc = 32; }
+    const long long M = (long long)B * H * W;
+    if (M % 32) return false;                      // whole chunks only (rows / images never straddle a chunk boundary badly)
+    if (W < 32 && ((long long)B * H) % (32 / W)) return false;
+    n_chunks = (int)(M / 32);
+    if (n_chunks < 128) return false;              // tiny maps: the per-tap kernel's 9x more workgroups win
+    const long long tiles = (long long)(N / 64) * (cx / 64);
+    static const int target = getenv("DDK_WGRAD_HALO_WGS") ? atoi(getenv("DDK_WGRAD_HALO_WGS")) : 512;   // tuning knob
+    long long s = ceil_div(target, tiles);
+    const long long max_s = n_chunks / 8 > 0 ? n_chunks / 8 : 1;
+    if (s > max_s) s = max_s;
+    if (s > 128) s = 128;
+    cps = (int)ceil_div(n_chunks, s);
+    splits = (int)ceil_div(n_chunks, cps);
+    return true;
+}
+
+template <int WC>
+static int launch_wgrad_halo(const WgHaloParams& p, hipStream_t st) {
+    constexpr int HALO_PX = (32 / WC) * 3 * (WC + 2);
+    constexpr size_t lds = 2 * (size_t)(32 * 64 + ((HALO_PX + 3) / 4) * 4 * 64) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        DDK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3_halo_kernel<WC>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds));
+        attr_set = true;
+    }
+    dim3 grid((unsigned)(p.N / 64), (unsigned)(p.cx / 64), (unsigned)p.splits);
+    hipLaunchKernelGGL((wgrad3x3_halo_kernel<WC>), grid, dim3(256), lds, st, p);
+    return check_launch("wgrad3x3_halo_kernel");
+}
+
 template <int BN, int BC, int WN, int WC>
 static int launch_wgrad(const WgradParams& p, int ntiles_n, int ntiles_c, hipStream_t st) {
     constexpr size_t lds = 2 * 32 * (size_t)(BN + BC) * sizeof(float);
@@ -333,6 +511,8 @@ extern "C" {
 size_t ddk_conv_wgrad_workspace_bytes(int kind, int B, int H, int W, int cx, int N) {
     int Hm, Wm, stride, tapmode, ntaps;
     if (!wgrad_geometry(kind, H, W, Hm, Wm, stride, tapmode, ntaps)) return 0;
+    int wc, hs, cps, nch;
+    if (wgrad_halo_plan(kind, B, H, W, cx, N, wc, hs, cps, nch)) return (size_t)hs * N * 9 * cx * sizeof(float);
     const WgChoice c = wgrad_choice(N, cx, ntaps, (long long)B * Hm * Wm);
     return (size_t)c.splits * N * ntaps * cx * sizeof(float);
 }
@@ -352,6 +532,33 @@ int ddk_conv_wgrad(int kind, const float* x, const float* dy, float* grad_w, int
     DDK_REQUIRE(aligned16(x) && aligned16(dy) && aligned16(workspace), "conv_wgrad: alignment");
     const long long M = (long long)B * Hm * Wm;
     DDK_REQUIRE(M < (1LL << 31) && (long long)B * H * W * cx < (1LL << 31), "conv_wgrad: tensor too large");
+    hipStream_t st = as_stream(s);
+    {
+        int wc, hs, cps, nch;
+        if (wgrad_halo_plan(kind, B, H, W, cx, N, wc, hs, cps, nch)) {
+            const size_t need_h = (size_t)hs * N * 9 * cx * sizeof(float);
+            if (workspace_bytes < need_h) {
+                set_error("conv_wgrad: workspace too small (%zu < %zu)", workspace_bytes, need_h);
+                return DDK_ERR_WORKSPACE;
+            }
+            WgHaloParams hp{};
+            hp.x = x; hp.dy = dy; hp.slab = static_cast<float*>(workspace);
+            hp.cx = cx; hp.N = N; hp.B = B; hp.H = H; hp.W = W; hp.M = (int)M;
+            hp.splits = hs; hp.chunks_per_split = cps; hp.n_chunks = nch;
+            hp.dH_ = make_fastdiv((unsigned)H); hp.dW_ = make_fastdiv((unsigned)W);
+            int rc;
+            if (wc == 32) rc = launch_wgrad_halo<32>(hp, st);
+            else if (wc == 16) rc = launch_wgrad_halo<16>(hp, st);
+            else if (wc == 8) rc = launch_wgrad_halo<8>(hp, st);
+            else rc = launch_wgrad_halo<4>(hp, st);
+            DDK_TRY(rc);
+            const long long total = (long long)N * 9 * cx;
+            const int blocks = (int)(ceil_div(total, 256) < 2048 ? ceil_div(total, 256) : 2048);
+            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, static_cast<const float*>(workspace), hs, total, grad_w,
+                               N, 9, cx, c_real, cw, c_off, total);
+            return check_launch("wgrad_reduce_kernel");
+        }
+    }
     const WgChoice c = wgrad_choice(N, cx, ntaps, M);
     const size_t need = (size_t)c.splits * N * ntaps * cx * sizeof(float);
     if (workspace_bytes < need) {
@@ -364,7 +571,6 @@ int ddk_conv_wgrad(int kind, const float* x, const float* dy, float* grad_w, int
     p.in_stride = stride; p.tapmode = tapmode; p.ntaps = ntaps;
     p.splits = c.splits; p.rows_per_split = c.rows_per;
     p.dW_ = make_fastdiv((unsigned)Wm); p.dH_ = make_fastdiv((unsigned)Hm);
-    hipStream_t st = as_stream(s);
     const int tn = (int)ceil_div(N, c.bn), tc = (int)ceil_div(cx, c.bc);
     int rc;
 #define WG(BN_, BC_, WN_, WC_) rc = launch_wgrad<BN_, BC_, WN_, WC_>(p, tn, tc, st)

@@ -36,6 +36,8 @@ CONV_BWD = [
     ("s1", 2, 8, 8, 32, 0, 64), ("s1", 4, 16, 16, 128, 0, 128), ("s1", 2, 8, 8, 64, 64, 64), ("s1", 3, 5, 7, 32, 0, 32),
     ("s1", 32, 4, 4, 256, 0, 256), ("s2", 4, 16, 16, 64, 0, 64), ("s2", 2, 8, 8, 128, 0, 128),
     ("1x1", 4, 8, 8, 128, 0, 384), ("1x1", 2, 4, 4, 64, 64, 128), ("T", 4, 4, 4, 64, 0, 64), ("T", 2, 8, 8, 128, 0, 128),
+    # halo weight-gradient kernel (N % 64 == 0, C % 64 == 0): row chunks at W = 32 / 8 (odd batch) / 64 (row segments)
+    ("s1", 2, 32, 32, 64, 0, 64), ("s1", 3, 8, 8, 128, 0, 64), ("s1", 1, 64, 64, 64, 0, 128), ("s1", 6, 4, 4, 64, 64, 128),
 ]
 
 
