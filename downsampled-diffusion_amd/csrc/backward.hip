@@ -772,29 +772,59 @@ __global__ __launch_bounds__(256) void conv1x1_small_n_bwd_kernel(const float* _
 }
 
 // ------------------------------------------------------------------------------------------------
-// Tiny dense helpers for the time-embedding path (B <= a few hundred rows):  C = op(A) op(B), one thread per output.
+// Small dense products of the time-embedding path:  C = op(A) op(B), 32x32 output tile per workgroup, k in chunks of 32
+// through LDS (coalesced loads for every mode), each of the 256 threads owns a 1x4 strip.
 //   mode 0: C[M][N]  = A[M][K]   B[K][N]            mode 1: C[M][N] = A[M][K] B[N][K]^T
 //   mode 2: C[M][N] (+)= A[K][M]^T B[K][N]   (accumulating, for weight gradients)
 __global__ __launch_bounds__(256) void small_gemm_kernel(int mode, const float* __restrict__ A, const float* __restrict__ Bm,
                                                          float* __restrict__ Cm, int M, int N, int K, int lda, int ldb, int ldc,
                                                          int accumulate) {
-    const long long idx = blockIdx.x * 256LL + threadIdx.x;
-    if (idx >= (long long)M * N) return;
-    const int m = (int)(idx / N), n = (int)(idx % N);
-    float s0 = 0.f, s1 = 0.f;
-    int k = 0;
-    if (mode == 0) {
-        for (; k + 1 < K; k += 2) { s0 += A[(long long)m * lda + k] * Bm[(long long)k * ldb + n]; s1 += A[(long long)m * lda + k + 1] * Bm[(long long)(k + 1) * ldb + n]; }
-        if (k < K) s0 += A[(long long)m * lda + k] * Bm[(long long)k * ldb + n];
-    } else if (mode == 1) {
-        for (; k + 1 < K; k += 2) { s0 += A[(long long)m * lda + k] * Bm[(long long)n * ldb + k]; s1 += A[(long long)m * lda + k + 1] * Bm[(long long)n * ldb + k + 1]; }
-        if (k < K) s0 += A[(long long)m * lda + k] * Bm[(long long)n * ldb + k];
-    } else {
-        for (; k + 1 < K; k += 2) { s0 += A[(long long)k * lda + m] * Bm[(long long)k * ldb + n]; s1 += A[(long long)(k + 1) * lda + m] * Bm[(long long)(k + 1) * ldb + n]; }
-        if (k < K) s0 += A[(long long)k * lda + m] * Bm[(long long)k * ldb + n];
+    __shared__ float As[32][33];   // [k][m]
+    __shared__ float Bs[32][33];   // [k][n]
+    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // ty: 0..7
+    const int mrow = threadIdx.x >> 3, nq = (threadIdx.x & 7) * 4;   // output strip: row mrow, columns nq..nq+3
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < K; k0 += 32) {
+        // stage A as [k][m] and B as [k][n]; the fast thread index follows the operand's contiguous dimension
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = ty + r * 8;
+            if (mode == 2) {       // A[K][M]: contiguous in m
+                const int k = k0 + i, m = m0 + tx;
+                As[i][tx] = (k < K && m < M) ? A[(long long)k * lda + m] : 0.f;
+            } else {               // A[M][K]: contiguous in k
+                const int m = m0 + i, k = k0 + tx;
+                As[tx][i] = (k < K && m < M) ? A[(long long)m * lda + k] : 0.f;
+            }
+            if (mode == 1) {       // B[N][K]: contiguous in k
+                const int n = n0 + i, k = k0 + tx;
+                Bs[tx][i] = (k < K && n < N) ? Bm[(long long)n * ldb + k] : 0.f;
+            } else {               // B[K][N]: contiguous in n
+                const int k = k0 + i, n = n0 + tx;
+                Bs[i][tx] = (k < K && n < N) ? Bm[(long long)k * ldb + n] : 0.f;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+            const float a = As[k][mrow];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] += a * Bs[k][nq + j];
+        }
+        __syncthreads();
     }
-    const float r = s0 + s1;
-    Cm[(long long)m * ldc + n] = accumulate ? Cm[(long long)m * ldc + n] + r : r;
+    const int m = m0 + mrow;
+    if (m < M) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + nq + j;
+            if (n < N) {
+                float* c = Cm + (long long)m * ldc + n;
+                *c = accumulate ? *c + acc[j] : acc[j];
+            }
+        }
+    }
 }
 
 // sinusoidal embedding + pre-activations of the time MLP, saved for its backward: e [B][dim], u1 [B][4dim] (pre-Mish), tv [B][dim]
@@ -1114,8 +1144,8 @@ int ddk_conv1x1_small_n_bwd(const float* a, const float* w, const float* dy, flo
 int ddk_small_gemm(int mode, const float* A, const float* Bm, float* Cm, int M, int N, int K, int lda, int ldb, int ldc, int accumulate,
                    ddk_stream_t s) {
     DDK_REQUIRE(A && Bm && Cm && M > 0 && N > 0 && K > 0 && mode >= 0 && mode <= 2, "small_gemm: arguments");
-    hipLaunchKernelGGL(small_gemm_kernel, dim3((unsigned)ceil_div((long long)M * N, 256)), dim3(256), 0, as_stream(s), mode, A, Bm, Cm, M, N,
-                       K, lda, ldb, ldc, accumulate);
+    hipLaunchKernelGGL(small_gemm_kernel, dim3((unsigned)ceil_div(N, 32), (unsigned)ceil_div(M, 32)), dim3(256), 0, as_stream(s), mode, A,
+                       Bm, Cm, M, N, K, lda, ldb, ldc, accumulate);
     return check_launch("small_gemm_kernel");
 }
 int ddk_sincos_embed(const int64_t* t, const float* freqs, float* e, int B, int dim, ddk_stream_t s) {

@@ -335,18 +335,28 @@ __global__ __launch_bounds__(256) void wgrad3x3_halo_kernel(const WgHaloParams p
 }
 
 // grad[(n*cw + c_off + c)*ntaps + tap] += sum_s slab[s][n][tap][c]   (only the first c_real channels: the input may be padded)
+// One workgroup per (n, 32-channel block): the [tap][32 c] rows of every slab are read coalesced and summed in split order,
+// transposed through LDS, and the 32*ntaps consecutive floats of the OIHW gradient are updated coalesced.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, int splits, long long slab_stride,
                                                            float* __restrict__ grad, int N, int ntaps, int cx, int c_real, int cw,
                                                            int c_off, long long total) {
-    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int c = (int)(i % cx);
-        long long r = i / cx;
-        const int tap = (int)(r % ntaps);
-        const int n = (int)(r / ntaps);
-        if (c >= c_real) continue;
-        float s = slab[i];
-        for (int k = 1; k < splits; ++k) s += slab[k * slab_stride + i];
-        grad[((long long)n * cw + c_off + c) * ntaps + tap] += s;
+    __shared__ float t_s[16][33];                       // [tap][c]
+    const int cblocks = cx >> 5;
+    const int n = blockIdx.x / cblocks, cb = blockIdx.x % cblocks;
+    const int c0 = cb * 32;
+    (void)total; (void)N;
+    for (int i = threadIdx.x; i < ntaps * 32; i += 256) {
+        const int tap = i >> 5, c = i & 31;
+        const long long src = ((long long)n * ntaps + tap) * cx + c0 + c;
+        float s = slab[src];
+        for (int k = 1; k < splits; ++k) s += slab[k * slab_stride + src];
+        t_s[tap][c] = s;
+    }
+    __syncthreads();
+    float* g = grad + ((long long)n * cw + c_off + c0) * ntaps;
+    for (int i = threadIdx.x; i < ntaps * 32; i += 256) {
+        const int c = i / ntaps, tap = i - c * ntaps;
+        if (c0 + c < c_real) g[i] += t_s[tap][c];
     }
 }
 
@@ -553,9 +563,8 @@ int ddk_conv_wgrad(int kind, const float* x, const float* dy, float* grad_w, int
             else rc = launch_wgrad_halo<4>(hp, st);
             DDK_TRY(rc);
             const long long total = (long long)N * 9 * cx;
-            const int blocks = (int)(ceil_div(total, 256) < 2048 ? ceil_div(total, 256) : 2048);
-            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, static_cast<const float*>(workspace), hs, total, grad_w,
-                               N, 9, cx, c_real, cw, c_off, total);
+            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(N * (cx / 32))), dim3(256), 0, st, static_cast<const float*>(workspace),
+                               hs, total, grad_w, N, 9, cx, c_real, cw, c_off, total);
             return check_launch("wgrad_reduce_kernel");
         }
     }
@@ -586,9 +595,8 @@ int ddk_conv_wgrad(int kind, const float* x, const float* dy, float* grad_w, int
 #undef WG
     DDK_TRY(rc);
     const long long total = (long long)N * ntaps * cx;
-    const int blocks = (int)(ceil_div(total, 256) < 2048 ? ceil_div(total, 256) : 2048);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, static_cast<const float*>(workspace), c.splits, total, grad_w,
-                       N, ntaps, cx, c_real, cw, c_off, total);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(N * (cx / 32))), dim3(256), 0, st, static_cast<const float*>(workspace),
+                       c.splits, total, grad_w, N, ntaps, cx, c_real, cw, c_off, total);
     return check_launch("wgrad_reduce_kernel");
 }
 
