@@ -348,8 +348,15 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     for (int i = threadIdx.x; i < ntaps * 32; i += 256) {
         const int tap = i >> 5, c = i & 31;
         const long long src = ((long long)n * ntaps + tap) * cx + c0 + c;
-        float s = slab[src];
-        for (int k = 1; k < splits; ++k) s += slab[k * slab_stride + src];
+        // fixed association, four loads in flight: ((s0 + s1) + (s2 + s3)) + ...
+        float s = 0.f;
+        int k = 0;
+        for (; k + 3 < splits; k += 4) {
+            const float a0 = slab[k * slab_stride + src], a1 = slab[(k + 1) * slab_stride + src];
+            const float a2 = slab[(k + 2) * slab_stride + src], a3 = slab[(k + 3) * slab_stride + src];
+            s += (a0 + a1) + (a2 + a3);
+        }
+        for (; k < splits; ++k) s += slab[k * slab_stride + src];
         t_s[tap][c] = s;
     }
     __syncthreads();
@@ -479,7 +486,7 @@ static bool wgrad_halo_plan(int kind, int B, int H, int W, int cx, int N, int& w
     n_chunks = (int)(M / 32);
     if (n_chunks < 128) return false;              // tiny maps: the per-tap kernel's 9x more workgroups win
     const long long tiles = (long long)(N / 64) * (cx / 64);
-    static const int target = getenv("DDK_WGRAD_HALO_WGS") ? atoi(getenv("DDK_WGRAD_HALO_WGS")) : 512;   // tuning knob
+    static const int target = getenv("DDK_WGRAD_HALO_WGS") ? atoi(getenv("DDK_WGRAD_HALO_WGS")) : 256;   // tuning knob (256 and 512 time the same; 256 halves the slabs)
     long long s = ceil_div(target, tiles);
     const long long max_s = n_chunks / 8 > 0 ? n_chunks / 8 : 1;
     if (s > max_s) s = max_s;
