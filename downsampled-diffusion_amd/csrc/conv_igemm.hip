@@ -23,6 +23,26 @@ namespace ddk {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// exact unsigned division by a runtime constant (Granlund-Montgomery): 3 VALU ops instead of the ~30 of a hardware-less
+// integer divide; the prologue of every workgroup does four of them per DMA piece
+struct FastDivU {
+    unsigned mul, sh1, sh2, d;
+};
+static FastDivU make_fastdiv_u(unsigned d) {
+    FastDivU f;
+    f.d = d;
+    unsigned l = 0;
+    while ((1ull << l) < d) ++l;
+    f.mul = (unsigned)(((1ull << 32) * ((1ull << l) - d)) / d + 1);
+    f.sh1 = l < 1 ? l : 1;
+    f.sh2 = l > 0 ? l - 1 : 0;
+    return f;
+}
+__device__ __forceinline__ unsigned fdiv_u(unsigned n, const FastDivU& f) {
+    const unsigned t = __umulhi(f.mul, n);
+    return (t + ((n - t) >> f.sh1)) >> f.sh2;
+}
+
 struct IgemmParams {
     const float* src0;
     const float* src1;
@@ -43,6 +63,8 @@ struct IgemmParams {
     int debug;    // tuning only (DDK_DEBUG): 1 skip in-loop DMA, 2 skip barrier, 4 skip output stores
     int tapmode;  // 0: single tap (1x1); 1: 3x3, (dy,dx) = (tap/3-1, tap%3-1); 2: transpose-conv phase taps (py-a, px-b);
                   // 3: 4x4, (dy,dx) = (tap/4-1, tap%4-1)
+    FastDivU dWm, dHm;   // division by Wm / Hm (pixel index -> (b, y, x))
+    FastDivU dImg, dWp, dRows;   // halo kernel: halo pixels per image, halo row pitch W+2, output rows per image in a tile
 };
 
 // Input offset of a tap: pure scalar arithmetic on wave-uniform values (a lookup table in the kernel
@@ -293,8 +315,11 @@ __device__ __forceinline__ void store_block_via_lds(const IgemmParams& p, f32x16
         if (gm >= p.M) continue;
         long long opix = gm;
         if (p.out_scale != 1) {          // transpose conv: this phase's pixels interleave into the 2x larger output
-            const int xm = gm % p.Wm, tmp = gm / p.Wm;
-            const int ym = tmp % p.Hm, b = tmp / p.Hm;
+            const unsigned tmp = fdiv_u((unsigned)gm, p.dWm);
+            const int xm = gm - (int)tmp * p.Wm;
+            const unsigned bq = fdiv_u(tmp, p.dHm);
+            const int ym = (int)tmp - (int)bq * p.Hm;
+            const long long b = bq;
             opix = ((long long)b * p.Ho + ym * p.out_scale + py) * p.Wo + xm * p.out_scale + px;
         }
         float4 v = *reinterpret_cast<const float4*>(Es + row * PITCH + col4);
@@ -370,16 +395,26 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_dma_kernel(const IgemmParam
     for (int j = 0; j < A_PW; ++j) {
         const int r = (wid * A_PW + j) * 8 + prow;
         const int gm = m0 + r;
-        const int xm = gm % p.Wm, tmp = gm / p.Wm;
-        const int ym = tmp % p.Hm, b = tmp / p.Hm;
+        const unsigned tmp = fdiv_u((unsigned)gm, p.dWm);
+        const int xm = gm - (int)tmp * p.Wm;
+        const unsigned bq = fdiv_u(tmp, p.dHm);
+        const int ym = (int)tmp - (int)bq * p.Hm, b = (int)bq;
         const int iy0 = ym * p.in_stride, ix0 = xm * p.in_stride;
         a_sw[j] = (ppos ^ ((r >> 1) & 7)) * 4;  // float offset of the k-chunk this lane fetches
         a_pix[j] = (b * p.H + iy0) * p.W + ix0;
         unsigned m = 0;
-        for (int t = 0; t < p.ntaps; ++t) {
-            int dy, dx;
-            tap_offset(p.tapmode, phase, t, dy, dx);
-            if ((unsigned)(iy0 + dy) < (unsigned)p.H && (unsigned)(ix0 + dx) < (unsigned)p.W) m |= 1u << t;
+        if (p.tapmode == 1) {            // 3x3: row / column validity separately, 9 ANDs (the common case, kept branch-light)
+            const unsigned vy = ((unsigned)(iy0 - 1) < (unsigned)p.H ? 1u : 0u) | ((unsigned)iy0 < (unsigned)p.H ? 2u : 0u) |
+                                ((unsigned)(iy0 + 1) < (unsigned)p.H ? 4u : 0u);
+            const unsigned vx = ((unsigned)(ix0 - 1) < (unsigned)p.W ? 1u : 0u) | ((unsigned)ix0 < (unsigned)p.W ? 2u : 0u) |
+                                ((unsigned)(ix0 + 1) < (unsigned)p.W ? 4u : 0u);
+            m = ((vy & 1u) ? vx : 0u) | ((vy & 2u) ? vx << 3 : 0u) | ((vy & 4u) ? vx << 6 : 0u);
+        } else {
+            for (int t = 0; t < p.ntaps; ++t) {
+                int dy, dx;
+                tap_offset(p.tapmode, phase, t, dy, dx);
+                if ((unsigned)(iy0 + dy) < (unsigned)p.H && (unsigned)(ix0 + dx) < (unsigned)p.W) m |= 1u << t;
+            }
         }
         a_mask[j] = gm < p.M ? m : 0u;
     }
@@ -616,10 +651,10 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const IgemmParams p) 
             h_pix[j] = 0;
             if (piece * 8 < halo_px) h_live |= 1u << j;           // wave-uniform
             if (hp < halo_px) {
-                const int img = hp / img_px, rem = hp - img * img_px;
-                const int hy = rem / Wp, hx = rem - hy * Wp;
+                const int img = (int)fdiv_u((unsigned)hp, p.dImg), rem = hp - img * img_px;
+                const int hy = (int)fdiv_u((unsigned)rem, p.dWp), hx = rem - hy * Wp;
                 const int row0 = R0 + img * rows_img;           // first output row of this image's part of the tile
-                const int b = row0 / H;
+                const int b = (int)fdiv_u((unsigned)row0, p.dHm);   // Hm == H for this kind
                 const int y = row0 - b * H + hy - 1, x = hx - 1;
                 if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W && b < p.B) {
                     h_pix[j] = (b * H + y) * W + x;
@@ -724,8 +759,8 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const IgemmParams p) 
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int pm = (wm * TM + i) * 32 + (lane & 31);         // pixel inside the tile
-        const int rt = pm / W, x = pm - rt * W;
-        const int img = rt / rows_img, y = rt - img * rows_img;
+        const int rt = (int)fdiv_u((unsigned)pm, p.dWm), x = pm - rt * W;   // Wm == W for this kind
+        const int img = (int)fdiv_u((unsigned)rt, p.dRows), y = rt - img * rows_img;
         a_row[i] = img * img_px + (y + 1) * Wp + x + 1;
     }
     const int bsw = ((lane & 31) >> 1) & 7;
@@ -1128,6 +1163,8 @@ int conv_forward(const ddk_conv_args& a, hipStream_t st) {
     }
     p.post_mish = a.post_mish;
     p.slab_stride = (long long)a.B * g.Ho * g.Wo * a.N;
+    p.dWm = make_fastdiv_u((unsigned)g.Wm);
+    p.dHm = make_fastdiv_u((unsigned)g.Hm);
     p.tapmode = (a.kind == DDK_CONV1X1) ? 0 : (a.kind == DDK_CONVT4X4_S2 ? 2 : (a.kind == DDK_CONV4X4_S2 ? 3 : 1));
     const ConvPlan plan = plan_conv(a.kind, a.B, a.H, a.W, p.cin, p.N, g, a.pre_mish != 0);
     const Choice c = plan.c;
@@ -1143,6 +1180,12 @@ int conv_forward(const ddk_conv_args& a, hipStream_t st) {
     }
     p.splits = c.splits;
     p.kiters_per_split = c.kps;
+    if (plan.halo) {   // tile geometry of conv3x3_halo_kernel, for its exact-division helpers
+        const int TR = 128 / a.W, TB = TR > a.H ? TR / a.H : 1, rows_img = TB > 1 ? a.H : TR;
+        p.dImg = make_fastdiv_u((unsigned)((rows_img + 2) * (a.W + 2)));
+        p.dWp = make_fastdiv_u((unsigned)(a.W + 2));
+        p.dRows = make_fastdiv_u((unsigned)rows_img);
+    }
     float* final_out = a.out;
     if (c.splits > 1) {
         const size_t need = (size_t)c.splits * p.slab_stride * sizeof(float);
