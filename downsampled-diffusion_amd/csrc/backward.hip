@@ -82,7 +82,7 @@ __global__ __launch_bounds__(NT) void gn_train_kernel(const float* __restrict__ 
     for (int i = 0; i < VPT; ++i) {
         const int u = threadIdx.x + i * NT;
         if (u < units) {
-            const int row = u / upr, cu = u - row * upr;
+            const int row = div_upr(u, upr), cu = u - row * upr;
             v[i] = *reinterpret_cast<const float4*>(x + base + (long long)row * C + cu * 4);
             s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
         } else {
@@ -102,7 +102,7 @@ __global__ __launch_bounds__(NT) void gn_train_kernel(const float* __restrict__ 
     }
     const float var = block_sum(q, red) * inv_n;
     const float rstd = 1.0f / sqrtf(var + eps);
-    const int cu_t = threadIdx.x % upr;  // NT % upr == 0: every unit of this thread has the same channel quad
+    const int cu_t = threadIdx.x - div_upr((int)threadIdx.x, upr) * upr;  // NT % upr == 0: every unit of this thread has the same channel quad
     const int c0 = g * cpg + cu_t * 4;
     const float4 ga = *reinterpret_cast<const float4*>(gamma + c0);
     const float4 be = *reinterpret_cast<const float4*>(beta + c0);
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(NT) void gn_train_kernel(const float* __restrict__ 
         for (int i = 0; i < VPT; ++i) {
             const int u = threadIdx.x + i * NT;
             if (u < units) {
-                const int row = u / upr;
+                const int row = div_upr(u, upr);
                 const long long o = base + (long long)row * C + cu_t * 4;
                 float4 y;
                 y.x = mish_f((v[i].x - mean) * rstd * ga.x + be.x) + tb.x;
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(NT) void gn_train_kernel(const float* __restrict__ 
         const int u = threadIdx.x + i * NT;
         du[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (u < units) {
-            const int row = u / upr;
+            const int row = div_upr(u, upr);
             const long long o = base + (long long)row * C + cu_t * 4;
             float4 g1 = *reinterpret_cast<const float4*>(dy + o);
             if (drop_p > 0.f) {
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(NT) void gn_train_kernel(const float* __restrict__ 
     for (int i = 0; i < VPT; ++i) {
         const int u = threadIdx.x + i * NT;
         if (u < units) {
-            const int row = u / upr;
+            const int row = div_upr(u, upr);
             const long long o = base + (long long)row * C + cu_t * 4;
             float4 r;
             r.x = rstd * (du[i].x - m1 - v[i].x * m2);
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(256) void gn_big_bwd_kernel(const float* __restrict
     const long long u0 = sp * per, u1 = (u0 + per < units) ? u0 + per : units;
     const long long base = (long long)b * HW * C + g * cpg;
     const float mean = stat[2 * bg], rstd = stat[2 * bg + 1];
-    const int cu_t = threadIdx.x % upr;
+    const int cu_t = threadIdx.x - div_upr((int)threadIdx.x, upr) * upr;
     const int c0 = g * cpg + cu_t * 4;
     const float4 ga = *reinterpret_cast<const float4*>(gamma + c0);
     const float4 be = *reinterpret_cast<const float4*>(beta + c0);
@@ -299,7 +299,7 @@ __global__ __launch_bounds__(256) void gn_big_bwd_kernel(const float* __restrict
     float4 st = make_float4(0.f, 0.f, 0.f, 0.f), sg = st, sb = st;
     float s1 = 0.f, s2 = 0.f;
     for (long long u = u0 + threadIdx.x; u < u1; u += 256) {
-        const long long row = u / upr;
+        const long long row = div_upr(u, upr);
         const long long o = base + row * C + cu_t * 4;
         const float4 v = *reinterpret_cast<const float4*>(x + o);
         float4 g1 = *reinterpret_cast<const float4*>(dy + o);

@@ -65,6 +65,15 @@ __device__ __forceinline__ float mish_f(float x) {
     return x * (n * __frcp_rn(n + 2.0f));
 }
 
+// u / upr for the float4-units-per-pixel count of a GroupNorm group (1, 2, 4 or 8 in every reference configuration): a
+// shift when upr is a power of two -- the integer divide is ~30 VALU ops and these kernels do it per element, per pass.
+__device__ __forceinline__ int div_upr(int u, int upr) {
+    return (upr & (upr - 1)) == 0 ? u >> (31 - __builtin_clz(upr)) : u / upr;
+}
+__device__ __forceinline__ long long div_upr(long long u, int upr) {
+    return (upr & (upr - 1)) == 0 ? u >> (31 - __builtin_clz(upr)) : u / upr;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -37,7 +37,7 @@ __global__ __launch_bounds__(NT) void gn_mish_resident_kernel(const float* __res
     for (int i = 0; i < VPT; ++i) {
         const int u = threadIdx.x + i * NT;
         if (u < units) {
-            const int row = u / upr, cu = u - row * upr;
+            const int row = div_upr(u, upr), cu = u - row * upr;
             const long long o = base + (long long)row * C + cu * 4;
             float4 a = *reinterpret_cast<const float4*>(x + o);
             for (int k = 1; k < nslab; ++k) {
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(NT) void gn_mish_resident_kernel(const float* __res
     for (int i = 0; i < VPT; ++i) {
         const int u = threadIdx.x + i * NT;
         if (u < units) {
-            const int row = u / upr, cu = u - row * upr;
+            const int row = div_upr(u, upr), cu = u - row * upr;
             const int c0 = g * cpg + cu * 4;
             const float4 ga = *reinterpret_cast<const float4*>(gamma + c0);
             const float4 be = *reinterpret_cast<const float4*>(beta + c0);
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict
     const long long base = (long long)b * HW * C + g * cpg;
     float s = 0.f;
     for (long long u = u0 + threadIdx.x; u < u1; u += 256) {
-        const long long row = u / upr;
+        const long long row = div_upr(u, upr);
         const int cu = (int)(u - row * upr);
         const float4 v = *reinterpret_cast<const float4*>(x + base + row * C + cu * 4);
         s += (v.x + v.y) + (v.z + v.w);
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict
     const float mean = cnt > 0 ? block_sum(s, red) / cnt : 0.f;
     float q = 0.f;
     for (long long u = u0 + threadIdx.x; u < u1; u += 256) {
-        const long long row = u / upr;
+        const long long row = div_upr(u, upr);
         const int cu = (int)(u - row * upr);
         const float4 v = *reinterpret_cast<const float4*>(x + base + row * C + cu * 4);
         const float a = v.x - mean, bb = v.y - mean, c = v.z - mean, d = v.w - mean;
