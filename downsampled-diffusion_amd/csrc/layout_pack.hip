@@ -110,9 +110,61 @@ __global__ __launch_bounds__(256) void conv1x1_small_n_kernel(const float* __res
     }
 }
 
+// n_out <= 8 (the UNet's final projection to the latent / image channels): the whole weight matrix lives in registers
+// (8 x VPL float4 per lane), waves walk the pixels grid-stride -- no weight reload per pixel, x is read exactly once.
+template <int LPP, int VPL>
+__global__ __launch_bounds__(256) void conv1x1_n8_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, float* __restrict__ out, long long M, int C,
+                                                         int n_out) {
+    constexpr int PPW = 64 / LPP;
+    const int lane = threadIdx.x & 63, sub = lane % LPP, pl = lane / LPP;
+    float4 ww[8][VPL];
+    float bb[8];
+#pragma unroll
+    for (int co = 0; co < 8; ++co) {
+        bb[co] = (bias && co < n_out) ? bias[co] : 0.f;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i)
+            ww[co][i] = co < n_out ? *reinterpret_cast<const float4*>(w + (long long)co * C + (sub + i * LPP) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const long long nwaves = (long long)gridDim.x * 4;
+    for (long long wave = blockIdx.x * 4LL + (threadIdx.x >> 6); wave * PPW < M; wave += nwaves) {
+        const long long pix = wave * PPW + pl;
+        const bool ok = pix < M;
+        float4 v[VPL];
+#pragma unroll
+        for (int i = 0; i < VPL; ++i)
+            v[i] = ok ? *reinterpret_cast<const float4*>(x + pix * C + (sub + i * LPP) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float s[8];
+#pragma unroll
+        for (int co = 0; co < 8; ++co) {
+            float t = 0.f;
+#pragma unroll
+            for (int i = 0; i < VPL; ++i) t += (v[i].x * ww[co][i].x + v[i].y * ww[co][i].y) + (v[i].z * ww[co][i].z + v[i].w * ww[co][i].w);
+#pragma unroll
+            for (int o = LPP / 2; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+            s[co] = t + bb[co];
+        }
+        if (ok && sub < n_out) {           // lane `sub` of the pixel's group writes output channel `sub`: n_out consecutive floats
+            float r = s[0];
+#pragma unroll
+            for (int co = 1; co < 8; ++co) r = sub == co ? s[co] : r;
+            out[pix * n_out + sub] = r;
+        }
+    }
+}
+
 int conv1x1_small_n(const float* x, const float* w, const float* bias, float* out, long long M, int C, int n_out, hipStream_t st) {
     DDK_REQUIRE(x && w && out && M > 0 && n_out > 0 && n_out <= 64, "conv1x1_small_n: arguments (n_out <= 64)");
     DDK_REQUIRE(aligned16(x) && aligned16(w), "conv1x1_small_n: alignment");
+    if (n_out <= 8 && (C == 64 || C == 128 || C == 256)) {
+        const long long want = ceil_div(M, 8);
+        const unsigned blocks = (unsigned)(want < 2048 ? want : 2048);
+        if (C == 64) hipLaunchKernelGGL((conv1x1_n8_kernel<16, 1>), dim3(blocks), dim3(256), 0, st, x, w, bias, out, M, C, n_out);
+        else if (C == 128) hipLaunchKernelGGL((conv1x1_n8_kernel<32, 1>), dim3(blocks), dim3(256), 0, st, x, w, bias, out, M, C, n_out);
+        else hipLaunchKernelGGL((conv1x1_n8_kernel<32, 2>), dim3(blocks), dim3(256), 0, st, x, w, bias, out, M, C, n_out);
+        return check_launch("conv1x1_n8_kernel");
+    }
 #define C1_CASE(LPP, VPL)                                                                                                       \
     do {                                                                                                                        \
         const long long waves = ceil_div(M, 64 / LPP);                                                                          \
