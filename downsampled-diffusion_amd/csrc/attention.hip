@@ -108,6 +108,90 @@ __global__ __launch_bounds__(256) void linattn_merge_kernel(const float* __restr
     *reinterpret_cast<float4*>(ctx + ((long long)bh * DH + d) * DH + e0) = acc;
 }
 
+// Small maps (H*W <= 64: the 8x8 and 4x4 levels): context AND apply for one (b, head) in one workgroup -- k, v, q of the head
+// (<= 64 x 32 each) sit in LDS, so the separate apply launch (and its re-read of q) disappears.  Same arithmetic as the two
+// kernels above: column max of k, exp, ctx = (exp k)^T v / den, out = q ctx.
+__global__ __launch_bounds__(256) void linattn_small_kernel(const float* __restrict__ qkv, float* __restrict__ ctx, float* __restrict__ out,
+                                                            int HW, int heads) {
+    __shared__ __attribute__((aligned(16))) float ks[64 * DH];
+    __shared__ __attribute__((aligned(16))) float vs[64 * DH];
+    __shared__ float qs[64 * (DH + 1)];
+    __shared__ float cs[DH * (DH + 4)];
+    __shared__ float smax[8 * DH];
+    const int b = blockIdx.x / heads, h = blockIdx.x % heads;
+    const int HC = heads * DH, RS = 3 * HC;
+    const float* base = qkv + (long long)b * HW * RS + h * DH;
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {                       // 64 rows x 8 float4 per operand
+        const int idx4 = tid + j * 256;
+        const int row = idx4 >> 3, c = (idx4 & 7) * 4;
+        float4 qv = make_float4(0.f, 0.f, 0.f, 0.f), kv = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY), vv = qv;
+        if (row < HW) {
+            const float* r = base + (long long)row * RS + c;
+            qv = *reinterpret_cast<const float4*>(r);
+            kv = *reinterpret_cast<const float4*>(r + HC);
+            vv = *reinterpret_cast<const float4*>(r + 2 * HC);
+        }
+        *reinterpret_cast<float4*>(ks + row * DH + c) = kv;
+        *reinterpret_cast<float4*>(vs + row * DH + c) = vv;
+        qs[row * (DH + 1) + c] = qv.x; qs[row * (DH + 1) + c + 1] = qv.y; qs[row * (DH + 1) + c + 2] = qv.z; qs[row * (DH + 1) + c + 3] = qv.w;
+    }
+    __syncthreads();
+    {   // max_n k[n][d]  (rows >= HW hold -inf)
+        const int d = tid & 31, ng = tid >> 5;
+        float m = -INFINITY;
+        for (int n = ng; n < 64; n += 8) m = fmaxf(m, ks[n * DH + d]);
+        smax[ng * DH + d] = m;
+        __syncthreads();
+        if (tid < DH) {
+            float mm = smax[tid];
+#pragma unroll
+            for (int j = 1; j < 8; ++j) mm = fmaxf(mm, smax[j * DH + tid]);
+            smax[tid] = mm;
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {                       // exp(k - max) in place; padding rows -> exp(-inf) = 0
+        const int i = tid + j * 256;
+        ks[i] = expf(ks[i] - smax[i & 31]);
+    }
+    __syncthreads();
+    {
+        const int d = tid >> 3, e0 = (tid & 7) * 4;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        float den = 0.f;
+#pragma unroll 8
+        for (int n = 0; n < 64; ++n) {
+            const float kd = ks[n * DH + d];
+            const float4 v4 = *reinterpret_cast<const float4*>(vs + n * DH + e0);
+            acc.x += kd * v4.x; acc.y += kd * v4.y; acc.z += kd * v4.z; acc.w += kd * v4.w;
+            den += kd;
+        }
+        const float inv = 1.0f / den;
+        acc.x *= inv; acc.y *= inv; acc.z *= inv; acc.w *= inv;
+        *reinterpret_cast<float4*>(ctx + (((long long)b * heads + h) * DH + d) * DH + e0) = acc;
+        cs[d * (DH + 4) + e0] = acc.x; cs[d * (DH + 4) + e0 + 1] = acc.y; cs[d * (DH + 4) + e0 + 2] = acc.z; cs[d * (DH + 4) + e0 + 3] = acc.w;
+    }
+    __syncthreads();
+    {   // out[n][e] = sum_d ctx[d][e] q[n][d]: thread = (pixel n, 8 consecutive e)
+        const int n = tid >> 2, e0 = (tid & 3) * 8;
+        float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+        for (int d = 0; d < DH; ++d) {
+            const float qd = qs[n * (DH + 1) + d];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] += cs[d * (DH + 4) + e0 + e] * qd;
+        }
+        if (n < HW) {
+            float* op = out + ((long long)b * HW + n) * HC + h * DH + e0;
+            *reinterpret_cast<float4*>(op) = make_float4(o[0], o[1], o[2], o[3]);
+            *reinterpret_cast<float4*>(op + 4) = make_float4(o[4], o[5], o[6], o[7]);
+        }
+    }
+}
+
 // 64 pixels x `heads` threads per workgroup; the sample's ctx (heads x 32 x 32) sits in LDS with a
 // 16-byte skew per head so the `heads` distinct addresses of a wave fall on distinct bank slots.
 __global__ __launch_bounds__(512) void linattn_apply_kernel(const float* __restrict__ qkv, const float* __restrict__ ctx,
@@ -190,6 +274,14 @@ int linattn_context(const float* qkv, float* ctx, int B, int HW, int heads, void
     return DDK_OK;
 }
 
+// context + apply in one launch when the map is small enough for one workgroup per (b, head); returns 0 and does nothing else
+int linattn_fused_small(const float* qkv, float* ctx, float* out, int B, int HW, int heads, hipStream_t st) {
+    DDK_REQUIRE(qkv && ctx && out && B > 0 && HW > 0 && HW <= 64 && heads > 0, "linattn_fused_small: arguments (HW <= 64)");
+    DDK_REQUIRE(aligned16(qkv) && aligned16(ctx) && aligned16(out), "linattn_fused_small: alignment");
+    hipLaunchKernelGGL(linattn_small_kernel, dim3(B * heads), dim3(256), 0, st, qkv, ctx, out, HW, heads);
+    return check_launch("linattn_small_kernel");
+}
+
 int linattn_apply(const float* qkv, const float* ctx, float* out, int B, int HW, int heads, hipStream_t st) {
     DDK_REQUIRE(qkv && ctx && out && B > 0 && HW > 0, "linattn_apply: arguments");
     DDK_REQUIRE(heads >= 1 && heads <= 8, "linattn_apply: heads must be in 1..8");
@@ -206,6 +298,9 @@ extern "C" {
 size_t ddk_linattn_context_workspace_bytes(int B, int HW, int heads) { return ddk::linattn_context_workspace_bytes(B, HW, heads); }
 int ddk_linattn_context(const float* qkv, float* ctx, int B, int HW, int heads, void* workspace, size_t workspace_bytes, ddk_stream_t s) {
     return ddk::linattn_context(qkv, ctx, B, HW, heads, workspace, workspace_bytes, ddk::as_stream(s));
+}
+int ddk_linattn_fused_small(const float* qkv, float* ctx, float* out, int B, int HW, int heads, ddk_stream_t s) {
+    return ddk::linattn_fused_small(qkv, ctx, out, B, HW, heads, ddk::as_stream(s));
 }
 int ddk_linattn_apply(const float* qkv, const float* ctx, float* out, int B, int HW, int heads, ddk_stream_t s) {
     return ddk::linattn_apply(qkv, ctx, out, B, HW, heads, ddk::as_stream(s));

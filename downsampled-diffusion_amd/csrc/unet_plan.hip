@@ -406,8 +406,12 @@ static int run_attn(Ctx& c, const AttnW& a, const float* x, float* out, int H, i
     const long long M = (long long)c.B * H * W;
     DDK_TRY(chan_layernorm(x, c.P + a.ln.g, c.P + a.ln.b, xn, M, a.c, LN_EPS, c.st));
     DDK_TRY(run_conv(c, DDK_CONV1X1, a.qkv, xn, a.c, nullptr, 0, nullptr, qkv, H, W, 3 * HIDDEN));
-    DDK_TRY(linattn_context(qkv, ctx, c.B, H * W, HEADS, c.W + c.ly.off_splitk, c.ly.splitk * sizeof(float), c.st));
-    DDK_TRY(linattn_apply(qkv, ctx, o, c.B, H * W, HEADS, c.st));
+    if (H * W <= 64) {
+        DDK_TRY(linattn_fused_small(qkv, ctx, o, c.B, H * W, HEADS, c.st));
+    } else {
+        DDK_TRY(linattn_context(qkv, ctx, c.B, H * W, HEADS, c.W + c.ly.off_splitk, c.ly.splitk * sizeof(float), c.st));
+        DDK_TRY(linattn_apply(qkv, ctx, o, c.B, H * W, HEADS, c.st));
+    }
     return run_conv(c, DDK_CONV1X1, a.out, o, HIDDEN, nullptr, 0, x, out, H, W, a.c);
 }
 

@@ -69,6 +69,7 @@ SIGNATURES = {
     "ddk_linattn_context_workspace_bytes": (_SZ, [_I, _I, _I]),
     "ddk_linattn_context": (_I, [_P, _P, _I, _I, _I, _P, _SZ, _P]),
     "ddk_linattn_apply": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "ddk_linattn_fused_small": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "ddk_time_mlp": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "ddk_time_proj": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "ddk_conv1x1_small_n": (_I, [_P, _P, _P, _P, _LL, _I, _I, _P]),

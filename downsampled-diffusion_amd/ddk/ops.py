@@ -208,6 +208,9 @@ def linattn(qkv, heads=4):
     ctx = torch.empty((b, heads, 32, 32), device=qkv.device, dtype=torch.float32)
     out = torch.empty((b, h, w, c3 // 3), device=qkv.device, dtype=torch.float32)
     lib = L.load()
+    if h * w <= 64:       # small maps: context + apply in one launch
+        L.check(lib.ddk_linattn_fused_small(L.ptr(_f32(qkv)), L.ptr(ctx), L.ptr(out), b, h * w, heads, L.stream()), "linattn_fused_small")
+        return out, ctx
     nbytes = lib.ddk_linattn_context_workspace_bytes(b, h * w, heads)
     ws = torch.empty(nbytes // 4, device=qkv.device, dtype=torch.float32) if nbytes else None
     L.check(lib.ddk_linattn_context(L.ptr(_f32(qkv)), L.ptr(ctx), b, h * w, heads, L.ptr(ws), nbytes, L.stream()), "linattn_context")

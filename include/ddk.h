@@ -120,6 +120,8 @@ int ddk_add(const float* a, const float* b, float* out, long long n, ddk_stream_
    (partials merged in split order: deterministic); workspace == NULL runs one workgroup per (b, head). */
 size_t ddk_linattn_context_workspace_bytes(int B, int HW, int heads);
 int ddk_linattn_context(const float* qkv, float* ctx, int B, int HW, int heads, void* workspace, size_t workspace_bytes, ddk_stream_t s);
+/* Both steps in one launch for maps with HW <= 64 (also writes ctx, which the backward needs). */
+int ddk_linattn_fused_small(const float* qkv, float* ctx, float* out, int B, int HW, int heads, ddk_stream_t s);
 /* out[b][n][h*32+e] = sum_d ctx[b][h][d][e] * q[b][n][h*32+d]. */
 int ddk_linattn_apply(const float* qkv, const float* ctx, float* out, int B, int HW, int heads, ddk_stream_t s);
 
