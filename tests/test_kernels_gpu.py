@@ -44,6 +44,9 @@ CONV_CASES = [
     ("s1", 64, 16, 16, 128, 0, 160),     # ragged N tile
     ("s1", 52, 8, 32, 256, 0, 128),      # 4-row tiles, two tiles per image
     ("s1", 32, 32, 32, 160, 0, 128),     # odd chunk count (5): halo double-buffer parity
+    # 32 -> 32 channel resampler convs (128x32 im2col tile) at the decoder's resolutions
+    ("s1", 32, 16, 16, 32, 0, 32), ("s1", 9, 32, 32, 32, 0, 32), ("s1", 3, 64, 64, 32, 0, 32), ("s1", 1, 128, 128, 32, 0, 32),
+    ("s1", 1, 40, 256, 32, 0, 32),
     ("s2", 4, 16, 16, 64, 0, 64),
     ("s2", 32, 32, 32, 128, 0, 128),
     ("s2", 2, 7, 9, 32, 0, 32),          # odd spatial size
