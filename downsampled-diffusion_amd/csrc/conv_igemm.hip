@@ -63,6 +63,12 @@ struct IgemmParams {
     int debug;    // tuning only (DDK_DEBUG): 1 skip in-loop DMA, 2 skip barrier, 4 skip output stores
     int tapmode;  // 0: single tap (1x1); 1: 3x3, (dy,dx) = (tap/3-1, tap%3-1); 2: transpose-conv phase taps (py-a, px-b);
                   // 3: 4x4, (dy,dx) = (tap/4-1, tap%4-1)
+    // Channel LayerNorm folded into a 1x1 conv (blocks.py:57-60 feeding to_qkv): with r = 1/(std + eps), W.LN(x) =
+    // r (W o g) x - r mean (W g) + W b.  The weight passed in is already W o g; ln_c1 = W g, ln_c2 = W b (per output
+    // channel); mean and r of every pixel row are accumulated from the staged A tile while it is multiplied.
+    const float* ln_c1;  // nullptr: no LayerNorm folding
+    const float* ln_c2;
+    float ln_eps;
     FastDivU dWm, dHm;   // division by Wm / Hm (pixel index -> (b, y, x))
     FastDivU dImg, dWp, dRows;   // halo kernel: halo pixels per image, halo row pitch W+2, output rows per image in a tile
 };
@@ -284,7 +290,7 @@ __device__ __forceinline__ void lds_dma16(const float* g, unsigned lds_byte_addr
 // `Es` is this wave's private staging area; the caller has made sure no wave still reads the LDS it overlays.
 template <int TM, int TN>
 __device__ __forceinline__ void store_block_via_lds(const IgemmParams& p, f32x16 (&acc)[TM][TN], float* Es, int lane, int m_base,
-                                                    int n_base, int split, int phase) {
+                                                    int n_base, int split, int phase, const float* rowstat = nullptr) {
     constexpr int PITCH = TN * 32 + 8;
     constexpr int LPR = TN * 8;          // lanes per row (one float4 each)
     constexpr int RPP = 64 / LPR;        // rows per pass
@@ -307,6 +313,8 @@ __device__ __forceinline__ void store_block_via_lds(const IgemmParams& p, f32x16
     if (gn >= p.N) return;               // N % 32 == 0: a float4 is all-or-nothing
     float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (direct && p.bias) bias4 = *reinterpret_cast<const float4*>(p.bias + gn);
+    float4 lc1 = make_float4(0.f, 0.f, 0.f, 0.f), lc2 = lc1;
+    if (rowstat) { lc1 = *reinterpret_cast<const float4*>(p.ln_c1 + gn); lc2 = *reinterpret_cast<const float4*>(p.ln_c2 + gn); }
     const int py = phase >> 1, px = phase & 1;
 #pragma unroll 4
     for (int pass = 0; pass < TM * 32 / RPP; ++pass) {
@@ -323,6 +331,11 @@ __device__ __forceinline__ void store_block_via_lds(const IgemmParams& p, f32x16
             opix = ((long long)b * p.Ho + ym * p.out_scale + py) * p.Wo + xm * p.out_scale + px;
         }
         float4 v = *reinterpret_cast<const float4*>(Es + row * PITCH + col4);
+        if (rowstat) {                   // folded LayerNorm: rowstat[row] = (r, r * mean) of this pixel
+            const float r = rowstat[2 * row], rm = rowstat[2 * row + 1];
+            v.x = r * v.x - rm * lc1.x + lc2.x; v.y = r * v.y - rm * lc1.y + lc2.y;
+            v.z = r * v.z - rm * lc1.z + lc2.z; v.w = r * v.w - rm * lc1.w + lc2.w;
+        }
         v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
         const long long o = opix * p.N + gn;
         if (direct && p.resid) {
@@ -341,8 +354,9 @@ __device__ __forceinline__ void store_block_via_lds(const IgemmParams& p, f32x16
 __device__ __forceinline__ void consume_epilogue_args(const IgemmParams& p) {
     const long long ss = p.slab_stride;
     const int sp = p.splits, pm = p.post_mish, MM = p.M, NN = p.N, os = p.out_scale, wm = p.Wm, hm = p.Hm, ho = p.Ho, wo = p.Wo;
+    const int le = __float_as_int(p.ln_eps);
     asm volatile("" ::"s"(ss), "s"(sp), "s"(pm), "s"(MM), "s"(NN), "s"(os), "s"(wm), "s"(hm), "s"(ho), "s"(wo), "s"(p.out), "s"(p.bias),
-                 "s"(p.resid));
+                 "s"(p.resid), "s"(p.ln_c1), "s"(p.ln_c2), "s"(le));
 }
 
 // im2col implicit GEMM, all waves load and multiply (every conv kind; the 3x3 stride-1 layers with enough pixels use the
@@ -475,6 +489,8 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_dma_kernel(const IgemmParam
     const int b_base = BM * 32 + wn * TN * 32 * 32;
 
     const int n_it = (dbg & 8) ? 0 : it_end - it_begin;
+    const bool ln_fold = p.ln_c1 != nullptr;
+    float ln_s = 0.f, ln_q = 0.f;
     if (n_it > 0) issue_chunk(0);
     unsigned long long t0 = 0, r0 = 0;
     if (dbg & 32) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
@@ -496,6 +512,16 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_dma_kernel(const IgemmParam
         if (dbg & 64) tb = stamp();
         if (k + 1 < n_it && !(dbg & 1)) issue_chunk(stage ^ 1);
         if (dbg & 64) tc = stamp();
+        if (ln_fold) {   // per-row sum / sum of squares of the staged A chunk (the swizzle only permutes a row's floats)
+            constexpr int TPR = NW * 64 / BM, F4 = 8 / TPR;      // threads per row, float4 per thread
+            const float4* rowp = reinterpret_cast<const float4*>(smem + stage * STAGE + (tid / TPR) * 32) + (tid % TPR) * F4;
+#pragma unroll
+            for (int i = 0; i < F4; ++i) {
+                const float4 v = rowp[i];
+                ln_s += (v.x + v.y) + (v.z + v.w);
+                ln_q += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+            }
+        }
         const float* As = smem + stage * STAGE + a_base;
         const float* Bs = smem + stage * STAGE + b_base;
         float4 a[2][TM], b[2][TN];
@@ -555,7 +581,24 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_dma_kernel(const IgemmParam
 
     __syncthreads();   // every wave is done reading the ring: its LDS now stages the output block
     constexpr int EPI_FLOATS = TM * 32 * (TN * 32 + 8);
-    store_block_via_lds<TM, TN>(p, acc, smem + wid * EPI_FLOATS, lane, m0 + wm * TM * 32, n0 + wn * TN * 32, split, phase);
+    float* rowstat = nullptr;
+    if (ln_fold) {     // mean and 1/(std + eps) per pixel row (blocks.py:57-60: biased variance, eps added to the std)
+        constexpr int TPR = NW * 64 / BM;
+#pragma unroll
+        for (int o = 1; o < TPR; o <<= 1) { ln_s += __shfl_xor(ln_s, o, 64); ln_q += __shfl_xor(ln_q, o, 64); }
+        rowstat = smem + NW * EPI_FLOATS;            // behind the staging areas (the launch sizes the LDS for it)
+        if (tid % TPR == 0) {
+            const float inv_c = 1.0f / (float)p.cin;
+            const float mean = ln_s * inv_c;
+            const float var = fmaxf(ln_q * inv_c - mean * mean, 0.f);
+            const float r = 1.0f / (sqrtf(var) + p.ln_eps);
+            rowstat[2 * (tid / TPR)] = r;
+            rowstat[2 * (tid / TPR) + 1] = r * mean;
+        }
+        __syncthreads();
+    }
+    store_block_via_lds<TM, TN>(p, acc, smem + wid * EPI_FLOATS, lane, m0 + wm * TM * 32, n0 + wn * TN * 32, split, phase,
+                                rowstat ? rowstat + 2 * wm * TM * 32 : nullptr);
     if ((dbg & 32) && tid == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const int wg = (blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) & 2047;
@@ -1099,7 +1142,7 @@ static int launch_tile(const IgemmParams& p, hipStream_t st) {
     if (!p.pre_mish && !no_dma) {
         constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
         constexpr size_t ring = 2 * (size_t)(BM + BN) * 32 * sizeof(float);
-        constexpr size_t epi = (size_t)WM * WN * TM * 32 * (TN * 32 + 8) * sizeof(float);
+        constexpr size_t epi = ((size_t)WM * WN * TM * 32 * (TN * 32 + 8) + 2 * BM) * sizeof(float);   // staging + folded-LN row stats
         constexpr size_t lds = ring > epi ? ring : epi;
         static bool attr_set = false;
         if (!attr_set) {
@@ -1132,7 +1175,15 @@ size_t conv_workspace_bytes(int kind, int B, int H, int W, int cin, int N) {
     return (size_t)c.splits * B * g.Ho * g.Wo * N * sizeof(float);
 }
 
-int conv_forward(const ddk_conv_args& a, hipStream_t st) {
+bool conv_ln_fold_ok(int B, int H, int W, int cin, int N) {
+    static const bool off = getenv("DDK_NO_LN_FOLD") != nullptr;   // A/B knob
+    Geometry g;
+    if (off || !conv_geometry(DDK_CONV1X1, H, W, g) || cin <= 0 || cin % 32 || N % 32) return false;
+    const Choice c = choose_tile((long long)B * H * W, N, 1, cin / 32);
+    return c.splits == 1 && (c.tile == T64x64 || c.tile == T128x64 || c.tile == T128x128);
+}
+
+int conv_forward(const ddk_conv_args& a, hipStream_t st, const ConvLnFold* ln) {
     Geometry g;
     DDK_REQUIRE(conv_geometry(a.kind, a.H, a.W, g), "conv kind");
     DDK_REQUIRE(a.src0 && a.weight && a.out, "conv: null src0/weight/out");
@@ -1180,6 +1231,13 @@ int conv_forward(const ddk_conv_args& a, hipStream_t st) {
     }
     p.splits = c.splits;
     p.kiters_per_split = c.kps;
+    if (ln) {
+        DDK_REQUIRE(a.kind == DDK_CONV1X1 && !plan.halo && c.splits == 1 && a.c1 == 0 && !a.pre_mish &&
+                        (c.tile == T64x64 || c.tile == T128x64 || c.tile == T128x128),
+                    "conv: LayerNorm folding needs an unsplit single-source 1x1 conv on a 4-wave tile (conv_ln_fold_ok)");
+        DDK_REQUIRE(ln->c1 && ln->c2 && aligned16(ln->c1) && aligned16(ln->c2), "conv: LayerNorm folding vectors");
+        p.ln_c1 = ln->c1; p.ln_c2 = ln->c2; p.ln_eps = ln->eps;
+    }
     if (plan.halo) {   // tile geometry of conv3x3_halo_kernel, for its exact-division helpers
         const int TR = 128 / a.W, TB = TR > a.H ? TR / a.H : 1, rows_img = TB > 1 ? a.H : TR;
         p.dImg = make_fastdiv_u((unsigned)((rows_img + 2) * (a.W + 2)));

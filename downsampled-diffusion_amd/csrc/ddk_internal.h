@@ -113,7 +113,15 @@ __device__ __forceinline__ float block_max(float v, float* red) {
 // ---- internal launchers used by the UNet plan (same arithmetic as the public entry points) ----
 // conv_igemm.hip
 size_t conv_workspace_bytes(int kind, int B, int H, int W, int cin, int N);
-int conv_forward(const ddk_conv_args& a, hipStream_t st);
+// Channel LayerNorm folded into a 1x1 conv: a.weight must hold W o g (per input channel), c1 = W g, c2 = W b per output
+// channel.  Only valid when conv_ln_fold_ok() says so for the shape.
+struct ConvLnFold {
+    const float* c1;
+    const float* c2;
+    float eps;
+};
+bool conv_ln_fold_ok(int B, int H, int W, int cin, int N);
+int conv_forward(const ddk_conv_args& a, hipStream_t st, const ConvLnFold* ln = nullptr);
 int conv_splits(int kind, int B, int H, int W, int cin, int N);
 double conv_flops(int kind, int B, int H, int W, int cin, int N);
 // norm_act.hip

@@ -49,6 +49,8 @@ struct AttnW {
     int c = 0;
     NormW ln;
     ConvW qkv, out;
+    // LayerNorm folded into to_qkv (derived at pack time by ddk_unet_finalize_pack): W o g, W g, W b
+    size_t qkv_lnw = 0, ln_c1 = 0, ln_c2 = 0;
 };
 
 }  // namespace ddk
@@ -130,6 +132,9 @@ struct ddk_unet {
         a.qkv = add_conv(p + "fn.fn.to_qkv.", 3 * HIDDEN, c, 1, false);
         a.out = add_conv(p + "fn.fn.to_out.", c, HIDDEN, 1, true);
         a.ln = add_norm(p + "fn.norm.g", p + "fn.norm.b", c);
+        a.qkv_lnw = alloc((size_t)3 * HIDDEN * pad32(c));
+        a.ln_c1 = alloc((size_t)3 * HIDDEN);
+        a.ln_c2 = alloc((size_t)3 * HIDDEN);
         return a;
     }
 };
@@ -217,6 +222,38 @@ extern "C" long long ddk_unet_slot_numel(const ddk_unet* u, int slot) {
     return (u && slot >= 0 && slot < (int)u->slots.size()) ? u->slots[slot].numel : -1;
 }
 extern "C" size_t ddk_unet_packed_bytes(const ddk_unet* u) { return u ? u->packed_floats * sizeof(float) : 0; }
+
+// w[n][c] (packed 1x1 weight, row pitch cp) -> wg[n][c] = w*g[c], c1[n] = sum_c w*g, c2[n] = sum_c w*b   (one wave per n)
+__global__ __launch_bounds__(64) void ln_fold_kernel(const float* __restrict__ w, const float* __restrict__ g, const float* __restrict__ b,
+                                                     float* __restrict__ wg, float* __restrict__ c1, float* __restrict__ c2, int C, int cp) {
+    const int n = blockIdx.x;
+    float s1 = 0.f, s2 = 0.f;
+    for (int c = threadIdx.x; c < cp; c += 64) {
+        const float wv = w[(long long)n * cp + c];
+        const float gv = c < C ? g[c] : 0.f, bv = c < C ? b[c] : 0.f;
+        wg[(long long)n * cp + c] = wv * gv;
+        s1 += wv * gv;
+        s2 += wv * bv;
+    }
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    if (threadIdx.x == 0) { c1[n] = s1; c2[n] = s2; }
+}
+
+// Derived weights: call once after every slot of `packed` has been (re)packed.
+extern "C" int ddk_unet_finalize_pack(const ddk_unet* u, void* packed, ddk_stream_t s) {
+    DDK_REQUIRE(u && packed, "unet_finalize_pack: arguments");
+    float* P = static_cast<float*>(packed);
+    auto fold = [&](const AttnW& a) -> int {
+        hipLaunchKernelGGL(ln_fold_kernel, dim3(3 * HIDDEN), dim3(64), 0, as_stream(s), P + a.qkv.w, P + a.ln.g, P + a.ln.b, P + a.qkv_lnw,
+                           P + a.ln_c1, P + a.ln_c2, a.c, pad32(a.c));
+        return check_launch("ln_fold_kernel");
+    };
+    for (const AttnW& a : u->down_attn) DDK_TRY(fold(a));
+    DDK_TRY(fold(u->mid_attn));
+    for (const AttnW& a : u->up_attn) DDK_TRY(fold(a));
+    return DDK_OK;
+}
 
 extern "C" int ddk_unet_pack_slot(const ddk_unet* u, int slot, const float* canonical, void* packed, ddk_stream_t s) {
     DDK_REQUIRE(u && canonical && packed && slot >= 0 && slot < (int)u->slots.size(), "unet_pack_slot: arguments");
@@ -334,11 +371,11 @@ struct Ctx {
 };
 
 static int run_conv(Ctx& c, int kind, const ConvW& cw, const float* src0, int c0, const float* src1, int c1, const float* resid,
-                    float* out, int H, int W, int N) {
+                    float* out, int H, int W, int N, const float* weight_override = nullptr, const ConvLnFold* ln = nullptr) {
     ddk_conv_args a{};
     a.kind = kind;
     a.src0 = src0; a.src1 = src1; a.c0 = c0; a.c1 = c1;
-    a.weight = c.P + cw.w;
+    a.weight = weight_override ? weight_override : c.P + cw.w;
     a.bias = cw.has_bias ? c.P + cw.b : nullptr;
     a.resid = resid;
     a.out = out;
@@ -348,7 +385,7 @@ static int run_conv(Ctx& c, int kind, const ConvW& cw, const float* src0, int c0
     a.defer_reduce = 0;
     a.workspace = c.W + c.ly.off_splitk;
     a.workspace_bytes = c.ly.splitk * sizeof(float);
-    return conv_forward(a, c.st);
+    return conv_forward(a, c.st, ln);
 }
 
 // conv3x3 -> GroupNorm+Mish(+shift)(+residual).  When the conv splits k, its slabs stay in the workspace and the
@@ -404,8 +441,14 @@ static int run_attn(Ctx& c, const AttnW& a, const float* x, float* out, int H, i
     float* ctx = c.W + c.ly.off_ctx;
     float* o = c.W + c.ly.off_o;
     const long long M = (long long)c.B * H * W;
-    DDK_TRY(chan_layernorm(x, c.P + a.ln.g, c.P + a.ln.b, xn, M, a.c, LN_EPS, c.st));
-    DDK_TRY(run_conv(c, DDK_CONV1X1, a.qkv, xn, a.c, nullptr, 0, nullptr, qkv, H, W, 3 * HIDDEN));
+    if (conv_ln_fold_ok(c.B, H, W, a.c, 3 * HIDDEN)) {
+        // LayerNorm folded into the projection: no LayerNorm launch, no normalised copy of x
+        const ConvLnFold ln{c.P + a.ln_c1, c.P + a.ln_c2, LN_EPS};
+        DDK_TRY(run_conv(c, DDK_CONV1X1, a.qkv, x, a.c, nullptr, 0, nullptr, qkv, H, W, 3 * HIDDEN, c.P + a.qkv_lnw, &ln));
+    } else {
+        DDK_TRY(chan_layernorm(x, c.P + a.ln.g, c.P + a.ln.b, xn, M, a.c, LN_EPS, c.st));
+        DDK_TRY(run_conv(c, DDK_CONV1X1, a.qkv, xn, a.c, nullptr, 0, nullptr, qkv, H, W, 3 * HIDDEN));
+    }
     if (H * W <= 64) {
         DDK_TRY(linattn_fused_small(qkv, ctx, o, c.B, H * W, HEADS, c.st));
     } else {

@@ -85,6 +85,7 @@ SIGNATURES = {
     "ddk_unet_slot_numel": (_LL, [_P, _I]),
     "ddk_unet_packed_bytes": (_SZ, [_P]),
     "ddk_unet_pack_slot": (_I, [_P, _I, _P, _P, _P]),
+    "ddk_unet_finalize_pack": (_I, [_P, _P, _P]),
     "ddk_unet_workspace_bytes": (_SZ, [_P, _I, _I, _I]),
     "ddk_unet_forward": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P, _SZ, _P]),
     "ddk_unet_flops": (C.c_double, [_P, _I, _I, _I]),
