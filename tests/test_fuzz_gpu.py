@@ -1,0 +1,88 @@
+"""Seeded shape fuzz of the conv family (forward, input gradient, weight gradient) against torch-CPU: odd spatial sizes,
+batch sizes that leave ragged tiles, channel counts on both sides of every kernel-selection threshold (halo kernel,
+split-K, halo weight gradient, small-N tiles).  One process, ~70 cases, each a few MFLOP to a few GFLOP."""
+import random
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import rel_err, to_nchw, to_nhwc
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _rnd(*shape, seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g)
+
+
+def _cases(n, seed):
+    rng = random.Random(seed)
+    out = []
+    for i in range(n):
+        kind = rng.choice(["s1", "s1", "s1", "s2", "1x1", "T"])
+        c0 = rng.choice([32, 64, 96, 128, 256])
+        c1 = rng.choice([0, 0, 0, 32, 128]) if kind in ("s1", "1x1") else 0
+        n_out = rng.choice([32, 64, 128, 160, 256, 384])
+        hw = rng.choice([(4, 4), (8, 8), (16, 16), (32, 32), (5, 7), (12, 20), (8, 32), (16, 8), (64, 64), (3, 3), (24, 24)])
+        b = rng.choice([1, 2, 3, 5, 8, 17, 32])
+        if kind == "T":
+            n_out = c0 = rng.choice([32, 64, 128])
+        # keep the CPU reference cheap
+        while b * hw[0] * hw[1] * (c0 + c1) * n_out * (9 if kind in ("s1", "s2") else 16 if kind == "T" else 1) > 6e9 and b > 1:
+            b = max(1, b // 2)
+        out.append((kind, b, hw[0], hw[1], c0, c1, n_out, 1000 + i))
+    return out
+
+
+@pytest.mark.parametrize("kind,B,H,W,c0,c1,N,seed", _cases(48, 20260901))
+def test_conv_forward_fuzz(kind, B, H, W, c0, c1, N, seed):
+    from ddk import ops
+    cin = c0 + c1
+    x = _rnd(B, cin, H, W, seed=seed)
+    k = {"s1": 3, "s2": 3, "1x1": 1, "T": 4}[kind]
+    bias = _rnd(N, seed=seed + 1) * 0.1
+    if kind == "T":
+        w = _rnd(cin, N, 4, 4, seed=seed + 2) * (cin * 4) ** -0.5
+        ref = F.conv_transpose2d(x, w, bias, stride=2, padding=1)
+        wp, code = ops.pack_convT_weight(w.to(DEV)), ops.CONVT4X4_S2
+    else:
+        w = _rnd(N, cin, k, k, seed=seed + 2) * (cin * k * k) ** -0.5
+        ref = F.conv2d(x, w, bias, stride=2 if kind == "s2" else 1, padding=k // 2)
+        wp = ops.pack_conv_weight(w.to(DEV))
+        code = {"s1": ops.CONV3X3_S1, "s2": ops.CONV3X3_S2, "1x1": ops.CONV1X1}[kind]
+    xh = to_nhwc(x).to(DEV)
+    x0 = xh[..., :c0].contiguous()
+    x1 = xh[..., c0:].contiguous() if c1 else None
+    resid = _rnd(*ref.shape, seed=seed + 3)
+    out = ops.conv(code, x0, wp, bias.to(DEV), x2=x1, resid=to_nhwc(resid).to(DEV), post_mish=bool(seed & 1))
+    want = ref + resid
+    if seed & 1:
+        want = want * torch.tanh(F.softplus(want))
+    assert rel_err(to_nchw(out.cpu()), want) < 3e-5
+
+
+@pytest.mark.parametrize("kind,B,H,W,c0,c1,N,seed", [c for c in _cases(40, 777) if c[0] in ("s1", "s2", "1x1")][:22])
+def test_conv_backward_fuzz(kind, B, H, W, c0, c1, N, seed):
+    from ddk import autograd as AG, ops
+    cin = c0 + c1
+    k = 1 if kind == "1x1" else 3
+    x = _rnd(B, cin, H, W, seed=seed).requires_grad_(True)
+    w = (_rnd(N, cin, k, k, seed=seed + 2) * (cin * k * k) ** -0.5).requires_grad_(True)
+    b = (_rnd(N, seed=seed + 1) * 0.1).requires_grad_(True)
+    ref = F.conv2d(x, w, b, stride=2 if kind == "s2" else 1, padding=k // 2)
+    go = _rnd(*ref.shape, seed=seed + 5)
+    gx, gw, gb = torch.autograd.grad(ref, (x, w, b), go)
+    code = {"s1": ops.CONV3X3_S1, "s2": ops.CONV3X3_S2, "1x1": ops.CONV1X1}[kind]
+    xh = to_nhwc(x.detach()).to(DEV)
+    x0 = xh[..., :c0].contiguous().requires_grad_(True)
+    x1 = xh[..., c0:].contiguous().requires_grad_(True) if c1 else None
+    wd, bd = w.detach().to(DEV).requires_grad_(True), b.detach().to(DEV).requires_grad_(True)
+    out = AG.conv(code, x0, wd, bd, x2=x1)
+    out.backward(to_nhwc(go).to(DEV))
+    got_gx = x0.grad.cpu() if x1 is None else torch.cat([x0.grad.cpu(), x1.grad.cpu()], dim=-1)
+    assert rel_err(to_nchw(out.detach().cpu()), ref.detach()) < 3e-5
+    assert rel_err(got_gx, to_nhwc(gx)) < 5e-5
+    assert rel_err(wd.grad.cpu(), gw) < 5e-5 and rel_err(bd.grad.cpu(), gb) < 5e-5
