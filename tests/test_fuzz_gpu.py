@@ -86,3 +86,56 @@ def test_conv_backward_fuzz(kind, B, H, W, c0, c1, N, seed):
     assert rel_err(to_nchw(out.detach().cpu()), ref.detach()) < 3e-5
     assert rel_err(got_gx, to_nhwc(gx)) < 5e-5
     assert rel_err(wd.grad.cpu(), gw) < 5e-5 and rel_err(bd.grad.cpu(), gb) < 5e-5
+
+
+def _norm_cases(n, seed):
+    rng = random.Random(seed)
+    out = []
+    for i in range(n):
+        c = rng.choice([32, 64, 128, 256])
+        hw = rng.choice([(4, 4), (8, 8), (16, 16), (32, 32), (5, 7), (48, 40), (64, 64), (96, 80), (3, 11)])
+        b = rng.choice([1, 2, 3, 6])
+        out.append((b, hw[0], hw[1], c, 3000 + i))
+    return out
+
+
+@pytest.mark.parametrize("B,H,W,C,seed", _norm_cases(14, 4242))
+def test_groupnorm_layernorm_attention_fuzz(B, H, W, C, seed):
+    """GroupNorm+Mish (register-resident and multi-workgroup statistics), its train-mode forward / backward, channel
+    LayerNorm and the linear-attention core (single workgroup, pixel-range splits, one-launch small maps) on the same shape."""
+    from ddk import autograd as AG, ops
+    from oracle import unet_ref as U
+    x = _rnd(B, C, H, W, seed=seed) * 1.7 + 0.4
+    g, b = 1 + 0.1 * _rnd(C, seed=seed + 1), 0.1 * _rnd(C, seed=seed + 2)
+    temb, add = _rnd(B, C, seed=seed + 3), _rnd(B, C, H, W, seed=seed + 4)
+    f = lambda xx, gg, bb, tt, aa: U.mish(F.group_norm(xx, 8, gg, bb, 1e-5)) + tt[:, :, None, None] + aa
+    leaves = [t.clone().requires_grad_(True) for t in (x, g, b, temb, add)]
+    ref = f(*leaves)
+    go = _rnd(*ref.shape, seed=seed + 5)
+    grads = torch.autograd.grad(ref, leaves, go)
+    xh = to_nhwc(x).to(DEV)
+    out = ops.groupnorm_mish(xh, g.to(DEV), b.to(DEV), temb=temb.to(DEV), addend=to_nhwc(add).to(DEV))
+    assert rel_err(to_nchw(out.cpu()), ref.detach()) < 1e-5
+    xd = xh.clone().requires_grad_(True)
+    gd, bd = g.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+    td, ad = temb.to(DEV).requires_grad_(True), to_nhwc(add).to(DEV).requires_grad_(True)
+    out_t = AG.groupnorm_mish(xd, gd, bd, temb=td, addend=ad)
+    assert rel_err(to_nchw(out_t.detach().cpu()), ref.detach()) < 1e-5
+    out_t.backward(to_nhwc(go).to(DEV))
+    assert rel_err(xd.grad.cpu(), to_nhwc(grads[0])) < 5e-5
+    assert rel_err(gd.grad.cpu(), grads[1]) < 5e-5 and rel_err(bd.grad.cpu(), grads[2]) < 5e-5
+    assert rel_err(td.grad.cpu(), grads[3]) < 5e-5
+    # channel LayerNorm
+    lg, lb = (1 + 0.1 * _rnd(1, C, 1, 1, seed=seed + 6)), 0.1 * _rnd(1, C, 1, 1, seed=seed + 7)
+    ln = ops.chan_layernorm(xh, lg.to(DEV), lb.to(DEV))
+    assert rel_err(to_nchw(ln.cpu()), U.chan_layernorm(x, lg, lb)) < 1e-5
+    # linear attention core on a qkv tensor of this spatial size
+    qkv = _rnd(B, 384, H, W, seed=seed + 8)
+    want = U.linear_attention_core(qkv, 4) if hasattr(U, "linear_attention_core") else None
+    got, _ = ops.linattn(to_nhwc(qkv).to(DEV), 4)
+    if want is None:
+        q, k, v = qkv.reshape(B, 3, 4, 32, H * W).unbind(1)
+        k = k.softmax(dim=-1)
+        ctx = torch.einsum("bhdn,bhen->bhde", k, v)
+        want = torch.einsum("bhde,bhdn->bhen", ctx, q).reshape(B, 128, H, W)
+    assert rel_err(to_nchw(got.cpu()), want) < 2e-5
