@@ -192,47 +192,54 @@ __global__ __launch_bounds__(256) void linattn_small_kernel(const float* __restr
     }
 }
 
-// 64 pixels x `heads` threads per workgroup; the sample's ctx (heads x 32 x 32) sits in LDS with a
-// 16-byte skew per head so the `heads` distinct addresses of a wave fall on distinct bank slots.
+// out[b][n][h*32+e] = sum_d ctx[b][h][d][e] q[b][n][h*32+d]: per head a (64 px x 32 d) x (32 d x 32 e) product on the matrix
+// pipe.  One workgroup = 64 pixels of one sample, one wave per head: the q tile is staged through LDS with coalesced
+// float4 loads (pitch 33: conflict-free operand reads), ctx fragments come straight from global (16 values per lane),
+// 2 x 16 v_mfma_f32_32x32x2_f32 per wave, rows of 128 contiguous bytes out.  (The earlier VALU version re-read ctx from LDS
+// 256 times per thread and was LDS-issue bound: 15 us at 32x32.)
+typedef float f32x16_att __attribute__((ext_vector_type(16)));
 __global__ __launch_bounds__(512) void linattn_apply_kernel(const float* __restrict__ qkv, const float* __restrict__ ctx,
                                                             float* __restrict__ out, int HW, int heads, int tiles_per_sample) {
-    extern __shared__ __attribute__((aligned(16))) float cs[];
-    constexpr int HP = DH * DH + 4;  // per-head pitch
+    extern __shared__ __attribute__((aligned(16))) float qs[];   // [heads][64 px][33]
     const int b = blockIdx.x / tiles_per_sample, tile = blockIdx.x % tiles_per_sample;
     const int HC = heads * DH, RS = 3 * HC;
     const int nthreads = 64 * heads;
-    for (int i = threadIdx.x; i < heads * DH * DH / 4; i += nthreads) {
-        const int hh = (i * 4) / (DH * DH), r = (i * 4) % (DH * DH);
-        *reinterpret_cast<float4*>(cs + hh * HP + r) =
-            *reinterpret_cast<const float4*>(ctx + ((long long)b * heads + hh) * DH * DH + r);
+    const int n0 = tile * 64;
+    // q tile: 64 rows x HC floats, consecutive threads along the row
+    const int f4_per_row = HC / 4;
+    for (int i = threadIdx.x; i < 64 * f4_per_row; i += nthreads) {
+        const int row = i / f4_per_row, c4 = i - row * f4_per_row;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (n0 + row < HW) v = *reinterpret_cast<const float4*>(qkv + ((long long)b * HW + n0 + row) * RS + c4 * 4);
+        const int hh = (c4 * 4) / DH, d = (c4 * 4) % DH;
+        float* dst = qs + (hh * 64 + row) * 33 + d;
+        dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
     }
+    const int h = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int l31 = lane & 31, fh = lane >> 5;
+    // B fragments: ctx[h][d = 2*kk + fh][e = lane & 31]
+    const float* cp = ctx + ((long long)b * heads + h) * DH * DH + l31;
+    float bf[16];
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) bf[kk] = cp[(2 * kk + fh) * DH];
     __syncthreads();
-    const int h = threadIdx.x % heads, pl = threadIdx.x / heads;
-    const int n = tile * 64 + pl;
-    if (n >= HW) return;
-    const float* qp = qkv + ((long long)b * HW + n) * RS + h * DH;
-    float q[DH];
+    const float* qh = qs + h * 64 * 33;
+    f32x16_att acc0, acc1;
 #pragma unroll
-    for (int i = 0; i < DH / 4; ++i) {
-        const float4 t = *reinterpret_cast<const float4*>(qp + i * 4);
-        q[4 * i] = t.x; q[4 * i + 1] = t.y; q[4 * i + 2] = t.z; q[4 * i + 3] = t.w;
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+        const float a0 = qh[l31 * 33 + 2 * kk + fh], a1 = qh[(32 + l31) * 33 + 2 * kk + fh];
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bf[kk], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bf[kk], acc1, 0, 0, 0);
     }
-    float4 acc[DH / 4];
+    // C layout: col e = lane & 31, row px = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
 #pragma unroll
-    for (int i = 0; i < DH / 4; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    const float* ch = cs + h * HP;
-#pragma unroll
-    for (int d = 0; d < DH; ++d) {
-        const float qd = q[d];
-#pragma unroll
-        for (int i = 0; i < DH / 4; ++i) {
-            const float4 c4 = *reinterpret_cast<const float4*>(ch + d * DH + i * 4);
-            acc[i].x += qd * c4.x; acc[i].y += qd * c4.y; acc[i].z += qd * c4.z; acc[i].w += qd * c4.w;
-        }
+    for (int r = 0; r < 16; ++r) {
+        const int px = (r & 3) + 8 * (r >> 2) + 4 * fh;
+        if (n0 + px < HW) out[((long long)b * HW + n0 + px) * HC + h * DH + l31] = acc0[r];
+        if (n0 + 32 + px < HW) out[((long long)b * HW + n0 + 32 + px) * HC + h * DH + l31] = acc1[r];
     }
-    float* op = out + ((long long)b * HW + n) * HC + h * DH;
-#pragma unroll
-    for (int i = 0; i < DH / 4; ++i) *reinterpret_cast<float4*>(op + i * 4) = acc[i];
 }
 
 // Pixel-range splits: ~1024 workgroups at most, at least one 64-pixel tile each.
@@ -287,7 +294,7 @@ int linattn_apply(const float* qkv, const float* ctx, float* out, int B, int HW,
     DDK_REQUIRE(heads >= 1 && heads <= 8, "linattn_apply: heads must be in 1..8");
     DDK_REQUIRE(aligned16(qkv) && aligned16(ctx) && aligned16(out), "linattn_apply: alignment");
     const int tiles = (int)ceil_div(HW, 64);
-    const size_t lds = (size_t)heads * (DH * DH + 4) * sizeof(float);
+    const size_t lds = (size_t)heads * 64 * 33 * sizeof(float);
     hipLaunchKernelGGL(linattn_apply_kernel, dim3(B * tiles), dim3(64 * heads), lds, st, qkv, ctx, out, HW, heads, tiles);
     return check_launch("linattn_apply_kernel");
 }
