@@ -330,13 +330,22 @@ class TimeEmbedFn(torch.autograd.Function):
         ops.bias_act_(out, bcat, False)
         ctx.save_for_backward(e, u1, h1, tv, act, w1, w2, wcat)
         ctx.couts = [w.shape[0] for w in ws]
-        return out
+        # one output per block: column ranges (views) of the single [B, sum C_out] product.  Separate outputs so that the
+        # backward gets one gradient per block -- slicing a single output would make autograd build a zero-filled
+        # [B, sum C_out] tensor per block and add them up.
+        views, off = [], 0
+        for co in ctx.couts:
+            views.append(out[:, off:off + co])
+            off += co
+        return tuple(views)
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, *douts):
         saved = ctx.saved_tensors
         e, u1, h1, tv, act, w1, w2, wcat = saved
-        dout = _c(dout)
+        bsz = act.shape[0]
+        dout = torch.cat([d if d is not None else torch.zeros((bsz, co), device=act.device, dtype=torch.float32)
+                          for d, co in zip(douts, ctx.couts)], dim=1)
         bsz, ctot = dout.shape
         d = w2.shape[0]
         dev = dout.device

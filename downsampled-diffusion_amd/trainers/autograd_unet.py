@@ -79,17 +79,12 @@ def unet_forward_autograd(unet, x, time):
     mlp_args = []
     for rb in rbs:
         mlp_args += [rb.mlp[1].weight, rb.mlp[1].bias]
-    temb_all = AG.TimeEmbedFn.apply(time.to(torch.int64).contiguous(), freqs, unet.time_mlp[1].weight, unet.time_mlp[1].bias,
-                                    unet.time_mlp[3].weight, unet.time_mlp[3].bias, *mlp_args)
-    offs, o = {}, 0
-    for rb in rbs:
-        co = rb.mlp[1].weight.shape[0]
-        offs[id(rb)] = (o, co)
-        o += co
+    shifts = AG.TimeEmbedFn.apply(time.to(torch.int64).contiguous(), freqs, unet.time_mlp[1].weight, unet.time_mlp[1].bias,
+                                  unet.time_mlp[3].weight, unet.time_mlp[3].bias, *mlp_args)
+    shift_of = {id(rb): s for rb, s in zip(rbs, shifts)}      # one [B, C_out] column range per ResnetBlock
 
     def shift(rb):
-        a, co = offs[id(rb)]
-        return temb_all[:, a:a + co]
+        return shift_of[id(rb)]
 
     c_in = x.shape[-1]
     if c_in % 32:

@@ -207,7 +207,8 @@ def test_time_embedding_backward(AG):
     flat = [w1, b1, w2, b2] + [p for pair in mlps for p in pair]
     out_ref, go, gs = grads_cpu(f, *flat)
     dev = [p.to(DEV).requires_grad_(True) for p in flat]
-    out = AG.TimeEmbedFn.apply(t.to(DEV), sinusoidal_freqs(dim).to(DEV), *dev)
+    outs = AG.TimeEmbedFn.apply(t.to(DEV), sinusoidal_freqs(dim).to(DEV), *dev)      # one [B, C_out] output per block
+    out = torch.cat(outs, dim=1)
     assert rel_err(out.detach().cpu(), out_ref) < 2e-5
     out.backward(go.to(DEV))
     for p, g in zip(dev, gs):
