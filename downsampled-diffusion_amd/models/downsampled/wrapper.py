@@ -1,5 +1,4 @@
 """Factories for the dDDPM resampling networks (reference models/downsampled/wrapper.py:6-59)."""
-from ddk.lib import DDKError
 from .convblocks import ConvResNet
 
 _ONLY = ("only 'convolutional_res' is built on the HIP path -- the mode train.py:34-35 selects; "

@@ -1,6 +1,5 @@
 """Host-side helpers with the reference's names (reference utils/utils.py:5-54)."""
 import numpy as np
-import torch
 
 
 def modify_config(config, model_config):
