@@ -31,6 +31,7 @@ struct Slot {
     int kind;
     size_t off;  // float offset into the packed arena
     int O, I, KH, KW, i_pad, ld, col0;
+    int attn = -1;  // >= 0: the slot feeds the folded LayerNorm of that attention site (packing it re-derives W o g, W g, W b)
 };
 
 struct ConvW {
@@ -126,15 +127,24 @@ struct ddk_unet {
         if (r.has_res) r.res = add_conv(p + "res_conv.", co, ci, 1, true);
         return r;
     }
+    int n_attn = 0;
+    std::vector<AttnW> attn_all;   // copies in creation order (slot.attn indexes this)
     AttnW add_attn(const std::string& p, int c) {
         AttnW a;
         a.c = c;
+        const size_t s0 = slots.size();
         a.qkv = add_conv(p + "fn.fn.to_qkv.", 3 * HIDDEN, c, 1, false);
+        const size_t s1 = slots.size();
         a.out = add_conv(p + "fn.fn.to_out.", c, HIDDEN, 1, true);
+        const size_t s2 = slots.size();
         a.ln = add_norm(p + "fn.norm.g", p + "fn.norm.b", c);
+        for (size_t i = s0; i < s1; ++i) slots[i].attn = n_attn;               // to_qkv weight
+        for (size_t i = s2; i < slots.size(); ++i) slots[i].attn = n_attn;     // LayerNorm g, b
         a.qkv_lnw = alloc((size_t)3 * HIDDEN * pad32(c));
         a.ln_c1 = alloc((size_t)3 * HIDDEN);
         a.ln_c2 = alloc((size_t)3 * HIDDEN);
+        attn_all.push_back(a);
+        ++n_attn;
         return a;
     }
 };
@@ -240,18 +250,18 @@ __global__ __launch_bounds__(64) void ln_fold_kernel(const float* __restrict__ w
     if (threadIdx.x == 0) { c1[n] = s1; c2[n] = s2; }
 }
 
-// Derived weights: call once after every slot of `packed` has been (re)packed.
+static int fold_attn(const AttnW& a, float* P, hipStream_t st) {
+    hipLaunchKernelGGL(ln_fold_kernel, dim3(3 * HIDDEN), dim3(64), 0, st, P + a.qkv.w, P + a.ln.g, P + a.ln.b, P + a.qkv_lnw, P + a.ln_c1,
+                       P + a.ln_c2, a.c, pad32(a.c));
+    return check_launch("ln_fold_kernel");
+}
+
+// Derived weights of every attention site.  ddk_unet_pack_slot already re-derives a site's weights whenever one of its three
+// source slots is packed (so a caller that packs every slot, in any order, ends up consistent); this entry point re-derives
+// all of them explicitly, e.g. after writing into the packed arena by other means.
 extern "C" int ddk_unet_finalize_pack(const ddk_unet* u, void* packed, ddk_stream_t s) {
     DDK_REQUIRE(u && packed, "unet_finalize_pack: arguments");
-    float* P = static_cast<float*>(packed);
-    auto fold = [&](const AttnW& a) -> int {
-        hipLaunchKernelGGL(ln_fold_kernel, dim3(3 * HIDDEN), dim3(64), 0, as_stream(s), P + a.qkv.w, P + a.ln.g, P + a.ln.b, P + a.qkv_lnw,
-                           P + a.ln_c1, P + a.ln_c2, a.c, pad32(a.c));
-        return check_launch("ln_fold_kernel");
-    };
-    for (const AttnW& a : u->down_attn) DDK_TRY(fold(a));
-    DDK_TRY(fold(u->mid_attn));
-    for (const AttnW& a : u->up_attn) DDK_TRY(fold(a));
+    for (const AttnW& a : u->attn_all) DDK_TRY(fold_attn(a, static_cast<float*>(packed), as_stream(s)));
     return DDK_OK;
 }
 
@@ -259,15 +269,22 @@ extern "C" int ddk_unet_pack_slot(const ddk_unet* u, int slot, const float* cano
     DDK_REQUIRE(u && canonical && packed && slot >= 0 && slot < (int)u->slots.size(), "unet_pack_slot: arguments");
     const Slot& sl = u->slots[slot];
     float* dst = static_cast<float*>(packed) + sl.off;
+    int rc;
     switch (sl.kind) {
         case PK_COPY:
             DDK_HIP(hipMemcpyAsync(dst, canonical, (size_t)sl.numel * sizeof(float), hipMemcpyDeviceToDevice, as_stream(s)));
-            return DDK_OK;
-        case PK_CONV: return ddk_pack_conv_weight(canonical, dst, sl.O, sl.I, sl.KH, sl.KW, sl.i_pad, s);
-        case PK_CONVT: return ddk_pack_convT_weight(canonical, dst, sl.I, sl.O, s);
-        case PK_LINEAR_T: return ddk_pack_linear_T(canonical, dst, sl.O, sl.I, sl.ld, sl.col0, s);
+            rc = DDK_OK;
+            break;
+        case PK_CONV: rc = ddk_pack_conv_weight(canonical, dst, sl.O, sl.I, sl.KH, sl.KW, sl.i_pad, s); break;
+        case PK_CONVT: rc = ddk_pack_convT_weight(canonical, dst, sl.I, sl.O, s); break;
+        case PK_LINEAR_T: rc = ddk_pack_linear_T(canonical, dst, sl.O, sl.I, sl.ld, sl.col0, s); break;
         default: return fail_arg("unet_pack_slot: slot kind");
     }
+    DDK_TRY(rc);
+    // to_qkv weight / LayerNorm g / b of an attention site: re-derive its folded weights (stream-ordered after the pack above;
+    // whichever of the three is packed last leaves them consistent)
+    if (sl.attn >= 0) DDK_TRY(fold_attn(u->attn_all[sl.attn], static_cast<float*>(packed), as_stream(s)));
+    return DDK_OK;
 }
 
 // ------------------------------------------------------------------------------------------------

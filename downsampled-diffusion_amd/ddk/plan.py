@@ -65,7 +65,6 @@ class UnetPlan:
                 raise L.DDKError(f"UNet weight '{name}': expected {self.slot_numel[i]} elements, got {src.numel()}")
             keep.append(src)
             L.check(lib.ddk_unet_pack_slot(self.handle, i, L.ptr(src), L.ptr(packed), L.stream()), f"pack {name}")
-        L.check(lib.ddk_unet_finalize_pack(self.handle, L.ptr(packed), L.stream()), "finalize_pack")
         torch.cuda.current_stream().synchronize()  # sources may be temporaries
         self.packed = packed
         return packed

@@ -180,8 +180,9 @@ long long ddk_unet_slot_numel(const ddk_unet* u, int slot);
 size_t ddk_unet_packed_bytes(const ddk_unet* u);
 /* repack one canonical (state_dict layout) tensor into the arena */
 int ddk_unet_pack_slot(const ddk_unet* u, int slot, const float* canonical, void* packed, ddk_stream_t s);
-/* Weights derived from the packed slots (LayerNorm folded into to_qkv: W o g, W g, W b): call once after every slot of
-   `packed` has been packed or re-packed. */
+/* Weights derived from the packed slots (LayerNorm folded into to_qkv: W o g, W g, W b).  ddk_unet_pack_slot re-derives a
+   site's weights whenever one of its source slots (to_qkv.weight, norm.g, norm.b) is packed, so packing every slot -- in
+   any order -- is enough; this call re-derives all sites explicitly (e.g. after writing into `packed` by other means). */
 int ddk_unet_finalize_pack(const ddk_unet* u, void* packed, ddk_stream_t s);
 size_t ddk_unet_workspace_bytes(const ddk_unet* u, int B, int H, int W);
 /* eps_hat = Unet(x, t).  x: NHWC [B][H][W][in_ch] (unpadded), out same shape. */
