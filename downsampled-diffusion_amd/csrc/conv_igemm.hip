@@ -359,27 +359,40 @@ __device__ __forceinline__ void consume_epilogue_args(const IgemmParams& p) {
                  "s"(p.resid), "s"(p.ln_c1), "s"(p.ln_c2), "s"(le));
 }
 
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
 // im2col implicit GEMM, all waves load and multiply (every conv kind; the 3x3 stride-1 layers with enough pixels use the
-// halo kernel further down).  2-stage ring: the pieces of chunk k+1 are all issued right after the barrier of chunk k
-// (small LDS footprint, so 2-5 workgroups share a CU and cover each other's barrier / issue phases).
-// DBG = 1 is the diagnostic instantiation (DDK_DEBUG stamps / ablations, tools/conv_clock.py); production is DBG = 0.
-template <int BM, int BN, int WM, int WN, int DBG>
+// halo kernel further down).
+//
+// NS-stage LDS ring with counted waits.  tools/dma_rate.hip (profiles/r02_dma_rate.txt) shows what a CU's LDS-DMA intake
+// is bounded by: the bytes it keeps in flight over the latency of the level that serves them (L2 hit ~300 cycles:
+// 30 GB/s per CU with 4 KiB in flight, 63-79 with 16 KiB, > 100 with 32 KiB; Infinity Cache ~700 cycles) -- not a fixed
+// per-CU rate.  A 2-stage ring has ONE k-chunk in flight per workgroup and only while that workgroup multiplies, so layers
+// with one or two workgroups per CU ran at the latency, not the bandwidth.  Here chunks k+1 .. k+NS-2 are already in flight
+// while chunk k is multiplied, and the pieces of chunk k+NS-1 are issued one at a time BETWEEN the MFMAs of chunk k (their
+// address arithmetic and issue slots hide in MFMA shadows instead of stalling the matrix pipe after each barrier).
+//   iteration k:  s_waitcnt vmcnt((NS-2)*PW)   this wave's pieces of chunk k have landed (PW pieces per wave and chunk)
+//                 s_barrier                    everyone's have; everyone is done reading stage (k-1) % NS
+//                 4 quarters of { prefetch next fragments | MFMA | issue PW/4 pieces of chunk k+NS-1 into stage (k-1) % NS | MFMAs }
+template <int BM, int BN, int WM, int WN, int NS>
 __global__ __launch_bounds__(WM* WN * 64) void igemm_dma_kernel(const IgemmParams p) {
     constexpr int NW = WM * WN;
     constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
     constexpr int A_PW = BM / 8 / NW, B_PW = BN / 8 / NW;  // 1-KiB DMA pieces per wave per stage
+    constexpr int PW = A_PW + B_PW;
     constexpr int STAGE = (BM + BN) * 32;                  // floats
     static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile rows must split into 8-row pieces per wave");
-    const int dbg = DBG ? p.debug : 0;
+    static_assert(NS >= 2 && (NS - 2) * PW <= 63, "vmcnt is a 6-bit counter");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const unsigned long long r_entry = (dbg & 32) ? __builtin_amdgcn_s_memrealtime() : 0ull;
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WN, wn = wid % WN;
     // XCD-aware tile order (speed only): workgroups are dealt round-robin over the 8 XCDs, each with its own L2.
     // Give every XCD a CONTIGUOUS run of logical tiles, ordered (n-tile fastest, then m-tile, then split / phase), so
-    // the workgroups sharing an L2 are the ones that re-read the same input rows (9 taps, halo rows, all n-tiles).
+    // the workgroups sharing an L2 are the ones that re-read the same input rows (9 taps, halo rows, all n-tiles) and,
+    // for split-k layers, the same k-slice of the weights (each XCD then pulls 1/8 of the weights from the Infinity Cache).
     int tile_m, tile_n, tile_z;
     {
         const int nwg = gridDim.x * gridDim.y * gridDim.z;
@@ -446,30 +459,38 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_dma_kernel(const IgemmParam
     const int it_begin = split * p.kiters_per_split;
     const int it_end = min(p.kiters, it_begin + p.kiters_per_split);
     const int cpt = p.cin >> 5;
-    int tap = it_begin / cpt, cc = (it_begin % cpt) << 5;
+    const int n_it = it_end - it_begin;
 
-    auto issue_chunk = [&](int stage) {   // all PW pieces of the next k-chunk; tap / channel state is wave-uniform
+    // ---- the issue cursor runs NS-1 chunks ahead of the multiply; everything in it is wave-uniform
+    int tap = it_begin / cpt, cc = (it_begin % cpt) << 5;
+    const float* i_src = p.src0;
+    int i_cs = 0, i_coff = 0, i_dpix = 0, i_tap = 0;
+    long long i_woff = 0;
+    unsigned i_st = 0;
+    auto begin_chunk = [&](int stage) {   // latch the position of the next chunk to issue, advance the cursor
         int dy, dx;
         tap_offset(p.tapmode, phase, tap, dy, dx);
         const bool first = cc < p.c0;
-        const float* src = first ? p.src0 : p.src1;
-        const int cs = first ? p.c0 : p.c1, coff = first ? cc : cc - p.c0;
-        const int dpix = dy * p.W + dx;
-        const long long woff = (long long)tap * p.cin + cc;
-        const unsigned st = lds_base + (unsigned)(stage * STAGE * 4);
-#pragma unroll
-        for (int j = 0; j < A_PW; ++j) {
-            const long long off = (long long)(a_pix[j] + dpix) * cs + (coff + a_sw[j]);
-            const float* g = ((a_mask[j] >> tap) & 1u) ? src + off : zero;
-            lds_dma16(g, st + (unsigned)((wid_u * A_PW + j) * 1024));
-        }
-#pragma unroll
-        for (int j = 0; j < B_PW; ++j) {
-            const float* g = b_ok[j] ? p.w + (b_off[j] + woff) : zero;
-            lds_dma16(g, st + (unsigned)(BM * 128 + (wid_u * B_PW + j) * 1024));
-        }
+        i_src = first ? p.src0 : p.src1;
+        i_cs = first ? p.c0 : p.c1;
+        i_coff = first ? cc : cc - p.c0;
+        i_dpix = dy * p.W + dx;
+        i_woff = (long long)tap * p.cin + cc;
+        i_st = lds_base + (unsigned)(stage * STAGE * 4);
+        i_tap = tap;
         cc += 32;
         if (cc == p.cin) { cc = 0; ++tap; }
+    };
+    auto issue_piece = [&](int j) {       // j is a compile-time constant after unrolling
+        if (j < A_PW) {
+            const long long off = (long long)(a_pix[j < A_PW ? j : 0] + i_dpix) * i_cs + (i_coff + a_sw[j < A_PW ? j : 0]);
+            const float* g = ((a_mask[j < A_PW ? j : 0] >> i_tap) & 1u) ? i_src + off : zero;
+            lds_dma16(g, i_st + (unsigned)((wid_u * A_PW + j) * 1024));
+        } else {
+            const int jb = j - A_PW;
+            const float* g = b_ok[jb >= 0 ? jb : 0] ? p.w + (b_off[jb >= 0 ? jb : 0] + i_woff) : zero;
+            lds_dma16(g, i_st + (unsigned)(BM * 128 + (wid_u * B_PW + jb) * 1024));
+        }
     };
 
     f32x16 acc[TM][TN];
@@ -488,30 +509,25 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_dma_kernel(const IgemmParam
     const int a_base = wm * TM * 32 * 32;
     const int b_base = BM * 32 + wn * TN * 32 * 32;
 
-    const int n_it = (dbg & 8) ? 0 : it_end - it_begin;
     const bool ln_fold = p.ln_c1 != nullptr;
     float ln_s = 0.f, ln_q = 0.f;
-    if (n_it > 0) issue_chunk(0);
-    unsigned long long t0 = 0, r0 = 0;
-    if (dbg & 32) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
+    // prologue: chunks 0 .. NS-2 go out back to back
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s)
+        if (s < n_it) {
+            begin_chunk(s);
+#pragma unroll
+            for (int j = 0; j < PW; ++j) issue_piece(j);
+        }
     consume_epilogue_args(p);
-    int stage = 0;
-    unsigned long long seg_wait = 0, seg_issue = 0, seg_mfma = 0;  // DDK_DEBUG & 64: where a k-chunk's cycles go
-    auto stamp = [&]() -> unsigned long long {
-        unsigned long long t;
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
-        __builtin_amdgcn_sched_barrier(0);
-        return t;
-    };
+    int stage = 0, istage = NS - 1;      // stage being multiplied, stage the next issued chunk goes to
     for (int k = 0; k < n_it; ++k) {
-        unsigned long long ta = 0, tb = 0, tc = 0;
-        if (dbg & 64) ta = stamp();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of chunk k have landed
-        if (!(dbg & 2)) __syncthreads();  // everyone's pieces of chunk k landed; everyone finished reading chunk k-1's stage
-        if (dbg & 64) tb = stamp();
-        if (k + 1 < n_it && !(dbg & 1)) issue_chunk(stage ^ 1);
-        if (dbg & 64) tc = stamp();
+        // chunks k+1 .. min(k+NS-2, n_it-1) may still fly; in the last NS-2 iterations (nothing left to issue) wait for all
+        if (k + NS - 2 < n_it) wait_vmcnt<(NS - 2) * PW>();
+        else wait_vmcnt<0>();
+        __syncthreads();
+        const bool more = k + NS - 1 < n_it;     // wave-uniform
+        if (more) begin_chunk(istage);
         if (ln_fold) {   // per-row sum / sum of squares of the staged A chunk (the swizzle only permutes a row's floats)
             constexpr int TPR = NW * 64 / BM, F4 = 8 / TPR;      // threads per row, float4 per thread
             const float4* rowp = reinterpret_cast<const float4*>(smem + stage * STAGE + (tid / TPR) * 32) + (tid % TPR) * F4;
@@ -539,44 +555,31 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_dma_kernel(const IgemmParam
                 for (int j = 0; j < TN; ++j) b[nxt][j] = *reinterpret_cast<const float4*>(Bs + j * 1024 + foff[q + 1]);
             }
             __builtin_amdgcn_sched_barrier(0);  // keep the prefetch above the MFMAs (hipcc otherwise sinks it to first use)
-            // e outermost: consecutive MFMAs go to different accumulators (round-robin over the TM*TN tiles)
+            // e outermost: consecutive MFMAs go to different accumulators (round-robin over the TM*TN tiles).
+            // The first MFMA of the quarter goes out alone, then this quarter's share of the next chunk's DMA pieces is
+            // issued in its shadow, then the rest.
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][0].x, b[cur][0].x, acc[0][0], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) {
+#pragma unroll
+                for (int j = 0; j < PW; ++j)
+                    if ((j * 4) / PW == q) issue_piece(j);
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j) {
+                        if (e == 0 && i == 0 && j == 0) continue;   // issued above
                         const float av = e == 0 ? a[cur][i].x : e == 1 ? a[cur][i].y : e == 2 ? a[cur][i].z : a[cur][i].w;
                         const float bv = e == 0 ? b[cur][j].x : e == 1 ? b[cur][j].y : e == 2 ? b[cur][j].z : b[cur][j].w;
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
                     }
         }
-        stage ^= 1;
-        if (dbg & 64) {
-            const unsigned long long td = stamp();
-            seg_wait += tb - ta; seg_issue += tc - tb; seg_mfma += td - tc;
-        }
-    }
-    if ((dbg & 64) && lane == 0) {
-        const int wg = (blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) & 511;
-        g_stamps[2048 * 8 + (wg * 4 + wid) * 4 + 0] = seg_wait;
-        g_stamps[2048 * 8 + (wg * 4 + wid) * 4 + 1] = seg_issue;
-        g_stamps[2048 * 8 + (wg * 4 + wid) * 4 + 2] = seg_mfma;
-        g_stamps[2048 * 8 + (wg * 4 + wid) * 4 + 3] = (unsigned long long)n_it;
-    }
-    unsigned long long r1 = 0;
-    if (dbg & 32) {
-        r1 = __builtin_amdgcn_s_memrealtime();
-        if (tid == 0) {
-            const int wg = (blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) & 2047;
-            g_stamps[wg * 8 + 0] = __builtin_amdgcn_s_memtime() - t0;  // shader cycles in the k-loop
-            g_stamps[wg * 8 + 1] = r1 - r0;                             // 100 MHz ticks in the k-loop
-            g_stamps[wg * 8 + 2] = (unsigned long long)n_it;
-            g_stamps[wg * 8 + 3] = 1;
-            g_stamps[wg * 8 + 4] = r_entry;                             // absolute: kernel entry
-            g_stamps[wg * 8 + 5] = r0;                                  // absolute: loop start
-            g_stamps[wg * 8 + 6] = r1;                                  // absolute: loop end
-        }
+        stage = stage + 1 == NS ? 0 : stage + 1;
+        istage = istage + 1 == NS ? 0 : istage + 1;
     }
 
     __syncthreads();   // every wave is done reading the ring: its LDS now stages the output block
@@ -599,11 +602,6 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_dma_kernel(const IgemmParam
     }
     store_block_via_lds<TM, TN>(p, acc, smem + wid * EPI_FLOATS, lane, m0 + wm * TM * 32, n0 + wn * TN * 32, split, phase,
                                 rowstat ? rowstat + 2 * wm * TM * 32 : nullptr);
-    if ((dbg & 32) && tid == 0) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const int wg = (blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) & 2047;
-        g_stamps[wg * 8 + 7] = __builtin_amdgcn_s_memrealtime();       // absolute: this wave's stores drained
-    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -990,7 +988,8 @@ enum TileId { T128x128 = 0, T128x64 = 1, T64x64 = 2, T128x32 = 3, T64x32 = 4 };
 struct Choice {
     TileId tile;
     int splits;
-    int kps;  // k-chunks per split
+    int kps;     // k-chunks per split
+    int stages;  // LDS ring depth of the im2col kernel (ignored by the halo kernel)
 };
 
 struct Geometry {
@@ -1018,23 +1017,65 @@ static void tile_dims(TileId t, int& bm, int& bn) {
     }
 }
 
+// Tuning knobs (environment variables) exist only in the -DDDK_TUNING build (libddk_tune.so, `make tune`) that
+// tools/conv_bench.py and friends load; the production library has no getenv in its launch path.
+#ifdef DDK_TUNING
+static bool tuning_force(int& tile, int& splits, int& stages) {
+    const char* f = getenv("DDK_FORCE_TILE");   // "<tile id>[,<splits>[,<stages>]]"
+    if (!f) return false;
+    tile = 0; splits = 1; stages = 0;
+    return sscanf(f, "%d,%d,%d", &tile, &splits, &stages) >= 1 && tile >= 0 && tile <= 4;
+}
+static bool tuning_flag(const char* name) { return getenv(name) != nullptr; }
+static int tuning_int(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
+#else
+static bool tuning_force(int&, int&, int&) { return false; }
+static bool tuning_flag(const char*) { return false; }
+static int tuning_int(const char*, int dflt) { return dflt; }
+#endif
+
+// Ring depth for a tile and grid: as deep as the LDS allows for the number of workgroups a CU will hold.
+// 64x64: 16 KB per stage; 128x64: 24 KB; 128x128: 32 KB; 128x32: 20 KB; 64x32: 12 KB.  The instantiated depths are
+// {3, 4, 6} (64x64), {3, 4} (128x64, 128x32, 64x32) and {3} (128x128).
+static int choose_stages(TileId t, long long workgroups, int kps) {
+    const bool one_per_cu = workgroups <= 256;
+    int ns;
+    switch (t) {
+        case T64x64: ns = one_per_cu ? 6 : 4; break;     // 96 KB alone, else 2 x 64 KB
+        case T128x64: ns = one_per_cu ? 4 : 3; break;    // 96 KB alone, else 2 x 72 KB
+        case T128x128: ns = 3; break;                    // 96 KB
+        case T128x32: ns = one_per_cu ? 4 : 3; break;
+        default: ns = one_per_cu ? 4 : 3; break;
+    }
+    // a ring deeper than the k-chunks of a split buys nothing
+    if (t == T64x64 && ns == 6 && kps < 5) ns = 4;
+    if (ns == 4 && kps < 3) ns = 3;
+    return ns;
+}
+
 // Pick the largest tile that still gives the 256 CUs about a full wave of workgroups; when even the
 // smallest does not, split k across workgroups (at least 4 k-chunks per split).
 static Choice choose_tile(long long M, int N, int nphase, int kiters) {
-    // tuning knob for tools/conv_bench.py only: DDK_FORCE_TILE="<tile id>[,<splits>]"
-    if (const char* f = getenv("DDK_FORCE_TILE")) {
-        int t = 0, s = 1;
-        if (sscanf(f, "%d,%d", &t, &s) >= 1 && t >= 0 && t <= 4) {
+    auto n_tiles = [&](TileId t) {
+        int bm, bn;
+        tile_dims(t, bm, bn);
+        return ceil_div(M, bm) * ceil_div(N, bn) * nphase;
+    };
+    auto with_splits = [&](TileId t, long long s, int stages = 0) {
+        Choice c{t, 1, kiters, 0};
+        if (s < 1) s = 1;
+        if (s > kiters) s = kiters;
+        c.kps = (int)ceil_div(kiters, s);
+        c.splits = (int)ceil_div(kiters, c.kps);
+        c.stages = stages > 0 ? stages : choose_stages(t, n_tiles(t) * c.splits, c.kps);
+        return c;
+    };
+    {
+        int t, s, st;
+        if (tuning_force(t, s, st)) {
             int bm, bn;
             tile_dims((TileId)t, bm, bn);
-            if (N % 32 == 0 && (bn <= N || bn == 32)) {
-                if (s < 1) s = 1;
-                if (s > kiters) s = kiters;
-                Choice c{(TileId)t, 1, kiters};
-                c.kps = (int)ceil_div(kiters, s);
-                c.splits = (int)ceil_div(kiters, c.kps);
-                return c;
-            }
+            if (N % 32 == 0 && (bn <= N || bn == 32)) return with_splits((TileId)t, s, st);
         }
     }
     TileId order_wide[] = {T128x128, T128x64, T64x64};
@@ -1045,19 +1086,7 @@ static Choice choose_tile(long long M, int N, int nphase, int kiters) {
     if (N % 64 != 0) { order = order_n32; n_order = 2; }
     else if (N % 128 != 0 && N < 128) { order = order_n64; n_order = 2; }
     else { order = order_wide; n_order = 3; }
-    auto n_tiles = [&](TileId t) {
-        int bm, bn;
-        tile_dims(t, bm, bn);
-        return ceil_div(M, bm) * ceil_div(N, bn) * nphase;
-    };
-    auto with_splits = [&](TileId t, long long s) {
-        Choice c{t, 1, kiters};
-        c.kps = (int)ceil_div(kiters, s);
-        c.splits = (int)ceil_div(kiters, c.kps);
-        return c;
-    };
-    // Rules fitted to tools/conv_bench.py sweeps on MI355X (profiles/r01_conv_sweep.txt).  The kernel runs best
-    // with 2+ workgroups per CU (~512 workgroups) and at least ~18 k-chunks per workgroup:
+    // Rules fitted to tools/conv_bench.py sweeps on MI355X (profiles/r02_conv_sweep.txt):
     // 1. short contractions (1x1 convs, <= 8 k-chunks): smallest tile, no split -- prologue/epilogue bound;
     if (kiters <= 8) return with_splits(order[n_order - 1], 1);
     // 2. the largest tile that gives >= 512 workgroups without splitting k;
@@ -1079,10 +1108,10 @@ static Choice choose_tile(long long M, int N, int nphase, int kiters) {
 // straddle images partially, and the (rows+2) x (W+2) halo must fit HALO_MAX_PX.  One workgroup per CU (120 KB of
 // LDS): the channel chunks are split until >= 208 workgroups exist, and the kernel is only used when that leaves
 // >= 4 chunks (36 k-steps) per workgroup -- with less, its 3 us prologue + 3 us epilogue lose to the im2col kernel's
-// smaller tiles (tools/conv_bench.py sweeps, profiles/r01_conv_sweep.txt).
+// smaller tiles (tools/conv_bench.py sweeps).
 static bool choose_halo(int kind, int B, int H, int W, int cin, int N, Choice& c) {
-    static const bool off = getenv("DDK_NO_HALO") != nullptr;   // A/B knobs for tools/conv_bench.py
-    static const int min_chunks = getenv("DDK_HALO_MIN_CHUNKS") ? atoi(getenv("DDK_HALO_MIN_CHUNKS")) : 4;
+    const bool off = tuning_flag("DDK_NO_HALO");
+    const int min_chunks = tuning_int("DDK_HALO_MIN_CHUNKS", 4);
     if (off || kind != DDK_CONV3X3_S1 || N < 128 || N % 32) return false;
     if (W < 8 || W > 128 || 128 % W) return false;
     const int TR = 128 / W;
@@ -1092,36 +1121,35 @@ static bool choose_halo(int kind, int B, int H, int W, int cin, int N, Choice& c
     const int chunks = cin / 32;
     const long long tiles = ceil_div((long long)B * H * W, 128) * ceil_div(N, 128);
     long long s = 1;
-    if (const char* f = getenv("DDK_FORCE_TILE")) {
-        int t = 0, fs = 1;
-        if (sscanf(f, "%d,%d", &t, &fs) == 2 && fs >= 1) s = fs;
+    int ft, fs, fst;
+    if (tuning_force(ft, fs, fst)) {
+        s = fs < 1 ? 1 : fs;
         if (s > chunks) s = chunks;
     } else {
         while (tiles * s < 208 && s < chunks) s *= 2;
         if (tiles * s < 208 || chunks / s < min_chunks) return false;
     }
-    c = Choice{T128x128, 1, chunks};
+    c = Choice{T128x128, 1, chunks, 0};
     c.kps = (int)ceil_div(chunks, s);
     c.splits = (int)ceil_div(chunks, c.kps);
     return true;
 }
 
+#ifdef DDK_TUNING
+#define DDK_HALO_VARIANTS(X) X(0) X(1) X(2)
+#else
+#define DDK_HALO_VARIANTS(X) X(0)
+#endif
+
 static int launch_halo(const IgemmParams& p, hipStream_t st) {
     constexpr size_t lds = (size_t)HALO_LDS_FLOATS * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        DDK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<0>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        DDK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<1>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        DDK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<2>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
     dim3 grid((unsigned)ceil_div(p.M, 128), (unsigned)ceil_div(p.N, HALO_BN), (unsigned)p.splits);
+#ifdef DDK_TUNING
     if (p.debug & (64 | 128)) hipLaunchKernelGGL(conv3x3_halo_kernel<2>, grid, dim3(512), lds, st, p);
     else if (p.debug & 32) hipLaunchKernelGGL(conv3x3_halo_kernel<1>, grid, dim3(512), lds, st, p);
-    else hipLaunchKernelGGL(conv3x3_halo_kernel<0>, grid, dim3(512), lds, st, p);
+    else
+#endif
+    hipLaunchKernelGGL(conv3x3_halo_kernel<0>, grid, dim3(512), lds, st, p);
     return check_launch("conv3x3_halo_kernel");
 }
 
@@ -1135,36 +1163,72 @@ static ConvPlan plan_conv(int kind, int B, int H, int W, int cin, int N, const G
     return {false, choose_tile((long long)B * g.Hm * g.Wm, N, g.nphase, g.ntaps * (cin / 32))};
 }
 
-template <int BM, int BN, int WM, int WN>
-static int launch_tile(const IgemmParams& p, hipStream_t st) {
-    static const bool no_dma = getenv("DDK_NO_DMA") != nullptr;  // A/B knob for tools/conv_bench.py
+template <int BM, int BN, int WM, int WN, int NS>
+constexpr size_t dma_lds_bytes() {
+    constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
+    constexpr size_t ring = (size_t)NS * (BM + BN) * 32 * sizeof(float);
+    constexpr size_t epi = ((size_t)WM * WN * TM * 32 * (TN * 32 + 8) + 2 * BM) * sizeof(float);   // staging + folded-LN row stats
+    return ring > epi ? ring : epi;
+}
+constexpr size_t reg_lds_bytes(int bm, int bn) { return 2 * (size_t)(bm + bn) * LDK * sizeof(float); }
+
+template <int BM, int BN, int WM, int WN, int NS>
+static int launch_dma(const IgemmParams& p, hipStream_t st) {
     dim3 grid((unsigned)ceil_div(p.M, BM), (unsigned)ceil_div(p.N, BN), (unsigned)(p.nphase * p.splits));
-    if (!p.pre_mish && !no_dma) {
-        constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
-        constexpr size_t ring = 2 * (size_t)(BM + BN) * 32 * sizeof(float);
-        constexpr size_t epi = ((size_t)WM * WN * TM * 32 * (TN * 32 + 8) + 2 * BM) * sizeof(float);   // staging + folded-LN row stats
-        constexpr size_t lds = ring > epi ? ring : epi;
-        static bool attr_set = false;
-        if (!attr_set) {
-            DDK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_dma_kernel<BM, BN, WM, WN, 0>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            DDK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_dma_kernel<BM, BN, WM, WN, 1>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            attr_set = true;
-        }
-        if (p.debug) hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, 1>), grid, dim3(WM * WN * 64), lds, st, p);
-        else hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, 0>), grid, dim3(WM * WN * 64), lds, st, p);
-        return check_launch("igemm_dma_kernel");
-    }
-    constexpr size_t lds = 2 * (size_t)(BM + BN) * LDK * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        DDK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, WM, WN>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
-    hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN>), grid, dim3(WM * WN * 64), lds, st, p);
+    hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, NS>), grid, dim3(WM * WN * 64), (dma_lds_bytes<BM, BN, WM, WN, NS>()), st, p);
+    return check_launch("igemm_dma_kernel");
+}
+template <int BM, int BN, int WM, int WN>
+static int launch_reg(const IgemmParams& p, hipStream_t st) {
+    dim3 grid((unsigned)ceil_div(p.M, BM), (unsigned)ceil_div(p.N, BN), (unsigned)(p.nphase * p.splits));
+    hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN>), grid, dim3(WM * WN * 64), reg_lds_bytes(BM, BN), st, p);
     return check_launch("igemm_kernel");
+}
+
+static int launch_tile(const IgemmParams& p, const Choice& c, hipStream_t st) {
+    const bool reg = p.pre_mish || tuning_flag("DDK_NO_DMA");   // Mish-on-load needs the register-staged kernel
+    const int ns = c.stages;
+    switch (c.tile) {
+        case T128x128: return reg ? launch_reg<128, 128, 2, 2>(p, st) : launch_dma<128, 128, 2, 2, 3>(p, st);
+        case T128x64:
+            if (reg) return launch_reg<128, 64, 2, 2>(p, st);
+            return ns >= 4 ? launch_dma<128, 64, 2, 2, 4>(p, st) : launch_dma<128, 64, 2, 2, 3>(p, st);
+        case T64x64:
+            if (reg) return launch_reg<64, 64, 2, 2>(p, st);
+            return ns >= 6 ? launch_dma<64, 64, 2, 2, 6>(p, st) : ns >= 4 ? launch_dma<64, 64, 2, 2, 4>(p, st) : launch_dma<64, 64, 2, 2, 3>(p, st);
+        case T128x32:
+            if (reg) return launch_reg<128, 32, 4, 1>(p, st);
+            return ns >= 4 ? launch_dma<128, 32, 4, 1, 4>(p, st) : launch_dma<128, 32, 4, 1, 3>(p, st);
+        default:
+            if (reg) return launch_reg<64, 32, 2, 1>(p, st);
+            return ns >= 4 ? launch_dma<64, 32, 2, 1, 4>(p, st) : launch_dma<64, 32, 2, 1, 3>(p, st);
+    }
+}
+
+// Kernels that need more dynamic LDS than the default 64 KB limit must be told so once per device, outside any stream
+// capture: ensure_device_init() (core.hip) runs this the first time a device is used (ddk_unet_create, every conv entry).
+template <typename K>
+static int allow_lds(K kernel, size_t bytes) {
+    DDK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return DDK_OK;
+}
+int conv_init_device() {
+#define HALO_ATTR(V) DDK_TRY(allow_lds(&conv3x3_halo_kernel<V>, (size_t)HALO_LDS_FLOATS * sizeof(float)));
+    DDK_HALO_VARIANTS(HALO_ATTR)
+#undef HALO_ATTR
+#define DMA_ATTR(BM, BN, WM, WN, NS) DDK_TRY(allow_lds(&igemm_dma_kernel<BM, BN, WM, WN, NS>, dma_lds_bytes<BM, BN, WM, WN, NS>()));
+    DMA_ATTR(128, 128, 2, 2, 3)
+    DMA_ATTR(128, 64, 2, 2, 3) DMA_ATTR(128, 64, 2, 2, 4)
+    DMA_ATTR(64, 64, 2, 2, 3) DMA_ATTR(64, 64, 2, 2, 4) DMA_ATTR(64, 64, 2, 2, 6)
+    DMA_ATTR(128, 32, 4, 1, 3) DMA_ATTR(128, 32, 4, 1, 4)
+    DMA_ATTR(64, 32, 2, 1, 3) DMA_ATTR(64, 32, 2, 1, 4)
+#undef DMA_ATTR
+    DDK_TRY(allow_lds(&igemm_kernel<128, 128, 2, 2>, reg_lds_bytes(128, 128)));
+    DDK_TRY(allow_lds(&igemm_kernel<128, 64, 2, 2>, reg_lds_bytes(128, 64)));
+    DDK_TRY(allow_lds(&igemm_kernel<64, 64, 2, 2>, reg_lds_bytes(64, 64)));
+    DDK_TRY(allow_lds(&igemm_kernel<128, 32, 4, 1>, reg_lds_bytes(128, 32)));
+    DDK_TRY(allow_lds(&igemm_kernel<64, 32, 2, 1>, reg_lds_bytes(64, 32)));
+    return DDK_OK;
 }
 
 size_t conv_workspace_bytes(int kind, int B, int H, int W, int cin, int N) {
@@ -1176,7 +1240,7 @@ size_t conv_workspace_bytes(int kind, int B, int H, int W, int cin, int N) {
 }
 
 bool conv_ln_fold_ok(int B, int H, int W, int cin, int N) {
-    static const bool off = getenv("DDK_NO_LN_FOLD") != nullptr;   // A/B knob
+    const bool off = tuning_flag("DDK_NO_LN_FOLD");
     Geometry g;
     if (off || !conv_geometry(DDK_CONV1X1, H, W, g) || cin <= 0 || cin % 32 || N % 32) return false;
     const Choice c = choose_tile((long long)B * H * W, N, 1, cin / 32);
@@ -1208,10 +1272,7 @@ int conv_forward(const ddk_conv_args& a, hipStream_t st, const ConvLnFold* ln) {
     p.ntaps = g.ntaps; p.nphase = g.nphase;
     p.kiters = g.ntaps * (p.cin / 32);
     p.pre_mish = a.pre_mish;
-    {
-        static const int dbg = getenv("DDK_DEBUG") ? atoi(getenv("DDK_DEBUG")) : 0;
-        p.debug = dbg;
-    }
+    p.debug = tuning_int("DDK_DEBUG", 0);   // diagnostic instantiations of the halo kernel (DDK_TUNING build only)
     p.post_mish = a.post_mish;
     p.slab_stride = (long long)a.B * g.Ho * g.Wo * a.N;
     p.dWm = make_fastdiv_u((unsigned)g.Wm);
@@ -1219,15 +1280,12 @@ int conv_forward(const ddk_conv_args& a, hipStream_t st, const ConvLnFold* ln) {
     p.tapmode = (a.kind == DDK_CONV1X1) ? 0 : (a.kind == DDK_CONVT4X4_S2 ? 2 : (a.kind == DDK_CONV4X4_S2 ? 3 : 1));
     const ConvPlan plan = plan_conv(a.kind, a.B, a.H, a.W, p.cin, p.N, g, a.pre_mish != 0);
     const Choice c = plan.c;
-    {
-        static const bool trace = getenv("DDK_TRACE") != nullptr;  // tuning aid: one line per conv launch
-        if (trace) {
-            int bm, bn;
-            tile_dims(c.tile, bm, bn);
-            fprintf(stderr, "[ddk] conv kind=%d B=%d %dx%d cin=%d N=%d M=%d kiters=%d -> %s tile %dx%d splits=%d (kps %d) wgs=%lld\n", a.kind,
-                    a.B, a.H, a.W, p.cin, p.N, p.M, p.kiters, plan.halo ? "halo" : "igemm", bm, bn, c.splits, c.kps,
-                    ceil_div(p.M, bm) * ceil_div(p.N, bn) * p.nphase * c.splits);
-        }
+    if (tuning_flag("DDK_TRACE")) {   // tuning aid: one line per conv launch
+        int bm, bn;
+        tile_dims(c.tile, bm, bn);
+        fprintf(stderr, "[ddk] conv kind=%d B=%d %dx%d cin=%d N=%d M=%d kiters=%d -> %s tile %dx%d splits=%d (kps %d) stages=%d wgs=%lld\n",
+                a.kind, a.B, a.H, a.W, p.cin, p.N, p.M, p.kiters, plan.halo ? "halo" : "igemm", bm, bn, c.splits, c.kps, c.stages,
+                ceil_div(p.M, bm) * ceil_div(p.N, bn) * p.nphase * c.splits);
     }
     p.splits = c.splits;
     p.kiters_per_split = c.kps;
@@ -1254,16 +1312,8 @@ int conv_forward(const ddk_conv_args& a, hipStream_t st, const ConvLnFold* ln) {
         DDK_REQUIRE(aligned16(a.workspace), "conv: workspace alignment");
         p.out = static_cast<float*>(a.workspace);
     }
-    int rc;
-    if (plan.halo) rc = launch_halo(p, st);
-    else switch (c.tile) {
-        case T128x128: rc = launch_tile<128, 128, 2, 2>(p, st); break;
-        case T128x64: rc = launch_tile<128, 64, 2, 2>(p, st); break;
-        case T64x64: rc = launch_tile<64, 64, 2, 2>(p, st); break;
-        case T128x32: rc = launch_tile<128, 32, 4, 1>(p, st); break;
-        default: rc = launch_tile<64, 32, 2, 1>(p, st); break;
-    }
-    DDK_TRY(rc);
+    DDK_TRY(ensure_device_init());
+    DDK_TRY(plan.halo ? launch_halo(p, st) : launch_tile(p, c, st));
     if (c.splits > 1 && !a.defer_reduce) {
         const long long n4 = p.slab_stride / 4;
         const int blocks = (int)(ceil_div(n4, 256) < 2048 ? ceil_div(n4, 256) : 2048);
@@ -1292,9 +1342,13 @@ extern "C" size_t ddk_conv_workspace_bytes(int kind, int B, int H, int W, int ci
     return ddk::conv_workspace_bytes(kind, B, H, W, cin, N);
 }
 
-// diagnostic: copy the stamp buffer (4 x 4096 u64) to the host and clear it
+// diagnostic: copy the stamp buffer (6 x 4096 u64) to the host and clear it (only the -DDDK_TUNING build writes stamps)
 extern "C" int ddk_debug_read_stamps(unsigned long long* host_out) {
     if (!host_out) return ddk::fail_arg("debug_read_stamps: null");
+#ifndef DDK_TUNING
+    ddk::set_error("debug_read_stamps: this is the production build; use libddk_tune.so (make tune)");
+    return DDK_ERR_ARG;
+#endif
     DDK_HIP(hipDeviceSynchronize());
     DDK_HIP(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(ddk::g_stamps), sizeof(unsigned long long) * 6 * 4096));
     static unsigned long long zeros[6 * 4096];

@@ -476,7 +476,11 @@ static bool wgrad_geometry(int kind, int H, int W, int& Hm, int& Wm, int& stride
 
 // halo weight-gradient kernel: eligibility and split over pixel chunks (~512 workgroups, >= 8 chunks each)
 static bool wgrad_halo_plan(int kind, int B, int H, int W, int cx, int N, int& wc, int& splits, int& cps, int& n_chunks) {
-    static const bool off = getenv("DDK_NO_WGRAD_HALO") != nullptr;   // A/B knob
+#ifdef DDK_TUNING
+    const bool off = getenv("DDK_NO_WGRAD_HALO") != nullptr;   // A/B knob (tuning build only)
+#else
+    const bool off = false;
+#endif
     if (off || kind != DDK_CONV3X3_S1 || N % 64 || cx % 64) return false;
     if (W <= 32) { if (W < 4 || 32 % W) return false; wc = W; }
     else { if (W % 32) return false; wc = 32; }
@@ -486,7 +490,11 @@ static bool wgrad_halo_plan(int kind, int B, int H, int W, int cx, int N, int& w
     n_chunks = (int)(M / 32);
     if (n_chunks < 128) return false;              // tiny maps: the per-tap kernel's 9x more workgroups win
     const long long tiles = (long long)(N / 64) * (cx / 64);
-    static const int target = getenv("DDK_WGRAD_HALO_WGS") ? atoi(getenv("DDK_WGRAD_HALO_WGS")) : 256;   // tuning knob (256 and 512 time the same; 256 halves the slabs)
+#ifdef DDK_TUNING
+    const int target = getenv("DDK_WGRAD_HALO_WGS") ? atoi(getenv("DDK_WGRAD_HALO_WGS")) : 256;
+#else
+    const int target = 256;   // 256 and 512 workgroups time the same; 256 halves the slabs
+#endif
     long long s = ceil_div(target, tiles);
     const long long max_s = n_chunks / 8 > 0 ? n_chunks / 8 : 1;
     if (s > max_s) s = max_s;
@@ -497,15 +505,14 @@ static bool wgrad_halo_plan(int kind, int B, int H, int W, int cx, int N, int& w
 }
 
 template <int WC>
-static int launch_wgrad_halo(const WgHaloParams& p, hipStream_t st) {
+constexpr size_t wgrad_halo_lds_bytes() {
     constexpr int HALO_PX = (32 / WC) * 3 * (WC + 2);
-    constexpr size_t lds = 2 * (size_t)(32 * 64 + ((HALO_PX + 3) / 4) * 4 * 64) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        DDK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3_halo_kernel<WC>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)lds));
-        attr_set = true;
-    }
+    return 2 * (size_t)(32 * 64 + ((HALO_PX + 3) / 4) * 4 * 64) * sizeof(float);
+}
+
+template <int WC>
+static int launch_wgrad_halo(const WgHaloParams& p, hipStream_t st) {
+    constexpr size_t lds = wgrad_halo_lds_bytes<WC>();
     dim3 grid((unsigned)(p.N / 64), (unsigned)(p.cx / 64), (unsigned)p.splits);
     hipLaunchKernelGGL((wgrad3x3_halo_kernel<WC>), grid, dim3(256), lds, st, p);
     return check_launch("wgrad3x3_halo_kernel");
@@ -517,6 +524,16 @@ static int launch_wgrad(const WgradParams& p, int ntiles_n, int ntiles_c, hipStr
     dim3 grid((unsigned)ntiles_n, (unsigned)ntiles_c, (unsigned)(p.ntaps * p.splits));
     hipLaunchKernelGGL((wgrad_kernel<BN, BC, WN, WC>), grid, dim3(WN * WC * 64), lds, st, p);
     return check_launch("wgrad_kernel");
+}
+
+// > 64 KB of dynamic LDS needs the attribute, once per device (ensure_device_init, core.hip)
+int wgrad_init_device() {
+#define WG_ATTR(WC)                                                                                                               \
+    DDK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3_halo_kernel<WC>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                (int)wgrad_halo_lds_bytes<WC>()));
+    WG_ATTR(32) WG_ATTR(16) WG_ATTR(8) WG_ATTR(4)
+#undef WG_ATTR
+    return DDK_OK;
 }
 
 }  // namespace ddk
@@ -550,6 +567,7 @@ int ddk_conv_wgrad(int kind, const float* x, const float* dy, float* grad_w, int
     const long long M = (long long)B * Hm * Wm;
     DDK_REQUIRE(M < (1LL << 31) && (long long)B * H * W * cx < (1LL << 31), "conv_wgrad: tensor too large");
     hipStream_t st = as_stream(s);
+    DDK_TRY(ensure_device_init());
     {
         int wc, hs, cps, nch;
         if (wgrad_halo_plan(kind, B, H, W, cx, N, wc, hs, cps, nch)) {

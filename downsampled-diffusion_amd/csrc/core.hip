@@ -1,5 +1,7 @@
 // core.hip -- error reporting, version and device probe of libddk.so.
+#include <atomic>
 #include <cstring>
+#include <mutex>
 
 #include "ddk_internal.h"
 
@@ -12,9 +14,28 @@ void set_error(const char* fmt, ...) {
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
 }
+
+// One-time, per-device setup (kernel attributes for > 64 KB of dynamic LDS).  Keyed by the CURRENT device, so a process
+// that drives several GPUs initialises each; thread-safe; must first run outside stream capture (ddk_unet_create and the
+// conv / wgrad entry points call it -- any warm-up call does).
+int ensure_device_init() {
+    static std::atomic<unsigned long long> done{0};
+    static std::mutex mu;
+    int dev = 0;
+    DDK_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) return fail_arg("device index out of range");
+    const unsigned long long bit = 1ull << dev;
+    if (done.load(std::memory_order_acquire) & bit) return DDK_OK;
+    std::lock_guard<std::mutex> lock(mu);
+    if (done.load(std::memory_order_relaxed) & bit) return DDK_OK;
+    DDK_TRY(conv_init_device());
+    DDK_TRY(wgrad_init_device());
+    done.fetch_or(bit, std::memory_order_release);
+    return DDK_OK;
+}
 }  // namespace ddk
 
-extern "C" int ddk_version(void) { return 100; }  // 0.1.0
+extern "C" int ddk_version(void) { return 200; }  // 0.2.0
 
 extern "C" const char* ddk_last_error(void) { return ddk::g_err; }
 

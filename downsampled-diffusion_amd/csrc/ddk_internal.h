@@ -110,6 +110,11 @@ __device__ __forceinline__ float block_max(float v, float* red) {
     return t;
 }
 
+// core.hip: per-device one-time setup; conv_igemm.hip / conv_wgrad.hip provide the per-file parts
+int ensure_device_init();
+int conv_init_device();
+int wgrad_init_device();
+
 // ---- internal launchers used by the UNet plan (same arithmetic as the public entry points) ----
 // conv_igemm.hip
 size_t conv_workspace_bytes(int kind, int B, int H, int W, int cin, int N);

@@ -171,6 +171,11 @@ extern "C" ddk_unet* ddk_unet_create(const ddk_unet_config* cfg) {
         set_error("unet_create: unet_dims[0] must be 1 (final Block(dim, dim), unet.py:69)");
         return nullptr;
     }
+    {   // best effort: a plan can be created on a host without a GPU (shape / FLOP queries); launches re-check
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) == hipSuccess && ndev > 0 && ensure_device_init() != DDK_OK) return nullptr;
+        (void)hipGetLastError();
+    }
     ddk_unet* u = new ddk_unet();
     u->cfg = *cfg;
     u->L = cfg->n_levels;
