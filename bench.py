@@ -41,23 +41,45 @@ def cfg4():
                 t_rec_max=100, force_latent=True, n_downsamples=3, dataset="celeba_hq", model="dddpm")
 
 
-def broadcast_model(model, rank, world):
-    """C1 of SURVEY.md section 2.1: rank 0's parameters + buffers go to every rank as ONE flat fp32 bucket over RCCL."""
-    import torch.distributed as dist
-    tensors = [t for t in model.state_dict().values() if t.dtype == torch.float32]
-    flat = torch.cat([t.reshape(-1) for t in tensors])
-    dist.broadcast(flat, src=0)
-    off = 0
-    with torch.no_grad():
-        for t in tensors:
-            t.copy_(flat[off:off + t.numel()].view_as(t))
-            off += t.numel()
-    return flat.numel() * 4
+HBM_PEAK_GBPS = 8000.0         # MI355X HBM3E spec peak (MI355X_MICROARCH.md; ~6300 GB/s achievable with a float4 copy)
+
+
+def graph_kernel_seconds(device, fn, n=50, reps=4):
+    """Average duration of ONE launch of `fn`'s kernel(s): n launches captured into a device graph and replayed, exactly how
+    the sampler issues them (back to back, no host in between), timed with HIP events recorded on the launch stream.
+    Launched one by one from the host each launch would carry a ~9 us dispatch gap that is not the kernel's."""
+    side = torch.cuda.Stream(device=device)
+    side.wait_stream(torch.cuda.current_stream(device))
+    with torch.cuda.stream(side):
+        fn()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            for _ in range(n):
+                fn()
+        graph.replay()
+        side.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(side)
+        for _ in range(reps):
+            graph.replay()
+        e1.record(side)
+        side.synchronize()
+    return e0.elapsed_time(e1) / 1e3 / (n * reps)
+
+
+def _profile_json(name):
+    try:
+        with open(os.path.join(ROOT, "profiles", name)) as f:
+            return json.load(f)
+    except Exception:   # noqa: BLE001 -- the profile file is optional evidence, never a reason to fail the bench
+        return None
 
 
 def time_conv_roofline(device):
-    """Dominant kernel: the 3x3 conv 128->128 @32x32, batch 32 (igemm 128x128 tile).  Average launch duration from
-    HIP events on the launch stream; algorithmic FLOPs = 2*B*H*W*9*Cin*Cout."""
+    """Dominant kernel: the 3x3 conv 128->128 @32x32, batch 32 (conv3x3_halo_kernel).  Launch duration measured live (HIP events
+    on the launch stream); algorithmic FLOPs = 2*B*H*W*9*Cin*Cout.  `traffic` (HBM/fabric bytes
+    per launch) and `mfma_busy` cannot be measured inside a timing loop: they come from separate rocprofv3 --pmc passes of
+    tools/conv_one.py on the same kernel and shape, committed under profiles/ (named in *_source)."""
     from ddk import ops
     B, H, W, C, N = 32, 32, 32, 128, 128
     g = torch.Generator(device="cpu").manual_seed(0)
@@ -68,42 +90,48 @@ def time_conv_roofline(device):
     for _ in range(5):
         ops.conv(ops.CONV3X3_S1, x, wp, b)
     torch.cuda.synchronize()
-    # 50 launches replayed as one device graph, exactly how the sampler issues them (back to back, no host in between):
-    # elapsed / 50 is then the kernel's own average duration, the figure rocprofv3 --kernel-trace reports for it.
-    # (Launched one by one from the host, each launch adds a ~9 us dispatch gap that is not the kernel's.)
-    n = 50
-    side = torch.cuda.Stream(device=device)
-    side.wait_stream(torch.cuda.current_stream(device))
-    with torch.cuda.stream(side):
-        y = ops.conv(ops.CONV3X3_S1, x, wp, b)
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, stream=side):
-            for _ in range(n):
-                y = ops.conv(ops.CONV3X3_S1, x, wp, b)
-        graph.replay()
-        side.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        reps = 4
-        e0.record(side)
-        for _ in range(reps):
-            graph.replay()
-        e1.record(side)
-        side.synchronize()
-    sec = e0.elapsed_time(e1) / 1e3 / (n * reps)
+    sec = graph_kernel_seconds(device, lambda: ops.conv(ops.CONV3X3_S1, x, wp, b))
     flops = 2.0 * B * H * W * 9 * C * N
     bytes_alg = 4.0 * (B * H * W * C + B * H * W * N + N * 9 * C)
-    # HBM/fabric bytes per launch come from a separate rocprofv3 --pmc run (FETCH_SIZE x2 + WRITE_SIZE, see
-    # profiles/r01_conv_pmc_traffic.json); a PMC pass cannot run inside this timing loop.
-    traffic = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_conv_pmc_traffic.json")) as f:
-            traffic = json.load(f)["traffic_bytes_per_launch"]
-    except Exception:
-        pass
-    return dict(kernel="conv3x3_halo_kernel conv3x3 128->128 @32x32 B=32 (fp32 MFMA, halo-tile implicit GEMM)", bound="mfma",
+    tr = _profile_json("r01_conv_pmc_traffic.json")
+    sq = _profile_json("r02_halo_pmc_sq.json")
+    return dict(kernel="conv3x3_halo_kernel<0> conv3x3 128->128 @32x32 B=32 (fp32 MFMA, halo-tile implicit GEMM)", bound="mfma",
                 achieved=flops / sec / 1e12, peak=FP32_PEAK_TFLOPS, unit="TFLOP/s", frac=flops / sec / 1e12 / FP32_PEAK_TFLOPS,
-                traffic=traffic, launch_us=sec * 1e6, algorithmic_gflop=flops / 1e9, algorithmic_mbytes=bytes_alg / 1e6,
+                traffic=tr["traffic_bytes_per_launch"] if tr else None,
+                traffic_source="profiles/r01_conv_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, fetch x2)" if tr else None,
+                mfma_busy=sq["mfma_busy"] if sq else None,
+                mfma_busy_source="profiles/r02_halo_pmc_sq.json (SQ_VALU_MFMA_BUSY_CYCLES / (SQ_BUSY_CYCLES/32 x 1024 SIMDs))" if sq else None,
+                launch_us=sec * 1e6, algorithmic_gflop=flops / 1e9, algorithmic_mbytes=bytes_alg / 1e6,
                 algorithmic_hbm_gbps=bytes_alg / sec / 1e9)
+
+
+def time_hbm_rooflines(device):
+    """Secondary rooflines (HBM-bound kernels of the step), live: GroupNorm+Mish(+time shift) on the 32x32 128-channel
+    tensor (8 B per element: one read, one write) and the fused reverse-step update with in-kernel Philox
+    noise (12 B per latent element: read x and eps_hat, write x)."""
+    from ddk import ops
+    out = []
+    B, H, W, C = 32, 32, 32, 128
+    x = torch.randn(B, H, W, C, device=device)
+    gam, bet = torch.ones(C, device=device), torch.zeros(C, device=device)
+    temb = torch.randn(B, C, device=device)
+    sec = graph_kernel_seconds(device, lambda: ops.groupnorm_mish(x, gam, bet, temb=temb))
+    nbytes = 8.0 * x.numel()
+    out.append(dict(kernel="gn_mish_resident_kernel<4,1024> GroupNorm(8)+Mish+time shift, 32x32x32x128", bound="hbm",
+                    achieved=nbytes / sec / 1e9, peak=HBM_PEAK_GBPS, unit="GB/s", frac=nbytes / sec / 1e9 / HBM_PEAK_GBPS,
+                    traffic=None, launch_us=sec * 1e6, algorithmic_mbytes=nbytes / 1e6))
+    Bz, S, Cz = 32, 32, 8
+    xs = torch.randn(Bz, S, S, Cz, device=device)
+    eps = torch.randn(Bz, S, S, Cz, device=device)
+    t = torch.full((Bz,), 500, device=device, dtype=torch.long)
+    tab = {k: torch.rand(1000, device=device) for k in ("c_recip", "c_recipm1", "c1", "c2", "sigma")}
+    sec = graph_kernel_seconds(device, lambda: ops.p_sample_update_(xs, eps, t, noise=None, seed=1, **tab))
+    nbytes = 12.0 * xs.numel()
+    out.append(dict(kernel="p_sample_kernel fused reverse-step update + Philox noise, 32x32x32x8 latents", bound="hbm",
+                    achieved=nbytes / sec / 1e9, peak=HBM_PEAK_GBPS, unit="GB/s", frac=nbytes / sec / 1e9 / HBM_PEAK_GBPS,
+                    traffic=None, launch_us=sec * 1e6, algorithmic_mbytes=nbytes / 1e6,
+                    note="3 MB per launch: the launch is at the ~2 us kernel-boundary floor, not on the HBM roof"))
+    return out
 
 
 def usable_cores():
@@ -120,27 +148,33 @@ def usable_cores():
     return max(1, min(n, int(os.environ.get("DDK_CPU_THREADS", "32"))))
 
 
-def cpu_baseline(cfg, state_dict):
-    """The CPU oracle (torch-CPU restatement, pinned to the reference by tests/golden) timed on the host cores:
-    1 warm + 3 timed UNet steps of the cfg4 shape at a reduced batch, extrapolated to T=1000."""
+def cpu_baseline(cfg, state_dict, batch):
+    """The CPU oracle (torch-CPU restatement, pinned to the reference by tests/golden) timed on the host cores on the SAME
+    work the GPU line measures: the cfg4 UNet step at the full batch (1 warm-up + 2 timed steps, extrapolated to T=1000)
+    plus one pass of the x3 ConvResNet decoder + tanh at the full batch."""
+    from oracle import resampler_ref as R
     from oracle import unet_ref as U
     from utils import synthetic as syn
     cores = usable_cores()
     torch.set_num_threads(cores)
-    bcpu = 8
-    sd = {k[len("latent_model."):]: v.detach().cpu() for k, v in state_dict.items() if k.startswith("latent_model.")}
-    x = syn.synthetic_normal((bcpu, 8, 32, 32), "bench.cpu.x")
-    t = torch.full((bcpu,), 500, dtype=torch.long)
+    sd_all = {k: v.detach().cpu() for k, v in state_dict.items()}
+    sd = {k[len("latent_model."):]: v for k, v in sd_all.items() if k.startswith("latent_model.")}
+    x = syn.synthetic_normal((batch, 8, 32, 32), "bench.cpu.x")
+    t = torch.full((batch,), 500, dtype=torch.long)
     with torch.no_grad():
         U.unet_forward(sd, cfg, x, t)
         t0 = time.perf_counter()
-        reps = 3
+        reps = 2
         for _ in range(reps):
             U.unet_forward(sd, cfg, x, t)
         dt = (time.perf_counter() - t0) / reps
-    return dict(value=bcpu / (T_STEPS * dt), unit="images/sec", cores=torch.get_num_threads(), kind="port",
-                sample=f"1 warm-up + {reps} timed UNet steps (8x32x32 latents, batch {bcpu}, {dt * 1e3:.0f} ms/step) "
-                       f"extrapolated to T={T_STEPS}; decoder excluded")
+        t1 = time.perf_counter()
+        img = R.rescaled_upsample(sd_all, cfg, torch.tanh(x))
+        t_dec = time.perf_counter() - t1
+    assert img.shape == (batch, 3, 256, 256)
+    return dict(value=batch / (T_STEPS * dt + t_dec), unit="images/sec", cores=torch.get_num_threads(), kind="port",
+                sample=f"1 warm-up + {reps} timed UNet steps (8x32x32 latents, batch {batch}, {dt * 1e3:.0f} ms/step) extrapolated to "
+                       f"T={T_STEPS}, + one decoder pass at batch {batch} ({t_dec:.1f} s)")
 
 
 def train_step_ms(device, steps=5):
@@ -213,7 +247,8 @@ def main():
     if rank == 0:
         model.load_state_dict(syn.fill_state_dict(model.state_dict(), skip=syn.SCHEDULE_KEYS))
     model = model.to(device).eval()
-    bcast_bytes = broadcast_model(model, rank, world) if world > 1 else 0
+    from parallel import dist as pdist
+    bcast_bytes = pdist.broadcast_module_(model, src=0) if world > 1 else 0   # C1: one flat fp32 bucket over RCCL
     model.rng_stream_id = rank
     model.use_graph = not args.no_graph
 
@@ -268,6 +303,7 @@ def main():
 
     if rank == 0:
         roof = time_conv_roofline(device)
+        roof_hbm = time_hbm_rooflines(device)
         out = {
             "metric": "images/sec (T=1000 sampling), 256x256 dDDPM-x3",
             "value": images_per_sec, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -281,6 +317,7 @@ def main():
                        "unet_frac_of_fp32_peak": flops_step / t_step / 1e12 / FP32_PEAK_TFLOPS,
                        "weights_broadcast_bytes": bcast_bytes},
             "roofline": roof,
+            "roofline_hbm": roof_hbm,
         }
         if world == 1 and not args.no_train:
             try:
@@ -289,7 +326,7 @@ def main():
                 out["config"]["train_step_ms_cfg3_bs64"] = None
                 log(f"training-step timing failed: {type(e).__name__}: {e}")
         if world == 1 and not args.no_cpu_baseline:          # reported baseline: rank 0 at N=1 only
-            out["cpu_baseline"] = cpu_baseline(cfg, model.state_dict())
+            out["cpu_baseline"] = cpu_baseline(cfg, model.state_dict(), B)
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.barrier()

@@ -375,8 +375,10 @@ __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)
 //   iteration k:  s_waitcnt vmcnt((NS-2)*PW)   this wave's pieces of chunk k have landed (PW pieces per wave and chunk)
 //                 s_barrier                    everyone's have; everyone is done reading stage (k-1) % NS
 //                 4 quarters of { prefetch next fragments | MFMA | issue PW/4 pieces of chunk k+NS-1 into stage (k-1) % NS | MFMAs }
-template <int BM, int BN, int WM, int WN, int NS>
+template <int BM, int BN, int WM, int WN, int NS, int DBG = 0>   // DBG = 1: timeline stamps (DDK_TUNING build, DDK_DEBUG & 32)
 __global__ __launch_bounds__(WM* WN * 64) void igemm_dma_kernel(const IgemmParams p) {
+    unsigned long long r_entry = 0;
+    if (DBG) r_entry = __builtin_amdgcn_s_memrealtime();
     constexpr int NW = WM * WN;
     constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
     constexpr int A_PW = BM / 8 / NW, B_PW = BN / 8 / NW;  // 1-KiB DMA pieces per wave per stage
@@ -520,6 +522,8 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_dma_kernel(const IgemmParam
             for (int j = 0; j < PW; ++j) issue_piece(j);
         }
     consume_epilogue_args(p);
+    unsigned long long r0 = 0, t0 = 0;
+    if (DBG) { r0 = __builtin_amdgcn_s_memrealtime(); t0 = __builtin_amdgcn_s_memtime(); asm volatile("" ::"s"(r0), "s"(t0), "s"(r_entry)); }
     int stage = 0, istage = NS - 1;      // stage being multiplied, stage the next issued chunk goes to
     for (int k = 0; k < n_it; ++k) {
         // chunks k+1 .. min(k+NS-2, n_it-1) may still fly; in the last NS-2 iterations (nothing left to issue) wait for all
@@ -527,17 +531,6 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_dma_kernel(const IgemmParam
         else wait_vmcnt<0>();
         __syncthreads();
         const bool more = k + NS - 1 < n_it;     // wave-uniform
-        if (more) begin_chunk(istage);
-        if (ln_fold) {   // per-row sum / sum of squares of the staged A chunk (the swizzle only permutes a row's floats)
-            constexpr int TPR = NW * 64 / BM, F4 = 8 / TPR;      // threads per row, float4 per thread
-            const float4* rowp = reinterpret_cast<const float4*>(smem + stage * STAGE + (tid / TPR) * 32) + (tid % TPR) * F4;
-#pragma unroll
-            for (int i = 0; i < F4; ++i) {
-                const float4 v = rowp[i];
-                ln_s += (v.x + v.y) + (v.z + v.w);
-                ln_q += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
-            }
-        }
         const float* As = smem + stage * STAGE + a_base;
         const float* Bs = smem + stage * STAGE + b_base;
         float4 a[2][TM], b[2][TN];
@@ -556,14 +549,28 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_dma_kernel(const IgemmParam
             }
             __builtin_amdgcn_sched_barrier(0);  // keep the prefetch above the MFMAs (hipcc otherwise sinks it to first use)
             // e outermost: consecutive MFMAs go to different accumulators (round-robin over the TM*TN tiles).
-            // The first MFMA of the quarter goes out alone, then this quarter's share of the next chunk's DMA pieces is
-            // issued in its shadow, then the rest.
+            // The first MFMA of the quarter goes out alone; everything that is not an MFMA or a fragment read -- the
+            // wave-uniform bookkeeping of the next chunk to issue (quarter 0), this quarter's share of its DMA pieces, the
+            // LayerNorm row statistics -- is placed in its shadow, then the rest of the MFMAs follow.  (With that work in
+            // front of the first MFMA, right after the barrier, a 64x64 tile spent 1600-1750 cycles per chunk for
+            // 1024 cycles of MFMA: tools/conv_clock.py.)
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][0].x, b[cur][0].x, acc[0][0], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             if (more) {
+                if (q == 0) begin_chunk(istage);
 #pragma unroll
                 for (int j = 0; j < PW; ++j)
                     if ((j * 4) / PW == q) issue_piece(j);
+            }
+            if (q == 0 && ln_fold) {   // per-row sum / sum of squares of the staged A chunk (the swizzle only permutes a row's floats)
+                constexpr int TPR = NW * 64 / BM, F4 = 8 / TPR;      // threads per row, float4 per thread
+                const float4* rowp = reinterpret_cast<const float4*>(smem + stage * STAGE + (tid / TPR) * 32) + (tid % TPR) * F4;
+#pragma unroll
+                for (int i = 0; i < F4; ++i) {
+                    const float4 v = rowp[i];
+                    ln_s += (v.x + v.y) + (v.z + v.w);
+                    ln_q += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -581,6 +588,8 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_dma_kernel(const IgemmParam
         stage = stage + 1 == NS ? 0 : stage + 1;
         istage = istage + 1 == NS ? 0 : istage + 1;
     }
+    unsigned long long r1 = 0, t1 = 0;
+    if (DBG) { r1 = __builtin_amdgcn_s_memrealtime(); t1 = __builtin_amdgcn_s_memtime(); }
 
     __syncthreads();   // every wave is done reading the ring: its LDS now stages the output block
     constexpr int EPI_FLOATS = TM * 32 * (TN * 32 + 8);
@@ -602,6 +611,18 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_dma_kernel(const IgemmParam
     }
     store_block_via_lds<TM, TN>(p, acc, smem + wid * EPI_FLOATS, lane, m0 + wm * TM * 32, n0 + wn * TN * 32, split, phase,
                                 rowstat ? rowstat + 2 * wm * TM * 32 : nullptr);
+    if (DBG && tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int wg = (blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) & 2047;
+        g_stamps[wg * 8 + 0] = t1 - t0;          // shader cycles in the k-loop
+        g_stamps[wg * 8 + 1] = r1 - r0;          // 100 MHz ticks in the k-loop
+        g_stamps[wg * 8 + 2] = (unsigned long long)n_it;
+        g_stamps[wg * 8 + 3] = 1;
+        g_stamps[wg * 8 + 4] = r_entry;          // absolute: kernel entry
+        g_stamps[wg * 8 + 5] = r0;               // absolute: loop start
+        g_stamps[wg * 8 + 6] = r1;               // absolute: loop end
+        g_stamps[wg * 8 + 7] = __builtin_amdgcn_s_memrealtime();   // absolute: this wave's stores drained
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1163,6 +1184,13 @@ static ConvPlan plan_conv(int kind, int B, int H, int W, int cin, int N, const G
     return {false, choose_tile((long long)B * g.Hm * g.Wm, N, g.nphase, g.ntaps * (cin / 32))};
 }
 
+// Kernels that need more dynamic LDS than the default 64 KB limit must be told so once per device, outside any stream
+// capture: ensure_device_init() (core.hip) runs this the first time a device is used (ddk_unet_create, every conv entry).
+template <typename K>
+static int allow_lds(K kernel, size_t bytes) {
+    DDK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return DDK_OK;
+}
 template <int BM, int BN, int WM, int WN, int NS>
 constexpr size_t dma_lds_bytes() {
     constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
@@ -1175,6 +1203,14 @@ constexpr size_t reg_lds_bytes(int bm, int bn) { return 2 * (size_t)(bm + bn) * 
 template <int BM, int BN, int WM, int WN, int NS>
 static int launch_dma(const IgemmParams& p, hipStream_t st) {
     dim3 grid((unsigned)ceil_div(p.M, BM), (unsigned)ceil_div(p.N, BN), (unsigned)(p.nphase * p.splits));
+#ifdef DDK_TUNING
+    if (p.debug & 32) {
+        static bool once = false;   // tuning build only
+        if (!once) { DDK_TRY(allow_lds(&igemm_dma_kernel<BM, BN, WM, WN, NS, 1>, dma_lds_bytes<BM, BN, WM, WN, NS>())); once = true; }
+        hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, NS, 1>), grid, dim3(WM * WN * 64), (dma_lds_bytes<BM, BN, WM, WN, NS>()), st, p);
+        return check_launch("igemm_dma_kernel<dbg>");
+    }
+#endif
     hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, NS>), grid, dim3(WM * WN * 64), (dma_lds_bytes<BM, BN, WM, WN, NS>()), st, p);
     return check_launch("igemm_dma_kernel");
 }
@@ -1205,13 +1241,6 @@ static int launch_tile(const IgemmParams& p, const Choice& c, hipStream_t st) {
     }
 }
 
-// Kernels that need more dynamic LDS than the default 64 KB limit must be told so once per device, outside any stream
-// capture: ensure_device_init() (core.hip) runs this the first time a device is used (ddk_unet_create, every conv entry).
-template <typename K>
-static int allow_lds(K kernel, size_t bytes) {
-    DDK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-    return DDK_OK;
-}
 int conv_init_device() {
 #define HALO_ATTR(V) DDK_TRY(allow_lds(&conv3x3_halo_kernel<V>, (size_t)HALO_LDS_FLOATS * sizeof(float)));
     DDK_HALO_VARIANTS(HALO_ATTR)

@@ -158,7 +158,8 @@ int conv1x1_small_n(const float* x, const float* w, const float* bias, float* ou
 // diffusion.hip
 int p_sample_update(float* x, const float* eps_hat, const float* noise, long long noise_step_stride, int t_first,
                     const int64_t* t, const float* c_recip, const float* c_recipm1, const float* c1, const float* c2,
-                    const float* sigma, int B, long long per, uint64_t seed, uint32_t stream_id, hipStream_t st);
+                    const float* sigma, int B, long long per, uint64_t seed, uint32_t stream_id, hipStream_t st,
+                    const int64_t* chain_state = nullptr);
 int randn(float* out, long long n, uint64_t seed, uint32_t step, uint32_t stream_id, hipStream_t st);
 
 }  // namespace ddk

@@ -93,7 +93,11 @@ __global__ __launch_bounds__(256) void p_sample_kernel(float* __restrict__ x, co
                                                        const float* __restrict__ c_recip, const float* __restrict__ c_recipm1,
                                                        const float* __restrict__ c1, const float* __restrict__ c2,
                                                        const float* __restrict__ sigma, long long per4, long long total4,
-                                                       uint64_t seed, uint32_t stream) {
+                                                       uint64_t seed, uint32_t stream, const int64_t* __restrict__ chain_state) {
+    if (chain_state) {   // sampler: the Philox key lives in device memory, so one captured graph serves every seed
+        seed = (uint64_t)chain_state[1];
+        stream = (uint32_t)chain_state[2];
+    }
     for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total4; i += (long long)gridDim.x * 256) {
         const int64_t tb = t[i / per4];
         const float cr = c_recip[tb], crm1 = c_recipm1[tb], a1 = c1[tb], a2 = c2[tb];
@@ -129,13 +133,14 @@ __global__ __launch_bounds__(1024) void sq_err_sum_kernel(const float* __restric
 
 int p_sample_update(float* x, const float* eps_hat, const float* noise, long long noise_step_stride, int t_first,
                     const int64_t* t, const float* c_recip, const float* c_recipm1, const float* c1, const float* c2,
-                    const float* sigma, int B, long long per, uint64_t seed, uint32_t stream_id, hipStream_t st) {
+                    const float* sigma, int B, long long per, uint64_t seed, uint32_t stream_id, hipStream_t st,
+                    const int64_t* chain_state) {
     DDK_REQUIRE(x && eps_hat && t && c_recip && c_recipm1 && c1 && c2 && sigma, "p_sample_update: null pointer");
     DDK_REQUIRE(B > 0 && per > 0 && per % 4 == 0, "p_sample_update: per-sample element count must be a multiple of 4");
     DDK_REQUIRE(aligned16(x) && aligned16(eps_hat) && aligned16(noise) && noise_step_stride % 4 == 0, "p_sample_update: alignment");
     const long long total4 = B * per / 4;
     hipLaunchKernelGGL(p_sample_kernel, dim3(grid1d(total4)), dim3(256), 0, st, x, eps_hat, noise, noise_step_stride, t_first, t,
-                       c_recip, c_recipm1, c1, c2, sigma, per / 4, total4, seed, stream_id);
+                       c_recip, c_recipm1, c1, c2, sigma, per / 4, total4, seed, stream_id, chain_state);
     return check_launch("p_sample_kernel");
 }
 

@@ -9,6 +9,7 @@
 // arithmetic step is a HIP kernel from the other translation units.  The sampler captures one reverse step
 // (t bookkeeping + UNet + x update) into a hipGraph and replays it, so the T-step loop costs one
 // hipGraphLaunch per step on the host.
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -58,7 +59,25 @@ struct AttnW {
 
 using namespace ddk;
 
+// One captured reverse step.  A hipGraph bakes in every pointer its kernels were launched with, so an entry is valid for
+// exactly this set of buffers and this shape; t, the Philox seed / stream id and the injected-noise step index are read
+// from device memory by the kernels, so the same graph serves every step of every chain on those buffers.
+struct SamplerGraph {
+    const void *packed, *x, *noise, *ws, *c_recip, *c_recipm1, *c1, *c2, *sigma;
+    int B, H, W, t_start, device;
+    unsigned long long pack_epoch;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    unsigned long long last_use = 0;
+};
+
 struct ddk_unet {
+    // sampler state cached across ddk_sampler_run calls (guarded by `mu`; see ddk_sampler_invalidate)
+    std::mutex mu;
+    std::vector<SamplerGraph> graphs;
+    unsigned long long use_clock = 0;
+    unsigned long long pack_epoch = 0;       // bumped by every pack / finalize: weights changed
+    struct { const void* ws = nullptr; int t_start = -1, B = 0, H = 0, W = 0; unsigned long long pack_epoch = 0; } table;
     ddk_unet_config cfg;
     std::vector<Slot> slots;
     size_t packed_floats = 0;
@@ -228,7 +247,31 @@ extern "C" ddk_unet* ddk_unet_create(const ddk_unet_config* cfg) {
     return u;
 }
 
-extern "C" void ddk_unet_destroy(ddk_unet* u) { delete u; }
+static void drop_graphs(ddk_unet* u) {   // caller holds u->mu (or owns u exclusively)
+    for (SamplerGraph& g : u->graphs) {
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+        if (g.graph) (void)hipGraphDestroy(g.graph);
+    }
+    u->graphs.clear();
+    u->table.ws = nullptr;
+}
+
+/* Destroying a plan that has captured sampler graphs waits for the device first (an executable graph must outlive its
+   in-flight launches). */
+extern "C" void ddk_unet_destroy(ddk_unet* u) {
+    if (!u) return;
+    if (!u->graphs.empty()) (void)hipDeviceSynchronize();
+    drop_graphs(u);
+    delete u;
+}
+
+extern "C" int ddk_sampler_invalidate(ddk_unet* u) {
+    DDK_REQUIRE(u, "sampler_invalidate: null plan");
+    std::lock_guard<std::mutex> lock(u->mu);
+    if (!u->graphs.empty()) DDK_HIP(hipDeviceSynchronize());
+    drop_graphs(u);
+    return DDK_OK;
+}
 extern "C" int ddk_unet_num_slots(const ddk_unet* u) { return u ? (int)u->slots.size() : 0; }
 extern "C" const char* ddk_unet_slot_name(const ddk_unet* u, int slot) {
     return (u && slot >= 0 && slot < (int)u->slots.size()) ? u->slots[slot].name.c_str() : nullptr;
@@ -264,8 +307,15 @@ static int fold_attn(const AttnW& a, float* P, hipStream_t st) {
 // Derived weights of every attention site.  ddk_unet_pack_slot already re-derives a site's weights whenever one of its three
 // source slots is packed (so a caller that packs every slot, in any order, ends up consistent); this entry point re-derives
 // all of them explicitly, e.g. after writing into the packed arena by other means.
+static void weights_changed(const ddk_unet* u) {
+    ddk_unet* m = const_cast<ddk_unet*>(u);      // the cache bookkeeping is logically mutable
+    std::lock_guard<std::mutex> lock(m->mu);
+    ++m->pack_epoch;
+}
+
 extern "C" int ddk_unet_finalize_pack(const ddk_unet* u, void* packed, ddk_stream_t s) {
     DDK_REQUIRE(u && packed, "unet_finalize_pack: arguments");
+    weights_changed(u);
     for (const AttnW& a : u->attn_all) DDK_TRY(fold_attn(a, static_cast<float*>(packed), as_stream(s)));
     return DDK_OK;
 }
@@ -274,6 +324,7 @@ extern "C" int ddk_unet_pack_slot(const ddk_unet* u, int slot, const float* cano
     DDK_REQUIRE(u && canonical && packed && slot >= 0 && slot < (int)u->slots.size(), "unet_pack_slot: arguments");
     const Slot& sl = u->slots[slot];
     float* dst = static_cast<float*>(packed) + sl.off;
+    weights_changed(u);
     int rc;
     switch (sl.kind) {
         case PK_COPY:
@@ -550,7 +601,12 @@ static int check_shape(const ddk_unet* u, int B, int H, int W) {
 }
 
 // sampler bookkeeping kernels ----------------------------------------------------------------------
-__global__ void set_counter_kernel(int64_t* counter, int64_t v) { *counter = v; }
+// per-chain state the captured step reads from memory: [0] step counter, [1] Philox seed, [2] Philox stream id
+__global__ void set_chain_state_kernel(int64_t* state, int64_t t_start, uint64_t seed, uint32_t stream_id) {
+    state[0] = t_start;
+    state[1] = (int64_t)seed;
+    state[2] = (int64_t)stream_id;
+}
 
 // t_cur[b] = counter for every sample, then counter -= 1; also zero-pads x into xpad.  First kernel of a
 // step: the previous step's kernels have all completed (stream order), nobody else reads the counter.
@@ -633,7 +689,7 @@ static SamplerLayout sampler_layout(const ddk_unet& u, int B, int H, int W, int 
     s.unet_floats = make_layout(u, B, H, W).total;
     s.off_eps = s.unet_floats;
     s.off_t = s.off_eps + al4((size_t)B * H * W * u.cfg.in_ch);
-    s.off_table = s.off_t + al4(2 * (size_t)(B + 1));  // int64 t_cur[B] + counter, in float units
+    s.off_table = s.off_t + al4(2 * (size_t)(B + 3));  // int64 t_cur[B] + chain state {counter, seed, stream id}, in float units
     s.off_tact_all = s.off_table + al4(rows * u.temb_total);
     s.off_tall = s.off_tact_all + al4(rows * u.time_dim);
     s.total = s.off_tall + al4(2 * rows);
@@ -654,7 +710,7 @@ extern "C" size_t ddk_sampler_workspace_bytes(const ddk_unet* u, int B, int H, i
 extern "C" int ddk_sampler_run(const ddk_sampler_args* a, ddk_stream_t s) {
     DDK_REQUIRE(a && a->unet && a->packed && a->x && a->workspace, "sampler: null pointer");
     DDK_REQUIRE(a->c_recip && a->c_recipm1 && a->c1 && a->c2 && a->sigma, "sampler: null schedule table");
-    const ddk_unet& u = *a->unet;
+    ddk_unet& u = *const_cast<ddk_unet*>(a->unet);     // the graph / table cache is logically mutable state of the plan
     DDK_TRY(check_shape(&u, a->B, a->H, a->W));
     DDK_REQUIRE(a->t_start >= a->t_end && a->t_end >= 0, "sampler: need t_start >= t_end >= 0");
     DDK_REQUIRE(aligned16(a->packed) && aligned16(a->workspace) && aligned16(a->x) && aligned16(a->noise), "sampler: alignment");
@@ -666,12 +722,13 @@ extern "C" int ddk_sampler_run(const ddk_sampler_args* a, ddk_stream_t s) {
         set_error("sampler: workspace too small (%zu < %zu)", a->workspace_bytes, sl.total * sizeof(float));
         return DDK_ERR_WORKSPACE;
     }
+    DDK_TRY(ensure_device_init());
     const Layout ly = make_layout(u, B, H, W);
     hipStream_t st = as_stream(s);
     float* ws = static_cast<float*>(a->workspace);
     float* eps_hat = ws + sl.off_eps;
     int64_t* t_cur = reinterpret_cast<int64_t*>(ws + sl.off_t);
-    int64_t* counter = t_cur + B;
+    int64_t* state = t_cur + B;                        // [0] step counter, [1] seed, [2] stream id
     float* xpad = ws + ly.off_xpad;
     const float* P = static_cast<const float*>(a->packed);
     const float* temb_table = ws + sl.off_table;
@@ -679,16 +736,21 @@ extern "C" int ddk_sampler_run(const ddk_sampler_args* a, ddk_stream_t s) {
     const int prep_blocks = (int)(ceil_div(padded, 256) < 1024 ? ceil_div(padded, 256) : 1024);
 
     auto one_step = [&]() -> int {
-        hipLaunchKernelGGL(step_prepare_kernel, dim3(prep_blocks), dim3(256), 0, st, a->x, xpad, padded, C, cp, counter, t_cur, B);
+        hipLaunchKernelGGL(step_prepare_kernel, dim3(prep_blocks), dim3(256), 0, st, a->x, xpad, padded, C, cp, state, t_cur, B);
         DDK_TRY(check_launch("step_prepare_kernel"));
         DDK_TRY(forward_core(u, P, xpad, t_cur, eps_hat, B, H, W, ws, ly, st, temb_table));
         return p_sample_update(a->x, eps_hat, a->noise, a->noise ? B * per : 0, a->t_start, t_cur, a->c_recip, a->c_recipm1, a->c1,
-                               a->c2, a->sigma, B, per, a->seed, a->stream_id, st);
+                               a->c2, a->sigma, B, per, 0, 0, st, state);
     };
 
-    hipLaunchKernelGGL(set_counter_kernel, dim3(1), dim3(1), 0, st, counter, (int64_t)a->t_start);
-    DDK_TRY(check_launch("set_counter_kernel"));
-    {   // time-shift table for t = 0..t_start: the same two kernels a forward runs, once, with "batch" = all timesteps
+    std::lock_guard<std::mutex> lock(u.mu);
+    hipLaunchKernelGGL(set_chain_state_kernel, dim3(1), dim3(1), 0, st, state, (int64_t)a->t_start, a->seed, a->stream_id);
+    DDK_TRY(check_launch("set_chain_state_kernel"));
+    // Time-shift table for t = 0..t_start: the same two kernels a forward runs, once, with "batch" = all timesteps.  It
+    // lives in the caller's workspace and stays valid while neither the weights (pack_epoch) nor the workspace change;
+    // a caller that rewrites or frees the workspace between calls says so with ddk_sampler_invalidate().
+    if (!(u.table.ws == a->workspace && u.table.t_start == a->t_start && u.table.B == B && u.table.H == H && u.table.W == W &&
+          u.table.pack_epoch == u.pack_epoch)) {
         const int rows = a->t_start + 1;
         int64_t* t_all = reinterpret_cast<int64_t*>(ws + sl.off_tall);
         float* tact_all = ws + sl.off_tact_all;
@@ -696,44 +758,66 @@ extern "C" int ddk_sampler_run(const ddk_sampler_args* a, ddk_stream_t s) {
         DDK_TRY(check_launch("iota64_kernel"));
         DDK_TRY(time_mlp(t_all, P + u.freqs, P + u.w1t, P + u.b1, P + u.w2t, P + u.b2, tact_all, nullptr, rows, u.time_dim, st));
         DDK_TRY(time_proj(tact_all, P + u.temb_wt, P + u.temb_bias, ws + sl.off_table, rows, u.time_dim, u.temb_total, st));
+        u.table.ws = a->workspace; u.table.t_start = a->t_start; u.table.B = B; u.table.H = H; u.table.W = W;
+        u.table.pack_epoch = u.pack_epoch;
     }
     const int n_steps = a->t_start - a->t_end + 1;
-    // first step eagerly: it also performs the one-time per-kernel attribute setup that must not run under capture
-    DDK_TRY(one_step());
-    if (n_steps == 1) return DDK_OK;
-    if (!a->use_graph) {
-        for (int k = 1; k < n_steps; ++k) DDK_TRY(one_step());
+    if (!a->use_graph || n_steps == 1) {
+        for (int k = 0; k < n_steps; ++k) DDK_TRY(one_step());
         return DDK_OK;
     }
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t exec = nullptr;
-    hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
-    if (e != hipSuccess) {
-        set_error("sampler: hipStreamBeginCapture failed (%s); the legacy NULL stream cannot be captured -- pass a created stream",
-                  hipGetErrorString(e));
-        return DDK_ERR_HIP;
+
+    int dev = 0;
+    DDK_HIP(hipGetDevice(&dev));
+    SamplerGraph* hit = nullptr;
+    for (SamplerGraph& g : u.graphs)
+        if (g.packed == a->packed && g.x == a->x && g.noise == a->noise && g.ws == a->workspace && g.c_recip == a->c_recip &&
+            g.c_recipm1 == a->c_recipm1 && g.c1 == a->c1 && g.c2 == a->c2 && g.sigma == a->sigma && g.B == B && g.H == H &&
+            g.W == W && g.t_start == a->t_start && g.device == dev && g.pack_epoch == u.pack_epoch) {
+            hit = &g;
+            break;
+        }
+    int first = 0;
+    if (!hit) {
+        // New buffer set: run the first step eagerly, capture the second, keep the executable graph in the plan.
+        if (u.graphs.size() >= 4) {      // bounded cache: retire the least recently used entry (its launches must have drained)
+            size_t lru = 0;
+            for (size_t i = 1; i < u.graphs.size(); ++i)
+                if (u.graphs[i].last_use < u.graphs[lru].last_use) lru = i;
+            DDK_HIP(hipDeviceSynchronize());
+            (void)hipGraphExecDestroy(u.graphs[lru].exec);
+            (void)hipGraphDestroy(u.graphs[lru].graph);
+            u.graphs.erase(u.graphs.begin() + (long)lru);
+        }
+        DDK_TRY(one_step());
+        first = 1;
+        SamplerGraph g{};
+        g.packed = a->packed; g.x = a->x; g.noise = a->noise; g.ws = a->workspace; g.c_recip = a->c_recip; g.c_recipm1 = a->c_recipm1;
+        g.c1 = a->c1; g.c2 = a->c2; g.sigma = a->sigma; g.B = B; g.H = H; g.W = W; g.t_start = a->t_start; g.device = dev;
+        g.pack_epoch = u.pack_epoch;
+        hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+        if (e != hipSuccess) {
+            set_error("sampler: hipStreamBeginCapture failed (%s); the legacy NULL stream cannot be captured -- pass a created stream",
+                      hipGetErrorString(e));
+            return DDK_ERR_HIP;
+        }
+        const int rc = one_step();
+        e = hipStreamEndCapture(st, &g.graph);
+        if (rc != DDK_OK) { if (g.graph) (void)hipGraphDestroy(g.graph); return rc; }
+        if (e != hipSuccess) { set_error("sampler: hipStreamEndCapture: %s", hipGetErrorString(e)); return DDK_ERR_HIP; }
+        e = hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0);
+        if (e != hipSuccess) {
+            (void)hipGraphDestroy(g.graph);
+            set_error("sampler: hipGraphInstantiate: %s", hipGetErrorString(e));
+            return DDK_ERR_HIP;
+        }
+        u.graphs.push_back(g);
+        hit = &u.graphs.back();
     }
-    int rc = one_step();
-    e = hipStreamEndCapture(st, &graph);
-    if (rc != DDK_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
-    if (e != hipSuccess) { set_error("sampler: hipStreamEndCapture: %s", hipGetErrorString(e)); return DDK_ERR_HIP; }
-    e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-    if (e != hipSuccess) {
-        (void)hipGraphDestroy(graph);
-        set_error("sampler: hipGraphInstantiate: %s", hipGetErrorString(e));
-        return DDK_ERR_HIP;
+    hit->last_use = ++u.use_clock;
+    for (int k = first; k < n_steps; ++k) {
+        const hipError_t e = hipGraphLaunch(hit->exec, st);
+        if (e != hipSuccess) { set_error("sampler: hipGraphLaunch: %s", hipGetErrorString(e)); return DDK_ERR_HIP; }
     }
-    rc = DDK_OK;
-    for (int k = 1; k < n_steps; ++k) {
-        e = hipGraphLaunch(exec, st);
-        if (e != hipSuccess) { set_error("sampler: hipGraphLaunch: %s", hipGetErrorString(e)); rc = DDK_ERR_HIP; break; }
-    }
-    // The exec object must outlive its in-flight launches: wait for this stream's work only.
-    if (rc == DDK_OK) {
-        e = hipStreamSynchronize(st);
-        if (e != hipSuccess) { set_error("sampler: hipStreamSynchronize: %s", hipGetErrorString(e)); rc = DDK_ERR_HIP; }
-    }
-    (void)hipGraphExecDestroy(exec);
-    (void)hipGraphDestroy(graph);
-    return rc;
+    return DDK_OK;
 }

@@ -91,6 +91,7 @@ SIGNATURES = {
     "ddk_unet_flops": (C.c_double, [_P, _I, _I, _I]),
     "ddk_sampler_workspace_bytes": (_SZ, [_P, _I, _I, _I, _I]),
     "ddk_sampler_run": (_I, [C.POINTER(SamplerArgs), _P]),
+    "ddk_sampler_invalidate": (_I, [_P]),
     "ddk_pack_conv_weight_dgrad": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "ddk_zero_stuff2": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "ddk_conv_wgrad_workspace_bytes": (_SZ, [_I, _I, _I, _I, _I, _I]),

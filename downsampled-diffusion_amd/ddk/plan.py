@@ -32,8 +32,8 @@ class UnetPlan:
         self.slot_names = [lib.ddk_unet_slot_name(self.handle, i).decode() for i in range(lib.ddk_unet_num_slots(self.handle))]
         self.slot_numel = [lib.ddk_unet_slot_numel(self.handle, i) for i in range(len(self.slot_names))]
         self.packed = None
-        self._ws = None
-        self._ws_key = None
+        self._ws = {}          # kind -> (key, tensor); the sampler workspace is its own buffer: cached graphs point into it
+        self._state = {}       # chain state x per (shape, device): a stable address for the captured sampler graph
 
     def __deepcopy__(self, memo):
         return None     # a copied module (EMA) builds its own native plan on first use
@@ -41,7 +41,7 @@ class UnetPlan:
     def __del__(self):
         try:
             if getattr(self, "handle", None):
-                self._lib.ddk_unet_destroy(self.handle)
+                self._lib.ddk_unet_destroy(self.handle)    # waits for the device if sampler graphs are cached
                 self.handle = None
         except Exception:
             pass
@@ -71,11 +71,15 @@ class UnetPlan:
 
     # ---------------------------------------------------------------- forward
     def _workspace(self, kind, nbytes, device):
-        key = (kind, nbytes, str(device))
-        if self._ws_key != key:
-            self._ws = torch.empty(max(nbytes, 16) // 4 + 4, device=device, dtype=torch.float32)
-            self._ws_key = key
-        return self._ws
+        key = (nbytes, str(device))
+        hit = self._ws.get(kind)
+        if hit is None or hit[0] != key:
+            if kind == "smp" and hit is not None:
+                # the cached sampler graphs and the time-shift table live in / point into the old buffer
+                L.check(self._lib.ddk_sampler_invalidate(self.handle), "sampler_invalidate")
+            hit = (key, torch.empty(max(nbytes, 16) // 4 + 4, device=device, dtype=torch.float32))
+            self._ws[kind] = hit
+        return hit[1]
 
     def flops(self, b, h, w):
         return self._lib.ddk_unet_flops(self.handle, b, h, w)
@@ -117,6 +121,15 @@ class UnetPlan:
         n_steps = t_start - t_end + 1
         if noise is not None and tuple(noise.shape) != (n_steps, b, h, w, c):
             raise L.DDKError(f"injected noise must be {(n_steps, b, h, w, c)}, got {tuple(noise.shape)}")
+        # The chain runs on a plan-owned state buffer: its address is what the captured graph holds, so the second and
+        # later calls for this shape only launch the cached graph (include/ddk.h, ddk_sampler_run).
+        skey = (tuple(x.shape), str(x.device))
+        state = self._state.get(skey)
+        if state is None:
+            state = self._state[skey] = torch.empty_like(x)
+        if state.data_ptr() != x.data_ptr():
+            state.copy_(x)
+        caller_x, x = x, state
 
         def call(stream_ptr):
             a = L.SamplerArgs(self.handle, L.ptr(self.packed), L.ptr(x), L.ptr(noise), L.ptr(tables["c_recip"]),
@@ -134,7 +147,9 @@ class UnetPlan:
             cur.wait_stream(side)
         else:
             call(L.stream())
-        return x
+        if caller_x.data_ptr() != x.data_ptr():
+            caller_x.copy_(x)
+        return caller_x
 
 
 _side_streams = {}

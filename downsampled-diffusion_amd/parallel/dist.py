@@ -72,3 +72,13 @@ def all_reduce_flat_(flat, average=True):
     if average:
         flat.div_(dist.get_world_size())
     return flat
+
+
+def is_main_rank():
+    """True on rank 0 (and in single-process runs): the rank that writes checkpoints, losses and logs."""
+    return not (dist.is_available() and dist.is_initialized()) or dist.get_rank() == 0
+
+
+def barrier():
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()

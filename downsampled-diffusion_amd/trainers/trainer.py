@@ -5,6 +5,7 @@ import os
 import numpy as np
 import torch
 
+from parallel import is_main_rank
 from utils import LOGGING_DIR, reduce_mean
 from .optim import FusedAdam
 from .train_helpers import RunLogger
@@ -47,6 +48,8 @@ class Trainer(object):
         self.logger = None
 
     def save_losses(self) -> None:
+        if not is_main_rank():
+            return
         file_path = os.path.join(LOGGING_DIR, f'loss_{self.name}_{self.config["dataset"]}.json')
         print(f'Saving losses to file {file_path}')
         os.makedirs(LOGGING_DIR, exist_ok=True)
@@ -55,11 +58,22 @@ class Trainer(object):
 
     def init_wandb(self) -> None:
         """trainer.py:78-92 with the JSONL logger standing in for wandb (same resume-by-id behaviour)."""
-        self.logger = RunLogger(LOGGING_DIR, self.wandb_name, self.config, run_id=self.config.get('wandb_id'), enabled=not self.mute or True)
-        self.wandb_id = self.logger.id
+        # rank 0 owns the JSONL log and the checkpoint file; the run id is rank 0's, shared so every rank names the same paths
+        self.logger = RunLogger(LOGGING_DIR, self.wandb_name, self.config, run_id=self.config.get('wandb_id'), enabled=is_main_rank())
+        self.wandb_id = self._shared_run_id(self.logger.id)
+        self.logger.id = self.wandb_id
         self.config['wandb_id'] = self.wandb_id
         os.makedirs(LOGGING_DIR, exist_ok=True)
         self.checkpoint_name = os.path.join(LOGGING_DIR, f'checkpoint_{self.name}_{self.wandb_id}.pt')
+
+    @staticmethod
+    def _shared_run_id(run_id):
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            box = [run_id]
+            dist.broadcast_object_list(box, src=0)
+            return box[0]
+        return run_id
 
     def finalize(self) -> None:
         """trainer.py:94-99; the local checkpoint is KEPT (the reference deletes it after its wandb upload)."""

@@ -11,7 +11,7 @@ import os
 import numpy as np
 import torch
 
-from parallel import all_reduce_flat_
+from parallel import all_reduce_flat_, barrier, is_main_rank
 from utils import LOGGING_DIR, min_max_norm_image
 from .ema import EMA
 from .trainer import Trainer
@@ -50,6 +50,11 @@ class TrainerDDPM(Trainer):
 
     # ------------------------------------------------------------------ checkpoints (trainer_ddpm.py:49-72)
     def save_checkpoint(self) -> None:
+        """Rank 0 writes the file (every rank holds the identical replicated state after the all-reduced step); the others
+        wait at a barrier so nobody races ahead into a resume / the next save of the same path."""
+        if not is_main_rank():
+            barrier()
+            return
         save_data = {
             'optimizer': self.opt.state_dict(),
             'model': {k: v.detach().clone() for k, v in self.model.state_dict().items()},
@@ -59,9 +64,12 @@ class TrainerDDPM(Trainer):
         }
         if self.use_ema:
             save_data['ema_model'] = self.ema.state_dict()
-        torch.save(save_data, self.checkpoint_name)
+        tmp = self.checkpoint_name + '.tmp'
+        torch.save(save_data, tmp)
+        os.replace(tmp, self.checkpoint_name)          # never leave a half-written checkpoint behind
         if self.logger:
             self.logger.save(self.checkpoint_name, policy='live')
+        barrier()
 
     def load_checkpoint(self, checkpoint: dict) -> None:
         self.opt.load_state_dict(checkpoint['optimizer'])
@@ -84,6 +92,8 @@ class TrainerDDPM(Trainer):
     @torch.no_grad()
     def log_wandb(self, x, commit: bool = True) -> None:
         """trainer_ddpm.py:91-105: sample + reconstruction grids, stored as .npy (no torchvision / wandb offline)."""
+        if not is_main_rank():       # image logs are rank 0's job; the other ranks skip the T-step sampling too
+            return
         samples, recon = self.sample(), self.recon(x)
         samples = samples[0] if isinstance(samples, tuple) else samples
         recon = recon[0] if isinstance(recon, tuple) else recon

@@ -10,8 +10,10 @@
  *   - plain C: pointers are DEVICE pointers (16-byte aligned, dense), sizes are ints; no torch types.
  *   - activations are NHWC fp32 ("pixel-major": [B][H][W][C]); channel counts on the conv/GEMM
  *     kernels are multiples of 32 (pad with ddk_nchw_to_nhwc / ddk_pad_channels).
- *   - every call is asynchronous on `stream` (a hipStream_t), allocates nothing, never syncs;
- *     the caller owns all buffers including workspaces (sizes from the *_workspace_bytes calls).
+ *   - every call is asynchronous on `stream` (a hipStream_t), allocates no device memory, never syncs
+ *     (the two calls that drop cached hipGraphs, ddk_unet_destroy and ddk_sampler_invalidate, wait for
+ *     the device first); the caller owns all buffers including workspaces (sizes from the
+ *     *_workspace_bytes calls).
  *   - return 0 on success, negative on error; ddk_last_error() gives the message (thread local).
  */
 #ifndef DDK_H
@@ -215,7 +217,16 @@ typedef struct ddk_sampler_args {
 /* workspace of ddk_sampler_run for chains starting at t_start (it holds, besides the UNet's scratch, the per-block time
    shifts of every timestep 0..t_start, computed once: no time-embedding kernel runs inside the loop) */
 size_t ddk_sampler_workspace_bytes(const ddk_unet* u, int B, int H, int W, int t_start);
+/* Runs steps t_start .. t_end.  With use_graph the plan keeps the captured step (a hipGraphExec_t) and the per-timestep
+ * shift table it computed in `workspace`, keyed by the buffer pointers, shape, t_start and the plan's weight epoch: the
+ * first call on a buffer set runs one step eagerly, captures and instantiates; every later call on the same buffers only
+ * writes {t_start, seed, stream_id} into the workspace and issues hipGraphLaunch per step (seed, stream id and t are read
+ * from device memory by the kernels, so they are not part of the key).  At most 4 buffer sets are cached (LRU).
+ * Contract: a caller that frees or overwrites `workspace` (or frees any buffer passed here) between calls must call
+ * ddk_sampler_invalidate() first. */
 int ddk_sampler_run(const ddk_sampler_args* a, ddk_stream_t s);
+/* Drops the plan's cached sampler graphs and shift table (waits for the device when graphs exist). */
+int ddk_sampler_invalidate(ddk_unet* u);
 
 
 /* ================================================================== training path (backward kernels) ==
