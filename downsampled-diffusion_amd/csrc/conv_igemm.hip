@@ -1055,23 +1055,15 @@ static bool tuning_flag(const char*) { return false; }
 static int tuning_int(const char*, int dflt) { return dflt; }
 #endif
 
-// Ring depth for a tile and grid: as deep as the LDS allows for the number of workgroups a CU will hold.
-// 64x64: 16 KB per stage; 128x64: 24 KB; 128x128: 32 KB; 128x32: 20 KB; 64x32: 12 KB.  The instantiated depths are
-// {3, 4, 6} (64x64), {3, 4} (128x64, 128x32, 64x32) and {3} (128x128).
+// Ring depth for a tile and grid.  Measured (profiles/r02_conv_sweep.txt, tools/conv_clock.py): a deeper ring only pays
+// when a CU holds ONE workgroup (<= 256 workgroups: the 4x4 maps, -5 % per launch); with 2+ workgroups per CU they cover each
+// other's DMA latency and the extra LDS only costs occupancy (the 1x1 projections at 32x32 lost 20 % at 64 KB per
+// workgroup), so everything else keeps the 2-stage ring.  Instantiated: {2, 4, 6} (64x64), {2, 4} (128x64), {2} (others).
 static int choose_stages(TileId t, long long workgroups, int kps) {
     const bool one_per_cu = workgroups <= 256;
-    int ns;
-    switch (t) {
-        case T64x64: ns = one_per_cu ? 6 : 4; break;     // 96 KB alone, else 2 x 64 KB
-        case T128x64: ns = one_per_cu ? 4 : 3; break;    // 96 KB alone, else 2 x 72 KB
-        case T128x128: ns = 3; break;                    // 96 KB
-        case T128x32: ns = one_per_cu ? 4 : 3; break;
-        default: ns = one_per_cu ? 4 : 3; break;
-    }
-    // a ring deeper than the k-chunks of a split buys nothing
-    if (t == T64x64 && ns == 6 && kps < 5) ns = 4;
-    if (ns == 4 && kps < 3) ns = 3;
-    return ns;
+    if (t == T64x64 && one_per_cu) return kps >= 5 ? 6 : (kps >= 3 ? 4 : 2);
+    if (t == T128x64 && one_per_cu && kps >= 3) return 4;
+    return 2;
 }
 
 // Pick the largest tile that still gives the 256 CUs about a full wave of workgroups; when even the
@@ -1225,19 +1217,15 @@ static int launch_tile(const IgemmParams& p, const Choice& c, hipStream_t st) {
     const bool reg = p.pre_mish || tuning_flag("DDK_NO_DMA");   // Mish-on-load needs the register-staged kernel
     const int ns = c.stages;
     switch (c.tile) {
-        case T128x128: return reg ? launch_reg<128, 128, 2, 2>(p, st) : launch_dma<128, 128, 2, 2, 3>(p, st);
+        case T128x128: return reg ? launch_reg<128, 128, 2, 2>(p, st) : launch_dma<128, 128, 2, 2, 2>(p, st);
         case T128x64:
             if (reg) return launch_reg<128, 64, 2, 2>(p, st);
-            return ns >= 4 ? launch_dma<128, 64, 2, 2, 4>(p, st) : launch_dma<128, 64, 2, 2, 3>(p, st);
+            return ns >= 4 ? launch_dma<128, 64, 2, 2, 4>(p, st) : launch_dma<128, 64, 2, 2, 2>(p, st);
         case T64x64:
             if (reg) return launch_reg<64, 64, 2, 2>(p, st);
-            return ns >= 6 ? launch_dma<64, 64, 2, 2, 6>(p, st) : ns >= 4 ? launch_dma<64, 64, 2, 2, 4>(p, st) : launch_dma<64, 64, 2, 2, 3>(p, st);
-        case T128x32:
-            if (reg) return launch_reg<128, 32, 4, 1>(p, st);
-            return ns >= 4 ? launch_dma<128, 32, 4, 1, 4>(p, st) : launch_dma<128, 32, 4, 1, 3>(p, st);
-        default:
-            if (reg) return launch_reg<64, 32, 2, 1>(p, st);
-            return ns >= 4 ? launch_dma<64, 32, 2, 1, 4>(p, st) : launch_dma<64, 32, 2, 1, 3>(p, st);
+            return ns >= 6 ? launch_dma<64, 64, 2, 2, 6>(p, st) : ns >= 4 ? launch_dma<64, 64, 2, 2, 4>(p, st) : launch_dma<64, 64, 2, 2, 2>(p, st);
+        case T128x32: return reg ? launch_reg<128, 32, 4, 1>(p, st) : launch_dma<128, 32, 4, 1, 2>(p, st);
+        default: return reg ? launch_reg<64, 32, 2, 1>(p, st) : launch_dma<64, 32, 2, 1, 2>(p, st);
     }
 }
 
@@ -1246,11 +1234,11 @@ int conv_init_device() {
     DDK_HALO_VARIANTS(HALO_ATTR)
 #undef HALO_ATTR
 #define DMA_ATTR(BM, BN, WM, WN, NS) DDK_TRY(allow_lds(&igemm_dma_kernel<BM, BN, WM, WN, NS>, dma_lds_bytes<BM, BN, WM, WN, NS>()));
-    DMA_ATTR(128, 128, 2, 2, 3)
-    DMA_ATTR(128, 64, 2, 2, 3) DMA_ATTR(128, 64, 2, 2, 4)
-    DMA_ATTR(64, 64, 2, 2, 3) DMA_ATTR(64, 64, 2, 2, 4) DMA_ATTR(64, 64, 2, 2, 6)
-    DMA_ATTR(128, 32, 4, 1, 3) DMA_ATTR(128, 32, 4, 1, 4)
-    DMA_ATTR(64, 32, 2, 1, 3) DMA_ATTR(64, 32, 2, 1, 4)
+    DMA_ATTR(128, 128, 2, 2, 2)
+    DMA_ATTR(128, 64, 2, 2, 2) DMA_ATTR(128, 64, 2, 2, 4)
+    DMA_ATTR(64, 64, 2, 2, 2) DMA_ATTR(64, 64, 2, 2, 4) DMA_ATTR(64, 64, 2, 2, 6)
+    DMA_ATTR(128, 32, 4, 1, 2)
+    DMA_ATTR(64, 32, 2, 1, 2)
 #undef DMA_ATTR
     DDK_TRY(allow_lds(&igemm_kernel<128, 128, 2, 2>, reg_lds_bytes(128, 128)));
     DDK_TRY(allow_lds(&igemm_kernel<128, 64, 2, 2>, reg_lds_bytes(128, 64)));

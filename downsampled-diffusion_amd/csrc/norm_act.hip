@@ -95,88 +95,6 @@ __global__ __launch_bounds__(NT) void gn_mish_resident_kernel(const float* __res
     }
 }
 
-// Small groups (the 4x4 / 8x8 maps: <= 512 float4 per (b, group)): ONE WAVE per group, VPT float4 per lane, statistics by
-// wavefront shuffles only -- no LDS, no workgroup barrier.  These launches are latency chains (load -> reduce -> reduce ->
-// store of a 2-8 KB slab); the 256/1024-thread kernel above spends most of its 6 us in four __syncthreads-separated
-// phases.  Same arithmetic: two-pass mean / biased variance, slabs summed in split order.
-template <int VPT>
-__global__ __launch_bounds__(64) void gn_mish_wave_kernel(const float* __restrict__ x, int nslab, long long slab_stride,
-                                                          const float* __restrict__ cbias, const float* __restrict__ gamma,
-                                                          const float* __restrict__ beta, const float* __restrict__ temb,
-                                                          int temb_stride, const long long* __restrict__ temb_rows,
-                                                          const float* __restrict__ addend, float* __restrict__ out, int HW, int C,
-                                                          int groups, float eps) {
-    const int b = blockIdx.x / groups, g = blockIdx.x % groups;
-    const int cpg = C / groups;
-    const int upr = cpg >> 2;
-    const int units = HW * upr;
-    const long long base = (long long)b * HW * C + g * cpg;
-    const int lane = threadIdx.x;
-
-    float4 v[VPT];
-    long long off[VPT];
-    int cu4[VPT];
-#pragma unroll
-    for (int i = 0; i < VPT; ++i) {
-        const int u = lane + i * 64;
-        const int row = div_upr(u, upr), cu = u - row * upr;
-        cu4[i] = cu * 4;
-        off[i] = base + (long long)row * C + cu * 4;
-        v[i] = u < units ? *reinterpret_cast<const float4*>(x + off[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    for (int k = 1; k < nslab; ++k) {
-#pragma unroll
-        for (int i = 0; i < VPT; ++i)
-            if (lane + i * 64 < units) {
-                const float4 t = *reinterpret_cast<const float4*>(x + k * slab_stride + off[i]);
-                v[i].x += t.x; v[i].y += t.y; v[i].z += t.z; v[i].w += t.w;
-            }
-    }
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < VPT; ++i)
-        if (lane + i * 64 < units) {
-            if (cbias) {
-                const float4 t = *reinterpret_cast<const float4*>(cbias + g * cpg + cu4[i]);
-                v[i].x += t.x; v[i].y += t.y; v[i].z += t.z; v[i].w += t.w;
-            }
-            s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
-        }
-    const float inv_n = 1.0f / (float)(HW * cpg);
-    const float mean = wave_sum(s) * inv_n;
-    float q = 0.f;
-#pragma unroll
-    for (int i = 0; i < VPT; ++i)
-        if (lane + i * 64 < units) {
-            const float a = v[i].x - mean, bb = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
-            q += (a * a + bb * bb) + (c * c + d * d);
-        }
-    const float var = wave_sum(q) * inv_n;
-    const float rstd = 1.0f / sqrtf(var + eps);
-    const long long tr = temb ? (temb_rows ? temb_rows[b] : b) : 0;
-#pragma unroll
-    for (int i = 0; i < VPT; ++i)
-        if (lane + i * 64 < units) {
-            const int c0 = g * cpg + cu4[i];
-            const float4 ga = *reinterpret_cast<const float4*>(gamma + c0);
-            const float4 be = *reinterpret_cast<const float4*>(beta + c0);
-            float4 y;
-            y.x = mish_f((v[i].x - mean) * rstd * ga.x + be.x);
-            y.y = mish_f((v[i].y - mean) * rstd * ga.y + be.y);
-            y.z = mish_f((v[i].z - mean) * rstd * ga.z + be.z);
-            y.w = mish_f((v[i].w - mean) * rstd * ga.w + be.w);
-            if (temb) {
-                const float4 t = *reinterpret_cast<const float4*>(temb + tr * temb_stride + c0);
-                y.x += t.x; y.y += t.y; y.z += t.z; y.w += t.w;
-            }
-            if (addend) {
-                const float4 r = *reinterpret_cast<const float4*>(addend + off[i]);
-                y.x += r.x; y.y += r.y; y.z += r.z; y.w += r.w;
-            }
-            *reinterpret_cast<float4*>(out + off[i]) = y;
-        }
-}
-
 // Large slabs (full-resolution DDPM, 256x256): stats by `nsplit` workgroups per (b, group) as Welford
 // partials (count, mean, M2) combined in a fixed order, then a grid-wide apply pass.
 __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict__ x, float* __restrict__ part, int HW, int C,
@@ -298,19 +216,15 @@ int groupnorm_mish_ex(const float* x, int nslab, long long slab_stride, const fl
 #define GN_CASE(V, NT)                                                                                                  \
     hipLaunchKernelGGL((gn_mish_resident_kernel<V, NT>), grid, dim3(NT), 0, st, x, nslab, slab_stride, cbias, gamma, beta, temb, \
                        temb_stride, temb_rows, addend, out, HW, C, groups, eps)
-#define GN_WAVE(V)                                                                                                    \
-    hipLaunchKernelGGL((gn_mish_wave_kernel<V>), grid, dim3(64), 0, st, x, nslab, slab_stride, cbias, gamma, beta, temb, \
-                       temb_stride, temb_rows, addend, out, HW, C, groups, eps)
-        // small groups: one wave each, shuffle-only reductions; big slabs: 1024 threads (16 waves per CU keep enough loads
-        // in flight)
-        if (units <= 128) GN_WAVE(2);
-        else if (units <= 256) GN_WAVE(4);
-        else if (units <= 512) GN_WAVE(8);
+        // big slabs: 1024 threads (16 waves per CU keep enough loads in flight); small ones: 256.  (One WAVE per group with
+        // shuffle-only reductions was tried for the 4x4 / 8x8 maps and lost -- 8.5 vs 5.9 us, 17 vs 7.3 us: a single wave per
+        // CU has too few loads in flight for the split-K slabs.)
+        if (units <= 256) GN_CASE(1, 256);
+        else if (units <= 512) GN_CASE(2, 256);
         else if (units <= 1024) GN_CASE(1, 1024);
         else if (units <= 2048) GN_CASE(2, 1024);
         else GN_CASE(4, 1024);
 #undef GN_CASE
-#undef GN_WAVE
         return check_launch("gn_mish_resident_kernel");
     }
     DDK_REQUIRE(nslab == 1 && cbias == nullptr, "groupnorm: split-K input is only supported on the register-resident path");

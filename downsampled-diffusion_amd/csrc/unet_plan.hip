@@ -525,8 +525,10 @@ static int run_attn(Ctx& c, const AttnW& a, const float* x, float* out, int H, i
     if (H * W <= 64) {
         DDK_TRY(linattn_fused_small(qkv, ctx, o, c.B, H * W, HEADS, c.st));
     } else {
-        DDK_TRY(linattn_context(qkv, ctx, c.B, H * W, HEADS, c.W + c.ly.off_splitk, c.ly.splitk * sizeof(float), c.st));
-        DDK_TRY(linattn_apply(qkv, ctx, o, c.B, H * W, HEADS, c.st));
+        // the split context's merge is folded into the apply kernel's fragment build (one launch less per site)
+        int splits = 1;
+        DDK_TRY(linattn_context(qkv, ctx, c.B, H * W, HEADS, c.W + c.ly.off_splitk, c.ly.splitk * sizeof(float), c.st, &splits));
+        DDK_TRY(linattn_apply(qkv, ctx, o, c.B, H * W, HEADS, c.st, splits > 1 ? c.W + c.ly.off_splitk : nullptr, splits));
     }
     return run_conv(c, DDK_CONV1X1, a.out, o, HIDDEN, nullptr, 0, x, out, H, W, a.c);
 }

@@ -16,7 +16,7 @@ import torch  # noqa: E402
 from ddk import ops  # noqa: E402
 
 TILES = {0: "128x128", 1: "128x64", 2: "64x64"}
-STAGES = {0: (3,), 1: (3, 4), 2: (3, 4, 6)}
+STAGES = {0: (2,), 1: (2, 4), 2: (2, 4, 6)}
 S1, S2, P1, TC = ops.CONV3X3_S1, ops.CONV3X3_S2, ops.CONV1X1, ops.CONVT4X4_S2
 SHAPES = [  # name, kind, H, c0, c1, N, count per step
     ("3x3  32->128 @32", S1, 32, 32, 0, 128, 1),
