@@ -198,11 +198,7 @@ __global__ __launch_bounds__(256) void linattn_small_kernel(const float* __restr
 // 2 x 16 v_mfma_f32_32x32x2_f32 per wave, rows of 128 contiguous bytes out.  (The earlier VALU version re-read ctx from LDS
 // 256 times per thread and was LDS-issue bound: 15 us at 32x32.)
 typedef float f32x16_att __attribute__((ext_vector_type(16)));
-// `part` != nullptr: the context is still in split form (linattn_context_kernel's partials); every workgroup merges the
-// `splits` partials of its (b, head) while it builds its B fragments -- the same expression, in the same order, as
-// linattn_merge_kernel (bit-identical), a few hundred L2-resident loads per lane instead of a 5 us launch in the chain.
 __global__ __launch_bounds__(512) void linattn_apply_kernel(const float* __restrict__ qkv, const float* __restrict__ ctx,
-                                                            const float* __restrict__ part, int splits,
                                                             float* __restrict__ out, int HW, int heads, int tiles_per_sample) {
     extern __shared__ __attribute__((aligned(16))) float qs[];   // [heads][64 px][33]
     const int b = blockIdx.x / tiles_per_sample, tile = blockIdx.x % tiles_per_sample;
@@ -222,28 +218,10 @@ __global__ __launch_bounds__(512) void linattn_apply_kernel(const float* __restr
     const int h = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int l31 = lane & 31, fh = lane >> 5;
     // B fragments: ctx[h][d = 2*kk + fh][e = lane & 31]
+    const float* cp = ctx + ((long long)b * heads + h) * DH * DH + l31;
     float bf[16];
-    if (part) {
-        const float* pp = part + ((long long)b * heads + h) * splits * PART;
 #pragma unroll
-        for (int kk = 0; kk < 16; ++kk) {
-            const int d = 2 * kk + fh;
-            float M = -INFINITY;
-            for (int s = 0; s < splits; ++s) M = fmaxf(M, pp[s * PART + d]);
-            float acc = 0.f, den = 0.f;
-            for (int s = 0; s < splits; ++s) {
-                const float w = expf(pp[s * PART + d] - M);
-                den += pp[s * PART + DH + d] * w;
-                acc += pp[s * PART + 2 * DH + d * DH + l31] * w;
-            }
-            const float inv = 1.0f / den;
-            bf[kk] = acc * inv;
-        }
-    } else {
-        const float* cp = ctx + ((long long)b * heads + h) * DH * DH + l31;
-#pragma unroll
-        for (int kk = 0; kk < 16; ++kk) bf[kk] = cp[(2 * kk + fh) * DH];
-    }
+    for (int kk = 0; kk < 16; ++kk) bf[kk] = cp[(2 * kk + fh) * DH];
     __syncthreads();
     const float* qh = qs + h * 64 * 33;
     f32x16_att acc0, acc1;
@@ -281,10 +259,7 @@ size_t linattn_context_workspace_bytes(int B, int HW, int heads) {
     return s > 1 ? (size_t)B * heads * s * PART * sizeof(float) : 0;
 }
 
-// defer_merge_splits != nullptr (inference plan): leave the partials in `workspace` and report their count; the apply kernel
-// merges them (linattn_apply_partials).  *defer_merge_splits == 1 means ctx was written directly.
-int linattn_context(const float* qkv, float* ctx, int B, int HW, int heads, void* workspace, size_t workspace_bytes, hipStream_t st,
-                    int* defer_merge_splits) {
+int linattn_context(const float* qkv, float* ctx, int B, int HW, int heads, void* workspace, size_t workspace_bytes, hipStream_t st) {
     DDK_REQUIRE(qkv && ctx && B > 0 && HW > 0 && heads > 0, "linattn_context: arguments");
     DDK_REQUIRE(aligned16(qkv) && aligned16(ctx) && aligned16(workspace), "linattn_context: alignment");
     int s, rows;
@@ -299,7 +274,6 @@ int linattn_context(const float* qkv, float* ctx, int B, int HW, int heads, void
     }
     hipLaunchKernelGGL(linattn_context_kernel, dim3(B * heads * s), dim3(256), 0, st, qkv, ctx, static_cast<float*>(workspace), HW, heads, s, rows);
     DDK_TRY(check_launch("linattn_context_kernel"));
-    if (defer_merge_splits) { *defer_merge_splits = s; return DDK_OK; }
     if (s > 1) {
         hipLaunchKernelGGL(linattn_merge_kernel, dim3(B * heads), dim3(256), 0, st, static_cast<const float*>(workspace), ctx, s);
         DDK_TRY(check_launch("linattn_merge_kernel"));
@@ -315,15 +289,13 @@ int linattn_fused_small(const float* qkv, float* ctx, float* out, int B, int HW,
     return check_launch("linattn_small_kernel");
 }
 
-int linattn_apply(const float* qkv, const float* ctx, float* out, int B, int HW, int heads, hipStream_t st, const float* part,
-                  int splits) {
+int linattn_apply(const float* qkv, const float* ctx, float* out, int B, int HW, int heads, hipStream_t st) {
     DDK_REQUIRE(qkv && ctx && out && B > 0 && HW > 0, "linattn_apply: arguments");
-    DDK_REQUIRE(part == nullptr || (splits > 1 && aligned16(part)), "linattn_apply: partials");
     DDK_REQUIRE(heads >= 1 && heads <= 8, "linattn_apply: heads must be in 1..8");
     DDK_REQUIRE(aligned16(qkv) && aligned16(ctx) && aligned16(out), "linattn_apply: alignment");
     const int tiles = (int)ceil_div(HW, 64);
     const size_t lds = (size_t)heads * 64 * 33 * sizeof(float);
-    hipLaunchKernelGGL(linattn_apply_kernel, dim3(B * tiles), dim3(64 * heads), lds, st, qkv, ctx, part, splits, out, HW, heads, tiles);
+    hipLaunchKernelGGL(linattn_apply_kernel, dim3(B * tiles), dim3(64 * heads), lds, st, qkv, ctx, out, HW, heads, tiles);
     return check_launch("linattn_apply_kernel");
 }
 
@@ -332,12 +304,12 @@ int linattn_apply(const float* qkv, const float* ctx, float* out, int B, int HW,
 extern "C" {
 size_t ddk_linattn_context_workspace_bytes(int B, int HW, int heads) { return ddk::linattn_context_workspace_bytes(B, HW, heads); }
 int ddk_linattn_context(const float* qkv, float* ctx, int B, int HW, int heads, void* workspace, size_t workspace_bytes, ddk_stream_t s) {
-    return ddk::linattn_context(qkv, ctx, B, HW, heads, workspace, workspace_bytes, ddk::as_stream(s), nullptr);
+    return ddk::linattn_context(qkv, ctx, B, HW, heads, workspace, workspace_bytes, ddk::as_stream(s));
 }
 int ddk_linattn_fused_small(const float* qkv, float* ctx, float* out, int B, int HW, int heads, ddk_stream_t s) {
     return ddk::linattn_fused_small(qkv, ctx, out, B, HW, heads, ddk::as_stream(s));
 }
 int ddk_linattn_apply(const float* qkv, const float* ctx, float* out, int B, int HW, int heads, ddk_stream_t s) {
-    return ddk::linattn_apply(qkv, ctx, out, B, HW, heads, ddk::as_stream(s), nullptr, 0);
+    return ddk::linattn_apply(qkv, ctx, out, B, HW, heads, ddk::as_stream(s));
 }
 }

@@ -531,6 +531,15 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_dma_kernel(const IgemmParam
         else wait_vmcnt<0>();
         __syncthreads();
         const bool more = k + NS - 1 < n_it;     // wave-uniform
+        // 2-stage ring: the next chunk has only this chunk's multiply to land in, so its pieces go out at once (2+
+        // workgroups per CU cover the issue slots with each other's MFMAs).  Deeper rings have slack: their pieces are
+        // spread over the four quarters below, in MFMA shadows.
+        constexpr bool EARLY = NS == 2;
+        if (EARLY && more) {
+            begin_chunk(istage);
+#pragma unroll
+            for (int j = 0; j < PW; ++j) issue_piece(j);
+        }
         const float* As = smem + stage * STAGE + a_base;
         const float* Bs = smem + stage * STAGE + b_base;
         float4 a[2][TM], b[2][TN];
@@ -556,7 +565,7 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_dma_kernel(const IgemmParam
             // 1024 cycles of MFMA: tools/conv_clock.py.)
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][0].x, b[cur][0].x, acc[0][0], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            if (more) {
+            if (!EARLY && more) {
                 if (q == 0) begin_chunk(istage);
 #pragma unroll
                 for (int j = 0; j < PW; ++j)

@@ -146,10 +146,8 @@ int avgpool2(const float* x, float* out, int B, int H, int W, int C, hipStream_t
 int upsample_nearest2(const float* x, float* out, int B, int H, int W, int C, hipStream_t st);
 // attention.hip
 size_t linattn_context_workspace_bytes(int B, int HW, int heads);
-int linattn_context(const float* qkv, float* ctx, int B, int HW, int heads, void* workspace, size_t workspace_bytes, hipStream_t st,
-                    int* defer_merge_splits = nullptr);
-int linattn_apply(const float* qkv, const float* ctx, float* out, int B, int HW, int heads, hipStream_t st, const float* part = nullptr,
-                  int splits = 0);
+int linattn_context(const float* qkv, float* ctx, int B, int HW, int heads, void* workspace, size_t workspace_bytes, hipStream_t st);
+int linattn_apply(const float* qkv, const float* ctx, float* out, int B, int HW, int heads, hipStream_t st);
 int linattn_fused_small(const float* qkv, float* ctx, float* out, int B, int HW, int heads, hipStream_t st);
 // time_embed.hip
 int time_mlp(const int64_t* t, const float* freqs, const float* w1t, const float* b1, const float* w2t, const float* b2,

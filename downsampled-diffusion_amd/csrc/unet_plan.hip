@@ -525,10 +525,10 @@ static int run_attn(Ctx& c, const AttnW& a, const float* x, float* out, int H, i
     if (H * W <= 64) {
         DDK_TRY(linattn_fused_small(qkv, ctx, o, c.B, H * W, HEADS, c.st));
     } else {
-        // the split context's merge is folded into the apply kernel's fragment build (one launch less per site)
-        int splits = 1;
-        DDK_TRY(linattn_context(qkv, ctx, c.B, H * W, HEADS, c.W + c.ly.off_splitk, c.ly.splitk * sizeof(float), c.st, &splits));
-        DDK_TRY(linattn_apply(qkv, ctx, o, c.B, H * W, HEADS, c.st, splits > 1 ? c.W + c.ly.off_splitk : nullptr, splits));
+        // (folding the split context's merge into the apply kernel's fragment build was tried: 73 vs 11 + 5.5 us at 32x32 --
+        //  hundreds of dependent L2 loads per lane; the 5 us merge launch stays)
+        DDK_TRY(linattn_context(qkv, ctx, c.B, H * W, HEADS, c.W + c.ly.off_splitk, c.ly.splitk * sizeof(float), c.st));
+        DDK_TRY(linattn_apply(qkv, ctx, o, c.B, H * W, HEADS, c.st));
     }
     return run_conv(c, DDK_CONV1X1, a.out, o, HIDDEN, nullptr, 0, x, out, H, W, a.c);
 }

@@ -78,6 +78,7 @@ SIGNATURES = {
     "ddk_randn": (_I, [_P, _LL, C.c_uint64, C.c_uint32, C.c_uint32, _P]),
     "ddk_fix_samples": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "ddk_sq_err_sum": (_I, [_P, _P, _P, _I, _LL, _P]),
+    "ddk_vlb_terms": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _LL, _P]),
     "ddk_unet_create": (_P, [C.POINTER(UnetConfig)]),
     "ddk_unet_destroy": (None, [_P]),
     "ddk_unet_num_slots": (_I, [_P]),

@@ -273,6 +273,17 @@ def randn(shape, device, seed, step, stream_id=0):
     return out
 
 
+def vlb_terms(x, x_t, eps_hat, t, c_recip, c_recipm1, c1, c2, post_logvar, eps=None):
+    """Per-sample VLB term in bits/dim (KL for t > 0, discretised NLL at t == 0) and, with eps, sum (eps - eps_hat)^2."""
+    b = x.shape[0]
+    vlb = torch.empty((b,), device=x.device, dtype=torch.float32)
+    sq = torch.empty((b,), device=x.device, dtype=torch.float32) if eps is not None else None
+    L.check(L.load().ddk_vlb_terms(L.ptr(_f32(x)), L.ptr(_f32(x_t)), L.ptr(_f32(eps_hat)), L.ptr(eps), L.ptr(t), L.ptr(c_recip),
+                                   L.ptr(c_recipm1), L.ptr(c1), L.ptr(c2), L.ptr(post_logvar), L.ptr(vlb), L.ptr(sq), b,
+                                   x.numel() // b, L.stream()), "vlb_terms")
+    return vlb, sq
+
+
 def sq_err_sum(a, b):
     bsz = a.shape[0]
     out = torch.empty((bsz,), device=a.device, dtype=torch.float32)

@@ -3,8 +3,9 @@ its hot path on HIP kernels.
 
 Hot path (HIP): q_sample, the UNet call, the fused reverse-step update, the T-step sampling loop (one C
 call, hipGraph-replayed), the per-sample squared-error loss.
-API-surface passthrough (plain torch on device tensors, evaluation only, out of the accelerated scope per
-SURVEY.md section 2): q_mean_variance, q_posterior, p_mean_variance, vlb_terms, calc_prior, test_losses_.
+Evaluation path: test_losses_ = T x {q_sample kernel, HIP UNet, one fused VLB kernel
+(normal_kl + discretised NLL + flat_bits + L_simple)}; q_mean_variance / q_posterior / p_mean_variance / calc_prior
+stay plain torch expressions on device tensors (a few [B] / [T] gathers, init-time cost).
 """
 from functools import partial
 
@@ -222,9 +223,19 @@ class DDPM(nn.Module):
         eps_hat = self.latent_model(x_t, t)
         return self.loss_ddpm(eps, eps_hat, t)
 
-    # ------------------------------------------------------------------ evaluation-only VLB (plain torch passthrough)
+    # ------------------------------------------------------------------ evaluation-time VLB (ddpm.py:317-446)
+    def _vlb_fused(self, x, x_t, t, eps_hat, eps=None):
+        """One HIP kernel for q_posterior (x2), predict_x_from_eps(clip), normal_kl, the discretised NLL and flat_bits."""
+        return ops.vlb_terms(x.contiguous(), x_t.contiguous(), eps_hat.contiguous(), t.contiguous(),
+                             self.sqrt_recip_alphas_cumprod, self.sqrt_recipm1_alphas_cumprod, self.posterior_mean_coef1,
+                             self.posterior_mean_coef2, self.posterior_log_variance_clipped,
+                             eps=None if eps is None else eps.contiguous())
+
     def vlb_terms(self, x, x_t, t):
-        """ddpm.py:317-366."""
+        """ddpm.py:317-366.  Without gradients (evaluation, the only caller in the reference: test_losses_) the UNet's
+        eps_hat feeds ONE fused kernel; with gradients enabled the reference's torch expression is kept."""
+        if not torch.is_grad_enabled() and x.is_cuda:
+            return self._vlb_fused(x, x_t, t, self.latent_model(x_t, t))[0]
         true_mean, _, true_log_var = self.q_posterior(x, x_t, t)
         pred_mean, _, pred_log_var = self.p_mean_variance(x_t, t)
         if self.L == 'hybrid':
@@ -242,15 +253,21 @@ class DDPM(nn.Module):
 
     @torch.no_grad()
     def test_losses_(self, x):
-        """ddpm.py:393-442: T sequential (q_sample, UNet x2) evaluations; returns the reference's dict."""
+        """ddpm.py:393-442: for t = T-1 .. 0: eps ~ N(0,1) (torch's generator, one draw per step like the reference),
+        x_t = q_sample, then the VLB term and L_simple of that step.  The reference calls the UNet twice per step on
+        identical inputs (vlb_terms, then L_simple); eval-mode forwards are deterministic, so here ONE UNet call feeds one
+        fused kernel that returns both the VLB term and sum (eps - eps_hat)^2.  Returns the reference's dict."""
+        self._check_device(x)
         vlb_t, l_simple_t = [], []
+        n_el = x.numel()
         for t in reversed(range(self.timesteps)):
             t_batch = torch.full((x.shape[0],), t, device=x.device, dtype=torch.long)
             eps = torch.randn_like(x)
             x_t = self.q_sample(x, t_batch, eps)
-            vlb_t.append(self.vlb_terms(x, x_t, t_batch))
             eps_hat = self.latent_model(x_t, t_batch)
-            l_simple_t.append(self.get_loss(eps, eps_hat).mean())
+            vlb, sq = self._vlb_fused(x, x_t, t_batch, eps_hat, eps)
+            vlb_t.append(vlb)
+            l_simple_t.append(sq.sum() / n_el)                      # l2_loss(reduction='none').mean()
         vlb_t = torch.stack(vlb_t, dim=1)
         l_simple_t = torch.stack(l_simple_t, dim=0)
         assert l_simple_t.shape[0] == self.timesteps

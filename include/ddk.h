@@ -158,6 +158,14 @@ int ddk_randn(float* out, long long n, uint64_t seed, uint32_t step, uint32_t st
 /* Sampler output stage (utils/eval_helpers.py:37-41): per-image min-max over C*H*W, x255, NCHW -> NHWC:
    out[b][h][w][c] = ((x[b][c][h][w] - min_b) / (max_b - min_b)) * 255, bit-identical to the reference expression. */
 int ddk_fix_samples(const float* x_nchw, float* out_nhwc, int B, int C, int H, int W, ddk_stream_t s);
+/* Evaluation-time variational bound, per sample (ddpm.py:317-366 after the UNet call; models/utils/losses.py:17-109;
+ * utils/utils.py:43-48 flat_bits): vlb[b] = mean over the sample of { t_b > 0: KL(q(x_{t-1}|x_t,x) || p(x_{t-1}|x_t));
+ * t_b == 0: discretised-Gaussian NLL of x } / ln 2, with p's mean from eps_hat (x0 clamped to [-1,1]) and both
+ * variances = exp(post_logvar[t_b]).  eps / sqerr optional (both or neither): sqerr[b] = sum (eps - eps_hat)^2, the
+ * L_simple term of test_losses_ (ddpm.py:424-426).  Any layout, as long as the five tensors agree. */
+int ddk_vlb_terms(const float* x, const float* x_t, const float* eps_hat, const float* eps, const int64_t* t,
+                  const float* c_recip, const float* c_recipm1, const float* c1, const float* c2,
+                  const float* post_logvar, float* vlb, float* sqerr, int B, long long per, ddk_stream_t s);
 /* per_sample[b] = sum_i (a - b)^2 over the sample's `per` elements (ddpm.py:279, utils/utils.py:34-40). */
 int ddk_sq_err_sum(const float* a, const float* b, float* per_sample, int B, long long per, ddk_stream_t s);
 

@@ -129,3 +129,74 @@ def min_max_norm_image(x):
 def fix_samples(x):
     """utils/eval_helpers.py:37-41: per-image min-max -> x255 -> NHWC numpy."""
     return np.moveaxis((min_max_norm_image(x) * 255.0).numpy(), 1, -1)
+
+
+# ---------------------------------------------------------------- evaluation-time VLB (ddpm.py:317-446)
+def normal_kl(mean1, logvar1, mean2, logvar2):
+    """models/utils/losses.py:17-53: 0.5 (logvar2 - logvar1 - 1 + exp(logvar1 - logvar2) + (mean1 - mean2)^2 exp(-logvar2)),
+    in the reference's order of additions."""
+    ref = next(v for v in (mean1, logvar1, mean2, logvar2) if isinstance(v, torch.Tensor))
+    logvar1, logvar2 = [v if isinstance(v, torch.Tensor) else torch.tensor(v).to(ref) for v in (logvar1, logvar2)]
+    return 0.5 * (+logvar2 - logvar1 - 1.0 + torch.exp(logvar1 - logvar2) + ((mean1 - mean2) ** 2) * torch.exp(-logvar2))
+
+
+def approx_standard_normal_cdf(x):
+    """models/utils/losses.py:56-64."""
+    return 0.5 * (1.0 + torch.tanh(np.sqrt(2.0 / np.pi) * (x + 0.044715 * torch.pow(x, 3))))
+
+
+def discretized_gaussian_log_likelihood(x, means, log_scales):
+    """models/utils/losses.py:67-109 (log_scales [N,1,1,1] broadcasts)."""
+    log_scales = log_scales * torch.ones_like(x)
+    centered_x = x - means
+    inv_stdv = torch.exp(-log_scales)
+    cdf_plus = approx_standard_normal_cdf(inv_stdv * (centered_x + 1.0 / 255.0))
+    cdf_min = approx_standard_normal_cdf(inv_stdv * (centered_x - 1.0 / 255.0))
+    log_cdf_plus = torch.log(cdf_plus.clamp(min=1e-12))
+    log_one_minus_cdf_min = torch.log((1.0 - cdf_min).clamp(min=1e-12))
+    cdf_delta = cdf_plus - cdf_min
+    return torch.where(x < -0.999, log_cdf_plus,
+                       torch.where(x > 0.999, log_one_minus_cdf_min, torch.log(cdf_delta.clamp(min=1e-12))))
+
+
+def flat_bits(x):
+    """utils/utils.py:43-48: mean over the non-batch dims / ln 2."""
+    return x.mean(dim=list(range(1, x.dim()))) / np.log(2.0)
+
+
+def vlb_terms(buf, x, x_t, t, eps_hat):
+    """ddpm.py:317-366 after the UNet call: L_t = KL(q(x_{t-1}|x_t,x) || p(x_{t-1}|x_t)) in bits/dim, L_0 = discretised NLL."""
+    c1, c2 = extract(buf["posterior_mean_coef1"], t), extract(buf["posterior_mean_coef2"], t)
+    logvar = extract(buf["posterior_log_variance_clipped"], t)
+    true_mean = c1 * x + c2 * x_t                                           # q_posterior(x, x_t, t), ddpm.py:177-185
+    pred_mean = c1 * predict_x_from_eps(buf, x_t, t, eps_hat, clip=True) + c2 * x_t      # p_mean_variance, ddpm.py:187-201
+    kl = flat_bits(normal_kl(true_mean, logvar, pred_mean, logvar))
+    nll = flat_bits(-discretized_gaussian_log_likelihood(x, pred_mean, 0.5 * logvar))
+    return torch.where(t == 0, nll, kl)
+
+
+def calc_prior(buf, x, T):
+    """ddpm.py:368-391: KL(q(x_T | x) || N(0, 1)) in bits/dim."""
+    t = torch.full((x.shape[0],), T - 1, dtype=torch.long)
+    mean = extract(buf["sqrt_alphas_cumprod"], t) * x
+    log_var = extract(buf["log_one_minus_alphas_cumprod"], t)
+    return flat_bits(normal_kl(mean, log_var, 0.0, 0.0))
+
+
+def test_losses(buf, eps_model, x, noises, T):
+    """ddpm.py:393-442 with the per-step draws injected: noises[k] is the k-th randn_like (timestep T-1-k)."""
+    vlb_t, l_simple_t = [], []
+    for k, i in enumerate(reversed(range(T))):
+        t = torch.full((x.shape[0],), i, dtype=torch.long)
+        eps = noises[k]
+        x_t = q_sample(buf, x, t, eps)
+        eps_hat = eps_model(x_t, t)
+        vlb_t.append(vlb_terms(buf, x, x_t, t, eps_hat))
+        l_simple_t.append(((eps - eps_hat) ** 2).mean())
+    vlb_t = torch.stack(vlb_t, dim=1)
+    l_simple_t = torch.stack(l_simple_t, dim=0)
+    prior = calc_prior(buf, x, T)
+    return {"vlb_t": vlb_t, "prior": prior, "vlb": vlb_t.sum(dim=1) + prior, "L_simple_t": l_simple_t, "L_simple": l_simple_t.sum()}
+
+
+test_losses.__test__ = False   # not a pytest test

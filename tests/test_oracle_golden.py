@@ -235,3 +235,36 @@ def test_train_step(tag):
             for n in probe:
                 d = np.abs(ema[n].numpy() - g[f"{tag}_ema_{n}"])
                 assert d.max() < 0.25 * lr and d.mean() < 2e-3 * lr, (n, d.max(), d.mean())
+
+
+# ---------------------------------------------------------------- G9 evaluation-time VLB
+def test_vlb_pieces_vs_reference():
+    g = golden("g9_test_losses")
+    x = syn.synthetic_input((2, 3, 16, 16), "g9.x").clamp(-1, 1)
+    x[0, 0, 0, :4] = torch.tensor([-1.0, 1.0, -0.9995, 0.9995])
+    mean1 = syn.synthetic_normal((2, 3, 16, 16), "g9.mean1") * 0.5
+    mean2 = syn.synthetic_normal((2, 3, 16, 16), "g9.mean2") * 0.5
+    lv1 = torch.tensor([-3.0, -0.5]).view(2, 1, 1, 1)
+    lv2 = torch.tensor([-2.5, -0.75]).view(2, 1, 1, 1)
+    assert np.array_equal(D.normal_kl(mean1, lv1, mean2, lv2).numpy(), g["piece_kl"])
+    assert np.array_equal(D.discretized_gaussian_log_likelihood(x, mean2, 0.5 * lv2).numpy(), g["piece_ll"])
+    assert np.array_equal(D.flat_bits(D.normal_kl(mean1, lv1, 0.0, 0.0)).numpy(), g["piece_prior"])
+
+
+def test_test_losses_vs_reference():
+    """oracle restatement of ddpm.py:393-442 vs the reference's own test_losses_ (T = 50, injected draws)"""
+    g = golden("g9_test_losses")
+    cfg = ddpm_cfg(32, 3, 16, T=50)
+    keys = {k: v for k, v in golden_keys()["ddpm_c3"].items()}
+    from oracle import unet_ref as UU
+    from models import DDPM, Unet
+    m = DDPM(cfg, Unet(cfg), "cpu", 3)
+    sd = det_state({k: tuple(v.shape) for k, v in m.state_dict().items()})
+    buf = D.schedule_buffers("linear", 50)
+    x = syn.synthetic_input((2, 3, 16, 16), "g9.x").clamp(-1, 1)
+    x[0, 0, 0, :4] = torch.tensor([-1.0, 1.0, -0.9995, 0.9995])
+    noises = [syn.synthetic_normal((2, 3, 16, 16), f"g9.eps{k}") for k in range(50)]
+    res = D.test_losses(buf, lambda a, b: UU.unet_forward(sd, cfg, a, b, pre="latent_model."), x, noises, 50)
+    for k in ("vlb_t", "prior", "vlb", "L_simple_t", "L_simple"):
+        assert rel_err(res[k], g[f"simple_{k}"]) < 2e-5, k
+    assert np.array_equal(g["simple_vlb_t"], g["hybrid_vlb_t"])     # the hybrid detach does not change values

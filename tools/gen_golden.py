@@ -314,9 +314,45 @@ def g6_train():
     save("g6_train", **out)
 
 
+# ---------------------------------------------------------------- G9 evaluation-time VLB (test_losses_)
+@torch.no_grad()
+def g9_test_losses():
+    """The reference's own test_losses_ (models/diffusion/ddpm.py:393-442: T x {q_sample, vlb_terms, L_simple}) on the tiny
+    model with T = 50 (T = 20 makes the linear schedule end at beta = 1: NaN at t = T-1) and the per-step noise injected (torch.randn_like patched, one draw per timestep, t = T-1 .. 0);
+    plus dDDPM.test_losses (dddpm.py: test_losses_ on the tanh-rescaled latents).  x has values beyond +-0.999 so every
+    branch of discretized_gaussian_log_likelihood (models/utils/losses.py:79-109) is exercised at t = 0."""
+    out = {}
+    for lt in ("simple", "hybrid"):
+        cfg = ddpm_cfg(32, 3, 16, T=50, loss_type=lt)
+        m = det_load(DDPM(cfg, Unet(cfg), "cpu", 3)).eval()
+        x = syn.synthetic_input((2, 3, 16, 16), "g9.x").clamp(-1, 1)
+        x[0, 0, 0, :4] = torch.tensor([-1.0, 1.0, -0.9995, 0.9995])
+        draws = iter([syn.synthetic_normal((2, 3, 16, 16), f"g9.eps{k}") for k in range(50)])
+        orig = torch.randn_like
+        torch.randn_like = lambda z: next(draws)
+        try:
+            res = m.test_losses(x)
+        finally:
+            torch.randn_like = orig
+        for k, v in res.items():
+            out[f"{lt}_{k}"] = v.numpy()
+    # the pieces, on fixed inputs (for the kernel-level test): kl / nll per element before flat_bits
+    from models.utils import discretized_gaussian_log_likelihood, normal_kl
+    x = syn.synthetic_input((2, 3, 16, 16), "g9.x").clamp(-1, 1)
+    x[0, 0, 0, :4] = torch.tensor([-1.0, 1.0, -0.9995, 0.9995])
+    mean1 = syn.synthetic_normal((2, 3, 16, 16), "g9.mean1") * 0.5
+    mean2 = syn.synthetic_normal((2, 3, 16, 16), "g9.mean2") * 0.5
+    lv1 = torch.tensor([-3.0, -0.5]).view(2, 1, 1, 1)
+    lv2 = torch.tensor([-2.5, -0.75]).view(2, 1, 1, 1)
+    out["piece_kl"] = normal_kl(mean1, lv1, mean2, lv2).numpy()
+    out["piece_ll"] = discretized_gaussian_log_likelihood(x, means=mean2, log_scales=0.5 * lv2).numpy()
+    out["piece_prior"] = uu.flat_bits(normal_kl(mean1, lv1, 0., 0.)).numpy()
+    save("g9_test_losses", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g0", "g1", "g2", "g3", "g4", "g6", "g7", "g8"]
+    which = sys.argv[1:] or ["g0", "g1", "g2", "g3", "g4", "g6", "g7", "g8", "g9"]
     table = dict(g0=g0_keys, g1=g1_schedule, g2=g2_blocks, g3=g3_unet, g4=g4_chain, g6=g6_train, g7=g7_qsample_loss,
-                 g8=g8_resamplers)
+                 g8=g8_resamplers, g9=g9_test_losses)
     for w in which:
         table[w]()
