@@ -563,8 +563,10 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_dma_kernel(const IgemmParam
             // LayerNorm row statistics -- is placed in its shadow, then the rest of the MFMAs follow.  (With that work in
             // front of the first MFMA, right after the barrier, a 64x64 tile spent 1600-1750 cycles per chunk for
             // 1024 cycles of MFMA: tools/conv_clock.py.)
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][0].x, b[cur][0].x, acc[0][0], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
+            if (!EARLY) {
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][0].x, b[cur][0].x, acc[0][0], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
             if (!EARLY && more) {
                 if (q == 0) begin_chunk(istage);
 #pragma unroll
@@ -581,14 +583,14 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_dma_kernel(const IgemmParam
                     ln_q += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
                 }
             }
-            __builtin_amdgcn_sched_barrier(0);
+            if (!EARLY) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j) {
-                        if (e == 0 && i == 0 && j == 0) continue;   // issued above
+                        if (!EARLY && e == 0 && i == 0 && j == 0) continue;   // issued above
                         const float av = e == 0 ? a[cur][i].x : e == 1 ? a[cur][i].y : e == 2 ? a[cur][i].z : a[cur][i].w;
                         const float bv = e == 0 ? b[cur][j].x : e == 1 ? b[cur][j].y : e == 2 ? b[cur][j].z : b[cur][j].w;
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);

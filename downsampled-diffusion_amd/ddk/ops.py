@@ -298,10 +298,17 @@ _scratch = {}
 
 
 def _ws(device, nbytes, tag="ws"):
-    """Reusable scratch buffer per (device, tag): backward kernels need short-lived workspaces."""
+    """Reusable scratch buffer per (device, tag): backward kernels need short-lived workspaces.
+
+    Under stream capture the buffer comes from the capturing graph's PRIVATE memory pool instead (a plain allocation while
+    capturing): the graph then owns every scratch address its kernels were recorded with, for as long as it lives.  Handing
+    out the shared buffer would bake its address into the graph while a later, larger eager request replaces (and frees)
+    it -- the replay would write into memory that belongs to someone else."""
+    n = max(nbytes, 16) // 4 + 4
+    if device is not None and torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+        return torch.empty(n, device=device, dtype=torch.float32)
     key = (str(device), tag)
     buf = _scratch.get(key)
-    n = max(nbytes, 16) // 4 + 4
     if buf is None or buf.numel() < n:
         buf = torch.empty(n, device=device, dtype=torch.float32)
         _scratch[key] = buf

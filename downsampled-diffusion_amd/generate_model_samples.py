@@ -5,8 +5,12 @@
 batches (+ latent list for dDDPM), printing the same three timing lines.
 
 The reference hard-codes its constants; here they are the defaults of optional flags.  Extensions:
-  * runs one process per GPU under torchrun: rank 0 broadcasts the weights once (RCCL), every rank samples its own
-    batches with its own Philox stream and writes ``{saved_model}.rank{r}.npy`` (no collective in the loop);
+  * runs one process per GPU under torchrun: rank 0 broadcasts the weights once (RCCL), every rank samples a contiguous
+    run of the job's batches (no collective in the loop) and writes ``{saved_model}.rank{r}.npy``; rank 0 then merges the
+    shards into the single ``{saved_model}.npy`` the evaluator loads (reference evaluate_ddpm.py:52).  A batch's draws
+    (x_T, Philox key) depend only on its GLOBAL batch index, so the merged file is bit-identical to a 1-process run;
+  * the device -> host stage is asynchronous (utils.OutputStage: pinned double buffer + events), so a batch's copy
+    overlaps the next batch's sampling;
   * ``--synthetic CONFIG`` builds deterministic synthetic weights when no checkpoint exists (offline boxes).
 """
 import argparse
@@ -18,8 +22,9 @@ import numpy as np
 import torch
 
 from models import DDPM, DownsampleDDPM, Unet
-from parallel import broadcast_module_, init_from_env, shard_sizes
-from utils import CHECKPOINT_DIR, SAMPLE_DIR, SAMPLE_LATENT_DIR, fix_samples, get_color_channels, get_model_state_dict
+from parallel import barrier, broadcast_module_, init_from_env, shard_sizes
+from utils import (CHECKPOINT_DIR, SAMPLE_DIR, SAMPLE_LATENT_DIR, OutputStage, get_color_channels, get_model_state_dict,
+                   load_checkpoint_file, merge_rank_shards)
 from utils import synthetic as syn
 
 
@@ -32,10 +37,14 @@ def main():
     ap.add_argument("--early_stop", type=int, default=None)
     ap.add_argument("--synthetic", default=None, help="JSON config file: use closed-form synthetic weights, no checkpoint")
     ap.add_argument("--out_dir", default=None)
+    ap.add_argument("--seed", type=int, default=1234, help="base seed: batch g of the job draws from seed + g")
+    ap.add_argument("--keep_shards", action="store_true", help="keep the per-rank .rank{r}.npy files after the merge")
     args = ap.parse_args()
 
     rank, world = init_from_env()
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if local >= torch.cuda.device_count():       # several ranks rehearsed on one GPU (DDK_DIST_BACKEND=gloo)
+        local = 0
     torch.cuda.set_device(local)
     device = f"cuda:{local}"
 
@@ -45,7 +54,7 @@ def main():
             config = json.load(f)
         model_state_dict = None
     else:
-        save_data = torch.load(os.path.join(CHECKPOINT_DIR, f"{args.saved_model}.pt"), map_location="cpu")
+        save_data = load_checkpoint_file(os.path.join(CHECKPOINT_DIR, f"{args.saved_model}.pt"))
         model_state_dict = get_model_state_dict(save_data)
         config = save_data["config"]
         step = save_data.get("step", 0)
@@ -65,43 +74,55 @@ def main():
         model.load_state_dict(model_state_dict)
     model = model.to(device).eval()
     broadcast_module_(model, src=0)
-    model.rng_stream_id = rank
-    torch.manual_seed(1234 + rank)
+    model.rng_stream_id = 0
 
-    n_mine = shard_sizes(args.fid_samples, world)[rank]
+    # the job = ceil(fid_samples / batch) batches; rank r takes a contiguous run of them
+    bs = config["batch_size"]
+    n_batches_total = int(np.ceil(args.fid_samples / bs))
+    mine = shard_sizes(n_batches_total, world)
+    g0, n_batches = sum(mine[:rank]), mine[rank]
     if rank == 0:
         print(f"\nGenerating {args.fid_samples} samples from checkpoint {args.saved_model}.")
         print(f"Trained for {step} steps with configuration dict:")
         print(json.dumps(config, sort_keys=False, indent=4, default=str) + "\n")
-    sample_list, latent_list = [], []
+    stage, latent_stage = OutputStage(), OutputStage()
     time_start = time.time()
-    n_batches = int(np.ceil(n_mine / config["batch_size"]))
-    for _ in range(n_batches):
-        samples = model.sample(config["batch_size"], args.sample_every, args.early_stop)
+    for g in range(g0, g0 + n_batches):
+        torch.manual_seed(args.seed + g)          # x_T and the Philox key of batch g: the same on whichever rank runs it
+        samples = model.sample(bs, args.sample_every, args.early_stop)
         if config["model"] == "dddpm":
             samples, latent_samples = samples
-            latent_list.append(fix_samples(latent_samples))
-        sample_list.append(fix_samples(samples))
+            latent_stage.submit(latent_samples)
+        stage.submit(samples)
+    sample_list, latent_list = stage.finish(), latent_stage.finish()
     torch.cuda.synchronize()
     sampling_time = time.time() - time_start
 
-    print(f"Using batch size {config['batch_size']}")
+    print(f"Using batch size {bs}")
     print(f"Total time: {sampling_time}")
-    print(f"Sample time: {sampling_time / max(n_mine, 1)}")
+    print(f"Sample time: {sampling_time / max(n_batches * bs, 1)}")
     print(f"Batch time: {sampling_time / max(n_batches, 1)}")
 
-    suffix = "" if world == 1 else f".rank{rank}"
-    out_dir = args.out_dir or SAMPLE_DIR
-    os.makedirs(out_dir, exist_ok=True)
-    save_path = os.path.join(out_dir, args.saved_model + suffix)
-    np.save(save_path, sample_list, allow_pickle=False)
-    print(f"Samples saved to {save_path}")
+    def save(directory, name, batches):
+        os.makedirs(directory, exist_ok=True)
+        base = os.path.join(directory, name)
+        if world == 1:
+            np.save(base, batches, allow_pickle=False)
+            return base
+        np.save(f"{base}.rank{rank}", batches, allow_pickle=False)
+        barrier()                                   # every shard is on disk
+        if rank == 0:
+            merge_rank_shards(base, world, remove=not args.keep_shards)
+        barrier()
+        return base
+
+    save_path = save(args.out_dir or SAMPLE_DIR, args.saved_model, sample_list)
+    if rank == 0:
+        print(f"Samples saved to {save_path}")
     if config["model"] == "dddpm":
-        lat_dir = args.out_dir or SAMPLE_LATENT_DIR
-        os.makedirs(lat_dir, exist_ok=True)
-        save_path = os.path.join(lat_dir, args.saved_model + "_latent" + suffix if args.out_dir else args.saved_model + suffix)
-        np.save(save_path, latent_list, allow_pickle=False)
-        print(f"Latent samples saved to {save_path}")
+        save_path = save(args.out_dir or SAMPLE_LATENT_DIR, args.saved_model + "_latent" if args.out_dir else args.saved_model, latent_list)
+        if rank == 0:
+            print(f"Latent samples saved to {save_path}")
 
 
 if __name__ == "__main__":

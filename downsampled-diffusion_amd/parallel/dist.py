@@ -19,8 +19,8 @@ def init_from_env(backend=None):
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend is None:      # DDK_DIST_BACKEND=gloo: rehearse N ranks on one GPU (RCCL wants one device per rank)
+            backend = os.environ.get("DDK_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         dist.init_process_group(backend, rank=rank, world_size=world)
     return rank, world
 

@@ -4,10 +4,8 @@ config, load optimiser / model / EMA / step, continue."""
 import argparse
 import os
 
-import torch
-
 from trainers import setup_trainer
-from utils import LOGGING_DIR
+from utils import LOGGING_DIR, load_checkpoint_file
 
 DATA_ROOT = '../data/'
 WANDB_PROJECT = 'ddpm-test'
@@ -19,7 +17,7 @@ if __name__ == '__main__':
     ap.add_argument('-mute', action='store_true')
     args = ap.parse_args()
     path = args.checkpoint if os.path.exists(args.checkpoint) else os.path.join(LOGGING_DIR, args.checkpoint)
-    checkpoint = torch.load(path, map_location='cpu', weights_only=False)
+    checkpoint = load_checkpoint_file(path)
     config = checkpoint['config']
     if args.n_steps is not None:
         config['n_steps'] = args.n_steps

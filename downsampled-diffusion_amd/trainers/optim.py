@@ -77,9 +77,23 @@ class FusedAdam:
         return {"state": state, "param_groups": [group]}
 
     def load_state_dict(self, sd):
+        """Accepts the dict torch.optim.Adam.state_dict() writes for the same parameter list (the reference trainer's
+        checkpoints, trainers/trainer_ddpm.py:51) as well as our own; parameter count and shapes are validated."""
+        if len(sd.get("param_groups", [])) != 1:
+            raise ValueError(f"FusedAdam: expected one param group, got {len(sd.get('param_groups', []))}")
         group = sd["param_groups"][0]
-        self.lr, self.betas, self.eps = group["lr"], tuple(group["betas"]), group["eps"]
+        if group.get("amsgrad") or group.get("weight_decay", 0) or group.get("maximize"):
+            raise ValueError("FusedAdam: amsgrad / weight_decay / maximize are not supported (the reference uses Adam defaults)")
+        if len(group["params"]) != len(self.fp.params):
+            raise ValueError(f"FusedAdam: optimizer state is for {len(group['params'])} parameters, the model has {len(self.fp.params)}")
         state = sd.get("state", {})
+        for i, st in state.items():
+            p = self.fp.params[int(i)]
+            for k in ("exp_avg", "exp_avg_sq"):
+                if tuple(st[k].shape) != tuple(p.shape):
+                    raise ValueError(f"FusedAdam: state[{i}].{k} has shape {tuple(st[k].shape)}, parameter '{self.fp.names[int(i)]}' is "
+                                     f"{tuple(p.shape)}")
+        self.lr, self.betas, self.eps = group["lr"], tuple(group["betas"]), group["eps"]
         self.exp_avg.zero_()
         self.exp_avg_sq.zero_()
         self.step_count = 0

@@ -44,3 +44,12 @@ def flat_bits(x):
 def get_model_state_dict(save_data):
     """utils.py:51-54: prefer the EMA weights of a checkpoint."""
     return save_data['ema_model'] if 'ema_model' in save_data else save_data['model']
+
+
+def load_checkpoint_file(path, map_location='cpu'):
+    """The ONE checkpoint reader of the CLIs (generate_model_samples.py, train_from_checkpoint.py).  Checkpoints written by
+    the reference trainer (trainers/trainer_ddpm.py:49-62) carry numpy scalars in `train_losses` (np.mean) and a config dict
+    with tuples: torch >= 2.6's default weights_only=True refuses to unpickle them, so the full unpickler is requested
+    explicitly -- these are the user's own training checkpoints, exactly what the reference's torch.load read."""
+    import torch
+    return torch.load(path, map_location=map_location, weights_only=False)

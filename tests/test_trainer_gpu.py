@@ -188,6 +188,52 @@ def test_graphed_accumulation_matches_eager(tag):
     assert not torch.equal(results["graph"][0][1], results["graph"][1][1])     # the second step saw the updated weights
 
 
+def test_graph_replay_survives_larger_eager_pass():
+    """the captured graph must own its scratch.  Capture at batch 4, then run an EAGER forward/backward at batch 16
+    on a second model (every shared scratch buffer is replaced by a larger one, the old ones are freed and their memory
+    re-used by fresh allocations), then replay: gradients must still equal the eager reference bit for bit."""
+    from models import DDPM, Unet
+    from trainers.graph_step import GraphedAccumulation
+    from trainers.optim import FusedAdam
+    cfg = ddpm_cfg(32, 3, 16)
+    tt = torch.tensor([0, 41, 500, 998], device=DEV)
+    eps = syn.synthetic_normal((4, 3, 16, 16), "graph.eps").to(DEV)
+    batches = [syn.synthetic_input((4, 3, 16, 16), f"graph.x{mb}").to(DEV) for mb in range(2)]
+    orig = torch.randn_like
+
+    def run(graph):
+        model = det_load(DDPM(cfg, Unet(cfg), DEV, 3)).to(DEV).train()
+        model.t_sample = lambda n, tt=tt: tt
+        torch.randn_like = lambda z, eps=eps: eps
+        opt = FusedAdam(model, lr=2e-4, max_grad_norm=1.0)
+        ga = GraphedAccumulation(model, 2)
+        if not graph:
+            ga.static_x = batches
+            rows = ga._run()
+            return rows.cpu(), opt.fp.grad.clone().cpu()
+        ga.capture(batches)
+        opt.zero_grad()
+        # a bigger eager pass on another model in between (different shapes -> larger scratch, fresh allocations)
+        big_cfg = ddpm_cfg(64, 3, 32)
+        big = det_load(DDPM(big_cfg, Unet(big_cfg), DEV, 3)).to(DEV).train()
+        torch.randn_like = orig
+        junk = [torch.full((1 << 20,), float("nan"), device=DEV) for _ in range(8)]      # poison freed blocks that get re-used
+        loss = big(syn.synthetic_input((16, 3, 32, 32), "graph.big").to(DEV))
+        loss.backward()
+        del junk
+        torch.cuda.synchronize()
+        torch.randn_like = lambda z, eps=eps: eps
+        rows = ga.replay(batches).clone()
+        return rows.cpu(), opt.fp.grad.clone().cpu()
+
+    try:
+        want = run(False)
+        got = run(True)
+    finally:
+        torch.randn_like = orig
+    assert torch.equal(want[0], got[0]) and torch.equal(want[1], got[1])
+
+
 def test_graphed_dropout_draws_fresh_masks():
     """With unet_dropout > 0 two replays of the same captured step on the same inputs give different objectives (the
     device-side dropout epoch advances inside the graph), and the trainer loop runs through the graph path."""
