@@ -17,31 +17,9 @@
 // tiny kernel in a fixed order, so results are run-to-run deterministic (no float atomics).
 #include <cstdlib>
 
-#include "ddk_internal.h"
+#include "conv_common.h"
 
 namespace ddk {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-// exact unsigned division by a runtime constant (Granlund-Montgomery): 3 VALU ops instead of the ~30 of a hardware-less
-// integer divide; the prologue of every workgroup does four of them per DMA piece
-struct FastDivU {
-    unsigned mul, sh1, sh2, d;
-};
-static FastDivU make_fastdiv_u(unsigned d) {
-    FastDivU f;
-    f.d = d;
-    unsigned l = 0;
-    while ((1ull << l) < d) ++l;
-    f.mul = (unsigned)(((1ull << 32) * ((1ull << l) - d)) / d + 1);
-    f.sh1 = l < 1 ? l : 1;
-    f.sh2 = l > 0 ? l - 1 : 0;
-    return f;
-}
-__device__ __forceinline__ unsigned fdiv_u(unsigned n, const FastDivU& f) {
-    const unsigned t = __umulhi(f.mul, n);
-    return (t + ((n - t) >> f.sh1)) >> f.sh2;
-}
 
 struct IgemmParams {
     const float* src0;
@@ -279,11 +257,6 @@ __device__ __attribute__((aligned(128))) float g_zero_page[32];
 // written to a buffer of their own, never read by any kernel (MI355X_MICROARCH.md, DVFS give-back item 6).
 __device__ unsigned long long g_stamps[6 * 4096];
 
-// one 1-KiB piece: LDS[m0 + lane*16 .. +16) <- 16 bytes at this lane's global address
-__device__ __forceinline__ void lds_dma16(const float* g, unsigned lds_byte_addr) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_byte_addr), "v"(g) : "memory", "m0");
-}
-
 // Shared epilogue of the DMA kernels: a wave's (TM*32) x (TN*32) accumulator block goes through LDS (pitch TN*32+8
 // floats: the two half-waves of an MFMA register, 4 rows apart, land 32 banks apart) and leaves as float4 rows --
 // 4x fewer store instructions than one dword store per accumulator register, and full 128/256-byte row segments.
@@ -358,9 +331,6 @@ __device__ __forceinline__ void consume_epilogue_args(const IgemmParams& p) {
     asm volatile("" ::"s"(ss), "s"(sp), "s"(pm), "s"(MM), "s"(NN), "s"(os), "s"(wm), "s"(hm), "s"(ho), "s"(wo), "s"(p.out), "s"(p.bias),
                  "s"(p.resid), "s"(p.ln_c1), "s"(p.ln_c2), "s"(le));
 }
-
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // im2col implicit GEMM, all waves load and multiply (every conv kind; the 3x3 stride-1 layers with enough pixels use the
 // halo kernel further down).
@@ -1290,6 +1260,30 @@ int conv_forward(const ddk_conv_args& a, hipStream_t st, const ConvLnFold* ln) {
     DDK_REQUIRE((long long)a.B * g.Ho * g.Wo * a.N < (1LL << 31) && (long long)a.B * a.H * a.W * (a.c0 + a.c1) < (1LL << 31),
                 "conv: tensor too large for 32-bit pixel indexing");
 
+    if (a.weight_wino && !a.pre_mish && conv_wino_ok(a.kind, a.H, a.W, a.c0 + a.c1, a.N)) {
+        // Winograd F(2x2, 3x3) path (conv_wino.hip): same slab / reduce conventions as the direct kernels
+        DDK_REQUIRE(aligned16(a.weight_wino), "conv: weight_wino alignment");
+        DDK_TRY(ensure_device_init());
+        const int ws = conv_wino_splits(a.B, a.H, a.W, a.c0 + a.c1, a.N);
+        const long long slab = (long long)a.B * a.H * a.W * a.N;
+        if (ws > 1) {
+            const size_t need = (size_t)ws * slab * sizeof(float);
+            if (!a.workspace || a.workspace_bytes < need) {
+                set_error("conv(wino): split-K workspace too small (%zu < %zu)", a.workspace_bytes, need);
+                return DDK_ERR_WORKSPACE;
+            }
+            DDK_REQUIRE(aligned16(a.workspace), "conv: workspace alignment");
+        }
+        DDK_TRY(conv_wino_forward(a, ws, st));
+        if (ws > 1 && !a.defer_reduce) {
+            const long long n4 = slab / 4;
+            const int blocks = (int)(ceil_div(n4, 256) < 2048 ? ceil_div(n4, 256) : 2048);
+            hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, static_cast<const float*>(a.workspace), ws, slab, a.bias,
+                               a.resid, a.out, n4, a.N, a.post_mish);
+            DDK_TRY(check_launch("splitk_reduce_kernel"));
+        }
+        return DDK_OK;
+    }
     IgemmParams p{};
     p.src0 = a.src0; p.src1 = a.src1; p.w = a.weight; p.bias = a.bias; p.resid = a.resid; p.out = a.out;
     p.c0 = a.c0; p.c1 = a.c1; p.cin = a.c0 + a.c1;

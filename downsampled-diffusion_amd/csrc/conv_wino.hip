@@ -1,0 +1,385 @@
+// conv_wino.hip -- 3x3 stride-1 conv as Winograd F(2x2, 3x3) on the fp32 matrix pipe (gfx950).
+//
+// Replaces the Conv2d(k3, p1) dispatch of reference models/unet/blocks.py:78 (and unet.py:97, the concat feeding it) where
+// the channel counts make it a dense contraction.  Why: sections 3.1 / 3.1b of DESIGN.md -- the direct implicit GEMM is
+// bound by the matrix pipe (MFMA busy 78 %, fp32 MFMA = the chip's fp32 rate), not by operand traffic (a CU takes in
+// 60-130 GB/s from L2 when enough is in flight).  F(2x2, 3x3) needs 16 multiplies per 2x2 output tile instead of 36:
+// 2.25x less MFMA work for 16/9 more weight bytes, which the DMA path has room for.
+//
+//   Y = A^T [ (G g G^T) o (B^T d B) ] A     per 4x4 input patch d (tiles stride 2), 3x3 filter g
+//   U[p][n][c] = (G g[n][c] G^T)[p]         packed once per weight update (pack_conv_weight_wino_kernel)
+//   V[p][t][c] = (B^T d[t][c] B)[p]         computed by the loader waves while they stage the input
+//   M[p][t][n] = sum_c V[p][t][c] U[p][n][c]   16 independent GEMMs (positions p = 4i + j), v_mfma_f32_32x32x2_f32
+//   Y[t][n]    = A^T M[:][t][n] A           register adds across the 4 accumulators of a wave + one LDS exchange
+// Exact fp32 products; the transforms only add and halve, so the result differs from the direct sum by reordering only
+// (tests: <= 2e-5 of the tensor's max against F.conv2d, same bar as the direct kernels).
+//
+// Workgroup = 32 tiles (128 output pixels, any 32 consecutive tiles of the (b, ty, tx) list) x 64 output channels,
+// 4 matrix waves + 4 loader waves (the halo kernel's split).  k runs over (32-channel chunk, position row i): one STAGE =
+// the 4 positions p = 4i + w of one chunk, matrix wave w multiplies position 4i + w: V image 32 tiles x 32 ch against U image
+// 64 n x 32 ch into acc[i][2] -- 32 MFMAs (2048 cycles) per wave and stage, 8 accumulators (128 registers) per wave.
+//   LDS: 3 stages x (V 16 KB + U 32 KB) = 144 KB; rows of 128 bytes, k-chunk position XOR-swizzled by (row >> 1) & 7
+//   loader thread (tile t = id >> 3, channel quad cq = id & 7): 16 float4 global loads per chunk (its 4x4 patch), ~100 adds,
+//     then one ds_write_b128 per position; row i of V goes out during stage i-1 (row 0 of the next chunk during stage 3)
+//   loader wave lw: the U image of position 4i + lw as 8 LDS-DMA pieces, issued two stages ahead
+//   one s_barrier per stage: U(S+1) landed (s_waitcnt vmcnt(8): only the pieces of U(S+2) may fly), V(S+1) written
+//     (lgkmcnt(0)), everyone done reading stage S-1.
+#include "conv_common.h"
+
+namespace ddk {
+
+__device__ __attribute__((aligned(128))) float g_wino_zero[32];
+
+struct WinoParams {
+    const float* src0;
+    const float* src1;
+    const float* wu;       // [cin/32][16][N][32]
+    const float* bias;
+    const float* resid;
+    float* out;
+    int c0, c1, cin;
+    int B, H, W, TH, TW;
+    int N, tiles;          // tiles = B * TH * TW
+    int splits, chunks, chunks_per_split;
+    long long slab_stride;
+    int post_mish;
+    FastDivU dTW, dTH;
+};
+
+constexpr int WBT = 32, WBN = 64;                        // tiles and output channels per workgroup
+constexpr int W_V = 4 * WBT * 32, W_U = 4 * WBN * 32;    // floats per stage: 4 V images, 4 U images
+constexpr int W_STAGE = W_V + W_U, W_NS = 3;
+constexpr int W_LDS_FLOATS = W_NS * W_STAGE;             // 36864 floats = 144 KB
+constexpr int W_TP = WBN + 4;                            // epilogue staging pitch
+static_assert(4 * 2 * WBT * W_TP <= W_LDS_FLOATS, "epilogue staging fits");
+
+// G g G^T for one (n, c): G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
+__global__ __launch_bounds__(256) void pack_conv_weight_wino_kernel(const float* __restrict__ w, float* __restrict__ dst, int O, int I,
+                                                                     int i_pad, long long total) {
+    for (long long idx = blockIdx.x * 256LL + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int c = (int)(idx % i_pad);
+        const int n = (int)(idx / i_pad);
+        float g[3][3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) g[a][b] = c < I ? w[(((long long)n * I + c) * 3 + a) * 3 + b] : 0.f;
+        float t[4][3];
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            t[0][b] = g[0][b];
+            t[1][b] = 0.5f * ((g[0][b] + g[1][b]) + g[2][b]);
+            t[2][b] = 0.5f * ((g[0][b] - g[1][b]) + g[2][b]);
+            t[3][b] = g[2][b];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float u0 = t[i][0], u1 = 0.5f * ((t[i][0] + t[i][1]) + t[i][2]), u2 = 0.5f * ((t[i][0] - t[i][1]) + t[i][2]), u3 = t[i][2];
+            const float u[4] = {u0, u1, u2, u3};
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                dst[((((long long)(c >> 5)) * 16 + (4 * i + j)) * O + n) * 32 + (c & 31)] = u[j];
+        }
+    }
+}
+
+__device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 f4sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+
+__global__ __launch_bounds__(512) void conv3x3_wino_kernel(const WinoParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int tile_m, tile_n, split;
+    {   // XCD-aware order: every XCD gets a contiguous run of (n fastest, then m, then split) tiles
+        const int nwg = gridDim.x * gridDim.y * gridDim.z;
+        const int bid = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        tile_n = logical % gridDim.y;
+        const int rest = logical / gridDim.y;
+        tile_m = rest % gridDim.x;
+        split = rest / gridDim.x;
+    }
+    const int t0 = tile_m * WBT, n0 = tile_n * WBN;
+    const int c_begin = split * p.chunks_per_split;
+    const int n_chunks = min(p.chunks, c_begin + p.chunks_per_split) - c_begin;
+    const int n_stages = n_chunks * 4;
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) float*)smem;
+
+    if (wid >= 4) {
+        // ================================================================ loader wave
+        const int lw = wid - 4;
+        const int lt = lw * 64 + lane;
+        const int t = lt >> 3, cq = lt & 7;
+        __builtin_amdgcn_s_setprio(3);
+        // this thread's tile and the validity of its 4x4 patch pixels
+        const int g = t0 + t;
+        const bool tile_ok = g < p.tiles;
+        const unsigned gg = tile_ok ? (unsigned)g : 0u;
+        const unsigned tmp = fdiv_u(gg, p.dTW);
+        const int tx = (int)(gg - tmp * (unsigned)p.TW);
+        const unsigned bq = fdiv_u(tmp, p.dTH);
+        const int ty = (int)(tmp - bq * (unsigned)p.TH), b = (int)bq;
+        const int py0 = 2 * ty - 1, px0 = 2 * tx - 1;
+        const int pix0 = (b * p.H + py0) * p.W + px0;          // may be "negative": only used where the mask says valid
+        unsigned mask = 0;
+#pragma unroll
+        for (int dy = 0; dy < 4; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 4; ++dx)
+                if (tile_ok && (unsigned)(py0 + dy) < (unsigned)p.H && (unsigned)(px0 + dx) < (unsigned)p.W) mask |= 1u << (dy * 4 + dx);
+        const float* zero = g_wino_zero;
+        const int v_off = t * 32 + ((cq ^ ((t >> 1) & 7)) << 2);     // float offset of this thread's float4 inside a V image
+        // U pieces: loader lw moves the image of position 4i + lw; piece j = rows j*8 + prow
+        const int prow = lane >> 3, ppos = lane & 7;
+        long long u_off[8];
+        unsigned u_ok = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int r = j * 8 + prow, n = n0 + r;
+            if (n < p.N) u_ok |= 1u << j;
+            u_off[j] = (long long)(n < p.N ? n : 0) * 32 + ((ppos ^ ((r >> 1) & 7)) << 2);
+        }
+
+        auto load_patch = [&](int chunk, float4 (&d)[16]) {
+            const int cc = chunk << 5;
+            const bool first = cc < p.c0;                              // wave-uniform
+            const float* src = first ? p.src0 : p.src1;
+            const int cs = first ? p.c0 : p.c1, coff = (first ? cc : cc - p.c0) + cq * 4;
+#pragma unroll
+            for (int dy = 0; dy < 4; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 4; ++dx) {
+                    const long long off = (long long)(pix0 + dy * p.W + dx) * cs + coff;
+                    const float* ptr = ((mask >> (dy * 4 + dx)) & 1u) ? src + off : zero;
+                    d[dy * 4 + dx] = *reinterpret_cast<const float4*>(ptr);
+                }
+        };
+        auto transform = [&](const float4 (&d)[16], float4 (&v)[16]) {   // V = B^T d B, B^T = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,1,0,-1]]
+            float4 r[16];
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                r[0 * 4 + x] = f4sub(d[0 * 4 + x], d[2 * 4 + x]);
+                r[1 * 4 + x] = f4add(d[1 * 4 + x], d[2 * 4 + x]);
+                r[2 * 4 + x] = f4sub(d[2 * 4 + x], d[1 * 4 + x]);
+                r[3 * 4 + x] = f4sub(d[1 * 4 + x], d[3 * 4 + x]);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                v[i * 4 + 0] = f4sub(r[i * 4 + 0], r[i * 4 + 2]);
+                v[i * 4 + 1] = f4add(r[i * 4 + 1], r[i * 4 + 2]);
+                v[i * 4 + 2] = f4sub(r[i * 4 + 2], r[i * 4 + 1]);
+                v[i * 4 + 3] = f4sub(r[i * 4 + 1], r[i * 4 + 3]);
+            }
+        };
+        auto write_v_row = [&](const float4 (&v)[16], int i, int buf) {   // the 4 positions 4i .. 4i+3 of this thread's tile / channels
+            float* base = smem + buf * W_STAGE + v_off;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                // static row select keeps v[] in registers
+                const float4 val = i == 0 ? v[0 * 4 + j] : i == 1 ? v[1 * 4 + j] : i == 2 ? v[2 * 4 + j] : v[3 * 4 + j];
+                *reinterpret_cast<float4*>(base + j * (WBT * 32)) = val;
+            }
+        };
+        auto issue_u = [&](int stage_idx, int buf) {                       // stage index relative to this workgroup's first
+            const int chunk = c_begin + (stage_idx >> 2), pos = 4 * (stage_idx & 3) + lw;
+            const float* ub = p.wu + (((long long)chunk * 16 + pos) * p.N) * 32;
+            const unsigned dst = lds_base + (unsigned)((buf * W_STAGE + W_V + lw * (WBN * 32)) * 4);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float* gptr = ((u_ok >> j) & 1u) ? ub + u_off[j] : zero + ppos * 4;
+                lds_dma16(gptr, dst + (unsigned)(j * 1024));
+            }
+        };
+
+        float4 d[16], v[16];
+        load_patch(c_begin, d);
+        issue_u(0, 0);
+        if (n_stages > 1) issue_u(1, 1);
+        transform(d, v);
+        write_v_row(v, 0, 0);
+        if (n_stages > 1) wait_vmcnt<8>(); else wait_vmcnt<0>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                       // B0: stage 0 complete
+        int b0 = 0;                                                         // buffer of stage S
+        for (int S = 0; S < n_stages; ++S) {
+            const int s = S & 3;
+            const int buf1 = b0 == 2 ? 0 : b0 + 1, buf2 = buf1 == 2 ? 0 : buf1 + 1;   // buffers of stages S+1, S+2 (S+2 re-uses S-1's)
+            if (s == 3 && S + 1 < n_stages) transform(d, v);               // next chunk's V (its patch was loaded during stage s == 0)
+            if (s == 0 && S + 4 < n_stages) load_patch(c_begin + (S >> 2) + 1, d);
+            if (S + 2 < n_stages) issue_u(S + 2, buf2);
+            if (S + 1 < n_stages) {
+                if (s == 0) write_v_row(v, 1, buf1);
+                else if (s == 1) write_v_row(v, 2, buf1);
+                else if (s == 2) write_v_row(v, 3, buf1);
+                else write_v_row(v, 0, buf1);
+            }
+            if (S + 2 < n_stages) wait_vmcnt<8>(); else wait_vmcnt<0>();   // everything but U(S+2)'s pieces has landed
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                                   // B(S+1)
+            b0 = buf1;
+        }
+    } else {
+        // ================================================================ matrix wave
+        const int w = wid;
+        f32x16 acc[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        const int fsw = ((lane & 31) >> 1) & 7, fh = lane >> 5;
+        int foff[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) foff[q] = (lane & 31) * 32 + (((2 * q + fh) ^ fsw) << 2);
+        const int a_img = w * (WBT * 32), b_img = W_V + w * (WBN * 32);
+
+        __builtin_amdgcn_s_barrier();                                       // B0
+        int buf = 0;
+        for (int c = 0; c < n_chunks; ++c) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float* As = smem + buf * W_STAGE + a_img;
+                const float* Bs = smem + buf * W_STAGE + b_img;
+                float4 a[2], b[2][2];
+                a[0] = *reinterpret_cast<const float4*>(As + foff[0]);
+                b[0][0] = *reinterpret_cast<const float4*>(Bs + foff[0]);
+                b[0][1] = *reinterpret_cast<const float4*>(Bs + 1024 + foff[0]);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int cur = q & 1, nxt = cur ^ 1;
+                    if (q < 3) {
+                        a[nxt] = *reinterpret_cast<const float4*>(As + foff[q + 1]);
+                        b[nxt][0] = *reinterpret_cast<const float4*>(Bs + foff[q + 1]);
+                        b[nxt][1] = *reinterpret_cast<const float4*>(Bs + 1024 + foff[q + 1]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const float av = e == 0 ? a[cur].x : e == 1 ? a[cur].y : e == 2 ? a[cur].z : a[cur].w;
+                            const float bv = e == 0 ? b[cur][j].x : e == 1 ? b[cur][j].y : e == 2 ? b[cur][j].z : b[cur][j].w;
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
+                        }
+                }
+                __builtin_amdgcn_s_barrier();                               // B(S+1): stage S released, stage S+1 complete
+                buf = buf == 2 ? 0 : buf + 1;
+            }
+        }
+        // ---- output transform, rows first (in registers): T[a] = sum_i A^T[a][i] M[i][w],  A^T = [[1,1,1,0],[0,1,-1,-1]]
+        float* Ts = smem + w * (2 * WBT * W_TP);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const float m0 = acc[0][j][r], m1 = acc[1][j][r], m2 = acc[2][j][r], m3 = acc[3][j][r];
+                Ts[row * W_TP + j * 32 + (lane & 31)] = (m0 + m1) + m2;
+                Ts[(WBT + row) * W_TP + j * 32 + (lane & 31)] = (m1 - m2) - m3;
+            }
+    }
+    __syncthreads();   // all 8 waves: the T blocks of the 4 matrix waves are in LDS
+
+    // ---- columns: Y[a][0] = T[a]_0 + T[a]_1 + T[a]_2,  Y[a][1] = T[a]_1 - T[a]_2 - T[a]_3  (T[a]_w = matrix wave w's block)
+    const bool direct = p.splits == 1;
+    float* outp = direct ? p.out : p.out + (long long)split * p.slab_stride;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int item = tid + it * 512;
+        const int t = item >> 5, a = (item >> 4) & 1, c4 = (item & 15) * 4;
+        const int g = t0 + t, gn = n0 + c4;
+        if (g >= p.tiles || gn >= p.N) continue;
+        const float* tp = smem + (a * WBT + t) * W_TP + c4;
+        const float4 q0 = *reinterpret_cast<const float4*>(tp);
+        const float4 q1 = *reinterpret_cast<const float4*>(tp + 1 * (2 * WBT * W_TP));
+        const float4 q2 = *reinterpret_cast<const float4*>(tp + 2 * (2 * WBT * W_TP));
+        const float4 q3 = *reinterpret_cast<const float4*>(tp + 3 * (2 * WBT * W_TP));
+        float4 y0 = f4add(f4add(q0, q1), q2);
+        float4 y1 = f4sub(f4sub(q1, q2), q3);
+        const unsigned tmp = fdiv_u((unsigned)g, p.dTW);
+        const int tx = g - (int)tmp * p.TW;
+        const unsigned bq = fdiv_u(tmp, p.dTH);
+        const int ty = (int)tmp - (int)bq * p.TH;
+        const long long o0 = ((((long long)bq * p.H + 2 * ty + a) * p.W) + 2 * tx) * p.N + gn;
+        const long long o1 = o0 + p.N;
+        if (direct) {
+            if (p.bias) {
+                const float4 bb = *reinterpret_cast<const float4*>(p.bias + gn);
+                y0 = f4add(y0, bb);
+                y1 = f4add(y1, bb);
+            }
+            if (p.resid) {
+                y0 = f4add(y0, *reinterpret_cast<const float4*>(p.resid + o0));
+                y1 = f4add(y1, *reinterpret_cast<const float4*>(p.resid + o1));
+            }
+            if (p.post_mish) {
+                y0 = make_float4(mish_f(y0.x), mish_f(y0.y), mish_f(y0.z), mish_f(y0.w));
+                y1 = make_float4(mish_f(y1.x), mish_f(y1.y), mish_f(y1.z), mish_f(y1.w));
+            }
+        }
+        *reinterpret_cast<float4*>(outp + o0) = y0;
+        *reinterpret_cast<float4*>(outp + o1) = y1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+bool conv_wino_ok(int kind, int H, int W, int cin, int N) {
+    return kind == DDK_CONV3X3_S1 && H >= 2 && W >= 2 && H % 2 == 0 && W % 2 == 0 && cin > 0 && cin % 32 == 0 && N % 64 == 0;
+}
+
+// Channel-chunk splits: one workgroup per CU needs >= 256 workgroups; every split keeps at least one chunk.
+int conv_wino_splits(int B, int H, int W, int cin, int N) {
+    const long long tiles = (long long)B * (H / 2) * (W / 2);
+    const long long wgs = ceil_div(tiles, WBT) * (N / WBN);
+    const int chunks = cin / 32;
+    int s = 1;
+    while (wgs * s < 256 && s * 2 <= chunks) s *= 2;
+    const int cps = (int)ceil_div(chunks, s);
+    return (int)ceil_div(chunks, cps);
+}
+
+int conv_wino_init_device() {
+    DDK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(W_LDS_FLOATS * sizeof(float))));
+    return DDK_OK;
+}
+
+// a: validated by conv_forward (shapes, alignment).  Writes the result (or, with splits > 1, the slabs in a.workspace).
+int conv_wino_forward(const ddk_conv_args& a, int splits, hipStream_t st) {
+    WinoParams p{};
+    p.src0 = a.src0; p.src1 = a.src1; p.wu = a.weight_wino; p.bias = a.bias; p.resid = a.resid; p.out = a.out;
+    p.c0 = a.c0; p.c1 = a.c1; p.cin = a.c0 + a.c1;
+    p.B = a.B; p.H = a.H; p.W = a.W; p.TH = a.H / 2; p.TW = a.W / 2;
+    p.N = a.N; p.tiles = a.B * p.TH * p.TW;
+    p.chunks = p.cin / 32;
+    p.chunks_per_split = (int)ceil_div(p.chunks, splits);
+    p.splits = (int)ceil_div(p.chunks, p.chunks_per_split);
+    p.slab_stride = (long long)a.B * a.H * a.W * a.N;
+    p.post_mish = a.post_mish;
+    p.dTW = make_fastdiv_u((unsigned)p.TW);
+    p.dTH = make_fastdiv_u((unsigned)p.TH);
+    if (p.splits > 1) p.out = static_cast<float*>(a.workspace);
+    dim3 grid((unsigned)ceil_div(p.tiles, WBT), (unsigned)(a.N / WBN), (unsigned)p.splits);
+    hipLaunchKernelGGL(conv3x3_wino_kernel, grid, dim3(512), W_LDS_FLOATS * sizeof(float), st, p);
+    return check_launch("conv3x3_wino_kernel");
+}
+
+}  // namespace ddk
+
+extern "C" int ddk_pack_conv_weight_wino(const float* w_oihw, float* dst, int O, int I, int i_pad, ddk_stream_t s) {
+    using namespace ddk;
+    DDK_REQUIRE(w_oihw && dst && O > 0 && I > 0 && i_pad >= I && i_pad % 32 == 0, "pack_conv_weight_wino: arguments (i_pad % 32 == 0)");
+    const long long total = (long long)O * i_pad;
+    const long long blocks = ceil_div(total, 256);
+    hipLaunchKernelGGL(pack_conv_weight_wino_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, as_stream(s), w_oihw, dst,
+                       O, I, i_pad, total);
+    return check_launch("pack_conv_weight_wino_kernel");
+}
+
+extern "C" int ddk_conv_wino_splits(int B, int H, int W, int cin, int N) {
+    if (!ddk::conv_wino_ok(DDK_CONV3X3_S1, H, W, cin, N)) return 0;
+    return ddk::conv_wino_splits(B, H, W, cin, N);
+}

@@ -128,6 +128,11 @@ struct ConvLnFold {
 bool conv_ln_fold_ok(int B, int H, int W, int cin, int N);
 int conv_forward(const ddk_conv_args& a, hipStream_t st, const ConvLnFold* ln = nullptr);
 int conv_splits(int kind, int B, int H, int W, int cin, int N);
+// conv_wino.hip
+bool conv_wino_ok(int kind, int H, int W, int cin, int N);
+int conv_wino_splits(int B, int H, int W, int cin, int N);
+int conv_wino_forward(const ddk_conv_args& a, int splits, hipStream_t st);
+int conv_wino_init_device();
 double conv_flops(int kind, int B, int H, int W, int cin, int N);
 // norm_act.hip
 size_t groupnorm_workspace_bytes(int B, int HW, int C, int groups);

@@ -22,7 +22,7 @@ class ConvArgs(C.Structure):
         ("kind", C.c_int), ("src0", C.c_void_p), ("src1", C.c_void_p), ("c0", C.c_int), ("c1", C.c_int),
         ("weight", C.c_void_p), ("bias", C.c_void_p), ("resid", C.c_void_p), ("out", C.c_void_p),
         ("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("N", C.c_int), ("pre_mish", C.c_int), ("post_mish", C.c_int), ("defer_reduce", C.c_int),
-        ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("weight_wino", C.c_void_p),
     ]
 
 
@@ -53,6 +53,8 @@ SIGNATURES = {
     "ddk_pack_conv_weight": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "ddk_pack_convT_weight": (_I, [_P, _P, _I, _I, _P]),
     "ddk_pack_linear_T": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "ddk_pack_conv_weight_wino": (_I, [_P, _P, _I, _I, _I, _P]),
+    "ddk_conv_wino_splits": (_I, [_I, _I, _I, _I, _I]),
     "ddk_conv_workspace_bytes": (_SZ, [_I, _I, _I, _I, _I, _I]),
     "ddk_conv_splits": (_I, [_I, _I, _I, _I, _I, _I]),
     "ddk_conv_forward": (_I, [C.POINTER(ConvArgs), _P]),

@@ -79,8 +79,16 @@ typedef struct ddk_conv_args {
                           *    (no bias / resid / Mish applied) for ddk_groupnorm_mish_slabs to sum while it loads */
     void* workspace;     /* split-K slabs; may be NULL when ddk_conv_workspace_bytes() == 0 */
     size_t workspace_bytes;
+    const float* weight_wino; /* optional (DDK_CONV3X3_S1 only): the same filter packed by ddk_pack_conv_weight_wino.  When given
+                               * and the shape is eligible (ddk_conv_wino_splits() > 0) the conv runs as Winograd F(2x2,3x3):
+                               * 2.25x fewer MFMA FLOPs, same result up to fp32 summation order.  Its split count (slabs in
+                               * `workspace`) is ddk_conv_wino_splits(), workspace = splits * B*H*W*N floats when > 1. */
 } ddk_conv_args;
 
+/* Conv2d 3x3 weight OIHW -> Winograd-domain filter U = G g G^T, [I_pad/32][16 positions][O][32] (blocks.py:78). */
+int ddk_pack_conv_weight_wino(const float* w_oihw, float* dst, int O, int I, int i_pad, ddk_stream_t s);
+/* 0: shape not eligible for the Winograd kernel (needs even H, W; cin % 32 == 0; N % 64 == 0); else its channel-chunk splits */
+int ddk_conv_wino_splits(int B, int H, int W, int cin, int N);
 size_t ddk_conv_workspace_bytes(int kind, int B, int H, int W, int cin, int N);
 /* number of k-splits (partial slabs) the launch for this shape uses; 1 = written directly */
 int ddk_conv_splits(int kind, int B, int H, int W, int cin, int N);

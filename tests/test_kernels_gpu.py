@@ -85,6 +85,52 @@ def test_conv(ops, kind, B, H, W, c0, c1, N):
     assert torch.equal(out, ops.conv(code, x0, wp, bias.to(DEV), x2=x1))
 
 
+WINO_CASES = [  # B, H, W, c0, c1, N  (Winograd F(2x2,3x3): even H, W; cin % 32 == 0; N % 64 == 0)
+    (2, 8, 8, 32, 0, 64),          # one chunk, 32 tiles exactly
+    (2, 4, 4, 64, 0, 64),          # 8 tiles < 32: ragged tile block, channel-chunk splits
+    (3, 6, 10, 96, 0, 128),        # odd tile counts (45 tiles), 3 chunks
+    (2, 16, 16, 128, 128, 128),    # concat of two sources (unet.py:97), 8 chunks
+    (32, 4, 4, 256, 0, 256),       # cfg4 4x4 level: splits > 1
+    (32, 4, 4, 256, 256, 256),     # cfg4 ups.0.0 conv1
+    (4, 32, 32, 128, 0, 128),      # cfg4 32x32 level
+    (4, 16, 16, 256, 0, 256),
+    (2, 2, 2, 32, 0, 64),          # a single tile per image
+]
+
+
+@pytest.mark.parametrize("B,H,W,c0,c1,N", WINO_CASES)
+def test_conv_winograd(ops, B, H, W, c0, c1, N):
+    """conv3x3_wino_kernel (F(2x2,3x3) on the fp32 MFMA) against F.conv2d: same bar as the direct kernels; bias, residual,
+    Mish epilogue, concat, split reduction, run-to-run bit stability, and agreement with the direct kernel."""
+    cin = c0 + c1
+    x = rnd(B, cin, H, W, seed=61)
+    w = rnd(N, cin, 3, 3, seed=62, scale=(cin * 9) ** -0.5)
+    bias = rnd(N, seed=63, scale=0.1)
+    ref = F.conv2d(x, w, bias, padding=1)
+    wp, wu = ops.pack_conv_weight(w.to(DEV)), ops.pack_conv_weight_wino(w.to(DEV))
+    assert ops.L.load().ddk_conv_wino_splits(B, H, W, cin, N) >= 1
+    xh = to_nhwc(x).to(DEV)
+    x0 = xh[..., :c0].contiguous()
+    x1 = xh[..., c0:].contiguous() if c1 else None
+    out = ops.conv(ops.CONV3X3_S1, x0, wp, bias.to(DEV), x2=x1, w_wino=wu)
+    assert rel_err(to_nchw(out.cpu()), ref) < 2e-5
+    direct = ops.conv(ops.CONV3X3_S1, x0, wp, bias.to(DEV), x2=x1)
+    assert rel_err(out.cpu(), direct.cpu()) < 2e-5
+    resid = rnd(*ref.shape, seed=64)
+    out_r = ops.conv(ops.CONV3X3_S1, x0, wp, bias.to(DEV), x2=x1, resid=to_nhwc(resid).to(DEV), post_mish=True, w_wino=wu)
+    assert rel_err(to_nchw(out_r.cpu()), U.mish(ref + resid)) < 2e-5
+    assert torch.equal(out, ops.conv(ops.CONV3X3_S1, x0, wp, bias.to(DEV), x2=x1, w_wino=wu))
+
+
+def test_conv_winograd_not_eligible_falls_back_to_direct(ops):
+    """odd W / N % 64 != 0: the Winograd weights are ignored, the direct kernel runs (same entry point, same result)"""
+    x = rnd(2, 32, 6, 7, seed=65)
+    w = rnd(32, 32, 3, 3, seed=66, scale=(32 * 9) ** -0.5)
+    assert ops.L.load().ddk_conv_wino_splits(2, 6, 7, 32, 32) == 0
+    out = ops.conv(ops.CONV3X3_S1, to_nhwc(x).to(DEV), ops.pack_conv_weight(w.to(DEV)), None, w_wino=ops.pack_conv_weight_wino(w.to(DEV)))
+    assert rel_err(to_nchw(out.cpu()), F.conv2d(x, w, None, padding=1)) < 2e-5
+
+
 def test_conv_pre_post_mish(ops):
     x = rnd(2, 64, 16, 16, seed=5)
     w = rnd(32, 64, 1, 1, seed=6, scale=0.125)
