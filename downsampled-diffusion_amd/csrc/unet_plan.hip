@@ -24,7 +24,7 @@ constexpr float GN_EPS = 1e-5f, LN_EPS = 1e-5f;
 
 static inline int pad32(int c) { return (c + 31) / 32 * 32; }
 
-enum PackKind { PK_COPY = 0, PK_CONV = 1, PK_CONVT = 2, PK_LINEAR_T = 3 };
+enum PackKind { PK_COPY = 0, PK_CONV = 1, PK_CONVT = 2, PK_LINEAR_T = 3, PK_WINO = 4 };
 
 struct Slot {
     std::string name;
@@ -39,6 +39,8 @@ struct ConvW {
     size_t w = 0, b = 0;
     bool has_bias = false;
     int cin = 0, cin_pad = 0, cout = 0;
+    size_t wu = 0;          // Winograd-domain copy of a 3x3 filter ([cin_pad/32][16][cout][32]); has_wu says whether it exists
+    bool has_wu = false;
 };
 struct NormW { size_t g = 0, b = 0; };
 struct ResW {
@@ -114,6 +116,12 @@ struct ddk_unet {
         slots.push_back(Slot{prefix + "weight", (long long)cout * cin * k * k, PK_CONV, c.w, cout, cin, k, k, c.cin_pad, 0, 0});
         c.has_bias = bias;
         if (bias) c.b = add_copy(prefix + "bias", cout);
+        if (k == 3 && cout % 64 == 0) {
+            // the same state_dict tensor feeds a second slot: its Winograd-domain form G g G^T for conv3x3_wino_kernel
+            c.wu = alloc((size_t)16 * cout * c.cin_pad);
+            c.has_wu = true;
+            slots.push_back(Slot{prefix + "weight", (long long)cout * cin * k * k, PK_WINO, c.wu, cout, cin, k, k, c.cin_pad, 0, 0});
+        }
         return c;
     }
     ConvW add_convT(const std::string& prefix, int ch) {
@@ -334,6 +342,7 @@ extern "C" int ddk_unet_pack_slot(const ddk_unet* u, int slot, const float* cano
         case PK_CONV: rc = ddk_pack_conv_weight(canonical, dst, sl.O, sl.I, sl.KH, sl.KW, sl.i_pad, s); break;
         case PK_CONVT: rc = ddk_pack_convT_weight(canonical, dst, sl.I, sl.O, s); break;
         case PK_LINEAR_T: rc = ddk_pack_linear_T(canonical, dst, sl.O, sl.I, sl.ld, sl.col0, s); break;
+        case PK_WINO: rc = ddk_pack_conv_weight_wino(canonical, dst, sl.O, sl.I, sl.i_pad, s); break;
         default: return fail_arg("unet_pack_slot: slot kind");
     }
     DDK_TRY(rc);
@@ -363,11 +372,25 @@ static size_t al4(size_t n) { return (n + 3) / 4 * 4; }
 
 static void upd(size_t& m, size_t v) { if (v > m) m = v; }
 
+// The 3x3 stride-1 convs run as Winograd F(2x2,3x3) wherever the shape allows (conv_wino.hip); their split count and slab
+// workspace follow that kernel's plan.
+static bool use_wino(const ConvW& cw, int H, int W, int cin, int N) {
+    return cw.has_wu && conv_wino_ok(DDK_CONV3X3_S1, H, W, cin, N);
+}
+static int conv3_splits(const ConvW& cw, int B, int H, int W, int cin, int N) {
+    return use_wino(cw, H, W, cin, N) ? conv_wino_splits(B, H, W, cin, N) : conv_splits(DDK_CONV3X3_S1, B, H, W, cin, N);
+}
+static size_t conv3_ws_floats(const ConvW& cw, int B, int H, int W, int cin, int N) {
+    if (!use_wino(cw, H, W, cin, N)) return conv_workspace_bytes(DDK_CONV3X3_S1, B, H, W, cin, N) / 4;
+    const int s = conv_wino_splits(B, H, W, cin, N);
+    return s > 1 ? (size_t)s * B * H * W * N : 0;
+}
+
 static void res_sizes(const ResW& r, int B, int H, int W, Layout& ly) {
     const size_t M = (size_t)B * H * W;
     upd(ly.act, M * r.co);
-    upd(ly.splitk, conv_workspace_bytes(DDK_CONV3X3_S1, B, H, W, r.ci_pad, r.co) / 4);
-    upd(ly.splitk, conv_workspace_bytes(DDK_CONV3X3_S1, B, H, W, r.co, r.co) / 4);
+    upd(ly.splitk, conv3_ws_floats(r.c1, B, H, W, r.ci_pad, r.co));
+    upd(ly.splitk, conv3_ws_floats(r.c2, B, H, W, r.co, r.co));
     if (r.has_res) upd(ly.splitk, conv_workspace_bytes(DDK_CONV1X1, B, H, W, r.ci_pad, r.co) / 4);
     upd(ly.gn_ws, groupnorm_workspace_bytes(B, H * W, r.co, GROUPS) / 4);
 }
@@ -411,7 +434,7 @@ static Layout make_layout(const ddk_unet& u, int B, int H0, int W0) {
         upd(ly.act, (size_t)B * H * W * c);
     }
     upd(ly.act, (size_t)B * H * W * u.cfg.chan);
-    upd(ly.splitk, conv_workspace_bytes(DDK_CONV3X3_S1, B, H, W, u.cfg.chan, u.cfg.chan) / 4);
+    upd(ly.splitk, conv3_ws_floats(u.final_conv, B, H, W, u.cfg.chan, u.cfg.chan));
     upd(ly.gn_ws, groupnorm_workspace_bytes(B, H * W, u.cfg.chan, GROUPS) / 4);
     ly.xpad = al4((size_t)B * H0 * W0 * pad32(u.cfg.in_ch));
     ly.temb = al4((size_t)B * u.temb_total);
@@ -458,6 +481,7 @@ static int run_conv(Ctx& c, int kind, const ConvW& cw, const float* src0, int c0
     a.defer_reduce = 0;
     a.workspace = c.W + c.ly.off_splitk;
     a.workspace_bytes = c.ly.splitk * sizeof(float);
+    if (kind == DDK_CONV3X3_S1 && !weight_override && use_wino(cw, H, W, c0 + c1, N)) a.weight_wino = c.P + cw.wu;
     return conv_forward(a, c.st, ln);
 }
 
@@ -465,13 +489,14 @@ static int run_conv(Ctx& c, int kind, const ConvW& cw, const float* src0, int c0
 // GroupNorm kernel sums them (plus the conv bias) while loading: one kernel and one HBM round trip fewer.
 static int run_conv_gn(Ctx& c, const ConvW& cw, const float* src0, int c0, const float* src1, int c1, float* raw, const NormW& n,
                        const float* temb, const float* addend, float* out, int H, int W, int N) {
-    const int splits = conv_splits(DDK_CONV3X3_S1, c.B, H, W, c0 + c1, N);
+    const int splits = conv3_splits(cw, c.B, H, W, c0 + c1, N);
     const bool resident = groupnorm_workspace_bytes(c.B, H * W, N, GROUPS) == 0;
     if (splits > 1 && resident) {
         ddk_conv_args a{};
         a.kind = DDK_CONV3X3_S1;
         a.src0 = src0; a.src1 = src1; a.c0 = c0; a.c1 = c1;
         a.weight = c.P + cw.w;
+        if (use_wino(cw, H, W, c0 + c1, N)) a.weight_wino = c.P + cw.wu;
         a.out = raw;  // unused: the slabs are the result
         a.B = c.B; a.H = H; a.W = W; a.N = N;
         a.defer_reduce = 1;
