@@ -32,6 +32,11 @@ __device__ __forceinline__ void lds_dma16(const float* g, unsigned lds_byte_addr
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_byte_addr), "v"(g) : "memory", "m0");
 }
 
+// the same with a wave-uniform 64-bit base (SGPR pair) + a 32-bit per-lane byte offset: no 64-bit VALU address arithmetic
+__device__ __forceinline__ void lds_dma16_s(const float* sbase, unsigned voff_bytes, unsigned lds_byte_addr) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_byte_addr), "v"(voff_bytes), "s"(sbase) : "memory", "m0");
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 

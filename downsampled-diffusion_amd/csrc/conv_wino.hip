@@ -21,9 +21,13 @@
 //   LDS: 3 stages x (V 16 KB + U 32 KB) = 144 KB; rows of 128 bytes, k-chunk position XOR-swizzled by (row >> 1) & 7
 //   loader thread (tile t = id >> 3, channel quad cq = id & 7): 16 float4 global loads per chunk (its 4x4 patch), ~100 adds,
 //     then one ds_write_b128 per position; row i of V goes out during stage i-1 (row 0 of the next chunk during stage 3)
-//   loader wave lw: the U image of position 4i + lw as 8 LDS-DMA pieces, issued two stages ahead
-//   one s_barrier per stage: U(S+1) landed (s_waitcnt vmcnt(8): only the pieces of U(S+2) may fly), V(S+1) written
-//     (lgkmcnt(0)), everyone done reading stage S-1.
+//   U image of position 4i + w (8 LDS-DMA pieces): pieces 0..3 by loader wave w, pieces 4..7 by matrix wave w (one per
+//     quarter, in MFMA shadows), two stages ahead; SGPR base + 32-bit lane offset, no VALU address arithmetic
+//   one s_barrier per stage: B(S) = V of stages <= S+1 written, U of stages <= S landed, everyone done reading stage S-1;
+//     before it a wave waits only for the DMA it issued one stage earlier (s_waitcnt vmcnt(4)); the matrix waves prefetch
+//     stage S+1's first A fragments in the last quarter of stage S.
+#include <cstdlib>
+
 #include "conv_common.h"
 
 namespace ddk {
@@ -86,8 +90,15 @@ __global__ __launch_bounds__(256) void pack_conv_weight_wino_kernel(const float*
 __device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 __device__ __forceinline__ float4 f4sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
 
+// Diagnostic stamps (DBG = 1, tuning build only): per workgroup {entry, loop start, loop end, end} in 100 MHz ticks and the
+// matrix wave's cycles spent waiting at the stage barriers vs multiplying; written to a buffer nothing else reads.
+__device__ unsigned long long g_wino_stamps[8 * 1024];
+
+template <int DBG>
 __global__ __launch_bounds__(512) void conv3x3_wino_kernel(const WinoParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    unsigned long long r_entry = 0;
+    if (DBG) r_entry = __builtin_amdgcn_s_memrealtime();
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     int tile_m, tile_n, split;
@@ -112,7 +123,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino_kernel(const WinoParams p) {
         const int lw = wid - 4;
         const int lt = lw * 64 + lane;
         const int t = lt >> 3, cq = lt & 7;
-        __builtin_amdgcn_s_setprio(3);
+        if (DBG != 3) __builtin_amdgcn_s_setprio(3);
         // this thread's tile and the validity of its 4x4 patch pixels
         const int g = t0 + t;
         const bool tile_ok = g < p.tiles;
@@ -131,94 +142,108 @@ __global__ __launch_bounds__(512) void conv3x3_wino_kernel(const WinoParams p) {
                 if (tile_ok && (unsigned)(py0 + dy) < (unsigned)p.H && (unsigned)(px0 + dx) < (unsigned)p.W) mask |= 1u << (dy * 4 + dx);
         const float* zero = g_wino_zero;
         const int v_off = t * 32 + ((cq ^ ((t >> 1) & 7)) << 2);     // float offset of this thread's float4 inside a V image
-        // U pieces: loader lw moves the image of position 4i + lw; piece j = rows j*8 + prow
+        // U image of position 4i + lw (64 rows x 128 B = 8 pieces of 8 rows): in the loop this loader issues pieces 0..3 and
+        // matrix wave lw issues pieces 4..7 (one per quarter, in MFMA shadows) -- an LDS-DMA piece costs 100-200 issue cycles
+        // next to a busy matrix pipe, and 8 per loader and stage made the loaders the critical path (tools/wino_clock.py).
+        // Wave-uniform base (SGPR pair) + per-lane 32-bit offset: no VALU address arithmetic per piece.
         const int prow = lane >> 3, ppos = lane & 7;
-        long long u_off[8];
-        unsigned u_ok = 0;
+        unsigned u_voff[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int r = j * 8 + prow, n = n0 + r;
-            if (n < p.N) u_ok |= 1u << j;
-            u_off[j] = (long long)(n < p.N ? n : 0) * 32 + ((ppos ^ ((r >> 1) & 7)) << 2);
+            const int r = j * 8 + prow;
+            u_voff[j] = (unsigned)(((n0 + r) * 32 + ((ppos ^ ((r >> 1) & 7)) << 2)) * 4);
         }
-
-        auto load_patch = [&](int chunk, float4 (&d)[16]) {
+        // patch rows (4 pixels x this thread's 4 channels each) of one channel chunk; rows are loaded two at a time so the loads
+        // spread over the stages of the previous chunk
+        auto load_rows = [&](int chunk, float4 (&d)[16], int ra, int rb) {
             const int cc = chunk << 5;
             const bool first = cc < p.c0;                              // wave-uniform
             const float* src = first ? p.src0 : p.src1;
             const int cs = first ? p.c0 : p.c1, coff = (first ? cc : cc - p.c0) + cq * 4;
 #pragma unroll
             for (int dy = 0; dy < 4; ++dy)
+                if (dy == ra || dy == rb) {
 #pragma unroll
-                for (int dx = 0; dx < 4; ++dx) {
-                    const long long off = (long long)(pix0 + dy * p.W + dx) * cs + coff;
-                    const float* ptr = ((mask >> (dy * 4 + dx)) & 1u) ? src + off : zero;
-                    d[dy * 4 + dx] = *reinterpret_cast<const float4*>(ptr);
+                    for (int dx = 0; dx < 4; ++dx) {
+                        const long long off = (long long)(pix0 + dy * p.W + dx) * cs + coff;
+                        const float* ptr = ((mask >> (dy * 4 + dx)) & 1u) ? src + off : zero;
+                        d[dy * 4 + dx] = *reinterpret_cast<const float4*>(ptr);
+                    }
                 }
         };
-        auto transform = [&](const float4 (&d)[16], float4 (&v)[16]) {   // V = B^T d B, B^T = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,1,0,-1]]
-            float4 r[16];
+        // Row i of V = B^T d B (the 4 positions 4i .. 4i+3) of this thread's tile / channels, straight into the V images of
+        // stage buffer `buf`.  B^T = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,1,0,-1]]: row i needs two patch rows only (0: d0-d2,
+        // 1: d1+d2, 2: d2-d1, 3: d1-d3), so the transform is 8 float4 operations per stage instead of 32 once per chunk.
+        auto write_v_row = [&](const float4 (&d)[16], int i, int buf) {
+            float4 r[4];
 #pragma unroll
-            for (int x = 0; x < 4; ++x) {
-                r[0 * 4 + x] = f4sub(d[0 * 4 + x], d[2 * 4 + x]);
-                r[1 * 4 + x] = f4add(d[1 * 4 + x], d[2 * 4 + x]);
-                r[2 * 4 + x] = f4sub(d[2 * 4 + x], d[1 * 4 + x]);
-                r[3 * 4 + x] = f4sub(d[1 * 4 + x], d[3 * 4 + x]);
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                v[i * 4 + 0] = f4sub(r[i * 4 + 0], r[i * 4 + 2]);
-                v[i * 4 + 1] = f4add(r[i * 4 + 1], r[i * 4 + 2]);
-                v[i * 4 + 2] = f4sub(r[i * 4 + 2], r[i * 4 + 1]);
-                v[i * 4 + 3] = f4sub(r[i * 4 + 1], r[i * 4 + 3]);
-            }
-        };
-        auto write_v_row = [&](const float4 (&v)[16], int i, int buf) {   // the 4 positions 4i .. 4i+3 of this thread's tile / channels
+            for (int x = 0; x < 4; ++x)
+                r[x] = i == 0 ? f4sub(d[0 * 4 + x], d[2 * 4 + x]) : i == 1 ? f4add(d[1 * 4 + x], d[2 * 4 + x])
+                     : i == 2 ? f4sub(d[2 * 4 + x], d[1 * 4 + x]) : f4sub(d[1 * 4 + x], d[3 * 4 + x]);
             float* base = smem + buf * W_STAGE + v_off;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                // static row select keeps v[] in registers
-                const float4 val = i == 0 ? v[0 * 4 + j] : i == 1 ? v[1 * 4 + j] : i == 2 ? v[2 * 4 + j] : v[3 * 4 + j];
-                *reinterpret_cast<float4*>(base + j * (WBT * 32)) = val;
-            }
+            *reinterpret_cast<float4*>(base + 0 * (WBT * 32)) = f4sub(r[0], r[2]);
+            *reinterpret_cast<float4*>(base + 1 * (WBT * 32)) = f4add(r[1], r[2]);
+            *reinterpret_cast<float4*>(base + 2 * (WBT * 32)) = f4sub(r[2], r[1]);
+            *reinterpret_cast<float4*>(base + 3 * (WBT * 32)) = f4sub(r[1], r[3]);
         };
-        auto issue_u = [&](int stage_idx, int buf) {                       // stage index relative to this workgroup's first
+        auto issue_u = [&](int stage_idx, int buf, int j_begin, int j_end) {   // stage index relative to this workgroup's first
             const int chunk = c_begin + (stage_idx >> 2), pos = 4 * (stage_idx & 3) + lw;
             const float* ub = p.wu + (((long long)chunk * 16 + pos) * p.N) * 32;
             const unsigned dst = lds_base + (unsigned)((buf * W_STAGE + W_V + lw * (WBN * 32)) * 4);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float* gptr = ((u_ok >> j) & 1u) ? ub + u_off[j] : zero + ppos * 4;
-                lds_dma16(gptr, dst + (unsigned)(j * 1024));
-            }
+            for (int j = 0; j < 8; ++j)
+                if (j >= j_begin && j < j_end) lds_dma16_s(ub, u_voff[j], dst + (unsigned)(j * 1024));
         };
 
-        float4 d[16], v[16];
-        load_patch(c_begin, d);
-        issue_u(0, 0);
-        if (n_stages > 1) issue_u(1, 1);
-        transform(d, v);
-        write_v_row(v, 0, 0);
-        if (n_stages > 1) wait_vmcnt<8>(); else wait_vmcnt<0>();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                                       // B0: stage 0 complete
+        // Schedule.  Barrier B(S) guarantees: V of stages <= S+1 written (so a matrix wave prefetches its next A fragments across
+        // the barrier) and U of stages <= S landed.  In iteration S (after B(S)) a loader writes V row (S+2) & 3 into the buffer
+        // stage S-1 just released and issues its half of U(S+2) into it.  Its work is spread evenly over the stages: 8 patch loads
+        // of the NEXT chunk in iterations s = 0 and 1, one V row (8 float4 adds + 4 ds_write_b128) and 4 DMA pieces per iteration.
+        // Nothing waits for what it has just issued: before B(S+1) a loader waits for the pieces of iteration S-1 only
+        // (s_waitcnt vmcnt(4 + the loads of this iteration)); loads are issued BEFORE the pieces of their iteration, so they are
+        // forced complete one iteration later, long before their first use.
         int b0 = 0;                                                         // buffer of stage S
-        for (int S = 0; S < n_stages; ++S) {
-            const int s = S & 3;
-            const int buf1 = b0 == 2 ? 0 : b0 + 1, buf2 = buf1 == 2 ? 0 : buf1 + 1;   // buffers of stages S+1, S+2 (S+2 re-uses S-1's)
-            if (s == 3 && S + 1 < n_stages) transform(d, v);               // next chunk's V (its patch was loaded during stage s == 0)
-            if (s == 0 && S + 4 < n_stages) load_patch(c_begin + (S >> 2) + 1, d);
-            if (S + 2 < n_stages) issue_u(S + 2, buf2);
-            if (S + 1 < n_stages) {
-                if (s == 0) write_v_row(v, 1, buf1);
-                else if (s == 1) write_v_row(v, 2, buf1);
-                else if (s == 2) write_v_row(v, 3, buf1);
-                else write_v_row(v, 0, buf1);
+        // one chunk = iterations s = 0..3; `cur` holds the patch of chunk (S + 2) / 4 - for s < 2 that is chunk qi, from s = 2 on
+        // chunk qi + 1, loaded into `nxt` during s = 0, 1 (the two arrays swap roles every chunk: static register allocation)
+        auto chunk_body = [&](float4 (&cur)[16], float4 (&nxt)[16], int qi) {
+            const bool has_next = qi + 1 < n_chunks;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int S = qi * 4 + s;
+                const int buf2 = b0 == 0 ? 2 : b0 - 1;                      // (S + 2) % 3 == (S - 1) % 3
+                const bool more = S + 2 < n_stages;
+                const bool loads = has_next && s < 2;
+                if (loads) load_rows(c_begin + qi + 1, nxt, s == 0 ? 0 : 1, s == 0 ? 2 : 3);
+                if (more) {
+                    // V row first: hipcc guards the patch registers with its own (conservative) vmcnt waits, which must not
+                    // cover the pieces issued below
+                    if (s == 0) write_v_row(cur, 2, buf2);
+                    else if (s == 1) write_v_row(cur, 3, buf2);
+                    else if (s == 2) write_v_row(nxt, 0, buf2);
+                    else write_v_row(nxt, 1, buf2);
+                    if (DBG != 4) issue_u(S + 2, buf2, 0, 4);
+                }
+                if (more && DBG != 4) { if (loads) wait_vmcnt<12>(); else wait_vmcnt<4>(); }
+                else { if (loads) wait_vmcnt<8>(); else wait_vmcnt<0>(); }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();                               // B(S+1)
+                b0 = b0 == 2 ? 0 : b0 + 1;
             }
-            if (S + 2 < n_stages) wait_vmcnt<8>(); else wait_vmcnt<0>();   // everything but U(S+2)'s pieces has landed
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();                                   // B(S+1)
-            b0 = buf1;
+        };
+        float4 da[16], db[16];
+        load_rows(c_begin, da, 0, 2);
+        load_rows(c_begin, da, 1, 3);
+        issue_u(0, 0, 0, 8);
+        issue_u(1, 1, 0, 8);
+        write_v_row(da, 0, 0);
+        write_v_row(da, 1, 1);
+        wait_vmcnt<0>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                       // B0: stages 0 and 1 complete
+        if (DBG == 2) return;                                               // ablation: matrix waves alone (terminated waves leave the barrier count)
+        for (int qi = 0; qi < n_chunks; qi += 2) {
+            chunk_body(da, db, qi);
+            if (qi + 1 < n_chunks) chunk_body(db, da, qi + 1);
         }
     } else {
         // ================================================================ matrix wave
@@ -236,15 +261,34 @@ __global__ __launch_bounds__(512) void conv3x3_wino_kernel(const WinoParams p) {
         for (int q = 0; q < 4; ++q) foff[q] = (lane & 31) * 32 + (((2 * q + fh) ^ fsw) << 2);
         const int a_img = w * (WBT * 32), b_img = W_V + w * (WBN * 32);
 
-        __builtin_amdgcn_s_barrier();                                       // B0
-        int buf = 0;
+        // this wave's half of the U DMA: rows 32..63 of the image of position 4i + w (pieces 4..7), one piece per quarter
+        const int prow = lane >> 3, ppos = lane & 7;
+        unsigned u_voff[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = (4 + j) * 8 + prow;
+            u_voff[j] = (unsigned)(((n0 + r) * 32 + ((ppos ^ ((r >> 1) & 7)) << 2)) * 4);
+        }
+        const unsigned u_dst = lds_base + (unsigned)((W_V + w * (WBN * 32) + 4 * 256) * 4);
+
+        __builtin_amdgcn_s_barrier();                                       // B0: stages 0, 1 complete
+        unsigned long long r_loop0 = 0, c_wait = 0, c_mma = 0;
+        if (DBG) r_loop0 = __builtin_amdgcn_s_memrealtime();
+        int buf = 0, S = 0;
+        float4 a[2], b[2][2];
+        a[0] = *reinterpret_cast<const float4*>(smem + a_img + foff[0]);
         for (int c = 0; c < n_chunks; ++c) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < 4; ++i, ++S) {
                 const float* As = smem + buf * W_STAGE + a_img;
                 const float* Bs = smem + buf * W_STAGE + b_img;
-                float4 a[2], b[2][2];
-                a[0] = *reinterpret_cast<const float4*>(As + foff[0]);
+                const int nbuf = buf == 2 ? 0 : buf + 1, pbuf = buf == 0 ? 2 : buf - 1;
+                const float* An = smem + nbuf * W_STAGE + a_img;             // V of stage S+1: complete since B(S)
+                const bool more = S + 2 < n_stages;                          // wave-uniform
+                // U(S+2), position 4 * ((S+2) & 3) + w, of chunk (S+2) / 4, into the buffer stage S-1 released
+                const int pos2 = 4 * ((i + 2) & 3) + w;
+                const float* ub = p.wu + (((long long)(c_begin + ((S + 2) >> 2)) * 16 + pos2) * p.N) * 32;
+                const unsigned dst2 = u_dst + (unsigned)(pbuf * W_STAGE * 4);
                 b[0][0] = *reinterpret_cast<const float4*>(Bs + foff[0]);
                 b[0][1] = *reinterpret_cast<const float4*>(Bs + 1024 + foff[0]);
 #pragma unroll
@@ -254,20 +298,43 @@ __global__ __launch_bounds__(512) void conv3x3_wino_kernel(const WinoParams p) {
                         a[nxt] = *reinterpret_cast<const float4*>(As + foff[q + 1]);
                         b[nxt][0] = *reinterpret_cast<const float4*>(Bs + foff[q + 1]);
                         b[nxt][1] = *reinterpret_cast<const float4*>(Bs + 1024 + foff[q + 1]);
+                    } else {
+                        a[nxt] = *reinterpret_cast<const float4*>(An + foff[0]);
                     }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
+                    for (int e = 0; e < 4; ++e) {
 #pragma unroll
                         for (int j = 0; j < 2; ++j) {
                             const float av = e == 0 ? a[cur].x : e == 1 ? a[cur].y : e == 2 ? a[cur].z : a[cur].w;
                             const float bv = e == 0 ? b[cur][j].x : e == 1 ? b[cur][j].y : e == 2 ? b[cur][j].z : b[cur][j].w;
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
                         }
+                        if (e == 0 && more && DBG != 4) {                   // one DMA piece per quarter, behind the quarter's first MFMAs
+                            __builtin_amdgcn_sched_barrier(0);
+                            lds_dma16_s(ub, q == 0 ? u_voff[0] : q == 1 ? u_voff[1] : q == 2 ? u_voff[2] : u_voff[3], dst2 + (unsigned)(q * 1024));
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
                 }
-                __builtin_amdgcn_s_barrier();                               // B(S+1): stage S released, stage S+1 complete
-                buf = buf == 2 ? 0 : buf + 1;
+                if (more) wait_vmcnt<4>(); else wait_vmcnt<0>();            // my pieces of U(S+1), issued during stage S-1, have landed
+                unsigned long long tA = 0, tB = 0;
+                if (DBG) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tA)::"memory"); }
+                __builtin_amdgcn_s_barrier();                               // B(S+1): stage S released; V <= S+2, U <= S+1 complete
+                if (DBG) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tB)::"memory"); c_wait += tB - tA; if (c_mma == 0) c_mma = tA; }
+                buf = nbuf;
             }
+        }
+        if (DBG && lane == 0 && w == 0) {
+            const int wg = (blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) & 1023;
+            unsigned long long tE;
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tE)::"memory");
+            g_wino_stamps[wg * 8 + 0] = r_entry;
+            g_wino_stamps[wg * 8 + 1] = r_loop0;
+            g_wino_stamps[wg * 8 + 2] = __builtin_amdgcn_s_memrealtime();
+            g_wino_stamps[wg * 8 + 3] = c_wait;                 // shader cycles parked at the stage barriers
+            g_wino_stamps[wg * 8 + 4] = tE - c_mma;             // shader cycles from the end of stage 0's multiply to the end of the loop
+            g_wino_stamps[wg * 8 + 5] = (unsigned long long)n_stages;
         }
         // ---- output transform, rows first (in registers): T[a] = sum_i A^T[a][i] M[i][w],  A^T = [[1,1,1,0],[0,1,-1,-1]]
         float* Ts = smem + w * (2 * WBT * W_TP);
@@ -323,6 +390,12 @@ __global__ __launch_bounds__(512) void conv3x3_wino_kernel(const WinoParams p) {
         *reinterpret_cast<float4*>(outp + o0) = y0;
         *reinterpret_cast<float4*>(outp + o1) = y1;
     }
+    if (DBG && tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int wg = (blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) & 1023;
+        g_wino_stamps[wg * 8 + 6] = __builtin_amdgcn_s_memrealtime();
+        g_wino_stamps[wg * 8 + 7] = 1;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -342,8 +415,14 @@ int conv_wino_splits(int B, int H, int W, int cin, int N) {
 }
 
 int conv_wino_init_device() {
-    DDK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+    DDK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)(W_LDS_FLOATS * sizeof(float))));
+#ifdef DDK_TUNING   // 1: stamps; 2: + loaders exit after the prologue; 3: + loaders at priority 0; 4: + no U DMA in the loop (2-4: wrong results)
+    DDK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(W_LDS_FLOATS * sizeof(float))));
+    DDK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(W_LDS_FLOATS * sizeof(float))));
+    DDK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(W_LDS_FLOATS * sizeof(float))));
+    DDK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(W_LDS_FLOATS * sizeof(float))));
+#endif
     return DDK_OK;
 }
 
@@ -363,7 +442,17 @@ int conv_wino_forward(const ddk_conv_args& a, int splits, hipStream_t st) {
     p.dTH = make_fastdiv_u((unsigned)p.TH);
     if (p.splits > 1) p.out = static_cast<float*>(a.workspace);
     dim3 grid((unsigned)ceil_div(p.tiles, WBT), (unsigned)(a.N / WBN), (unsigned)p.splits);
-    hipLaunchKernelGGL(conv3x3_wino_kernel, grid, dim3(512), W_LDS_FLOATS * sizeof(float), st, p);
+#ifdef DDK_TUNING
+    if (getenv("DDK_WINO_STAMPS")) {
+        const int v = getenv("DDK_WINO_DEBUG") ? atoi(getenv("DDK_WINO_DEBUG")) : 1;
+        if (v == 2) hipLaunchKernelGGL(conv3x3_wino_kernel<2>, grid, dim3(512), W_LDS_FLOATS * sizeof(float), st, p);
+        else if (v == 3) hipLaunchKernelGGL(conv3x3_wino_kernel<3>, grid, dim3(512), W_LDS_FLOATS * sizeof(float), st, p);
+        else if (v == 4) hipLaunchKernelGGL(conv3x3_wino_kernel<4>, grid, dim3(512), W_LDS_FLOATS * sizeof(float), st, p);
+        else hipLaunchKernelGGL(conv3x3_wino_kernel<1>, grid, dim3(512), W_LDS_FLOATS * sizeof(float), st, p);
+        return check_launch("conv3x3_wino_kernel<dbg>");
+    }
+#endif
+    hipLaunchKernelGGL(conv3x3_wino_kernel<0>, grid, dim3(512), W_LDS_FLOATS * sizeof(float), st, p);
     return check_launch("conv3x3_wino_kernel");
 }
 
@@ -378,6 +467,15 @@ extern "C" int ddk_pack_conv_weight_wino(const float* w_oihw, float* dst, int O,
                        O, I, i_pad, total);
     return check_launch("pack_conv_weight_wino_kernel");
 }
+
+#ifdef DDK_TUNING
+extern "C" int ddk_debug_read_wino_stamps(unsigned long long* host_out) {   // tuning build only (not in include/ddk.h)
+    if (hipDeviceSynchronize() != hipSuccess) return -2;
+    if (hipMemcpyFromSymbol(host_out, HIP_SYMBOL(ddk::g_wino_stamps), sizeof(unsigned long long) * 8 * 1024) != hipSuccess) return -2;
+    static unsigned long long zeros[8 * 1024];
+    return hipMemcpyToSymbol(HIP_SYMBOL(ddk::g_wino_stamps), zeros, sizeof(zeros)) == hipSuccess ? 0 : -2;
+}
+#endif
 
 extern "C" int ddk_conv_wino_splits(int B, int H, int W, int cin, int N) {
     if (!ddk::conv_wino_ok(DDK_CONV3X3_S1, H, W, cin, N)) return 0;
