@@ -76,33 +76,42 @@ def _profile_json(name):
 
 
 def time_conv_roofline(device):
-    """Dominant kernel: the 3x3 conv 128->128 @32x32, batch 32 (conv3x3_halo_kernel).  Launch duration measured live (HIP events
-    on the launch stream); algorithmic FLOPs = 2*B*H*W*9*Cin*Cout.  `traffic` (HBM/fabric bytes
-    per launch) and `mfma_busy` cannot be measured inside a timing loop: they come from separate rocprofv3 --pmc passes of
-    tools/conv_one.py on the same kernel and shape, committed under profiles/ (named in *_source)."""
+    """Dominant kernel of the step: the 3x3 conv 128->128 @32x32, batch 32, which the sampler runs as conv3x3_wino_kernel
+    (Winograd F(2x2,3x3) on the fp32 matrix pipe; 33 of the step's 114 launches, ~46 % of its time).  Launch duration is measured
+    live (HIP events on the launch stream, graph replay).  `achieved` prices the ALGORITHMIC work of the op -- the direct-conv
+    FLOPs 2*B*H*W*9*Cin*Cout of SURVEY.md section 8d -- so it can exceed the MFMA peak: F(2x2,3x3) executes 2.25x fewer
+    multiplies than the direct algorithm.  `executed_tflops` / `frac_executed` price the MFMA FLOPs the kernel really issues
+    (16/36 of the algorithmic ones); `mfma_busy` and `traffic` come from committed rocprofv3 --pmc passes of
+    tools/conv_one.py on the same kernel and shape (they cannot be collected inside a timing loop; named in *_source)."""
     from ddk import ops
     B, H, W, C, N = 32, 32, 32, 128, 128
     g = torch.Generator(device="cpu").manual_seed(0)
     x = torch.randn(B, H, W, C, generator=g).to(device)
     w = (torch.randn(N, C, 3, 3, generator=g) * (C * 9) ** -0.5).to(device)
     b = torch.zeros(N, device=device)
-    wp = ops.pack_conv_weight(w)
+    wp, wu = ops.pack_conv_weight(w), ops.pack_conv_weight_wino(w)
     for _ in range(5):
-        ops.conv(ops.CONV3X3_S1, x, wp, b)
+        ops.conv(ops.CONV3X3_S1, x, wp, b, w_wino=wu)
     torch.cuda.synchronize()
-    sec = graph_kernel_seconds(device, lambda: ops.conv(ops.CONV3X3_S1, x, wp, b))
+    sec = graph_kernel_seconds(device, lambda: ops.conv(ops.CONV3X3_S1, x, wp, b, w_wino=wu))
+    sec_direct = graph_kernel_seconds(device, lambda: ops.conv(ops.CONV3X3_S1, x, wp, b), n=20, reps=2)
     flops = 2.0 * B * H * W * 9 * C * N
+    executed = flops * 16.0 / 36.0
     bytes_alg = 4.0 * (B * H * W * C + B * H * W * N + N * 9 * C)
-    tr = _profile_json("r01_conv_pmc_traffic.json")
-    sq = _profile_json("r02_halo_pmc_sq.json")
-    return dict(kernel="conv3x3_halo_kernel<0> conv3x3 128->128 @32x32 B=32 (fp32 MFMA, halo-tile implicit GEMM)", bound="mfma",
-                achieved=flops / sec / 1e12, peak=FP32_PEAK_TFLOPS, unit="TFLOP/s", frac=flops / sec / 1e12 / FP32_PEAK_TFLOPS,
-                traffic=tr["traffic_bytes_per_launch"] if tr else None,
-                traffic_source="profiles/r01_conv_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, fetch x2)" if tr else None,
-                mfma_busy=sq["mfma_busy"] if sq else None,
-                mfma_busy_source="profiles/r02_halo_pmc_sq.json (SQ_VALU_MFMA_BUSY_CYCLES / (SQ_BUSY_CYCLES/32 x 1024 SIMDs))" if sq else None,
-                launch_us=sec * 1e6, algorithmic_gflop=flops / 1e9, algorithmic_mbytes=bytes_alg / 1e6,
-                algorithmic_hbm_gbps=bytes_alg / sec / 1e9)
+    pm = _profile_json("r02_wino_pmc.json")
+    src = "profiles/r02_wino_pmc.json (rocprofv3 --pmc, separate passes: SQ_* | FETCH_SIZE x2 | WRITE_SIZE)" if pm else None
+    return dict(kernel="conv3x3_wino_kernel<0> conv3x3 128->128 @32x32 B=32 (Winograd F(2x2,3x3), fp32 MFMA, 4 matrix + 4 loader waves)",
+                bound="mfma", achieved=flops / sec / 1e12, peak=FP32_PEAK_TFLOPS, unit="TFLOP/s", frac=flops / sec / 1e12 / FP32_PEAK_TFLOPS,
+                traffic=pm["traffic_bytes_per_launch"] if pm else None, traffic_source=src,
+                executed_tflops=executed / sec / 1e12, frac_executed=executed / sec / 1e12 / FP32_PEAK_TFLOPS,
+                mfma_busy=pm["mfma_busy"] if pm else None, mfma_busy_source=src,
+                launch_us=sec * 1e6, algorithmic_gflop=flops / 1e9, executed_gflop=executed / 1e9, algorithmic_mbytes=bytes_alg / 1e6,
+                algorithmic_hbm_gbps=bytes_alg / sec / 1e9,
+                note="frac > 1 is not an error: achieved prices the direct algorithm's FLOPs, the kernel executes 16/36 of them; "
+                     "frac_executed is the share of the fp32 MFMA peak the issued MFMAs reach",
+                direct_kernel={"kernel": "conv3x3_halo_kernel<0> (direct implicit GEMM, same shape; used when a shape is not Winograd-eligible)",
+                               "launch_us": sec_direct * 1e6, "achieved": flops / sec_direct / 1e12, "frac": flops / sec_direct / 1e12 / FP32_PEAK_TFLOPS,
+                               "mfma_busy": (_profile_json("r02_halo_pmc_sq.json") or {}).get("mfma_busy")})
 
 
 def time_hbm_rooflines(device):
