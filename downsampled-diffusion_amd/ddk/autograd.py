@@ -59,10 +59,13 @@ def _conv_backward(kind, x, x2, weight, bias, dy, needs, gb_ready=False):
             k = ops.CONV1X1 if kind == ops.CONV1X1 else ops.CONV3X3_S1
             if kind == ops.CONV3X3_S2:
                 src = ops.zero_stuff2(dy, x.shape[1], x.shape[2])
+            # 3x3 input gradients (also the zero-stuffed stride-2 one) run as Winograd F(2x2,3x3) where the shape allows
+            wino = k == ops.CONV3X3_S1
             if need_x:
-                dx = ops.conv(k, src, wd[:c0], n_out=c0)
+                dx = ops.conv(k, src, wd[:c0], n_out=c0,
+                              w_wino=ops.wino_weight(weight, src.shape, 0, min(c0, weight.shape[1]), dgrad=True) if wino and c0 <= weight.shape[1] else None)
             if need_x2:
-                dx2 = ops.conv(k, src, wd[c0:], n_out=c1)
+                dx2 = ops.conv(k, src, wd[c0:], n_out=c1, w_wino=ops.wino_weight(weight, src.shape, c0, c0 + c1, dgrad=True) if wino else None)
     return dx, dx2, gw, gb
 
 
@@ -77,7 +80,10 @@ class ConvFn(torch.autograd.Function):
         else:
             wp = ops.cached_pack("fwd", weight, ops.pack_conv_weight)
             n = weight.shape[0]
-        out = ops.conv(kind, x, wp, None if bias is None else bias.detach(), n_out=n, x2=x2, resid=resid)
+        wu = None
+        if kind == ops.CONV3X3_S1:
+            wu = ops.wino_weight(weight, (x.shape[0], x.shape[1], x.shape[2], x.shape[3] + (0 if x2 is None else x2.shape[3])))
+        out = ops.conv(kind, x, wp, None if bias is None else bias.detach(), n_out=n, x2=x2, resid=resid, w_wino=wu)
         ctx.kind = kind
         ctx.save_for_backward(x, x2, weight, bias)
         ctx.has_resid = resid is not None
@@ -122,8 +128,9 @@ class ConvGNMishFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, x2, weight, bias, gamma, beta, temb, addend, drop_p, seed, layer, groups, eps):
+        wu = ops.wino_weight(weight, (x.shape[0], x.shape[1], x.shape[2], x.shape[3] + (0 if x2 is None else x2.shape[3])))
         raw = ops.conv(ops.CONV3X3_S1, x, ops.cached_pack("fwd", weight, ops.pack_conv_weight), bias.detach(),
-                       n_out=weight.shape[0], x2=x2)
+                       n_out=weight.shape[0], x2=x2, w_wino=wu)
         ctx.save_for_backward(x, x2, weight, bias, raw, gamma, beta)
         ctx.cfg = (drop_p, seed, layer, groups, eps, temb is not None, addend is not None)
         return ops.groupnorm_mish_train(raw, gamma.detach(), beta.detach(), temb=temb, addend=addend, drop_p=drop_p, seed=seed,

@@ -102,6 +102,27 @@ def pack_conv_weight_wino(w):
     return out
 
 
+def wino_weight(weight, x_shape, c_lo=None, c_hi=None, dgrad=False):
+    """Cached Winograd-domain copy of a canonical OIHW 3x3 filter for a conv on NHWC input shape `x_shape`, or None when the
+    shape is not eligible (ddk_conv_wino_splits == 0).  dgrad=True: the filter of the INPUT-gradient conv for input channels
+    [c_lo, c_hi) -- g'[ci][n][a][b] = w[n][ci][2-a][2-b] -- which is again a 3x3 stride-1 conv (of dY)."""
+    b, h, w_, cin_x = x_shape
+    o, i = weight.shape[0], weight.shape[1]
+    if tuple(weight.shape[2:]) != (3, 3):
+        return None
+    if dgrad:
+        lo, hi = (0 if c_lo is None else c_lo), (i if c_hi is None else c_hi)
+        n_out, cin = hi - lo, o
+    else:
+        lo, hi, n_out, cin = 0, i, o, pad32(i)
+    if L.load().ddk_conv_wino_splits(b, h, w_, pad32(cin), n_out) <= 0:
+        return None
+    if dgrad:
+        return cached_pack(("wino_dgrad", lo, hi), weight,
+                           lambda t: pack_conv_weight_wino(t[:, lo:hi].flip(2, 3).transpose(0, 1).contiguous()))
+    return cached_pack("wino", weight, pack_conv_weight_wino)
+
+
 # ------------------------------------------------------------------ conv family
 def conv(kind, x, w_packed, bias=None, n_out=None, x2=None, resid=None, pre_mish=False, post_mish=False, w_wino=None):
     """Implicit-GEMM conv on NHWC x (optionally channel-concatenated with x2 without materialising it).

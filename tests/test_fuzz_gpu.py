@@ -139,3 +139,43 @@ def test_groupnorm_layernorm_attention_fuzz(B, H, W, C, seed):
         ctx = torch.einsum("bhdn,bhen->bhde", k, v)
         want = torch.einsum("bhde,bhdn->bhen", ctx, q).reshape(B, 128, H, W)
     assert rel_err(to_nchw(got.cpu()), want) < 2e-5
+
+
+def _wino_cases(n, seed):
+    rng = random.Random(seed)
+    out = []
+    for i in range(n):
+        c0 = rng.choice([32, 64, 96, 128, 256])
+        c1 = rng.choice([0, 0, 32, 128, 256])
+        n_out = rng.choice([64, 128, 192, 256])
+        hw = rng.choice([(2, 2), (4, 4), (8, 8), (16, 16), (32, 32), (6, 10), (12, 20), (8, 32), (2, 14), (24, 24), (64, 64)])
+        b = rng.choice([1, 2, 3, 5, 8, 17, 32])
+        while b * hw[0] * hw[1] * (c0 + c1) * n_out * 9 > 6e9 and b > 1:
+            b = max(1, b // 2)
+        out.append((b, hw[0], hw[1], c0, c1, n_out, 5000 + i))
+    return out
+
+
+@pytest.mark.parametrize("B,H,W,c0,c1,N,seed", _wino_cases(24, 20261004))
+def test_conv_winograd_fuzz(B, H, W, c0, c1, N, seed):
+    """conv3x3_wino_kernel on random eligible shapes (even H, W; cin % 32 == 0; N % 64 == 0): ragged tile blocks, every split
+    count, concat sources, epilogue options -- against F.conv2d and bit-stable run to run."""
+    from ddk import ops
+    cin = c0 + c1
+    x = _rnd(B, cin, H, W, seed=seed)
+    w = _rnd(N, cin, 3, 3, seed=seed + 2) * (cin * 9) ** -0.5
+    bias = _rnd(N, seed=seed + 1) * 0.1
+    ref = F.conv2d(x, w, bias, padding=1)
+    assert ops.L.load().ddk_conv_wino_splits(B, H, W, cin, N) >= 1
+    wp, wu = ops.pack_conv_weight(w.to(DEV)), ops.pack_conv_weight_wino(w.to(DEV))
+    xh = to_nhwc(x).to(DEV)
+    x0 = xh[..., :c0].contiguous()
+    x1 = xh[..., c0:].contiguous() if c1 else None
+    resid = _rnd(*ref.shape, seed=seed + 3)
+    mish = bool(seed & 1)
+    out = ops.conv(ops.CONV3X3_S1, x0, wp, bias.to(DEV), x2=x1, resid=to_nhwc(resid).to(DEV), post_mish=mish, w_wino=wu)
+    want = ref + resid
+    if mish:
+        want = want * torch.tanh(F.softplus(want))
+    assert rel_err(to_nchw(out.cpu()), want) < 2e-5
+    assert torch.equal(out, ops.conv(ops.CONV3X3_S1, x0, wp, bias.to(DEV), x2=x1, resid=to_nhwc(resid).to(DEV), post_mish=mish, w_wino=wu))
