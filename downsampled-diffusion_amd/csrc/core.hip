@@ -30,6 +30,7 @@ int ensure_device_init() {
     if (done.load(std::memory_order_relaxed) & bit) return DDK_OK;
     DDK_TRY(conv_init_device());
     DDK_TRY(conv_wino_init_device());
+    DDK_TRY(conv_gn_local_init_device());
     DDK_TRY(wgrad_init_device());
     done.fetch_or(bit, std::memory_order_release);
     return DDK_OK;

@@ -133,6 +133,12 @@ bool conv_wino_ok(int kind, int H, int W, int cin, int N);
 int conv_wino_splits(int B, int H, int W, int cin, int N);
 int conv_wino_forward(const ddk_conv_args& a, int splits, hipStream_t st);
 int conv_wino_init_device();
+// conv_local.hip: conv3x3 + GroupNorm + Mish (+shift, +residual) in one launch for 4x4 / 8x8 maps
+bool conv_gn_local_ok(int H, int W, int cin, int c0, int N, int groups);
+int conv_gn_local(const float* src0, int c0, const float* src1, int c1, const float* w, const float* bias, const float* gamma,
+                  const float* beta, const float* temb, int temb_stride, const long long* temb_rows, const float* addend, float* out,
+                  int B, int H, int W, int N, int groups, float eps, hipStream_t st);
+int conv_gn_local_init_device();
 double conv_flops(int kind, int B, int H, int W, int cin, int N);
 // norm_act.hip
 size_t groupnorm_workspace_bytes(int B, int HW, int C, int groups);

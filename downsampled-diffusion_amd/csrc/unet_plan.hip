@@ -24,7 +24,7 @@ constexpr float GN_EPS = 1e-5f, LN_EPS = 1e-5f;
 
 static inline int pad32(int c) { return (c + 31) / 32 * 32; }
 
-enum PackKind { PK_COPY = 0, PK_CONV = 1, PK_CONVT = 2, PK_LINEAR_T = 3, PK_WINO = 4 };
+enum PackKind { PK_COPY = 0, PK_CONV = 1, PK_CONVT = 2, PK_LINEAR_T = 3, PK_WINO = 4, PK_LOCAL = 5 };
 
 struct Slot {
     std::string name;
@@ -41,6 +41,8 @@ struct ConvW {
     int cin = 0, cin_pad = 0, cout = 0;
     size_t wu = 0;          // Winograd-domain copy of a 3x3 filter ([cin_pad/32][16][cout][32]); has_wu says whether it exists
     bool has_wu = false;
+    size_t wl = 0;          // conv_local.hip's operand-order copy (3x3 convs that feed a GroupNorm); has_wl says whether it exists
+    bool has_wl = false;
 };
 struct NormW { size_t g = 0, b = 0; };
 struct ResW {
@@ -109,7 +111,7 @@ struct ddk_unet {
     void add_copy_at(const std::string& name, long long n, size_t off) {
         slots.push_back(Slot{name, n, PK_COPY, off, 0, 0, 0, 0, 0, 0, 0});
     }
-    ConvW add_conv(const std::string& prefix, int cout, int cin, int k, bool bias) {
+    ConvW add_conv(const std::string& prefix, int cout, int cin, int k, bool bias, bool gn_follows = false) {
         ConvW c;
         c.cin = cin; c.cin_pad = pad32(cin); c.cout = cout;
         c.w = alloc((size_t)cout * k * k * c.cin_pad);
@@ -121,6 +123,12 @@ struct ddk_unet {
             c.wu = alloc((size_t)16 * cout * c.cin_pad);
             c.has_wu = true;
             slots.push_back(Slot{prefix + "weight", (long long)cout * cin * k * k, PK_WINO, c.wu, cout, cin, k, k, c.cin_pad, 0, 0});
+        }
+        if (k == 3 && gn_follows && cout % 32 == 0) {
+            // and a third for the one-launch conv + GroupNorm kernel of the 4x4 maps (its MFMA operand order)
+            c.wl = alloc((size_t)9 * cout * c.cin_pad);
+            c.has_wl = true;
+            slots.push_back(Slot{prefix + "weight", (long long)cout * cin * k * k, PK_LOCAL, c.wl, cout, cin, k, k, c.cin_pad, 0, 0});
         }
         return c;
     }
@@ -146,9 +154,9 @@ struct ddk_unet {
         temb_cursor += co;
         slots.push_back(Slot{p + "mlp.1.weight", (long long)co * time_dim, PK_LINEAR_T, temb_wt, co, time_dim, 0, 0, 0, temb_total, r.temb_off});
         add_copy_at(p + "mlp.1.bias", co, temb_bias + r.temb_off);
-        r.c1 = add_conv(p + "block1.block.0.", co, ci, 3, true);
+        r.c1 = add_conv(p + "block1.block.0.", co, ci, 3, true, true);
         r.n1 = add_norm(p + "block1.block.1.weight", p + "block1.block.1.bias", co);
-        r.c2 = add_conv(p + "block2.block.0.", co, co, 3, true);
+        r.c2 = add_conv(p + "block2.block.0.", co, co, 3, true, true);
         r.n2 = add_norm(p + "block2.block.1.weight", p + "block2.block.1.bias", co);
         r.has_res = ci != co;
         if (r.has_res) r.res = add_conv(p + "res_conv.", co, ci, 1, true);
@@ -243,7 +251,7 @@ extern "C" ddk_unet* ddk_unet_create(const ddk_unet_config* cfg) {
         u->up_attn.push_back(u->add_attn(p + "2.", din));
         u->up_conv.push_back(u->add_convT(p + "3.conv.", din));
     }
-    u->final_conv = u->add_conv("final_conv.0.block.0.", cfg->chan, cfg->chan, 3, true);
+    u->final_conv = u->add_conv("final_conv.0.block.0.", cfg->chan, cfg->chan, 3, true, true);
     u->final_norm = u->add_norm("final_conv.0.block.1.weight", "final_conv.0.block.1.bias", cfg->chan);
     u->final_w = u->add_copy("final_conv.1.weight", (long long)cfg->in_ch * cfg->chan);
     u->final_b = u->add_copy("final_conv.1.bias", cfg->in_ch);
@@ -343,6 +351,7 @@ extern "C" int ddk_unet_pack_slot(const ddk_unet* u, int slot, const float* cano
         case PK_CONVT: rc = ddk_pack_convT_weight(canonical, dst, sl.I, sl.O, s); break;
         case PK_LINEAR_T: rc = ddk_pack_linear_T(canonical, dst, sl.O, sl.I, sl.ld, sl.col0, s); break;
         case PK_WINO: rc = ddk_pack_conv_weight_wino(canonical, dst, sl.O, sl.I, sl.i_pad, s); break;
+        case PK_LOCAL: rc = ddk_pack_conv_weight_local(canonical, dst, sl.O, sl.I, sl.i_pad, s); break;
         default: return fail_arg("unet_pack_slot: slot kind");
     }
     DDK_TRY(rc);
@@ -489,6 +498,11 @@ static int run_conv(Ctx& c, int kind, const ConvW& cw, const float* src0, int c0
 // GroupNorm kernel sums them (plus the conv bias) while loading: one kernel and one HBM round trip fewer.
 static int run_conv_gn(Ctx& c, const ConvW& cw, const float* src0, int c0, const float* src1, int c1, float* raw, const NormW& n,
                        const float* temb, const float* addend, float* out, int H, int W, int N) {
+    if (cw.has_wl && H * W == 16 && conv_gn_local_ok(H, W, c0 + c1, c0, N, GROUPS))
+        // 4x4 maps: one image x 32 channels per workgroup, k reduced inside it -> statistics, Mish, shift and residual in the
+        // conv's own epilogue, no slabs and no GroupNorm launch (conv_local.hip)
+        return conv_gn_local(src0, c0, src1, c1, c.P + cw.wl, cw.has_bias ? c.P + cw.b : nullptr, c.P + n.g, c.P + n.b, temb,
+                             c.u.temb_total, c.temb_rows, addend, out, c.B, H, W, N, GROUPS, GN_EPS, c.st);
     const int splits = conv3_splits(cw, c.B, H, W, c0 + c1, N);
     const bool resident = groupnorm_workspace_bytes(c.B, H * W, N, GROUPS) == 0;
     if (splits > 1 && resident) {

@@ -55,6 +55,9 @@ SIGNATURES = {
     "ddk_pack_linear_T": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "ddk_pack_conv_weight_wino": (_I, [_P, _P, _I, _I, _I, _P]),
     "ddk_conv_wino_splits": (_I, [_I, _I, _I, _I, _I]),
+    "ddk_pack_conv_weight_local": (_I, [_P, _P, _I, _I, _I, _P]),
+    "ddk_conv3x3_gn_mish_ok": (_I, [_I, _I, _I, _I, _I, _I]),
+    "ddk_conv3x3_gn_mish": (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
     "ddk_conv_workspace_bytes": (_SZ, [_I, _I, _I, _I, _I, _I]),
     "ddk_conv_splits": (_I, [_I, _I, _I, _I, _I, _I]),
     "ddk_conv_forward": (_I, [C.POINTER(ConvArgs), _P]),

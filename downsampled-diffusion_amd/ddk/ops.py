@@ -102,6 +102,16 @@ def pack_conv_weight_wino(w):
     return out
 
 
+def pack_conv_weight_local(w):
+    """OIHW 3x3 -> the operand order of conv3x3_gn_mish (ddk_pack_conv_weight_local): [O/32][9][pad32(I)/32][1024]."""
+    o, i, kh, kw = w.shape
+    if (kh, kw) != (3, 3) or o % 32:
+        raise L.DDKError("pack_conv_weight_local: kernel must be 3x3 and O % 32 == 0")
+    out = torch.empty((o // 32, 9, pad32(i) // 32, 1024), device=w.device, dtype=torch.float32)
+    L.check(L.load().ddk_pack_conv_weight_local(L.ptr(_f32(w.contiguous())), L.ptr(out), o, i, pad32(i), L.stream()), "pack_conv_weight_local")
+    return out
+
+
 def wino_weight(weight, x_shape, c_lo=None, c_hi=None, dgrad=False):
     """Cached Winograd-domain copy of a canonical OIHW 3x3 filter for a conv on NHWC input shape `x_shape`, or None when the
     shape is not eligible (ddk_conv_wino_splits == 0).  dgrad=True: the filter of the INPUT-gradient conv for input channels
@@ -152,21 +162,24 @@ def conv(kind, x, w_packed, bias=None, n_out=None, x2=None, resid=None, pre_mish
     return out
 
 
-def conv3x3_groupnorm_mish(x, w_packed, bias, gamma, beta, x2=None, temb=None, addend=None, groups=GN_GROUPS, eps=GN_EPS):
-    """conv3x3(pad 1) -> GroupNorm -> Mish (+temb)(+addend).  When the conv splits k its partial slabs are summed by the
-    GroupNorm kernel's load (ddk_groupnorm_mish_slabs) instead of a separate reduce pass."""
+def conv3x3_groupnorm_mish(x, w_packed, bias, gamma, beta, x2=None, temb=None, addend=None, groups=GN_GROUPS, eps=GN_EPS, w_wino=None):
+    """conv3x3(pad 1) -> GroupNorm -> Mish (+temb)(+addend), two launches.  When the conv splits k its partial slabs are summed by
+    the GroupNorm kernel's load (ddk_groupnorm_mish_slabs) instead of a separate reduce pass.  w_wino: the Winograd-domain filter
+    (pack_conv_weight_wino) -- the conv then runs on the Winograd kernel where the shape is eligible."""
     b, h, w_, c0 = x.shape
     c1 = 0 if x2 is None else x2.shape[-1]
     n = w_packed.shape[0]
     lib = L.load()
-    splits = lib.ddk_conv_splits(CONV3X3_S1, b, h, w_, c0 + c1, n)
+    wino = w_wino is not None and lib.ddk_conv_wino_splits(b, h, w_, c0 + c1, n) > 0
+    splits = lib.ddk_conv_wino_splits(b, h, w_, c0 + c1, n) if wino else lib.ddk_conv_splits(CONV3X3_S1, b, h, w_, c0 + c1, n)
     if splits == 1 or lib.ddk_groupnorm_workspace_bytes(b, h * w_, n, groups) != 0:
-        return groupnorm_mish(conv(CONV3X3_S1, x, w_packed, bias, x2=x2), gamma, beta, temb=temb, addend=addend, groups=groups, eps=eps)
-    ws_bytes = lib.ddk_conv_workspace_bytes(CONV3X3_S1, b, h, w_, c0 + c1, n)
+        return groupnorm_mish(conv(CONV3X3_S1, x, w_packed, bias, x2=x2, w_wino=w_wino), gamma, beta, temb=temb, addend=addend,
+                              groups=groups, eps=eps)
+    ws_bytes = splits * b * h * w_ * n * 4 if wino else lib.ddk_conv_workspace_bytes(CONV3X3_S1, b, h, w_, c0 + c1, n)
     ws = torch.empty(ws_bytes // 4, device=x.device, dtype=torch.float32)
     out = torch.empty((b, h, w_, n), device=x.device, dtype=torch.float32)
     a = L.ConvArgs(CONV3X3_S1, L.ptr(_f32(x)), L.ptr(x2), c0, c1, L.ptr(w_packed), None, None, L.ptr(out), b, h, w_, n, 0, 0, 1,
-                   L.ptr(ws), ws_bytes)
+                   L.ptr(ws), ws_bytes, L.ptr(w_wino) if wino else None)
     L.check(lib.ddk_conv_forward(C.byref(a), L.stream()), "conv_forward(defer)")
     stride = temb.stride(0) if temb is not None else 0
     L.check(lib.ddk_groupnorm_mish_slabs(L.ptr(ws), splits, b * h * w_ * n, L.ptr(bias), L.ptr(gamma), L.ptr(beta),
@@ -186,6 +199,26 @@ def groupnorm_mish(x, gamma, beta, temb=None, addend=None, groups=GN_GROUPS, eps
     L.check(lib.ddk_groupnorm_mish(L.ptr(_f32(x)), L.ptr(gamma), L.ptr(beta),
                                    temb.data_ptr() if temb is not None else None, stride, L.ptr(addend), L.ptr(out),
                                    b, h * w, c, groups, eps, L.ptr(ws), ws_bytes, L.stream()), "groupnorm_mish")
+    return out
+
+
+def conv3x3_gn_mish(x, w_local, bias, gamma, beta, temb=None, addend=None, x2=None, groups=GN_GROUPS, eps=GN_EPS):
+    """Block (blocks.py:75-84) in one launch on a 4x4 / 8x8 map: x [B,H,W,c0] (+ x2 [B,H,W,c1], the concat of unet.py:97),
+    w_local = pack_conv_weight_local(weight) -> Mish(GN(conv(x) + bias)) (+ temb[b]) (+ addend)."""
+    b, h, w, c0 = x.shape
+    c1 = x2.shape[-1] if x2 is not None else 0
+    n = w_local.shape[0] * 32
+    w_packed = w_local
+    if w_local.shape[2] * 32 != c0 + c1:
+        raise L.DDKError(f"conv3x3_gn_mish: filter packed for {w_local.shape[2] * 32} input channels, input has {c0 + c1}")
+    lib = L.load()
+    if not lib.ddk_conv3x3_gn_mish_ok(h, w, c0 + c1, c0, n, groups):
+        raise L.DDKError(f"conv3x3_gn_mish: shape {tuple(x.shape)} (+{c1}) -> {n} not eligible")
+    out = torch.empty((b, h, w, n), device=x.device, dtype=torch.float32)
+    stride = temb.stride(0) if temb is not None else 0
+    L.check(lib.ddk_conv3x3_gn_mish(L.ptr(_f32(x)), c0, L.ptr(_f32(x2)) if x2 is not None else None, c1, L.ptr(w_packed), L.ptr(bias),
+                                    L.ptr(gamma), L.ptr(beta), temb.data_ptr() if temb is not None else None, stride, L.ptr(addend),
+                                    L.ptr(out), b, h, w, n, groups, eps, L.stream()), "conv3x3_gn_mish")
     return out
 
 

@@ -111,6 +111,16 @@ int ddk_groupnorm_mish_slabs(const float* slabs, int nslab, long long slab_strid
                              const float* gamma, const float* beta, const float* temb, int temb_stride,
                              const float* addend, float* out, int B, int HW, int C, int groups, float eps,
                              ddk_stream_t s);
+/* Conv2d(3, padding=1) -> GroupNorm(groups) -> Mish (+ temb[b][c] shift) (+ addend) in ONE launch, for small maps
+ * (H*W == 16 or 64): Block of models/unet/blocks.py:75-84 with the ResnetBlock additions of blocks.py:110-115.  The
+ * input is src0 (c0 channels) followed by src1 (c1 channels, may be 0/NULL: the concat of unet.py:97), NHWC; `weight` is
+ * the filter packed by ddk_pack_conv_weight_local (O*9*i_pad floats: the kernel's MFMA operand order, O % 32 == 0).
+ * ddk_conv3x3_gn_mish_ok() != 0 when the shape is eligible. */
+int ddk_pack_conv_weight_local(const float* w_oihw, float* dst, int O, int I, int i_pad, ddk_stream_t s);
+int ddk_conv3x3_gn_mish_ok(int H, int W, int cin, int c0, int N, int groups);
+int ddk_conv3x3_gn_mish(const float* src0, int c0, const float* src1, int c1, const float* weight, const float* bias,
+                        const float* gamma, const float* beta, const float* temb, int temb_stride, const float* addend,
+                        float* out, int B, int H, int W, int N, int groups, float eps, ddk_stream_t s);
 /* per-pixel channel LayerNorm, (x-mean)/(sqrt(var)+eps)*g+b, biased var (blocks.py:57-60). */
 int ddk_chan_layernorm(const float* x, const float* g, const float* b, float* out, long long M, int C,
                        float eps, ddk_stream_t s);

@@ -131,6 +131,58 @@ def test_conv_winograd_not_eligible_falls_back_to_direct(ops):
     assert rel_err(to_nchw(out.cpu()), F.conv2d(x, w, None, padding=1)) < 2e-5
 
 
+LOCAL_CASES = [    # B, H, W, c0, c1, N   (GroupNorm groups = 8)
+    (32, 4, 4, 256, 0, 256),       # cfg4 4x4 level (blocks.py:75-84 at downs.3 / mid / ups.0)
+    (32, 4, 4, 256, 256, 256),     # ups.0.0 conv1: concat of two sources (unet.py:97)
+    (3, 4, 4, 64, 0, 128),         # 16 channels per group: two groups per 32-channel tile
+    (2, 4, 4, 32, 0, 64),          # 8 channels per group; a single (tap, chunk) unit for most waves
+    (5, 8, 8, 256, 0, 256),        # 8x8 map: four M blocks
+    (2, 8, 8, 128, 384, 256),      # 8x8 concat, c0 != c1, 134 KB of LDS
+    (2, 2, 8, 96, 0, 96),          # non-square 16-pixel map, 3 chunks, 12 channels/group is not eligible -> see below
+]
+
+
+@pytest.mark.parametrize("B,H,W,c0,c1,N", LOCAL_CASES)
+def test_conv3x3_groupnorm_mish_one_launch(ops, B, H, W, c0, c1, N):
+    """conv3x3_gn_local_kernel: Conv2d(3, padding=1) -> GroupNorm(8) -> Mish (+ time shift) (+ residual) in one launch
+    (blocks.py:75-84, 110-115) against torch; same 2e-5-of-max bar as the two-launch path, and bit-stable run to run."""
+    cin = c0 + c1
+    lib = ops.L.load()
+    if not lib.ddk_conv3x3_gn_mish_ok(H, W, cin, c0, N, 8):
+        assert (N // 8) not in (8, 16, 32)
+        pytest.skip("shape not eligible (channels per group)")
+    x = rnd(B, cin, H, W, seed=71)
+    w = rnd(N, cin, 3, 3, seed=72, scale=(cin * 9) ** -0.5)
+    bias = rnd(N, seed=73, scale=0.1)
+    gamma, beta = 1 + rnd(N, seed=74, scale=0.2), rnd(N, seed=75, scale=0.2)
+    temb = rnd(B, N, seed=76)
+    resid = rnd(B, N, H, W, seed=77)
+    h = F.group_norm(F.conv2d(x, w, bias, padding=1), 8, gamma, beta, eps=1e-5)
+    xh = to_nhwc(x).to(DEV)
+    x0 = xh[..., :c0].contiguous()
+    x1 = xh[..., c0:].contiguous() if c1 else None
+    wp = ops.pack_conv_weight(w.to(DEV))
+    args = (x0, ops.pack_conv_weight_local(w.to(DEV)), bias.to(DEV), gamma.to(DEV), beta.to(DEV))
+    out = ops.conv3x3_gn_mish(*args, x2=x1)
+    assert rel_err(to_nchw(out.cpu()), U.mish(h)) < 2e-5
+    out_t = ops.conv3x3_gn_mish(*args, temb=temb.to(DEV), x2=x1)
+    assert rel_err(to_nchw(out_t.cpu()), U.mish(h) + temb[:, :, None, None]) < 2e-5
+    out_r = ops.conv3x3_gn_mish(*args, addend=to_nhwc(resid).to(DEV), x2=x1)
+    assert rel_err(to_nchw(out_r.cpu()), U.mish(h) + resid) < 2e-5
+    assert torch.equal(out, ops.conv3x3_gn_mish(*args, x2=x1))
+    # the two-launch path (conv, then GroupNorm+Mish) gives the same tensor up to summation order
+    two = ops.groupnorm_mish(ops.conv(ops.CONV3X3_S1, x0, wp, bias.to(DEV), x2=x1), gamma.to(DEV), beta.to(DEV))
+    assert rel_err(out.cpu(), two.cpu()) < 2e-5
+
+
+def test_conv3x3_groupnorm_mish_rejects_other_maps(ops):
+    x = torch.zeros(1, 16, 16, 32, device=DEV)
+    wp = torch.zeros(1, 9, 1, 1024, device=DEV)
+    z = torch.zeros(32, device=DEV)
+    with pytest.raises(ops.L.DDKError):
+        ops.conv3x3_gn_mish(x, wp, z, z, z)
+
+
 def test_conv_pre_post_mish(ops):
     x = rnd(2, 64, 16, 16, seed=5)
     w = rnd(32, 64, 1, 1, seed=6, scale=0.125)
