@@ -1284,6 +1284,7 @@ int conv_forward(const ddk_conv_args& a, hipStream_t st, const ConvLnFold* ln) {
         }
         return DDK_OK;
     }
+    DDK_REQUIRE(!a.gn_partials, "conv: gn_partials is only produced by the Winograd path (weight_wino given, ddk_conv_gn_partials() > 0)");
     IgemmParams p{};
     p.src0 = a.src0; p.src1 = a.src1; p.w = a.weight; p.bias = a.bias; p.resid = a.resid; p.out = a.out;
     p.c0 = a.c0; p.c1 = a.c1; p.cin = a.c0 + a.c1;

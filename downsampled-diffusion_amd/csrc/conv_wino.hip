@@ -48,6 +48,8 @@ struct WinoParams {
     long long slab_stride;
     int post_mish;
     FastDivU dTW, dTH;
+    float2* gn_part;       // optional: per (m tile, GroupNorm group) {mean, M2} of the output (splits == 1 only)
+    int cpg, groups;       // channels per group, groups in N
 };
 
 constexpr int WBT = 32, WBN = 64;                        // tiles and output channels per workgroup
@@ -353,11 +355,13 @@ __global__ __launch_bounds__(512) void conv3x3_wino_kernel(const WinoParams p) {
     // ---- columns: Y[a][0] = T[a]_0 + T[a]_1 + T[a]_2,  Y[a][1] = T[a]_1 - T[a]_2 - T[a]_3  (T[a]_w = matrix wave w's block)
     const bool direct = p.splits == 1;
     float* outp = direct ? p.out : p.out + (long long)split * p.slab_stride;
+    float4 keep[2][2];
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
         const int item = tid + it * 512;
         const int t = item >> 5, a = (item >> 4) & 1, c4 = (item & 15) * 4;
         const int g = t0 + t, gn = n0 + c4;
+        keep[it][0] = keep[it][1] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (g >= p.tiles || gn >= p.N) continue;
         const float* tp = smem + (a * WBT + t) * W_TP + c4;
         const float4 q0 = *reinterpret_cast<const float4*>(tp);
@@ -389,6 +393,37 @@ __global__ __launch_bounds__(512) void conv3x3_wino_kernel(const WinoParams p) {
         }
         *reinterpret_cast<float4*>(outp + o0) = y0;
         *reinterpret_cast<float4*>(outp + o1) = y1;
+        keep[it][0] = y0;
+        keep[it][1] = y1;
+    }
+    // ---- optional GroupNorm statistics of this tile (the host only asks for them when every m tile is full and lies inside one
+    //      image): per group {mean, M2 about that mean} over the tile's 128 pixels x cpg channels, two passes over the registers;
+    //      the consumer (gn_apply_parts_kernel) merges an image's tiles in fixed order -- GroupNorm then is one read + one write.
+    if (p.gn_part) {
+        const int cq = tid & 15, qpg = p.cpg >> 2;     // this thread's channel quad; quads per group
+        const int gl = cq / qpg;                       // group within the 64-channel tile
+        float* red = smem + 4 * 2 * WBT * W_TP;        // behind the staging area; one 128-float region per pass
+        // barrier on LDS traffic only: __syncthreads() would also wait for the output stores issued above (vmcnt), ~1 us
+        auto group_sum = [&](float v, float* rd) {
+            for (int o = 1; o < qpg; o <<= 1) v += __shfl_xor(v, o, 64);
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            if ((lane & 48) == 0 && (cq & (qpg - 1)) == 0) rd[wid * 16 + gl] = v;
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            float t = rd[gl];
+#pragma unroll
+            for (int w = 1; w < 8; ++w) t += rd[w * 16 + gl];
+            return t;
+        };
+        auto sum4 = [](float4 v) { return (v.x + v.y) + (v.z + v.w); };
+        const float inv = 1.0f / (float)(4 * WBT * p.cpg);
+        const float mean = group_sum((sum4(keep[0][0]) + sum4(keep[0][1])) + (sum4(keep[1][0]) + sum4(keep[1][1])), red) * inv;
+        auto sq4 = [&](float4 v) {
+            const float a = v.x - mean, b = v.y - mean, c = v.z - mean, d = v.w - mean;
+            return (a * a + b * b) + (c * c + d * d);
+        };
+        const float m2 = group_sum((sq4(keep[0][0]) + sq4(keep[0][1])) + (sq4(keep[1][0]) + sq4(keep[1][1])), red + 128);
+        if (tid < 16 && (cq & (qpg - 1)) == 0) p.gn_part[(long long)tile_m * p.groups + n0 / p.cpg + gl] = make_float2(mean, m2);
     }
     if (DBG && tid == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -414,6 +449,16 @@ int conv_wino_splits(int B, int H, int W, int cin, int N) {
     return (int)ceil_div(chunks, cps);
 }
 
+// Can the kernel emit GroupNorm partials for this shape?  One pass (no channel-chunk split), every m tile full and inside one
+// image, whole groups inside an n tile, and few enough tiles per image that the consumer's merge stays trivial.
+int conv_wino_stats_parts(int B, int H, int W, int cin, int N, int groups) {
+    if (!conv_wino_ok(DDK_CONV3X3_S1, H, W, cin, N) || groups <= 0 || N % groups) return 0;
+    const int cpg = N / groups, tpi = (H / 2) * (W / 2);
+    if (cpg % 4 || WBN % cpg || tpi % WBT || tpi / WBT > 32) return 0;
+    if (conv_wino_splits(B, H, W, cin, N) != 1) return 0;
+    return tpi / WBT;
+}
+
 int conv_wino_init_device() {
     DDK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)(W_LDS_FLOATS * sizeof(float))));
@@ -429,6 +474,14 @@ int conv_wino_init_device() {
 // a: validated by conv_forward (shapes, alignment).  Writes the result (or, with splits > 1, the slabs in a.workspace).
 int conv_wino_forward(const ddk_conv_args& a, int splits, hipStream_t st) {
     WinoParams p{};
+    if (a.gn_partials) {
+        DDK_REQUIRE(conv_wino_stats_parts(a.B, a.H, a.W, a.c0 + a.c1, a.N, a.gn_groups) > 0 && splits == 1 && !a.resid && !a.post_mish,
+                    "conv: gn_partials needs a shape with ddk_conv_gn_partials() > 0 and no resid / post_mish");
+        DDK_REQUIRE((reinterpret_cast<uintptr_t>(a.gn_partials) & 7u) == 0, "conv: gn_partials alignment");
+        p.gn_part = reinterpret_cast<float2*>(a.gn_partials);
+        p.groups = a.gn_groups;
+        p.cpg = a.N / a.gn_groups;
+    }
     p.src0 = a.src0; p.src1 = a.src1; p.wu = a.weight_wino; p.bias = a.bias; p.resid = a.resid; p.out = a.out;
     p.c0 = a.c0; p.c1 = a.c1; p.cin = a.c0 + a.c1;
     p.B = a.B; p.H = a.H; p.W = a.W; p.TH = a.H / 2; p.TW = a.W / 2;
@@ -476,6 +529,10 @@ extern "C" int ddk_debug_read_wino_stamps(unsigned long long* host_out) {   // t
     return hipMemcpyToSymbol(HIP_SYMBOL(ddk::g_wino_stamps), zeros, sizeof(zeros)) == hipSuccess ? 0 : -2;
 }
 #endif
+
+extern "C" int ddk_conv_gn_partials(int B, int H, int W, int cin, int N, int groups) {
+    return ddk::conv_wino_stats_parts(B, H, W, cin, N, groups);
+}
 
 extern "C" int ddk_conv_wino_splits(int B, int H, int W, int cin, int N) {
     if (!ddk::conv_wino_ok(DDK_CONV3X3_S1, H, W, cin, N)) return 0;

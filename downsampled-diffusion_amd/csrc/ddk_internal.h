@@ -133,6 +133,7 @@ bool conv_wino_ok(int kind, int H, int W, int cin, int N);
 int conv_wino_splits(int B, int H, int W, int cin, int N);
 int conv_wino_forward(const ddk_conv_args& a, int splits, hipStream_t st);
 int conv_wino_init_device();
+int conv_wino_stats_parts(int B, int H, int W, int cin, int N, int groups);   // tiles per image, or 0
 // conv_local.hip: conv3x3 + GroupNorm + Mish (+shift, +residual) in one launch for 4x4 / 8x8 maps
 bool conv_gn_local_ok(int H, int W, int cin, int c0, int N, int groups);
 int conv_gn_local(const float* src0, int c0, const float* src1, int c1, const float* w, const float* bias, const float* gamma,
@@ -150,6 +151,9 @@ int groupnorm_mish(const float* x, const float* gamma, const float* beta, const 
 int groupnorm_mish_ex(const float* x, int nslab, long long slab_stride, const float* cbias, const float* gamma,
                       const float* beta, const float* temb, int temb_stride, const float* addend, float* out, int B, int HW, int C,
                       int groups, float eps, void* ws, size_t ws_bytes, hipStream_t st, const long long* temb_rows = nullptr);
+int groupnorm_mish_parts(const float* x, const float* part, int np, const float* gamma, const float* beta, const float* temb,
+                         int temb_stride, const float* addend, float* out, int B, int HW, int C, int groups, float eps, hipStream_t st,
+                         const long long* temb_rows = nullptr);
 int chan_layernorm(const float* x, const float* g, const float* b, float* out, long long M, int C, float eps, hipStream_t st);
 int unary(int op, const float* x, float* out, long long n, hipStream_t st);
 int add(const float* a, const float* b, float* out, long long n, hipStream_t st);

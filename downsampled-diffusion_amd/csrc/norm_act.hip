@@ -95,6 +95,104 @@ __global__ __launch_bounds__(NT) void gn_mish_resident_kernel(const float* __res
     }
 }
 
+// GroupNorm+Mish when the producing conv already left per-tile statistics (conv3x3_wino_kernel, gn_part): `np` tiles of 128
+// pixels per image, each {mean, M2 about that mean} per group.  Every workgroup first merges the np partials of its image's
+// groups in fixed order (Chan et al.: equal counts), then streams its share of the image: one read, one write.
+__global__ __launch_bounds__(256) void gn_apply_parts_kernel(const float* __restrict__ x, const float2* __restrict__ part, int np,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             const float* __restrict__ temb, int temb_stride,
+                                                             const long long* __restrict__ temb_rows, const float* __restrict__ addend,
+                                                             float* __restrict__ out, int HW, int C, int cpg, float eps, int wg_per_image,
+                                                             int units_per_wg) {
+    __shared__ float2 mr[128];
+    __shared__ float2 sp[1024];
+    const int b = blockIdx.x / wg_per_image, chunk = blockIdx.x - b * wg_per_image;
+    const int G = C / cpg;
+    const int upr = C >> 2;                      // float4 units per pixel
+    const int units = HW * upr;
+    const int u_begin = chunk * units_per_wg, u_end = min(units, (chunk + 1) * units_per_wg);
+    const long long base = (long long)b * HW * C;
+    // the first batch of x is requested before the statistics are merged: both latencies overlap
+    float4 v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int u = u_begin + threadIdx.x + k * 256;
+        if (u < u_end) v[k] = *reinterpret_cast<const float4*>(x + base + (long long)u * 4);
+    }
+    const float2* pb = part + (long long)b * np * G;
+    for (int i = threadIdx.x; i < np * G; i += 256) sp[i] = pb[i];          // [tile][group], host guarantees np * G <= 1024
+    __syncthreads();
+    if (threadIdx.x < G) {
+        float ms = 0.f;
+        for (int i = 0; i < np; ++i) ms += sp[i * G + threadIdx.x].x;
+        const float mean = ms / (float)np;
+        float m2 = 0.f, d2 = 0.f;
+        for (int i = 0; i < np; ++i) {
+            const float2 t = sp[i * G + threadIdx.x];
+            m2 += t.y;
+            d2 += (t.x - mean) * (t.x - mean);
+        }
+        const float n_i = 128.0f * (float)cpg;
+        const float var = (m2 + n_i * d2) / ((float)np * n_i);
+        mr[threadIdx.x] = make_float2(mean, 1.0f / sqrtf(var + eps));
+    }
+    __syncthreads();
+    const long long tr = temb ? (temb_rows ? temb_rows[b] : b) : 0;
+    for (int u0 = u_begin + threadIdx.x; u0 < u_end; u0 += 1024) {
+        if (u0 != u_begin + (int)threadIdx.x) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int u = u0 + k * 256;
+                if (u < u_end) v[k] = *reinterpret_cast<const float4*>(x + base + (long long)u * 4);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int u = u0 + k * 256;
+            if (u >= u_end) continue;
+            const int c0 = (u - div_upr(u, upr) * upr) << 2;
+            const float2 st = mr[c0 / cpg];
+            const float4 ga = *reinterpret_cast<const float4*>(gamma + c0);
+            const float4 be = *reinterpret_cast<const float4*>(beta + c0);
+            float4 y;
+            y.x = mish_f((v[k].x - st.x) * st.y * ga.x + be.x);
+            y.y = mish_f((v[k].y - st.x) * st.y * ga.y + be.y);
+            y.z = mish_f((v[k].z - st.x) * st.y * ga.z + be.z);
+            y.w = mish_f((v[k].w - st.x) * st.y * ga.w + be.w);
+            if (temb) {
+                const float4 t = *reinterpret_cast<const float4*>(temb + tr * temb_stride + c0);
+                y.x += t.x; y.y += t.y; y.z += t.z; y.w += t.w;
+            }
+            const long long o = base + (long long)u * 4;
+            if (addend) {
+                const float4 r = *reinterpret_cast<const float4*>(addend + o);
+                y.x += r.x; y.y += r.y; y.z += r.z; y.w += r.w;
+            }
+            *reinterpret_cast<float4*>(out + o) = y;
+        }
+    }
+}
+
+int groupnorm_mish_parts(const float* x, const float* part, int np, const float* gamma, const float* beta, const float* temb,
+                         int temb_stride, const float* addend, float* out, int B, int HW, int C, int groups, float eps, hipStream_t st,
+                         const long long* temb_rows) {
+    DDK_REQUIRE(x && part && gamma && beta && out, "groupnorm_mish_partials: null pointer");
+    DDK_REQUIRE(B > 0 && HW > 0 && groups > 0 && groups <= 128 && C % groups == 0 && (C / groups) % 4 == 0,
+                "groupnorm_mish_partials: C must split into <= 128 groups of a multiple of 4 channels");
+    DDK_REQUIRE(np > 0 && HW == np * 128 && np * groups <= 1024, "groupnorm_mish_partials: tiles_per_image * 128 must equal H*W "
+                "(and tiles_per_image * groups <= 1024)");
+    DDK_REQUIRE(aligned16(x) && aligned16(out) && aligned16(gamma) && aligned16(beta) && aligned16(addend) && aligned16(temb) &&
+                    temb_stride % 4 == 0, "groupnorm_mish_partials: pointers must be 16-byte aligned");
+    const int units = HW * (C / 4);
+    int wpi = (int)ceil_div(units, 1024);                       // 1024 float4 per workgroup ...
+    while ((long long)wpi * B > 2048 && wpi > 1) wpi = (wpi + 1) / 2;   // ... unless that makes more than ~8 workgroups per CU
+    const int upw = (int)(ceil_div(ceil_div(units, wpi), 256) * 256);
+    wpi = (int)ceil_div(units, upw);
+    hipLaunchKernelGGL(gn_apply_parts_kernel, dim3((unsigned)(B * wpi)), dim3(256), 0, st, x, reinterpret_cast<const float2*>(part), np, gamma,
+                       beta, temb, temb_stride, temb_rows, addend, out, HW, C, C / groups, eps, wpi, upw);
+    return check_launch("gn_apply_parts_kernel");
+}
+
 // Large slabs (full-resolution DDPM, 256x256): stats by `nsplit` workgroups per (b, group) as Welford
 // partials (count, mean, M2) combined in a fixed order, then a grid-wide apply pass.
 __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict__ x, float* __restrict__ part, int HW, int C,
@@ -436,6 +534,12 @@ int ddk_groupnorm_mish_slabs(const float* slabs, int nslab, long long slab_strid
                              int C, int groups, float eps, ddk_stream_t s) {
     return ddk::groupnorm_mish_ex(slabs, nslab, slab_stride, conv_bias, gamma, beta, temb, temb_stride, addend, out, B, HW, C, groups,
                                   eps, nullptr, 0, ddk::as_stream(s));
+}
+int ddk_groupnorm_mish_partials(const float* x, const float* partials, int tiles_per_image, const float* gamma, const float* beta,
+                                const float* temb, int temb_stride, const float* addend, float* out, int B, int HW, int C,
+                                int groups, float eps, ddk_stream_t s) {
+    return ddk::groupnorm_mish_parts(x, partials, tiles_per_image, gamma, beta, temb, temb_stride, addend, out, B, HW, C, groups, eps,
+                                     ddk::as_stream(s));
 }
 int ddk_chan_layernorm(const float* x, const float* g, const float* b, float* out, long long M, int C, float eps, ddk_stream_t s) {
     return ddk::chan_layernorm(x, g, b, out, M, C, eps, ddk::as_stream(s));

@@ -402,6 +402,7 @@ static void res_sizes(const ResW& r, int B, int H, int W, Layout& ly) {
     upd(ly.splitk, conv3_ws_floats(r.c2, B, H, W, r.co, r.co));
     if (r.has_res) upd(ly.splitk, conv_workspace_bytes(DDK_CONV1X1, B, H, W, r.ci_pad, r.co) / 4);
     upd(ly.gn_ws, groupnorm_workspace_bytes(B, H * W, r.co, GROUPS) / 4);
+    upd(ly.gn_ws, (size_t)2 * GROUPS * (M / 128 + 1));      // {mean, M2} partials the Winograd conv leaves for GroupNorm
 }
 
 static void attn_sizes(const AttnW& a, int B, int H, int W, Layout& ly) {
@@ -445,6 +446,7 @@ static Layout make_layout(const ddk_unet& u, int B, int H0, int W0) {
     upd(ly.act, (size_t)B * H * W * u.cfg.chan);
     upd(ly.splitk, conv3_ws_floats(u.final_conv, B, H, W, u.cfg.chan, u.cfg.chan));
     upd(ly.gn_ws, groupnorm_workspace_bytes(B, H * W, u.cfg.chan, GROUPS) / 4);
+    upd(ly.gn_ws, (size_t)2 * GROUPS * ((size_t)B * H * W / 128 + 1));
     ly.xpad = al4((size_t)B * H0 * W0 * pad32(u.cfg.in_ch));
     ly.temb = al4((size_t)B * u.temb_total);
     ly.tact = al4((size_t)B * u.time_dim);
@@ -503,6 +505,23 @@ static int run_conv_gn(Ctx& c, const ConvW& cw, const float* src0, int c0, const
         // conv's own epilogue, no slabs and no GroupNorm launch (conv_local.hip)
         return conv_gn_local(src0, c0, src1, c1, c.P + cw.wl, cw.has_bias ? c.P + cw.b : nullptr, c.P + n.g, c.P + n.b, temb,
                              c.u.temb_total, c.temb_rows, addend, out, c.B, H, W, N, GROUPS, GN_EPS, c.st);
+    const int np = cw.has_wu ? conv_wino_stats_parts(c.B, H, W, c0 + c1, N, GROUPS) : 0;
+    if (np > 0) {
+        // one-pass Winograd conv: its epilogue leaves per-tile {mean, M2}; GroupNorm then is a single streaming read + write
+        ddk_conv_args a{};
+        a.kind = DDK_CONV3X3_S1;
+        a.src0 = src0; a.src1 = src1; a.c0 = c0; a.c1 = c1;
+        a.weight = c.P + cw.w;
+        a.weight_wino = c.P + cw.wu;
+        a.bias = cw.has_bias ? c.P + cw.b : nullptr;
+        a.out = raw;
+        a.B = c.B; a.H = H; a.W = W; a.N = N;
+        a.gn_partials = c.W + c.ly.off_gn;
+        a.gn_groups = GROUPS;
+        DDK_TRY(conv_forward(a, c.st));
+        return groupnorm_mish_parts(raw, c.W + c.ly.off_gn, np, c.P + n.g, c.P + n.b, temb, c.u.temb_total, addend, out, c.B, H * W, N,
+                                    GROUPS, GN_EPS, c.st, c.temb_rows);
+    }
     const int splits = conv3_splits(cw, c.B, H, W, c0 + c1, N);
     const bool resident = groupnorm_workspace_bytes(c.B, H * W, N, GROUPS) == 0;
     if (splits > 1 && resident) {

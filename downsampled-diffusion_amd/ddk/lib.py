@@ -23,6 +23,7 @@ class ConvArgs(C.Structure):
         ("weight", C.c_void_p), ("bias", C.c_void_p), ("resid", C.c_void_p), ("out", C.c_void_p),
         ("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("N", C.c_int), ("pre_mish", C.c_int), ("post_mish", C.c_int), ("defer_reduce", C.c_int),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("weight_wino", C.c_void_p),
+        ("gn_partials", C.c_void_p), ("gn_groups", C.c_int),
     ]
 
 
@@ -55,6 +56,8 @@ SIGNATURES = {
     "ddk_pack_linear_T": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "ddk_pack_conv_weight_wino": (_I, [_P, _P, _I, _I, _I, _P]),
     "ddk_conv_wino_splits": (_I, [_I, _I, _I, _I, _I]),
+    "ddk_conv_gn_partials": (_I, [_I, _I, _I, _I, _I, _I]),
+    "ddk_groupnorm_mish_partials": (_I, [_P, _P, _I, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _F, _P]),
     "ddk_pack_conv_weight_local": (_I, [_P, _P, _I, _I, _I, _P]),
     "ddk_conv3x3_gn_mish_ok": (_I, [_I, _I, _I, _I, _I, _I]),
     "ddk_conv3x3_gn_mish": (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _F, _P]),

@@ -171,6 +171,20 @@ def conv3x3_groupnorm_mish(x, w_packed, bias, gamma, beta, x2=None, temb=None, a
     n = w_packed.shape[0]
     lib = L.load()
     wino = w_wino is not None and lib.ddk_conv_wino_splits(b, h, w_, c0 + c1, n) > 0
+    np_ = lib.ddk_conv_gn_partials(b, h, w_, c0 + c1, n, groups) if wino else 0
+    if np_ > 0:
+        # one-pass Winograd conv leaves per-tile {mean, M2}; GroupNorm reads the tensor once
+        out = torch.empty((b, h, w_, n), device=x.device, dtype=torch.float32)
+        raw = torch.empty_like(out)
+        part = torch.empty((b * np_, groups, 2), device=x.device, dtype=torch.float32)
+        a = L.ConvArgs(CONV3X3_S1, L.ptr(_f32(x)), L.ptr(x2), c0, c1, L.ptr(w_packed), L.ptr(bias), None, L.ptr(raw), b, h, w_, n, 0, 0, 0,
+                       None, 0, L.ptr(w_wino), L.ptr(part), groups)
+        L.check(lib.ddk_conv_forward(C.byref(a), L.stream()), "conv_forward(gn_partials)")
+        stride = temb.stride(0) if temb is not None else 0
+        L.check(lib.ddk_groupnorm_mish_partials(L.ptr(raw), L.ptr(part), np_, L.ptr(gamma), L.ptr(beta),
+                                                temb.data_ptr() if temb is not None else None, stride, L.ptr(addend), L.ptr(out),
+                                                b, h * w_, n, groups, eps, L.stream()), "groupnorm_mish_partials")
+        return out
     splits = lib.ddk_conv_wino_splits(b, h, w_, c0 + c1, n) if wino else lib.ddk_conv_splits(CONV3X3_S1, b, h, w_, c0 + c1, n)
     if splits == 1 or lib.ddk_groupnorm_workspace_bytes(b, h * w_, n, groups) != 0:
         return groupnorm_mish(conv(CONV3X3_S1, x, w_packed, bias, x2=x2, w_wino=w_wino), gamma, beta, temb=temb, addend=addend,

@@ -83,10 +83,17 @@ typedef struct ddk_conv_args {
                                * and the shape is eligible (ddk_conv_wino_splits() > 0) the conv runs as Winograd F(2x2,3x3):
                                * 2.25x fewer MFMA FLOPs, same result up to fp32 summation order.  Its split count (slabs in
                                * `workspace`) is ddk_conv_wino_splits(), workspace = splits * B*H*W*N floats when > 1. */
+    float* gn_partials;  /* optional (Winograd path, ddk_conv_gn_partials() > 0, no resid / post_mish): the kernel also writes, per
+                          * (128-pixel tile, GroupNorm group), {mean, M2} of its output: B*H*W/128 * gn_groups float pairs, which
+                          * ddk_groupnorm_mish_partials turns into GroupNorm+Mish with one read and one write of the tensor */
+    int gn_groups;
 } ddk_conv_args;
 
 /* Conv2d 3x3 weight OIHW -> Winograd-domain filter U = G g G^T, [I_pad/32][16 positions][O][32] (blocks.py:78). */
 int ddk_pack_conv_weight_wino(const float* w_oihw, float* dst, int O, int I, int i_pad, ddk_stream_t s);
+/* > 0: the Winograd kernel can emit GroupNorm partials for this shape (the value = 128-pixel tiles per image); 0: it cannot
+ * (channel-chunk splits, ragged tiles, groups that straddle a 64-channel tile). */
+int ddk_conv_gn_partials(int B, int H, int W, int cin, int N, int groups);
 /* 0: shape not eligible for the Winograd kernel (needs even H, W; cin % 32 == 0; N % 64 == 0); else its channel-chunk splits */
 int ddk_conv_wino_splits(int B, int H, int W, int cin, int N);
 size_t ddk_conv_workspace_bytes(int kind, int B, int H, int W, int cin, int N);
@@ -121,6 +128,11 @@ int ddk_conv3x3_gn_mish_ok(int H, int W, int cin, int c0, int N, int groups);
 int ddk_conv3x3_gn_mish(const float* src0, int c0, const float* src1, int c1, const float* weight, const float* bias,
                         const float* gamma, const float* beta, const float* temb, int temb_stride, const float* addend,
                         float* out, int B, int H, int W, int N, int groups, float eps, ddk_stream_t s);
+/* GroupNorm+Mish(+temb)(+addend) of x [B][HW][C] from the {mean, M2} partials a conv left in ddk_conv_args.gn_partials
+ * (tiles_per_image = ddk_conv_gn_partials()): statistics merged in fixed order, x read once (blocks.py:78-80). */
+int ddk_groupnorm_mish_partials(const float* x, const float* partials, int tiles_per_image, const float* gamma, const float* beta,
+                                const float* temb, int temb_stride, const float* addend, float* out, int B, int HW, int C,
+                                int groups, float eps, ddk_stream_t s);
 /* per-pixel channel LayerNorm, (x-mean)/(sqrt(var)+eps)*g+b, biased var (blocks.py:57-60). */
 int ddk_chan_layernorm(const float* x, const float* g, const float* b, float* out, long long M, int C,
                        float eps, ddk_stream_t s);

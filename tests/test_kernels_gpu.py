@@ -131,6 +131,48 @@ def test_conv_winograd_not_eligible_falls_back_to_direct(ops):
     assert rel_err(to_nchw(out.cpu()), F.conv2d(x, w, None, padding=1)) < 2e-5
 
 
+@pytest.mark.parametrize("B,H,W,c0,c1,N", [(32, 16, 16, 64, 0, 256), (16, 32, 32, 64, 0, 128), (32, 16, 16, 32, 32, 256), (1, 32, 16, 32, 0, 64),
+                                          (40, 16, 16, 32, 0, 64)])
+def test_conv_winograd_groupnorm_partials(ops, B, H, W, c0, c1, N):
+    """One-pass Winograd conv that also emits per-tile {mean, M2} + the GroupNorm kernel that merges them (one read, one write)
+    against torch's conv2d -> group_norm -> mish (blocks.py:75-84); bit-stable; agrees with the register-resident GroupNorm."""
+    cin = c0 + c1
+    lib = ops.L.load()
+    assert lib.ddk_conv_gn_partials(B, H, W, cin, N, 8) == H * W // 128
+    x = rnd(B, cin, H, W, seed=81)
+    w = rnd(N, cin, 3, 3, seed=82, scale=(cin * 9) ** -0.5)
+    bias = rnd(N, seed=83, scale=0.3)
+    gamma, beta = 1 + rnd(N, seed=84, scale=0.2), rnd(N, seed=85, scale=0.2)
+    temb = rnd(B, N, seed=86)
+    resid = rnd(B, N, H, W, seed=87)
+    h = F.group_norm(F.conv2d(x, w, bias, padding=1), 8, gamma, beta, eps=1e-5)
+    xh = to_nhwc(x).to(DEV)
+    x0 = xh[..., :c0].contiguous()
+    x1 = xh[..., c0:].contiguous() if c1 else None
+    wp, wu = ops.pack_conv_weight(w.to(DEV)), ops.pack_conv_weight_wino(w.to(DEV))
+    args = (x0, wp, bias.to(DEV), gamma.to(DEV), beta.to(DEV))
+    out = ops.conv3x3_groupnorm_mish(*args, x2=x1, temb=temb.to(DEV), addend=to_nhwc(resid).to(DEV), w_wino=wu)
+    assert rel_err(to_nchw(out.cpu()), U.mish(h) + temb[:, :, None, None] + resid) < 2e-5
+    assert torch.equal(out, ops.conv3x3_groupnorm_mish(*args, x2=x1, temb=temb.to(DEV), addend=to_nhwc(resid).to(DEV), w_wino=wu))
+    two = ops.groupnorm_mish(ops.conv(ops.CONV3X3_S1, x0, wp, bias.to(DEV), x2=x1, w_wino=wu), gamma.to(DEV), beta.to(DEV), temb=temb.to(DEV),
+                             addend=to_nhwc(resid).to(DEV))
+    assert rel_err(out.cpu(), two.cpu()) < 2e-6
+
+
+def test_conv_groupnorm_partials_offset_mean(ops):
+    """statistics as {mean, M2} per tile, merged by Chan's formula: a conv output with |mean| >> std (large bias) keeps its precision"""
+    B, H, W, cin, N = 2, 16, 16, 32, 64
+    x = rnd(B, cin, H, W, seed=88)
+    w = rnd(N, cin, 3, 3, seed=89, scale=0.01 * (cin * 9) ** -0.5)
+    bias = 50.0 + rnd(N, seed=90)
+    gamma, beta = torch.ones(N), torch.zeros(N)
+    ref = U.mish(F.group_norm(F.conv2d(x.double(), w.double(), bias.double(), padding=1), 8, eps=1e-5)).float()
+    assert ops.L.load().ddk_conv_gn_partials(B, H, W, cin, N, 8) == 2      # one channel chunk: no split
+    out = ops.conv3x3_groupnorm_mish(to_nhwc(x).to(DEV), ops.pack_conv_weight(w.to(DEV)), bias.to(DEV), gamma.to(DEV), beta.to(DEV),
+                                     w_wino=ops.pack_conv_weight_wino(w.to(DEV)))
+    assert rel_err(to_nchw(out.cpu()), ref) < 2e-4      # the input of the normalisation itself carries ~50 * 2^-24 of rounding
+
+
 LOCAL_CASES = [    # B, H, W, c0, c1, N   (GroupNorm groups = 8)
     (32, 4, 4, 256, 0, 256),       # cfg4 4x4 level (blocks.py:75-84 at downs.3 / mid / ups.0)
     (32, 4, 4, 256, 256, 256),     # ups.0.0 conv1: concat of two sources (unet.py:97)
