@@ -50,6 +50,49 @@ __host__ __device__ static inline size_t local_lds_bytes(int MT, int cin) {
     return (a > p ? a : p) + 256;
 }
 
+// Shared tail of the image-local kernels.  Every thread holds NV conv outputs (bias added) of ONE output channel c = n0 + col
+// of image b; lane = (other index bit) * 32 + col.  GroupNorm statistics of (image, group of col): two passes over the
+// registers, like torch's native_group_norm.  Wave level: lanes that share the group (xor masks below cpg, and 32); workgroup
+// level: the 8 waves' sums in fixed order.  Then affine, Mish, time shift, residual, store.
+template <int NV, typename P>
+__device__ __forceinline__ void gn_mish_tail(const float (&v)[NV], const long long (&o)[NV], int col, int c, int b, int hw, int lane, int wave,
+                                             float* red, const P& p) {
+    const int gl = col / p.cpg;                 // group within the tile: 0 .. 32/cpg - 1
+    auto group_sum = [&](float s) {
+        for (int x = 1; x < p.cpg; x <<= 1) s += __shfl_xor(s, x, 64);
+        s += __shfl_xor(s, 32, 64);
+        __syncthreads();                        // red free again
+        if ((lane & 32) == 0 && (col & (p.cpg - 1)) == 0) red[wave * 4 + gl] = s;
+        __syncthreads();
+        float t = red[gl];
+#pragma unroll
+        for (int w = 1; w < 8; ++w) t += red[w * 4 + gl];
+        return t;
+    };
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) s += v[i];
+    const float inv_n = 1.0f / (float)(hw * p.cpg);
+    const float mean = group_sum(s) * inv_n;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) q += (v[i] - mean) * (v[i] - mean);
+    const float var = group_sum(q) * inv_n;
+    const float rstd = 1.0f / sqrtf(var + p.eps);
+    const float ga = p.gamma[c], be = p.beta[c];
+    float sh = 0.f;
+    if (p.temb) {
+        const long long tr = p.temb_rows ? p.temb_rows[b] : b;
+        sh = p.temb[tr * p.temb_stride + c];
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        float y = mish_f((v[i] - mean) * rstd * ga + be) + sh;
+        if (p.addend) y += p.addend[o[i]];
+        p.out[o[i]] = y;
+    }
+}
+
 template <int MT>
 __global__ __launch_bounds__(512) void conv3x3_gn_local_kernel(const LocalParams p) {
     extern __shared__ __align__(16) float lds[];
@@ -176,45 +219,203 @@ __global__ __launch_bounds__(512) void conv3x3_gn_local_kernel(const LocalParams
         v[i] = s + cb;
     }
 
-    // ---- GroupNorm statistics of (this image, group of column col): two passes over the registers, like torch's
-    //      native_group_norm.  Wave level: lanes that share the group (xor masks below cpg, and 32 = the other row of the
-    //      wave); workgroup level: the 8 waves' sums in fixed order.
-    const int gl = col / p.cpg;                 // group within the tile: 0 .. 32/cpg - 1
-    auto group_sum = [&](float s) {
-        for (int o = 1; o < p.cpg; o <<= 1) s += __shfl_xor(s, o, 64);
-        s += __shfl_xor(s, 32, 64);
-        __syncthreads();                        // red free again
-        if ((lane & 32) == 0 && (col & (p.cpg - 1)) == 0) red[wave * 4 + gl] = s;
-        __syncthreads();
-        float t = red[gl];
+    long long o[MB];
 #pragma unroll
-        for (int w = 1; w < 8; ++w) t += red[w * 4 + gl];
-        return t;
-    };
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < MB; ++i) s += v[i];
-    const float inv_n = 1.0f / (float)(MT * p.cpg);
-    const float mean = group_sum(s) * inv_n;
-    float q = 0.f;
-#pragma unroll
-    for (int i = 0; i < MB; ++i) q += (v[i] - mean) * (v[i] - mean);
-    const float var = group_sum(q) * inv_n;
-    const float rstd = 1.0f / sqrtf(var + p.eps);
+    for (int i = 0; i < MB; ++i) o[i] = ((long long)b * MT + row + 16 * i) * p.N + c;
+    gn_mish_tail<MB>(v, o, col, c, b, MT, lane, wave, red, p);
+}
 
-    const float ga = p.gamma[c], be = p.beta[c];
-    float sh = 0.f;
-    if (p.temb) {
-        const long long tr = p.temb_rows ? p.temb_rows[b] : b;
-        sh = p.temb[tr * p.temb_stride + c];
-    }
+// ---------------------------------------------------------------------------------------------------------------------------
+// The same idea for the 64-pixel maps (8x8), where the direct form would be MFMA-bound (9.4 MFLOP per workgroup): Winograd
+// F(2x2, 3x3) inside the image-local tiling.  An image is 16 tiles = exactly one M block of v_mfma_f32_16x16x4_f32; per
+// 32-channel chunk four TRANSFORM waves build V = B^T d B for (tile, channel) from the image in LDS (16 reads, 32 adds, 16
+// writes per item) one chunk ahead, while eight MATRIX waves multiply: wave w takes positions 2w and 2w+1 (32 MFMAs) against
+// U streamed from L2 in operand order (ddk_pack_conv_weight_wino_local: [n tile][chunk][position][n block][k half][lane][4]).
+// V is double-buffered, one barrier per chunk.  Output transform A^T M A per (tile, channel) through LDS, then the shared
+// GroupNorm tail.
+struct WLocalParams {
+    const float* src0;
+    const float* src1;
+    int c0, c1;
+    const float* w;
+    const float* bias;
+    const float* gamma;
+    const float* beta;
+    const float* temb;
+    int temb_stride;
+    const long long* temb_rows;
+    const float* addend;
+    float* out;
+    int H, W, N, cpg;
+    float eps;
+};
+
+constexpr int WL_VP = 36;                       // V / M row pitch (floats): 16 rows cover the 64 banks once
+constexpr int WL_VBUF = 16 * 16 * WL_VP;        // one V buffer: [position][tile][36]
+
+__host__ __device__ static inline size_t wlocal_lds_bytes(int cin) { return ((size_t)65 * (cin + 4) + 2 * WL_VBUF) * 4 + 256; }
+
+__global__ __launch_bounds__(768) void conv3x3_gn_wlocal_kernel(const WLocalParams p) {
+    extern __shared__ __align__(16) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // 0..7 matrix waves, 8..11 transform waves
+    const int m = lane & 15, kq = lane >> 4;
+    const int NT = p.N >> 5;
+    const int nt = blockIdx.x % NT, b = blockIdx.x / NT;
+    const int n0 = nt << 5;
+    const int cin = p.c0 + p.c1;
+    const int pitch = cin + 4;
+    const int nch = cin >> 5;
+    float* V = lds + 65 * pitch;
+    float* red = V + 2 * WL_VBUF;
+    auto lds_barrier = [] {   // LDS traffic only: __syncthreads() would also wait (vmcnt) for the weight loads deliberately in flight
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    };
+
+    // ---- weights of a matrix wave's two positions, one chunk ahead (two register sets, one per chunk parity).  Measured at
+    //      batch 32: 1.85 us per chunk where the MFMAs need 0.95 -- the 32 workgroups of an XCD stream the same 524 KB of U
+    //      through that XCD's L2 at the same time (16.8 MB per launch and XCD, ~1.1 TB/s); prefetching two chunks ahead changes
+    //      nothing, two images per workgroup halve the traffic and double the MFMA time per workgroup: same 21 us either way.
+    const float* wl = p.w + ((size_t)nt * nch * 16 + 2 * (wave & 7)) * 1024 + lane * 4;
+    float4 bA[2][2][2], bB[2][2][2];            // [position of the pair][n block][k half]
+    auto load_b = [&](int chunk, float4 (&bq)[2][2][2]) {
+        chunk = chunk < nch ? chunk : nch - 1;  // past the end: harmless re-read, no load under a condition
+        const float* wp = wl + (size_t)chunk * 16 * 1024;
 #pragma unroll
-    for (int i = 0; i < MB; ++i) {
-        const long long o = ((long long)b * MT + row + 16 * i) * p.N + c;
-        float y = mish_f((v[i] - mean) * rstd * ga + be) + sh;
-        if (p.addend) y += p.addend[o];
-        p.out[o] = y;
+        for (int pp = 0; pp < 2; ++pp) {
+            bq[pp][0][0] = *reinterpret_cast<const float4*>(wp + pp * 1024);
+            bq[pp][0][1] = *reinterpret_cast<const float4*>(wp + pp * 1024 + 256);
+            bq[pp][1][0] = *reinterpret_cast<const float4*>(wp + pp * 1024 + 512);
+            bq[pp][1][1] = *reinterpret_cast<const float4*>(wp + pp * 1024 + 768);
+        }
+    };
+    if (wave < 8) {
+        load_b(0, bA);
+        load_b(1, bB);
     }
+
+    // ---- the image: [64 rows][cin] into LDS, row 64 = zeros (all 12 waves)
+    {
+        const int q4 = cin >> 2;
+        const long long row0 = (long long)b * 64;
+        for (int i = tid; i < 64 * q4; i += 768) {
+            const int row = i / q4, c = (i - row * q4) << 2;
+            const float4 v = c < p.c0 ? *reinterpret_cast<const float4*>(p.src0 + (row0 + row) * p.c0 + c)
+                                      : *reinterpret_cast<const float4*>(p.src1 + (row0 + row) * p.c1 + (c - p.c0));
+            *reinterpret_cast<float4*>(lds + row * pitch + c) = v;
+        }
+        for (int i = tid; i < q4; i += 768) *reinterpret_cast<float4*>(lds + 64 * pitch + (i << 2)) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();                            // image complete
+
+    const int TW = p.W >> 1;
+    if (wave >= 8) {
+        // ================================================================ transform waves: V = B^T d B, one chunk ahead of the
+        // matrix waves.  256 threads, two (tile, channel) items each: item = t2 + 256 k -> tile item / 32, channel item % 32
+        const int t2 = tid - 512;
+        int poff[2][16];                        // LDS offsets of the 4x4 patches (the zero row where a patch leaves the image)
+        int voff[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int item = t2 + 256 * k;
+            const int tt = item >> 5, tch = item & 31;
+            const int tty = tt / TW, ttx = tt - tty * TW;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int y = 2 * tty - 1 + i, x = 2 * ttx - 1 + j;
+                    const bool ok = (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+                    poff[k][i * 4 + j] = (ok ? y * p.W + x : 64) * pitch + tch;
+                }
+            voff[k] = tt * WL_VP + tch;
+        }
+        auto transform = [&](int chunk, int buf) {
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                float d[16];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) d[e] = lds[poff[k][e] + (chunk << 5)];
+                float* vb = V + buf * WL_VBUF + voff[k];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float r[4];
+#pragma unroll
+                    for (int x = 0; x < 4; ++x)
+                        r[x] = i == 0 ? d[0 + x] - d[8 + x] : i == 1 ? d[4 + x] + d[8 + x] : i == 2 ? d[8 + x] - d[4 + x] : d[4 + x] - d[12 + x];
+                    vb[(4 * i + 0) * (16 * WL_VP)] = r[0] - r[2];
+                    vb[(4 * i + 1) * (16 * WL_VP)] = r[1] + r[2];
+                    vb[(4 * i + 2) * (16 * WL_VP)] = r[2] - r[1];
+                    vb[(4 * i + 3) * (16 * WL_VP)] = r[1] - r[3];
+                }
+            }
+        };
+        transform(0, 0);
+        for (int c = 0; c < nch; ++c) {
+            lds_barrier();                      // V[c & 1] complete, V[(c + 1) & 1] consumed
+            if (c + 1 < nch) transform(c + 1, (c + 1) & 1);
+        }
+        return;                                 // a finished wave no longer counts at the workgroup's barriers
+    }
+
+    // ==================================================================== matrix waves (512 threads)
+    f32x4 acc[2][2];
+    acc[0][0] = acc[0][1] = acc[1][0] = acc[1][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto chunk_step = [&](int chunk, const float4 (&bq)[2][2][2]) {
+        lds_barrier();
+        const float* vb = V + (chunk & 1) * WL_VBUF + ((2 * wave) * 16 + m) * WL_VP + kq * 8;
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp) {
+            float4 a[2];
+            a[0] = *reinterpret_cast<const float4*>(vb + pp * (16 * WL_VP));
+            a[1] = *reinterpret_cast<const float4*>(vb + pp * (16 * WL_VP) + 4);
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+                const float av = reinterpret_cast<const float*>(&a[0])[kk];
+                acc[pp][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, reinterpret_cast<const float*>(&bq[pp][0][0])[kk], acc[pp][0], 0, 0, 0);
+                acc[pp][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, reinterpret_cast<const float*>(&bq[pp][1][0])[kk], acc[pp][1], 0, 0, 0);
+            }
+        }
+    };
+    for (int c = 0; c < nch; c += 2) {
+        chunk_step(c, bA);
+        load_b(c + 2, bA);
+        if (c + 1 < nch) chunk_step(c + 1, bB);
+        load_b(c + 3, bB);
+    }
+
+    // ---- M[position][tile][n] of the 8 waves into LDS (over the V buffers; the transform waves have finished)
+    __syncthreads();
+#pragma unroll
+    for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) V[((2 * wave + pp) * 16 + kq * 4 + r) * WL_VP + nb * 16 + m] = acc[pp][nb][r];
+    __syncthreads();
+
+    // ---- output transform: thread = (tile tid / 32, channel tid % 32), Y = A^T M A, A^T = [[1,1,1,0],[0,1,-1,-1]]
+    const int tt = tid >> 5, col = tid & 31, c = n0 + col;
+    const int tty = tt / TW, ttx = tt - tty * TW;
+    float mm[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) mm[k] = V[(k * 16 + tt) * WL_VP + col];
+    float t0[4], t1[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        t0[j] = (mm[0 + j] + mm[4 + j]) + mm[8 + j];
+        t1[j] = (mm[4 + j] - mm[8 + j]) - mm[12 + j];
+    }
+    const float cb = p.bias ? p.bias[c] : 0.f;
+    float v[4];
+    v[0] = ((t0[0] + t0[1]) + t0[2]) + cb;
+    v[1] = ((t0[1] - t0[2]) - t0[3]) + cb;
+    v[2] = ((t1[0] + t1[1]) + t1[2]) + cb;
+    v[3] = ((t1[1] - t1[2]) - t1[3]) + cb;
+    long long o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = ((long long)b * 64 + (2 * tty + (k >> 1)) * p.W + 2 * ttx + (k & 1)) * p.N + c;
+    gn_mish_tail<4>(v, o, col, c, b, 64, lane, wave, red, p);
 }
 
 // dst[n tile][tap][chunk][n block][k half][lane = kq * 16 + n][j] = w[o = 32 nt + 16 nb + n][i = 32 chunk + 8 kq + 4 half + j][tap]
@@ -233,6 +434,57 @@ __global__ __launch_bounds__(256) void pack_conv_weight_local_kernel(const float
     }
 }
 
+// Winograd-domain filter U = G g G^T in the operand order of conv3x3_gn_wlocal_kernel:
+// dst[n tile][chunk][position][n block][k half][lane][j], same (o, i) decoding as above.  G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
+__global__ __launch_bounds__(256) void pack_conv_weight_wlocal_kernel(const float* __restrict__ w, float* __restrict__ dst, int O, int I,
+                                                                      int i_pad, long long total) {
+    const int nch = i_pad >> 5;
+    for (long long idx = blockIdx.x * 256LL + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int j = (int)(idx & 3), lane = (int)((idx >> 2) & 63), half = (int)((idx >> 8) & 1), nb = (int)((idx >> 9) & 1);
+        long long r = idx >> 10;
+        const int pos = (int)(r & 15); r >>= 4;
+        const int chunk = (int)(r % nch);
+        const int nt = (int)(r / nch);
+        const int o = nt * 32 + nb * 16 + (lane & 15);
+        const int i = chunk * 32 + (lane >> 4) * 8 + half * 4 + j;
+        float u = 0.f;
+        if (i < I) {
+            const float* g = w + ((long long)o * I + i) * 9;
+            const int pi = pos >> 2, pj = pos & 3;
+            float t[3];
+#pragma unroll
+            for (int bb = 0; bb < 3; ++bb)
+                t[bb] = pi == 0 ? g[bb] : pi == 1 ? 0.5f * ((g[bb] + g[3 + bb]) + g[6 + bb]) : pi == 2 ? 0.5f * ((g[bb] - g[3 + bb]) + g[6 + bb])
+                                                                                                        : g[6 + bb];
+            u = pj == 0 ? t[0] : pj == 1 ? 0.5f * ((t[0] + t[1]) + t[2]) : pj == 2 ? 0.5f * ((t[0] - t[1]) + t[2]) : t[2];
+        }
+        dst[idx] = u;
+    }
+}
+
+bool conv_gn_wlocal_ok(int H, int W, int cin, int c0, int N, int groups) {
+    if (H * W != 64 || H % 2 || W % 2) return false;
+    if (cin % 32 || c0 % 4 || (cin - c0) % 4 || N % 32 || N % groups) return false;
+    const int cpg = N / groups;
+    if (cpg != 8 && cpg != 16 && cpg != 32) return false;
+    return wlocal_lds_bytes(cin) <= 160 * 1024;
+}
+
+int conv_gn_wlocal(const float* src0, int c0, const float* src1, int c1, const float* w, const float* bias, const float* gamma,
+                   const float* beta, const float* temb, int temb_stride, const long long* temb_rows, const float* addend, float* out,
+                   int B, int H, int W, int N, int groups, float eps, hipStream_t st) {
+    DDK_REQUIRE(src0 && w && gamma && beta && out, "conv_gn_wlocal: null pointer");
+    DDK_REQUIRE(B > 0 && groups > 0, "conv_gn_wlocal: B and groups must be positive");
+    DDK_REQUIRE(c1 == 0 || src1, "conv_gn_wlocal: second source missing");
+    DDK_REQUIRE(conv_gn_wlocal_ok(H, W, c0 + c1, c0, N, groups), "conv_gn_wlocal: shape not eligible (needs H*W == 64 with even H, W; "
+                "cin % 32 == 0 and <= 320; N % 32 == 0; channels per group in {8, 16, 32})");
+    DDK_REQUIRE(aligned16(src0) && aligned16(src1) && aligned16(w), "conv_gn_wlocal: sources and weights must be 16-byte aligned");
+    DDK_TRY(ensure_device_init());
+    WLocalParams p{src0, src1, c0, c1, w, bias, gamma, beta, temb, temb_stride, temb_rows, addend, out, H, W, N, N / groups, eps};
+    hipLaunchKernelGGL(conv3x3_gn_wlocal_kernel, dim3((unsigned)((long long)B * (N / 32))), dim3(768), wlocal_lds_bytes(c0 + c1), st, p);
+    return check_launch("conv3x3_gn_wlocal_kernel");
+}
+
 bool conv_gn_local_ok(int H, int W, int cin, int c0, int N, int groups) {
     const int HW = H * W;
     if (HW != 16 && HW != 64) return false;
@@ -246,6 +498,8 @@ int conv_gn_local_init_device() {
     DDK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_gn_local_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 160 * 1024));
     DDK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_gn_local_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024));
+    DDK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_gn_wlocal_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 160 * 1024));
     return DDK_OK;
 }
@@ -284,6 +538,28 @@ int ddk_pack_conv_weight_local(const float* w_oihw, float* dst, int O, int I, in
     hipLaunchKernelGGL(pack_conv_weight_local_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, as_stream(s), w_oihw,
                        dst, O, I, i_pad, total);
     return check_launch("pack_conv_weight_local_kernel");
+}
+
+int ddk_pack_conv_weight_wino_local(const float* w_oihw, float* dst, int O, int I, int i_pad, ddk_stream_t s) {
+    using namespace ddk;
+    DDK_REQUIRE(w_oihw && dst && O > 0 && I > 0 && O % 32 == 0 && i_pad >= I && i_pad % 32 == 0,
+                "pack_conv_weight_wino_local: arguments (O % 32 == 0, i_pad % 32 == 0)");
+    const long long total = (long long)O * 16 * i_pad;
+    const long long blocks = ceil_div(total, 256);
+    hipLaunchKernelGGL(pack_conv_weight_wlocal_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, as_stream(s), w_oihw,
+                       dst, O, I, i_pad, total);
+    return check_launch("pack_conv_weight_wlocal_kernel");
+}
+
+int ddk_conv3x3_gn_mish_wino_ok(int H, int W, int cin, int c0, int N, int groups) {
+    return ddk::conv_gn_wlocal_ok(H, W, cin, c0, N, groups) ? 1 : 0;
+}
+
+int ddk_conv3x3_gn_mish_wino(const float* src0, int c0, const float* src1, int c1, const float* weight, const float* bias,
+                             const float* gamma, const float* beta, const float* temb, int temb_stride, const float* addend, float* out,
+                             int B, int H, int W, int N, int groups, float eps, ddk_stream_t s) {
+    return ddk::conv_gn_wlocal(src0, c0, src1, c1, weight, bias, gamma, beta, temb, temb_stride, nullptr, addend, out, B, H, W, N, groups,
+                               eps, ddk::as_stream(s));
 }
 
 int ddk_conv3x3_gn_mish_ok(int H, int W, int cin, int c0, int N, int groups) { return ddk::conv_gn_local_ok(H, W, cin, c0, N, groups) ? 1 : 0; }

@@ -24,7 +24,7 @@ constexpr float GN_EPS = 1e-5f, LN_EPS = 1e-5f;
 
 static inline int pad32(int c) { return (c + 31) / 32 * 32; }
 
-enum PackKind { PK_COPY = 0, PK_CONV = 1, PK_CONVT = 2, PK_LINEAR_T = 3, PK_WINO = 4, PK_LOCAL = 5 };
+enum PackKind { PK_COPY = 0, PK_CONV = 1, PK_CONVT = 2, PK_LINEAR_T = 3, PK_WINO = 4, PK_LOCAL = 5, PK_WLOCAL = 6 };
 
 struct Slot {
     std::string name;
@@ -43,6 +43,8 @@ struct ConvW {
     bool has_wu = false;
     size_t wl = 0;          // conv_local.hip's operand-order copy (3x3 convs that feed a GroupNorm); has_wl says whether it exists
     bool has_wl = false;
+    size_t wwl = 0;         // and its Winograd-domain form for the 8x8 maps (conv3x3_gn_wlocal_kernel); has_wwl
+    bool has_wwl = false;
 };
 struct NormW { size_t g = 0, b = 0; };
 struct ResW {
@@ -129,6 +131,11 @@ struct ddk_unet {
             c.wl = alloc((size_t)9 * cout * c.cin_pad);
             c.has_wl = true;
             slots.push_back(Slot{prefix + "weight", (long long)cout * cin * k * k, PK_LOCAL, c.wl, cout, cin, k, k, c.cin_pad, 0, 0});
+            if (c.cin_pad <= 320) {
+                c.wwl = alloc((size_t)16 * cout * c.cin_pad);
+                c.has_wwl = true;
+                slots.push_back(Slot{prefix + "weight", (long long)cout * cin * k * k, PK_WLOCAL, c.wwl, cout, cin, k, k, c.cin_pad, 0, 0});
+            }
         }
         return c;
     }
@@ -352,6 +359,7 @@ extern "C" int ddk_unet_pack_slot(const ddk_unet* u, int slot, const float* cano
         case PK_LINEAR_T: rc = ddk_pack_linear_T(canonical, dst, sl.O, sl.I, sl.ld, sl.col0, s); break;
         case PK_WINO: rc = ddk_pack_conv_weight_wino(canonical, dst, sl.O, sl.I, sl.i_pad, s); break;
         case PK_LOCAL: rc = ddk_pack_conv_weight_local(canonical, dst, sl.O, sl.I, sl.i_pad, s); break;
+        case PK_WLOCAL: rc = ddk_pack_conv_weight_wino_local(canonical, dst, sl.O, sl.I, sl.i_pad, s); break;
         default: return fail_arg("unet_pack_slot: slot kind");
     }
     DDK_TRY(rc);
@@ -505,6 +513,10 @@ static int run_conv_gn(Ctx& c, const ConvW& cw, const float* src0, int c0, const
         // conv's own epilogue, no slabs and no GroupNorm launch (conv_local.hip)
         return conv_gn_local(src0, c0, src1, c1, c.P + cw.wl, cw.has_bias ? c.P + cw.b : nullptr, c.P + n.g, c.P + n.b, temb,
                              c.u.temb_total, c.temb_rows, addend, out, c.B, H, W, N, GROUPS, GN_EPS, c.st);
+    if (cw.has_wwl && H * W == 64 && conv_gn_wlocal_ok(H, W, c0 + c1, c0, N, GROUPS))
+        // 8x8 maps: the same image-local tiling in Winograd form
+        return conv_gn_wlocal(src0, c0, src1, c1, c.P + cw.wwl, cw.has_bias ? c.P + cw.b : nullptr, c.P + n.g, c.P + n.b, temb,
+                              c.u.temb_total, c.temb_rows, addend, out, c.B, H, W, N, GROUPS, GN_EPS, c.st);
     const int np = cw.has_wu ? conv_wino_stats_parts(c.B, H, W, c0 + c1, N, GROUPS) : 0;
     if (np > 0) {
         // one-pass Winograd conv: its epilogue leaves per-tile {mean, M2}; GroupNorm then is a single streaming read + write

@@ -112,6 +112,17 @@ def pack_conv_weight_local(w):
     return out
 
 
+def pack_conv_weight_wino_local(w):
+    """OIHW 3x3 -> Winograd-domain filter in the operand order of conv3x3_gn_mish_wino: [O/32][pad32(I)/32][16][1024]."""
+    o, i, kh, kw = w.shape
+    if (kh, kw) != (3, 3) or o % 32:
+        raise L.DDKError("pack_conv_weight_wino_local: kernel must be 3x3 and O % 32 == 0")
+    out = torch.empty((o // 32, pad32(i) // 32, 16, 1024), device=w.device, dtype=torch.float32)
+    L.check(L.load().ddk_pack_conv_weight_wino_local(L.ptr(_f32(w.contiguous())), L.ptr(out), o, i, pad32(i), L.stream()),
+            "pack_conv_weight_wino_local")
+    return out
+
+
 def wino_weight(weight, x_shape, c_lo=None, c_hi=None, dgrad=False):
     """Cached Winograd-domain copy of a canonical OIHW 3x3 filter for a conv on NHWC input shape `x_shape`, or None when the
     shape is not eligible (ddk_conv_wino_splits == 0).  dgrad=True: the filter of the INPUT-gradient conv for input channels
@@ -233,6 +244,24 @@ def conv3x3_gn_mish(x, w_local, bias, gamma, beta, temb=None, addend=None, x2=No
     L.check(lib.ddk_conv3x3_gn_mish(L.ptr(_f32(x)), c0, L.ptr(_f32(x2)) if x2 is not None else None, c1, L.ptr(w_packed), L.ptr(bias),
                                     L.ptr(gamma), L.ptr(beta), temb.data_ptr() if temb is not None else None, stride, L.ptr(addend),
                                     L.ptr(out), b, h, w, n, groups, eps, L.stream()), "conv3x3_gn_mish")
+    return out
+
+
+def conv3x3_gn_mish_wino(x, w_wl, bias, gamma, beta, temb=None, addend=None, x2=None, groups=GN_GROUPS, eps=GN_EPS):
+    """Block (blocks.py:75-84) in one launch on a 64-pixel map (8x8), Winograd form; w_wl = pack_conv_weight_wino_local(weight)."""
+    b, h, w, c0 = x.shape
+    c1 = x2.shape[-1] if x2 is not None else 0
+    n = w_wl.shape[0] * 32
+    lib = L.load()
+    if w_wl.shape[1] * 32 != c0 + c1:
+        raise L.DDKError(f"conv3x3_gn_mish_wino: filter packed for {w_wl.shape[1] * 32} input channels, input has {c0 + c1}")
+    if not lib.ddk_conv3x3_gn_mish_wino_ok(h, w, c0 + c1, c0, n, groups):
+        raise L.DDKError(f"conv3x3_gn_mish_wino: shape {tuple(x.shape)} (+{c1}) -> {n} not eligible")
+    out = torch.empty((b, h, w, n), device=x.device, dtype=torch.float32)
+    stride = temb.stride(0) if temb is not None else 0
+    L.check(lib.ddk_conv3x3_gn_mish_wino(L.ptr(_f32(x)), c0, L.ptr(_f32(x2)) if x2 is not None else None, c1, L.ptr(w_wl), L.ptr(bias),
+                                         L.ptr(gamma), L.ptr(beta), temb.data_ptr() if temb is not None else None, stride, L.ptr(addend),
+                                         L.ptr(out), b, h, w, n, groups, eps, L.stream()), "conv3x3_gn_mish_wino")
     return out
 
 

@@ -133,6 +133,13 @@ int ddk_conv3x3_gn_mish(const float* src0, int c0, const float* src1, int c1, co
 int ddk_groupnorm_mish_partials(const float* x, const float* partials, int tiles_per_image, const float* gamma, const float* beta,
                                 const float* temb, int temb_stride, const float* addend, float* out, int B, int HW, int C,
                                 int groups, float eps, ddk_stream_t s);
+/* The same Block in one launch for 64-pixel maps (8x8; H, W even), as Winograd F(2x2,3x3) inside an image-local tiling.
+ * `weight`: ddk_pack_conv_weight_wino_local (O*16*i_pad floats, O % 32 == 0); cin <= 320. */
+int ddk_pack_conv_weight_wino_local(const float* w_oihw, float* dst, int O, int I, int i_pad, ddk_stream_t s);
+int ddk_conv3x3_gn_mish_wino_ok(int H, int W, int cin, int c0, int N, int groups);
+int ddk_conv3x3_gn_mish_wino(const float* src0, int c0, const float* src1, int c1, const float* weight, const float* bias,
+                             const float* gamma, const float* beta, const float* temb, int temb_stride, const float* addend,
+                             float* out, int B, int H, int W, int N, int groups, float eps, ddk_stream_t s);
 /* per-pixel channel LayerNorm, (x-mean)/(sqrt(var)+eps)*g+b, biased var (blocks.py:57-60). */
 int ddk_chan_layernorm(const float* x, const float* g, const float* b, float* out, long long M, int C,
                        float eps, ddk_stream_t s);

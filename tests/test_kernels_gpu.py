@@ -217,6 +217,45 @@ def test_conv3x3_groupnorm_mish_one_launch(ops, B, H, W, c0, c1, N):
     assert rel_err(out.cpu(), two.cpu()) < 2e-5
 
 
+WLOCAL_CASES = [   # B, H, W, c0, c1, N
+    (32, 8, 8, 256, 0, 256),       # cfg4 8x8 level
+    (3, 8, 8, 64, 0, 128),         # 16 channels per group
+    (2, 8, 8, 32, 0, 64),          # one chunk, 8 channels per group
+    (2, 4, 16, 96, 32, 96),        # non-square 64-pixel map, concat; 12 channels per group is not eligible
+    (2, 16, 4, 128, 192, 256),     # concat filling the 320-channel LDS budget
+    (5, 8, 8, 160, 0, 64),         # odd chunk count (5)
+]
+
+
+@pytest.mark.parametrize("B,H,W,c0,c1,N", WLOCAL_CASES)
+def test_conv3x3_groupnorm_mish_one_launch_winograd(ops, B, H, W, c0, c1, N):
+    """conv3x3_gn_wlocal_kernel (64-pixel maps, Winograd F(2x2,3x3) inside the image-local tiling) against torch's
+    conv2d -> group_norm -> mish (+ shift, + residual), blocks.py:75-84, 110-115; bit-stable; agrees with the two-launch path."""
+    cin = c0 + c1
+    lib = ops.L.load()
+    if not lib.ddk_conv3x3_gn_mish_wino_ok(H, W, cin, c0, N, 8):
+        assert (N // 8) not in (8, 16, 32)
+        pytest.skip("shape not eligible (channels per group)")
+    x = rnd(B, cin, H, W, seed=91)
+    w = rnd(N, cin, 3, 3, seed=92, scale=(cin * 9) ** -0.5)
+    bias = rnd(N, seed=93, scale=0.1)
+    gamma, beta = 1 + rnd(N, seed=94, scale=0.2), rnd(N, seed=95, scale=0.2)
+    temb = rnd(B, N, seed=96)
+    resid = rnd(B, N, H, W, seed=97)
+    h = F.group_norm(F.conv2d(x, w, bias, padding=1), 8, gamma, beta, eps=1e-5)
+    xh = to_nhwc(x).to(DEV)
+    x0 = xh[..., :c0].contiguous()
+    x1 = xh[..., c0:].contiguous() if c1 else None
+    args = (x0, ops.pack_conv_weight_wino_local(w.to(DEV)), bias.to(DEV), gamma.to(DEV), beta.to(DEV))
+    out = ops.conv3x3_gn_mish_wino(*args, x2=x1)
+    assert rel_err(to_nchw(out.cpu()), U.mish(h)) < 2e-5
+    out_t = ops.conv3x3_gn_mish_wino(*args, temb=temb.to(DEV), addend=to_nhwc(resid).to(DEV), x2=x1)
+    assert rel_err(to_nchw(out_t.cpu()), U.mish(h) + temb[:, :, None, None] + resid) < 2e-5
+    assert torch.equal(out, ops.conv3x3_gn_mish_wino(*args, x2=x1))
+    two = ops.groupnorm_mish(ops.conv(ops.CONV3X3_S1, x0, ops.pack_conv_weight(w.to(DEV)), bias.to(DEV), x2=x1), gamma.to(DEV), beta.to(DEV))
+    assert rel_err(out.cpu(), two.cpu()) < 2e-5
+
+
 def test_conv3x3_groupnorm_mish_rejects_other_maps(ops):
     x = torch.zeros(1, 16, 16, 32, device=DEV)
     wp = torch.zeros(1, 9, 1, 1024, device=DEV)

@@ -26,4 +26,9 @@ for name, H, c0, c1, N in SHAPES:
     t_one = graph_time(lambda: ops.conv3x3_gn_mish(x0, wl, bias, gam, bet, temb=temb, x2=x1))
     a = ops.conv3x3_groupnorm_mish(x0, wp, bias, gam, bet, x2=x1, temb=temb, w_wino=wu)
     b = ops.conv3x3_gn_mish(x0, wl, bias, gam, bet, temb=temb, x2=x1)
+    if H == 8 and ops.L.load().ddk_conv3x3_gn_mish_wino_ok(H, H, cin, c0, N, 8):
+        wwl = ops.pack_conv_weight_wino_local(w)
+        t_w = graph_time(lambda: ops.conv3x3_gn_mish_wino(x0, wwl, bias, gam, bet, temb=temb, x2=x1))
+        cw = ops.conv3x3_gn_mish_wino(x0, wwl, bias, gam, bet, temb=temb, x2=x1)
+        print(f"{name:12s} B={B}: one launch, Winograd form {t_w:6.1f} us   max|diff| {float((a - cw).abs().max()):.2e}", flush=True)
     print(f"{name:12s} B={B}: two launches {t_two:6.1f} us   one launch {t_one:6.1f} us   max|diff| {float((a - b).abs().max()):.2e}", flush=True)
