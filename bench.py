@@ -116,19 +116,26 @@ def time_conv_roofline(device):
 
 def time_hbm_rooflines(device):
     """Secondary rooflines (HBM-bound kernels of the step), live: GroupNorm+Mish(+time shift) on the 32x32 128-channel
-    tensor (8 B per element: one read, one write) and the fused reverse-step update with in-kernel Philox
-    noise (12 B per latent element: read x and eps_hat, write x)."""
+    tensor (8 B per element: one read, one write) -- the kernel on the step's path (statistics from the conv
+    epilogue) and the register-resident one -- and the fused reverse-step update with in-kernel Philox noise (12 B per latent
+    element: read x and eps_hat, write x)."""
     from ddk import ops
     out = []
     B, H, W, C = 32, 32, 32, 128
     x = torch.randn(B, H, W, C, device=device)
     gam, bet = torch.ones(C, device=device), torch.zeros(C, device=device)
     temb = torch.randn(B, C, device=device)
-    sec = graph_kernel_seconds(device, lambda: ops.groupnorm_mish(x, gam, bet, temb=temb))
+    w = torch.randn(C, C, 3, 3, device=device) * (C * 9) ** -0.5
+    raw, part, tiles = ops.conv_with_gn_partials(x, ops.pack_conv_weight(w), torch.zeros(C, device=device), ops.pack_conv_weight_wino(w))
+    sec = graph_kernel_seconds(device, lambda: ops.groupnorm_mish_from_partials(raw, part, tiles, gam, bet, temb=temb))
     nbytes = 8.0 * x.numel()
-    out.append(dict(kernel="gn_mish_resident_kernel<4,1024> GroupNorm(8)+Mish+time shift, 32x32x32x128", bound="hbm",
-                    achieved=nbytes / sec / 1e9, peak=HBM_PEAK_GBPS, unit="GB/s", frac=nbytes / sec / 1e9 / HBM_PEAK_GBPS,
+    out.append(dict(kernel="gn_apply_parts_kernel GroupNorm(8)+Mish+time shift from the conv epilogue's per-tile statistics, 32x32x32x128",
+                    bound="hbm", achieved=nbytes / sec / 1e9, peak=HBM_PEAK_GBPS, unit="GB/s", frac=nbytes / sec / 1e9 / HBM_PEAK_GBPS,
                     traffic=None, launch_us=sec * 1e6, algorithmic_mbytes=nbytes / 1e6))
+    sec = graph_kernel_seconds(device, lambda: ops.groupnorm_mish(x, gam, bet, temb=temb))
+    out.append(dict(kernel="gn_mish_resident_kernel<4,1024> (statistics + apply in one kernel; shapes whose conv splits channel chunks), "
+                           "same tensor", bound="hbm", achieved=nbytes / sec / 1e9, peak=HBM_PEAK_GBPS, unit="GB/s",
+                    frac=nbytes / sec / 1e9 / HBM_PEAK_GBPS, traffic=None, launch_us=sec * 1e6, algorithmic_mbytes=nbytes / 1e6))
     Bz, S, Cz = 32, 32, 8
     xs = torch.randn(Bz, S, S, Cz, device=device)
     eps = torch.randn(Bz, S, S, Cz, device=device)

@@ -173,6 +173,35 @@ def conv(kind, x, w_packed, bias=None, n_out=None, x2=None, resid=None, pre_mish
     return out
 
 
+def conv_with_gn_partials(x, w_packed, bias, w_wino, x2=None, groups=GN_GROUPS):
+    """3x3 conv on the Winograd kernel that also emits GroupNorm partials (ddk_conv_args.gn_partials): -> (raw output, partials
+    [B * tiles_per_image][groups][2] = {mean, M2} per 128-pixel tile, tiles_per_image).  Only where ddk_conv_gn_partials() > 0."""
+    b, h, w_, c0 = x.shape
+    c1 = 0 if x2 is None else x2.shape[-1]
+    n = w_packed.shape[0]
+    lib = L.load()
+    np_ = lib.ddk_conv_gn_partials(b, h, w_, c0 + c1, n, groups)
+    if np_ <= 0:
+        raise L.DDKError(f"conv_with_gn_partials: shape {tuple(x.shape)} (+{c1}) -> {n} cannot emit GroupNorm partials")
+    raw = torch.empty((b, h, w_, n), device=x.device, dtype=torch.float32)
+    part = torch.empty((b * np_, groups, 2), device=x.device, dtype=torch.float32)
+    a = L.ConvArgs(CONV3X3_S1, L.ptr(_f32(x)), L.ptr(x2), c0, c1, L.ptr(w_packed), L.ptr(bias), None, L.ptr(raw), b, h, w_, n, 0, 0, 0,
+                   None, 0, L.ptr(w_wino), L.ptr(part), groups)
+    L.check(lib.ddk_conv_forward(C.byref(a), L.stream()), "conv_forward(gn_partials)")
+    return raw, part, np_
+
+
+def groupnorm_mish_from_partials(x, part, tiles_per_image, gamma, beta, temb=None, addend=None, groups=GN_GROUPS, eps=GN_EPS):
+    """GroupNorm+Mish(+temb)(+addend) of x from the partials of conv_with_gn_partials: one read, one write (ddk_groupnorm_mish_partials)."""
+    b, h, w_, n = x.shape
+    out = torch.empty_like(x)
+    stride = temb.stride(0) if temb is not None else 0
+    L.check(L.load().ddk_groupnorm_mish_partials(L.ptr(_f32(x)), L.ptr(part), tiles_per_image, L.ptr(gamma), L.ptr(beta),
+                                                 temb.data_ptr() if temb is not None else None, stride, L.ptr(addend), L.ptr(out),
+                                                 b, h * w_, n, groups, eps, L.stream()), "groupnorm_mish_partials")
+    return out
+
+
 def conv3x3_groupnorm_mish(x, w_packed, bias, gamma, beta, x2=None, temb=None, addend=None, groups=GN_GROUPS, eps=GN_EPS, w_wino=None):
     """conv3x3(pad 1) -> GroupNorm -> Mish (+temb)(+addend), two launches.  When the conv splits k its partial slabs are summed by
     the GroupNorm kernel's load (ddk_groupnorm_mish_slabs) instead of a separate reduce pass.  w_wino: the Winograd-domain filter
@@ -182,20 +211,10 @@ def conv3x3_groupnorm_mish(x, w_packed, bias, gamma, beta, x2=None, temb=None, a
     n = w_packed.shape[0]
     lib = L.load()
     wino = w_wino is not None and lib.ddk_conv_wino_splits(b, h, w_, c0 + c1, n) > 0
-    np_ = lib.ddk_conv_gn_partials(b, h, w_, c0 + c1, n, groups) if wino else 0
-    if np_ > 0:
+    if wino and lib.ddk_conv_gn_partials(b, h, w_, c0 + c1, n, groups) > 0:
         # one-pass Winograd conv leaves per-tile {mean, M2}; GroupNorm reads the tensor once
-        out = torch.empty((b, h, w_, n), device=x.device, dtype=torch.float32)
-        raw = torch.empty_like(out)
-        part = torch.empty((b * np_, groups, 2), device=x.device, dtype=torch.float32)
-        a = L.ConvArgs(CONV3X3_S1, L.ptr(_f32(x)), L.ptr(x2), c0, c1, L.ptr(w_packed), L.ptr(bias), None, L.ptr(raw), b, h, w_, n, 0, 0, 0,
-                       None, 0, L.ptr(w_wino), L.ptr(part), groups)
-        L.check(lib.ddk_conv_forward(C.byref(a), L.stream()), "conv_forward(gn_partials)")
-        stride = temb.stride(0) if temb is not None else 0
-        L.check(lib.ddk_groupnorm_mish_partials(L.ptr(raw), L.ptr(part), np_, L.ptr(gamma), L.ptr(beta),
-                                                temb.data_ptr() if temb is not None else None, stride, L.ptr(addend), L.ptr(out),
-                                                b, h * w_, n, groups, eps, L.stream()), "groupnorm_mish_partials")
-        return out
+        raw, part, np_ = conv_with_gn_partials(x, w_packed, bias, w_wino, x2=x2, groups=groups)
+        return groupnorm_mish_from_partials(raw, part, np_, gamma, beta, temb=temb, addend=addend, groups=groups, eps=eps)
     splits = lib.ddk_conv_wino_splits(b, h, w_, c0 + c1, n) if wino else lib.ddk_conv_splits(CONV3X3_S1, b, h, w_, c0 + c1, n)
     if splits == 1 or lib.ddk_groupnorm_workspace_bytes(b, h * w_, n, groups) != 0:
         return groupnorm_mish(conv(CONV3X3_S1, x, w_packed, bias, x2=x2, w_wino=w_wino), gamma, beta, temb=temb, addend=addend,
