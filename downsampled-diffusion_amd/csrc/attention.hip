@@ -108,36 +108,12 @@ __global__ __launch_bounds__(256) void linattn_merge_kernel(const float* __restr
     *reinterpret_cast<float4*>(ctx + ((long long)bh * DH + d) * DH + e0) = acc;
 }
 
-// Small maps (H*W <= 64: the 8x8 and 4x4 levels): context AND apply for one (b, head) in one workgroup -- k, v, q of the head
-// (<= 64 x 32 each) sit in LDS, so the separate apply launch (and its re-read of q) disappears.  Same arithmetic as the two
-// kernels above: column max of k, exp, ctx = (exp k)^T v / den, out = q ctx.
-__global__ __launch_bounds__(256) void linattn_small_kernel(const float* __restrict__ qkv, float* __restrict__ ctx, float* __restrict__ out,
-                                                            int HW, int heads) {
-    __shared__ __attribute__((aligned(16))) float ks[64 * DH];
-    __shared__ __attribute__((aligned(16))) float vs[64 * DH];
-    __shared__ float qs[64 * (DH + 1)];
-    __shared__ float cs[DH * (DH + 4)];
-    __shared__ float smax[8 * DH];
-    const int b = blockIdx.x / heads, h = blockIdx.x % heads;
-    const int HC = heads * DH, RS = 3 * HC;
-    const float* base = qkv + (long long)b * HW * RS + h * DH;
+// Core of the small-map kernels (256 threads): k (64 x 32, rows >= HW hold -inf), v (64 x 32), q (64 x 33 pitch) of one
+// (b, head) are in LDS; column max of k, exp, ctx = (exp k)^T v / den, out = q ctx -- same arithmetic as the two kernels above.
+__device__ __forceinline__ void linattn_small_core(float* ks, float* vs, float* qs, float* cs, float* smax, float* __restrict__ ctx,
+                                                   float* __restrict__ out, int b, int h, int HW, int heads) {
+    const int HC = heads * DH;
     const int tid = threadIdx.x;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {                       // 64 rows x 8 float4 per operand
-        const int idx4 = tid + j * 256;
-        const int row = idx4 >> 3, c = (idx4 & 7) * 4;
-        float4 qv = make_float4(0.f, 0.f, 0.f, 0.f), kv = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY), vv = qv;
-        if (row < HW) {
-            const float* r = base + (long long)row * RS + c;
-            qv = *reinterpret_cast<const float4*>(r);
-            kv = *reinterpret_cast<const float4*>(r + HC);
-            vv = *reinterpret_cast<const float4*>(r + 2 * HC);
-        }
-        *reinterpret_cast<float4*>(ks + row * DH + c) = kv;
-        *reinterpret_cast<float4*>(vs + row * DH + c) = vv;
-        qs[row * (DH + 1) + c] = qv.x; qs[row * (DH + 1) + c + 1] = qv.y; qs[row * (DH + 1) + c + 2] = qv.z; qs[row * (DH + 1) + c + 3] = qv.w;
-    }
-    __syncthreads();
     {   // max_n k[n][d]  (rows >= HW hold -inf)
         const int d = tid & 31, ng = tid >> 5;
         float m = -INFINITY;
@@ -189,6 +165,197 @@ __global__ __launch_bounds__(256) void linattn_small_kernel(const float* __restr
             *reinterpret_cast<float4*>(op) = make_float4(o[0], o[1], o[2], o[3]);
             *reinterpret_cast<float4*>(op + 4) = make_float4(o[4], o[5], o[6], o[7]);
         }
+    }
+}
+
+// Small maps (H*W <= 64: the 8x8 and 4x4 levels): context AND apply for one (b, head) in one workgroup -- k, v, q of the head
+// (<= 64 x 32 each) sit in LDS, so the separate apply launch (and its re-read of q) disappears.
+__global__ __launch_bounds__(256) void linattn_small_kernel(const float* __restrict__ qkv, float* __restrict__ ctx, float* __restrict__ out,
+                                                            int HW, int heads) {
+    __shared__ __attribute__((aligned(16))) float ks[64 * DH];
+    __shared__ __attribute__((aligned(16))) float vs[64 * DH];
+    __shared__ float qs[64 * (DH + 1)];
+    __shared__ float cs[DH * (DH + 4)];
+    __shared__ float smax[8 * DH];
+    const int b = blockIdx.x / heads, h = blockIdx.x % heads;
+    const int HC = heads * DH, RS = 3 * HC;
+    const float* base = qkv + (long long)b * HW * RS + h * DH;
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {                       // 64 rows x 8 float4 per operand
+        const int idx4 = tid + j * 256;
+        const int row = idx4 >> 3, c = (idx4 & 7) * 4;
+        float4 qv = make_float4(0.f, 0.f, 0.f, 0.f), kv = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY), vv = qv;
+        if (row < HW) {
+            const float* r = base + (long long)row * RS + c;
+            qv = *reinterpret_cast<const float4*>(r);
+            kv = *reinterpret_cast<const float4*>(r + HC);
+            vv = *reinterpret_cast<const float4*>(r + 2 * HC);
+        }
+        *reinterpret_cast<float4*>(ks + row * DH + c) = kv;
+        *reinterpret_cast<float4*>(vs + row * DH + c) = vv;
+        qs[row * (DH + 1) + c] = qv.x; qs[row * (DH + 1) + c + 1] = qv.y; qs[row * (DH + 1) + c + 2] = qv.z; qs[row * (DH + 1) + c + 3] = qv.w;
+    }
+    __syncthreads();
+    linattn_small_core(ks, vs, qs, cs, smax, ctx, out, b, h, HW, heads);
+}
+
+// The same with the projection inside: to_qkv (1x1 conv with the channel LayerNorm folded in, blocks.py:57-60, 123) for ONE head
+// of ONE image is a [HW x C] x [C x 96] product -- small enough to run in the workgroup that consumes it, so the small maps need
+// no to_qkv launch and no qkv tensor.  The image (<= 64 x C) sits in LDS; per-pixel mean and 1/(std + eps) come from it; the 4
+// waves split the channel chunks (v_mfma_f32_16x16x4_f32, weights in operand order streamed L2 -> registers: qkv_operand_pack_kernel)
+// and meet in LDS; r (W o g) x - r mean (W g) + W b lands in the k / v / q arrays of the core.
+typedef float f32x4_att __attribute__((ext_vector_type(4)));
+constexpr int QP_PITCH = 100;                           // partial-sum row pitch: 96 columns + 4
+
+__host__ __device__ static inline size_t small_qkv_lds_bytes(int MB, int C) {
+    const size_t xs = (size_t)16 * MB * (C + 4), part = (size_t)4 * 16 * MB * QP_PITCH;
+    const size_t core = 64 * DH * 2 + 64 * (DH + 1) + DH * (DH + 4) + 8 * DH + 128 + 192;   // ks, vs, qs, cs, smax, rowstat, c1 | c2
+    return ((xs > part ? xs : part) + core) * 4;
+}
+
+template <int MB>
+__global__ __launch_bounds__(256) void linattn_small_qkv_kernel(const float* __restrict__ x, const float* __restrict__ wop,
+                                                                const float* __restrict__ c1, const float* __restrict__ c2, float ln_eps,
+                                                                float* __restrict__ ctx, float* __restrict__ out, int HW, int C, int heads) {
+    extern __shared__ __align__(16) float sm[];
+    constexpr int ROWS = 16 * MB;
+    const int pitch = C + 4, nch = C >> 5;
+    const size_t big = (size_t)ROWS * pitch > (size_t)4 * ROWS * QP_PITCH ? (size_t)ROWS * pitch : (size_t)4 * ROWS * QP_PITCH;
+    float* xs = sm;                                     // the image; later the 4 waves' partial sums
+    float* ks = sm + big;
+    float* vs = ks + 64 * DH;
+    float* qs = vs + 64 * DH;
+    float* cs = qs + 64 * (DH + 1);
+    float* smax = cs + DH * (DH + 4);
+    float* rowstat = smax + 8 * DH;                     // [64][2]: r, r * mean
+    float* cfold = rowstat + 128;                       // [96] W g and [96] W b of this head's q | k | v columns
+    const int b = blockIdx.x / heads, h = blockIdx.x % heads;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m = lane & 15, kq = lane >> 4;
+    const int HC = heads * DH;
+
+    // weights of this wave's first chunk while the image loads
+    const float* wl = wop + (size_t)h * nch * 3072 + lane * 4;          // a chunk = 6 n blocks x 512 floats
+    float4 bA[6][2], bB[6][2];
+    auto load_b = [&](int chunk, float4 (&bq)[6][2]) {
+        chunk = chunk < nch ? chunk : nch - 1;
+        const float* wp = wl + (size_t)chunk * 3072;
+#pragma unroll
+        for (int nb = 0; nb < 6; ++nb) {
+            bq[nb][0] = *reinterpret_cast<const float4*>(wp + nb * 512);
+            bq[nb][1] = *reinterpret_cast<const float4*>(wp + nb * 512 + 256);
+        }
+    };
+    load_b(wave, bA);
+    load_b(wave + 4, bB);
+    if (tid < 192) {                                    // the fold vectors of this head's 96 columns: one global load each, up front
+        const int n = tid % 96;
+        const int col = (n >> 5) * HC + h * DH + (n & 31);
+        cfold[tid] = tid < 96 ? c1[col] : c2[col];
+    }
+    {
+        const int q4 = C >> 2;
+        for (int i = tid; i < ROWS * q4; i += 256) {
+            const int row = i / q4, c = (i - row * q4) << 2;
+            const float4 v = row < HW ? *reinterpret_cast<const float4*>(x + ((long long)b * HW + row) * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4*>(xs + row * pitch + c) = v;
+        }
+    }
+    __syncthreads();
+    {   // LayerNorm statistics of every pixel row: TPR threads per row (biased variance, eps added to the std: blocks.py:57-60)
+        constexpr int TPR = 256 / ROWS;
+        const int row = tid / TPR, sub = tid % TPR;
+        float s1 = 0.f, s2 = 0.f;
+        for (int c = sub * 4; c < C; c += TPR * 4) {
+            const float4 v = *reinterpret_cast<const float4*>(xs + row * pitch + c);
+            s1 += (v.x + v.y) + (v.z + v.w);
+            s2 += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+        }
+#pragma unroll
+        for (int o = 1; o < TPR; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+        if (sub == 0) {
+            const float inv_c = 1.0f / (float)C;
+            const float mean = s1 * inv_c;
+            const float var = fmaxf(s2 * inv_c - mean * mean, 0.f);
+            const float r = 1.0f / (sqrtf(var) + ln_eps);
+            rowstat[2 * row] = r;
+            rowstat[2 * row + 1] = r * mean;
+        }
+    }
+
+    // ---- [ROWS x C] x [C x 96]: wave w takes chunks w, w + 4, ...
+    f32x4_att acc[MB][6];
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int nb = 0; nb < 6; ++nb) acc[i][nb] = f32x4_att{0.f, 0.f, 0.f, 0.f};
+    auto compute = [&](int chunk, const float4 (&bq)[6][2]) {
+        float4 a[MB][2];
+#pragma unroll
+        for (int i = 0; i < MB; ++i) {
+            const float* ap = xs + (i * 16 + m) * pitch + (chunk << 5) + kq * 8;
+            a[i][0] = *reinterpret_cast<const float4*>(ap);
+            a[i][1] = *reinterpret_cast<const float4*>(ap + 4);
+        }
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk)
+#pragma unroll
+            for (int i = 0; i < MB; ++i) {
+                const float av = reinterpret_cast<const float*>(&a[i][0])[kk];
+#pragma unroll
+                for (int nb = 0; nb < 6; ++nb)
+                    acc[i][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, reinterpret_cast<const float*>(&bq[nb][0])[kk], acc[i][nb], 0, 0, 0);
+            }
+    };
+    for (int c = wave; c < nch; c += 8) {
+        compute(c, bA);
+        load_b(c + 8, bA);
+        if (c + 4 < nch) compute(c + 4, bB);
+        load_b(c + 12, bB);
+    }
+    __syncthreads();                                    // image consumed, rowstat written
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int nb = 0; nb < 6; ++nb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) xs[((wave * ROWS) + i * 16 + kq * 4 + r) * QP_PITCH + nb * 16 + m] = acc[i][nb][r];
+    __syncthreads();
+    // ---- sum of the 4 partials (fixed order) + folded LayerNorm -> q | k | v of the core (rows >= HW: k = -inf, q = v = 0)
+    for (int e = tid; e < 64 * 96; e += 256) {
+        const int row = e / 96, n = e - row * 96;
+        const int sel = n >> 5, d = n & 31;             // 0: q, 1: k, 2: v
+        float v = sel == 1 ? -INFINITY : 0.f;
+        if (row < HW) {
+            float s = xs[row * QP_PITCH + n];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) s += xs[(w * ROWS + row) * QP_PITCH + n];
+            v = rowstat[2 * row] * s - rowstat[2 * row + 1] * cfold[n] + cfold[96 + n];
+        }
+        if (sel == 0) qs[row * (DH + 1) + d] = v;
+        else if (sel == 1) ks[row * DH + d] = v;
+        else vs[row * DH + d] = v;
+    }
+    __syncthreads();
+    linattn_small_core(ks, vs, qs, cs, smax, ctx, out, b, h, HW, heads);
+}
+
+// wop[head][chunk][n block 0..5][k half][lane][j] = lnw[o][i]: o = (nb / 2) * HC + head * 32 + (nb % 2) * 16 + lane % 16 (q, k, v
+// columns of the head), i = 32 chunk + 8 (lane / 16) + 4 half + j; lnw = [3 HC][cp] (the LayerNorm-folded to_qkv weight)
+__global__ __launch_bounds__(256) void qkv_operand_pack_kernel(const float* __restrict__ lnw, float* __restrict__ wop, int heads, int cp,
+                                                               long long total) {
+    const int nch = cp >> 5, HC = heads * DH;
+    for (long long idx = blockIdx.x * 256LL + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int j = (int)(idx & 3), lane = (int)((idx >> 2) & 63), half = (int)((idx >> 8) & 1);
+        long long r = idx >> 9;
+        const int nb = (int)(r % 6); r /= 6;
+        const int chunk = (int)(r % nch);
+        const int head = (int)(r / nch);
+        const int o = (nb >> 1) * HC + head * DH + (nb & 1) * 16 + (lane & 15);
+        const int i = chunk * 32 + (lane >> 4) * 8 + half * 4 + j;
+        wop[idx] = lnw[(long long)o * cp + i];
     }
 }
 
@@ -289,6 +456,38 @@ int linattn_fused_small(const float* qkv, float* ctx, float* out, int B, int HW,
     return check_launch("linattn_small_kernel");
 }
 
+bool linattn_small_qkv_ok(int HW, int C) { return HW > 0 && HW <= 64 && C % 32 == 0 && C >= 32 && small_qkv_lds_bytes(HW <= 16 ? 1 : 4, C) <= 160 * 1024; }
+
+int linattn_small_qkv_init_device() {
+    DDK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(linattn_small_qkv_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    DDK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(linattn_small_qkv_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    return DDK_OK;
+}
+
+int qkv_operand_pack(const float* lnw, float* wop, int heads, int cp, hipStream_t st) {
+    DDK_REQUIRE(lnw && wop && heads > 0 && cp > 0 && cp % 32 == 0, "qkv_operand_pack: arguments");
+    const long long total = (long long)3 * heads * DH * cp;
+    const long long blocks = ceil_div(total, 256);
+    hipLaunchKernelGGL(qkv_operand_pack_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, st, lnw, wop, heads, cp, total);
+    return check_launch("qkv_operand_pack_kernel");
+}
+
+// to_qkv (LayerNorm folded) + context + apply of the small maps in one launch; x [B][HW][C], wop from qkv_operand_pack
+int linattn_small_qkv(const float* x, const float* wop, const float* c1, const float* c2, float ln_eps, float* ctx, float* out, int B, int HW,
+                      int C, int heads, hipStream_t st) {
+    DDK_REQUIRE(x && wop && c1 && c2 && ctx && out && B > 0 && heads > 0, "linattn_small_qkv: arguments");
+    DDK_REQUIRE(linattn_small_qkv_ok(HW, C), "linattn_small_qkv: needs H*W <= 64 and C % 32 == 0 (LDS budget)");
+    DDK_REQUIRE(aligned16(x) && aligned16(wop) && aligned16(ctx) && aligned16(out), "linattn_small_qkv: alignment");
+    DDK_TRY(ensure_device_init());
+    if (HW <= 16)
+        hipLaunchKernelGGL(linattn_small_qkv_kernel<1>, dim3(B * heads), dim3(256), small_qkv_lds_bytes(1, C), st, x, wop, c1, c2, ln_eps, ctx, out,
+                           HW, C, heads);
+    else
+        hipLaunchKernelGGL(linattn_small_qkv_kernel<4>, dim3(B * heads), dim3(256), small_qkv_lds_bytes(4, C), st, x, wop, c1, c2, ln_eps, ctx, out,
+                           HW, C, heads);
+    return check_launch("linattn_small_qkv_kernel");
+}
+
 int linattn_apply(const float* qkv, const float* ctx, float* out, int B, int HW, int heads, hipStream_t st) {
     DDK_REQUIRE(qkv && ctx && out && B > 0 && HW > 0, "linattn_apply: arguments");
     DDK_REQUIRE(heads >= 1 && heads <= 8, "linattn_apply: heads must be in 1..8");
@@ -308,6 +507,13 @@ int ddk_linattn_context(const float* qkv, float* ctx, int B, int HW, int heads, 
 }
 int ddk_linattn_fused_small(const float* qkv, float* ctx, float* out, int B, int HW, int heads, ddk_stream_t s) {
     return ddk::linattn_fused_small(qkv, ctx, out, B, HW, heads, ddk::as_stream(s));
+}
+int ddk_pack_qkv_operand(const float* folded_w, float* dst, int heads, int c_pad, ddk_stream_t s) {
+    return ddk::qkv_operand_pack(folded_w, dst, heads, c_pad, ddk::as_stream(s));
+}
+int ddk_linattn_small_from_x(const float* x, const float* w_operand, const float* c1, const float* c2, float ln_eps, float* ctx, float* out,
+                             int B, int HW, int C, int heads, ddk_stream_t s) {
+    return ddk::linattn_small_qkv(x, w_operand, c1, c2, ln_eps, ctx, out, B, HW, C, heads, ddk::as_stream(s));
 }
 int ddk_linattn_apply(const float* qkv, const float* ctx, float* out, int B, int HW, int heads, ddk_stream_t s) {
     return ddk::linattn_apply(qkv, ctx, out, B, HW, heads, ddk::as_stream(s));

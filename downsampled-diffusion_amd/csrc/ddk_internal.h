@@ -168,6 +168,11 @@ size_t linattn_context_workspace_bytes(int B, int HW, int heads);
 int linattn_context(const float* qkv, float* ctx, int B, int HW, int heads, void* workspace, size_t workspace_bytes, hipStream_t st);
 int linattn_apply(const float* qkv, const float* ctx, float* out, int B, int HW, int heads, hipStream_t st);
 int linattn_fused_small(const float* qkv, float* ctx, float* out, int B, int HW, int heads, hipStream_t st);
+bool linattn_small_qkv_ok(int HW, int C);
+int linattn_small_qkv_init_device();
+int qkv_operand_pack(const float* lnw, float* wop, int heads, int cp, hipStream_t st);
+int linattn_small_qkv(const float* x, const float* wop, const float* c1, const float* c2, float ln_eps, float* ctx, float* out, int B, int HW,
+                      int C, int heads, hipStream_t st);
 // time_embed.hip
 int time_mlp(const int64_t* t, const float* freqs, const float* w1t, const float* b1, const float* w2t, const float* b2,
              float* act, float* raw, int B, int dim, hipStream_t st);

@@ -549,6 +549,28 @@ def chan_layernorm_bwd(x, g, dy, eps=LN_EPS):
     return dx, dg, db
 
 
+def linattn_small_from_x(x, w_qkv, ln_g, ln_b, heads=4, eps=LN_EPS):
+    """PreNorm(LinearAttention) up to (not including) to_out on a small map (H*W <= 64) in ONE launch: x [B,H,W,C]; w_qkv the
+    canonical to_qkv weight [3*heads*32, C(,1,1)]; ln_g / ln_b the channel LayerNorm's g, b (blocks.py:57-60, 123-134).
+    -> (out [B,H,W,heads*32], ctx [B,heads,32,32]).  The folded weights are derived here (the UNet plan caches them)."""
+    b, h, w, c = x.shape
+    wq = w_qkv.reshape(w_qkv.shape[0], -1).to(torch.float32)
+    g, bb = ln_g.reshape(-1).to(torch.float32), ln_b.reshape(-1).to(torch.float32)
+    cp = pad32(c)
+    lnw = torch.zeros((wq.shape[0], cp), device=x.device, dtype=torch.float32)
+    lnw[:, :c] = wq * g[None, :]
+    c1 = (wq * g[None, :]).sum(dim=1).contiguous()
+    c2 = (wq * bb[None, :]).sum(dim=1).contiguous()
+    wop = torch.empty_like(lnw)
+    lib = L.load()
+    L.check(lib.ddk_pack_qkv_operand(L.ptr(lnw), L.ptr(wop), heads, cp, L.stream()), "pack_qkv_operand")
+    ctx = torch.empty((b, heads, 32, 32), device=x.device, dtype=torch.float32)
+    out = torch.empty((b, h, w, heads * 32), device=x.device, dtype=torch.float32)
+    L.check(lib.ddk_linattn_small_from_x(L.ptr(_f32(x)), L.ptr(wop), L.ptr(c1), L.ptr(c2), eps, L.ptr(ctx), L.ptr(out), b, h * w, c, heads,
+                                         L.stream()), "linattn_small_from_x")
+    return out, ctx
+
+
 def linattn_train(qkv, heads=4):
     out, ctx = linattn(qkv, heads)
     b, h, w, _ = qkv.shape

@@ -163,6 +163,12 @@ int ddk_linattn_context(const float* qkv, float* ctx, int B, int HW, int heads, 
 int ddk_linattn_fused_small(const float* qkv, float* ctx, float* out, int B, int HW, int heads, ddk_stream_t s);
 /* out[b][n][h*32+e] = sum_d ctx[b][h][d][e] * q[b][n][h*32+d]. */
 int ddk_linattn_apply(const float* qkv, const float* ctx, float* out, int B, int HW, int heads, ddk_stream_t s);
+/* Small maps (H*W <= 64): to_qkv with the channel LayerNorm folded in (blocks.py:57-60, 123) + context + apply for one (image,
+ * head) per workgroup -- no qkv tensor.  x [B][HW][C]; w_operand = ddk_pack_qkv_operand(folded_w [3*heads*32][c_pad] = W o g);
+ * c1 = W g, c2 = W b per output column; ln_eps is added to the std.  out [B][HW][heads*32], ctx [B][heads][32][32]. */
+int ddk_pack_qkv_operand(const float* folded_w, float* dst, int heads, int c_pad, ddk_stream_t s);
+int ddk_linattn_small_from_x(const float* x, const float* w_operand, const float* c1, const float* c2, float ln_eps, float* ctx,
+                             float* out, int B, int HW, int C, int heads, ddk_stream_t s);
 
 /* ------------------------------------------------------------------ time embedding (blocks.py:22-29, unet.py:30-35, blocks.py:92-95) */
 /* act[b][:] = Mish(Linear2(Mish(Linear1(sincos(t[b] * freqs)))))  -- the vector every ResnetBlock's

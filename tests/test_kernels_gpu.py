@@ -363,6 +363,29 @@ def test_linattn(ops, B, H, W):
     assert rel_err(to_nchw(out.cpu()), out_ref) < 1e-5
 
 
+@pytest.mark.parametrize("B,H,W,C", [(32, 4, 4, 256), (5, 8, 8, 256), (3, 8, 8, 128), (2, 2, 2, 64), (2, 6, 6, 96), (1, 8, 8, 384)])
+def test_linattn_small_maps_projection_inside(ops, B, H, W, C):
+    """linattn_small_qkv_kernel: channel LayerNorm -> to_qkv -> softmax_n(k) -> ctx -> out for one (image, head) per workgroup
+    (blocks.py:57-60, 123-134), against torch; and against the two-launch path (LN-folded to_qkv conv, then the core)."""
+    x = rnd(B, C, H, W, seed=62, scale=1.3) + 0.4
+    g, b = 1 + rnd(C, seed=63, scale=0.2), rnd(C, seed=64, scale=0.2)
+    wq = rnd(384, C, seed=65, scale=C ** -0.5)
+    mean = x.mean(dim=1, keepdim=True)
+    std = x.var(dim=1, unbiased=False, keepdim=True).sqrt()
+    xn = (x - mean) / (std + 1e-5) * g[None, :, None, None] + b[None, :, None, None]
+    qkv = F.conv2d(xn, wq[:, :, None, None])
+    q, k, v = qkv.reshape(B, 3, 4, 32, H * W).unbind(1)
+    ctx_ref = torch.einsum("bhdn,bhen->bhde", k.softmax(dim=-1), v)
+    out_ref = torch.einsum("bhde,bhdn->bhen", ctx_ref, q).reshape(B, 128, H, W)
+    out, ctx = ops.linattn_small_from_x(to_nhwc(x).to(DEV), wq.to(DEV), g.to(DEV), b.to(DEV))
+    assert rel_err(ctx.cpu(), ctx_ref) < 2e-5
+    assert rel_err(to_nchw(out.cpu()), out_ref) < 2e-5
+    out2, _ = ops.linattn_small_from_x(to_nhwc(x).to(DEV), wq.to(DEV), g.to(DEV), b.to(DEV))
+    assert torch.equal(out, out2)
+    two, _ = ops.linattn(to_nhwc(qkv).to(DEV), 4)
+    assert rel_err(out.cpu(), two.cpu()) < 2e-5
+
+
 def test_linattn_softmax_extremes(ops):
     """a dominant key (softmax ~ one-hot) and large negative logits must not overflow / lose the max"""
     B, H, W = 1, 8, 8
