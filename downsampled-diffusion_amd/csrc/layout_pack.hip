@@ -119,10 +119,11 @@ __global__ __launch_bounds__(256) void conv1x1_n8_kernel(const float* __restrict
     constexpr int PPW = 64 / LPP;
     const int lane = threadIdx.x & 63, sub = lane % LPP, pl = lane / LPP;
     float4 ww[8][VPL];
-    float bb[8];
+    const bool h2 = sub & (LPP / 2), h4 = sub & (LPP / 4), h8 = sub & (LPP / 8);
+    const int my_co = (h2 ? 4 : 0) + (h4 ? 2 : 0) + (h8 ? 1 : 0);      // the output channel this lane ends up holding (see below)
+    const float my_bias = (bias && my_co < n_out) ? bias[my_co] : 0.f;
 #pragma unroll
     for (int co = 0; co < 8; ++co) {
-        bb[co] = (bias && co < n_out) ? bias[co] : 0.f;
 #pragma unroll
         for (int i = 0; i < VPL; ++i)
             ww[co][i] = co < n_out ? *reinterpret_cast<const float4*>(w + (long long)co * C + (sub + i * LPP) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -141,16 +142,28 @@ __global__ __launch_bounds__(256) void conv1x1_n8_kernel(const float* __restrict
             float t = 0.f;
 #pragma unroll
             for (int i = 0; i < VPL; ++i) t += (v[i].x * ww[co][i].x + v[i].y * ww[co][i].y) + (v[i].z * ww[co][i].z + v[i].w * ww[co][i].w);
-#pragma unroll
-            for (int o = LPP / 2; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
-            s[co] = t + bb[co];
+            s[co] = t;
         }
-        if (ok && sub < n_out) {           // lane `sub` of the pixel's group writes output channel `sub`: n_out consecutive floats
-            float r = s[0];
+        // Reduce the 8 partial dot products over the pixel's LPP lanes with 4 + 2 + 1 + (log2(LPP) - 3) shuffles instead of
+        // 8 log2(LPP): each of the first three butterfly steps also halves the number of outputs a lane carries (the upper half
+        // of the lane group keeps the upper half of the outputs), so afterwards lane l holds output
+        // co = 4 bit(LPP/2) + 2 bit(LPP/4) + bit(LPP/8) of its lane index, summed over 8 lanes; the remaining steps are plain sums.
+        float t4[4];
 #pragma unroll
-            for (int co = 1; co < 8; ++co) r = sub == co ? s[co] : r;
-            out[pix * n_out + sub] = r;
+        for (int i = 0; i < 4; ++i) {
+            const float keep = h2 ? s[4 + i] : s[i], send = h2 ? s[i] : s[4 + i];
+            t4[i] = keep + __shfl_xor(send, LPP / 2, 64);
         }
+        float t2[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const float keep = h4 ? t4[2 + i] : t4[i], send = h4 ? t4[i] : t4[2 + i];
+            t2[i] = keep + __shfl_xor(send, LPP / 4, 64);
+        }
+        float r = (h8 ? t2[1] : t2[0]) + __shfl_xor(h8 ? t2[0] : t2[1], LPP / 8, 64);
+#pragma unroll
+        for (int o = LPP / 16; o > 0; o >>= 1) r += __shfl_xor(r, o, 64);
+        if (ok && (sub & (LPP / 8 - 1)) == 0 && my_co < n_out) out[pix * n_out + my_co] = r + my_bias;
     }
 }
 

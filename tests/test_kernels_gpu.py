@@ -417,7 +417,7 @@ def test_time_embedding(ops, dim):
 
 
 def test_conv1x1_small_n(ops):
-    for C, n_out in ((128, 8), (128, 3), (32, 1), (64, 3), (64, 8)):
+    for C, n_out in ((128, 8), (128, 3), (32, 1), (64, 3), (64, 8), (256, 8), (256, 5), (128, 1)):
         x = rnd(2, C, 9, 7, seed=80)
         w, b = rnd(n_out, C, 1, 1, seed=81, scale=C ** -0.5), rnd(n_out, seed=82)
         out = ops.conv1x1_small_n(to_nhwc(x).to(DEV), w.to(DEV), b.to(DEV))
