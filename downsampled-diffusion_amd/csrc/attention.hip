@@ -108,8 +108,9 @@ __global__ __launch_bounds__(256) void linattn_merge_kernel(const float* __restr
     *reinterpret_cast<float4*>(ctx + ((long long)bh * DH + d) * DH + e0) = acc;
 }
 
-// Core of the small-map kernels (256 threads): k (64 x 32, rows >= HW hold -inf), v (64 x 32), q (64 x 33 pitch) of one
+// Core of the small-map kernels (256 threads): k (ROWS x 32, rows >= HW hold -inf), v (ROWS x 32), q (ROWS x 33 pitch) of one
 // (b, head) are in LDS; column max of k, exp, ctx = (exp k)^T v / den, out = q ctx -- same arithmetic as the two kernels above.
+template <int ROWS>
 __device__ __forceinline__ void linattn_small_core(float* ks, float* vs, float* qs, float* cs, float* smax, float* __restrict__ ctx,
                                                    float* __restrict__ out, int b, int h, int HW, int heads) {
     const int HC = heads * DH;
@@ -117,7 +118,7 @@ __device__ __forceinline__ void linattn_small_core(float* ks, float* vs, float* 
     {   // max_n k[n][d]  (rows >= HW hold -inf)
         const int d = tid & 31, ng = tid >> 5;
         float m = -INFINITY;
-        for (int n = ng; n < 64; n += 8) m = fmaxf(m, ks[n * DH + d]);
+        for (int n = ng; n < ROWS; n += 8) m = fmaxf(m, ks[n * DH + d]);
         smax[ng * DH + d] = m;
         __syncthreads();
         if (tid < DH) {
@@ -128,8 +129,8 @@ __device__ __forceinline__ void linattn_small_core(float* ks, float* vs, float* 
         }
         __syncthreads();
     }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {                       // exp(k - max) in place; padding rows -> exp(-inf) = 0
+#pragma unroll 8
+    for (int j = 0; j < ROWS / 8; ++j) {                // exp(k - max) in place; padding rows -> exp(-inf) = 0
         const int i = tid + j * 256;
         ks[i] = expf(ks[i] - smax[i & 31]);
     }
@@ -139,7 +140,7 @@ __device__ __forceinline__ void linattn_small_core(float* ks, float* vs, float* 
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         float den = 0.f;
 #pragma unroll 8
-        for (int n = 0; n < 64; ++n) {
+        for (int n = 0; n < ROWS; ++n) {
             const float kd = ks[n * DH + d];
             const float4 v4 = *reinterpret_cast<const float4*>(vs + n * DH + e0);
             acc.x += kd * v4.x; acc.y += kd * v4.y; acc.z += kd * v4.z; acc.w += kd * v4.w;
@@ -151,8 +152,9 @@ __device__ __forceinline__ void linattn_small_core(float* ks, float* vs, float* 
         cs[d * (DH + 4) + e0] = acc.x; cs[d * (DH + 4) + e0 + 1] = acc.y; cs[d * (DH + 4) + e0 + 2] = acc.z; cs[d * (DH + 4) + e0 + 3] = acc.w;
     }
     __syncthreads();
-    {   // out[n][e] = sum_d ctx[d][e] q[n][d]: thread = (pixel n, 8 consecutive e)
-        const int n = tid >> 2, e0 = (tid & 3) * 8;
+    // out[n][e] = sum_d ctx[d][e] q[n][d]: thread = (pixel n, 8 consecutive e), 64 pixels per pass
+    for (int n = tid >> 2; n < ROWS; n += 64) {
+        const int e0 = (tid & 3) * 8;
         float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll 8
         for (int d = 0; d < DH; ++d) {
@@ -168,21 +170,24 @@ __device__ __forceinline__ void linattn_small_core(float* ks, float* vs, float* 
     }
 }
 
-// Small maps (H*W <= 64: the 8x8 and 4x4 levels): context AND apply for one (b, head) in one workgroup -- k, v, q of the head
-// (<= 64 x 32 each) sit in LDS, so the separate apply launch (and its re-read of q) disappears.
+// Small maps: context AND apply for one (b, head) in one workgroup -- k, v, q of the head (ROWS x 32 each) sit in LDS, so the
+// separate merge and apply launches (and the re-read of q) disappear.  ROWS = 64 for the 8x8 and 4x4 levels (30 KB of LDS),
+// 256 for the 16x16 level (100 KB).
+template <int ROWS>
 __global__ __launch_bounds__(256) void linattn_small_kernel(const float* __restrict__ qkv, float* __restrict__ ctx, float* __restrict__ out,
                                                             int HW, int heads) {
-    __shared__ __attribute__((aligned(16))) float ks[64 * DH];
-    __shared__ __attribute__((aligned(16))) float vs[64 * DH];
-    __shared__ float qs[64 * (DH + 1)];
-    __shared__ float cs[DH * (DH + 4)];
-    __shared__ float smax[8 * DH];
+    extern __shared__ __align__(16) float lsm[];
+    float* ks = lsm;
+    float* vs = ks + ROWS * DH;
+    float* qs = vs + ROWS * DH;
+    float* cs = qs + ROWS * (DH + 1);
+    float* smax = cs + DH * (DH + 4);
     const int b = blockIdx.x / heads, h = blockIdx.x % heads;
     const int HC = heads * DH, RS = 3 * HC;
     const float* base = qkv + (long long)b * HW * RS + h * DH;
     const int tid = threadIdx.x;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {                       // 64 rows x 8 float4 per operand
+    for (int j = 0; j < ROWS / 32; ++j) {               // ROWS rows x 8 float4 per operand
         const int idx4 = tid + j * 256;
         const int row = idx4 >> 3, c = (idx4 & 7) * 4;
         float4 qv = make_float4(0.f, 0.f, 0.f, 0.f), kv = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY), vv = qv;
@@ -197,8 +202,10 @@ __global__ __launch_bounds__(256) void linattn_small_kernel(const float* __restr
         qs[row * (DH + 1) + c] = qv.x; qs[row * (DH + 1) + c + 1] = qv.y; qs[row * (DH + 1) + c + 2] = qv.z; qs[row * (DH + 1) + c + 3] = qv.w;
     }
     __syncthreads();
-    linattn_small_core(ks, vs, qs, cs, smax, ctx, out, b, h, HW, heads);
+    linattn_small_core<ROWS>(ks, vs, qs, cs, smax, ctx, out, b, h, HW, heads);
 }
+
+static size_t small_lds_bytes(int rows) { return ((size_t)rows * DH * 2 + (size_t)rows * (DH + 1) + DH * (DH + 4) + 8 * DH) * 4; }
 
 // The same with the projection inside: to_qkv (1x1 conv with the channel LayerNorm folded in, blocks.py:57-60, 123) for ONE head
 // of ONE image is a [HW x C] x [C x 96] product -- small enough to run in the workgroup that consumes it, so the small maps need
@@ -339,7 +346,7 @@ __global__ __launch_bounds__(256) void linattn_small_qkv_kernel(const float* __r
         else vs[row * DH + d] = v;
     }
     __syncthreads();
-    linattn_small_core(ks, vs, qs, cs, smax, ctx, out, b, h, HW, heads);
+    linattn_small_core<64>(ks, vs, qs, cs, smax, ctx, out, b, h, HW, heads);
 }
 
 // wop[head][chunk][n block 0..5][k half][lane][j] = lnw[o][i]: o = (nb / 2) * HC + head * 32 + (nb % 2) * 16 + lane % 16 (q, k, v
@@ -448,17 +455,22 @@ int linattn_context(const float* qkv, float* ctx, int B, int HW, int heads, void
     return DDK_OK;
 }
 
-// context + apply in one launch when the map is small enough for one workgroup per (b, head); returns 0 and does nothing else
+// context + apply in one launch when the map is small enough (<= 256 pixels) for one workgroup per (b, head)
 int linattn_fused_small(const float* qkv, float* ctx, float* out, int B, int HW, int heads, hipStream_t st) {
-    DDK_REQUIRE(qkv && ctx && out && B > 0 && HW > 0 && HW <= 64 && heads > 0, "linattn_fused_small: arguments (HW <= 64)");
+    DDK_REQUIRE(qkv && ctx && out && B > 0 && HW > 0 && HW <= 256 && heads > 0, "linattn_fused_small: arguments (HW <= 256)");
     DDK_REQUIRE(aligned16(qkv) && aligned16(ctx) && aligned16(out), "linattn_fused_small: alignment");
-    hipLaunchKernelGGL(linattn_small_kernel, dim3(B * heads), dim3(256), 0, st, qkv, ctx, out, HW, heads);
+    DDK_TRY(ensure_device_init());
+    if (HW <= 64)
+        hipLaunchKernelGGL(linattn_small_kernel<64>, dim3(B * heads), dim3(256), small_lds_bytes(64), st, qkv, ctx, out, HW, heads);
+    else
+        hipLaunchKernelGGL(linattn_small_kernel<256>, dim3(B * heads), dim3(256), small_lds_bytes(256), st, qkv, ctx, out, HW, heads);
     return check_launch("linattn_small_kernel");
 }
 
 bool linattn_small_qkv_ok(int HW, int C) { return HW > 0 && HW <= 64 && C % 32 == 0 && C >= 32 && small_qkv_lds_bytes(HW <= 16 ? 1 : 4, C) <= 160 * 1024; }
 
 int linattn_small_qkv_init_device() {
+    DDK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(linattn_small_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     DDK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(linattn_small_qkv_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     DDK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(linattn_small_qkv_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     return DDK_OK;

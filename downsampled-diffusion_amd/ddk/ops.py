@@ -333,13 +333,14 @@ def fix_samples(x):
 
 
 # ------------------------------------------------------------------ linear attention core
-def linattn(qkv, heads=4):
-    """qkv [B,H,W,3*heads*32] -> attention output [B,H,W,heads*32] (before to_out)."""
+def linattn(qkv, heads=4, fused_up_to=64):
+    """qkv [B,H,W,3*heads*32] -> attention output [B,H,W,heads*32] (before to_out).  Maps of up to `fused_up_to` pixels (<= 256)
+    run context + apply in one launch; the UNet plan uses that for H*W <= 64."""
     b, h, w, c3 = qkv.shape
     ctx = torch.empty((b, heads, 32, 32), device=qkv.device, dtype=torch.float32)
     out = torch.empty((b, h, w, c3 // 3), device=qkv.device, dtype=torch.float32)
     lib = L.load()
-    if h * w <= 64:       # small maps: context + apply in one launch
+    if h * w <= min(fused_up_to, 256):      # small maps: context + apply in one launch
         L.check(lib.ddk_linattn_fused_small(L.ptr(_f32(qkv)), L.ptr(ctx), L.ptr(out), b, h * w, heads, L.stream()), "linattn_fused_small")
         return out, ctx
     nbytes = lib.ddk_linattn_context_workspace_bytes(b, h * w, heads)

@@ -351,7 +351,7 @@ def test_pool_upsample_add(ops):
 
 
 # ---------------------------------------------------------------- attention
-@pytest.mark.parametrize("B,H,W", [(2, 4, 4), (3, 8, 8), (2, 32, 32), (1, 10, 13)])
+@pytest.mark.parametrize("B,H,W", [(2, 4, 4), (3, 8, 8), (2, 32, 32), (1, 10, 13), (32, 16, 16), (2, 15, 17), (1, 16, 17)])
 def test_linattn(ops, B, H, W):
     qkv = rnd(B, 384, H, W, seed=60, scale=1.5)
     q, k, v = qkv.reshape(B, 3, 4, 32, H * W).unbind(1)
@@ -361,6 +361,9 @@ def test_linattn(ops, B, H, W):
     out, ctx = ops.linattn(to_nhwc(qkv).to(DEV), 4)
     assert rel_err(ctx.cpu(), ctx_ref) < 1e-5
     assert rel_err(to_nchw(out.cpu()), out_ref) < 1e-5
+    if 64 < H * W <= 256:        # the one-launch kernel with 256 rows in LDS
+        out1, ctx1 = ops.linattn(to_nhwc(qkv).to(DEV), 4, fused_up_to=256)
+        assert rel_err(ctx1.cpu(), ctx_ref) < 1e-5 and rel_err(to_nchw(out1.cpu()), out_ref) < 1e-5
 
 
 @pytest.mark.parametrize("B,H,W,C", [(32, 4, 4, 256), (5, 8, 8, 256), (3, 8, 8, 128), (2, 2, 2, 64), (2, 6, 6, 96), (1, 8, 8, 384)])
