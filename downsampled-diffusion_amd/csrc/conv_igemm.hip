@@ -1092,6 +1092,14 @@ static Choice choose_tile(long long M, int N, int nphase, int kiters) {
         while (n_tiles(order[i]) * s < 512 && s < 16) s *= 2;
         if (kiters / s >= 18) return with_splits(order[i], s);
     }
+    // 3b. a small grid with a long contraction (the 1x1 skip convs 512 -> 256 of the 4x4 / 8x8 maps: 32 / 128 tiles, 16 chunks):
+    //     split k up to ~256 workgroups while every workgroup keeps >= 4 chunks (16.3 -> 10.3 us at 4x4, 16.6 -> 14.8 at 8x8
+    //     including the reduce; profiles/r02_conv_sweep.txt);
+    if (kiters >= 16 && kiters < 36 && n_tiles(order[n_order - 1]) <= 128) {
+        long long s = 1;
+        while (n_tiles(order[n_order - 1]) * s * 2 <= 256 && kiters / (s * 2) >= 4) s *= 2;
+        if (s > 1) return with_splits(order[n_order - 1], s);
+    }
     // 4. else the smallest tile with the deepest split that keeps >= 9 chunks per workgroup.
     long long s = 16;
     while (s > 1 && (kiters / s < 9 || n_tiles(order[n_order - 1]) * s > 1024)) s /= 2;
