@@ -170,6 +170,95 @@ __device__ __forceinline__ void linattn_small_core(float* ks, float* vs, float* 
     }
 }
 
+// The same core on the matrix pipe, for the 256-row case (16x16 maps) where the VALU form above is LDS-bound (it re-reads k, v,
+// ctx per multiply: 2.5 MB of LDS traffic per workgroup): ctx = (exp k)^T v is a [32 x ROWS] x [ROWS x 32] product -- each of
+// the 4 waves takes ROWS/4 rows (v_mfma_f32_32x32x2_f32, operands read from LDS one float per lane), the partial 32 x 32 blocks
+// meet in LDS in wave order; out = q ctx is ROWS/32 blocks of [32 x 32] x [32 x 32], two per wave.  `part` = 4 x 32 x 33 floats.
+typedef float f32x16_sm __attribute__((ext_vector_type(16)));
+template <int ROWS>
+__device__ __forceinline__ void linattn_core_mfma(float* ks, float* vs, float* qs, float* cs, float* smax, float* part,
+                                                  float* __restrict__ ctx, float* __restrict__ out, int b, int h, int HW, int heads) {
+    static_assert(ROWS % 128 == 0, "4 waves x multiples of 32 rows");
+    const int HC = heads * DH;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c32 = lane & 31, kk = lane >> 5;
+    {   // max_n k[n][d]  (rows >= HW hold -inf)
+        const int d = tid & 31, ng = tid >> 5;
+        float m = -INFINITY;
+        for (int n = ng; n < ROWS; n += 8) m = fmaxf(m, ks[n * DH + d]);
+        smax[ng * DH + d] = m;
+        __syncthreads();
+        if (tid < DH) {
+            float mm = smax[tid];
+#pragma unroll
+            for (int j = 1; j < 8; ++j) mm = fmaxf(mm, smax[j * DH + tid]);
+            smax[tid] = mm;
+        }
+        __syncthreads();
+    }
+#pragma unroll 8
+    for (int j = 0; j < ROWS / 8; ++j) {                // exp(k - max) in place; padding rows -> exp(-inf) = 0
+        const int i = tid + j * 256;
+        ks[i] = expf(ks[i] - smax[i & 31]);
+    }
+    __syncthreads();
+    {   // softmax denominators: den[d] = sum_n exp k[n][d], 8 strided partials per column summed in fixed order
+        const int d = tid & 31, ng = tid >> 5;
+        float t = 0.f;
+        for (int n = ng; n < ROWS; n += 8) t += ks[n * DH + d];
+        smax[DH + ng * DH + d] = t;                     // smax holds 8 * DH floats... use the area behind the maxima
+    }
+    // raw context of this wave's rows
+    {
+        constexpr int RPW = ROWS / 4;
+        f32x16_sm acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const float* kp = ks + (wave * RPW + kk) * DH + c32;
+        const float* vp = vs + (wave * RPW + kk) * DH + c32;
+#pragma unroll 8
+        for (int j = 0; j < RPW / 2; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(kp[j * 2 * DH], vp[j * 2 * DH], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) part[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk) * 33 + c32] = acc[r];
+    }
+    __syncthreads();
+    {   // ctx[d][e] = (sum of the 4 partials) / den[d]: thread = (d, 4 consecutive e)
+        const int d = tid >> 3, e0 = (tid & 7) * 4;
+        float den = 0.f;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) den += smax[DH + g * DH + d];
+        const float inv = 1.0f / den;
+        float a4[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float t = part[d * 33 + e0 + e];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) t += part[(w * 32 + d) * 33 + e0 + e];
+            a4[e] = t * inv;
+            cs[d * (DH + 4) + e0 + e] = a4[e];
+        }
+        *reinterpret_cast<float4*>(ctx + (((long long)b * heads + h) * DH + d) * DH + e0) = make_float4(a4[0], a4[1], a4[2], a4[3]);
+    }
+    __syncthreads();
+    // out[n][e] = sum_d q[n][d] ctx[d][e]: blocks of 32 pixels, ROWS / 128 blocks per wave
+#pragma unroll
+    for (int mb = 0; mb < ROWS / 128; ++mb) {
+        const int n0 = (wave * (ROWS / 128) + mb) * 32;
+        f32x16_sm acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const float* qp = qs + (n0 + c32) * (DH + 1) + kk;
+        const float* cp = cs + kk * (DH + 4) + c32;
+#pragma unroll
+        for (int j = 0; j < DH / 2; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qp[2 * j], cp[2 * j * (DH + 4)], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int n = n0 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+            if (n < HW) out[((long long)b * HW + n) * HC + h * DH + c32] = acc[r];
+        }
+    }
+}
+
 // Small maps: context AND apply for one (b, head) in one workgroup -- k, v, q of the head (ROWS x 32 each) sit in LDS, so the
 // separate merge and apply launches (and the re-read of q) disappear.  ROWS = 64 for the 8x8 and 4x4 levels (30 KB of LDS),
 // 256 for the 16x16 level (100 KB).
@@ -181,7 +270,8 @@ __global__ __launch_bounds__(256) void linattn_small_kernel(const float* __restr
     float* vs = ks + ROWS * DH;
     float* qs = vs + ROWS * DH;
     float* cs = qs + ROWS * (DH + 1);
-    float* smax = cs + DH * (DH + 4);
+    float* smax = cs + DH * (DH + 4);                   // 8 * DH maxima partials (+ 8 * DH denominator partials, + the context partials,
+    float* part = smax + 16 * DH;                       //  for the matrix-pipe core)
     const int b = blockIdx.x / heads, h = blockIdx.x % heads;
     const int HC = heads * DH, RS = 3 * HC;
     const float* base = qkv + (long long)b * HW * RS + h * DH;
@@ -202,10 +292,13 @@ __global__ __launch_bounds__(256) void linattn_small_kernel(const float* __restr
         qs[row * (DH + 1) + c] = qv.x; qs[row * (DH + 1) + c + 1] = qv.y; qs[row * (DH + 1) + c + 2] = qv.z; qs[row * (DH + 1) + c + 3] = qv.w;
     }
     __syncthreads();
-    linattn_small_core<ROWS>(ks, vs, qs, cs, smax, ctx, out, b, h, HW, heads);
+    if constexpr (ROWS >= 128) linattn_core_mfma<ROWS>(ks, vs, qs, cs, smax, part, ctx, out, b, h, HW, heads);
+    else linattn_small_core<ROWS>(ks, vs, qs, cs, smax, ctx, out, b, h, HW, heads);
 }
 
-static size_t small_lds_bytes(int rows) { return ((size_t)rows * DH * 2 + (size_t)rows * (DH + 1) + DH * (DH + 4) + 8 * DH) * 4; }
+static size_t small_lds_bytes(int rows) {
+    return ((size_t)rows * DH * 2 + (size_t)rows * (DH + 1) + DH * (DH + 4) + 16 * DH + (rows >= 128 ? 4 * 32 * 33 : 0)) * 4;
+}
 
 // The same with the projection inside: to_qkv (1x1 conv with the channel LayerNorm folded in, blocks.py:57-60, 123) for ONE head
 // of ONE image is a [HW x C] x [C x 96] product -- small enough to run in the workgroup that consumes it, so the small maps need

@@ -602,8 +602,8 @@ static int run_attn(Ctx& c, const AttnW& a, const float* x, float* out, int H, i
         DDK_TRY(chan_layernorm(x, c.P + a.ln.g, c.P + a.ln.b, xn, M, a.c, LN_EPS, c.st));
         DDK_TRY(run_conv(c, DDK_CONV1X1, a.qkv, xn, a.c, nullptr, 0, nullptr, qkv, H, W, 3 * HIDDEN));
     }
-    if (H * W <= 64) {       // (the same kernel with 256 rows covers 16x16, but its VALU core is LDS-bound there: 23 us against
-                             //  6.5 + 4.8 + 7.4 for context / merge / apply on 4x the workgroups)
+    if (H * W <= 256) {      // 16x16 and smaller: k, v, q of one (image, head) fit the LDS -- context, merge and apply in one launch
+                             // (256 rows: both products on the matrix pipe; the VALU form was LDS-bound there, 23 us)
         DDK_TRY(linattn_fused_small(qkv, ctx, o, c.B, H * W, HEADS, c.st));
     } else {
         // (folding the split context's merge into the apply kernel's fragment build was tried: 73 vs 11 + 5.5 us at 32x32 --

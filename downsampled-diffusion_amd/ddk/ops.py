@@ -333,9 +333,9 @@ def fix_samples(x):
 
 
 # ------------------------------------------------------------------ linear attention core
-def linattn(qkv, heads=4, fused_up_to=64):
+def linattn(qkv, heads=4, fused_up_to=256):
     """qkv [B,H,W,3*heads*32] -> attention output [B,H,W,heads*32] (before to_out).  Maps of up to `fused_up_to` pixels (<= 256)
-    run context + apply in one launch; the UNet plan uses that for H*W <= 64."""
+    run context + apply in one launch, as in the UNet plan."""
     b, h, w, c3 = qkv.shape
     ctx = torch.empty((b, heads, 32, 32), device=qkv.device, dtype=torch.float32)
     out = torch.empty((b, h, w, c3 // 3), device=qkv.device, dtype=torch.float32)
