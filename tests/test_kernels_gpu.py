@@ -181,6 +181,8 @@ LOCAL_CASES = [    # B, H, W, c0, c1, N   (GroupNorm groups = 8)
     (5, 8, 8, 256, 0, 256),        # 8x8 map: four M blocks
     (2, 8, 8, 128, 384, 256),      # 8x8 concat, c0 != c1, 134 KB of LDS
     (2, 2, 8, 96, 0, 96),          # non-square 16-pixel map, 3 chunks, 12 channels/group is not eligible -> see below
+    (3, 2, 8, 64, 32, 64),         # non-square 16-pixel map, concat, 8 channels per group
+    (1, 8, 2, 32, 0, 64),          # batch 1
 ]
 
 
@@ -224,6 +226,8 @@ WLOCAL_CASES = [   # B, H, W, c0, c1, N
     (2, 4, 16, 96, 32, 96),        # non-square 64-pixel map, concat; 12 channels per group is not eligible
     (2, 16, 4, 128, 192, 256),     # concat filling the 320-channel LDS budget
     (5, 8, 8, 160, 0, 64),         # odd chunk count (5)
+    (1, 4, 16, 64, 0, 64),         # batch 1, non-square
+    (3, 32, 2, 32, 32, 64),        # 32x2 map (tiles 16x1), concat
 ]
 
 
