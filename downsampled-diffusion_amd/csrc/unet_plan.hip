@@ -75,8 +75,11 @@ struct SamplerGraph {
     unsigned long long pack_epoch;
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
+    hipGraph_t graph_multi = nullptr;        // SAMPLER_MULTI consecutive steps in one graph (captured when a chain is long enough)
+    hipGraphExec_t exec_multi = nullptr;
     unsigned long long last_use = 0;
 };
+constexpr int SAMPLER_MULTI = 8;
 
 struct ddk_unet {
     // sampler state cached across ddk_sampler_run calls (guarded by `mu`; see ddk_sampler_invalidate)
@@ -276,6 +279,8 @@ static void drop_graphs(ddk_unet* u) {   // caller holds u->mu (or owns u exclus
     for (SamplerGraph& g : u->graphs) {
         if (g.exec) (void)hipGraphExecDestroy(g.exec);
         if (g.graph) (void)hipGraphDestroy(g.graph);
+        if (g.exec_multi) (void)hipGraphExecDestroy(g.exec_multi);
+        if (g.graph_multi) (void)hipGraphDestroy(g.graph_multi);
     }
     u->graphs.clear();
     u->table.ws = nullptr;
@@ -826,6 +831,28 @@ extern "C" int ddk_sampler_run(const ddk_sampler_args* a, ddk_stream_t s) {
                                a->c2, a->sigma, B, per, 0, 0, st, state);
     };
 
+    auto capture = [&](int steps, hipGraph_t& graph, hipGraphExec_t& exec) -> int {
+        hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+        if (e != hipSuccess) {
+            set_error("sampler: hipStreamBeginCapture failed (%s); the legacy NULL stream cannot be captured -- pass a created stream",
+                      hipGetErrorString(e));
+            return DDK_ERR_HIP;
+        }
+        int rc = DDK_OK;
+        for (int i = 0; i < steps && rc == DDK_OK; ++i) rc = one_step();
+        e = hipStreamEndCapture(st, &graph);
+        if (rc != DDK_OK) { if (graph) (void)hipGraphDestroy(graph); graph = nullptr; return rc; }
+        if (e != hipSuccess) { graph = nullptr; set_error("sampler: hipStreamEndCapture: %s", hipGetErrorString(e)); return DDK_ERR_HIP; }
+        e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        if (e != hipSuccess) {
+            (void)hipGraphDestroy(graph);
+            graph = nullptr; exec = nullptr;
+            set_error("sampler: hipGraphInstantiate: %s", hipGetErrorString(e));
+            return DDK_ERR_HIP;
+        }
+        return DDK_OK;
+    };
+
     std::lock_guard<std::mutex> lock(u.mu);
     hipLaunchKernelGGL(set_chain_state_kernel, dim3(1), dim3(1), 0, st, state, (int64_t)a->t_start, a->seed, a->stream_id);
     DDK_TRY(check_launch("set_chain_state_kernel"));
@@ -870,6 +897,8 @@ extern "C" int ddk_sampler_run(const ddk_sampler_args* a, ddk_stream_t s) {
             DDK_HIP(hipDeviceSynchronize());
             (void)hipGraphExecDestroy(u.graphs[lru].exec);
             (void)hipGraphDestroy(u.graphs[lru].graph);
+            if (u.graphs[lru].exec_multi) (void)hipGraphExecDestroy(u.graphs[lru].exec_multi);
+            if (u.graphs[lru].graph_multi) (void)hipGraphDestroy(u.graphs[lru].graph_multi);
             u.graphs.erase(u.graphs.begin() + (long)lru);
         }
         DDK_TRY(one_step());
@@ -878,27 +907,23 @@ extern "C" int ddk_sampler_run(const ddk_sampler_args* a, ddk_stream_t s) {
         g.packed = a->packed; g.x = a->x; g.noise = a->noise; g.ws = a->workspace; g.c_recip = a->c_recip; g.c_recipm1 = a->c_recipm1;
         g.c1 = a->c1; g.c2 = a->c2; g.sigma = a->sigma; g.B = B; g.H = H; g.W = W; g.t_start = a->t_start; g.device = dev;
         g.pack_epoch = u.pack_epoch;
-        hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
-        if (e != hipSuccess) {
-            set_error("sampler: hipStreamBeginCapture failed (%s); the legacy NULL stream cannot be captured -- pass a created stream",
-                      hipGetErrorString(e));
-            return DDK_ERR_HIP;
-        }
-        const int rc = one_step();
-        e = hipStreamEndCapture(st, &g.graph);
-        if (rc != DDK_OK) { if (g.graph) (void)hipGraphDestroy(g.graph); return rc; }
-        if (e != hipSuccess) { set_error("sampler: hipStreamEndCapture: %s", hipGetErrorString(e)); return DDK_ERR_HIP; }
-        e = hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0);
-        if (e != hipSuccess) {
-            (void)hipGraphDestroy(g.graph);
-            set_error("sampler: hipGraphInstantiate: %s", hipGetErrorString(e));
-            return DDK_ERR_HIP;
-        }
+        DDK_TRY(capture(1, g.graph, g.exec));
         u.graphs.push_back(g);
         hit = &u.graphs.back();
     }
     hit->last_use = ++u.use_clock;
-    for (int k = first; k < n_steps; ++k) {
+    int k = first;
+    // long chains: SAMPLER_MULTI steps per graph launch (t and the Philox counter live in device memory, so a graph of any number
+    // of steps continues the chain); the one-step graph finishes the remainder
+    // (captured with the one-step graph, on the first call for a buffer set whose chain can be that long -- not in a later, timed call)
+    if (!hit->exec_multi && (first || n_steps - k >= 2 * SAMPLER_MULTI) && a->t_start + 1 >= 2 * SAMPLER_MULTI)
+        DDK_TRY(capture(SAMPLER_MULTI, hit->graph_multi, hit->exec_multi));
+    if (hit->exec_multi)
+        for (; k + SAMPLER_MULTI <= n_steps; k += SAMPLER_MULTI) {
+            const hipError_t e = hipGraphLaunch(hit->exec_multi, st);
+            if (e != hipSuccess) { set_error("sampler: hipGraphLaunch: %s", hipGetErrorString(e)); return DDK_ERR_HIP; }
+        }
+    for (; k < n_steps; ++k) {
         const hipError_t e = hipGraphLaunch(hit->exec, st);
         if (e != hipSuccess) { set_error("sampler: hipGraphLaunch: %s", hipGetErrorString(e)); return DDK_ERR_HIP; }
     }
