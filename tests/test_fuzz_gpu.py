@@ -179,3 +179,56 @@ def test_conv_winograd_fuzz(B, H, W, c0, c1, N, seed):
         want = want * torch.tanh(F.softplus(want))
     assert rel_err(to_nchw(out.cpu()), want) < 2e-5
     assert torch.equal(out, ops.conv(ops.CONV3X3_S1, x0, wp, bias.to(DEV), x2=x1, resid=to_nhwc(resid).to(DEV), post_mish=mish, w_wino=wu))
+
+
+def _local_cases(n, seed0):
+    import random
+    rng = random.Random(seed0)
+    out = []
+    for i in range(n):
+        px = rng.choice([16, 16, 64, 64])
+        h = rng.choice([2, 4, 8] if px == 16 else [2, 4, 8, 16, 32])
+        w = px // h
+        n_out = rng.choice([64, 128, 256])          # 8 groups: 8 / 16 / 32 channels per group
+        c0 = rng.choice([32, 64, 96, 128, 160, 256])
+        c1 = rng.choice([0, 0, 32, 64, 128])
+        if px == 64 and c0 + c1 > 320:              # LDS budget of the Winograd form
+            c1 = 0
+        b = rng.choice([1, 2, 3, 7, 32])
+        out.append((b, h, w, c0, c1, n_out, 7000 + i))
+    return out
+
+
+@pytest.mark.parametrize("B,H,W,c0,c1,N,seed", _local_cases(20, 20261005))
+def test_conv_groupnorm_one_launch_fuzz(B, H, W, c0, c1, N, seed):
+    """The image-local one-launch Block kernels (direct on 16-pixel maps, Winograd on 64-pixel maps) on random eligible shapes --
+    non-square maps, every channels-per-group count, concat sources, shift / residual options -- against torch's
+    conv2d -> group_norm -> mish (blocks.py:75-84, 110-115), and bit-stable run to run."""
+    from ddk import ops
+    cin = c0 + c1
+    lib = ops.L.load()
+    x = _rnd(B, cin, H, W, seed=seed)
+    w = _rnd(N, cin, 3, 3, seed=seed + 2) * (cin * 9) ** -0.5
+    bias = _rnd(N, seed=seed + 1) * 0.1
+    gamma, beta = 1 + 0.2 * _rnd(N, seed=seed + 4), 0.2 * _rnd(N, seed=seed + 5)
+    temb = _rnd(B, N, seed=seed + 6) if seed & 1 else None
+    resid = _rnd(B, N, H, W, seed=seed + 3) if seed & 2 else None
+    h = F.group_norm(F.conv2d(x, w, bias, padding=1), 8, gamma, beta, eps=1e-5)
+    want = h * torch.tanh(F.softplus(h))
+    if temb is not None:
+        want = want + temb[:, :, None, None]
+    if resid is not None:
+        want = want + resid
+    xh = to_nhwc(x).to(DEV)
+    x0 = xh[..., :c0].contiguous()
+    x1 = xh[..., c0:].contiguous() if c1 else None
+    kw = dict(temb=temb.to(DEV) if temb is not None else None, addend=to_nhwc(resid).to(DEV) if resid is not None else None, x2=x1)
+    if H * W == 16:
+        assert lib.ddk_conv3x3_gn_mish_ok(H, W, cin, c0, N, 8)
+        run = lambda: ops.conv3x3_gn_mish(x0, ops.pack_conv_weight_local(w.to(DEV)), bias.to(DEV), gamma.to(DEV), beta.to(DEV), **kw)
+    else:
+        assert lib.ddk_conv3x3_gn_mish_wino_ok(H, W, cin, c0, N, 8)
+        run = lambda: ops.conv3x3_gn_mish_wino(x0, ops.pack_conv_weight_wino_local(w.to(DEV)), bias.to(DEV), gamma.to(DEV), beta.to(DEV), **kw)
+    out = run()
+    assert rel_err(to_nchw(out.cpu()), want) < 2e-5
+    assert torch.equal(out, run())
