@@ -1,0 +1,223 @@
+// conv_first.hip -- the UNet's first Block conv: Conv2d(C_in, N, 3, padding=1) with C_in = image / latent channels (1..8).
+//
+// Reference: models/unet/unet.py:43-50 (dims[0] = unet_in: 1 MNIST, 3 CIFAR / CelebA, 8 dDDPM latents), models/unet/blocks.py:78
+// (the conv of Block), :79 (the GroupNorm whose statistics the epilogue prepares).
+//
+// The generic kernels need C_in % 32 == 0, so this conv used to run zero-padded to 32 input channels (K = 288 per tap set, 512
+// in the Winograd form) behind a pad kernel: 23.5 us for an op SURVEY.md section 8d prices at 2.2 us (HBM) / 3.8 us (FLOP).
+// Here K = 9 * C_in exactly (72 at C_in = 8) and the input is read unpadded.
+//
+//   GEMM view: D[n][pixel] = sum_k W[n][k] X[pixel][k],  k = tap * C_in + c,  v_mfma_f32_32x32x2_f32 with the WEIGHTS as the
+//   A operand (rows = output channels) and the gathered input patch as the B operand (columns = pixels): a lane then ends up
+//   with 4 consecutive output channels of its pixel per accumulator quad -> float4 NHWC stores straight from registers.
+//   Workgroup = 128 consecutive pixels (4 waves x 32) x all N channels; a lane gathers its pixel's K values once (they stay in
+//   registers for all N / 32 channel blocks); the packed filter ([N/32][K/2][64 lanes], 36 KB at N = 128, C_in = 8) is staged
+//   in LDS once per workgroup.
+//   Epilogue: + bias, stores, and per (128-pixel tile, GroupNorm group) {mean, M2 about that mean} by Chan's pairwise merge
+//   (quad -> 32 lanes -> 4 waves -> quads of the group: one pass, no cancellation), the format gn_apply_parts_kernel consumes.
+//   In the sampler the workgroup 0 also does the step's bookkeeping (t_cur[b] <- counter; counter -= 1): it is the first kernel
+//   of a reverse step, so the separate prepare / pad kernel disappears.
+#include "conv_common.h"
+
+namespace ddk {
+
+struct FirstParams {
+    const float* x;        // [B][H][W][CIN], unpadded
+    const float* wp;       // [N/32][K2][64]
+    const float* bias;     // [N] or nullptr
+    float* out;            // [B][H][W][N]
+    float2* gn_part;       // [B*HW/128][groups] or nullptr
+    int H, W, HW, N, NB;
+    int cpg, groups;
+    int64_t* counter;      // sampler bookkeeping (nullptr outside the sampler)
+    int64_t* t_cur;
+    int B;
+};
+
+// dst[(nb*K2 + s)*64 + l] = w[n = nb*32 + (l & 31)][k = 2s + (l >> 5)],  k = tap*I + c  <-  OIHW w[n][c][tap]
+__global__ __launch_bounds__(256) void pack_conv_weight_first_kernel(const float* __restrict__ w, float* __restrict__ dst, int O, int I,
+                                                                      int K2, long long total) {
+    for (long long idx = blockIdx.x * 256LL + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int l = (int)(idx & 63);
+        const long long r = idx >> 6;
+        const int s = (int)(r % K2), nb = (int)(r / K2);
+        const int n = nb * 32 + (l & 31), k = 2 * s + (l >> 5);
+        float v = 0.f;
+        if (k < 9 * I && n < O) {
+            const int tap = k / I, c = k - tap * I;
+            v = w[((long long)n * I + c) * 9 + tap];
+        }
+        dst[idx] = v;
+    }
+}
+
+template <int CIN>
+__global__ __launch_bounds__(256) void conv_first_kernel(const FirstParams p) {
+    constexpr int K = 9 * CIN, K2 = (K + 1) / 2;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* wl = smem;                                                 // NB * K2 * 64 floats
+    float2* qs = reinterpret_cast<float2*>(smem + p.NB * K2 * 64);    // [4 waves][N / 4 quads] {mean, M2} over 32 pixels x 4 channels
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int pl = lane & 31, h = lane >> 5;
+
+    if (p.counter && blockIdx.x == 0) {          // first kernel of a reverse step: nobody else touches the counter now
+        const int64_t v = *p.counter;
+        for (int b = tid; b < p.B; b += 256) p.t_cur[b] = v;
+        __syncthreads();
+        if (tid == 0) *p.counter = v - 1;
+    }
+    {   // the packed filter, once per workgroup
+        const int n4 = p.NB * K2 * 16;
+        const float4* src = reinterpret_cast<const float4*>(p.wp);
+        float4* dst = reinterpret_cast<float4*>(wl);
+        for (int i = tid; i < n4; i += 256) dst[i] = src[i];
+    }
+    // this lane's pixel and its 3x3 neighbourhood
+    const int g = blockIdx.x * 128 + wave * 32 + pl;
+    const int b = g / p.HW, r = g - b * p.HW;
+    const int y = r / p.W, x = r - y * p.W;
+    int toff[9];
+    unsigned tmask = 0;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+        const bool ok = (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
+        toff[t] = ok ? ((b * p.H + yy) * p.W + xx) * CIN : 0;
+        if (ok) tmask |= 1u << t;
+    }
+    float bv[K2];
+#pragma unroll
+    for (int s = 0; s < K2; ++s) {
+        const int k0 = 2 * s, k1 = 2 * s + 1;
+        const int t0 = k0 / CIN, c0 = k0 % CIN;
+        const int t1 = k1 < K ? k1 / CIN : 0, c1 = k1 < K ? k1 % CIN : 0;
+        const bool ok = h ? (k1 < K && ((tmask >> t1) & 1u)) : ((tmask >> t0) & 1u);
+        const int idx = h ? toff[t1] + c1 : toff[t0] + c0;
+        const float v = p.x[idx];                 // index 0 when the tap is outside: always a valid address
+        bv[s] = ok ? v : 0.f;
+    }
+    __syncthreads();                              // filter staged
+
+    const long long orow = (long long)g * p.N;
+    for (int nb = 0; nb < p.NB; ++nb) {
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        const float* wrow = wl + nb * K2 * 64 + lane;
+#pragma unroll
+        for (int s = 0; s < K2; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wrow[s * 64], bv[s], acc, 0, 0, 0);
+        // accumulator register 4q + i of this lane = channel nb*32 + 8q + 4h + i of pixel pl
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c = nb * 32 + 8 * q + 4 * h;
+            float4 v = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+            if (p.bias) {
+                const float4 bb = *reinterpret_cast<const float4*>(p.bias + c);
+                v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
+            }
+            *reinterpret_cast<float4*>(p.out + orow + c) = v;
+            if (p.gn_part) {
+                // {mean, M2} of the quad, then merged over the 32 lanes that hold the same channels (equal counts at every level)
+                float m = ((v.x + v.y) + (v.z + v.w)) * 0.25f;
+                const float d0 = v.x - m, d1 = v.y - m, d2 = v.z - m, d3 = v.w - m;
+                float m2 = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+                float half_cnt = 2.0f;            // n_a * n_b / (n_a + n_b) with n_a = n_b = 4, 8, ...
+#pragma unroll
+                for (int o = 1; o < 32; o <<= 1) {
+                    const float mo = __shfl_xor(m, o, 64), qo = __shfl_xor(m2, o, 64);
+                    const float d = mo - m;
+                    m2 = (m2 + qo) + d * d * half_cnt;
+                    m = 0.5f * (m + mo);
+                    half_cnt *= 2.0f;
+                }
+                if (pl == 0) qs[wave * (p.N >> 2) + (c >> 2)] = make_float2(m, m2);
+            }
+        }
+    }
+    if (p.gn_part) {
+        __syncthreads();
+        if (tid < p.groups) {
+            // fixed order: waves, then the group's quads (Chan et al., unequal counts)
+            const int qpg = p.cpg >> 2, q0 = tid * qpg;
+            float n = 0.f, mean = 0.f, m2 = 0.f;
+            const float ni = 128.0f;              // 32 pixels x 4 channels per item
+            for (int w = 0; w < 4; ++w)
+                for (int q = 0; q < qpg; ++q) {
+                    const float2 t = qs[w * (p.N >> 2) + q0 + q];
+                    const float tot = n + ni, d = t.x - mean;
+                    mean += d * (ni / tot);
+                    m2 += t.y + d * d * (n * ni / tot);
+                    n = tot;
+                }
+            p.gn_part[(long long)blockIdx.x * p.groups + tid] = make_float2(mean, m2);
+        }
+    }
+}
+
+static size_t first_lds_bytes(int cin, int N) {
+    const int K2 = (9 * cin + 1) / 2;
+    return (size_t)(N / 32) * K2 * 64 * sizeof(float) + (size_t)4 * (N / 4) * sizeof(float2);
+}
+
+bool conv_first_ok(int cin, int N, int H, int W, int groups) {
+    if (cin < 1 || cin > 8 || N < 32 || N % 32 || N > 256 || H < 1 || W < 1) return false;
+    if ((long long)H * W % 128) return false;                      // a workgroup's 128 pixels lie inside one image
+    if (groups <= 0 || groups > 64 || N % groups || (N / groups) % 4) return false;
+    return true;
+}
+
+#define FIRST_CASES(X) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8)
+
+int conv_first_init_device() {
+#define X(C) DDK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_first_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    FIRST_CASES(X)
+#undef X
+    return DDK_OK;
+}
+
+int conv_first(const float* x, const float* wp, const float* bias, float* out, float* gn_partials, int B, int H, int W, int cin, int N,
+               int groups, int64_t* counter, int64_t* t_cur, hipStream_t st) {
+    DDK_REQUIRE(x && wp && out && B > 0, "conv_first: null pointer / B");
+    DDK_REQUIRE(conv_first_ok(cin, N, H, W, groups), "conv_first: needs 1 <= C_in <= 8, N % 32 == 0, N <= 256, H*W % 128 == 0, "
+                "N / groups a multiple of 4");
+    DDK_REQUIRE(aligned16(wp) && aligned16(out) && aligned16(bias) && (reinterpret_cast<uintptr_t>(gn_partials) & 7u) == 0 &&
+                    (reinterpret_cast<uintptr_t>(x) & 3u) == 0, "conv_first: alignment");
+    DDK_REQUIRE((long long)B * H * W * 8 < (1ll << 31), "conv_first: B*H*W too large for 32-bit pixel offsets");
+    DDK_REQUIRE((counter == nullptr) == (t_cur == nullptr), "conv_first: counter and t_cur go together");
+    FirstParams p{};
+    p.x = x; p.wp = wp; p.bias = bias; p.out = out; p.gn_part = reinterpret_cast<float2*>(gn_partials);
+    p.H = H; p.W = W; p.HW = H * W; p.N = N; p.NB = N / 32;
+    p.groups = groups; p.cpg = N / groups;
+    p.counter = counter; p.t_cur = t_cur; p.B = B;
+    const dim3 grid((unsigned)((long long)B * H * W / 128));
+    const size_t lds = first_lds_bytes(cin, N);
+    switch (cin) {
+#define X(C) case C: hipLaunchKernelGGL(conv_first_kernel<C>, grid, dim3(256), lds, st, p); break;
+        FIRST_CASES(X)
+#undef X
+        default: return fail_arg("conv_first: C_in");
+    }
+    return check_launch("conv_first_kernel");
+}
+
+}  // namespace ddk
+
+using namespace ddk;
+
+extern "C" int ddk_pack_conv_weight_first(const float* w_oihw, float* dst, int O, int I, ddk_stream_t s) {
+    DDK_REQUIRE(w_oihw && dst && O > 0 && O % 32 == 0 && I >= 1 && I <= 8, "pack_conv_weight_first: arguments (O % 32 == 0, 1 <= I <= 8)");
+    const int K2 = (9 * I + 1) / 2;
+    const long long total = (long long)(O / 32) * K2 * 64;
+    const long long blocks = ceil_div(total, 256);
+    hipLaunchKernelGGL(pack_conv_weight_first_kernel, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), 0, as_stream(s), w_oihw, dst,
+                       O, I, K2, total);
+    return check_launch("pack_conv_weight_first_kernel");
+}
+
+extern "C" int ddk_conv_first_ok(int cin, int N, int H, int W, int groups) { return conv_first_ok(cin, N, H, W, groups) ? 1 : 0; }
+
+extern "C" int ddk_conv_first(const float* x, const float* w_first, const float* bias, float* out, float* gn_partials, int B, int H, int W,
+                              int cin, int N, int groups, ddk_stream_t s) {
+    DDK_TRY(ensure_device_init());
+    return conv_first(x, w_first, bias, out, gn_partials, B, H, W, cin, N, groups, nullptr, nullptr, as_stream(s));
+}

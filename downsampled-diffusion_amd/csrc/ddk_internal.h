@@ -134,6 +134,12 @@ int conv_wino_splits(int B, int H, int W, int cin, int N);
 int conv_wino_forward(const ddk_conv_args& a, int splits, hipStream_t st);
 int conv_wino_init_device();
 int conv_wino_stats_parts(int B, int H, int W, int cin, int N, int groups);   // tiles per image, or 0
+// conv_first.hip: Conv2d(C_in <= 8, N, 3, padding=1) on the unpadded input, GroupNorm partials in the epilogue; with
+// counter / t_cur it also does the sampler's per-step bookkeeping (t_cur[b] <- counter; counter -= 1)
+bool conv_first_ok(int cin, int N, int H, int W, int groups);
+int conv_first(const float* x, const float* wp, const float* bias, float* out, float* gn_partials, int B, int H, int W, int cin, int N,
+               int groups, int64_t* counter, int64_t* t_cur, hipStream_t st);
+int conv_first_init_device();
 // conv_local.hip: conv3x3 + GroupNorm + Mish (+shift, +residual) in one launch for 4x4 / 8x8 maps
 bool conv_gn_local_ok(int H, int W, int cin, int c0, int N, int groups);
 int conv_gn_local(const float* src0, int c0, const float* src1, int c1, const float* w, const float* bias, const float* gamma,
@@ -155,9 +161,11 @@ int groupnorm_mish(const float* x, const float* gamma, const float* beta, const 
 int groupnorm_mish_ex(const float* x, int nslab, long long slab_stride, const float* cbias, const float* gamma,
                       const float* beta, const float* temb, int temb_stride, const float* addend, float* out, int B, int HW, int C,
                       int groups, float eps, void* ws, size_t ws_bytes, hipStream_t st, const long long* temb_rows = nullptr);
+// rc_*: optional on-the-fly 1x1 addend  rc_b[c] + sum_k rc_x[pix][k] rc_w[c*rc_ld + k]  (k < rc_cin <= 8), instead of `addend`
 int groupnorm_mish_parts(const float* x, const float* part, int np, const float* gamma, const float* beta, const float* temb,
                          int temb_stride, const float* addend, float* out, int B, int HW, int C, int groups, float eps, hipStream_t st,
-                         const long long* temb_rows = nullptr);
+                         const long long* temb_rows = nullptr, const float* rc_x = nullptr, const float* rc_w = nullptr,
+                         const float* rc_b = nullptr, int rc_cin = 0, int rc_ld = 0);
 int chan_layernorm(const float* x, const float* g, const float* b, float* out, long long M, int C, float eps, hipStream_t st);
 int unary(int op, const float* x, float* out, long long n, hipStream_t st);
 int add(const float* a, const float* b, float* out, long long n, hipStream_t st);
@@ -185,5 +193,11 @@ int p_sample_update(float* x, const float* eps_hat, const float* noise, long lon
                     const float* sigma, int B, long long per, uint64_t seed, uint32_t stream_id, hipStream_t st,
                     const int64_t* chain_state = nullptr);
 int randn(float* out, long long n, uint64_t seed, uint32_t step, uint32_t stream_id, hipStream_t st);
+// GroupNorm (from conv partials) + Mish + 1x1 projection to n_out <= 8 channels (+ the reverse-step update of x) in one launch
+bool final_tail_ok(int HW, int C, int groups, int n_out, int np);
+int final_tail(const float* raw, const float* part, int np, const float* gamma, const float* beta, float eps, const float* w,
+               const float* bias, int n_out, float* eps_out, float* x, const float* noise, long long noise_step_stride, int t_first,
+               const int64_t* t, const float* c_recip, const float* c_recipm1, const float* c1, const float* c2, const float* sigma,
+               const int64_t* chain_state, uint64_t seed, uint32_t stream_id, int B, int HW, int C, int groups, hipStream_t st);
 
 }  // namespace ddk

@@ -115,6 +115,178 @@ __global__ __launch_bounds__(256) void p_sample_kernel(float* __restrict__ x, co
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The end of a forward in ONE launch (reference models/unet/unet.py:69-72 after the final Block's conv, blocks.py:79-80;
+// in the sampler also models/diffusion/ddpm.py:149-158,177-185,216-227): GroupNorm (statistics from the final conv's per-tile
+// partials) -> Mish -> 1x1 projection to n_out <= 8 channels -> eps_hat, and -- when x is given -- the reverse-step update of x
+// in place.  Replaces gn_apply_parts_kernel + conv1x1_n8_kernel + p_sample_kernel: the normalised activation (16.8 MB at
+// cfg4) and eps_hat never go to memory.
+//   workgroup = one 128-pixel tile of one image; phase 1: LPP lanes share a pixel (conv1x1_n8_kernel's butterfly), eps_hat of
+//   the tile goes to LDS; phase 2: the tile's 128 * n_out latent elements are updated with p_sample_kernel's exact arithmetic
+//   and Philox indexing (bit-identical given the same eps_hat).
+struct TailParams {
+    const float* raw;          // [B][HW][C] output of the final Block's conv
+    const float2* part;        // [B*np][G] {mean, M2} per (128-pixel tile, group)
+    const float* gamma;
+    const float* beta;
+    const float* w;            // [n_out][C]
+    const float* bias;         // [n_out] or nullptr
+    float* eps_out;            // [B][HW][n_out] or nullptr
+    float* x;                  // [B][HW][n_out] or nullptr: updated in place
+    const float* noise;
+    long long noise_step_stride;
+    int t_first;
+    const int64_t* t;
+    const float *c_recip, *c_recipm1, *c1, *c2, *sigma;
+    const int64_t* chain_state;   // sampler: {counter, Philox seed, stream id} in device memory; else seed / stream below
+    uint64_t seed;
+    uint32_t stream;
+    int np, HW, C, cpg, n_out;
+    float eps;
+};
+
+template <int LPP, int VPL>
+__global__ __launch_bounds__(256) void final_tail_kernel(const TailParams p) {
+    constexpr int PPW = 64 / LPP;
+    __shared__ float2 mr[64];
+    __shared__ float2 sp[1024];
+    __shared__ __attribute__((aligned(16))) float es[128 * 8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, sub = lane % LPP, pl = lane / LPP;
+    const int b = blockIdx.x / p.np, tile = blockIdx.x - b * p.np;
+    const int G = p.C / p.cpg;
+    const long long pix0 = (long long)b * p.HW + tile * 128;
+    // first pixels requested before the statistics are merged
+    float4 v[VPL];
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) v[i] = *reinterpret_cast<const float4*>(p.raw + (pix0 + wave * PPW + pl) * p.C + (sub + i * LPP) * 4);
+    const float2* pb = p.part + (long long)b * p.np * G;
+    for (int i = tid; i < p.np * G; i += 256) sp[i] = pb[i];
+    __syncthreads();
+    if (tid < G) {          // the same fixed-order merge as gn_apply_parts_kernel
+        float ms = 0.f;
+        for (int i = 0; i < p.np; ++i) ms += sp[i * G + tid].x;
+        const float mean = ms / (float)p.np;
+        float m2 = 0.f, d2 = 0.f;
+        for (int i = 0; i < p.np; ++i) {
+            const float2 t = sp[i * G + tid];
+            m2 += t.y;
+            d2 += (t.x - mean) * (t.x - mean);
+        }
+        const float n_i = 128.0f * (float)p.cpg;
+        const float var = (m2 + n_i * d2) / ((float)p.np * n_i);
+        mr[tid] = make_float2(mean, 1.0f / sqrtf(var + p.eps));
+    }
+    __syncthreads();
+    float4 ga[VPL], be[VPL], ww[8][VPL];
+    float2 st[VPL];
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const int c0 = (sub + i * LPP) * 4;
+        ga[i] = *reinterpret_cast<const float4*>(p.gamma + c0);
+        be[i] = *reinterpret_cast<const float4*>(p.beta + c0);
+        st[i] = mr[c0 / p.cpg];
+#pragma unroll
+        for (int co = 0; co < 8; ++co)
+            ww[co][i] = co < p.n_out ? *reinterpret_cast<const float4*>(p.w + (long long)co * p.C + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const bool h2 = sub & (LPP / 2), h4 = sub & (LPP / 4), h8 = sub & (LPP / 8);
+    const int my_co = (h2 ? 4 : 0) + (h4 ? 2 : 0) + (h8 ? 1 : 0);
+    const float my_bias = (p.bias && my_co < p.n_out) ? p.bias[my_co] : 0.f;
+    constexpr int PPI = 4 * PPW;                     // pixels per iteration of the workgroup
+    for (int it = 0; it < 128 / PPI; ++it) {
+        const int lp = it * PPI + wave * PPW + pl;   // pixel within the tile
+        if (it > 0) {
+#pragma unroll
+            for (int i = 0; i < VPL; ++i) v[i] = *reinterpret_cast<const float4*>(p.raw + (pix0 + lp) * p.C + (sub + i * LPP) * 4);
+        }
+        float s[8];
+#pragma unroll
+        for (int co = 0; co < 8; ++co) s[co] = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            float4 y;
+            y.x = mish_f((v[i].x - st[i].x) * st[i].y * ga[i].x + be[i].x);
+            y.y = mish_f((v[i].y - st[i].x) * st[i].y * ga[i].y + be[i].y);
+            y.z = mish_f((v[i].z - st[i].x) * st[i].y * ga[i].z + be[i].z);
+            y.w = mish_f((v[i].w - st[i].x) * st[i].y * ga[i].w + be[i].w);
+#pragma unroll
+            for (int co = 0; co < 8; ++co) s[co] += (y.x * ww[co][i].x + y.y * ww[co][i].y) + (y.z * ww[co][i].z + y.w * ww[co][i].w);
+        }
+        // conv1x1_n8_kernel's packed butterfly: lane l ends with output my_co summed over the pixel's LPP lanes
+        float t4[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float keep = h2 ? s[4 + i] : s[i], send = h2 ? s[i] : s[4 + i];
+            t4[i] = keep + __shfl_xor(send, LPP / 2, 64);
+        }
+        float t2[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const float keep = h4 ? t4[2 + i] : t4[i], send = h4 ? t4[i] : t4[2 + i];
+            t2[i] = keep + __shfl_xor(send, LPP / 4, 64);
+        }
+        float r = (h8 ? t2[1] : t2[0]) + __shfl_xor(h8 ? t2[0] : t2[1], LPP / 8, 64);
+#pragma unroll
+        for (int o = LPP / 16; o > 0; o >>= 1) r += __shfl_xor(r, o, 64);
+        if ((sub & (LPP / 8 - 1)) == 0 && my_co < p.n_out) es[lp * p.n_out + my_co] = r + my_bias;
+    }
+    __syncthreads();
+    // phase 2: the tile's 128 * n_out elements, contiguous in the NHWC latent
+    const int cnt4 = 128 * p.n_out / 4;
+    const long long e4 = pix0 * p.n_out / 4;          // host: (128 * n_out) % 4 == 0
+    if (p.eps_out)
+        for (int q = tid; q < cnt4; q += 256) reinterpret_cast<float4*>(p.eps_out)[e4 + q] = reinterpret_cast<const float4*>(es)[q];
+    if (p.x) {
+        const uint64_t seed = p.chain_state ? (uint64_t)p.chain_state[1] : p.seed;
+        const uint32_t stream = p.chain_state ? (uint32_t)p.chain_state[2] : p.stream;
+        const int64_t tb = p.t[b];
+        const float cr = p.c_recip[tb], crm1 = p.c_recipm1[tb], a1 = p.c1[tb], a2 = p.c2[tb];
+        const float sg = tb > 0 ? p.sigma[tb] : 0.0f;
+        for (int q = tid; q < cnt4; q += 256) {
+            const long long i = e4 + q;
+            const float4 xv = reinterpret_cast<const float4*>(p.x)[i], ev = reinterpret_cast<const float4*>(es)[q];
+            const float4 zv = p.noise ? reinterpret_cast<const float4*>(p.noise + (long long)(p.t_first - tb) * p.noise_step_stride)[i]
+                                      : philox_normal4((unsigned long long)i, (uint32_t)tb, stream, seed);
+            float4 o;
+            o.x = p_step(xv.x, ev.x, zv.x, cr, crm1, a1, a2, sg);
+            o.y = p_step(xv.y, ev.y, zv.y, cr, crm1, a1, a2, sg);
+            o.z = p_step(xv.z, ev.z, zv.z, cr, crm1, a1, a2, sg);
+            o.w = p_step(xv.w, ev.w, zv.w, cr, crm1, a1, a2, sg);
+            reinterpret_cast<float4*>(p.x)[i] = o;
+        }
+    }
+}
+
+bool final_tail_ok(int HW, int C, int groups, int n_out, int np) {
+    if (!(C == 32 || C == 64 || C == 128 || C == 256)) return false;
+    if (groups <= 0 || groups > 64 || C % groups || (C / groups) % 4) return false;
+    if (n_out < 1 || n_out > 8 || (128 * n_out) % 4) return false;
+    return np > 0 && HW == np * 128 && np * groups <= 1024;
+}
+
+int final_tail(const float* raw, const float* part, int np, const float* gamma, const float* beta, float eps, const float* w,
+               const float* bias, int n_out, float* eps_out, float* x, const float* noise, long long noise_step_stride, int t_first,
+               const int64_t* t, const float* c_recip, const float* c_recipm1, const float* c1, const float* c2, const float* sigma,
+               const int64_t* chain_state, uint64_t seed, uint32_t stream_id, int B, int HW, int C, int groups, hipStream_t st) {
+    DDK_REQUIRE(raw && part && gamma && beta && w && (eps_out || x) && B > 0, "final_tail: null pointer");
+    DDK_REQUIRE(final_tail_ok(HW, C, groups, n_out, np), "final_tail: needs C in {32,64,128,256}, n_out <= 8, H*W == tiles * 128");
+    DDK_REQUIRE(aligned16(raw) && aligned16(gamma) && aligned16(beta) && aligned16(w) && aligned16(eps_out) && aligned16(x) &&
+                    aligned16(noise) && noise_step_stride % 4 == 0, "final_tail: alignment");
+    DDK_REQUIRE(!x || (t && c_recip && c_recipm1 && c1 && c2 && sigma), "final_tail: the update needs t and the schedule tables");
+    TailParams p{};
+    p.raw = raw; p.part = reinterpret_cast<const float2*>(part); p.gamma = gamma; p.beta = beta; p.w = w; p.bias = bias;
+    p.eps_out = eps_out; p.x = x; p.noise = noise; p.noise_step_stride = noise_step_stride; p.t_first = t_first; p.t = t;
+    p.c_recip = c_recip; p.c_recipm1 = c_recipm1; p.c1 = c1; p.c2 = c2; p.sigma = sigma; p.chain_state = chain_state;
+    p.seed = seed; p.stream = stream_id;
+    p.np = np; p.HW = HW; p.C = C; p.cpg = C / groups; p.n_out = n_out; p.eps = eps;
+    const dim3 grid((unsigned)(B * np));
+    if (C == 32) hipLaunchKernelGGL((final_tail_kernel<8, 1>), grid, dim3(256), 0, st, p);
+    else if (C == 64) hipLaunchKernelGGL((final_tail_kernel<16, 1>), grid, dim3(256), 0, st, p);
+    else if (C == 128) hipLaunchKernelGGL((final_tail_kernel<32, 1>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((final_tail_kernel<32, 2>), grid, dim3(256), 0, st, p);
+    return check_launch("final_tail_kernel");
+}
+
 // one workgroup per sample: fixed summation tree -> run-to-run deterministic
 __global__ __launch_bounds__(1024) void sq_err_sum_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                           float* __restrict__ per_sample, long long per4) {
@@ -250,6 +422,14 @@ int ddk_p_sample_update(float* x, const float* eps_hat, const float* noise, cons
                         const float* c_recipm1, const float* c1, const float* c2, const float* sigma, int B, long long per,
                         uint64_t seed, uint32_t stream_id, ddk_stream_t s) {
     return p_sample_update(x, eps_hat, noise, 0, 0, t, c_recip, c_recipm1, c1, c2, sigma, B, per, seed, stream_id, as_stream(s));
+}
+
+int ddk_final_tail(const float* raw, const float* partials, int tiles_per_image, const float* gamma, const float* beta, float eps,
+                   const float* w, const float* bias, int n_out, float* eps_out, float* x, const float* noise, const int64_t* t,
+                   const float* c_recip, const float* c_recipm1, const float* c1, const float* c2, const float* sigma, uint64_t seed,
+                   uint32_t stream_id, int B, int HW, int C, int groups, ddk_stream_t s) {
+    return final_tail(raw, partials, tiles_per_image, gamma, beta, eps, w, bias, n_out, eps_out, x, noise, 0, 0, t, c_recip, c_recipm1, c1,
+                      c2, sigma, nullptr, seed, stream_id, B, HW, C, groups, as_stream(s));
 }
 
 int ddk_randn(float* out, long long n, uint64_t seed, uint32_t step, uint32_t stream_id, ddk_stream_t s) {

@@ -98,12 +98,25 @@ __global__ __launch_bounds__(NT) void gn_mish_resident_kernel(const float* __res
 // GroupNorm+Mish when the producing conv already left per-tile statistics (conv3x3_wino_kernel, gn_part): `np` tiles of 128
 // pixels per image, each {mean, M2 about that mean} per group.  Every workgroup first merges the np partials of its image's
 // groups in fixed order (Chan et al.: equal counts), then streams its share of the image: one read, one write.
+//
+// RC: the addend is a 1x1 conv of a narrow tensor (the first ResnetBlock's res_conv, blocks.py:103,115: C_in = image / latent
+// channels <= 8) evaluated on the fly -- addend[pix][c] = rb[c] + sum_k rx[pix][k] rw[c][k] -- instead of a [M][C] tensor that
+// a separate launch would write and this one read back (2 x 16.8 MB at cfg4).  A thread's channel quad is the same for every
+// unit it touches (host: 256 % (C/4) == 0), so its 4 x C_in weights live in registers.
+struct Res1x1 {
+    const float* x;     // [B*HW][cin]
+    const float* w;     // [C][ld], row c = output channel, first cin entries used
+    const float* b;     // [C] or nullptr
+    int cin, ld;
+};
+
+template <bool RC>
 __global__ __launch_bounds__(256) void gn_apply_parts_kernel(const float* __restrict__ x, const float2* __restrict__ part, int np,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
                                                              const float* __restrict__ temb, int temb_stride,
                                                              const long long* __restrict__ temb_rows, const float* __restrict__ addend,
                                                              float* __restrict__ out, int HW, int C, int cpg, float eps, int wg_per_image,
-                                                             int units_per_wg) {
+                                                             int units_per_wg, const Res1x1 rc) {
     __shared__ float2 mr[128];
     __shared__ float2 sp[1024];
     const int b = blockIdx.x / wg_per_image, chunk = blockIdx.x - b * wg_per_image;
@@ -138,6 +151,16 @@ __global__ __launch_bounds__(256) void gn_apply_parts_kernel(const float* __rest
     }
     __syncthreads();
     const long long tr = temb ? (temb_rows ? temb_rows[b] : b) : 0;
+    float rw[4][8], rb[4];
+    if (RC) {
+        const int c0 = ((u_begin + (int)threadIdx.x) - div_upr(u_begin + (int)threadIdx.x, upr) * upr) << 2;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            rb[j] = rc.b ? rc.b[c0 + j] : 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) rw[j][k] = k < rc.cin ? rc.w[(long long)(c0 + j) * rc.ld + k] : 0.f;
+        }
+    }
     for (int u0 = u_begin + threadIdx.x; u0 < u_end; u0 += 1024) {
         if (u0 != u_begin + (int)threadIdx.x) {
 #pragma unroll
@@ -164,7 +187,21 @@ __global__ __launch_bounds__(256) void gn_apply_parts_kernel(const float* __rest
                 y.x += t.x; y.y += t.y; y.z += t.z; y.w += t.w;
             }
             const long long o = base + (long long)u * 4;
-            if (addend) {
+            if (RC) {
+                const float* xs = rc.x + ((long long)b * HW + div_upr(u, upr)) * rc.cin;
+                float xv[8];
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) xv[kk] = kk < rc.cin ? xs[kk] : 0.f;
+                float r[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float a = rb[j];
+#pragma unroll
+                    for (int kk = 0; kk < 8; ++kk) a += xv[kk] * rw[j][kk];
+                    r[j] = a;
+                }
+                y.x += r[0]; y.y += r[1]; y.z += r[2]; y.w += r[3];
+            } else if (addend) {
                 const float4 r = *reinterpret_cast<const float4*>(addend + o);
                 y.x += r.x; y.y += r.y; y.z += r.z; y.w += r.w;
             }
@@ -175,7 +212,7 @@ __global__ __launch_bounds__(256) void gn_apply_parts_kernel(const float* __rest
 
 int groupnorm_mish_parts(const float* x, const float* part, int np, const float* gamma, const float* beta, const float* temb,
                          int temb_stride, const float* addend, float* out, int B, int HW, int C, int groups, float eps, hipStream_t st,
-                         const long long* temb_rows) {
+                         const long long* temb_rows, const float* rc_x, const float* rc_w, const float* rc_b, int rc_cin, int rc_ld) {
     DDK_REQUIRE(x && part && gamma && beta && out, "groupnorm_mish_partials: null pointer");
     DDK_REQUIRE(B > 0 && HW > 0 && groups > 0 && groups <= 128 && C % groups == 0 && (C / groups) % 4 == 0,
                 "groupnorm_mish_partials: C must split into <= 128 groups of a multiple of 4 channels");
@@ -188,8 +225,18 @@ int groupnorm_mish_parts(const float* x, const float* part, int np, const float*
     while ((long long)wpi * B > 2048 && wpi > 1) wpi = (wpi + 1) / 2;   // ... unless that makes more than ~8 workgroups per CU
     const int upw = (int)(ceil_div(ceil_div(units, wpi), 256) * 256);
     wpi = (int)ceil_div(units, upw);
-    hipLaunchKernelGGL(gn_apply_parts_kernel, dim3((unsigned)(B * wpi)), dim3(256), 0, st, x, reinterpret_cast<const float2*>(part), np, gamma,
-                       beta, temb, temb_stride, temb_rows, addend, out, HW, C, C / groups, eps, wpi, upw);
+    Res1x1 rc{rc_x, rc_w, rc_b, rc_cin, rc_ld};
+    if (rc_x) {
+        const int upr = C / 4;
+        DDK_REQUIRE(!addend && rc_w && rc_cin >= 1 && rc_cin <= 8 && rc_ld >= rc_cin, "groupnorm_mish_partials: 1x1 addend needs "
+                    "1 <= C_in <= 8, its weights, and no tensor addend");
+        DDK_REQUIRE(upr <= 256 && 256 % upr == 0, "groupnorm_mish_partials: 1x1 addend needs C/4 to divide 256");
+        hipLaunchKernelGGL(gn_apply_parts_kernel<true>, dim3((unsigned)(B * wpi)), dim3(256), 0, st, x, reinterpret_cast<const float2*>(part),
+                           np, gamma, beta, temb, temb_stride, temb_rows, addend, out, HW, C, C / groups, eps, wpi, upw, rc);
+    } else {
+        hipLaunchKernelGGL(gn_apply_parts_kernel<false>, dim3((unsigned)(B * wpi)), dim3(256), 0, st, x, reinterpret_cast<const float2*>(part),
+                           np, gamma, beta, temb, temb_stride, temb_rows, addend, out, HW, C, C / groups, eps, wpi, upw, rc);
+    }
     return check_launch("gn_apply_parts_kernel");
 }
 
@@ -540,6 +587,12 @@ int ddk_groupnorm_mish_partials(const float* x, const float* partials, int tiles
                                 int groups, float eps, ddk_stream_t s) {
     return ddk::groupnorm_mish_parts(x, partials, tiles_per_image, gamma, beta, temb, temb_stride, addend, out, B, HW, C, groups, eps,
                                      ddk::as_stream(s));
+}
+int ddk_groupnorm_mish_partials_res1x1(const float* x, const float* partials, int tiles_per_image, const float* gamma, const float* beta,
+                                       const float* temb, int temb_stride, const float* res_x, const float* res_w, const float* res_b,
+                                       int res_cin, float* out, int B, int HW, int C, int groups, float eps, ddk_stream_t s) {
+    return ddk::groupnorm_mish_parts(x, partials, tiles_per_image, gamma, beta, temb, temb_stride, nullptr, out, B, HW, C, groups, eps,
+                                     ddk::as_stream(s), nullptr, res_x, res_w, res_b, res_cin, res_cin);
 }
 int ddk_chan_layernorm(const float* x, const float* g, const float* b, float* out, long long M, int C, float eps, ddk_stream_t s) {
     return ddk::chan_layernorm(x, g, b, out, M, C, eps, ddk::as_stream(s));

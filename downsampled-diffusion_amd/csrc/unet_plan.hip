@@ -24,7 +24,7 @@ constexpr float GN_EPS = 1e-5f, LN_EPS = 1e-5f;
 
 static inline int pad32(int c) { return (c + 31) / 32 * 32; }
 
-enum PackKind { PK_COPY = 0, PK_CONV = 1, PK_CONVT = 2, PK_LINEAR_T = 3, PK_WINO = 4, PK_LOCAL = 5, PK_WLOCAL = 6 };
+enum PackKind { PK_COPY = 0, PK_CONV = 1, PK_CONVT = 2, PK_LINEAR_T = 3, PK_WINO = 4, PK_LOCAL = 5, PK_WLOCAL = 6, PK_FIRST = 7 };
 
 struct Slot {
     std::string name;
@@ -45,6 +45,8 @@ struct ConvW {
     bool has_wl = false;
     size_t wwl = 0;         // and its Winograd-domain form for the 8x8 maps (conv3x3_gn_wlocal_kernel); has_wwl
     bool has_wwl = false;
+    size_t wf = 0;          // conv_first.hip's operand-order copy (the network's first conv, C_in <= 8); has_wf
+    bool has_wf = false;
 };
 struct NormW { size_t g = 0, b = 0; };
 struct ResW {
@@ -247,6 +249,14 @@ extern "C" ddk_unet* ddk_unet_create(const ddk_unet_config* cfg) {
         const std::string p = "downs." + std::to_string(l) + ".";
         const int ci = u->dims[l], co = u->dims[l + 1];
         u->down_res.push_back(u->add_res(p + "0.", ci, co, cur));
+        if (l == 0 && ci <= 8 && co <= 256) {
+            // the network's first conv also gets conv_first.hip's layout (K = 9 * C_in exactly, unpadded input)
+            ConvW& c1 = u->down_res[0].c1;
+            const int K2 = (9 * ci + 1) / 2;
+            c1.wf = u->alloc((size_t)(co / 32) * K2 * 64);
+            c1.has_wf = true;
+            u->slots.push_back(Slot{p + "0.block1.block.0.weight", (long long)co * ci * 9, PK_FIRST, c1.wf, co, ci, 3, 3, 0, 0, 0});
+        }
         u->down_res.push_back(u->add_res(p + "1.", co, co, cur));
         u->down_attn.push_back(u->add_attn(p + "2.", co));
         if (l < u->L - 1) u->down_conv.push_back(u->add_conv(p + "3.conv.", co, co, 3, true));
@@ -368,6 +378,7 @@ extern "C" int ddk_unet_pack_slot(const ddk_unet* u, int slot, const float* cano
         case PK_WINO: rc = ddk_pack_conv_weight_wino(canonical, dst, sl.O, sl.I, sl.i_pad, s); break;
         case PK_LOCAL: rc = ddk_pack_conv_weight_local(canonical, dst, sl.O, sl.I, sl.i_pad, s); break;
         case PK_WLOCAL: rc = ddk_pack_conv_weight_wino_local(canonical, dst, sl.O, sl.I, sl.i_pad, s); break;
+        case PK_FIRST: rc = ddk_pack_conv_weight_first(canonical, dst, sl.O, sl.I, s); break;
         default: return fail_arg("unet_pack_slot: slot kind");
     }
     DDK_TRY(rc);
@@ -619,13 +630,72 @@ static int run_attn(Ctx& c, const AttnW& a, const float* x, float* out, int H, i
     return run_conv(c, DDK_CONV1X1, a.out, o, HIDDEN, nullptr, 0, x, out, H, W, a.c);
 }
 
-// xpad: NHWC input already zero-padded to pad32(in_ch) channels.
+// What a reverse step of the sampler adds to a forward: the bookkeeping in front (t_cur[b] <- counter; counter -= 1) and the
+// update of x behind it (ddpm.py:203-227).  Both ride on the forward's own first / last kernel where the shape allows.
+struct StepArgs {
+    int64_t* state;               // [0] step counter, [1] Philox seed, [2] stream id
+    float* x;                     // chain state, updated in place
+    float* eps_hat;               // scratch for the unfused tail
+    const float* noise;
+    long long noise_step_stride;
+    int t_first;
+    const float *c_recip, *c_recipm1, *c1, *c2, *sigma;
+    long long per;
+};
+
+// t_cur[b] = counter for every sample, then counter -= 1; also zero-pads x into xpad.  First kernel of a step on shapes the
+// first-layer kernel does not take: the previous step's kernels have all completed (stream order), nobody else reads the counter.
+__global__ __launch_bounds__(256) void step_prepare_kernel(const float* __restrict__ x, float* __restrict__ xpad, long long total,
+                                                           int C, int c_pad, int64_t* __restrict__ counter,
+                                                           int64_t* __restrict__ t_cur, int B) {
+    if (blockIdx.x == 0) {
+        const int64_t v = *counter;
+        for (int b = threadIdx.x; b < B; b += blockDim.x) t_cur[b] = v;
+        __syncthreads();
+        if (threadIdx.x == 0) *counter = v - 1;
+    }
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int ch = (int)(i % c_pad);
+        const long long m = i / c_pad;
+        xpad[i] = ch < C ? x[m * C + ch] : 0.f;
+    }
+}
+
+// The first ResnetBlock on the unpadded input: conv_first.hip for its first conv, and its 1x1 res_conv evaluated inside the
+// second GroupNorm launch (norm_act.hip, Res1x1) -- no pad kernel, no padded 32-channel conv, no res_conv launch.  Needs the
+// second conv to leave GroupNorm partials (one-pass Winograd shape).
+static bool first_fast(const ddk_unet& u, int B, int H, int W) {
+    const ResW& r = u.down_res[0];
+    if (!r.c1.has_wf || !r.has_res || !r.c2.has_wu) return false;
+    if (!conv_first_ok(r.ci, r.co, H, W, GROUPS)) return false;
+    const int upr = r.co / 4;
+    if (upr > 256 || 256 % upr) return false;
+    if ((long long)H * W / 128 * GROUPS > 1024) return false;
+    return conv_wino_stats_parts(B, H, W, r.co, r.co, GROUPS) > 0;
+}
+
+// x: NHWC input, unpadded ([B][H0][W0][in_ch]).
 // temb_table != nullptr (sampler): the per-block time shifts of EVERY timestep were computed once up front
 // (build_temb_table); row t[b] of the table is read directly by the GroupNorm kernels and no time kernel runs per step.
-static int forward_core(const ddk_unet& u, const float* P, const float* xpad, const int64_t* t, float* out, int B, int H0, int W0,
-                        float* ws, const Layout& ly, hipStream_t st, const float* temb_table = nullptr) {
+// step != nullptr (sampler): t is the t_cur array the step's first kernel fills from step->state, and the forward ends with
+// the update of step->x instead of writing eps_hat to `out`.
+static int forward_core(const ddk_unet& u, const float* P, const float* x, int64_t* t, float* out, int B, int H0, int W0,
+                        float* ws, const Layout& ly, hipStream_t st, const float* temb_table = nullptr, const StepArgs* step = nullptr) {
     float* tact = ws + ly.off_tact;
     float* temb = ws + ly.off_temb;
+    float* xpad = ws + ly.off_xpad;
+    const bool fast0 = first_fast(u, B, H0, W0);
+    if (!fast0) {
+        const int C = u.cfg.in_ch, cp = pad32(C);
+        const long long padded = (long long)B * H0 * W0 * cp;
+        if (step) {
+            const int prep_blocks = (int)(ceil_div(padded, 256) < 1024 ? ceil_div(padded, 256) : 1024);
+            hipLaunchKernelGGL(step_prepare_kernel, dim3(prep_blocks), dim3(256), 0, st, x, xpad, padded, C, cp, step->state, t, B);
+            DDK_TRY(check_launch("step_prepare_kernel"));
+        } else {
+            DDK_TRY(ddk_pad_channels(x, xpad, (long long)B * H0 * W0, C, cp, st));
+        }
+    }
     if (!temb_table) {
         DDK_TRY(time_mlp(t, P + u.freqs, P + u.w1t, P + u.b1, P + u.w2t, P + u.b2, tact, nullptr, B, u.time_dim, st));
         DDK_TRY(time_proj(tact, P + u.temb_wt, P + u.temb_bias, temb, B, u.time_dim, u.temb_total, st));
@@ -635,6 +705,9 @@ static int forward_core(const ddk_unet& u, const float* P, const float* xpad, co
     float* bufA = ws + ly.off_A;
     float* bufB = ws + ly.off_B;
     float* bufC = ws + ly.off_C;
+    float* raw = ws + ly.off_raw;
+    float* a1 = ws + ly.off_a1;
+    float* gnp = ws + ly.off_gn;
 
     int H = H0, W = W0;
     const float* cur = xpad;
@@ -642,7 +715,29 @@ static int forward_core(const ddk_unet& u, const float* P, const float* xpad, co
     for (int l = 0; l < u.L; ++l) {
         float* skip = ws + ly.off_skip[l];
         const int co = u.dims[l + 1];
-        DDK_TRY(run_res(c, u.down_res[2 * l], cur, cur_c, nullptr, 0, bufB, H, W));
+        if (l == 0 && fast0) {
+            const ResW& r = u.down_res[0];
+            DDK_TRY(conv_first(x, P + r.c1.wf, r.c1.has_bias ? P + r.c1.b : nullptr, raw, gnp, B, H, W, r.ci, r.co, GROUPS,
+                               step ? step->state : nullptr, step ? t : nullptr, st));
+            DDK_TRY(groupnorm_mish_parts(raw, gnp, H * W / 128, P + r.n1.g, P + r.n1.b, c.temb + r.temb_off, u.temb_total, nullptr, a1, B,
+                                         H * W, r.co, GROUPS, GN_EPS, st, c.temb_rows));
+            ddk_conv_args a{};
+            a.kind = DDK_CONV3X3_S1;
+            a.src0 = a1; a.c0 = r.co;
+            a.weight = P + r.c2.w;
+            a.weight_wino = P + r.c2.wu;
+            a.bias = r.c2.has_bias ? P + r.c2.b : nullptr;
+            a.out = raw;
+            a.B = B; a.H = H; a.W = W; a.N = r.co;
+            a.gn_partials = gnp;
+            a.gn_groups = GROUPS;
+            DDK_TRY(conv_forward(a, st));
+            DDK_TRY(groupnorm_mish_parts(raw, gnp, conv_wino_stats_parts(B, H, W, r.co, r.co, GROUPS), P + r.n2.g, P + r.n2.b, nullptr,
+                                         u.temb_total, nullptr, bufB, B, H * W, r.co, GROUPS, GN_EPS, st, nullptr, x, P + r.res.w,
+                                         r.res.has_bias ? P + r.res.b : nullptr, r.ci, r.res.cin_pad));
+        } else {
+            DDK_TRY(run_res(c, u.down_res[2 * l], cur, cur_c, nullptr, 0, bufB, H, W));
+        }
         DDK_TRY(run_res(c, u.down_res[2 * l + 1], bufB, co, nullptr, 0, bufC, H, W));
         DDK_TRY(run_attn(c, u.down_attn[l], bufC, skip, H, W));
         if (l < u.L - 1) {
@@ -671,10 +766,34 @@ static int forward_core(const ddk_unet& u, const float* P, const float* xpad, co
         cur_c = din;
     }
     // final_conv: Block(dim, dim) then 1x1 to in_ch (unet.py:69-72)
-    float* raw = ws + ly.off_raw;
-    float* a1 = ws + ly.off_a1;
-    DDK_TRY(run_conv_gn(c, u.final_conv, cur, cur_c, nullptr, 0, raw, u.final_norm, nullptr, nullptr, a1, H, W, u.cfg.chan));
-    return conv1x1_small_n(a1, P + u.final_w, P + u.final_b, out, (long long)B * H * W, u.cfg.chan, u.cfg.in_ch, st);
+    const int chan = u.cfg.chan, n_out = u.cfg.in_ch;
+    const int npf = u.final_conv.has_wu ? conv_wino_stats_parts(B, H, W, cur_c, chan, GROUPS) : 0;
+    if (npf > 0 && final_tail_ok(H * W, chan, GROUPS, n_out, npf) && (!step || step->per == (long long)H * W * n_out)) {
+        // one-pass Winograd conv with statistics, then GroupNorm + Mish + projection (+ the update of x) in ONE launch
+        ddk_conv_args a{};
+        a.kind = DDK_CONV3X3_S1;
+        a.src0 = cur; a.c0 = cur_c;
+        a.weight = P + u.final_conv.w;
+        a.weight_wino = P + u.final_conv.wu;
+        a.bias = u.final_conv.has_bias ? P + u.final_conv.b : nullptr;
+        a.out = raw;
+        a.B = B; a.H = H; a.W = W; a.N = chan;
+        a.gn_partials = gnp;
+        a.gn_groups = GROUPS;
+        DDK_TRY(conv_forward(a, st));
+        if (step)
+            return final_tail(raw, gnp, npf, P + u.final_norm.g, P + u.final_norm.b, GN_EPS, P + u.final_w, P + u.final_b, n_out, nullptr,
+                              step->x, step->noise, step->noise_step_stride, step->t_first, t, step->c_recip, step->c_recipm1, step->c1,
+                              step->c2, step->sigma, step->state, 0, 0, B, H * W, chan, GROUPS, st);
+        return final_tail(raw, gnp, npf, P + u.final_norm.g, P + u.final_norm.b, GN_EPS, P + u.final_w, P + u.final_b, n_out, out, nullptr,
+                          nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, B, H * W, chan, GROUPS, st);
+    }
+    DDK_TRY(run_conv_gn(c, u.final_conv, cur, cur_c, nullptr, 0, raw, u.final_norm, nullptr, nullptr, a1, H, W, chan));
+    float* eps_hat = step ? step->eps_hat : out;
+    DDK_TRY(conv1x1_small_n(a1, P + u.final_w, P + u.final_b, eps_hat, (long long)B * H * W, chan, n_out, st));
+    if (!step) return DDK_OK;
+    return p_sample_update(step->x, eps_hat, step->noise, step->noise_step_stride, step->t_first, t, step->c_recip, step->c_recipm1,
+                           step->c1, step->c2, step->sigma, B, step->per, 0, 0, st, step->state);
 }
 
 static int check_shape(const ddk_unet* u, int B, int H, int W) {
@@ -696,24 +815,6 @@ __global__ void set_chain_state_kernel(int64_t* state, int64_t t_start, uint64_t
     state[2] = (int64_t)stream_id;
 }
 
-// t_cur[b] = counter for every sample, then counter -= 1; also zero-pads x into xpad.  First kernel of a
-// step: the previous step's kernels have all completed (stream order), nobody else reads the counter.
-__global__ __launch_bounds__(256) void step_prepare_kernel(const float* __restrict__ x, float* __restrict__ xpad, long long total,
-                                                           int C, int c_pad, int64_t* __restrict__ counter,
-                                                           int64_t* __restrict__ t_cur, int B) {
-    if (blockIdx.x == 0) {
-        const int64_t v = *counter;
-        for (int b = threadIdx.x; b < B; b += blockDim.x) t_cur[b] = v;
-        __syncthreads();
-        if (threadIdx.x == 0) *counter = v - 1;
-    }
-    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int ch = (int)(i % c_pad);
-        const long long m = i / c_pad;
-        xpad[i] = ch < C ? x[m * C + ch] : 0.f;
-    }
-}
-
 }  // namespace ddk
 
 extern "C" size_t ddk_unet_workspace_bytes(const ddk_unet* u, int B, int H, int W) {
@@ -732,9 +833,8 @@ extern "C" int ddk_unet_forward(const ddk_unet* u, const void* packed, const flo
         return DDK_ERR_WORKSPACE;
     }
     float* ws = static_cast<float*>(workspace);
-    float* xpad = ws + ly.off_xpad;
-    DDK_TRY(ddk_pad_channels(x, xpad, (long long)B * H * W, u->cfg.in_ch, pad32(u->cfg.in_ch), s));
-    return forward_core(*u, static_cast<const float*>(packed), xpad, t, out, B, H, W, ws, ly, as_stream(s));
+    DDK_TRY(ensure_device_init());
+    return forward_core(*u, static_cast<const float*>(packed), x, const_cast<int64_t*>(t), out, B, H, W, ws, ly, as_stream(s));
 }
 
 extern "C" double ddk_unet_flops(const ddk_unet* u, int B, int H0, int W0) {
@@ -802,7 +902,7 @@ extern "C" int ddk_sampler_run(const ddk_sampler_args* a, ddk_stream_t s) {
     DDK_TRY(check_shape(&u, a->B, a->H, a->W));
     DDK_REQUIRE(a->t_start >= a->t_end && a->t_end >= 0, "sampler: need t_start >= t_end >= 0");
     DDK_REQUIRE(aligned16(a->packed) && aligned16(a->workspace) && aligned16(a->x) && aligned16(a->noise), "sampler: alignment");
-    const int B = a->B, H = a->H, W = a->W, C = u.cfg.in_ch, cp = pad32(C);
+    const int B = a->B, H = a->H, W = a->W, C = u.cfg.in_ch;
     const long long per = (long long)H * W * C;
     DDK_REQUIRE(per % 4 == 0, "sampler: H*W*in_ch must be a multiple of 4");
     const SamplerLayout sl = sampler_layout(u, B, H, W, a->t_start);
@@ -817,19 +917,13 @@ extern "C" int ddk_sampler_run(const ddk_sampler_args* a, ddk_stream_t s) {
     float* eps_hat = ws + sl.off_eps;
     int64_t* t_cur = reinterpret_cast<int64_t*>(ws + sl.off_t);
     int64_t* state = t_cur + B;                        // [0] step counter, [1] seed, [2] stream id
-    float* xpad = ws + ly.off_xpad;
     const float* P = static_cast<const float*>(a->packed);
     const float* temb_table = ws + sl.off_table;
-    const long long padded = (long long)B * H * W * cp;
-    const int prep_blocks = (int)(ceil_div(padded, 256) < 1024 ? ceil_div(padded, 256) : 1024);
+    const StepArgs step{state, a->x, eps_hat, a->noise, a->noise ? B * per : 0, a->t_start, a->c_recip, a->c_recipm1, a->c1, a->c2,
+                        a->sigma, per};
 
-    auto one_step = [&]() -> int {
-        hipLaunchKernelGGL(step_prepare_kernel, dim3(prep_blocks), dim3(256), 0, st, a->x, xpad, padded, C, cp, state, t_cur, B);
-        DDK_TRY(check_launch("step_prepare_kernel"));
-        DDK_TRY(forward_core(u, P, xpad, t_cur, eps_hat, B, H, W, ws, ly, st, temb_table));
-        return p_sample_update(a->x, eps_hat, a->noise, a->noise ? B * per : 0, a->t_start, t_cur, a->c_recip, a->c_recipm1, a->c1,
-                               a->c2, a->sigma, B, per, 0, 0, st, state);
-    };
+    // one reverse step: bookkeeping (in the forward's first kernel), UNet, update of x (in its last kernel)
+    auto one_step = [&]() -> int { return forward_core(u, P, a->x, t_cur, nullptr, B, H, W, ws, ly, st, temb_table, &step); };
 
     auto capture = [&](int steps, hipGraph_t& graph, hipGraphExec_t& exec) -> int {
         hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);

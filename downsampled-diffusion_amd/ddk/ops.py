@@ -202,6 +202,62 @@ def groupnorm_mish_from_partials(x, part, tiles_per_image, gamma, beta, temb=Non
     return out
 
 
+def pack_conv_weight_first(w):
+    """OIHW 3x3 with 1 <= I <= 8 -> conv_first's operand order [O/32][ceil(9 I / 2)][64] (ddk_pack_conv_weight_first)."""
+    o, i, kh, kw = w.shape
+    if (kh, kw) != (3, 3) or o % 32 or not 1 <= i <= 8:
+        raise L.DDKError("pack_conv_weight_first: kernel must be 3x3, O % 32 == 0, 1 <= I <= 8")
+    out = torch.empty((o // 32, (9 * i + 1) // 2, 64), device=w.device, dtype=torch.float32)
+    L.check(L.load().ddk_pack_conv_weight_first(L.ptr(_f32(w.contiguous())), L.ptr(out), o, i, L.stream()), "pack_conv_weight_first")
+    return out
+
+
+def conv_first(x, w_first, bias, n_out, groups=GN_GROUPS, partials=True):
+    """The network's first 3x3 conv on the unpadded NHWC input (C_in <= 8): -> (raw output, GroupNorm partials or None, tiles per
+    image).  ddk_conv_first."""
+    b, h, w_, cin = x.shape
+    lib = L.load()
+    if not lib.ddk_conv_first_ok(cin, n_out, h, w_, groups):
+        raise L.DDKError(f"conv_first: shape {tuple(x.shape)} -> {n_out} not eligible")
+    raw = torch.empty((b, h, w_, n_out), device=x.device, dtype=torch.float32)
+    tiles = h * w_ // 128
+    part = torch.empty((b * tiles, groups, 2), device=x.device, dtype=torch.float32) if partials else None
+    L.check(lib.ddk_conv_first(L.ptr(_f32(x)), L.ptr(w_first), L.ptr(bias), L.ptr(raw), L.ptr(part), b, h, w_, cin, n_out, groups,
+                               L.stream()), "conv_first")
+    return raw, part, tiles
+
+
+def groupnorm_mish_from_partials_res1x1(x, part, tiles_per_image, gamma, beta, res_x, res_w, res_b, temb=None, groups=GN_GROUPS,
+                                        eps=GN_EPS):
+    """groupnorm_mish_from_partials with the addend res_b + res_x @ res_w^T (a 1x1 conv of a <= 8-channel tensor) computed on the
+    fly (ddk_groupnorm_mish_partials_res1x1)."""
+    b, h, w_, n = x.shape
+    cin = res_x.shape[-1]
+    out = torch.empty_like(x)
+    stride = temb.stride(0) if temb is not None else 0
+    L.check(L.load().ddk_groupnorm_mish_partials_res1x1(
+        L.ptr(_f32(x)), L.ptr(part), tiles_per_image, L.ptr(gamma), L.ptr(beta), temb.data_ptr() if temb is not None else None, stride,
+        L.ptr(_f32(res_x)), L.ptr(res_w.reshape(n, cin).contiguous()), L.ptr(res_b), cin, L.ptr(out), b, h * w_, n, groups, eps,
+        L.stream()), "groupnorm_mish_partials_res1x1")
+    return out
+
+
+def final_tail(raw, part, tiles_per_image, gamma, beta, w, bias, x=None, t=None, tables=None, noise=None, seed=0, stream_id=0,
+               want_eps=True, groups=GN_GROUPS, eps=GN_EPS):
+    """GroupNorm (from conv partials) + Mish + 1x1 projection to n_out <= 8 channels, and -- with x, t, tables -- the in-place
+    reverse-step update of x, in one launch (ddk_final_tail).  Returns eps_hat (or None when want_eps is False)."""
+    b, h, w_, c = raw.shape
+    n_out = w.shape[0]
+    eps_out = torch.empty((b, h, w_, n_out), device=raw.device, dtype=torch.float32) if want_eps else None
+    tb = tables or {}
+    L.check(L.load().ddk_final_tail(L.ptr(_f32(raw)), L.ptr(part), tiles_per_image, L.ptr(gamma), L.ptr(beta), eps,
+                                    L.ptr(w.reshape(n_out, c).contiguous()), L.ptr(bias), n_out, L.ptr(eps_out), L.ptr(x), L.ptr(noise),
+                                    L.ptr(t), L.ptr(tb.get("c_recip")), L.ptr(tb.get("c_recipm1")), L.ptr(tb.get("c1")),
+                                    L.ptr(tb.get("c2")), L.ptr(tb.get("sigma")), seed, stream_id, b, h * w_, c, groups, L.stream()),
+            "final_tail")
+    return eps_out
+
+
 def conv3x3_groupnorm_mish(x, w_packed, bias, gamma, beta, x2=None, temb=None, addend=None, groups=GN_GROUPS, eps=GN_EPS, w_wino=None):
     """conv3x3(pad 1) -> GroupNorm -> Mish (+temb)(+addend), two launches.  When the conv splits k its partial slabs are summed by
     the GroupNorm kernel's load (ddk_groupnorm_mish_slabs) instead of a separate reduce pass.  w_wino: the Winograd-domain filter

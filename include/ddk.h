@@ -133,6 +133,20 @@ int ddk_conv3x3_gn_mish(const float* src0, int c0, const float* src1, int c1, co
 int ddk_groupnorm_mish_partials(const float* x, const float* partials, int tiles_per_image, const float* gamma, const float* beta,
                                 const float* temb, int temb_stride, const float* addend, float* out, int B, int HW, int C,
                                 int groups, float eps, ddk_stream_t s);
+/* The network's first conv (unet.py:43-50, blocks.py:78): Conv2d(C_in, N, 3, padding=1) with 1 <= C_in <= 8 on the UNPADDED NHWC
+ * input x [B][H][W][C_in]; K = 9 * C_in exactly.  w_first = ddk_pack_conv_weight_first(OIHW weight) ((N/32) * ceil(9 C_in / 2) * 64
+ * floats); gn_partials optional: per (128-pixel tile, group) {mean, M2}, B*H*W/128 * groups float pairs, for
+ * ddk_groupnorm_mish_partials.  Eligible shapes: ddk_conv_first_ok() != 0 (N % 32 == 0, N <= 256, H*W % 128 == 0). */
+int ddk_pack_conv_weight_first(const float* w_oihw, float* dst, int O, int I, ddk_stream_t s);
+int ddk_conv_first_ok(int cin, int N, int H, int W, int groups);
+int ddk_conv_first(const float* x, const float* w_first, const float* bias, float* out, float* gn_partials, int B, int H, int W,
+                   int cin, int N, int groups, ddk_stream_t s);
+/* ddk_groupnorm_mish_partials whose addend is a 1x1 conv of a narrow tensor, evaluated on the fly (the first ResnetBlock's
+ * res_conv, blocks.py:103,115): out = Mish(GN(x)) [+ temb] + (res_b[c] + sum_k res_x[pix][k] res_w[c][k]), res_x [B*HW][res_cin],
+ * res_w [C][res_cin] (the OIHW 1x1 weight as is), 1 <= res_cin <= 8; C/4 must divide 256. */
+int ddk_groupnorm_mish_partials_res1x1(const float* x, const float* partials, int tiles_per_image, const float* gamma, const float* beta,
+                                       const float* temb, int temb_stride, const float* res_x, const float* res_w, const float* res_b,
+                                       int res_cin, float* out, int B, int HW, int C, int groups, float eps, ddk_stream_t s);
 /* The same Block in one launch for 64-pixel maps (8x8; H, W even), as Winograd F(2x2,3x3) inside an image-local tiling.
  * `weight`: ddk_pack_conv_weight_wino_local (O*16*i_pad floats, O % 32 == 0); cin <= 320. */
 int ddk_pack_conv_weight_wino_local(const float* w_oihw, float* dst, int O, int I, int i_pad, ddk_stream_t s);
@@ -196,6 +210,14 @@ int ddk_p_sample_update(float* x, const float* eps_hat, const float* noise, cons
                         const float* c_recip, const float* c_recipm1, const float* c1, const float* c2,
                         const float* sigma, int B, long long per, uint64_t seed, uint32_t stream_id,
                         ddk_stream_t s);
+/* The end of a forward in one launch (unet.py:69-72 behind the final Block's conv; ddpm.py:203-227): GroupNorm from the conv's
+ * partials -> Mish -> 1x1 projection to n_out <= 8 channels (w [n_out][C], bias [n_out]) -> eps_hat; eps_out and / or x may be
+ * given: eps_out [B][HW][n_out] receives eps_hat, x [B][HW][n_out] gets the reverse-step update of ddk_p_sample_update in place
+ * (bit-identical to it given the same eps_hat).  C in {32, 64, 128, 256}, HW == tiles_per_image * 128. */
+int ddk_final_tail(const float* raw, const float* partials, int tiles_per_image, const float* gamma, const float* beta, float eps,
+                   const float* w, const float* bias, int n_out, float* eps_out, float* x, const float* noise, const int64_t* t,
+                   const float* c_recip, const float* c_recipm1, const float* c1, const float* c2, const float* sigma, uint64_t seed,
+                   uint32_t stream_id, int B, int HW, int C, int groups, ddk_stream_t s);
 /* out[i] ~ N(0,1): Philox4x32-10 + Box-Muller, counter (i/4, step, stream_id)  (ddpm.py:241). */
 int ddk_randn(float* out, long long n, uint64_t seed, uint32_t step, uint32_t stream_id, ddk_stream_t s);
 /* Sampler output stage (utils/eval_helpers.py:37-41): per-image min-max over C*H*W, x255, NCHW -> NHWC:

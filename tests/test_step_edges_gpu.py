@@ -1,0 +1,168 @@
+"""The first and last kernels of a reverse step (round 3): the small-C_in first conv on the unpadded input (conv_first.hip), the
+first ResnetBlock's 1x1 res_conv evaluated inside the GroupNorm launch, and GroupNorm + Mish + final 1x1 projection + reverse-step
+update in one launch (final_tail_kernel), each through the C ABI against plain torch-CPU fp32 / the oracle on the same seeded inputs.
+Reference: models/unet/unet.py:43-50,69-72, models/unet/blocks.py:74-84,103-115, models/diffusion/ddpm.py:203-227."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import rel_err, to_nchw, to_nhwc
+from oracle import diffusion_ref as D
+from oracle import philox_ref
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from ddk import ops as o
+    from ddk import lib
+    assert lib.load().ddk_device_ok() == 1, lib.last_error()
+    return o
+
+
+def gn_mish(x, gamma, beta, groups=8):
+    return F.mish(F.group_norm(x, groups, gamma, beta, 1e-5))
+
+
+FIRST_CASES = [
+    # B, H, W, cin, N
+    (2, 16, 16, 1, 32), (2, 16, 16, 3, 64), (3, 16, 8, 8, 128), (2, 32, 32, 2, 96), (1, 16, 24, 5, 160), (2, 16, 16, 7, 256),
+    (32, 32, 32, 8, 128),     # cfg4
+    (64, 32, 32, 3, 128),     # cfg2
+    (16, 32, 32, 1, 128),     # cfg1
+    (64, 16, 16, 8, 128),     # cfg3
+    (1, 8, 16, 4, 64), (2, 32, 32, 6, 128),
+]
+
+
+@pytest.mark.parametrize("B,H,W,cin,N", FIRST_CASES)
+def test_conv_first_and_partials(ops, B, H, W, cin, N):
+    """conv_first == F.conv2d(padding=1) on the unpadded input; its partials drive GroupNorm+Mish(+shift) == torch"""
+    x = rnd(B, cin, H, W, seed=1 + cin) + 0.3
+    w = rnd(N, cin, 3, 3, seed=2 + cin, scale=(cin * 9) ** -0.5)
+    b = rnd(N, seed=3)
+    ref = F.conv2d(x, w, b, padding=1)
+    raw, part, tiles = ops.conv_first(to_nhwc(x).to(DEV), ops.pack_conv_weight_first(w.to(DEV)), b.to(DEV), N)
+    assert tiles == H * W // 128
+    assert rel_err(to_nchw(raw.cpu()), ref) < 2e-5
+    # run-to-run bit stability
+    raw2, part2, _ = ops.conv_first(to_nhwc(x).to(DEV), ops.pack_conv_weight_first(w.to(DEV)), b.to(DEV), N)
+    assert torch.equal(raw, raw2) and torch.equal(part, part2)
+    # partials: {mean, M2} per (128-pixel tile, group) of the output
+    cpg = N // 8
+    t = to_nhwc(ref).reshape(B * tiles, 128, 8, cpg).permute(0, 2, 1, 3).reshape(B * tiles, 8, 128 * cpg).double()
+    mean = t.mean(-1)
+    m2 = ((t - mean[..., None]) ** 2).sum(-1)
+    assert (part[..., 0].cpu().double() - mean).abs().max() < 2e-5 * ref.abs().max()
+    assert rel_err(part[..., 1].cpu(), m2) < 1e-4
+    gamma, beta, temb = 1 + 0.1 * rnd(N, seed=5), 0.1 * rnd(N, seed=6), rnd(B, N, seed=7)
+    out = ops.groupnorm_mish_from_partials(raw, part, tiles, gamma.to(DEV), beta.to(DEV), temb=temb.to(DEV))
+    want = gn_mish(ref, gamma, beta) + temb[:, :, None, None]
+    assert rel_err(to_nchw(out.cpu()), want) < 2e-5
+
+
+def test_conv_first_offset_mean(ops):
+    """|mean| >> std: the pairwise {mean, M2} merge does not cancel"""
+    B, H, W, cin, N = 2, 16, 16, 8, 128
+    x = rnd(B, cin, H, W, seed=11) * 0.01
+    w = rnd(N, cin, 3, 3, seed=12, scale=0.1)
+    b = torch.full((N,), 100.0)
+    ref = F.conv2d(x, w, b, padding=1)
+    raw, part, tiles = ops.conv_first(to_nhwc(x).to(DEV), ops.pack_conv_weight_first(w.to(DEV)), b.to(DEV), N)
+    gamma, beta = torch.ones(N), torch.zeros(N)
+    out = ops.groupnorm_mish_from_partials(raw, part, tiles, gamma.to(DEV), beta.to(DEV))
+    want = gn_mish(ref.double(), gamma.double(), beta.double()).float()
+    assert rel_err(to_nchw(out.cpu()), want) < 2e-3      # the fp32 input itself carries ~1e-7 * 100 / 0.003 of relative noise
+
+
+@pytest.mark.parametrize("B,H,W,cin,N", [(2, 16, 16, 3, 64), (32, 32, 32, 8, 128), (4, 16, 16, 1, 128), (2, 16, 16, 8, 256), (2, 16, 32, 5, 32)])
+def test_groupnorm_res1x1_addend(ops, B, H, W, cin, N):
+    """out = Mish(GN(h)) + res_conv(x): the 1x1 conv of the <= 8-channel input evaluated inside the GroupNorm launch"""
+    x = rnd(B, cin, H, W, seed=21)
+    h_in = rnd(B, 4, H, W, seed=22)
+    w3 = rnd(N, 4, 3, 3, seed=23, scale=(4 * 9) ** -0.5)
+    b3 = rnd(N, seed=24)
+    wr, br = rnd(N, cin, 1, 1, seed=25, scale=cin ** -0.5), rnd(N, seed=26)
+    gamma, beta = 1 + 0.1 * rnd(N, seed=27), 0.1 * rnd(N, seed=28)
+    conv = F.conv2d(h_in, w3, b3, padding=1)
+    want = gn_mish(conv, gamma, beta) + F.conv2d(x, wr, br)
+    raw, part, tiles = ops.conv_first(to_nhwc(h_in).to(DEV), ops.pack_conv_weight_first(w3.to(DEV)), b3.to(DEV), N)
+    out = ops.groupnorm_mish_from_partials_res1x1(raw, part, tiles, gamma.to(DEV), beta.to(DEV), to_nhwc(x).to(DEV), wr.to(DEV), br.to(DEV))
+    assert rel_err(to_nchw(out.cpu()), want) < 2e-5
+    temb = rnd(B, N, seed=29)
+    out = ops.groupnorm_mish_from_partials_res1x1(raw, part, tiles, gamma.to(DEV), beta.to(DEV), to_nhwc(x).to(DEV), wr.to(DEV), None,
+                                                  temb=temb.to(DEV))
+    assert rel_err(to_nchw(out.cpu()), gn_mish(conv, gamma, beta) + temb[:, :, None, None] + F.conv2d(x, wr)) < 2e-5
+
+
+def _tables():
+    buf = D.schedule_buffers("linear", 1000)
+    sigma = torch.exp(0.5 * buf["posterior_log_variance_clipped"])
+    tb = {k: buf[v].to(DEV) for k, v in (("c_recip", "sqrt_recip_alphas_cumprod"), ("c_recipm1", "sqrt_recipm1_alphas_cumprod"),
+                                         ("c1", "posterior_mean_coef1"), ("c2", "posterior_mean_coef2"))}
+    tb["sigma"] = sigma.to(DEV)
+    return buf, tb
+
+
+@pytest.mark.parametrize("B,H,W,C,n_out", [(2, 16, 16, 32, 3), (2, 16, 16, 64, 1), (32, 32, 32, 128, 8), (3, 16, 8, 128, 3),
+                                           (2, 16, 16, 256, 8), (2, 32, 32, 128, 5)])
+def test_final_tail(ops, B, H, W, C, n_out):
+    """GroupNorm + Mish + 1x1 projection (+ reverse-step update) in one launch == the separate kernels / torch"""
+    h_in = rnd(B, 8, H, W, seed=31)
+    w3 = rnd(C, 8, 3, 3, seed=32, scale=(8 * 9) ** -0.5)
+    b3 = rnd(C, seed=33)
+    gamma, beta = 1 + 0.1 * rnd(C, seed=34), 0.1 * rnd(C, seed=35)
+    wf, bf = rnd(n_out, C, 1, 1, seed=36, scale=C ** -0.5), rnd(n_out, seed=37)
+    raw, part, tiles = ops.conv_first(to_nhwc(h_in).to(DEV), ops.pack_conv_weight_first(w3.to(DEV)), b3.to(DEV), C)
+    eps_ref = F.conv2d(gn_mish(F.conv2d(h_in, w3, b3, padding=1), gamma, beta), wf, bf)
+    eps = ops.final_tail(raw, part, tiles, gamma.to(DEV), beta.to(DEV), wf.to(DEV), bf.to(DEV))
+    assert rel_err(to_nchw(eps.cpu()), eps_ref) < 2e-5
+    # the unfused kernels give the same eps_hat up to summation order
+    a1 = ops.groupnorm_mish_from_partials(raw, part, tiles, gamma.to(DEV), beta.to(DEV))
+    eps2 = ops.conv1x1_small_n(a1, wf.to(DEV), bf.to(DEV))
+    assert rel_err(eps.cpu(), eps2.cpu()) < 5e-6
+    # with the update: bit-identical to p_sample_update on the eps_hat the same launch reports (injected noise and Philox)
+    buf, tb = _tables()
+    x0 = rnd(B, H, W, n_out, seed=38, scale=1.5)
+    t = torch.tensor([0, 1, 500, 999] * 8)[:B]
+    z = rnd(B, H, W, n_out, seed=39)
+    xa = x0.to(DEV).clone()
+    eps3 = ops.final_tail(raw, part, tiles, gamma.to(DEV), beta.to(DEV), wf.to(DEV), bf.to(DEV), x=xa, t=t.to(DEV), tables=tb,
+                          noise=z.to(DEV))
+    assert torch.equal(eps3, eps)
+    xb = ops.p_sample_update_(x0.to(DEV).clone(), eps, t.to(DEV), noise=z.to(DEV), **tb)
+    assert torch.equal(xa, xb)
+    if (H * W * n_out) % 4 == 0:
+        seed, stream = 0x1234567887654321, 3
+        xa = x0.to(DEV).clone()
+        ops.final_tail(raw, part, tiles, gamma.to(DEV), beta.to(DEV), wf.to(DEV), bf.to(DEV), x=xa, t=t.to(DEV), tables=tb, seed=seed,
+                       stream_id=stream, want_eps=False)
+        xb = ops.p_sample_update_(x0.to(DEV).clone(), eps, t.to(DEV), seed=seed, stream_id=stream, **tb)
+        assert torch.equal(xa, xb)
+
+
+def test_unet_forward_takes_the_fast_edges():
+    """The plan's eager forward (first-layer kernel + res1x1 addend + fused tail) against the oracle at full width, C_in = 8 and 3"""
+    from helpers import det_state, unet_cfg
+    from models import Unet
+    from oracle import unet_ref as U
+    from utils import synthetic as syn
+    for cin in (8, 3):
+        cfg = unet_cfg(128, cin)
+        net = Unet(cfg)
+        sd = det_state({k: v.shape for k, v in net.state_dict().items()})
+        net.load_state_dict(sd)
+        net = net.to(DEV).eval()
+        x = syn.synthetic_normal((2, cin, 32, 32), f"edges.x{cin}")
+        t = torch.tensor([3, 977])
+        with torch.no_grad():
+            y = net(x.to(DEV), t.to(DEV)).cpu()
+        ref = U.unet_forward(sd, cfg, x, t)
+        assert rel_err(y, ref) < 5e-5
