@@ -865,6 +865,57 @@ extern "C" double ddk_unet_flops(const ddk_unet* u, int B, int H0, int W0) {
     return f;
 }
 
+// MFMA / FMA FLOPs the plan's kernels really issue for one forward: the same walk as ddk_unet_flops, but every 3x3 stride-1
+// conv is priced by the kernel the plan dispatches it to -- Winograd F(2x2,3x3) forms issue 16 multiplies per 2x2 output tile
+// instead of 36 (conv_wino.hip, conv3x3_gn_wlocal_kernel), m tiles are padded to 32 tiles, input channels to 32 -- so that
+// executed / time / peak is a fraction of the matrix pipe's peak (<= 1 by construction).
+extern "C" double ddk_unet_flops_executed(const ddk_unet* u, int B, int H0, int W0) {
+    if (check_shape(u, B, H0, W0) != DDK_OK) return 0;
+    double f = 0;
+    auto conv3 = [&](const ConvW& cw, int H, int W, int c0, int c1, int N, bool gn) {
+        const int cin = c0 + c1;
+        if (gn && cw.has_wl && H * W == 16 && conv_gn_local_ok(H, W, cin, c0, N, GROUPS)) return 2.0 * B * H * W * 9.0 * cin * N;
+        if (gn && cw.has_wwl && H * W == 64 && conv_gn_wlocal_ok(H, W, cin, c0, N, GROUPS)) return 2.0 * B * (H * W / 4) * 16.0 * cin * N;
+        if (use_wino(cw, H, W, cin, N)) return 2.0 * (double)(ceil_div((long long)B * (H / 2) * (W / 2), 32) * 32) * 16.0 * cin * N;
+        return 2.0 * B * H * W * 9.0 * cin * N;
+    };
+    auto res = [&](const ResW& r, int H, int W, int c0, int c1, bool fast) {
+        if (fast) {
+            f += 2.0 * B * H * W * (2.0 * ((9 * r.ci + 1) / 2)) * r.co;        // conv_first: K = 9 * C_in rounded up to even
+            f += 2.0 * B * H * W * (double)r.ci * r.co;                        // res_conv inside the GroupNorm launch (FMA)
+        } else {
+            f += conv3(r.c1, H, W, c0, c1, r.co, true);
+            if (r.has_res) f += conv_flops(DDK_CONV1X1, B, H, W, c0 + c1, r.co);
+        }
+        f += conv3(r.c2, H, W, r.co, 0, r.co, true);
+    };
+    auto attn = [&](const AttnW& a, int H, int W) {
+        f += conv_flops(DDK_CONV1X1, B, H, W, a.c, 3 * HIDDEN) + conv_flops(DDK_CONV1X1, B, H, W, HIDDEN, a.c);
+        f += 2.0 * 2.0 * B * HEADS * 32.0 * 32.0 * H * W;
+    };
+    int H = H0, W = W0, cur_c = pad32(u->cfg.in_ch);
+    for (int l = 0; l < u->L; ++l) {
+        const int co = u->dims[l + 1];
+        res(u->down_res[2 * l], H, W, cur_c, 0, l == 0 && first_fast(*u, B, H, W));
+        res(u->down_res[2 * l + 1], H, W, co, 0, false);
+        attn(u->down_attn[l], H, W);
+        if (l < u->L - 1) { f += conv_flops(DDK_CONV3X3_S2, B, H, W, co, co); H /= 2; W /= 2; }
+        cur_c = co;
+    }
+    res(u->mid1, H, W, cur_c, 0, false); attn(u->mid_attn, H, W); res(u->mid2, H, W, cur_c, 0, false);
+    for (int i = 0; i < u->L - 1; ++i) {
+        const int lvl = u->L - 1 - i, dout = u->dims[lvl + 1], din = u->dims[lvl];
+        res(u->up_res[2 * i], H, W, cur_c, dout, false);
+        res(u->up_res[2 * i + 1], H, W, din, 0, false);
+        attn(u->up_attn[i], H, W);
+        f += conv_flops(DDK_CONVT4X4_S2, B, H, W, din, din);
+        H *= 2; W *= 2;
+        cur_c = din;
+    }
+    f += conv3(u->final_conv, H, W, cur_c, 0, u->cfg.chan, true) + 2.0 * B * H * W * (double)u->cfg.chan * u->cfg.in_ch;
+    return f;
+}
+
 // ------------------------------------------------------------------------------------------------ sampler
 namespace ddk {
 struct SamplerLayout {

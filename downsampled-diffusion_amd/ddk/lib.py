@@ -108,6 +108,7 @@ SIGNATURES = {
     "ddk_unet_workspace_bytes": (_SZ, [_P, _I, _I, _I]),
     "ddk_unet_forward": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P, _SZ, _P]),
     "ddk_unet_flops": (C.c_double, [_P, _I, _I, _I]),
+    "ddk_unet_flops_executed": (C.c_double, [_P, _I, _I, _I]),
     "ddk_sampler_workspace_bytes": (_SZ, [_P, _I, _I, _I, _I]),
     "ddk_sampler_run": (_I, [C.POINTER(SamplerArgs), _P]),
     "ddk_sampler_invalidate": (_I, [_P]),

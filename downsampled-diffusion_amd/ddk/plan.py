@@ -84,6 +84,10 @@ class UnetPlan:
     def flops(self, b, h, w):
         return self._lib.ddk_unet_flops(self.handle, b, h, w)
 
+    def flops_executed(self, b, h, w):
+        """FLOPs the dispatched kernels issue (Winograd convs: 16/36 of the direct multiplies)."""
+        return self._lib.ddk_unet_flops_executed(self.handle, b, h, w)
+
     def forward_nhwc(self, x, t):
         """x [B,H,W,in_ch] fp32, t [B] int64 -> eps_hat [B,H,W,in_ch]."""
         if self.packed is None:

@@ -22,7 +22,7 @@ import numpy as np
 import torch
 
 from models import DDPM, DownsampleDDPM, Unet
-from parallel import barrier, broadcast_module_, init_from_env, shard_sizes
+from parallel import barrier, broadcast_module_, init_from_env, main_rank_does, shard_sizes
 from utils import (CHECKPOINT_DIR, SAMPLE_DIR, SAMPLE_LATENT_DIR, OutputStage, get_color_channels, get_model_state_dict,
                    load_checkpoint_file, merge_rank_shards)
 from utils import synthetic as syn
@@ -43,7 +43,11 @@ def main():
 
     rank, world = init_from_env()
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if local >= torch.cuda.device_count():       # several ranks rehearsed on one GPU (DDK_DIST_BACKEND=gloo)
+    if local >= torch.cuda.device_count():
+        # several ranks on one GPU only work as a gloo rehearsal: RCCL wants one device per rank and would deadlock or error
+        if world > 1 and torch.distributed.get_backend() != "gloo":
+            raise RuntimeError(f"LOCAL_RANK {local} but only {torch.cuda.device_count()} GPU(s) visible: one process per GPU is "
+                               "required with the nccl (RCCL) backend; set DDK_DIST_BACKEND=gloo to rehearse on one GPU")
         local = 0
     torch.cuda.set_device(local)
     device = f"cuda:{local}"
@@ -109,11 +113,10 @@ def main():
         if world == 1:
             np.save(base, batches, allow_pickle=False)
             return base
+        # per-rank shards on a filesystem rank 0 can read (one node, or a shared mount: merge_rank_shards checks every shard exists)
         np.save(f"{base}.rank{rank}", batches, allow_pickle=False)
         barrier()                                   # every shard is on disk
-        if rank == 0:
-            merge_rank_shards(base, world, remove=not args.keep_shards)
-        barrier()
+        main_rank_does(lambda: merge_rank_shards(base, world, remove=not args.keep_shards) is None, "merge of the sampling shards")
         return base
 
     save_path = save(args.out_dir or SAMPLE_DIR, args.saved_model, sample_list)

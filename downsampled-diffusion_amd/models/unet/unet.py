@@ -91,6 +91,12 @@ class Unet(nn.Module):
             self._plan = UnetPlan(self.in_channels, self.dim, self.dim_mults)
         return self._plan.flops(batch, height, width)
 
+    def flops_executed(self, batch, height, width):
+        """FLOPs the dispatched HIP kernels issue for one forward (Winograd convs: 16/36 of the direct multiplies)."""
+        if self._plan is None:
+            self._plan = UnetPlan(self.in_channels, self.dim, self.dim_mults)
+        return self._plan.flops_executed(batch, height, width)
+
     # ------------------------------------------------------------------ forward
     def _wants_grad(self, x):
         return torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))

@@ -53,9 +53,16 @@ def unflatten_into_(flat, tensors):
     return tensors
 
 
-def broadcast_module_(module, src=0):
-    """C1: rank `src`'s parameters + floating buffers to every rank as one flat bucket.  Returns bytes moved."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+def _active(force):
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return force or dist.get_world_size() > 1
+
+
+def broadcast_module_(module, src=0, force=False):
+    """C1: rank `src`'s parameters + floating buffers to every rank as one flat bucket.  Returns bytes moved.
+    force=True issues the collective even on a world of one rank (tests: walks the RCCL device-tensor path on a 1-GPU box)."""
+    if not _active(force):
         return 0
     tensors = [t for t in module.state_dict().values() if torch.is_floating_point(t)]
     flat = flatten_tensors(tensors)
@@ -64,9 +71,9 @@ def broadcast_module_(module, src=0):
     return flat.numel() * 4
 
 
-def all_reduce_flat_(flat, average=True):
+def all_reduce_flat_(flat, average=True, force=False):
     """C2: sum (then average) a flat gradient bucket over all ranks, in place."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not _active(force):
         return flat
     dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     if average:
@@ -82,3 +89,25 @@ def is_main_rank():
 def barrier():
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.barrier()
+
+
+def main_rank_does(fn, what="rank-0 work"):
+    """Run `fn()` on rank 0 only and make EVERY rank learn whether it worked: rank 0's success / error text is broadcast
+    afterwards, and all ranks raise together when it failed.  A bare barrier behind rank-0-only file I/O hangs the other
+    ranks forever if rank 0 raises (disk full, permissions) before reaching its own barrier.  Returns fn()'s value on rank 0,
+    None elsewhere."""
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    result, err = None, None
+    if is_main_rank():
+        try:
+            result = fn()
+        except Exception as e:      # noqa: BLE001 -- reported to every rank below, then re-raised
+            if not multi:
+                raise
+            err = f"{type(e).__name__}: {e}"
+    if multi:
+        box = [err]
+        dist.broadcast_object_list(box, src=0)
+        if box[0] is not None:
+            raise RuntimeError(f"{what} failed on rank 0: {box[0]}")
+    return result

@@ -11,7 +11,7 @@ import os
 import numpy as np
 import torch
 
-from parallel import all_reduce_flat_, barrier, is_main_rank
+from parallel import all_reduce_flat_, is_main_rank, main_rank_does
 from utils import LOGGING_DIR, min_max_norm_image
 from .ema import EMA
 from .trainer import Trainer
@@ -51,25 +51,24 @@ class TrainerDDPM(Trainer):
     # ------------------------------------------------------------------ checkpoints (trainer_ddpm.py:49-72)
     def save_checkpoint(self) -> None:
         """Rank 0 writes the file (every rank holds the identical replicated state after the all-reduced step); the others
-        wait at a barrier so nobody races ahead into a resume / the next save of the same path."""
-        if not is_main_rank():
-            barrier()
-            return
-        save_data = {
-            'optimizer': self.opt.state_dict(),
-            'model': {k: v.detach().clone() for k, v in self.model.state_dict().items()},
-            'config': self.config,
-            'train_losses': self.train_losses,
-            'step': self.step,
-        }
-        if self.use_ema:
-            save_data['ema_model'] = self.ema.state_dict()
-        tmp = self.checkpoint_name + '.tmp'
-        torch.save(save_data, tmp)
-        os.replace(tmp, self.checkpoint_name)          # never leave a half-written checkpoint behind
-        if self.logger:
-            self.logger.save(self.checkpoint_name, policy='live')
-        barrier()
+        wait for its verdict (parallel.main_rank_does: success or the error text is broadcast, so a failed write raises on
+        every rank instead of leaving them parked at a barrier) -- nobody races ahead into a resume / the next save."""
+        def write():
+            save_data = {
+                'optimizer': self.opt.state_dict(),
+                'model': {k: v.detach().clone() for k, v in self.model.state_dict().items()},
+                'config': self.config,
+                'train_losses': self.train_losses,
+                'step': self.step,
+            }
+            if self.use_ema:
+                save_data['ema_model'] = self.ema.state_dict()
+            tmp = self.checkpoint_name + '.tmp'
+            torch.save(save_data, tmp)
+            os.replace(tmp, self.checkpoint_name)          # never leave a half-written checkpoint behind
+            if self.logger:
+                self.logger.save(self.checkpoint_name, policy='live')
+        main_rank_does(write, "save_checkpoint")
 
     def load_checkpoint(self, checkpoint: dict) -> None:
         self.opt.load_state_dict(checkpoint['optimizer'])
@@ -131,6 +130,12 @@ class TrainerDDPM(Trainer):
                 self._graph = GraphedAccumulation(self.model, self.gradient_accumulate_every).capture(batches)
                 self.opt.zero_grad()      # the warm-up / capture passes accumulated gradients of their own
             except Exception as e:       # noqa: BLE001 -- e.g. a model whose forward synchronises with the host
+                # A silent fall-back to ~3000 eager launches per step is a performance regression nobody would notice:
+                # only config['graph_train'] == 'auto' may degrade; the default (True) treats a failed capture as an error.
+                if self.config.get('graph_train', True) != 'auto':
+                    raise RuntimeError(f"device-graph capture of the training step failed ({type(e).__name__}: {e}); set "
+                                       "config['graph_train'] = 'auto' to fall back to eager launches, or False to disable "
+                                       "graph replay") from e
                 print(f"[trainer] device-graph capture of the training step failed ({type(e).__name__}: {e}); running eagerly")
                 self._graph = False
                 torch.cuda.synchronize()

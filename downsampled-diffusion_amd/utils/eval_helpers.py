@@ -1,5 +1,4 @@
 """Sampler output stage (reference utils/eval_helpers.py:37-41, generate_model_samples.py:48-69)."""
-import glob
 import os
 
 import numpy as np
@@ -64,17 +63,18 @@ def merge_rank_shards(base_path, world, remove=False):
     """Batch-sharded sampling writes ``{base}.rank{r}.npy`` per rank; the evaluator (reference evaluate_ddpm.py:52) loads
     ONE ``{base}.npy``.  Concatenates the shards in rank order (= global batch order: ranks take contiguous runs of the
     job's batches) into that file.  Returns the merged array."""
-    parts = []
+    parts, paths = [], []
     for r in range(world):
         path = f"{base_path}.rank{r}.npy"
         if not os.path.exists(path):
-            raise FileNotFoundError(f"missing sampling shard {path}")
+            raise FileNotFoundError(f"missing sampling shard {path} (the ranks must write to a filesystem rank 0 can read)")
+        paths.append(path)
         a = np.load(path)
         if a.size:
             parts.append(a)
     merged = np.concatenate(parts, axis=0) if parts else np.zeros((0,), dtype=np.float32)
     np.save(base_path, merged, allow_pickle=False)
     if remove:
-        for f in glob.glob(f"{base_path}.rank*.npy"):
-            os.remove(f)
+        for path in paths:          # exactly the shards that were merged: no glob (metacharacters in the name, stale shards of
+            os.remove(path)         # an earlier, larger world are not ours to delete unseen)
     return merged

@@ -265,6 +265,9 @@ int ddk_unet_forward(const ddk_unet* u, const void* packed, const float* x, cons
                      int B, int H, int W, void* workspace, size_t workspace_bytes, ddk_stream_t s);
 /* FLOPs (2*MAC) of one forward for B samples at HxW: the algorithmic work bench.py prices. */
 double ddk_unet_flops(const ddk_unet* u, int B, int H, int W);
+/* FLOPs the plan's kernels really issue for that forward: 3x3 convs dispatched to a Winograd F(2x2,3x3) kernel count 16/36 of
+ * their direct multiplies, tiles / channels padded as launched.  executed / time / peak is a fraction of the MFMA peak. */
+double ddk_unet_flops_executed(const ddk_unet* u, int B, int H, int W);
 
 /* ------------------------------------------------------------------ T-step sampler (ddpm.py:229-249) */
 typedef struct ddk_sampler_args {

@@ -70,3 +70,39 @@ def test_shard_sizes_cover_everything():
             spans = [shard_batch(total, r, world) for r in range(world)]
             assert spans[0][0] == 0 and spans[-1][1] == total
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+
+
+def _worker_main_rank_does(rank, world, port, q):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path[:0] = [os.path.join(os.path.dirname(here), "downsampled-diffusion_amd")]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from parallel import init_from_env, main_rank_does
+    init_from_env("gloo")
+    ok = main_rank_does(lambda: "written", "a write that works")
+    try:
+        main_rank_does(lambda: (_ for _ in ()).throw(OSError("disk full")), "save_checkpoint")
+        raised = None
+    except RuntimeError as e:
+        raised = str(e)
+    q.put((rank, ok, raised))
+    dist.barrier()          # every rank is still in step after the failure
+    dist.destroy_process_group()
+
+
+def test_rank0_failure_raises_on_every_rank_instead_of_hanging():
+    """parallel.main_rank_does: a rank-0-only write that fails must raise on all ranks (a bare barrier behind it would park the
+    others forever) -- the pattern behind TrainerDDPM.save_checkpoint and the sampler's shard merge"""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_main_rank_does, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][1] == "written" and res[1][1] is None
+    for _, _, raised in res:
+        assert raised and "save_checkpoint failed on rank 0" in raised and "disk full" in raised
