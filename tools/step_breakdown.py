@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Per-position breakdown of one sampler reverse step from a rocprofv3 --kernel-trace CSV.
 
-A step = the dispatches from one `step_prepare_kernel` up to (not including) the next.  For every position in the
+A step = the dispatches from the step's first kernel (`conv_first_kernel`, or `step_prepare_kernel` on shapes the first-layer
+kernel does not take) up to (not including) the next.  For every position in the
 step the script prints the kernel, its grid (in workgroups) and the mean duration and mean gap to the previous kernel
 over all complete steps found, then totals per kernel family.   python tools/step_breakdown.py <kernel_trace.csv>"""
 import collections
@@ -19,7 +20,8 @@ def short(name):
 def main(path, out=sys.stdout):
     rows = [r for r in csv.DictReader(open(path)) if r["Kind"] == "KERNEL_DISPATCH"]
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    starts = [i for i, r in enumerate(rows) if "step_prepare_kernel" in r["Kernel_Name"]]
+    first = "conv_first_kernel" if any("conv_first_kernel" in r["Kernel_Name"] for r in rows) else "step_prepare_kernel"
+    starts = [i for i, r in enumerate(rows) if first in r["Kernel_Name"]]
     steps = []
     for a, b in zip(starts, starts[1:]):
         steps.append(rows[a:b])
