@@ -10,9 +10,10 @@
 //   GEMM view: D[n][pixel] = sum_k W[n][k] X[pixel][k],  k = tap * C_in + c,  v_mfma_f32_32x32x2_f32 with the WEIGHTS as the
 //   A operand (rows = output channels) and the gathered input patch as the B operand (columns = pixels): a lane then ends up
 //   with 4 consecutive output channels of its pixel per accumulator quad -> float4 NHWC stores straight from registers.
-//   Workgroup = 128 consecutive pixels (4 waves x 32) x all N channels; a lane gathers its pixel's K values once (they stay in
-//   registers for all N / 32 channel blocks); the packed filter ([N/32][K/2][64 lanes], 36 KB at N = 128, C_in = 8) is staged
-//   in LDS once per workgroup.
+//   Workgroup = 128 consecutive pixels x all N channels, 8 waves = 4 pixel groups of 32 x {even, odd} 32-channel blocks (the two
+//   waves of a SIMD alternate between their MFMA run and their epilogue); a lane gathers its pixel's K values once (they stay in
+//   registers for all its channel blocks); the packed filter ([N/32][K/2][64 lanes], 36 KB at N = 128, C_in = 8) and the tile's
+//   input neighbourhood (in row-major order ONE contiguous range of 130 + 2 W pixels) are staged in LDS once per workgroup.
 //   Epilogue: + bias, stores, and per (128-pixel tile, GroupNorm group) {mean, M2 about that mean} by Chan's pairwise merge
 //   (quad -> 32 lanes -> 4 waves -> quads of the group: one pass, no cancellation), the format gn_apply_parts_kernel consumes.
 //   In the sampler the workgroup 0 also does the step's bookkeeping (t_cur[b] <- counter; counter -= 1): it is the first kernel
@@ -51,40 +52,64 @@ __global__ __launch_bounds__(256) void pack_conv_weight_first_kernel(const float
     }
 }
 
+// One level of the pairwise {mean, M2} merge inside a row of 16 lanes, on the DPP path (no LDS crossbar): CTRL pairs every lane
+// with a partner (an involution), both sides compute the same merged pair.
+template <int CTRL>
+__device__ __forceinline__ float dpp_partner(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+
 template <int CIN>
-__global__ __launch_bounds__(256) void conv_first_kernel(const FirstParams p) {
+__global__ __launch_bounds__(512) void conv_first_kernel(const FirstParams p) {
     constexpr int K = 9 * CIN, K2 = (K + 1) / 2;
+    constexpr int XS = CIN | 1;                      // LDS pixel stride of the staged input: odd -> conflict-free 4-byte gathers
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* wl = smem;                                                 // NB * K2 * 64 floats
-    float2* qs = reinterpret_cast<float2*>(smem + p.NB * K2 * 64);    // [4 waves][N / 4 quads] {mean, M2} over 32 pixels x 4 channels
+    float* bl = smem + p.NB * K2 * 64;                                // N floats: the bias (zeros when there is none)
+    float2* qs = reinterpret_cast<float2*>(bl + p.N);                 // [4 pixel groups][N / 4 quads] {mean, M2} over 32 pixels x 4 channels
+    float* xl = reinterpret_cast<float*>(qs + 4 * (p.N >> 2));       // (130 + 2 W) pixels x XS: the tile's input neighbourhood
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int pl = lane & 31, h = lane >> 5;
+    const int pg = wave & 3, par = wave >> 2;        // 8 waves: pixel group (32 pixels) x parity of the channel blocks it multiplies --
+    const int pl = lane & 31, h = lane >> 5;         // the two waves of a SIMD alternate between their MFMA run and their epilogue
 
     if (p.counter && blockIdx.x == 0) {          // first kernel of a reverse step: nobody else touches the counter now
         const int64_t v = *p.counter;
-        for (int b = tid; b < p.B; b += 256) p.t_cur[b] = v;
+        for (int b = tid; b < p.B; b += 512) p.t_cur[b] = v;
         __syncthreads();
         if (tid == 0) *p.counter = v - 1;
     }
-    {   // the packed filter, once per workgroup
+    // In row-major order the 3x3 neighbourhoods of 128 consecutive pixels of an image are ONE contiguous pixel range,
+    // [first - W - 1, first + 128 + W + 1): staged once, coalesced; what falls outside the image is zero (and masked anyway).
+    const int tile_pix = blockIdx.x * 128;
+    const int bimg = tile_pix / p.HW, r0 = tile_pix - bimg * p.HW;        // the tile's image and its first pixel in it
+    const int lo = r0 - p.W - 1, span = 130 + 2 * p.W;
+    {
+        const float* xi = p.x + (long long)bimg * p.HW * CIN;
+        for (int i = tid; i < span * CIN; i += 512) {
+            const int pix = i / CIN, c = i - pix * CIN, gp = lo + pix;
+            xl[pix * XS + c] = (unsigned)gp < (unsigned)p.HW ? xi[gp * CIN + c] : 0.f;
+        }
+        // the packed filter and the bias, once per workgroup
         const int n4 = p.NB * K2 * 16;
         const float4* src = reinterpret_cast<const float4*>(p.wp);
         float4* dst = reinterpret_cast<float4*>(wl);
-        for (int i = tid; i < n4; i += 256) dst[i] = src[i];
+        for (int i = tid; i < n4; i += 512) dst[i] = src[i];
+        for (int i = tid; i < p.N; i += 512) bl[i] = p.bias ? p.bias[i] : 0.f;
     }
-    // this lane's pixel and its 3x3 neighbourhood
-    const int g = blockIdx.x * 128 + wave * 32 + pl;
-    const int b = g / p.HW, r = g - b * p.HW;
+    // this lane's pixel and which of its 9 taps lie inside the image
+    const int g = tile_pix + pg * 32 + pl;
+    const int r = r0 + pg * 32 + pl;
     const int y = r / p.W, x = r - y * p.W;
     int toff[9];
     unsigned tmask = 0;
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
-        const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
-        const bool ok = (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
-        toff[t] = ok ? ((b * p.H + yy) * p.W + xx) * CIN : 0;
+        const int dy = t / 3 - 1, dx = t % 3 - 1;
+        const bool ok = (unsigned)(y + dy) < (unsigned)p.H && (unsigned)(x + dx) < (unsigned)p.W;
+        toff[t] = (r + dy * p.W + dx - lo) * XS;      // always inside the staged range
         if (ok) tmask |= 1u << t;
     }
+    __syncthreads();                              // input range, filter and bias staged
     float bv[K2];
 #pragma unroll
     for (int s = 0; s < K2; ++s) {
@@ -93,13 +118,12 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const FirstParams p) {
         const int t1 = k1 < K ? k1 / CIN : 0, c1 = k1 < K ? k1 % CIN : 0;
         const bool ok = h ? (k1 < K && ((tmask >> t1) & 1u)) : ((tmask >> t0) & 1u);
         const int idx = h ? toff[t1] + c1 : toff[t0] + c0;
-        const float v = p.x[idx];                 // index 0 when the tap is outside: always a valid address
+        const float v = xl[idx];
         bv[s] = ok ? v : 0.f;
     }
-    __syncthreads();                              // filter staged
 
     const long long orow = (long long)g * p.N;
-    for (int nb = 0; nb < p.NB; ++nb) {
+    for (int nb = par; nb < p.NB; nb += 2) {
         f32x16 acc;
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] = 0.f;
@@ -107,37 +131,60 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const FirstParams p) {
 #pragma unroll
         for (int s = 0; s < K2; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wrow[s * 64], bv[s], acc, 0, 0, 0);
         // accumulator register 4q + i of this lane = channel nb*32 + 8q + 4h + i of pixel pl
+        const int cb = nb * 32 + 4 * h;
+        float4 v[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int c = nb * 32 + 8 * q + 4 * h;
-            float4 v = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
-            if (p.bias) {
-                const float4 bb = *reinterpret_cast<const float4*>(p.bias + c);
-                v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
-            }
-            *reinterpret_cast<float4*>(p.out + orow + c) = v;
-            if (p.gn_part) {
-                // {mean, M2} of the quad, then merged over the 32 lanes that hold the same channels (equal counts at every level)
-                float m = ((v.x + v.y) + (v.z + v.w)) * 0.25f;
-                const float d0 = v.x - m, d1 = v.y - m, d2 = v.z - m, d3 = v.w - m;
-                float m2 = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
-                float half_cnt = 2.0f;            // n_a * n_b / (n_a + n_b) with n_a = n_b = 4, 8, ...
+            const float4 bb = *reinterpret_cast<const float4*>(bl + cb + 8 * q);
+            v[q] = make_float4(acc[4 * q] + bb.x, acc[4 * q + 1] + bb.y, acc[4 * q + 2] + bb.z, acc[4 * q + 3] + bb.w);
+            *reinterpret_cast<float4*>(p.out + orow + cb + 8 * q) = v[q];
+        }
+        if (p.gn_part) {
+            // {mean, M2} of each quad, then merged over the 32 lanes that hold the same channels (equal counts at every level);
+            // the four quads' trees run side by side
+            float m[4], m2[4];
 #pragma unroll
-                for (int o = 1; o < 32; o <<= 1) {
-                    const float mo = __shfl_xor(m, o, 64), qo = __shfl_xor(m2, o, 64);
-                    const float d = mo - m;
-                    m2 = (m2 + qo) + d * d * half_cnt;
-                    m = 0.5f * (m + mo);
-                    half_cnt *= 2.0f;
+            for (int q = 0; q < 4; ++q) {
+                m[q] = ((v[q].x + v[q].y) + (v[q].z + v[q].w)) * 0.25f;
+                const float d0 = v[q].x - m[q], d1 = v[q].y - m[q], d2 = v[q].z - m[q], d3 = v[q].w - m[q];
+                m2[q] = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+            }
+            // lanes 1, 2 apart (quad permutes), then the mirrored quad of the 8-lane group and the mirrored half of the 16-lane
+            // row (DPP row_half_mirror / row_mirror: any involution that crosses the halves is a valid pairing), then the other row
+            auto merge = [&](float (&mo)[4], float (&qo)[4], float half_cnt) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float d = mo[q] - m[q];
+                    m2[q] = (m2[q] + qo[q]) + d * d * half_cnt;
+                    m[q] = 0.5f * (m[q] + mo[q]);
                 }
-                if (pl == 0) qs[wave * (p.N >> 2) + (c >> 2)] = make_float2(m, m2);
+            };
+            float mo[4], qo[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { mo[q] = dpp_partner<0xB1>(m[q]); qo[q] = dpp_partner<0xB1>(m2[q]); }     // quad_perm [1,0,3,2]
+            merge(mo, qo, 2.0f);                  // n_a * n_b / (n_a + n_b) with n_a = n_b = 4, then 8, ...
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { mo[q] = dpp_partner<0x4E>(m[q]); qo[q] = dpp_partner<0x4E>(m2[q]); }     // quad_perm [2,3,0,1]
+            merge(mo, qo, 4.0f);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { mo[q] = dpp_partner<0x141>(m[q]); qo[q] = dpp_partner<0x141>(m2[q]); }   // row_half_mirror
+            merge(mo, qo, 8.0f);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { mo[q] = dpp_partner<0x140>(m[q]); qo[q] = dpp_partner<0x140>(m2[q]); }   // row_mirror
+            merge(mo, qo, 16.0f);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { mo[q] = __shfl_xor(m[q], 16, 64); qo[q] = __shfl_xor(m2[q], 16, 64); }
+            merge(mo, qo, 32.0f);
+            if (pl == 0) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) qs[pg * (p.N >> 2) + ((cb + 8 * q) >> 2)] = make_float2(m[q], m2[q]);
             }
         }
     }
     if (p.gn_part) {
         __syncthreads();
         if (tid < p.groups) {
-            // fixed order: waves, then the group's quads (Chan et al., unequal counts)
+            // fixed order: pixel groups, then the group's quads (Chan et al., unequal counts)
             const int qpg = p.cpg >> 2, q0 = tid * qpg;
             float n = 0.f, mean = 0.f, m2 = 0.f;
             const float ni = 128.0f;              // 32 pixels x 4 channels per item
@@ -154,14 +201,16 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const FirstParams p) {
     }
 }
 
-static size_t first_lds_bytes(int cin, int N) {
+static size_t first_lds_bytes(int cin, int N, int W) {
     const int K2 = (9 * cin + 1) / 2;
-    return (size_t)(N / 32) * K2 * 64 * sizeof(float) + (size_t)4 * (N / 4) * sizeof(float2);
+    return (size_t)(N / 32) * K2 * 64 * sizeof(float) + (size_t)N * sizeof(float) + (size_t)4 * (N / 4) * sizeof(float2) +
+           (size_t)(130 + 2 * W) * (cin | 1) * sizeof(float);
 }
 
 bool conv_first_ok(int cin, int N, int H, int W, int groups) {
     if (cin < 1 || cin > 8 || N < 32 || N % 32 || N > 256 || H < 1 || W < 1) return false;
     if ((long long)H * W % 128) return false;                      // a workgroup's 128 pixels lie inside one image
+    if (first_lds_bytes(cin, N, W) > 96 * 1024) return false;
     if (groups <= 0 || groups > 64 || N % groups || (N / groups) % 4) return false;
     return true;
 }
@@ -190,9 +239,9 @@ int conv_first(const float* x, const float* wp, const float* bias, float* out, f
     p.groups = groups; p.cpg = N / groups;
     p.counter = counter; p.t_cur = t_cur; p.B = B;
     const dim3 grid((unsigned)((long long)B * H * W / 128));
-    const size_t lds = first_lds_bytes(cin, N);
+    const size_t lds = first_lds_bytes(cin, N, W);
     switch (cin) {
-#define X(C) case C: hipLaunchKernelGGL(conv_first_kernel<C>, grid, dim3(256), lds, st, p); break;
+#define X(C) case C: hipLaunchKernelGGL(conv_first_kernel<C>, grid, dim3(512), lds, st, p); break;
         FIRST_CASES(X)
 #undef X
         default: return fail_arg("conv_first: C_in");

@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256) void p_sample_kernel(float* __restrict__ x, co
 // partials) -> Mish -> 1x1 projection to n_out <= 8 channels -> eps_hat, and -- when x is given -- the reverse-step update of x
 // in place.  Replaces gn_apply_parts_kernel + conv1x1_n8_kernel + p_sample_kernel: the normalised activation (16.8 MB at
 // cfg4) and eps_hat never go to memory.
-//   workgroup = one 128-pixel tile of one image; phase 1: LPP lanes share a pixel (conv1x1_n8_kernel's butterfly), eps_hat of
+//   workgroup (16 waves) = one 128-pixel tile of one image; phase 1: LPP lanes share a pixel (conv1x1_n8_kernel's butterfly), eps_hat of
 //   the tile goes to LDS; phase 2: the tile's 128 * n_out latent elements are updated with p_sample_kernel's exact arithmetic
 //   and Philox indexing (bit-identical given the same eps_hat).
 struct TailParams {
@@ -146,8 +146,10 @@ struct TailParams {
 };
 
 template <int LPP, int VPL>
-__global__ __launch_bounds__(256) void final_tail_kernel(const TailParams p) {
-    constexpr int PPW = 64 / LPP;
+__global__ __launch_bounds__(1024) void final_tail_kernel(const TailParams p) {
+    constexpr int PPW = 64 / LPP;                    // pixels per wave and iteration
+    constexpr int PPI = 16 * PPW;                    // ... per iteration of the 16-wave workgroup
+    constexpr int NIT = 128 / PPI;                   // 4 at C = 128 / 256, 2 at C = 64, 1 at C = 32
     __shared__ float2 mr[64];
     __shared__ float2 sp[1024];
     __shared__ __attribute__((aligned(16))) float es[128 * 8];
@@ -155,12 +157,29 @@ __global__ __launch_bounds__(256) void final_tail_kernel(const TailParams p) {
     const int b = blockIdx.x / p.np, tile = blockIdx.x - b * p.np;
     const int G = p.C / p.cpg;
     const long long pix0 = (long long)b * p.HW + tile * 128;
-    // first pixels requested before the statistics are merged
-    float4 v[VPL];
+    // every pixel this wave will touch is requested up front, before the statistics are merged: one latency, not NIT
+    float4 v[NIT][VPL];
 #pragma unroll
-    for (int i = 0; i < VPL; ++i) v[i] = *reinterpret_cast<const float4*>(p.raw + (pix0 + wave * PPW + pl) * p.C + (sub + i * LPP) * 4);
+    for (int it = 0; it < NIT; ++it)
+#pragma unroll
+        for (int i = 0; i < VPL; ++i)
+            v[it][i] = *reinterpret_cast<const float4*>(p.raw + (pix0 + it * PPI + wave * PPW + pl) * p.C + (sub + i * LPP) * 4);
     const float2* pb = p.part + (long long)b * p.np * G;
-    for (int i = tid; i < p.np * G; i += 256) sp[i] = pb[i];
+    for (int i = tid; i < p.np * G; i += 1024) sp[i] = pb[i];
+    // ... and so is everything else that does not depend on the statistics
+    float4 ga[VPL], be[VPL], ww[8][VPL];
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const int c0 = (sub + i * LPP) * 4;
+        ga[i] = *reinterpret_cast<const float4*>(p.gamma + c0);
+        be[i] = *reinterpret_cast<const float4*>(p.beta + c0);
+#pragma unroll
+        for (int co = 0; co < 8; ++co)
+            ww[co][i] = co < p.n_out ? *reinterpret_cast<const float4*>(p.w + (long long)co * p.C + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const bool h2 = sub & (LPP / 2), h4 = sub & (LPP / 4), h8 = sub & (LPP / 8);
+    const int my_co = (h2 ? 4 : 0) + (h4 ? 2 : 0) + (h8 ? 1 : 0);
+    const float my_bias = (p.bias && my_co < p.n_out) ? p.bias[my_co] : 0.f;
     __syncthreads();
     if (tid < G) {          // the same fixed-order merge as gn_apply_parts_kernel
         float ms = 0.f;
@@ -177,38 +196,22 @@ __global__ __launch_bounds__(256) void final_tail_kernel(const TailParams p) {
         mr[tid] = make_float2(mean, 1.0f / sqrtf(var + p.eps));
     }
     __syncthreads();
-    float4 ga[VPL], be[VPL], ww[8][VPL];
     float2 st[VPL];
 #pragma unroll
-    for (int i = 0; i < VPL; ++i) {
-        const int c0 = (sub + i * LPP) * 4;
-        ga[i] = *reinterpret_cast<const float4*>(p.gamma + c0);
-        be[i] = *reinterpret_cast<const float4*>(p.beta + c0);
-        st[i] = mr[c0 / p.cpg];
+    for (int i = 0; i < VPL; ++i) st[i] = mr[((sub + i * LPP) * 4) / p.cpg];
 #pragma unroll
-        for (int co = 0; co < 8; ++co)
-            ww[co][i] = co < p.n_out ? *reinterpret_cast<const float4*>(p.w + (long long)co * p.C + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    const bool h2 = sub & (LPP / 2), h4 = sub & (LPP / 4), h8 = sub & (LPP / 8);
-    const int my_co = (h2 ? 4 : 0) + (h4 ? 2 : 0) + (h8 ? 1 : 0);
-    const float my_bias = (p.bias && my_co < p.n_out) ? p.bias[my_co] : 0.f;
-    constexpr int PPI = 4 * PPW;                     // pixels per iteration of the workgroup
-    for (int it = 0; it < 128 / PPI; ++it) {
+    for (int it = 0; it < NIT; ++it) {
         const int lp = it * PPI + wave * PPW + pl;   // pixel within the tile
-        if (it > 0) {
-#pragma unroll
-            for (int i = 0; i < VPL; ++i) v[i] = *reinterpret_cast<const float4*>(p.raw + (pix0 + lp) * p.C + (sub + i * LPP) * 4);
-        }
         float s[8];
 #pragma unroll
         for (int co = 0; co < 8; ++co) s[co] = 0.f;
 #pragma unroll
         for (int i = 0; i < VPL; ++i) {
             float4 y;
-            y.x = mish_f((v[i].x - st[i].x) * st[i].y * ga[i].x + be[i].x);
-            y.y = mish_f((v[i].y - st[i].x) * st[i].y * ga[i].y + be[i].y);
-            y.z = mish_f((v[i].z - st[i].x) * st[i].y * ga[i].z + be[i].z);
-            y.w = mish_f((v[i].w - st[i].x) * st[i].y * ga[i].w + be[i].w);
+            y.x = mish_f((v[it][i].x - st[i].x) * st[i].y * ga[i].x + be[i].x);
+            y.y = mish_f((v[it][i].y - st[i].x) * st[i].y * ga[i].y + be[i].y);
+            y.z = mish_f((v[it][i].z - st[i].x) * st[i].y * ga[i].z + be[i].z);
+            y.w = mish_f((v[it][i].w - st[i].x) * st[i].y * ga[i].w + be[i].w);
 #pragma unroll
             for (int co = 0; co < 8; ++co) s[co] += (y.x * ww[co][i].x + y.y * ww[co][i].y) + (y.z * ww[co][i].z + y.w * ww[co][i].w);
         }
@@ -235,14 +238,14 @@ __global__ __launch_bounds__(256) void final_tail_kernel(const TailParams p) {
     const int cnt4 = 128 * p.n_out / 4;
     const long long e4 = pix0 * p.n_out / 4;          // host: (128 * n_out) % 4 == 0
     if (p.eps_out)
-        for (int q = tid; q < cnt4; q += 256) reinterpret_cast<float4*>(p.eps_out)[e4 + q] = reinterpret_cast<const float4*>(es)[q];
+        for (int q = tid; q < cnt4; q += 1024) reinterpret_cast<float4*>(p.eps_out)[e4 + q] = reinterpret_cast<const float4*>(es)[q];
     if (p.x) {
         const uint64_t seed = p.chain_state ? (uint64_t)p.chain_state[1] : p.seed;
         const uint32_t stream = p.chain_state ? (uint32_t)p.chain_state[2] : p.stream;
         const int64_t tb = p.t[b];
         const float cr = p.c_recip[tb], crm1 = p.c_recipm1[tb], a1 = p.c1[tb], a2 = p.c2[tb];
         const float sg = tb > 0 ? p.sigma[tb] : 0.0f;
-        for (int q = tid; q < cnt4; q += 256) {
+        for (int q = tid; q < cnt4; q += 1024) {
             const long long i = e4 + q;
             const float4 xv = reinterpret_cast<const float4*>(p.x)[i], ev = reinterpret_cast<const float4*>(es)[q];
             const float4 zv = p.noise ? reinterpret_cast<const float4*>(p.noise + (long long)(p.t_first - tb) * p.noise_step_stride)[i]
@@ -280,10 +283,10 @@ int final_tail(const float* raw, const float* part, int np, const float* gamma, 
     p.seed = seed; p.stream = stream_id;
     p.np = np; p.HW = HW; p.C = C; p.cpg = C / groups; p.n_out = n_out; p.eps = eps;
     const dim3 grid((unsigned)(B * np));
-    if (C == 32) hipLaunchKernelGGL((final_tail_kernel<8, 1>), grid, dim3(256), 0, st, p);
-    else if (C == 64) hipLaunchKernelGGL((final_tail_kernel<16, 1>), grid, dim3(256), 0, st, p);
-    else if (C == 128) hipLaunchKernelGGL((final_tail_kernel<32, 1>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((final_tail_kernel<32, 2>), grid, dim3(256), 0, st, p);
+    if (C == 32) hipLaunchKernelGGL((final_tail_kernel<8, 1>), grid, dim3(1024), 0, st, p);
+    else if (C == 64) hipLaunchKernelGGL((final_tail_kernel<16, 1>), grid, dim3(1024), 0, st, p);
+    else if (C == 128) hipLaunchKernelGGL((final_tail_kernel<32, 1>), grid, dim3(1024), 0, st, p);
+    else hipLaunchKernelGGL((final_tail_kernel<32, 2>), grid, dim3(1024), 0, st, p);
     return check_launch("final_tail_kernel");
 }
 

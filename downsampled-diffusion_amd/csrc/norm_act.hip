@@ -120,12 +120,15 @@ __global__ __launch_bounds__(256) void gn_apply_parts_kernel(const float* __rest
     __shared__ float2 mr[128];
     __shared__ float2 sp[1024];
     const int b = blockIdx.x / wg_per_image, chunk = blockIdx.x - b * wg_per_image;
+    const long long tr = temb ? (temb_rows ? temb_rows[b] : b) : 0;          // first: the shift row's load depends on it
     const int G = C / cpg;
     const int upr = C >> 2;                      // float4 units per pixel
     const int units = HW * upr;
     const int u_begin = chunk * units_per_wg, u_end = min(units, (chunk + 1) * units_per_wg);
     const long long base = (long long)b * HW * C;
-    // the first batch of x is requested before the statistics are merged: both latencies overlap
+    // Everything that does not depend on the statistics is requested BEFORE they are merged, so the launch pays one memory
+    // latency, not a chain of them: the first batch of x, the per-tile partials, and -- when every unit of this thread has the
+    // same channel quad (256 % (C/4) == 0: all reference widths) -- gamma, beta and the time shift.
     float4 v[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -134,6 +137,40 @@ __global__ __launch_bounds__(256) void gn_apply_parts_kernel(const float* __rest
     }
     const float2* pb = part + (long long)b * np * G;
     for (int i = threadIdx.x; i < np * G; i += 256) sp[i] = pb[i];          // [tile][group], host guarantees np * G <= 1024
+    const bool same_c0 = (256 % upr) == 0 && (units_per_wg % upr) == 0;      // wave-uniform
+    const int c0_fixed = ((u_begin + (int)threadIdx.x) - div_upr(u_begin + (int)threadIdx.x, upr) * upr) << 2;
+    float4 ga_f = make_float4(0.f, 0.f, 0.f, 0.f), be_f = ga_f, t_f = ga_f;
+    if (same_c0) {
+        ga_f = *reinterpret_cast<const float4*>(gamma + c0_fixed);
+        be_f = *reinterpret_cast<const float4*>(beta + c0_fixed);
+        if (temb) t_f = *reinterpret_cast<const float4*>(temb + tr * temb_stride + c0_fixed);
+    }
+    float rw[4][8], rb[4];
+    float xr[4][8];         // RC: the narrow input rows of this iteration's four pixels, requested together with x
+    auto load_rows = [&](int u0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int u = u0 + k * 256;
+            const float* xs = rc.x + ((long long)b * HW + div_upr(u < u_end ? u : u_begin, upr)) * rc.cin;
+            if (rc.cin == 8) {      // 32-byte rows: two 16-byte loads (rc.x is 16-byte aligned, host-checked)
+                const float4 a = *reinterpret_cast<const float4*>(xs), c = *reinterpret_cast<const float4*>(xs + 4);
+                xr[k][0] = a.x; xr[k][1] = a.y; xr[k][2] = a.z; xr[k][3] = a.w;
+                xr[k][4] = c.x; xr[k][5] = c.y; xr[k][6] = c.z; xr[k][7] = c.w;
+            } else {
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) xr[k][kk] = kk < rc.cin ? xs[kk] : 0.f;
+            }
+        }
+    };
+    __shared__ __attribute__((aligned(16))) float rws[RC ? 256 * 8 : 4];     // RC: the [C][8] 1x1 weights (host: C <= 256)
+    if constexpr (RC) {
+        // through LDS (a few coalesced loads per thread): a workgroup handles only 4-8 outputs per thread, so 32 scattered weight
+        // loads per thread would be most of its memory instructions
+        for (int i = threadIdx.x; i < C * 8; i += 256) rws[i] = (i & 7) < rc.cin ? rc.w[(long long)(i >> 3) * rc.ld + (i & 7)] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) rb[j] = rc.b ? rc.b[c0_fixed + j] : 0.f;
+        load_rows(u_begin + threadIdx.x);
+    }
     __syncthreads();
     if (threadIdx.x < G) {
         float ms = 0.f;
@@ -149,18 +186,15 @@ __global__ __launch_bounds__(256) void gn_apply_parts_kernel(const float* __rest
         const float var = (m2 + n_i * d2) / ((float)np * n_i);
         mr[threadIdx.x] = make_float2(mean, 1.0f / sqrtf(var + eps));
     }
-    __syncthreads();
-    const long long tr = temb ? (temb_rows ? temb_rows[b] : b) : 0;
-    float rw[4][8], rb[4];
-    if (RC) {
-        const int c0 = ((u_begin + (int)threadIdx.x) - div_upr(u_begin + (int)threadIdx.x, upr) * upr) << 2;
+    if constexpr (RC) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            rb[j] = rc.b ? rc.b[c0 + j] : 0.f;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) rw[j][k] = k < rc.cin ? rc.w[(long long)(c0 + j) * rc.ld + k] : 0.f;
+            const float4 a = *reinterpret_cast<const float4*>(rws + (c0_fixed + j) * 8), c = *reinterpret_cast<const float4*>(rws + (c0_fixed + j) * 8 + 4);
+            rw[j][0] = a.x; rw[j][1] = a.y; rw[j][2] = a.z; rw[j][3] = a.w;
+            rw[j][4] = c.x; rw[j][5] = c.y; rw[j][6] = c.z; rw[j][7] = c.w;
         }
     }
+    __syncthreads();
     for (int u0 = u_begin + threadIdx.x; u0 < u_end; u0 += 1024) {
         if (u0 != u_begin + (int)threadIdx.x) {
 #pragma unroll
@@ -168,36 +202,33 @@ __global__ __launch_bounds__(256) void gn_apply_parts_kernel(const float* __rest
                 const int u = u0 + k * 256;
                 if (u < u_end) v[k] = *reinterpret_cast<const float4*>(x + base + (long long)u * 4);
             }
+            if (RC) load_rows(u0);
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int u = u0 + k * 256;
             if (u >= u_end) continue;
-            const int c0 = (u - div_upr(u, upr) * upr) << 2;
+            const int c0 = same_c0 ? c0_fixed : (u - div_upr(u, upr) * upr) << 2;
             const float2 st = mr[c0 / cpg];
-            const float4 ga = *reinterpret_cast<const float4*>(gamma + c0);
-            const float4 be = *reinterpret_cast<const float4*>(beta + c0);
-            float4 y;
-            y.x = mish_f((v[k].x - st.x) * st.y * ga.x + be.x);
-            y.y = mish_f((v[k].y - st.x) * st.y * ga.y + be.y);
-            y.z = mish_f((v[k].z - st.x) * st.y * ga.z + be.z);
-            y.w = mish_f((v[k].w - st.x) * st.y * ga.w + be.w);
-            if (temb) {
-                const float4 t = *reinterpret_cast<const float4*>(temb + tr * temb_stride + c0);
-                y.x += t.x; y.y += t.y; y.z += t.z; y.w += t.w;
+            float4 ga = ga_f, be = be_f, ts = t_f;
+            if (!same_c0) {
+                ga = *reinterpret_cast<const float4*>(gamma + c0);
+                be = *reinterpret_cast<const float4*>(beta + c0);
+                if (temb) ts = *reinterpret_cast<const float4*>(temb + tr * temb_stride + c0);
             }
+            float4 y;
+            y.x = mish_f((v[k].x - st.x) * st.y * ga.x + be.x) + ts.x;
+            y.y = mish_f((v[k].y - st.x) * st.y * ga.y + be.y) + ts.y;
+            y.z = mish_f((v[k].z - st.x) * st.y * ga.z + be.z) + ts.z;
+            y.w = mish_f((v[k].w - st.x) * st.y * ga.w + be.w) + ts.w;
             const long long o = base + (long long)u * 4;
             if (RC) {
-                const float* xs = rc.x + ((long long)b * HW + div_upr(u, upr)) * rc.cin;
-                float xv[8];
-#pragma unroll
-                for (int kk = 0; kk < 8; ++kk) xv[kk] = kk < rc.cin ? xs[kk] : 0.f;
                 float r[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     float a = rb[j];
 #pragma unroll
-                    for (int kk = 0; kk < 8; ++kk) a += xv[kk] * rw[j][kk];
+                    for (int kk = 0; kk < 8; ++kk) a += xr[k][kk] * rw[j][kk];
                     r[j] = a;
                 }
                 y.x += r[0]; y.y += r[1]; y.z += r[2]; y.w += r[3];
@@ -223,6 +254,7 @@ int groupnorm_mish_parts(const float* x, const float* part, int np, const float*
     const int units = HW * (C / 4);
     int wpi = (int)ceil_div(units, 1024);                       // 1024 float4 per workgroup ...
     while ((long long)wpi * B > 2048 && wpi > 1) wpi = (wpi + 1) / 2;   // ... unless that makes more than ~8 workgroups per CU
+    if (rc_x && (long long)wpi * B >= 1024 && wpi > 1) wpi = (wpi + 1) / 2;    // the 1x1 addend has a per-workgroup prologue: 2 rounds each
     const int upw = (int)(ceil_div(ceil_div(units, wpi), 256) * 256);
     wpi = (int)ceil_div(units, upw);
     Res1x1 rc{rc_x, rc_w, rc_b, rc_cin, rc_ld};
@@ -230,7 +262,8 @@ int groupnorm_mish_parts(const float* x, const float* part, int np, const float*
         const int upr = C / 4;
         DDK_REQUIRE(!addend && rc_w && rc_cin >= 1 && rc_cin <= 8 && rc_ld >= rc_cin, "groupnorm_mish_partials: 1x1 addend needs "
                     "1 <= C_in <= 8, its weights, and no tensor addend");
-        DDK_REQUIRE(upr <= 256 && 256 % upr == 0, "groupnorm_mish_partials: 1x1 addend needs C/4 to divide 256");
+        DDK_REQUIRE(C <= 256 && 256 % upr == 0, "groupnorm_mish_partials: 1x1 addend needs C <= 256 and C/4 to divide 256");
+        DDK_REQUIRE(aligned16(rc_x) && (reinterpret_cast<uintptr_t>(rc_w) & 3u) == 0, "groupnorm_mish_partials: 1x1 addend alignment");
         hipLaunchKernelGGL(gn_apply_parts_kernel<true>, dim3((unsigned)(B * wpi)), dim3(256), 0, st, x, reinterpret_cast<const float2*>(part),
                            np, gamma, beta, temb, temb_stride, temb_rows, addend, out, HW, C, C / groups, eps, wpi, upw, rc);
     } else {
