@@ -40,6 +40,9 @@ struct LocalParams {
     float* out;           // [B][HW][N]
     int H, W, N, cpg;
     float eps;
+    int addend_slabs;            // > 1: `addend` is still in split-K form: that many slabs, `addend_stride` floats apart, summed in
+    long long addend_stride;     // order, plus addend_bias[c] (the skip conv's reduce pass folded into this load)
+    const float* addend_bias;
 };
 
 constexpr int LOC_PP = 36;   // pitch (floats) of a partial-accumulator row: 4 rows apart = 16 banks apart
@@ -88,7 +91,12 @@ __device__ __forceinline__ void gn_mish_tail(const float (&v)[NV], const long lo
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         float y = mish_f((v[i] - mean) * rstd * ga + be) + sh;
-        if (p.addend) y += p.addend[o[i]];
+        if (p.addend) {
+            float r = p.addend[o[i]];
+            for (int sl = 1; sl < p.addend_slabs; ++sl) r += p.addend[sl * p.addend_stride + o[i]];
+            if (p.addend_bias) r += p.addend_bias[c];
+            y += r;
+        }
         p.out[o[i]] = y;
     }
 }
@@ -248,6 +256,9 @@ struct WLocalParams {
     float* out;
     int H, W, N, cpg;
     float eps;
+    int addend_slabs;
+    long long addend_stride;
+    const float* addend_bias;
 };
 
 constexpr int WL_VP = 36;                       // V / M row pitch (floats): 16 rows cover the 64 banks once
@@ -472,15 +483,17 @@ bool conv_gn_wlocal_ok(int H, int W, int cin, int c0, int N, int groups) {
 
 int conv_gn_wlocal(const float* src0, int c0, const float* src1, int c1, const float* w, const float* bias, const float* gamma,
                    const float* beta, const float* temb, int temb_stride, const long long* temb_rows, const float* addend, float* out,
-                   int B, int H, int W, int N, int groups, float eps, hipStream_t st) {
+                   int B, int H, int W, int N, int groups, float eps, hipStream_t st, const AddendSlabs& as) {
     DDK_REQUIRE(src0 && w && gamma && beta && out, "conv_gn_wlocal: null pointer");
+    DDK_REQUIRE(as.n >= 1 && (as.n == 1 || addend), "conv_gn_wlocal: addend slabs");
     DDK_REQUIRE(B > 0 && groups > 0, "conv_gn_wlocal: B and groups must be positive");
     DDK_REQUIRE(c1 == 0 || src1, "conv_gn_wlocal: second source missing");
     DDK_REQUIRE(conv_gn_wlocal_ok(H, W, c0 + c1, c0, N, groups), "conv_gn_wlocal: shape not eligible (needs H*W == 64 with even H, W; "
                 "cin % 32 == 0 and <= 320; N % 32 == 0; channels per group in {8, 16, 32})");
     DDK_REQUIRE(aligned16(src0) && aligned16(src1) && aligned16(w), "conv_gn_wlocal: sources and weights must be 16-byte aligned");
     DDK_TRY(ensure_device_init());
-    WLocalParams p{src0, src1, c0, c1, w, bias, gamma, beta, temb, temb_stride, temb_rows, addend, out, H, W, N, N / groups, eps};
+    WLocalParams p{src0, src1, c0, c1, w, bias, gamma, beta, temb, temb_stride, temb_rows, addend, out, H, W, N, N / groups, eps,
+                   as.n, as.stride, as.bias};
     hipLaunchKernelGGL(conv3x3_gn_wlocal_kernel, dim3((unsigned)((long long)B * (N / 32))), dim3(768), wlocal_lds_bytes(c0 + c1), st, p);
     return check_launch("conv3x3_gn_wlocal_kernel");
 }
@@ -506,15 +519,17 @@ int conv_gn_local_init_device() {
 
 int conv_gn_local(const float* src0, int c0, const float* src1, int c1, const float* w, const float* bias, const float* gamma,
                   const float* beta, const float* temb, int temb_stride, const long long* temb_rows, const float* addend, float* out,
-                  int B, int H, int W, int N, int groups, float eps, hipStream_t st) {
+                  int B, int H, int W, int N, int groups, float eps, hipStream_t st, const AddendSlabs& as) {
     DDK_REQUIRE(src0 && w && gamma && beta && out, "conv_gn_local: null pointer");
+    DDK_REQUIRE(as.n >= 1 && (as.n == 1 || addend), "conv_gn_local: addend slabs");
     DDK_REQUIRE(B > 0 && groups > 0, "conv_gn_local: B and groups must be positive");
     DDK_REQUIRE(c1 == 0 || src1, "conv_gn_local: second source missing");
     DDK_REQUIRE(conv_gn_local_ok(H, W, c0 + c1, c0, N, groups), "conv_gn_local: shape not eligible (needs H*W in {16, 64}, "
                 "cin % 32 == 0, N % 32 == 0, channels per group in {8, 16, 32})");
     DDK_REQUIRE(aligned16(src0) && aligned16(src1) && aligned16(w), "conv_gn_local: sources and weights must be 16-byte aligned");
     DDK_TRY(ensure_device_init());
-    LocalParams p{src0, src1, c0, c1, w, bias, gamma, beta, temb, temb_stride, temb_rows, addend, out, H, W, N, N / groups, eps};
+    LocalParams p{src0, src1, c0, c1, w, bias, gamma, beta, temb, temb_stride, temb_rows, addend, out, H, W, N, N / groups, eps,
+                  as.n, as.stride, as.bias};
     const int HW = H * W;
     const size_t ldsb = local_lds_bytes(HW, c0 + c1);
     const dim3 grid((unsigned)((long long)B * (N / 32)));

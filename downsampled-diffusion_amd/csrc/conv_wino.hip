@@ -57,6 +57,10 @@ constexpr int W_V = 4 * WBT * 32, W_U = 4 * WBN * 32;    // floats per stage: 4 
 constexpr int W_STAGE = W_V + W_U, W_NS = 3;
 constexpr int W_LDS_FLOATS = W_NS * W_STAGE;             // 36864 floats = 144 KB
 constexpr int W_TP = WBN + 4;                            // epilogue staging pitch
+#ifndef DDK_WINO_LP
+#define DDK_WINO_LP 8
+#endif
+constexpr int W_LP = DDK_WINO_LP;                        // of a U image's 8 DMA pieces per stage, the loader wave issues W_LP, the matrix wave the rest
 static_assert(4 * 2 * WBT * W_TP <= W_LDS_FLOATS, "epilogue staging fits");
 
 // G g G^T for one (n, c): G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
@@ -87,6 +91,29 @@ __global__ __launch_bounds__(256) void pack_conv_weight_wino_kernel(const float*
                 dst[((((long long)(c >> 5)) * 16 + (4 * i + j)) * O + n) * 32 + (c & 31)] = u[j];
         }
     }
+}
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));      // native vector: usable as an inline-asm register operand
+
+// Raw buffer descriptor (wave-uniform) over `bytes` bytes at p: a lane whose offset is >= bytes reads zeros -- the zero padding
+// of the convolution costs no address arithmetic, no select and no branch in the loader.
+__device__ __forceinline__ i32x4 make_srd(const void* p, unsigned bytes) {
+    const unsigned long long a = reinterpret_cast<unsigned long long>(p);
+    i32x4 r;
+    r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+    r.y = __builtin_amdgcn_readfirstlane((int)(unsigned)((a >> 32) & 0xFFFFu));
+    r.z = __builtin_amdgcn_readfirstlane((int)bytes);
+    r.w = 0x00020000;
+    return r;
+}
+constexpr unsigned WINO_OOB = 0x80000000u;      // > any tensor this kernel takes (host: bytes < 2^31)
+
+// 16 bytes from descriptor + lane offset + wave-uniform offset.  Issued from inline asm on purpose: hipcc cannot count the
+// LDS-DMA pieces this wave issues from asm, so every load it counts itself makes it wait vmcnt(0) -- for the pieces too -- in
+// front of the next use of ANY loaded register; the loader's waits are placed by hand (see the schedule below).
+__device__ __forceinline__ void buf_load16(f32x4& d, unsigned voff, const i32x4& srd, unsigned soff) {
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(d) : "v"(voff), "s"(srd), "s"(soff) : "memory");
 }
 
 __device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
@@ -142,7 +169,21 @@ __global__ __launch_bounds__(512) void conv3x3_wino_kernel(const WinoParams p) {
 #pragma unroll
             for (int dx = 0; dx < 4; ++dx)
                 if (tile_ok && (unsigned)(py0 + dy) < (unsigned)p.H && (unsigned)(px0 + dx) < (unsigned)p.W) mask |= 1u << (dy * 4 + dx);
-        const float* zero = g_wino_zero;
+        // buffer descriptors of the two sources and this thread's 16 patch-pixel offsets into the current one (padding pixels:
+        // an out-of-range offset, which the buffer load turns into zeros)
+        const i32x4 srd0 = make_srd(p.src0, (unsigned)((long long)p.B * p.H * p.W * p.c0 * 4));
+        const i32x4 srd1 = make_srd(p.src1 ? p.src1 : p.src0, (unsigned)((long long)p.B * p.H * p.W * (p.src1 ? p.c1 : p.c0) * 4));
+        unsigned voff[16];
+        int cur_src = -1;
+        auto set_source = [&](int which) {
+            const int cs = which == 0 ? p.c0 : p.c1;
+#pragma unroll
+            for (int dy = 0; dy < 4; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 4; ++dx)
+                    voff[dy * 4 + dx] = ((mask >> (dy * 4 + dx)) & 1u) ? (unsigned)(((pix0 + dy * p.W + dx) * cs + cq * 4) * 4) : WINO_OOB;
+            cur_src = which;
+        };
         const int v_off = t * 32 + ((cq ^ ((t >> 1) & 7)) << 2);     // float offset of this thread's float4 inside a V image
         // U image of position 4i + lw (64 rows x 128 B = 8 pieces of 8 rows): in the loop this loader issues pieces 0..3 and
         // matrix wave lw issues pieces 4..7 (one per quarter, in MFMA shadows) -- an LDS-DMA piece costs 100-200 issue cycles
@@ -156,37 +197,40 @@ __global__ __launch_bounds__(512) void conv3x3_wino_kernel(const WinoParams p) {
             u_voff[j] = (unsigned)(((n0 + r) * 32 + ((ppos ^ ((r >> 1) & 7)) << 2)) * 4);
         }
         // patch rows (4 pixels x this thread's 4 channels each) of one channel chunk; rows are loaded two at a time so the loads
-        // spread over the stages of the previous chunk
-        auto load_rows = [&](int chunk, float4 (&d)[16], int ra, int rb) {
+        // spread over the stages of the previous chunk.  One buffer_load per pixel, nothing else.
+        auto load_rows = [&](int chunk, f32x4 (&d)[16], int ra, int rb) {
             const int cc = chunk << 5;
             const bool first = cc < p.c0;                              // wave-uniform
-            const float* src = first ? p.src0 : p.src1;
-            const int cs = first ? p.c0 : p.c1, coff = (first ? cc : cc - p.c0) + cq * 4;
+            if ((first ? 0 : 1) != cur_src) set_source(first ? 0 : 1);
+            const unsigned soff = (unsigned)((first ? cc : cc - p.c0) * 4);
+            i32x4 srd;                                                 // four scalar selects, not a branch per load
+            srd.x = first ? srd0.x : srd1.x; srd.y = first ? srd0.y : srd1.y; srd.z = first ? srd0.z : srd1.z; srd.w = srd0.w;
 #pragma unroll
             for (int dy = 0; dy < 4; ++dy)
                 if (dy == ra || dy == rb) {
 #pragma unroll
-                    for (int dx = 0; dx < 4; ++dx) {
-                        const long long off = (long long)(pix0 + dy * p.W + dx) * cs + coff;
-                        const float* ptr = ((mask >> (dy * 4 + dx)) & 1u) ? src + off : zero;
-                        d[dy * 4 + dx] = *reinterpret_cast<const float4*>(ptr);
-                    }
+                    for (int dx = 0; dx < 4; ++dx) buf_load16(d[dy * 4 + dx], voff[dy * 4 + dx], srd, soff);
                 }
+        };
+        // the compiler must not move a use of the patch registers above this point (their loads are invisible to it)
+        auto pin = [&](f32x4 (&d)[16]) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) asm volatile("" : "+v"(d[i]));
         };
         // Row i of V = B^T d B (the 4 positions 4i .. 4i+3) of this thread's tile / channels, straight into the V images of
         // stage buffer `buf`.  B^T = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,1,0,-1]]: row i needs two patch rows only (0: d0-d2,
         // 1: d1+d2, 2: d2-d1, 3: d1-d3), so the transform is 8 float4 operations per stage instead of 32 once per chunk.
-        auto write_v_row = [&](const float4 (&d)[16], int i, int buf) {
-            float4 r[4];
+        auto write_v_row = [&](const f32x4 (&d)[16], int i, int buf) {
+            f32x4 r[4];
 #pragma unroll
             for (int x = 0; x < 4; ++x)
-                r[x] = i == 0 ? f4sub(d[0 * 4 + x], d[2 * 4 + x]) : i == 1 ? f4add(d[1 * 4 + x], d[2 * 4 + x])
-                     : i == 2 ? f4sub(d[2 * 4 + x], d[1 * 4 + x]) : f4sub(d[1 * 4 + x], d[3 * 4 + x]);
+                r[x] = i == 0 ? d[0 * 4 + x] - d[2 * 4 + x] : i == 1 ? d[1 * 4 + x] + d[2 * 4 + x]
+                     : i == 2 ? d[2 * 4 + x] - d[1 * 4 + x] : d[1 * 4 + x] - d[3 * 4 + x];
             float* base = smem + buf * W_STAGE + v_off;
-            *reinterpret_cast<float4*>(base + 0 * (WBT * 32)) = f4sub(r[0], r[2]);
-            *reinterpret_cast<float4*>(base + 1 * (WBT * 32)) = f4add(r[1], r[2]);
-            *reinterpret_cast<float4*>(base + 2 * (WBT * 32)) = f4sub(r[2], r[1]);
-            *reinterpret_cast<float4*>(base + 3 * (WBT * 32)) = f4sub(r[1], r[3]);
+            *reinterpret_cast<f32x4*>(base + 0 * (WBT * 32)) = r[0] - r[2];
+            *reinterpret_cast<f32x4*>(base + 1 * (WBT * 32)) = r[1] + r[2];
+            *reinterpret_cast<f32x4*>(base + 2 * (WBT * 32)) = r[2] - r[1];
+            *reinterpret_cast<f32x4*>(base + 3 * (WBT * 32)) = r[1] - r[3];
         };
         auto issue_u = [&](int stage_idx, int buf, int j_begin, int j_end) {   // stage index relative to this workgroup's first
             const int chunk = c_begin + (stage_idx >> 2), pos = 4 * (stage_idx & 3) + lw;
@@ -207,7 +251,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino_kernel(const WinoParams p) {
         int b0 = 0;                                                         // buffer of stage S
         // one chunk = iterations s = 0..3; `cur` holds the patch of chunk (S + 2) / 4 - for s < 2 that is chunk qi, from s = 2 on
         // chunk qi + 1, loaded into `nxt` during s = 0, 1 (the two arrays swap roles every chunk: static register allocation)
-        auto chunk_body = [&](float4 (&cur)[16], float4 (&nxt)[16], int qi) {
+        auto chunk_body = [&](f32x4 (&cur)[16], f32x4 (&nxt)[16], int qi) {
             const bool has_next = qi + 1 < n_chunks;
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
@@ -217,26 +261,28 @@ __global__ __launch_bounds__(512) void conv3x3_wino_kernel(const WinoParams p) {
                 const bool loads = has_next && s < 2;
                 if (loads) load_rows(c_begin + qi + 1, nxt, s == 0 ? 0 : 1, s == 0 ? 2 : 3);
                 if (more) {
-                    // V row first: hipcc guards the patch registers with its own (conservative) vmcnt waits, which must not
-                    // cover the pieces issued below
+                    // rows 0 / 2 of `nxt` were requested in iteration s = 0, rows 1 / 3 in s = 1; the wait in front of the barrier
+                    // that ended iteration s = 1 (resp. 2) left only younger operations outstanding, so they have landed
                     if (s == 0) write_v_row(cur, 2, buf2);
                     else if (s == 1) write_v_row(cur, 3, buf2);
-                    else if (s == 2) write_v_row(nxt, 0, buf2);
+                    else if (s == 2) { pin(nxt); write_v_row(nxt, 0, buf2); }
                     else write_v_row(nxt, 1, buf2);
-                    if (DBG != 4) issue_u(S + 2, buf2, 0, 4);
+                    if (DBG != 4) issue_u(S + 2, buf2, 0, W_LP);
                 }
-                if (more && DBG != 4) { if (loads) wait_vmcnt<12>(); else wait_vmcnt<4>(); }
+                if (more && DBG != 4) { if (loads) wait_vmcnt<W_LP + 8>(); else wait_vmcnt<W_LP>(); }
                 else { if (loads) wait_vmcnt<8>(); else wait_vmcnt<0>(); }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();                               // B(S+1)
                 b0 = b0 == 2 ? 0 : b0 + 1;
             }
         };
-        float4 da[16], db[16];
+        f32x4 da[16], db[16];
         load_rows(c_begin, da, 0, 2);
         load_rows(c_begin, da, 1, 3);
         issue_u(0, 0, 0, 8);
         issue_u(1, 1, 0, 8);
+        wait_vmcnt<16>();                                                   // the 16 patch loads (older than the 16 pieces)
+        pin(da);
         write_v_row(da, 0, 0);
         write_v_row(da, 1, 1);
         wait_vmcnt<0>();
@@ -268,10 +314,10 @@ __global__ __launch_bounds__(512) void conv3x3_wino_kernel(const WinoParams p) {
         unsigned u_voff[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int r = (4 + j) * 8 + prow;
+            const int r = ((W_LP + j) & 7) * 8 + prow;
             u_voff[j] = (unsigned)(((n0 + r) * 32 + ((ppos ^ ((r >> 1) & 7)) << 2)) * 4);
         }
-        const unsigned u_dst = lds_base + (unsigned)((W_V + w * (WBN * 32) + 4 * 256) * 4);
+        const unsigned u_dst = lds_base + (unsigned)((W_V + w * (WBN * 32) + (W_LP & 7) * 256) * 4);
 
         __builtin_amdgcn_s_barrier();                                       // B0: stages 0, 1 complete
         unsigned long long r_loop0 = 0, c_wait = 0, c_mma = 0;
@@ -312,14 +358,14 @@ __global__ __launch_bounds__(512) void conv3x3_wino_kernel(const WinoParams p) {
                             const float bv = e == 0 ? b[cur][j].x : e == 1 ? b[cur][j].y : e == 2 ? b[cur][j].z : b[cur][j].w;
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
                         }
-                        if (e == 0 && more && DBG != 4) {                   // one DMA piece per quarter, behind the quarter's first MFMAs
+                        if (e == 0 && more && DBG != 4 && q < 8 - W_LP) {      // its DMA pieces: one per quarter, behind the quarter's first MFMAs
                             __builtin_amdgcn_sched_barrier(0);
                             lds_dma16_s(ub, q == 0 ? u_voff[0] : q == 1 ? u_voff[1] : q == 2 ? u_voff[2] : u_voff[3], dst2 + (unsigned)(q * 1024));
                             __builtin_amdgcn_sched_barrier(0);
                         }
                     }
                 }
-                if (more) wait_vmcnt<4>(); else wait_vmcnt<0>();            // my pieces of U(S+1), issued during stage S-1, have landed
+                if (more) wait_vmcnt<8 - W_LP>(); else wait_vmcnt<0>();     // my pieces of U(S+1), issued during stage S-1, have landed
                 unsigned long long tA = 0, tB = 0;
                 if (DBG) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tA)::"memory"); }
                 __builtin_amdgcn_s_barrier();                               // B(S+1): stage S released; V <= S+2, U <= S+1 complete

@@ -141,15 +141,22 @@ int conv_first(const float* x, const float* wp, const float* bias, float* out, f
                int groups, int64_t* counter, int64_t* t_cur, hipStream_t st);
 int conv_first_init_device();
 // conv_local.hip: conv3x3 + GroupNorm + Mish (+shift, +residual) in one launch for 4x4 / 8x8 maps
+// the addend of the image-local kernels may still be in split-K form (the 1x1 skip conv's slabs): n slabs `stride` floats apart,
+// summed in order, plus bias[c] -- the skip conv's reduce launch folded into the consumer's load
+struct AddendSlabs {
+    int n = 1;
+    long long stride = 0;
+    const float* bias = nullptr;
+};
 bool conv_gn_local_ok(int H, int W, int cin, int c0, int N, int groups);
 int conv_gn_local(const float* src0, int c0, const float* src1, int c1, const float* w, const float* bias, const float* gamma,
                   const float* beta, const float* temb, int temb_stride, const long long* temb_rows, const float* addend, float* out,
-                  int B, int H, int W, int N, int groups, float eps, hipStream_t st);
+                  int B, int H, int W, int N, int groups, float eps, hipStream_t st, const AddendSlabs& as = AddendSlabs());
 int conv_gn_local_init_device();
 bool conv_gn_wlocal_ok(int H, int W, int cin, int c0, int N, int groups);     // 64-pixel maps: the same in Winograd form
 int conv_gn_wlocal(const float* src0, int c0, const float* src1, int c1, const float* w, const float* bias, const float* gamma,
                    const float* beta, const float* temb, int temb_stride, const long long* temb_rows, const float* addend, float* out,
-                   int B, int H, int W, int N, int groups, float eps, hipStream_t st);
+                   int B, int H, int W, int N, int groups, float eps, hipStream_t st, const AddendSlabs& as = AddendSlabs());
 double conv_flops(int kind, int B, int H, int W, int cin, int N);
 // norm_act.hip
 size_t groupnorm_workspace_bytes(int B, int HW, int C, int groups);

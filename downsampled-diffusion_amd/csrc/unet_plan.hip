@@ -81,7 +81,7 @@ struct SamplerGraph {
     hipGraphExec_t exec_multi = nullptr;
     unsigned long long last_use = 0;
 };
-constexpr int SAMPLER_MULTI = 8;
+constexpr int SAMPLER_MULTI = 16;
 
 struct ddk_unet {
     // sampler state cached across ddk_sampler_run calls (guarded by `mu`; see ddk_sampler_invalidate)
@@ -525,17 +525,23 @@ static int run_conv(Ctx& c, int kind, const ConvW& cw, const float* src0, int c0
 
 // conv3x3 -> GroupNorm+Mish(+shift)(+residual).  When the conv splits k, its slabs stay in the workspace and the
 // GroupNorm kernel sums them (plus the conv bias) while loading: one kernel and one HBM round trip fewer.
+static bool conv_gn_is_local(const ConvW& cw, int H, int W, int c0, int c1, int N) {
+    return (cw.has_wl && H * W == 16 && conv_gn_local_ok(H, W, c0 + c1, c0, N, GROUPS)) ||
+           (cw.has_wwl && H * W == 64 && conv_gn_wlocal_ok(H, W, c0 + c1, c0, N, GROUPS));
+}
+
 static int run_conv_gn(Ctx& c, const ConvW& cw, const float* src0, int c0, const float* src1, int c1, float* raw, const NormW& n,
-                       const float* temb, const float* addend, float* out, int H, int W, int N) {
+                       const float* temb, const float* addend, float* out, int H, int W, int N, const AddendSlabs& as = AddendSlabs()) {
     if (cw.has_wl && H * W == 16 && conv_gn_local_ok(H, W, c0 + c1, c0, N, GROUPS))
         // 4x4 maps: one image x 32 channels per workgroup, k reduced inside it -> statistics, Mish, shift and residual in the
         // conv's own epilogue, no slabs and no GroupNorm launch (conv_local.hip)
         return conv_gn_local(src0, c0, src1, c1, c.P + cw.wl, cw.has_bias ? c.P + cw.b : nullptr, c.P + n.g, c.P + n.b, temb,
-                             c.u.temb_total, c.temb_rows, addend, out, c.B, H, W, N, GROUPS, GN_EPS, c.st);
+                             c.u.temb_total, c.temb_rows, addend, out, c.B, H, W, N, GROUPS, GN_EPS, c.st, as);
     if (cw.has_wwl && H * W == 64 && conv_gn_wlocal_ok(H, W, c0 + c1, c0, N, GROUPS))
         // 8x8 maps: the same image-local tiling in Winograd form
         return conv_gn_wlocal(src0, c0, src1, c1, c.P + cw.wwl, cw.has_bias ? c.P + cw.b : nullptr, c.P + n.g, c.P + n.b, temb,
-                              c.u.temb_total, c.temb_rows, addend, out, c.B, H, W, N, GROUPS, GN_EPS, c.st);
+                              c.u.temb_total, c.temb_rows, addend, out, c.B, H, W, N, GROUPS, GN_EPS, c.st, as);
+    if (as.n > 1) return fail_arg("run_conv_gn: slab addend on a path that cannot sum it");
     const int np = cw.has_wu ? conv_wino_stats_parts(c.B, H, W, c0 + c1, N, GROUPS) : 0;
     if (np > 0) {
         // one-pass Winograd conv: its epilogue leaves per-tile {mean, M2}; GroupNorm then is a single streaming read + write
@@ -588,12 +594,33 @@ static int run_res(Ctx& c, const ResW& r, const float* src0, int c0, const float
     float* res = c.W + c.ly.off_res;
     // the 1x1 skip first: the second conv's split-K slabs and the skip conv's would otherwise share the workspace
     const float* addend = src0;
+    AddendSlabs as;
     if (r.has_res) {
-        DDK_TRY(run_conv(c, DDK_CONV1X1, r.res, src0, c0, src1, c1, nullptr, res, H, W, r.co));
-        addend = res;
+        const int rs = conv_splits(DDK_CONV1X1, c.B, H, W, c0 + c1, r.co);
+        if (rs > 1 && conv_gn_is_local(r.c1, H, W, c0, c1, r.co) && conv_gn_is_local(r.c2, H, W, r.co, 0, r.co)) {
+            // neither Block conv touches the split-K workspace on these maps: the skip conv leaves its slabs there and the
+            // second Block's epilogue sums them (+ bias) while it adds the residual -- no reduce launch
+            ddk_conv_args a{};
+            a.kind = DDK_CONV1X1;
+            a.src0 = src0; a.src1 = src1; a.c0 = c0; a.c1 = c1;
+            a.weight = c.P + r.res.w;
+            a.out = res;                      // unused: the slabs are the result
+            a.B = c.B; a.H = H; a.W = W; a.N = r.co;
+            a.defer_reduce = 1;
+            a.workspace = c.W + c.ly.off_splitk;
+            a.workspace_bytes = c.ly.splitk * sizeof(float);
+            DDK_TRY(conv_forward(a, c.st));
+            addend = c.W + c.ly.off_splitk;
+            as.n = rs;
+            as.stride = (long long)c.B * H * W * r.co;
+            as.bias = r.res.has_bias ? c.P + r.res.b : nullptr;
+        } else {
+            DDK_TRY(run_conv(c, DDK_CONV1X1, r.res, src0, c0, src1, c1, nullptr, res, H, W, r.co));
+            addend = res;
+        }
     }
     DDK_TRY(run_conv_gn(c, r.c1, src0, c0, src1, c1, raw, r.n1, c.temb + r.temb_off, nullptr, a1, H, W, r.co));
-    return run_conv_gn(c, r.c2, a1, r.co, nullptr, 0, raw, r.n2, nullptr, addend, out, H, W, r.co);
+    return run_conv_gn(c, r.c2, a1, r.co, nullptr, 0, raw, r.n2, nullptr, addend, out, H, W, r.co, as);
 }
 
 // blocks.py:8-14,63-71,126-134: out = to_out(attn(to_qkv(LN(x)))) + x

@@ -296,8 +296,8 @@ size_t ddk_sampler_workspace_bytes(const ddk_unet* u, int B, int H, int W, int t
 /* Runs steps t_start .. t_end.  With use_graph the plan keeps the captured step (a hipGraphExec_t) and the per-timestep
  * shift table it computed in `workspace`, keyed by the buffer pointers, shape, t_start and the plan's weight epoch: the
  * first call on a buffer set runs one step eagerly, captures and instantiates (a one-step graph and, for chains that can be
- * long, an 8-step graph); every later call on the same buffers only writes {t_start, seed, stream_id} into the workspace and
- * issues one hipGraphLaunch per 8 steps plus one per remaining step (seed, stream id and t are read from device memory by
+ * long, a 16-step graph); every later call on the same buffers only writes {t_start, seed, stream_id} into the workspace and
+ * issues one hipGraphLaunch per 16 steps plus one per remaining step (seed, stream id and t are read from device memory by
  * the kernels, so they are not part of the key).  At most 4 buffer sets are cached (LRU).
  * Contract: a caller that frees or overwrites `workspace` (or frees any buffer passed here) between calls must call
  * ddk_sampler_invalidate() first. */
