@@ -1253,7 +1253,7 @@ bool conv_ln_fold_ok(int B, int H, int W, int cin, int N) {
     return c.splits == 1 && (c.tile == T64x64 || c.tile == T128x64 || c.tile == T128x128);
 }
 
-int conv_forward(const ddk_conv_args& a, hipStream_t st, const ConvLnFold* ln) {
+int conv_forward(const ddk_conv_args& a, hipStream_t st, const ConvLnFold* ln, const WinoGnFuse* fuse) {
     Geometry g;
     DDK_REQUIRE(conv_geometry(a.kind, a.H, a.W, g), "conv kind");
     DDK_REQUIRE(a.src0 && a.weight && a.out, "conv: null src0/weight/out");
@@ -1282,7 +1282,8 @@ int conv_forward(const ddk_conv_args& a, hipStream_t st, const ConvLnFold* ln) {
             }
             DDK_REQUIRE(aligned16(a.workspace), "conv: workspace alignment");
         }
-        DDK_TRY(conv_wino_forward(a, ws, st));
+        DDK_REQUIRE((long long)a.B * a.H * a.W * (a.c0 > a.c1 ? a.c0 : a.c1) * 4 < (1LL << 31), "conv(wino): a source of 2 GiB or more");
+        DDK_TRY(conv_wino_forward(a, ws, st, fuse));
         if (ws > 1 && !a.defer_reduce) {
             const long long n4 = slab / 4;
             const int blocks = (int)(ceil_div(n4, 256) < 2048 ? ceil_div(n4, 256) : 2048);
@@ -1293,6 +1294,7 @@ int conv_forward(const ddk_conv_args& a, hipStream_t st, const ConvLnFold* ln) {
         return DDK_OK;
     }
     DDK_REQUIRE(!a.gn_partials, "conv: gn_partials is only produced by the Winograd path (weight_wino given, ddk_conv_gn_partials() > 0)");
+    DDK_REQUIRE(!fuse, "conv: the in-launch GroupNorm exists on the Winograd path only");
     IgemmParams p{};
     p.src0 = a.src0; p.src1 = a.src1; p.w = a.weight; p.bias = a.bias; p.resid = a.resid; p.out = a.out;
     p.c0 = a.c0; p.c1 = a.c1; p.cin = a.c0 + a.c1;

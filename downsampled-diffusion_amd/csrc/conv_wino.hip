@@ -50,6 +50,17 @@ struct WinoParams {
     FastDivU dTW, dTH;
     float2* gn_part;       // optional: per (m tile, GroupNorm group) {mean, M2} of the output (splits == 1 only)
     int cpg, groups;       // channels per group, groups in N
+    // CL variant (GroupNorm + Mish + shift + residual finished in THIS launch): the np workgroups that hold one image's
+    // m tiles of the same n tile exchange their {mean, M2} records through memory and normalise their own tile in registers
+    const float* gn_gamma;
+    const float* gn_beta;
+    const float* gn_temb;          // [rows][gn_temb_stride] or null
+    const long long* gn_temb_rows; // row of image b (sampler: its timestep), null = b
+    int gn_temb_stride;
+    float gn_eps;
+    float* cl_rec;                 // [m tile][n tile][16 floats]: 64-byte record, {mean, M2} of up to 8 groups
+    unsigned* cl_cnt;              // [image][n tile][16]: [0] arrivals, [1] departures (self-resetting)
+    int cl_np;                     // m tiles per image = workgroups per cluster
 };
 
 constexpr int WBT = 32, WBN = 64;                        // tiles and output channels per workgroup
@@ -123,7 +134,9 @@ __device__ __forceinline__ float4 f4sub(float4 a, float4 b) { return make_float4
 // matrix wave's cycles spent waiting at the stage barriers vs multiplying; written to a buffer nothing else reads.
 __device__ unsigned long long g_wino_stamps[8 * 1024];
 
-template <int DBG>
+__device__ unsigned g_wino_cl_timeouts;       // workgroups that gave up waiting for their cluster (must stay 0; see ddk_debug_cluster_timeouts)
+
+template <int DBG, bool CL = false>
 __global__ __launch_bounds__(512) void conv3x3_wino_kernel(const WinoParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     unsigned long long r_entry = 0;
@@ -428,7 +441,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino_kernel(const WinoParams p) {
                 y0 = f4add(y0, bb);
                 y1 = f4add(y1, bb);
             }
-            if (p.resid) {
+            if (!CL && p.resid) {
                 y0 = f4add(y0, *reinterpret_cast<const float4*>(p.resid + o0));
                 y1 = f4add(y1, *reinterpret_cast<const float4*>(p.resid + o1));
             }
@@ -437,15 +450,17 @@ __global__ __launch_bounds__(512) void conv3x3_wino_kernel(const WinoParams p) {
                 y1 = make_float4(mish_f(y1.x), mish_f(y1.y), mish_f(y1.z), mish_f(y1.w));
             }
         }
-        *reinterpret_cast<float4*>(outp + o0) = y0;
-        *reinterpret_cast<float4*>(outp + o1) = y1;
+        if (!CL) {
+            *reinterpret_cast<float4*>(outp + o0) = y0;
+            *reinterpret_cast<float4*>(outp + o1) = y1;
+        }
         keep[it][0] = y0;
         keep[it][1] = y1;
     }
     // ---- optional GroupNorm statistics of this tile (the host only asks for them when every m tile is full and lies inside one
     //      image): per group {mean, M2 about that mean} over the tile's 128 pixels x cpg channels, two passes over the registers;
     //      the consumer (gn_apply_parts_kernel) merges an image's tiles in fixed order -- GroupNorm then is one read + one write.
-    if (p.gn_part) {
+    if (CL || p.gn_part) {
         const int cq = tid & 15, qpg = p.cpg >> 2;     // this thread's channel quad; quads per group
         const int gl = cq / qpg;                       // group within the 64-channel tile
         float* red = smem + 4 * 2 * WBT * W_TP;        // behind the staging area; one 128-float region per pass
@@ -469,7 +484,96 @@ __global__ __launch_bounds__(512) void conv3x3_wino_kernel(const WinoParams p) {
             return (a * a + b * b) + (c * c + d * d);
         };
         const float m2 = group_sum((sq4(keep[0][0]) + sq4(keep[0][1])) + (sq4(keep[1][0]) + sq4(keep[1][1])), red + 128);
-        if (tid < 16 && (cq & (qpg - 1)) == 0) p.gn_part[(long long)tile_m * p.groups + n0 / p.cpg + gl] = make_float2(mean, m2);
+        if (!CL) {
+            if (tid < 16 && (cq & (qpg - 1)) == 0) p.gn_part[(long long)tile_m * p.groups + n0 / p.cpg + gl] = make_float2(mean, m2);
+        } else {
+            // ---- cluster exchange (MI355X_MICROARCH.md, "Valid forms", first row of the sc1 table): every record byte is stored
+            // sc1 by wave 0, which drains its stores (vmcnt(0)) before its lane 0 adds to the cluster's arrival counter (agent
+            // scope); lane 0 polls the counter with sc1 loads, the other waves pass a workgroup barrier behind it, and every record
+            // is read with sc1 loads.  One workgroup per CU (144 KB of LDS).  The workgroups of a cluster have consecutive launch
+            // indices inside one XCD's run, so they are co-resident whenever the dispatcher works in order; the spin is bounded
+            // anyway (a give-up leaves wrong numbers and a non-zero g_wino_cl_timeouts, never a hang).
+            const int image = tile_m / p.cl_np;
+            unsigned long long* rec = reinterpret_cast<unsigned long long*>(p.cl_rec) + ((long long)tile_m * gridDim.y + tile_n) * 8;
+            unsigned* cnt = p.cl_cnt + ((long long)image * gridDim.y + tile_n) * 16;
+            if (tid < 16 && (cq & (qpg - 1)) == 0) {
+                const unsigned long long bits = (unsigned long long)__float_as_uint(mean) | ((unsigned long long)__float_as_uint(m2) << 32);
+                __hip_atomic_store(rec + gl, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (wid == 0) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0) {
+                    __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    unsigned spins = 0;
+                    while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)p.cl_np) {
+                        __builtin_amdgcn_s_sleep(4);
+                        if (++spins > (1u << 22)) { atomicAdd(&g_wino_cl_timeouts, 1u); break; }
+                    }
+                }
+            }
+            __syncthreads();
+            // the image's statistics: the np records of this thread's group merged in tile order (the arithmetic of
+            // gn_apply_parts_kernel, so both paths give the same bits)
+            const unsigned long long* r0 = reinterpret_cast<const unsigned long long*>(p.cl_rec) +
+                                           ((long long)image * p.cl_np * gridDim.y + tile_n) * 8 + gl;
+            float rm[8], rq[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                rm[i] = 0.f; rq[i] = 0.f;
+                if (i < p.cl_np) {
+                    const unsigned long long bits = __hip_atomic_load(r0 + (long long)i * gridDim.y * 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    rm[i] = __uint_as_float((unsigned)bits);
+                    rq[i] = __uint_as_float((unsigned)(bits >> 32));
+                }
+            }
+            if (tid == 0) {          // departure: the last one out re-arms the counters for the next launch
+                const unsigned old = __hip_atomic_fetch_add(cnt + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (old == (unsigned)p.cl_np - 1u) {
+                    __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(cnt + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            float ms = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) if (i < p.cl_np) ms += rm[i];
+            const float gmean = ms / (float)p.cl_np;
+            float gm2 = 0.f, gd2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) if (i < p.cl_np) { gm2 += rq[i]; gd2 += (rm[i] - gmean) * (rm[i] - gmean); }
+            const float n_i = 128.0f * (float)p.cpg;
+            const float rstd = 1.0f / sqrtf((gm2 + n_i * gd2) / ((float)p.cl_np * n_i) + p.gn_eps);
+            const int gn = n0 + (tid & 15) * 4;
+            const float4 ga = *reinterpret_cast<const float4*>(p.gn_gamma + gn), be = *reinterpret_cast<const float4*>(p.gn_beta + gn);
+            float4 ts = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p.gn_temb) {
+                const int b_img = (int)((long long)t0 / ((long long)p.TH * p.TW));
+                const long long tr = p.gn_temb_rows ? p.gn_temb_rows[b_img] : b_img;
+                ts = *reinterpret_cast<const float4*>(p.gn_temb + tr * p.gn_temb_stride + gn);
+            }
+            auto fin = [&](float4 v) {
+                return make_float4(mish_f((v.x - gmean) * rstd * ga.x + be.x) + ts.x, mish_f((v.y - gmean) * rstd * ga.y + be.y) + ts.y,
+                                   mish_f((v.z - gmean) * rstd * ga.z + be.z) + ts.z, mish_f((v.w - gmean) * rstd * ga.w + be.w) + ts.w);
+            };
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int item = tid + it * 512;
+                const int t = item >> 5, a = (item >> 4) & 1;
+                const int g = t0 + t;
+                const unsigned tmp = fdiv_u((unsigned)g, p.dTW);
+                const int tx = g - (int)tmp * p.TW;
+                const unsigned bq = fdiv_u(tmp, p.dTH);
+                const int ty = (int)tmp - (int)bq * p.TH;
+                const long long o0 = ((((long long)bq * p.H + 2 * ty + a) * p.W) + 2 * tx) * p.N + gn;
+                const long long o1 = o0 + p.N;
+                float4 y0 = fin(keep[it][0]), y1 = fin(keep[it][1]);
+                if (p.resid) {
+                    y0 = f4add(y0, *reinterpret_cast<const float4*>(p.resid + o0));
+                    y1 = f4add(y1, *reinterpret_cast<const float4*>(p.resid + o1));
+                }
+                *reinterpret_cast<float4*>(p.out + o0) = y0;
+                *reinterpret_cast<float4*>(p.out + o1) = y1;
+            }
+        }
     }
     if (DBG && tid == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -508,6 +612,8 @@ int conv_wino_stats_parts(int B, int H, int W, int cin, int N, int groups) {
 int conv_wino_init_device() {
     DDK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)(W_LDS_FLOATS * sizeof(float))));
+    DDK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_kernel<0, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(W_LDS_FLOATS * sizeof(float))));
 #ifdef DDK_TUNING   // 1: stamps; 2: + loaders exit after the prologue; 3: + loaders at priority 0; 4: + no U DMA in the loop (2-4: wrong results)
     DDK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(W_LDS_FLOATS * sizeof(float))));
     DDK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(W_LDS_FLOATS * sizeof(float))));
@@ -517,9 +623,41 @@ int conv_wino_init_device() {
     return DDK_OK;
 }
 
+// Cluster variant: can this shape finish GroupNorm inside the conv launch?  One-pass shape with partials, at most 8 m tiles per
+// image, and every cluster resident at once under in-order dispatch: at most 256 workgroups per round and whole clusters per round.
+int conv_wino_cluster_np(int B, int H, int W, int cin, int N, int groups) {
+    const int np = conv_wino_stats_parts(B, H, W, cin, N, groups);
+    if (np <= 0 || np > 8) return 0;
+    if (N / groups > 32 || WBN % (N / groups)) return 0;        // a 64-byte record holds the n tile's <= 8 groups ... of >= 8 channels
+    if (WBN / (N / groups) > 8) return 0;
+    const long long mt = (long long)B * np, nt = N / WBN;
+    if ((mt * nt) % 8) return 0;                                 // the XCD-aware order below assumes equal runs per XCD
+    // a round = the first 256 launch indices = 32 logical tiles (n fastest, then m) of each XCD's run: whole clusters only
+    const long long run = mt * nt / 8;                           // logical tiles per XCD
+    const long long per_round = run < 32 ? run : 32;
+    if (run % (np * nt) || per_round % (np * nt)) return 0;      // runs and rounds begin on cluster boundaries
+    return np;
+}
+size_t conv_wino_cluster_ws_floats(int B, int H, int W, int N) {
+    const long long mt = (long long)B * (H / 2) * (W / 2) / WBT, nt = N / WBN;
+    return (size_t)(mt * nt * 16 + (long long)B * nt * 16);
+}
+
 // a: validated by conv_forward (shapes, alignment).  Writes the result (or, with splits > 1, the slabs in a.workspace).
-int conv_wino_forward(const ddk_conv_args& a, int splits, hipStream_t st) {
+int conv_wino_forward(const ddk_conv_args& a, int splits, hipStream_t st, const WinoGnFuse* fuse) {
     WinoParams p{};
+    if (fuse) {
+        const int np = conv_wino_cluster_np(a.B, a.H, a.W, a.c0 + a.c1, a.N, fuse->groups);
+        DDK_REQUIRE(np > 0 && splits == 1 && !a.post_mish && !a.gn_partials, "conv(wino): shape not eligible for the in-launch GroupNorm");
+        DDK_REQUIRE(fuse->gamma && fuse->beta && fuse->records && fuse->counters && aligned16(fuse->gamma) && aligned16(fuse->beta) &&
+                        aligned16(fuse->temb) && fuse->temb_stride % 4 == 0 && aligned16(fuse->records) && aligned16(fuse->counters),
+                    "conv(wino): in-launch GroupNorm arguments");
+        p.gn_gamma = fuse->gamma; p.gn_beta = fuse->beta; p.gn_temb = fuse->temb; p.gn_temb_rows = fuse->temb_rows;
+        p.gn_temb_stride = fuse->temb_stride; p.gn_eps = fuse->eps;
+        p.cl_rec = fuse->records; p.cl_cnt = fuse->counters; p.cl_np = np;
+        p.groups = fuse->groups;
+        p.cpg = a.N / fuse->groups;
+    }
     if (a.gn_partials) {
         DDK_REQUIRE(conv_wino_stats_parts(a.B, a.H, a.W, a.c0 + a.c1, a.N, a.gn_groups) > 0 && splits == 1 && !a.resid && !a.post_mish,
                     "conv: gn_partials needs a shape with ddk_conv_gn_partials() > 0 and no resid / post_mish");
@@ -551,8 +689,18 @@ int conv_wino_forward(const ddk_conv_args& a, int splits, hipStream_t st) {
         return check_launch("conv3x3_wino_kernel<dbg>");
     }
 #endif
+    if (fuse) {
+        hipLaunchKernelGGL((conv3x3_wino_kernel<0, true>), grid, dim3(512), W_LDS_FLOATS * sizeof(float), st, p);
+        return check_launch("conv3x3_wino_kernel<cluster>");
+    }
     hipLaunchKernelGGL(conv3x3_wino_kernel<0>, grid, dim3(512), W_LDS_FLOATS * sizeof(float), st, p);
     return check_launch("conv3x3_wino_kernel");
+}
+
+unsigned conv_wino_cluster_timeouts() {
+    unsigned v = 0;
+    if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_wino_cl_timeouts), sizeof(v)) != hipSuccess) return ~0u;
+    return v;
 }
 
 }  // namespace ddk
@@ -584,3 +732,38 @@ extern "C" int ddk_conv_wino_splits(int B, int H, int W, int cin, int N) {
     if (!ddk::conv_wino_ok(DDK_CONV3X3_S1, H, W, cin, N)) return 0;
     return ddk::conv_wino_splits(B, H, W, cin, N);
 }
+
+/* Block of models/unet/blocks.py:75-84,110-115 in ONE Winograd launch on maps whose images span several workgroups (32x32,
+ * 16x16): see WinoGnFuse / the CL variant above. */
+extern "C" int ddk_conv3x3_gn_mish_cluster_ok(int B, int H, int W, int cin, int N, int groups) {
+    return ddk::conv_wino_cluster_np(B, H, W, cin, N, groups);
+}
+extern "C" size_t ddk_conv3x3_gn_mish_cluster_workspace_bytes(int B, int H, int W, int N) {
+    if (B <= 0 || H <= 0 || W <= 0 || N <= 0 || N % ddk::WBN) return 0;
+    return ((size_t)B * 8 * 16 + ddk::conv_wino_cluster_ws_floats(B, H, W, N)) * sizeof(float);
+}
+extern "C" int ddk_conv3x3_gn_mish_cluster(const float* src0, int c0, const float* src1, int c1, const float* weight_wino, const float* bias,
+                                           const float* gamma, const float* beta, const float* temb, int temb_stride, const float* addend,
+                                           float* out, int B, int H, int W, int N, int groups, float eps, void* workspace,
+                                           size_t workspace_bytes, ddk_stream_t s) {
+    using namespace ddk;
+    DDK_REQUIRE(src0 && weight_wino && gamma && beta && out && workspace, "conv3x3_gn_mish_cluster: null pointer");
+    DDK_REQUIRE(conv_wino_cluster_np(B, H, W, c0 + c1, N, groups) > 0, "conv3x3_gn_mish_cluster: shape not eligible "
+                "(ddk_conv3x3_gn_mish_cluster_ok)");
+    DDK_REQUIRE(workspace_bytes >= ddk_conv3x3_gn_mish_cluster_workspace_bytes(B, H, W, N) && aligned16(workspace),
+                "conv3x3_gn_mish_cluster: workspace");
+    float* ws = static_cast<float*>(workspace);
+    DDK_HIP(hipMemsetAsync(ws, 0, (size_t)B * 8 * 16 * sizeof(float), as_stream(s)));
+    ddk_conv_args a{};
+    a.kind = DDK_CONV3X3_S1;
+    a.src0 = src0; a.src1 = src1; a.c0 = c0; a.c1 = c1;
+    a.weight = weight_wino;          // only validated as non-null: the Winograd path reads weight_wino
+    a.weight_wino = weight_wino;
+    a.bias = bias;
+    a.resid = addend;
+    a.out = out;
+    a.B = B; a.H = H; a.W = W; a.N = N;
+    const WinoGnFuse f{gamma, beta, temb, nullptr, temb_stride, eps, groups, ws + (size_t)B * 8 * 16, reinterpret_cast<unsigned*>(ws)};
+    return conv_forward(a, as_stream(s), nullptr, &f);
+}
+

@@ -125,13 +125,30 @@ struct ConvLnFold {
     const float* c2;
     float eps;
 };
+// GroupNorm + Mish (+ time shift, + residual = ddk_conv_args.resid) finished inside the Winograd conv's launch: the workgroups
+// of one image exchange their per-tile statistics through `records` / `counters` (conv_wino_cluster_ws_floats() floats, the
+// counters zero before the first launch; they re-arm themselves)
+struct WinoGnFuse {
+    const float* gamma;
+    const float* beta;
+    const float* temb;
+    const long long* temb_rows;
+    int temb_stride;
+    float eps;
+    int groups;
+    float* records;
+    unsigned* counters;
+};
 bool conv_ln_fold_ok(int B, int H, int W, int cin, int N);
-int conv_forward(const ddk_conv_args& a, hipStream_t st, const ConvLnFold* ln = nullptr);
+int conv_forward(const ddk_conv_args& a, hipStream_t st, const ConvLnFold* ln = nullptr, const WinoGnFuse* fuse = nullptr);
 int conv_splits(int kind, int B, int H, int W, int cin, int N);
 // conv_wino.hip
 bool conv_wino_ok(int kind, int H, int W, int cin, int N);
 int conv_wino_splits(int B, int H, int W, int cin, int N);
-int conv_wino_forward(const ddk_conv_args& a, int splits, hipStream_t st);
+int conv_wino_forward(const ddk_conv_args& a, int splits, hipStream_t st, const WinoGnFuse* fuse = nullptr);
+int conv_wino_cluster_np(int B, int H, int W, int cin, int N, int groups);    // m tiles per image when eligible, else 0
+size_t conv_wino_cluster_ws_floats(int B, int H, int W, int N);
+unsigned conv_wino_cluster_timeouts();
 int conv_wino_init_device();
 int conv_wino_stats_parts(int B, int H, int W, int cin, int N, int groups);   // tiles per image, or 0
 // conv_first.hip: Conv2d(C_in <= 8, N, 3, padding=1) on the unpadded input, GroupNorm partials in the epilogue; with

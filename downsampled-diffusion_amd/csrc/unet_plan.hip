@@ -91,6 +91,8 @@ struct ddk_unet {
     unsigned long long pack_epoch = 0;       // bumped by every pack / finalize: weights changed
     struct { const void* ws = nullptr; int t_start = -1, B = 0, H = 0, W = 0; unsigned long long pack_epoch = 0; } table;
     ddk_unet_config cfg;
+    bool cluster_gn = true;                  // GroupNorm finished inside the Winograd conv launch where eligible (ddk_unet_set_option)
+    int cluster_limit = 1 << 30;             // diagnostic: only the first so many eligible launches of a forward take that path
     std::vector<Slot> slots;
     size_t packed_floats = 0;
     int L = 0;
@@ -312,6 +314,23 @@ extern "C" int ddk_sampler_invalidate(ddk_unet* u) {
     drop_graphs(u);
     return DDK_OK;
 }
+extern "C" int ddk_unet_set_option(ddk_unet* u, int option, int value) {
+    DDK_REQUIRE(u, "unet_set_option: null plan");
+    if (option == DDK_OPT_CLUSTER_GROUPNORM) {
+        std::lock_guard<std::mutex> lock(u->mu);
+        if (!u->graphs.empty()) DDK_HIP(hipDeviceSynchronize());
+        drop_graphs(u);                          // a captured step bakes the choice in
+        u->cluster_gn = value != 0;
+        return DDK_OK;
+    }
+    if (option == 2) {   // diagnostic (not in ddk.h): cap on the cluster launches per forward
+        std::lock_guard<std::mutex> lock(u->mu);
+        u->cluster_limit = value;
+        return DDK_OK;
+    }
+    return fail_arg("unet_set_option: unknown option");
+}
+extern "C" unsigned ddk_debug_cluster_timeouts(void) { return ddk::conv_wino_cluster_timeouts(); }
 extern "C" int ddk_unet_num_slots(const ddk_unet* u) { return u ? (int)u->slots.size() : 0; }
 extern "C" const char* ddk_unet_slot_name(const ddk_unet* u, int slot) {
     return (u && slot >= 0 && slot < (int)u->slots.size()) ? u->slots[slot].name.c_str() : nullptr;
@@ -394,12 +413,12 @@ namespace ddk {
 // Workspace carve-up (all offsets in floats, 16-byte aligned).
 struct Layout {
     size_t act = 0;      // one general activation buffer (max over layers of M*C)
-    size_t qkv = 0, o = 0, ctx = 0, splitk = 0, gn_ws = 0;
+    size_t qkv = 0, o = 0, ctx = 0, splitk = 0, gn_ws = 0, cl = 0;
     std::vector<size_t> skip;  // per level
     size_t xpad = 0, temb = 0, tact = 0;
     // offsets
     size_t off_A = 0, off_B = 0, off_C = 0, off_raw = 0, off_a1 = 0, off_res = 0, off_xn = 0, off_qkv = 0, off_o = 0, off_ctx = 0,
-           off_splitk = 0, off_gn = 0, off_xpad = 0, off_temb = 0, off_tact = 0;
+           off_splitk = 0, off_gn = 0, off_xpad = 0, off_temb = 0, off_tact = 0, off_cl = 0;
     std::vector<size_t> off_skip;
     size_t total = 0;
 };
@@ -422,6 +441,9 @@ static size_t conv3_ws_floats(const ConvW& cw, int B, int H, int W, int cin, int
     return s > 1 ? (size_t)s * B * H * W * N : 0;
 }
 
+// counters of the cluster GroupNorm: fixed place (16 words per (image, n tile), N <= 512) so every layer re-arms the same words
+static size_t cl_counter_floats(int B) { return (size_t)B * 8 * 16; }
+
 static void res_sizes(const ResW& r, int B, int H, int W, Layout& ly) {
     const size_t M = (size_t)B * H * W;
     upd(ly.act, M * r.co);
@@ -430,6 +452,7 @@ static void res_sizes(const ResW& r, int B, int H, int W, Layout& ly) {
     if (r.has_res) upd(ly.splitk, conv_workspace_bytes(DDK_CONV1X1, B, H, W, r.ci_pad, r.co) / 4);
     upd(ly.gn_ws, groupnorm_workspace_bytes(B, H * W, r.co, GROUPS) / 4);
     upd(ly.gn_ws, (size_t)2 * GROUPS * (M / 128 + 1));      // {mean, M2} partials the Winograd conv leaves for GroupNorm
+    upd(ly.cl, cl_counter_floats(B) + conv_wino_cluster_ws_floats(B, H, W, r.co));   // cluster GroupNorm: counters, then records
 }
 
 static void attn_sizes(const AttnW& a, int B, int H, int W, Layout& ly) {
@@ -478,14 +501,14 @@ static Layout make_layout(const ddk_unet& u, int B, int H0, int W0) {
     ly.temb = al4((size_t)B * u.temb_total);
     ly.tact = al4((size_t)B * u.time_dim);
     ly.act = al4(ly.act); ly.qkv = al4(ly.qkv); ly.o = al4(ly.o); ly.ctx = al4(ly.ctx);
-    ly.splitk = al4(ly.splitk); ly.gn_ws = al4(ly.gn_ws);
+    ly.splitk = al4(ly.splitk); ly.gn_ws = al4(ly.gn_ws); ly.cl = al4(ly.cl);
 
     size_t off = 0;
     auto take = [&](size_t n) { const size_t o = off; off += n; return o; };
     ly.off_A = take(ly.act); ly.off_B = take(ly.act); ly.off_C = take(ly.act);
     ly.off_raw = take(ly.act); ly.off_a1 = take(ly.act); ly.off_res = take(ly.act); ly.off_xn = take(ly.act);
     ly.off_qkv = take(ly.qkv); ly.off_o = take(ly.o); ly.off_ctx = take(ly.ctx);
-    ly.off_splitk = take(ly.splitk); ly.off_gn = take(ly.gn_ws);
+    ly.off_splitk = take(ly.splitk); ly.off_gn = take(ly.gn_ws); ly.off_cl = take(ly.cl);
     ly.off_xpad = take(ly.xpad); ly.off_temb = take(ly.temb); ly.off_tact = take(ly.tact);
     ly.off_skip.resize(u.L);
     for (int l = 0; l < u.L; ++l) ly.off_skip[l] = take(ly.skip[l]);
@@ -502,6 +525,7 @@ struct Ctx {
     hipStream_t st;
     const float* temb;            // [B][temb_total], or the sampler's per-timestep table [t_start+1][temb_total]
     const long long* temb_rows;   // nullptr: row b;  sampler: row = t_cur[b] (device), so one table serves every step
+    int n_cluster = 0;            // cluster launches issued so far in this forward
 };
 
 static int run_conv(Ctx& c, int kind, const ConvW& cw, const float* src0, int c0, const float* src1, int c1, const float* resid,
@@ -542,6 +566,22 @@ static int run_conv_gn(Ctx& c, const ConvW& cw, const float* src0, int c0, const
         return conv_gn_wlocal(src0, c0, src1, c1, c.P + cw.wwl, cw.has_bias ? c.P + cw.b : nullptr, c.P + n.g, c.P + n.b, temb,
                               c.u.temb_total, c.temb_rows, addend, out, c.B, H, W, N, GROUPS, GN_EPS, c.st, as);
     if (as.n > 1) return fail_arg("run_conv_gn: slab addend on a path that cannot sum it");
+    if (c.u.cluster_gn && cw.has_wu && conv_wino_cluster_np(c.B, H, W, c0 + c1, N, GROUPS) > 0 && c.n_cluster++ < c.u.cluster_limit) {
+        // one launch: the workgroups of an image exchange their tile statistics and normalise their own tile in registers
+        ddk_conv_args a{};
+        a.kind = DDK_CONV3X3_S1;
+        a.src0 = src0; a.src1 = src1; a.c0 = c0; a.c1 = c1;
+        a.weight = c.P + cw.w;
+        a.weight_wino = c.P + cw.wu;
+        a.bias = cw.has_bias ? c.P + cw.b : nullptr;
+        a.resid = addend;
+        a.out = out;
+        a.B = c.B; a.H = H; a.W = W; a.N = N;
+        float* cl = c.W + c.ly.off_cl;
+        const WinoGnFuse f{c.P + n.g, c.P + n.b, temb, c.temb_rows, c.u.temb_total, GN_EPS, GROUPS, cl + cl_counter_floats(c.B),
+                           reinterpret_cast<unsigned*>(cl)};
+        return conv_forward(a, c.st, nullptr, &f);
+    }
     const int np = cw.has_wu ? conv_wino_stats_parts(c.B, H, W, c0 + c1, N, GROUPS) : 0;
     if (np > 0) {
         // one-pass Winograd conv: its epilogue leaves per-tile {mean, M2}; GroupNorm then is a single streaming read + write
@@ -861,6 +901,8 @@ extern "C" int ddk_unet_forward(const ddk_unet* u, const void* packed, const flo
     }
     float* ws = static_cast<float*>(workspace);
     DDK_TRY(ensure_device_init());
+    // the cluster GroupNorm's arrival / departure counters start at zero (they re-arm themselves after every launch)
+    DDK_HIP(hipMemsetAsync(ws + ly.off_cl, 0, cl_counter_floats(B) * sizeof(float), as_stream(s)));
     return forward_core(*u, static_cast<const float*>(packed), x, const_cast<int64_t*>(t), out, B, H, W, ws, ly, as_stream(s));
 }
 
@@ -1026,6 +1068,7 @@ extern "C" int ddk_sampler_run(const ddk_sampler_args* a, ddk_stream_t s) {
     };
 
     std::lock_guard<std::mutex> lock(u.mu);
+    DDK_HIP(hipMemsetAsync(ws + ly.off_cl, 0, cl_counter_floats(B) * sizeof(float), st));    // cluster GroupNorm counters (outside the graph)
     hipLaunchKernelGGL(set_chain_state_kernel, dim3(1), dim3(1), 0, st, state, (int64_t)a->t_start, a->seed, a->stream_id);
     DDK_TRY(check_launch("set_chain_state_kernel"));
     // Time-shift table for t = 0..t_start: the same two kernels a forward runs, once, with "batch" = all timesteps.  It

@@ -258,6 +258,29 @@ def final_tail(raw, part, tiles_per_image, gamma, beta, w, bias, x=None, t=None,
     return eps_out
 
 
+def conv3x3_gn_mish_cluster(x, w_wino, bias, gamma, beta, x2=None, temb=None, addend=None, groups=GN_GROUPS, eps=GN_EPS):
+    """Block (conv3x3 + GroupNorm + Mish + shift + residual) in ONE Winograd launch whose workgroups exchange tile statistics
+    (ddk_conv3x3_gn_mish_cluster); raises when the shape is not eligible."""
+    b, h, w_, c0 = x.shape
+    c1 = 0 if x2 is None else x2.shape[-1]
+    n = w_wino.shape[2]
+    lib = L.load()
+    if lib.ddk_conv3x3_gn_mish_cluster_ok(b, h, w_, c0 + c1, n, groups) <= 0:
+        raise L.DDKError(f"conv3x3_gn_mish_cluster: shape {tuple(x.shape)} (+{c1}) -> {n} not eligible")
+    nbytes = lib.ddk_conv3x3_gn_mish_cluster_workspace_bytes(b, h, w_, n)
+    ws = _ws(x.device, nbytes, "cluster")
+    out = torch.empty((b, h, w_, n), device=x.device, dtype=torch.float32)
+    stride = temb.stride(0) if temb is not None else 0
+    L.check(lib.ddk_conv3x3_gn_mish_cluster(L.ptr(_f32(x)), c0, L.ptr(x2), c1, L.ptr(w_wino), L.ptr(bias), L.ptr(gamma), L.ptr(beta),
+                                            temb.data_ptr() if temb is not None else None, stride, L.ptr(addend), L.ptr(out), b, h, w_, n,
+                                            groups, eps, L.ptr(ws), nbytes, L.stream()), "conv3x3_gn_mish_cluster")
+    return out
+
+
+def cluster_timeouts():
+    return int(L.load().ddk_debug_cluster_timeouts())
+
+
 def conv3x3_groupnorm_mish(x, w_packed, bias, gamma, beta, x2=None, temb=None, addend=None, groups=GN_GROUPS, eps=GN_EPS, w_wino=None):
     """conv3x3(pad 1) -> GroupNorm -> Mish (+temb)(+addend), two launches.  When the conv splits k its partial slabs are summed by
     the GroupNorm kernel's load (ddk_groupnorm_mish_slabs) instead of a separate reduce pass.  w_wino: the Winograd-domain filter

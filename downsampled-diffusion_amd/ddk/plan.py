@@ -81,6 +81,15 @@ class UnetPlan:
             self._ws[kind] = hit
         return hit[1]
 
+    OPT_CLUSTER_GROUPNORM = 1
+
+    def set_option(self, option, value):
+        """ddk_unet_set_option: e.g. (OPT_CLUSTER_GROUPNORM, 0) keeps conv + GroupNorm-apply as two launches."""
+        L.check(self._lib.ddk_unet_set_option(self.handle, option, int(value)), "unet_set_option")
+
+    def cluster_timeouts(self):
+        return int(self._lib.ddk_debug_cluster_timeouts())
+
     def flops(self, b, h, w):
         return self._lib.ddk_unet_flops(self.handle, b, h, w)
 

@@ -154,6 +154,16 @@ int ddk_conv3x3_gn_mish_wino_ok(int H, int W, int cin, int c0, int N, int groups
 int ddk_conv3x3_gn_mish_wino(const float* src0, int c0, const float* src1, int c1, const float* weight, const float* bias,
                              const float* gamma, const float* beta, const float* temb, int temb_stride, const float* addend,
                              float* out, int B, int H, int W, int N, int groups, float eps, ddk_stream_t s);
+/* The same Block in ONE launch on maps whose images span several 128-pixel tiles (32x32, 16x16): the Winograd conv's workgroups
+ * of one image exchange their tile statistics through `workspace` and finish GroupNorm + Mish (+ temb[b][c]) (+ addend) on their own
+ * tile in registers (blocks.py:75-84,110-115).  Eligible when ddk_conv3x3_gn_mish_cluster_ok() > 0: one-pass Winograd shape
+ * (ddk_conv_gn_partials() > 0), <= 8 tiles per image, whole clusters per dispatch round.  weight_wino: ddk_pack_conv_weight_wino. */
+int ddk_conv3x3_gn_mish_cluster_ok(int B, int H, int W, int cin, int N, int groups);
+size_t ddk_conv3x3_gn_mish_cluster_workspace_bytes(int B, int H, int W, int N);
+int ddk_conv3x3_gn_mish_cluster(const float* src0, int c0, const float* src1, int c1, const float* weight_wino, const float* bias,
+                                const float* gamma, const float* beta, const float* temb, int temb_stride, const float* addend,
+                                float* out, int B, int H, int W, int N, int groups, float eps, void* workspace, size_t workspace_bytes,
+                                ddk_stream_t s);
 /* per-pixel channel LayerNorm, (x-mean)/(sqrt(var)+eps)*g+b, biased var (blocks.py:57-60). */
 int ddk_chan_layernorm(const float* x, const float* g, const float* b, float* out, long long M, int C,
                        float eps, ddk_stream_t s);
@@ -263,6 +273,13 @@ size_t ddk_unet_workspace_bytes(const ddk_unet* u, int B, int H, int W);
 /* eps_hat = Unet(x, t).  x: NHWC [B][H][W][in_ch] (unpadded), out same shape. */
 int ddk_unet_forward(const ddk_unet* u, const void* packed, const float* x, const int64_t* t, float* out,
                      int B, int H, int W, void* workspace, size_t workspace_bytes, ddk_stream_t s);
+/* Plan options.  DDK_OPT_CLUSTER_GROUPNORM (default 1): where a Block's 3x3 conv runs as a one-pass Winograd launch whose
+ * workgroups of one image are co-resident, GroupNorm + Mish + shift + residual finish INSIDE that launch (the workgroups exchange
+ * their tile statistics through the workspace); 0 keeps the conv + GroupNorm-apply pair.  Changing it drops cached sampler graphs. */
+#define DDK_OPT_CLUSTER_GROUPNORM 1
+int ddk_unet_set_option(ddk_unet* u, int option, int value);
+/* workgroups that ever gave up waiting for their cluster in this process (0 unless the GPU could not host a whole cluster) */
+unsigned ddk_debug_cluster_timeouts(void);
 /* FLOPs (2*MAC) of one forward for B samples at HxW: the algorithmic work bench.py prices. */
 double ddk_unet_flops(const ddk_unet* u, int B, int H, int W);
 /* FLOPs the plan's kernels really issue for that forward: 3x3 convs dispatched to a Winograd F(2x2,3x3) kernel count 16/36 of

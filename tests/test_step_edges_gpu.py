@@ -166,3 +166,76 @@ def test_unet_forward_takes_the_fast_edges():
             y = net(x.to(DEV), t.to(DEV)).cpu()
         ref = U.unet_forward(sd, cfg, x, t)
         assert rel_err(y, ref) < 5e-5
+
+
+# ---------------------------------------------------------------- GroupNorm finished inside the Winograd conv launch
+CLUSTER_CASES = [
+    # B, H, W, c0, c1, N: cfg4's eligible Block shapes (32x32: 8 workgroups per image cluster, 2 rounds; 16x16: 2 per cluster)
+    (32, 32, 32, 128, 0, 128), (32, 16, 16, 128, 0, 256), (32, 16, 16, 256, 0, 256), (64, 32, 32, 128, 0, 128), (16, 32, 32, 128, 0, 128),
+    (64, 16, 16, 128, 0, 128), (64, 16, 16, 64, 64, 128),
+]
+
+
+@pytest.mark.parametrize("B,H,W,c0,c1,N", CLUSTER_CASES)
+def test_conv3x3_gn_mish_cluster(ops, B, H, W, c0, c1, N):
+    """conv3x3 + GroupNorm + Mish + shift + residual in ONE Winograd launch (tile statistics exchanged between the workgroups of an
+    image) == the two-launch path (same statistics, same merge order: <= 1e-6, FMA contraction of the last adds may differ),
+    == torch within 2e-5; bit-stable run to run; no cluster ever timed out"""
+    cin = c0 + c1
+    if ops.L.load().ddk_conv3x3_gn_mish_cluster_ok(B, H, W, cin, N, 8) <= 0:
+        pytest.skip("shape not eligible")
+    x = rnd(B, cin, H, W, seed=41)
+    w = rnd(N, cin, 3, 3, seed=42, scale=(cin * 9) ** -0.5)
+    b = rnd(N, seed=43)
+    gamma, beta, temb = 1 + 0.1 * rnd(N, seed=44), 0.1 * rnd(N, seed=45), rnd(B, N, seed=46)
+    add = rnd(B, N, H, W, seed=47)
+    xh = to_nhwc(x).to(DEV)
+    x0, x1 = (xh[..., :c0].contiguous(), xh[..., c0:].contiguous()) if c1 else (xh, None)
+    wu = ops.pack_conv_weight_wino(w.to(DEV))
+    before = ops.cluster_timeouts()
+    out = ops.conv3x3_gn_mish_cluster(x0, wu, b.to(DEV), gamma.to(DEV), beta.to(DEV), x2=x1, temb=temb.to(DEV), addend=to_nhwc(add).to(DEV))
+    out2 = ops.conv3x3_gn_mish_cluster(x0, wu, b.to(DEV), gamma.to(DEV), beta.to(DEV), x2=x1, temb=temb.to(DEV), addend=to_nhwc(add).to(DEV))
+    torch.cuda.synchronize()
+    assert ops.cluster_timeouts() == before
+    assert torch.equal(out, out2)
+    raw, part, tiles = ops.conv_with_gn_partials(x0, ops.pack_conv_weight(w.to(DEV)), b.to(DEV), wu, x2=x1)
+    two = ops.groupnorm_mish_from_partials(raw, part, tiles, gamma.to(DEV), beta.to(DEV), temb=temb.to(DEV), addend=to_nhwc(add).to(DEV))
+    assert rel_err(out.cpu(), two.cpu()) < 1e-6
+    if B <= 32:
+        want = gn_mish(F.conv2d(x, w, b, padding=1), gamma, beta) + temb[:, :, None, None] + add
+        assert rel_err(to_nchw(out.cpu()), want) < 2e-5
+    # no shift, no residual
+    out3 = ops.conv3x3_gn_mish_cluster(x0, wu, b.to(DEV), gamma.to(DEV), beta.to(DEV), x2=x1)
+    assert rel_err(out3.cpu(), ops.groupnorm_mish_from_partials(raw, part, tiles, gamma.to(DEV), beta.to(DEV)).cpu()) < 1e-6
+    # consecutive launches on DIFFERENT inputs through the same records / counters: a stale record would show
+    for k in range(3):
+        xk = (xh * (k + 2.0)).contiguous()
+        xk0, xk1 = (xk[..., :c0].contiguous(), xk[..., c0:].contiguous()) if c1 else (xk, None)
+        ok = ops.conv3x3_gn_mish_cluster(xk0, wu, b.to(DEV), gamma.to(DEV), beta.to(DEV), x2=xk1)
+        rk, pk, _ = ops.conv_with_gn_partials(xk0, ops.pack_conv_weight(w.to(DEV)), b.to(DEV), wu, x2=xk1)
+        assert rel_err(ok.cpu(), ops.groupnorm_mish_from_partials(rk, pk, tiles, gamma.to(DEV), beta.to(DEV)).cpu()) < 1e-6
+    assert ops.cluster_timeouts() == before
+
+
+def test_cluster_groupnorm_option_gives_identical_unet():
+    """The plan with GroupNorm finished inside the conv launches == the plan with the conv + GroupNorm-apply pairs (<= 2e-5 of the
+    output's max: the two differ in FMA contraction of the residual add only), and is bit-stable run to run"""
+    from helpers import det_state, unet_cfg
+    from models import Unet
+    from utils import synthetic as syn
+    cfg = unet_cfg(128, 8)
+    net = Unet(cfg)
+    net.load_state_dict(det_state({k: v.shape for k, v in net.state_dict().items()}))
+    net = net.to(DEV).eval()
+    x = syn.synthetic_normal((32, 8, 32, 32), "cluster.x").to(DEV)
+    t = torch.arange(32, device=DEV) * 31
+    with torch.no_grad():
+        y_on = net(x, t)
+        plan = net.plan()
+        plan.set_option(plan.OPT_CLUSTER_GROUPNORM, 0)
+        y_off = net(x, t)
+        plan.set_option(plan.OPT_CLUSTER_GROUPNORM, 1)
+        y_on2 = net(x, t)
+    assert plan.cluster_timeouts() == 0
+    assert torch.equal(y_on, y_on2)
+    assert rel_err(y_on.cpu(), y_off.cpu()) < 2e-5

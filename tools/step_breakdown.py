@@ -3,8 +3,8 @@
 
 A step = the dispatches from the step's first kernel (`conv_first_kernel`, or `step_prepare_kernel` on shapes the first-layer
 kernel does not take) up to (not including) the next.  For every position in the
-step the script prints the kernel, its grid (in workgroups) and the mean duration and mean gap to the previous kernel
-over all complete steps found, then totals per kernel family.   python tools/step_breakdown.py <kernel_trace.csv>"""
+step the script prints the kernel, its grid (in workgroups) and the median duration and median gap to the previous
+kernel over all complete steps found, then totals per kernel family.   python tools/step_breakdown.py <kernel_trace.csv>"""
 import collections
 import csv
 import re
@@ -34,14 +34,18 @@ def main(path, out=sys.stdout):
     sig0 = [short(r["Kernel_Name"]) for r in steps[0]]
     steps = [s for s in steps if [short(r["Kernel_Name"]) for r in s] == sig0]
     print(f"{len(steps)} complete steps of {n} launches", file=out)
-    dur = [0.0] * n
-    gap = [0.0] * n
+    import statistics
+    durs = [[] for _ in range(n)]
+    gaps = [[0.0] for _ in range(n)]
     for s in steps:
         for i, r in enumerate(s):
-            dur[i] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+            durs[i].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
             if i:
-                gap[i] += int(r["Start_Timestamp"]) - int(s[i - 1]["End_Timestamp"])
-    k = len(steps)
+                gaps[i].append(int(r["Start_Timestamp"]) - int(s[i - 1]["End_Timestamp"]))
+    # medians: one step that borders other work (warm-up / timed boundary, a graph launch) must not smear a gap over all of them
+    dur = [statistics.median(d) for d in durs]
+    gap = [statistics.median(g) if len(g) > 1 else 0.0 for g in gaps]
+    k = 1
     fam = collections.OrderedDict()
     tot_d = tot_g = 0.0
     for i, r in enumerate(steps[0]):
