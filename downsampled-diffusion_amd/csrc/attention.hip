@@ -367,18 +367,27 @@ __global__ __launch_bounds__(256) void linattn_small_qkv_kernel(const float* __r
     {   // LayerNorm statistics of every pixel row: TPR threads per row (biased variance, eps added to the std: blocks.py:57-60)
         constexpr int TPR = 256 / ROWS;
         const int row = tid / TPR, sub = tid % TPR;
-        float s1 = 0.f, s2 = 0.f;
+        // two passes over the row (it is resident in LDS): E[x^2] - mean^2 cancels catastrophically where |mean| >> std, which the
+        // residual stream at the 4x4 bottleneck can reach; torch.var(unbiased=False) of the reference is two-pass too
+        float s1 = 0.f;
         for (int c = sub * 4; c < C; c += TPR * 4) {
             const float4 v = *reinterpret_cast<const float4*>(xs + row * pitch + c);
             s1 += (v.x + v.y) + (v.z + v.w);
-            s2 += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
         }
 #pragma unroll
-        for (int o = 1; o < TPR; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+        for (int o = 1; o < TPR; o <<= 1) s1 += __shfl_xor(s1, o, 64);
+        const float inv_c = 1.0f / (float)C;
+        const float mean = s1 * inv_c;
+        float s2 = 0.f;
+        for (int c = sub * 4; c < C; c += TPR * 4) {
+            const float4 v = *reinterpret_cast<const float4*>(xs + row * pitch + c);
+            const float a0 = v.x - mean, a1 = v.y - mean, a2 = v.z - mean, a3 = v.w - mean;
+            s2 += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+        }
+#pragma unroll
+        for (int o = 1; o < TPR; o <<= 1) s2 += __shfl_xor(s2, o, 64);
         if (sub == 0) {
-            const float inv_c = 1.0f / (float)C;
-            const float mean = s1 * inv_c;
-            const float var = fmaxf(s2 * inv_c - mean * mean, 0.f);
+            const float var = s2 * inv_c;
             const float r = 1.0f / (sqrtf(var) + ln_eps);
             rowstat[2 * row] = r;
             rowstat[2 * row + 1] = r * mean;

@@ -75,8 +75,12 @@ constexpr int W_LP = DDK_WINO_LP;                        // of a U image's 8 DMA
 static_assert(4 * 2 * WBT * W_TP <= W_LDS_FLOATS, "epilogue staging fits");
 
 // G g G^T for one (n, c): G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
+// DGRAD: the filter of the INPUT-gradient conv for the forward conv's input channels [lo, lo + O): again a 3x3 stride-1 conv, of
+// dY, with g'[n][c][a][b] = w[c][lo + n][2-a][2-b] (taps flipped, channel roles swapped); w is the forward OIHW tensor with
+// `wi` input channels, I = its output channels.  One kernel instead of flip + transpose + contiguous + pack.
+template <bool DGRAD>
 __global__ __launch_bounds__(256) void pack_conv_weight_wino_kernel(const float* __restrict__ w, float* __restrict__ dst, int O, int I,
-                                                                     int i_pad, long long total) {
+                                                                     int i_pad, long long total, int lo, int wi) {
     for (long long idx = blockIdx.x * 256LL + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
         const int c = (int)(idx % i_pad);
         const int n = (int)(idx / i_pad);
@@ -84,7 +88,10 @@ __global__ __launch_bounds__(256) void pack_conv_weight_wino_kernel(const float*
 #pragma unroll
         for (int a = 0; a < 3; ++a)
 #pragma unroll
-            for (int b = 0; b < 3; ++b) g[a][b] = c < I ? w[(((long long)n * I + c) * 3 + a) * 3 + b] : 0.f;
+            for (int b = 0; b < 3; ++b) {
+                if (DGRAD) g[a][b] = c < I ? w[(((long long)c * wi + lo + n) * 3 + (2 - a)) * 3 + (2 - b)] : 0.f;
+                else g[a][b] = c < I ? w[(((long long)n * I + c) * 3 + a) * 3 + b] : 0.f;
+            }
         float t[4][3];
 #pragma unroll
         for (int b = 0; b < 3; ++b) {
@@ -710,9 +717,20 @@ extern "C" int ddk_pack_conv_weight_wino(const float* w_oihw, float* dst, int O,
     DDK_REQUIRE(w_oihw && dst && O > 0 && I > 0 && i_pad >= I && i_pad % 32 == 0, "pack_conv_weight_wino: arguments (i_pad % 32 == 0)");
     const long long total = (long long)O * i_pad;
     const long long blocks = ceil_div(total, 256);
-    hipLaunchKernelGGL(pack_conv_weight_wino_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, as_stream(s), w_oihw, dst,
-                       O, I, i_pad, total);
+    hipLaunchKernelGGL(pack_conv_weight_wino_kernel<false>, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, as_stream(s), w_oihw,
+                       dst, O, I, i_pad, total, 0, I);
     return check_launch("pack_conv_weight_wino_kernel");
+}
+
+extern "C" int ddk_pack_conv_weight_wino_dgrad(const float* w_oihw, float* dst, int O, int I, int c_lo, int c_hi, int o_pad, ddk_stream_t s) {
+    using namespace ddk;
+    DDK_REQUIRE(w_oihw && dst && O > 0 && I > 0 && c_lo >= 0 && c_hi > c_lo && c_hi <= I && o_pad >= O && o_pad % 32 == 0,
+                "pack_conv_weight_wino_dgrad: arguments (0 <= c_lo < c_hi <= I, o_pad % 32 == 0)");
+    const long long total = (long long)(c_hi - c_lo) * o_pad;
+    const long long blocks = ceil_div(total, 256);
+    hipLaunchKernelGGL(pack_conv_weight_wino_kernel<true>, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, as_stream(s), w_oihw,
+                       dst, c_hi - c_lo, O, o_pad, total, c_lo, I);
+    return check_launch("pack_conv_weight_wino_kernel<dgrad>");
 }
 
 #ifdef DDK_TUNING

@@ -318,21 +318,28 @@ __device__ __forceinline__ float std_normal_cdf_approx(float v) {
     return 0.5f * (1.0f + tanhf(0.7978845608028654f * (v + 0.044715f * (v * v * v))));      // sqrt(2/pi)
 }
 
+// Each sample is split over `ns` workgroups (a batch of 8 full-resolution images would otherwise occupy 8 of 256 CUs); a slice
+// leaves {sum of terms, sum of squared errors} in the workspace (sc1 stores), adds to the sample's arrival counter, and the
+// workgroup whose add came last sums the ns partials IN SLICE ORDER -- deterministic whatever the arrival order -- writes the
+// outputs and re-arms the counter (MI355X_MICROARCH.md, sc1 table, first row: "the workgroup whose add came last").
 __global__ __launch_bounds__(1024) void vlb_terms_kernel(const float* __restrict__ x, const float* __restrict__ x_t,
                                                          const float* __restrict__ eps_hat, const float* __restrict__ eps,
                                                          const int64_t* __restrict__ t, const float* __restrict__ c_recip,
                                                          const float* __restrict__ c_recipm1, const float* __restrict__ c1,
                                                          const float* __restrict__ c2, const float* __restrict__ logvar,
-                                                         float* __restrict__ vlb, float* __restrict__ sqerr, long long per) {
+                                                         float* __restrict__ vlb, float* __restrict__ sqerr, long long per, int ns,
+                                                         unsigned* __restrict__ counters, float* __restrict__ partials) {
     __shared__ float red[32];
-    const int b = blockIdx.x;
+    __shared__ unsigned last;
+    const int b = blockIdx.y, sl = blockIdx.x;
     const int64_t tb = t[b];
     const float cr = c_recip[tb], crm1 = c_recipm1[tb], a1 = c1[tb], a2 = c2[tb], lv = logvar[tb];
     const float inv_var = expf(-lv), inv_std = expf(-(0.5f * lv));
     const float kl0 = (lv - lv - 1.0f) + expf(lv - lv);
     const long long base = (long long)b * per;
+    const long long chunk = (per + ns - 1) / ns, i0 = sl * chunk, i1 = i0 + chunk < per ? i0 + chunk : per;
     float acc = 0.f, sq = 0.f;
-    for (long long i = threadIdx.x; i < per; i += blockDim.x) {
+    for (long long i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
         const float xv = x[base + i], xt = x_t[base + i], eh = eps_hat[base + i];
         float x0 = __fsub_rn(__fmul_rn(cr, xt), __fmul_rn(crm1, eh));
         x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
@@ -356,9 +363,31 @@ __global__ __launch_bounds__(1024) void vlb_terms_kernel(const float* __restrict
     acc = block_sum(acc, red);
     sq = block_sum(sq, red);
     if (threadIdx.x == 0) {
-        vlb[b] = (acc / (float)per) / 0.6931471805599453f;
-        if (sqerr) sqerr[b] = sq;
+        float* part = partials + ((long long)b * ns + sl) * 2;
+        __hip_atomic_store(part, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(part + 1, sq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned old = __hip_atomic_fetch_add(counters + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last = old == (unsigned)ns - 1u;
+        if (last) {
+            float a = 0.f, s2 = 0.f;
+            for (int k = 0; k < ns; ++k) {
+                a += __hip_atomic_load(partials + ((long long)b * ns + k) * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s2 += __hip_atomic_load(partials + ((long long)b * ns + k) * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            vlb[b] = (a / (float)per) / 0.6931471805599453f;
+            if (sqerr) sqerr[b] = s2;
+            __hip_atomic_store(counters + b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
+}
+
+static int vlb_slices(int B, long long per) {
+    int ns = (int)((256 + B - 1) / B);                    // fill the chip ...
+    const long long cap = (per + 4095) / 4096;            // ... but keep at least ~4 elements per thread and slice
+    if (ns > cap) ns = (int)cap;
+    if (ns > 64) ns = 64;
+    return ns < 1 ? 1 : ns;
 }
 
 int p_sample_update(float* x, const float* eps_hat, const float* noise, long long noise_step_stride, int t_first,
@@ -445,14 +474,25 @@ int ddk_fix_samples(const float* x_nchw, float* out_nhwc, int B, int C, int H, i
     return check_launch("fix_samples_kernel");
 }
 
+size_t ddk_vlb_terms_workspace_bytes(int B, long long per) {
+    if (B <= 0 || per <= 0) return 0;
+    return ((size_t)B + (size_t)B * vlb_slices(B, per) * 2) * sizeof(float);
+}
+
 int ddk_vlb_terms(const float* x, const float* x_t, const float* eps_hat, const float* eps, const int64_t* t, const float* c_recip,
                   const float* c_recipm1, const float* c1, const float* c2, const float* post_logvar, float* vlb, float* sqerr, int B,
-                  long long per, ddk_stream_t s) {
+                  long long per, void* workspace, size_t workspace_bytes, ddk_stream_t s) {
     DDK_REQUIRE(x && x_t && eps_hat && t && c_recip && c_recipm1 && c1 && c2 && post_logvar && vlb, "vlb_terms: null pointer");
     DDK_REQUIRE((eps == nullptr) == (sqerr == nullptr), "vlb_terms: eps and sqerr go together");
     DDK_REQUIRE(B > 0 && per > 0, "vlb_terms: B / per");
-    hipLaunchKernelGGL(vlb_terms_kernel, dim3(B), dim3(1024), 0, as_stream(s), x, x_t, eps_hat, eps, t, c_recip, c_recipm1, c1, c2,
-                       post_logvar, vlb, sqerr, per);
+    DDK_REQUIRE(workspace && workspace_bytes >= ddk_vlb_terms_workspace_bytes(B, per) && (reinterpret_cast<uintptr_t>(workspace) & 3u) == 0,
+                "vlb_terms: workspace (ddk_vlb_terms_workspace_bytes)");
+    const int ns = vlb_slices(B, per);
+    unsigned* counters = static_cast<unsigned*>(workspace);
+    float* partials = static_cast<float*>(workspace) + B;
+    DDK_HIP(hipMemsetAsync(counters, 0, (size_t)B * sizeof(unsigned), as_stream(s)));      // they re-arm themselves; a fresh workspace starts at 0
+    hipLaunchKernelGGL(vlb_terms_kernel, dim3(ns, B), dim3(1024), 0, as_stream(s), x, x_t, eps_hat, eps, t, c_recip, c_recipm1, c1, c2,
+                       post_logvar, vlb, sqerr, per, ns, counters, partials);
     return check_launch("vlb_terms_kernel");
 }
 

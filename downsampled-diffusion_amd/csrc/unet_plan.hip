@@ -79,6 +79,7 @@ struct SamplerGraph {
     hipGraphExec_t exec = nullptr;
     hipGraph_t graph_multi = nullptr;        // SAMPLER_MULTI consecutive steps in one graph (captured when a chain is long enough)
     hipGraphExec_t exec_multi = nullptr;
+    hipEvent_t done = nullptr;               // recorded behind the entry's latest launches: what an eviction has to wait for
     unsigned long long last_use = 0;
 };
 constexpr int SAMPLER_MULTI = 16;
@@ -293,6 +294,7 @@ static void drop_graphs(ddk_unet* u) {   // caller holds u->mu (or owns u exclus
         if (g.graph) (void)hipGraphDestroy(g.graph);
         if (g.exec_multi) (void)hipGraphExecDestroy(g.exec_multi);
         if (g.graph_multi) (void)hipGraphDestroy(g.graph_multi);
+        if (g.done) (void)hipEventDestroy(g.done);
     }
     u->graphs.clear();
     u->table.ws = nullptr;
@@ -1109,7 +1111,8 @@ extern "C" int ddk_sampler_run(const ddk_sampler_args* a, ddk_stream_t s) {
             size_t lru = 0;
             for (size_t i = 1; i < u.graphs.size(); ++i)
                 if (u.graphs[i].last_use < u.graphs[lru].last_use) lru = i;
-            DDK_HIP(hipDeviceSynchronize());
+            // wait for the evicted entry's own launches only (not the device: another stream may be mid-capture)
+            if (u.graphs[lru].done) { DDK_HIP(hipEventSynchronize(u.graphs[lru].done)); (void)hipEventDestroy(u.graphs[lru].done); }
             (void)hipGraphExecDestroy(u.graphs[lru].exec);
             (void)hipGraphDestroy(u.graphs[lru].graph);
             if (u.graphs[lru].exec_multi) (void)hipGraphExecDestroy(u.graphs[lru].exec_multi);
@@ -1131,7 +1134,9 @@ extern "C" int ddk_sampler_run(const ddk_sampler_args* a, ddk_stream_t s) {
     // long chains: SAMPLER_MULTI steps per graph launch (t and the Philox counter live in device memory, so a graph of any number
     // of steps continues the chain); the one-step graph finishes the remainder
     // (captured with the one-step graph, on the first call for a buffer set whose chain can be that long -- not in a later, timed call)
-    if (!hit->exec_multi && (first || n_steps - k >= 2 * SAMPLER_MULTI) && a->t_start + 1 >= 2 * SAMPLER_MULTI)
+    // (not for injected noise: a fresh noise tensor per call means a fresh cache entry per call -- parity tests -- and capturing
+    //  SAMPLER_MULTI x ~80 launches for a chain that is never replayed is pure overhead)
+    if (!hit->exec_multi && !a->noise && (first || n_steps - k >= 2 * SAMPLER_MULTI) && a->t_start + 1 >= 2 * SAMPLER_MULTI)
         DDK_TRY(capture(SAMPLER_MULTI, hit->graph_multi, hit->exec_multi));
     if (hit->exec_multi)
         for (; k + SAMPLER_MULTI <= n_steps; k += SAMPLER_MULTI) {
@@ -1142,5 +1147,7 @@ extern "C" int ddk_sampler_run(const ddk_sampler_args* a, ddk_stream_t s) {
         const hipError_t e = hipGraphLaunch(hit->exec, st);
         if (e != hipSuccess) { set_error("sampler: hipGraphLaunch: %s", hipGetErrorString(e)); return DDK_ERR_HIP; }
     }
+    if (!hit->done) DDK_HIP(hipEventCreateWithFlags(&hit->done, hipEventDisableTiming));
+    DDK_HIP(hipEventRecord(hit->done, st));
     return DDK_OK;
 }

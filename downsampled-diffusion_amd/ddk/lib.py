@@ -55,6 +55,7 @@ SIGNATURES = {
     "ddk_pack_convT_weight": (_I, [_P, _P, _I, _I, _P]),
     "ddk_pack_linear_T": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "ddk_pack_conv_weight_wino": (_I, [_P, _P, _I, _I, _I, _P]),
+    "ddk_pack_conv_weight_wino_dgrad": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "ddk_conv_wino_splits": (_I, [_I, _I, _I, _I, _I]),
     "ddk_conv_gn_partials": (_I, [_I, _I, _I, _I, _I, _I]),
     "ddk_groupnorm_mish_partials": (_I, [_P, _P, _I, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _F, _P]),
@@ -96,7 +97,8 @@ SIGNATURES = {
     "ddk_randn": (_I, [_P, _LL, C.c_uint64, C.c_uint32, C.c_uint32, _P]),
     "ddk_fix_samples": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "ddk_sq_err_sum": (_I, [_P, _P, _P, _I, _LL, _P]),
-    "ddk_vlb_terms": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _LL, _P]),
+    "ddk_vlb_terms_workspace_bytes": (_SZ, [_I, _LL]),
+    "ddk_vlb_terms": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _LL, _P, _SZ, _P]),
     "ddk_unet_create": (_P, [C.POINTER(UnetConfig)]),
     "ddk_unet_destroy": (None, [_P]),
     "ddk_unet_num_slots": (_I, [_P]),

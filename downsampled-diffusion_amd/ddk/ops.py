@@ -139,8 +139,12 @@ def wino_weight(weight, x_shape, c_lo=None, c_hi=None, dgrad=False):
     if L.load().ddk_conv_wino_splits(b, h, w_, pad32(cin), n_out) <= 0:
         return None
     if dgrad:
-        return cached_pack(("wino_dgrad", lo, hi), weight,
-                           lambda t: pack_conv_weight_wino(t[:, lo:hi].flip(2, 3).transpose(0, 1).contiguous()))
+        def pack(t):       # flip + transpose + Winograd transform in ONE kernel (was three torch kernels + the pack)
+            out = torch.empty((pad32(o) // 32, 16, hi - lo, 32), device=t.device, dtype=torch.float32)
+            L.check(L.load().ddk_pack_conv_weight_wino_dgrad(L.ptr(_f32(t.contiguous())), L.ptr(out), o, i, lo, hi, pad32(o), L.stream()),
+                    "pack_conv_weight_wino_dgrad")
+            return out
+        return cached_pack(("wino_dgrad", lo, hi), weight, pack)
     return cached_pack("wino", weight, pack_conv_weight_wino)
 
 
@@ -489,9 +493,12 @@ def vlb_terms(x, x_t, eps_hat, t, c_recip, c_recipm1, c1, c2, post_logvar, eps=N
     b = x.shape[0]
     vlb = torch.empty((b,), device=x.device, dtype=torch.float32)
     sq = torch.empty((b,), device=x.device, dtype=torch.float32) if eps is not None else None
-    L.check(L.load().ddk_vlb_terms(L.ptr(_f32(x)), L.ptr(_f32(x_t)), L.ptr(_f32(eps_hat)), L.ptr(eps), L.ptr(t), L.ptr(c_recip),
-                                   L.ptr(c_recipm1), L.ptr(c1), L.ptr(c2), L.ptr(post_logvar), L.ptr(vlb), L.ptr(sq), b,
-                                   x.numel() // b, L.stream()), "vlb_terms")
+    lib = L.load()
+    nbytes = lib.ddk_vlb_terms_workspace_bytes(b, x.numel() // b)
+    ws = _ws(x.device, nbytes, "vlb")
+    L.check(lib.ddk_vlb_terms(L.ptr(_f32(x)), L.ptr(_f32(x_t)), L.ptr(_f32(eps_hat)), L.ptr(eps), L.ptr(t), L.ptr(c_recip),
+                              L.ptr(c_recipm1), L.ptr(c1), L.ptr(c2), L.ptr(post_logvar), L.ptr(vlb), L.ptr(sq), b,
+                              x.numel() // b, L.ptr(ws), nbytes, L.stream()), "vlb_terms")
     return vlb, sq
 
 

@@ -32,7 +32,7 @@ class UnetPlan:
         self.slot_names = [lib.ddk_unet_slot_name(self.handle, i).decode() for i in range(lib.ddk_unet_num_slots(self.handle))]
         self.slot_numel = [lib.ddk_unet_slot_numel(self.handle, i) for i in range(len(self.slot_names))]
         self.packed = None
-        self._ws = {}          # kind -> (key, tensor); the sampler workspace is its own buffer: cached graphs point into it
+        self._ws = {}          # (kind, nbytes, device) -> tensor; sampler workspaces are kept (LRU of 3): cached graphs point into them
         self._state = {}       # chain state x per (shape, device): a stable address for the captured sampler graph
 
     def __deepcopy__(self, memo):
@@ -71,15 +71,27 @@ class UnetPlan:
 
     # ---------------------------------------------------------------- forward
     def _workspace(self, kind, nbytes, device):
-        key = (nbytes, str(device))
-        hit = self._ws.get(kind)
-        if hit is None or hit[0] != key:
-            if kind == "smp" and hit is not None:
-                # the cached sampler graphs and the time-shift table live in / point into the old buffer
+        """Scratch per (kind, size, device).  The sampler keeps up to 3 workspaces (LRU): the captured step graphs and the
+        time-shift table live in / point into their workspace, so a trainer that alternates sample() (t_start = T-1) and
+        reconstruct() (t_start = t_rec_max) at every logging event keeps both sets of graphs instead of re-capturing twice per event.
+        Only an eviction drops the plan's cached graphs (ddk_sampler_invalidate waits for the device)."""
+        key = (kind, nbytes, str(device))
+        hit = self._ws.get(key)
+        if hit is not None:
+            self._ws[key] = self._ws.pop(key)          # most recently used last
+            return hit
+        if kind == "smp":
+            mine = [k for k in self._ws if k[0] == "smp"]
+            if len(mine) >= 3:
                 L.check(self._lib.ddk_sampler_invalidate(self.handle), "sampler_invalidate")
-            hit = (key, torch.empty(max(nbytes, 16) // 4 + 4, device=device, dtype=torch.float32))
-            self._ws[kind] = hit
-        return hit[1]
+                for k in mine:
+                    del self._ws[k]
+        else:
+            for k in [k for k in self._ws if k[0] == kind]:
+                del self._ws[k]
+        buf = torch.empty(max(nbytes, 16) // 4 + 4, device=device, dtype=torch.float32)
+        self._ws[key] = buf
+        return buf
 
     OPT_CLUSTER_GROUPNORM = 1
 

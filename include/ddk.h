@@ -237,10 +237,14 @@ int ddk_fix_samples(const float* x_nchw, float* out_nhwc, int B, int C, int H, i
  * utils/utils.py:43-48 flat_bits): vlb[b] = mean over the sample of { t_b > 0: KL(q(x_{t-1}|x_t,x) || p(x_{t-1}|x_t));
  * t_b == 0: discretised-Gaussian NLL of x } / ln 2, with p's mean from eps_hat (x0 clamped to [-1,1]) and both
  * variances = exp(post_logvar[t_b]).  eps / sqerr optional (both or neither): sqerr[b] = sum (eps - eps_hat)^2, the
- * L_simple term of test_losses_ (ddpm.py:424-426).  Any layout, as long as the five tensors agree. */
+ * L_simple term of test_losses_ (ddpm.py:424-426).  Any layout, as long as the five tensors agree.
+ * Every sample is split over several workgroups (ddk_vlb_terms_workspace_bytes of scratch); the partial sums are added in slice
+ * order by whichever workgroup finishes last, so the result does not depend on the arrival order. */
+size_t ddk_vlb_terms_workspace_bytes(int B, long long per);
 int ddk_vlb_terms(const float* x, const float* x_t, const float* eps_hat, const float* eps, const int64_t* t,
                   const float* c_recip, const float* c_recipm1, const float* c1, const float* c2,
-                  const float* post_logvar, float* vlb, float* sqerr, int B, long long per, ddk_stream_t s);
+                  const float* post_logvar, float* vlb, float* sqerr, int B, long long per, void* workspace,
+                  size_t workspace_bytes, ddk_stream_t s);
 /* per_sample[b] = sum_i (a - b)^2 over the sample's `per` elements (ddpm.py:279, utils/utils.py:34-40). */
 int ddk_sq_err_sum(const float* a, const float* b, float* per_sample, int B, long long per, ddk_stream_t s);
 
@@ -327,6 +331,10 @@ int ddk_sampler_invalidate(ddk_unet* u);
  * Autograd counterparts of the ops above, driven by objective.backward() in trainers/trainer_ddpm.py:124-128.
  * Parameter gradients ACCUMULATE into the caller's (canonical-layout) gradient tensors. */
 
+/* Winograd-domain filter of the INPUT-gradient conv of a 3x3 stride-1 conv, for its input channels [c_lo, c_hi): the 3x3 conv of
+ * dY with g'[n][c][a][b] = w[c][c_lo + n][2-a][2-b] -> [o_pad/32][16][c_hi - c_lo][32] (o_pad = O rounded up to 32), the layout
+ * ddk_conv_args.weight_wino takes; w is the forward OIHW tensor (O, I, 3, 3).  Flip, transpose and pack in one kernel. */
+int ddk_pack_conv_weight_wino_dgrad(const float* w_oihw, float* dst, int O, int I, int c_lo, int c_hi, int o_pad, ddk_stream_t s);
 /* input gradient of conv3x3 s1 / 1x1: run ddk_conv_forward on dY with this operand; [I_pad][taps][O_pad], taps flipped */
 int ddk_pack_conv_weight_dgrad(const float* w_oihw, float* dst, int O, int I, int KH, int KW, int i_pad, int o_pad,
                                ddk_stream_t s);

@@ -393,6 +393,26 @@ def test_linattn_small_maps_projection_inside(ops, B, H, W, C):
     assert rel_err(out.cpu(), two.cpu()) < 2e-5
 
 
+def test_linattn_small_maps_offset_input(ops):
+    """|mean| >> std per pixel (x + 50): the in-kernel LayerNorm variance is two-pass like torch.var, not E[x^2] - mean^2"""
+    B, H, W, C = 4, 4, 4, 256
+    x = rnd(B, C, H, W, seed=66, scale=0.5) + 50.0
+    g, b = 1 + rnd(C, seed=67, scale=0.2), rnd(C, seed=68, scale=0.2)
+    wq = rnd(384, C, seed=69, scale=C ** -0.5)
+    xd = x.double()
+    mean = xd.mean(dim=1, keepdim=True)
+    std = xd.var(dim=1, unbiased=False, keepdim=True).sqrt()
+    xn = ((xd - mean) / (std + 1e-5) * g.double()[None, :, None, None] + b.double()[None, :, None, None])
+    qkv = F.conv2d(xn, wq.double()[:, :, None, None])
+    q, k, v = qkv.reshape(B, 3, 4, 32, H * W).unbind(1)
+    ctx_ref = torch.einsum("bhdn,bhen->bhde", k.softmax(dim=-1), v)
+    out_ref = torch.einsum("bhde,bhdn->bhen", ctx_ref, q).reshape(B, 128, H, W)
+    out, ctx = ops.linattn_small_from_x(to_nhwc(x).to(DEV), wq.to(DEV), g.to(DEV), b.to(DEV))
+    # the folded form r (W o g) x - r mean (W g) still subtracts two numbers ~ |mean| / std apart: ~1e-7 * 100 of relative noise
+    assert rel_err(to_nchw(out.cpu()), out_ref.float()) < 3e-4
+    assert rel_err(ctx.cpu(), ctx_ref.float()) < 3e-4
+
+
 def test_linattn_softmax_extremes(ops):
     """a dominant key (softmax ~ one-hot) and large negative logits must not overflow / lose the max"""
     B, H, W = 1, 8, 8
