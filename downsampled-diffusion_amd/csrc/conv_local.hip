@@ -284,9 +284,12 @@ __global__ __launch_bounds__(768) void conv3x3_gn_wlocal_kernel(const WLocalPara
     };
 
     // ---- weights of a matrix wave's two positions, one chunk ahead (two register sets, one per chunk parity).  Measured at
-    //      batch 32: 1.85 us per chunk where the MFMAs need 0.95 -- the 32 workgroups of an XCD stream the same 524 KB of U
-    //      through that XCD's L2 at the same time (16.8 MB per launch and XCD, ~1.1 TB/s); prefetching two chunks ahead changes
-    //      nothing, two images per workgroup halve the traffic and double the MFMA time per workgroup: same 21 us either way.
+    //      batch 32: 1.85 us per chunk where the MFMAs need 0.95.  Round 3 (tools/share_rate.hip, profiles/r03_share_rate.txt,
+    //      r03_wlocal8_pmc.json): the stream itself is NOT the limit -- 256 workgroups pulling 512 KB each, 32 per XCD on the same
+    //      bytes, finish in 5.3-6.3 us from registers or LDS-DMA alike (90-98 GB/s per CU); with the weight loads ablated the kernel
+    //      still takes 19.7 of 20.8 us, with the transform ablated 18.7.  What is left is the per-chunk barrier with two matrix waves
+    //      per SIMD parked at it together, and ~8 us of launch + image staging + output transform + GroupNorm tail around the loop.
+    //      (Rotating the n tiles over the XCDs so that an XCD's workgroups stream different bytes is slower: 23.1 us.)
     const float* wl = p.w + ((size_t)nt * nch * 16 + 2 * (wave & 7)) * 1024 + lane * 4;
     float4 bA[2][2][2], bB[2][2][2];            // [position of the pair][n block][k half]
     auto load_b = [&](int chunk, float4 (&bq)[2][2][2]) {

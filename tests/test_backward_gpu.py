@@ -1,5 +1,7 @@
 """Backward-kernel parity on the GPU: every HIP backward op (through ddk.autograd) against torch-CPU autograd of the
 oracle's functional ops on the same inputs, then a whole training objective against the reference goldens (G6)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -311,3 +313,40 @@ def test_unet_grads_large_resolution_vs_oracle():
     assert rel_err(xd.grad.cpu(), xr.grad) < 2e-4
     for k in probe:
         assert rel_err(params[k].grad.cpu(), ref_sd[k].grad) < 2e-4, k
+
+
+def test_unet_grads_cfg5_full_resolution_vs_oracle():
+    """cfg5 itself (CelebA-HQ 256x256 DDPM, unet_chan 128, dims (1,2,2,2), C_in 3): ONE micro-batch of B = 1 at the full
+    256 x 256 resolution -- 65 536-pixel linear attention backward, streamed GroupNorm over 1 M-element groups, the Winograd
+    forward / input-gradient convs and the weight-gradient GEMMs at their real sizes.  Output and gradients of the input and of six
+    probe tensors against torch-CPU autograd through the oracle's functional UNet (reference: trainers/trainer_ddpm.py:118-144,
+    models/unet/unet.py:74-104).  Tens of seconds of oracle time on the GPU box's host cores."""
+    from models import Unet
+    cfg = dict(unet_chan=128, unet_in=3, unet_dims=(1, 2, 2, 2), unet_dropout=0.0)
+    model = Unet(cfg)
+    sd = syn.fill_state_dict(model.state_dict(), 55)
+    model.load_state_dict(sd)
+    model = model.to(DEV).train()
+    x = syn.synthetic_input((1, 3, 256, 256), "cfg5.train.x")
+    t = torch.tensor([437])
+    wgt = syn.synthetic_normal((1, 3, 256, 256), "cfg5.train.w")
+
+    probe = ["downs.0.0.block1.block.0.weight", "downs.0.2.fn.fn.to_qkv.weight", "downs.1.0.res_conv.weight",
+             "mid_block1.block2.block.1.weight", "ups.2.0.block1.block.0.weight", "final_conv.1.weight"]
+    ref_sd = {k: v.clone() for k, v in sd.items()}
+    for k in probe:
+        ref_sd[k].requires_grad_(True)
+    xr = x.clone().requires_grad_(True)
+    torch.set_num_threads(max(1, min(32, len(os.sched_getaffinity(0)))))
+    out_ref = U.unet_forward(ref_sd, cfg, xr, t)
+    (out_ref * wgt).sum().backward()
+
+    xd = x.to(DEV).requires_grad_(True)
+    out = model(xd, t.to(DEV))
+    assert rel_err(out.detach().cpu(), out_ref.detach()) < 5e-5
+    (out * wgt.to(DEV)).sum().backward()
+    params = dict(model.named_parameters())
+    assert rel_err(xd.grad.cpu(), xr.grad) < 3e-4
+    for k in probe:
+        assert rel_err(params[k].grad.cpu(), ref_sd[k].grad) < 3e-4, k
+

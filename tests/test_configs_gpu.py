@@ -177,3 +177,30 @@ def test_sampler_graph_cache_reuse_and_reseed():
     m.use_graph = False
     assert torch.equal(d, m.p_sample_loop(shape, early_stop=990, x_T=x_T, seed=11).cpu())
     assert not torch.equal(a, d)
+
+
+def test_cfg2_cifar_batch64_cin3_properties():
+    """cfg2 at its full batch (CIFAR-10 32x32 DDPM, bs 64, C_in 3): size-independent properties of the forward -- every sample's
+    output equals that sample run in a batch of 2 (no cross-sample coupling; the B = 2 slice is pinned by g3.full_c3), the run is
+    bit-stable, and a 10-step chain from the same x_T / noise is bit-identical for the samples two different batch compositions
+    share (reference: models/unet/unet.py:74-104, models/diffusion/ddpm.py:229-249)."""
+    from models import DDPM, Unet
+    cfg = ddpm_cfg(128, 3, 32)
+    m = det_load(DDPM(cfg, Unet(cfg), DEV, 3)).to(DEV).eval()
+    u = m.latent_model
+    x = syn.synthetic_normal((64, 3, 32, 32), "cfg2.prop.x").to(DEV)
+    t = (torch.arange(64, device=DEV) * 15) % 1000
+    with torch.no_grad():
+        y = u(x, t)
+        assert torch.equal(y, u(x, t))
+        for lo in (0, 31, 62):
+            y2 = u(x[lo:lo + 2].contiguous(), t[lo:lo + 2].contiguous())
+            assert rel_err(y[lo:lo + 2].cpu(), y2.cpu()) < 2e-5
+        assert torch.isfinite(y).all()
+        noise = torch.stack([syn.synthetic_normal((64, 3, 32, 32), f"cfg2.prop.n{k}") for k in range(10)]).to(DEV)
+        full = m.p_sample_loop((64, 3, 32, 32), early_stop=990, x_T=x, noise=noise)
+        again = m.p_sample_loop((64, 3, 32, 32), early_stop=990, x_T=x, noise=noise)
+        assert torch.equal(full, again)
+        part = m.p_sample_loop((8, 3, 32, 32), early_stop=990, x_T=x[40:48].contiguous(), noise=noise[:, 40:48].contiguous())
+        assert (full[40:48] - part).abs().max() < 1e-4
+

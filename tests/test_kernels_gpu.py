@@ -93,6 +93,7 @@ WINO_CASES = [  # B, H, W, c0, c1, N  (Winograd F(2x2,3x3): even H, W; cin % 32 
     (32, 4, 4, 256, 0, 256),       # cfg4 4x4 level: splits > 1
     (32, 4, 4, 256, 256, 256),     # cfg4 ups.0.0 conv1
     (4, 32, 32, 128, 0, 128),      # cfg4 32x32 level
+    (32, 32, 32, 128, 0, 128),     # ... at the full batch: the headline shape of bench.py's roofline (512 workgroups, two rounds)
     (4, 16, 16, 256, 0, 256),
     (2, 2, 2, 32, 0, 64),          # a single tile per image
 ]

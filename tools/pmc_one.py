@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""Launch ONE kernel of the reverse step, at its cfg4 shape, 20 times -- the program rocprofv3 counter passes run
+(`rocprofv3 --kernel-trace --pmc ... -- python3 tools/pmc_one.py <case>`; counters and --stats in separate passes).
+cases: wino (conv3x3 128->128 @32x32 B=32, Winograd), gn (GroupNorm-apply from partials, 32x32x32x128), local4 (conv+GroupNorm+Mish
+one launch, 256->256 @4x4), wlocal8 (the same @8x8, Winograd form), first (conv_first 8->128 @32x32), tail (final_tail_kernel),
+cluster16 (conv3x3 256->256 @16x16 with GroupNorm finished in the launch)."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(ROOT, "downsampled-diffusion_amd"), ROOT]
+import torch  # noqa: E402
+from ddk import ops  # noqa: E402
+
+case = sys.argv[1] if len(sys.argv) > 1 else "wino"
+dev, B = "cuda", 32
+
+
+def rw(n, c, k=3):
+    return torch.randn(n, c, k, k, device=dev) * (c * k * k) ** -0.5
+
+
+if case == "wino":
+    x, w = torch.randn(B, 32, 32, 128, device=dev), rw(128, 128)
+    wp, wu, b = ops.pack_conv_weight(w), ops.pack_conv_weight_wino(w), torch.zeros(128, device=dev)
+    fn = lambda: ops.conv(ops.CONV3X3_S1, x, wp, b, w_wino=wu)
+elif case == "gn":
+    x, w = torch.randn(B, 32, 32, 128, device=dev), rw(128, 128)
+    raw, part, tiles = ops.conv_with_gn_partials(x, ops.pack_conv_weight(w), torch.zeros(128, device=dev), ops.pack_conv_weight_wino(w))
+    gam, bet, temb = torch.ones(128, device=dev), torch.zeros(128, device=dev), torch.randn(B, 128, device=dev)
+    fn = lambda: ops.groupnorm_mish_from_partials(raw, part, tiles, gam, bet, temb=temb)
+elif case in ("local4", "wlocal8"):
+    H = 4 if case == "local4" else 8
+    x, w = torch.randn(B, H, H, 256, device=dev), rw(256, 256)
+    gam, bet, b = torch.ones(256, device=dev), torch.zeros(256, device=dev), torch.zeros(256, device=dev)
+    temb = torch.randn(B, 256, device=dev)
+    if case == "local4":
+        wl = ops.pack_conv_weight_local(w)
+        fn = lambda: ops.conv3x3_gn_mish(x, wl, b, gam, bet, temb=temb)
+    else:
+        wl = ops.pack_conv_weight_wino_local(w)
+        fn = lambda: ops.conv3x3_gn_mish_wino(x, wl, b, gam, bet, temb=temb)
+elif case == "first":
+    x, w = torch.randn(B, 32, 32, 8, device=dev), rw(128, 8)
+    wf, b = ops.pack_conv_weight_first(w), torch.zeros(128, device=dev)
+    fn = lambda: ops.conv_first(x, wf, b, 128)
+elif case == "tail":
+    x, w = torch.randn(B, 32, 32, 8, device=dev), rw(128, 8)
+    raw, part, tiles = ops.conv_first(x, ops.pack_conv_weight_first(w), torch.zeros(128, device=dev), 128)
+    gam, bet = torch.ones(128, device=dev), torch.zeros(128, device=dev)
+    wo, bo = torch.randn(8, 128, device=dev) * 128 ** -0.5, torch.zeros(8, device=dev)
+    xs = torch.randn(B, 32, 32, 8, device=dev)
+    t = torch.full((B,), 500, device=dev, dtype=torch.long)
+    tab = {k: torch.rand(1000, device=dev) for k in ("c_recip", "c_recipm1", "c1", "c2", "sigma")}
+    fn = lambda: ops.final_tail(raw, part, tiles, gam, bet, wo, bo, x=xs, t=t, tables=tab, seed=3, want_eps=False)
+elif case == "cluster16":
+    x, w = torch.randn(B, 16, 16, 256, device=dev), rw(256, 256)
+    wu, b = ops.pack_conv_weight_wino(w), torch.zeros(256, device=dev)
+    gam, bet, temb = torch.ones(256, device=dev), torch.zeros(256, device=dev), torch.randn(B, 256, device=dev)
+    fn = lambda: ops.conv3x3_gn_mish_cluster(x, wu, b, gam, bet, temb=temb)
+else:
+    raise SystemExit(f"unknown case {case}")
+for _ in range(20):
+    y = fn()
+torch.cuda.synchronize()
+print("ok", case)
