@@ -57,9 +57,40 @@ __host__ __device__ static inline size_t local_lds_bytes(int MT, int cin) {
 // of image b; lane = (other index bit) * 32 + col.  GroupNorm statistics of (image, group of col): two passes over the
 // registers, like torch's native_group_norm.  Wave level: lanes that share the group (xor masks below cpg, and 32); workgroup
 // level: the 8 waves' sums in fixed order.  Then affine, Mish, time shift, residual, store.
+// What the tail needs from global memory besides the conv result -- affine, time shift, residual -- requested at the START of
+// the kernel (tail_prefetch), so that their latency (two dependent loads for the shift: temb_rows[b], then the row) hides behind
+// the k loop instead of standing at the very end of every launch.
+template <int NV>
+struct TailPre {
+    float ga, be, sh;
+    float add[NV];
+};
+template <int NV, typename P>
+__device__ __forceinline__ TailPre<NV> tail_prefetch(const long long (&o)[NV], int c, int b, const P& p) {
+    TailPre<NV> t;
+    t.ga = p.gamma[c];
+    t.be = p.beta[c];
+    t.sh = 0.f;
+    if (p.temb) {
+        const long long tr = p.temb_rows ? p.temb_rows[b] : b;
+        t.sh = p.temb[tr * p.temb_stride + c];
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        float r = 0.f;
+        if (p.addend) {
+            r = p.addend[o[i]];
+            for (int sl = 1; sl < p.addend_slabs; ++sl) r += p.addend[sl * p.addend_stride + o[i]];
+            if (p.addend_bias) r += p.addend_bias[c];
+        }
+        t.add[i] = r;
+    }
+    return t;
+}
+
 template <int NV, typename P>
 __device__ __forceinline__ void gn_mish_tail(const float (&v)[NV], const long long (&o)[NV], int col, int c, int b, int hw, int lane, int wave,
-                                             float* red, const P& p) {
+                                             float* red, const P& p, const TailPre<NV>& pre) {
     const int gl = col / p.cpg;                 // group within the tile: 0 .. 32/cpg - 1
     auto group_sum = [&](float s) {
         for (int x = 1; x < p.cpg; x <<= 1) s += __shfl_xor(s, x, 64);
@@ -82,21 +113,10 @@ __device__ __forceinline__ void gn_mish_tail(const float (&v)[NV], const long lo
     for (int i = 0; i < NV; ++i) q += (v[i] - mean) * (v[i] - mean);
     const float var = group_sum(q) * inv_n;
     const float rstd = 1.0f / sqrtf(var + p.eps);
-    const float ga = p.gamma[c], be = p.beta[c];
-    float sh = 0.f;
-    if (p.temb) {
-        const long long tr = p.temb_rows ? p.temb_rows[b] : b;
-        sh = p.temb[tr * p.temb_stride + c];
-    }
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-        float y = mish_f((v[i] - mean) * rstd * ga + be) + sh;
-        if (p.addend) {
-            float r = p.addend[o[i]];
-            for (int sl = 1; sl < p.addend_slabs; ++sl) r += p.addend[sl * p.addend_stride + o[i]];
-            if (p.addend_bias) r += p.addend_bias[c];
-            y += r;
-        }
+        float y = mish_f((v[i] - mean) * rstd * pre.ga + pre.be) + pre.sh;
+        if (p.addend) y += pre.add[i];
         p.out[o[i]] = y;
     }
 }
@@ -139,6 +159,13 @@ __global__ __launch_bounds__(512) void conv3x3_gn_local_kernel(const LocalParams
     load_b(bA);
     load_b(bB);
     load_b(bC);
+    // ... and so do the tail's operands (affine, time shift, residual) of this thread's outputs: (column tid % 32, rows tid / 32 + 16 i)
+    const int col = tid & 31, row = tid >> 5;
+    const int c = n0 + col;
+    long long o_t[MB];
+#pragma unroll
+    for (int i = 0; i < MB; ++i) o_t[i] = ((long long)b * MT + row + 16 * i) * p.N + c;
+    const TailPre<MB> pre = tail_prefetch<MB>(o_t, c, b, p);
 
     // ---- the image: [MT rows][cin] into LDS, row MT = zeros
     {
@@ -215,8 +242,6 @@ __global__ __launch_bounds__(512) void conv3x3_gn_local_kernel(const LocalParams
     __syncthreads();
 
     // ---- thread = (column tid % 32, rows tid / 32 + 16 i): fixed-order sum of the partials + bias
-    const int col = tid & 31, row = tid >> 5;
-    const int c = n0 + col;
     float v[MB];
     const float cb = p.bias ? p.bias[c] : 0.f;
 #pragma unroll
@@ -227,10 +252,7 @@ __global__ __launch_bounds__(512) void conv3x3_gn_local_kernel(const LocalParams
         v[i] = s + cb;
     }
 
-    long long o[MB];
-#pragma unroll
-    for (int i = 0; i < MB; ++i) o[i] = ((long long)b * MT + row + 16 * i) * p.N + c;
-    gn_mish_tail<MB>(v, o, col, c, b, MT, lane, wave, red, p);
+    gn_mish_tail<MB>(v, o_t, col, c, b, MT, lane, wave, red, p, pre);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -373,6 +395,14 @@ __global__ __launch_bounds__(768) void conv3x3_gn_wlocal_kernel(const WLocalPara
     }
 
     // ==================================================================== matrix waves (512 threads)
+    // the tail's operands of this thread's four outputs (tile tid / 32, channel tid % 32) are requested now: their latency hides
+    // behind the k loop
+    const int tt = tid >> 5, col = tid & 31, c = n0 + col;
+    const int tty = tt / TW, ttx = tt - tty * TW;
+    long long o_t[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o_t[k] = ((long long)b * 64 + (2 * tty + (k >> 1)) * p.W + 2 * ttx + (k & 1)) * p.N + c;
+    const TailPre<4> pre = tail_prefetch<4>(o_t, c, b, p);
     f32x4 acc[2][2];
     acc[0][0] = acc[0][1] = acc[1][0] = acc[1][1] = f32x4{0.f, 0.f, 0.f, 0.f};
     auto chunk_step = [&](int chunk, const float4 (&bq)[2][2][2]) {
@@ -409,8 +439,6 @@ __global__ __launch_bounds__(768) void conv3x3_gn_wlocal_kernel(const WLocalPara
     __syncthreads();
 
     // ---- output transform: thread = (tile tid / 32, channel tid % 32), Y = A^T M A, A^T = [[1,1,1,0],[0,1,-1,-1]]
-    const int tt = tid >> 5, col = tid & 31, c = n0 + col;
-    const int tty = tt / TW, ttx = tt - tty * TW;
     float mm[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) mm[k] = V[(k * 16 + tt) * WL_VP + col];
@@ -426,10 +454,7 @@ __global__ __launch_bounds__(768) void conv3x3_gn_wlocal_kernel(const WLocalPara
     v[1] = ((t0[1] - t0[2]) - t0[3]) + cb;
     v[2] = ((t1[0] + t1[1]) + t1[2]) + cb;
     v[3] = ((t1[1] - t1[2]) - t1[3]) + cb;
-    long long o[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) o[k] = ((long long)b * 64 + (2 * tty + (k >> 1)) * p.W + 2 * ttx + (k & 1)) * p.N + c;
-    gn_mish_tail<4>(v, o, col, c, b, 64, lane, wave, red, p);
+    gn_mish_tail<4>(v, o_t, col, c, b, 64, lane, wave, red, p, pre);
 }
 
 // dst[n tile][tap][chunk][n block][k half][lane = kq * 16 + n][j] = w[o = 32 nt + 16 nb + n][i = 32 chunk + 8 kq + 4 half + j][tap]

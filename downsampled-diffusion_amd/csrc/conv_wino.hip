@@ -507,10 +507,50 @@ __global__ __launch_bounds__(512) void conv3x3_wino_kernel(const WinoParams p) {
                 const unsigned long long bits = (unsigned long long)__float_as_uint(mean) | ((unsigned long long)__float_as_uint(m2) << 32);
                 __hip_atomic_store(rec + gl, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
+            // what the finish needs from memory besides the records is requested BEFORE the wait (waves 1..7; wave 0 right behind
+            // its counter add): affine and time shift of this thread's channel quad
+            const int gn = n0 + (tid & 15) * 4;
+            float4 ga, be, ts = make_float4(0.f, 0.f, 0.f, 0.f);
+            auto load_affine = [&] {
+                ga = *reinterpret_cast<const float4*>(p.gn_gamma + gn);
+                be = *reinterpret_cast<const float4*>(p.gn_beta + gn);
+                if (p.gn_temb) {
+                    const int b_img = (int)((long long)t0 / ((long long)p.TH * p.TW));
+                    const long long tr = p.gn_temb_rows ? p.gn_temb_rows[b_img] : b_img;
+                    ts = *reinterpret_cast<const float4*>(p.gn_temb + tr * p.gn_temb_stride + gn);
+                }
+            };
+            // ... and the residual of this thread's four output pixels
+            long long oo[2];
+            float4 rs[2][2];
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int item = tid + it * 512;
+                const int t = item >> 5, a = (item >> 4) & 1;
+                const int g = t0 + t;
+                const unsigned tmp = fdiv_u((unsigned)g, p.dTW);
+                const int tx = g - (int)tmp * p.TW;
+                const unsigned bq = fdiv_u(tmp, p.dTH);
+                const int ty = (int)tmp - (int)bq * p.TH;
+                oo[it] = ((((long long)bq * p.H + 2 * ty + a) * p.W) + 2 * tx) * p.N + gn;
+            }
+            auto load_resid = [&] {
+#pragma unroll
+                for (int it = 0; it < 2; ++it) {
+                    rs[it][0] = rs[it][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (p.resid) {
+                        rs[it][0] = *reinterpret_cast<const float4*>(p.resid + oo[it]);
+                        rs[it][1] = *reinterpret_cast<const float4*>(p.resid + oo[it] + p.N);
+                    }
+                }
+            };
+            if (wid != 0) { load_affine(); load_resid(); }
             if (wid == 0) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                load_affine();
+                load_resid();
                 if (lane == 0) {
-                    __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     unsigned spins = 0;
                     while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)p.cl_np) {
                         __builtin_amdgcn_s_sleep(4);
@@ -549,36 +589,14 @@ __global__ __launch_bounds__(512) void conv3x3_wino_kernel(const WinoParams p) {
             for (int i = 0; i < 8; ++i) if (i < p.cl_np) { gm2 += rq[i]; gd2 += (rm[i] - gmean) * (rm[i] - gmean); }
             const float n_i = 128.0f * (float)p.cpg;
             const float rstd = 1.0f / sqrtf((gm2 + n_i * gd2) / ((float)p.cl_np * n_i) + p.gn_eps);
-            const int gn = n0 + (tid & 15) * 4;
-            const float4 ga = *reinterpret_cast<const float4*>(p.gn_gamma + gn), be = *reinterpret_cast<const float4*>(p.gn_beta + gn);
-            float4 ts = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (p.gn_temb) {
-                const int b_img = (int)((long long)t0 / ((long long)p.TH * p.TW));
-                const long long tr = p.gn_temb_rows ? p.gn_temb_rows[b_img] : b_img;
-                ts = *reinterpret_cast<const float4*>(p.gn_temb + tr * p.gn_temb_stride + gn);
-            }
             auto fin = [&](float4 v) {
                 return make_float4(mish_f((v.x - gmean) * rstd * ga.x + be.x) + ts.x, mish_f((v.y - gmean) * rstd * ga.y + be.y) + ts.y,
                                    mish_f((v.z - gmean) * rstd * ga.z + be.z) + ts.z, mish_f((v.w - gmean) * rstd * ga.w + be.w) + ts.w);
             };
 #pragma unroll
             for (int it = 0; it < 2; ++it) {
-                const int item = tid + it * 512;
-                const int t = item >> 5, a = (item >> 4) & 1;
-                const int g = t0 + t;
-                const unsigned tmp = fdiv_u((unsigned)g, p.dTW);
-                const int tx = g - (int)tmp * p.TW;
-                const unsigned bq = fdiv_u(tmp, p.dTH);
-                const int ty = (int)tmp - (int)bq * p.TH;
-                const long long o0 = ((((long long)bq * p.H + 2 * ty + a) * p.W) + 2 * tx) * p.N + gn;
-                const long long o1 = o0 + p.N;
-                float4 y0 = fin(keep[it][0]), y1 = fin(keep[it][1]);
-                if (p.resid) {
-                    y0 = f4add(y0, *reinterpret_cast<const float4*>(p.resid + o0));
-                    y1 = f4add(y1, *reinterpret_cast<const float4*>(p.resid + o1));
-                }
-                *reinterpret_cast<float4*>(p.out + o0) = y0;
-                *reinterpret_cast<float4*>(p.out + o1) = y1;
+                *reinterpret_cast<float4*>(p.out + oo[it]) = f4add(fin(keep[it][0]), rs[it][0]);
+                *reinterpret_cast<float4*>(p.out + oo[it] + p.N) = f4add(fin(keep[it][1]), rs[it][1]);
             }
         }
     }
