@@ -283,15 +283,25 @@ struct WLocalParams {
     const float* addend_bias;
 };
 
+#ifdef DDK_TUNING
+// Diagnostic stamps of conv3x3_gn_wlocal_kernel (tuning build only): per workgroup, in shader cycles (s_memtime) --
+// [0] entry, [1] image staged, [2] k loop done, [3] end of kernel, [4] cycles matrix wave 0 spent parked at the chunk barriers,
+// [5] cycles transform wave 8 spent transforming, [6] chunks, [7] valid.  Written to a buffer nothing else reads.
+__device__ unsigned long long g_wl_stamps[8 * 512];
+#define WL_STAMP(x) do { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(x) :: "memory"); } while (0)
+#else
+#define WL_STAMP(x) do { } while (0)
+#endif
+
 constexpr int WL_VP = 36;                       // V / M row pitch (floats): 16 rows cover the 64 banks once
 constexpr int WL_VBUF = 16 * 16 * WL_VP;        // one V buffer: [position][tile][36]
 
 __host__ __device__ static inline size_t wlocal_lds_bytes(int cin) { return ((size_t)65 * (cin + 4) + 2 * WL_VBUF) * 4 + 256; }
 
-__global__ __launch_bounds__(768) void conv3x3_gn_wlocal_kernel(const WLocalParams p) {
+__global__ __launch_bounds__(1024) void conv3x3_gn_wlocal_kernel(const WLocalParams p) {
     extern __shared__ __align__(16) float lds[];
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // 0..7 matrix waves, 8..11 transform waves
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // 0..7 matrix waves, 8..15 transform waves
     const int m = lane & 15, kq = lane >> 4;
     const int NT = p.N >> 5;
     const int nt = blockIdx.x % NT, b = blockIdx.x / NT;
@@ -304,6 +314,9 @@ __global__ __launch_bounds__(768) void conv3x3_gn_wlocal_kernel(const WLocalPara
     auto lds_barrier = [] {   // LDS traffic only: __syncthreads() would also wait (vmcnt) for the weight loads deliberately in flight
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     };
+    unsigned long long st_entry = 0, st_img = 0, st_loop = 0, st_a = 0, st_b = 0, st_wait = 0, st_tr = 0;
+    (void)st_entry; (void)st_img; (void)st_loop; (void)st_a; (void)st_b; (void)st_wait; (void)st_tr;
+    WL_STAMP(st_entry);
 
     // ---- weights of a matrix wave's two positions, one chunk ahead (two register sets, one per chunk parity).  Measured at
     //      batch 32: 1.85 us per chunk where the MFMAs need 0.95.  Round 3 (tools/share_rate.hip, profiles/r03_share_rate.txt,
@@ -330,67 +343,73 @@ __global__ __launch_bounds__(768) void conv3x3_gn_wlocal_kernel(const WLocalPara
         load_b(1, bB);
     }
 
-    // ---- the image: [64 rows][cin] into LDS, row 64 = zeros (all 12 waves)
+    // ---- the image: [64 rows][cin] into LDS, row 64 = zeros (all 16 waves)
     {
         const int q4 = cin >> 2;
         const long long row0 = (long long)b * 64;
-        for (int i = tid; i < 64 * q4; i += 768) {
+        for (int i = tid; i < 64 * q4; i += 1024) {
             const int row = i / q4, c = (i - row * q4) << 2;
             const float4 v = c < p.c0 ? *reinterpret_cast<const float4*>(p.src0 + (row0 + row) * p.c0 + c)
                                       : *reinterpret_cast<const float4*>(p.src1 + (row0 + row) * p.c1 + (c - p.c0));
             *reinterpret_cast<float4*>(lds + row * pitch + c) = v;
         }
-        for (int i = tid; i < q4; i += 768) *reinterpret_cast<float4*>(lds + 64 * pitch + (i << 2)) = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = tid; i < q4; i += 1024) *reinterpret_cast<float4*>(lds + 64 * pitch + (i << 2)) = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     __syncthreads();                            // image complete
+    WL_STAMP(st_img);
 
     const int TW = p.W >> 1;
     if (wave >= 8) {
         // ================================================================ transform waves: V = B^T d B, one chunk ahead of the
-        // matrix waves.  256 threads, two (tile, channel) items each: item = t2 + 256 k -> tile item / 32, channel item % 32
+        // matrix waves.  512 threads: thread = (tile t2 / 32, position row i = (t2 / 8) % 4, channel quad t2 % 8) -- row i of B^T d
+        // needs two patch rows only (0: d0 - d2, 1: d1 + d2, 2: d2 - d1, 3: d1 - d3): 8 ds_read_b128, 8 float4 operations and
+        // 4 ds_write_b128 per chunk and thread; the 8 lanes of a write group cover one tile's 128 contiguous bytes (no conflicts).
+        // History (tools/wl_clock.py): one channel per item on 4 waves (32 + 32 four-byte LDS operations per thread and chunk) kept the
+        // transform busy 2961 cycles per chunk where the MFMAs need 2048 -- it, not weight delivery, was this kernel's critical
+        // path; float4 items on 4 waves 2720; 8 waves: see profiles/r03_wl_clock.txt.
+        __builtin_amdgcn_s_setprio(3);          // a short burst the matrix waves wait for: it goes first on its SIMD
         const int t2 = tid - 512;
-        int poff[2][16];                        // LDS offsets of the 4x4 patches (the zero row where a patch leaves the image)
-        int voff[2];
+        const int tt = t2 >> 5, ri = (t2 >> 3) & 3, q4 = t2 & 7;
+        const int tty = tt / TW, ttx = tt - tty * TW;
+        const int row_a = ri == 0 ? 0 : ri == 2 ? 2 : 1, row_b = ri == 0 ? 2 : ri == 1 ? 2 : ri == 2 ? 1 : 3;
+        int poff[8];                            // LDS offsets of the two patch rows (the zero row where the patch leaves the image)
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int item = t2 + 256 * k;
-            const int tt = item >> 5, tch = item & 31;
-            const int tty = tt / TW, ttx = tt - tty * TW;
+        for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int y = 2 * tty - 1 + i, x = 2 * ttx - 1 + j;
-                    const bool ok = (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
-                    poff[k][i * 4 + j] = (ok ? y * p.W + x : 64) * pitch + tch;
-                }
-            voff[k] = tt * WL_VP + tch;
-        }
-        auto transform = [&](int chunk, int buf) {
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                float d[16];
-#pragma unroll
-                for (int e = 0; e < 16; ++e) d[e] = lds[poff[k][e] + (chunk << 5)];
-                float* vb = V + buf * WL_VBUF + voff[k];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    float r[4];
-#pragma unroll
-                    for (int x = 0; x < 4; ++x)
-                        r[x] = i == 0 ? d[0 + x] - d[8 + x] : i == 1 ? d[4 + x] + d[8 + x] : i == 2 ? d[8 + x] - d[4 + x] : d[4 + x] - d[12 + x];
-                    vb[(4 * i + 0) * (16 * WL_VP)] = r[0] - r[2];
-                    vb[(4 * i + 1) * (16 * WL_VP)] = r[1] + r[2];
-                    vb[(4 * i + 2) * (16 * WL_VP)] = r[2] - r[1];
-                    vb[(4 * i + 3) * (16 * WL_VP)] = r[1] - r[3];
-                }
+            for (int j = 0; j < 4; ++j) {
+                const int y = 2 * tty - 1 + (h == 0 ? row_a : row_b), x = 2 * ttx - 1 + j;
+                const bool ok = (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+                poff[h * 4 + j] = (ok ? y * p.W + x : 64) * pitch + q4 * 4;
             }
+        const int voff = (4 * ri * 16 + tt) * WL_VP + q4 * 4;
+        const float sgn = ri == 1 ? 1.0f : -1.0f;  // row = a + sgn * b: one exact FMA per float instead of add, subtract and select
+        auto f4 = [](const float* q) { return *reinterpret_cast<const float4*>(q); };
+        auto sub = [](float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); };
+        auto add = [](float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); };
+        auto transform = [&](int chunk, int buf) {
+            float4 r[4];
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                const float4 a = f4(lds + poff[x] + (chunk << 5)), b = f4(lds + poff[4 + x] + (chunk << 5));
+                r[x] = make_float4(fmaf(sgn, b.x, a.x), fmaf(sgn, b.y, a.y), fmaf(sgn, b.z, a.z), fmaf(sgn, b.w, a.w));
+            }
+            float* vb = V + buf * WL_VBUF + voff;
+            *reinterpret_cast<float4*>(vb + 0 * (16 * WL_VP)) = sub(r[0], r[2]);
+            *reinterpret_cast<float4*>(vb + 1 * (16 * WL_VP)) = add(r[1], r[2]);
+            *reinterpret_cast<float4*>(vb + 2 * (16 * WL_VP)) = sub(r[2], r[1]);
+            *reinterpret_cast<float4*>(vb + 3 * (16 * WL_VP)) = sub(r[1], r[3]);
         };
         transform(0, 0);
         for (int c = 0; c < nch; ++c) {
             lds_barrier();                      // V[c & 1] complete, V[(c + 1) & 1] consumed
+            WL_STAMP(st_a);
             if (c + 1 < nch) transform(c + 1, (c + 1) & 1);
+            WL_STAMP(st_b);
+            st_tr += st_b - st_a;
         }
+#ifdef DDK_TUNING
+        if (tid == 512) g_wl_stamps[(blockIdx.x & 511) * 8 + 5] = st_tr;
+#endif
         return;                                 // a finished wave no longer counts at the workgroup's barriers
     }
 
@@ -406,7 +425,10 @@ __global__ __launch_bounds__(768) void conv3x3_gn_wlocal_kernel(const WLocalPara
     f32x4 acc[2][2];
     acc[0][0] = acc[0][1] = acc[1][0] = acc[1][1] = f32x4{0.f, 0.f, 0.f, 0.f};
     auto chunk_step = [&](int chunk, const float4 (&bq)[2][2][2]) {
+        WL_STAMP(st_a);
         lds_barrier();
+        WL_STAMP(st_b);
+        st_wait += st_b - st_a;
         const float* vb = V + (chunk & 1) * WL_VBUF + ((2 * wave) * 16 + m) * WL_VP + kq * 8;
 #pragma unroll
         for (int pp = 0; pp < 2; ++pp) {
@@ -416,8 +438,13 @@ __global__ __launch_bounds__(768) void conv3x3_gn_wlocal_kernel(const WLocalPara
 #pragma unroll
             for (int kk = 0; kk < 8; ++kk) {
                 const float av = reinterpret_cast<const float*>(&a[0])[kk];
+#ifdef DDK_WL_NO_MFMA     /* ablation (wrong results): how long does the transform take when the matrix pipe is idle? */
+                acc[pp][0][0] += av * reinterpret_cast<const float*>(&bq[pp][0][0])[kk];
+                acc[pp][1][0] += av * reinterpret_cast<const float*>(&bq[pp][1][0])[kk];
+#else
                 acc[pp][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, reinterpret_cast<const float*>(&bq[pp][0][0])[kk], acc[pp][0], 0, 0, 0);
                 acc[pp][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, reinterpret_cast<const float*>(&bq[pp][1][0])[kk], acc[pp][1], 0, 0, 0);
+#endif
             }
         }
     };
@@ -429,6 +456,7 @@ __global__ __launch_bounds__(768) void conv3x3_gn_wlocal_kernel(const WLocalPara
     }
 
     // ---- M[position][tile][n] of the 8 waves into LDS (over the V buffers; the transform waves have finished)
+    WL_STAMP(st_loop);
     __syncthreads();
 #pragma unroll
     for (int pp = 0; pp < 2; ++pp)
@@ -455,6 +483,15 @@ __global__ __launch_bounds__(768) void conv3x3_gn_wlocal_kernel(const WLocalPara
     v[2] = ((t1[0] + t1[1]) + t1[2]) + cb;
     v[3] = ((t1[1] - t1[2]) - t1[3]) + cb;
     gn_mish_tail<4>(v, o_t, col, c, b, 64, lane, wave, red, p, pre);
+#ifdef DDK_TUNING
+    if (tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned long long st_end;
+        WL_STAMP(st_end);
+        unsigned long long* o = g_wl_stamps + (blockIdx.x & 511) * 8;
+        o[0] = st_entry; o[1] = st_img; o[2] = st_loop; o[3] = st_end; o[4] = st_wait; o[6] = (unsigned long long)nch; o[7] = 1;
+    }
+#endif
 }
 
 // dst[n tile][tap][chunk][n block][k half][lane = kq * 16 + n][j] = w[o = 32 nt + 16 nb + n][i = 32 chunk + 8 kq + 4 half + j][tap]
@@ -522,7 +559,7 @@ int conv_gn_wlocal(const float* src0, int c0, const float* src1, int c1, const f
     DDK_TRY(ensure_device_init());
     WLocalParams p{src0, src1, c0, c1, w, bias, gamma, beta, temb, temb_stride, temb_rows, addend, out, H, W, N, N / groups, eps,
                    as.n, as.stride, as.bias};
-    hipLaunchKernelGGL(conv3x3_gn_wlocal_kernel, dim3((unsigned)((long long)B * (N / 32))), dim3(768), wlocal_lds_bytes(c0 + c1), st, p);
+    hipLaunchKernelGGL(conv3x3_gn_wlocal_kernel, dim3((unsigned)((long long)B * (N / 32))), dim3(1024), wlocal_lds_bytes(c0 + c1), st, p);
     return check_launch("conv3x3_gn_wlocal_kernel");
 }
 
@@ -615,3 +652,12 @@ int ddk_conv3x3_gn_mish(const float* src0, int c0, const float* src1, int c1, co
 }
 
 }  // extern "C"
+
+#ifdef DDK_TUNING
+extern "C" int ddk_debug_read_wl_stamps(unsigned long long* host_out) {   // tuning build only (not in include/ddk.h)
+    if (hipDeviceSynchronize() != hipSuccess) return -2;
+    if (hipMemcpyFromSymbol(host_out, HIP_SYMBOL(ddk::g_wl_stamps), sizeof(unsigned long long) * 8 * 512) != hipSuccess) return -2;
+    static unsigned long long zeros[8 * 512];
+    return hipMemcpyToSymbol(HIP_SYMBOL(ddk::g_wl_stamps), zeros, sizeof(zeros)) == hipSuccess ? 0 : -2;
+}
+#endif

@@ -247,6 +247,8 @@ __global__ __launch_bounds__(512) void conv3x3_wino_kernel(const WinoParams p) {
                 r[x] = i == 0 ? d[0 * 4 + x] - d[2 * 4 + x] : i == 1 ? d[1 * 4 + x] + d[2 * 4 + x]
                      : i == 2 ? d[2 * 4 + x] - d[1 * 4 + x] : d[1 * 4 + x] - d[3 * 4 + x];
             float* base = smem + buf * W_STAGE + v_off;
+            // (plain adds on purpose: forcing v_pk_add_f32 -- half the instructions -- made the stage slower, 2699 vs 2654 cycles, the
+            //  loader parked the matrix waves 335 instead of 100 cycles: next to the fp32 MFMA a packed add costs more than two plain ones)
             *reinterpret_cast<f32x4*>(base + 0 * (WBT * 32)) = r[0] - r[2];
             *reinterpret_cast<f32x4*>(base + 1 * (WBT * 32)) = r[1] + r[2];
             *reinterpret_cast<f32x4*>(base + 2 * (WBT * 32)) = r[2] - r[1];
