@@ -19,6 +19,8 @@
 // pace: 35 GB/s per CU, 0.9 us per unit.)
 // grid = B * N/32 with the n tile fastest: workgroup ids that share an n tile's 295 KB of weights land on the same XCD
 // (ids round-robin over the 8 XCDs), so each L2 holds 1/8 of the filter.
+#include <type_traits>
+
 #include "ddk_internal.h"
 
 namespace ddk {
@@ -92,26 +94,36 @@ template <int NV, typename P>
 __device__ __forceinline__ void gn_mish_tail(const float (&v)[NV], const long long (&o)[NV], int col, int c, int b, int hw, int lane, int wave,
                                              float* red, const P& p, const TailPre<NV>& pre) {
     const int gl = col / p.cpg;                 // group within the tile: 0 .. 32/cpg - 1
-    auto group_sum = [&](float s) {
-        for (int x = 1; x < p.cpg; x <<= 1) s += __shfl_xor(s, x, 64);
+    // Sum over the lanes of the group (cpg consecutive columns, both 32-lane halves), then over the 8 waves through `rd` (two
+    // disjoint regions for the two passes, so one barrier per pass).  Inside a 16-lane row the tree runs on DPP (quad permutes,
+    // row_half_mirror, row_mirror: any pairing that crosses the halves adds the same numbers in every lane), only the steps
+    // across rows go through the LDS crossbar.
+    auto dpp_add = [](float v, auto ctrl) {
+        return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), decltype(ctrl)::value, 0xF, 0xF, true));
+    };
+    auto group_sum = [&](float s, float* rd) {
+        s = dpp_add(s, std::integral_constant<int, 0xB1>{});                          // lanes 1 apart
+        s = dpp_add(s, std::integral_constant<int, 0x4E>{});                          // 2 apart
+        if (p.cpg >= 8) s = dpp_add(s, std::integral_constant<int, 0x141>{});         // the other quad of the 8-lane group
+        if (p.cpg >= 16) s = dpp_add(s, std::integral_constant<int, 0x140>{});        // the other half of the 16-lane row
+        if (p.cpg >= 32) s += __shfl_xor(s, 16, 64);
         s += __shfl_xor(s, 32, 64);
-        __syncthreads();                        // red free again
-        if ((lane & 32) == 0 && (col & (p.cpg - 1)) == 0) red[wave * 4 + gl] = s;
+        if ((lane & 32) == 0 && (col & (p.cpg - 1)) == 0) rd[wave * 4 + gl] = s;
         __syncthreads();
-        float t = red[gl];
+        float t = rd[gl];
 #pragma unroll
-        for (int w = 1; w < 8; ++w) t += red[w * 4 + gl];
+        for (int w = 1; w < 8; ++w) t += rd[w * 4 + gl];
         return t;
     };
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) s += v[i];
     const float inv_n = 1.0f / (float)(hw * p.cpg);
-    const float mean = group_sum(s) * inv_n;
+    const float mean = group_sum(s, red) * inv_n;
     float q = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) q += (v[i] - mean) * (v[i] - mean);
-    const float var = group_sum(q) * inv_n;
+    const float var = group_sum(q, red + 32) * inv_n;
     const float rstd = 1.0f / sqrtf(var + p.eps);
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
