@@ -69,7 +69,7 @@ constexpr int W_STAGE = W_V + W_U, W_NS = 3;
 constexpr int W_LDS_FLOATS = W_NS * W_STAGE;             // 36864 floats = 144 KB
 constexpr int W_TP = WBN + 4;                            // epilogue staging pitch
 #ifndef DDK_WINO_LP
-#define DDK_WINO_LP 8
+#define DDK_WINO_LP 4
 #endif
 constexpr int W_LP = DDK_WINO_LP;                        // of a U image's 8 DMA pieces per stage, the loader wave issues W_LP, the matrix wave the rest
 static_assert(4 * 2 * WBT * W_TP <= W_LDS_FLOATS, "epilogue staging fits");

@@ -157,6 +157,12 @@ bool conv_first_ok(int cin, int N, int H, int W, int groups);
 int conv_first(const float* x, const float* wp, const float* bias, float* out, float* gn_partials, int B, int H, int W, int cin, int N,
                int groups, int64_t* counter, int64_t* t_cur, hipStream_t st);
 int conv_first_init_device();
+// conv1x1_ws.hip: 1x1 conv with 128 input channels on a large map as a weights-stationary, pixel-streaming GEMM
+// (w = the packed 1x1 weight [N][128]; ln as in conv_forward)
+bool conv1x1_ws_ok(long long M, int K, int N);
+int conv1x1_ws(const float* x, const float* w, const float* bias, const float* resid, float* out, long long M, int N, const ConvLnFold* ln,
+               hipStream_t st);
+int conv1x1_ws_init_device();
 // conv_local.hip: conv3x3 + GroupNorm + Mish (+shift, +residual) in one launch for 4x4 / 8x8 maps
 // the addend of the image-local kernels may still be in split-K form (the 1x1 skip conv's slabs): n slabs `stride` floats apart,
 // summed in order, plus bias[c] -- the skip conv's reduce launch folded into the consumer's load

@@ -231,6 +231,21 @@ def conv_first(x, w_first, bias, n_out, groups=GN_GROUPS, partials=True):
     return raw, part, tiles
 
 
+def conv1x1_ws(x, w_packed, bias=None, resid=None, ln=None, eps=1e-5):
+    """1x1 conv of a 128-channel NHWC tensor by the weights-stationary kernel (ddk_conv1x1_ws); w_packed [N][128].
+    ln = (c1, c2): LayerNorm folded in (w_packed then holds W o g)."""
+    b, h, w_, k = x.shape
+    n = w_packed.shape[0]
+    lib = L.load()
+    if not lib.ddk_conv1x1_ws_ok(b * h * w_, k, n):
+        raise L.DDKError(f"conv1x1_ws: shape {tuple(x.shape)} -> {n} not eligible")
+    out = torch.empty((b, h, w_, n), device=x.device, dtype=torch.float32)
+    c1, c2 = ln if ln is not None else (None, None)
+    L.check(lib.ddk_conv1x1_ws(L.ptr(_f32(x)), L.ptr(w_packed), L.ptr(bias), L.ptr(resid), L.ptr(out), b * h * w_, n, L.ptr(c1), L.ptr(c2),
+                               eps, L.stream()), "conv1x1_ws")
+    return out
+
+
 def groupnorm_mish_from_partials_res1x1(x, part, tiles_per_image, gamma, beta, res_x, res_w, res_b, temb=None, groups=GN_GROUPS,
                                         eps=GN_EPS):
     """groupnorm_mish_from_partials with the addend res_b + res_x @ res_w^T (a 1x1 conv of a <= 8-channel tensor) computed on the

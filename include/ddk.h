@@ -141,6 +141,15 @@ int ddk_pack_conv_weight_first(const float* w_oihw, float* dst, int O, int I, dd
 int ddk_conv_first_ok(int cin, int N, int H, int W, int groups);
 int ddk_conv_first(const float* x, const float* w_first, const float* bias, float* out, float* gn_partials, int B, int H, int W,
                    int cin, int N, int groups, ddk_stream_t s);
+/* 1x1 conv with exactly 128 input channels on M = B*H*W >= 2048 pixels (M % 64 == 0, N % 128 == 0) as a weights-stationary
+ * GEMM: a workgroup keeps a 128-output-channel slice of the weight in LDS and streams 64-pixel tiles of x through it
+ * (replaces the nn.Conv2d(k=1) dispatches of reference models/unet/blocks.py:103,123,124 on the 32x32 / 16x16 maps; ddk_conv_forward
+ * takes this path by itself when the shape is eligible).  x [M][128]; w [N][128] = ddk_pack_conv_weight(kind 1x1); bias [N] or null;
+ * resid [M][N] or null (added to the output); ln_c1 != null: the channel LayerNorm of blocks.py:57-60 is folded in -- w must then
+ * hold W o g and (ln_c1, ln_c2) = (W g, W b) per output channel (what ddk_unet_pack derives). */
+int ddk_conv1x1_ws_ok(long long M, int K, int N);
+int ddk_conv1x1_ws(const float* x, const float* w, const float* bias, const float* resid, float* out, long long M, int N,
+                   const float* ln_c1, const float* ln_c2, float ln_eps, ddk_stream_t s);
 /* ddk_groupnorm_mish_partials whose addend is a 1x1 conv of a narrow tensor, evaluated on the fly (the first ResnetBlock's
  * res_conv, blocks.py:103,115): out = Mish(GN(x)) [+ temb] + (res_b[c] + sum_k res_x[pix][k] res_w[c][k]), res_x [B*HW][res_cin],
  * res_w [C][res_cin] (the OIHW 1x1 weight as is), 1 <= res_cin <= 8; C/4 must divide 256. */

@@ -239,3 +239,59 @@ def test_cluster_groupnorm_option_gives_identical_unet():
     assert plan.cluster_timeouts() == 0
     assert torch.equal(y_on, y_on2)
     assert rel_err(y_on.cpu(), y_off.cpu()) < 2e-5
+
+
+# ---- weights-stationary 1x1 conv (conv1x1_ws.hip): blocks.py:103 (res_conv), :123 (to_qkv behind the channel LayerNorm), :124 + :13-14
+WS_CASES = [
+    # B, H, W, N, bias, resid, ln
+    (32, 32, 32, 384, False, False, True),    # to_qkv at 32x32 (cfg4): 512 tiles over 3 x 85 workgroups
+    (32, 32, 32, 128, True, True, False),     # to_out + Residual at 32x32
+    (32, 16, 16, 256, True, False, False),    # res_conv 128 -> 256 at 16x16: one tile per workgroup
+    (32, 16, 16, 384, False, False, True),    # to_qkv at 16x16 (up path): ragged tile counts per workgroup (128 tiles, 85 workgroups)
+    (2, 32, 32, 128, False, True, True),      # the minimum size: 32 tiles, every option at once
+    (3, 32, 32, 256, True, True, True),
+    (5, 16, 32, 128, False, False, False),    # 40 tiles
+]
+
+
+@pytest.mark.parametrize("B,H,W,N,use_bias,use_resid,use_ln", WS_CASES)
+def test_conv1x1_ws(ops, B, H, W, N, use_bias, use_resid, use_ln):
+    """ddk_conv1x1_ws == F.conv2d(k=1) (+ bias, + residual), with the channel LayerNorm folded in == conv(LayerNorm(x)); and the
+    generic conv entry takes the same kernel for these shapes (bit-identical)"""
+    K = 128
+    x = rnd(B, K, H, W, seed=11) * 1.5 + 0.4
+    w = rnd(N, K, 1, 1, seed=12, scale=K ** -0.5)
+    b = rnd(N, seed=13) if use_bias else None
+    r = rnd(B, N, H, W, seed=14) if use_resid else None
+    g, be = 1 + 0.2 * rnd(K, seed=15), 0.1 * rnd(K, seed=16)
+    xin = x
+    if use_ln:
+        std = x.var(dim=1, unbiased=False, keepdim=True).sqrt()
+        xin = (x - x.mean(dim=1, keepdim=True)) / (std + 1e-5) * g.view(1, K, 1, 1) + be.view(1, K, 1, 1)
+    ref = F.conv2d(xin.double(), w.double(), b.double() if use_bias else None)
+    if use_resid:
+        ref = ref + r.double()
+    w2 = w.reshape(N, K)
+    ln = None
+    if use_ln:
+        ln = ((w2 @ g).to(DEV).contiguous(), (w2 @ be).to(DEV).contiguous())
+        w2 = w2 * g.view(1, K)
+    xd = to_nhwc(x).to(DEV)
+    rd = to_nhwc(r).to(DEV) if use_resid else None
+    bd = b.to(DEV) if use_bias else None
+    out = ops.conv1x1_ws(xd, w2.contiguous().to(DEV), bd, rd, ln)
+    assert rel_err(to_nchw(out.cpu()).double(), ref) < 2e-5
+    out2 = ops.conv1x1_ws(xd, w2.contiguous().to(DEV), bd, rd, ln)
+    assert torch.equal(out, out2)
+    if not use_ln:
+        y = ops.conv(ops.CONV1X1, xd, ops.pack_conv_weight(w.to(DEV)), bd, resid=rd)
+        assert torch.equal(y, out)
+
+
+def test_conv1x1_ws_eligibility(ops):
+    from ddk import lib
+    ok = lib.load().ddk_conv1x1_ws_ok
+    assert ok(32768, 128, 384) and ok(2048, 128, 128)
+    assert not ok(32768, 256, 384) and not ok(32768, 128, 96) and not ok(1024, 128, 128) and not ok(2048 + 32, 128, 128)
+    with pytest.raises(lib.DDKError):
+        ops.conv1x1_ws(torch.zeros(1, 8, 8, 128, device=DEV), torch.zeros(128, 128, device=DEV))
