@@ -80,6 +80,19 @@ class ConvResNet(nn.Module):
             if pk is not None:
                 pk._store.clear()
 
+    def flops(self, batch, height, width):
+        """Algorithmic FLOPs (2*MAC) of one forward on a [batch, in_channels, height, width] input."""
+        d = self.dim
+        total, h, w = 2 * batch * height * width * self.in_channels * d, height, width
+        for blk in list(self.conv)[1:-1]:
+            m = d // 2
+            total += 2 * batch * h * w * (d * m + 2 * 9 * m * m + m * d)
+            if blk.upsample:
+                h, w = 2 * h, 2 * w
+            elif blk.downsample:
+                h, w = h // 2, w // 2
+        return total + 2 * batch * h * w * d * self.out_channels
+
     def forward_nhwc(self, x, final_tanh=False):
         """x [B,H,W,pad32(in_channels)] -> [B,H',W',out_channels]; optional fused-after tanh (dddpm.py:99,110)."""
         first, last = self.conv[0], self.conv[-1]

@@ -257,7 +257,7 @@ WS_CASES = [
 @pytest.mark.parametrize("B,H,W,N,use_bias,use_resid,use_ln", WS_CASES)
 def test_conv1x1_ws(ops, B, H, W, N, use_bias, use_resid, use_ln):
     """ddk_conv1x1_ws == F.conv2d(k=1) (+ bias, + residual), with the channel LayerNorm folded in == conv(LayerNorm(x)); and the
-    generic conv entry takes the same kernel for these shapes (bit-identical)"""
+    generic conv entry takes the same kernel on full-chip shapes (bit-identical)"""
     K = 128
     x = rnd(B, K, H, W, seed=11) * 1.5 + 0.4
     w = rnd(N, K, 1, 1, seed=12, scale=K ** -0.5)
@@ -284,8 +284,12 @@ def test_conv1x1_ws(ops, B, H, W, N, use_bias, use_resid, use_ln):
     out2 = ops.conv1x1_ws(xd, w2.contiguous().to(DEV), bd, rd, ln)
     assert torch.equal(out, out2)
     if not use_ln:
+        # the generic entry takes this kernel from 256 (tile, slice) pairs on (a full chip), the tile kernel below that
         y = ops.conv(ops.CONV1X1, xd, ops.pack_conv_weight(w.to(DEV)), bd, resid=rd)
-        assert torch.equal(y, out)
+        if (B * H * W // 64) * (N // 128) >= 256:
+            assert torch.equal(y, out)
+        else:
+            assert rel_err(y.cpu(), out.cpu()) < 2e-6
 
 
 def test_conv1x1_ws_eligibility(ops):
