@@ -44,6 +44,7 @@ struct WgradParams {
     const float* x;   // [B][H][W][cx]
     const float* dy;  // [M][N], M = B*Hm*Wm
     float* slab;      // [splits][N][ntaps][cx]
+    float* bias_slab; // [splits][N] column sums of dy (the bias gradient's slabs), or null
     int cx, N;
     int H, W, Hm, Wm, M;
     int in_stride, tapmode, ntaps;
@@ -138,13 +139,21 @@ __global__ __launch_bounds__(WN* WC * 64) void wgrad_kernel(const WgradParams p)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    // bias gradient = column sums of dY: the MFMA operand a lane reads from the dY tile is dY[k = 2q + (lane >> 5)][n = lane & 31],
+    // so a running sum of those registers over the k-pairs IS the column sum of half the rows -- TN adds per k-pair in the
+    // workgroups of the first channel tile and tap, no separate pass over dY
+    const bool do_bias = p.bias_slab != nullptr && blockIdx.y == 0 && tap == 0;
+    float bsum[TN];
+#pragma unroll
+    for (int i = 0; i < TN; ++i) bsum[i] = 0.f;
+
     const int a_off = wn * TN * 32 + (lane & 31) + (lane >> 5) * BN;
     const int b_off = 32 * BN + wc * TC * 32 + (lane & 31) + (lane >> 5) * BC;
 
     if (n_it > 0) issue(0, m_begin);
     {   // keep SMEM out of the k-loop (see conv_igemm.hip consume_epilogue_args): epilogue-only arguments are consumed here
         const int nt = p.ntaps, NN = p.N, cxx = p.cx;
-        asm volatile("" ::"s"(p.slab), "s"(nt), "s"(NN), "s"(cxx));
+        asm volatile("" ::"s"(p.slab), "s"(p.bias_slab), "s"(nt), "s"(NN), "s"(cxx));
     }
     for (int k = 0; k < n_it; ++k) {
         const int stage = k & 1;
@@ -173,7 +182,19 @@ __global__ __launch_bounds__(WN* WC * 64) void wgrad_kernel(const WgradParams p)
             for (int i = 0; i < TN; ++i)
 #pragma unroll
                 for (int j = 0; j < TC; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
+            if (do_bias) {
+#pragma unroll
+                for (int i = 0; i < TN; ++i) bsum[i] += a[cur][i];
+            }
             __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if (do_bias && wc == 0) {                          // even-k half + odd-k half; the waves of one wn hold the same sums
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+            const float t = bsum[i] + __shfl_xor(bsum[i], 32, 64);
+            const int n = n0 + (wn * TN + i) * 32 + (lane & 31);
+            if (lane < 32 && n < p.N) p.bias_slab[(long long)split * p.N + n] = t;
         }
     }
 
@@ -207,6 +228,7 @@ struct WgHaloParams {
     const float* x;    // [B][H][W][cx]
     const float* dy;   // [M][N]
     float* slab;       // [splits][N][9][cx]
+    float* bias_slab;  // [splits][N] column sums of dy, or null
     int cx, N, B, H, W, M;
     int splits, chunks_per_split, n_chunks;
     FastDiv dH_, dW_;
@@ -268,6 +290,8 @@ __global__ __launch_bounds__(256) void wgrad3x3_halo_kernel(const WgHaloParams p
     for (int t = 0; t < 9; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    const bool do_bias = p.bias_slab != nullptr && blockIdx.y == 0;      // column sums of dY on the side (see wgrad_kernel)
+    float bsum = 0.f;
 
     // per-lane operand offsets (floats): k = 2*kk + (lane >> 5)
     const int fh = lane >> 5, l31 = lane & 31;
@@ -283,7 +307,7 @@ __global__ __launch_bounds__(256) void wgrad3x3_halo_kernel(const WgHaloParams p
     if (n_it > 0) issue(0, g_begin);
     {   // keep SMEM out of the k-loop (conv_igemm.hip consume_epilogue_args)
         const int NN = p.N, cxx = p.cx, sp = p.splits;
-        asm volatile("" ::"s"(p.slab), "s"(NN), "s"(cxx), "s"(sp));
+        asm volatile("" ::"s"(p.slab), "s"(p.bias_slab), "s"(NN), "s"(cxx), "s"(sp));
     }
     for (int it = 0; it < n_it; ++it) {
         const int stage = it & 1;
@@ -305,8 +329,14 @@ __global__ __launch_bounds__(256) void wgrad3x3_halo_kernel(const WgHaloParams p
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int t = 0; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur], b[cur][t], acc[t], 0, 0, 0);
+            if (do_bias) bsum += a[cur];
             __builtin_amdgcn_sched_barrier(0);
         }
+    }
+    if (do_bias && wc == 0) {
+        const float t = bsum + __shfl_xor(bsum, 32, 64);
+        const int n = n0 + wn * 32 + l31;
+        if (lane < 32 && n < p.N) p.bias_slab[(long long)split * p.N + n] = t;
     }
 
     // epilogue: per tap, this wave's 32x32 block -> LDS (pitch 40) -> float4 rows -> slab[split][n][tap][c]
@@ -335,35 +365,37 @@ __global__ __launch_bounds__(256) void wgrad3x3_halo_kernel(const WgHaloParams p
 }
 
 // grad[(n*cw + c_off + c)*ntaps + tap] += sum_s slab[s][n][tap][c]   (only the first c_real channels: the input may be padded)
-// One workgroup per (n, 32-channel block): the [tap][32 c] rows of every slab are read coalesced and summed in split order,
-// transposed through LDS, and the 32*ntaps consecutive floats of the OIHW gradient are updated coalesced.
+// One workgroup per (n, 32-channel block, tap): 8 row groups of 32 lanes read the [32 c] row of every 8th slab coalesced, four
+// loads in flight each, and the eight partial sums are added in a fixed order -- deterministic, and wide enough for the 256-split
+// slabs of the narrow convs (one workgroup per (n, block) summing 256 x 9 rows serially took 38 us; profiles/r03_train_wgrad.txt).
+// Grid row y == ntaps (present when the launch carries a bias gradient) sums the [splits][N] column-sum slabs into grad_b.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, int splits, long long slab_stride,
                                                            float* __restrict__ grad, int N, int ntaps, int cx, int c_real, int cw,
-                                                           int c_off, long long total) {
-    __shared__ float t_s[16][33];                       // [tap][c]
+                                                           int c_off, long long total, const float* __restrict__ bias_slab,
+                                                           float* __restrict__ grad_b) {
+    __shared__ float part[8][32];
     const int cblocks = cx >> 5;
-    const int n = blockIdx.x / cblocks, cb = blockIdx.x % cblocks;
-    const int c0 = cb * 32;
-    (void)total; (void)N;
-    for (int i = threadIdx.x; i < ntaps * 32; i += 256) {
-        const int tap = i >> 5, c = i & 31;
-        const long long src = ((long long)n * ntaps + tap) * cx + c0 + c;
-        // fixed association, four loads in flight: ((s0 + s1) + (s2 + s3)) + ...
-        float s = 0.f;
-        int k = 0;
-        for (; k + 3 < splits; k += 4) {
-            const float a0 = slab[k * slab_stride + src], a1 = slab[(k + 1) * slab_stride + src];
-            const float a2 = slab[(k + 2) * slab_stride + src], a3 = slab[(k + 3) * slab_stride + src];
-            s += (a0 + a1) + (a2 + a3);
-        }
-        for (; k < splits; ++k) s += slab[k * slab_stride + src];
-        t_s[tap][c] = s;
+    const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
+    (void)total;
+    const bool bias_row = (int)blockIdx.y == ntaps;         // extra grid row: grad_b[n] += sum_s bias_slab[s][n], 32 n per workgroup
+    if (bias_row && (int)blockIdx.x * 32 >= N) return;
+    const int n = blockIdx.x / cblocks, cb = blockIdx.x % cblocks, tap = blockIdx.y;
+    const float* src = bias_row ? bias_slab + blockIdx.x * 32 + c : slab + ((long long)n * ntaps + tap) * cx + cb * 32 + c;
+    const long long stride = bias_row ? N : slab_stride;
+    float s = 0.f;
+    int k = g;
+    for (; k + 24 < splits; k += 32) {
+        const float a0 = src[k * stride], a1 = src[(k + 8) * stride];
+        const float a2 = src[(k + 16) * stride], a3 = src[(k + 24) * stride];
+        s += (a0 + a1) + (a2 + a3);
     }
+    for (; k < splits; k += 8) s += src[k * stride];
+    part[g][c] = s;
     __syncthreads();
-    float* g = grad + ((long long)n * cw + c_off + c0) * ntaps;
-    for (int i = threadIdx.x; i < ntaps * 32; i += 256) {
-        const int c = i / ntaps, tap = i - c * ntaps;
-        if (c0 + c < c_real) g[i] += t_s[tap][c];
+    if (threadIdx.x < 32) {
+        const float t = ((part[0][c] + part[1][c]) + (part[2][c] + part[3][c])) + ((part[4][c] + part[5][c]) + (part[6][c] + part[7][c]));
+        if (bias_row) grad_b[blockIdx.x * 32 + c] += t;
+        else if (cb * 32 + c < c_real) grad[((long long)n * cw + c_off + cb * 32 + c) * ntaps + tap] += t;
     }
 }
 
@@ -454,10 +486,15 @@ static WgChoice wgrad_choice(int N, int cx, int ntaps, long long M) {
     c.bn = tile32(N);
     c.bc = tile32(cx);
     const long long tiles = ceil_div(N, c.bn) * ceil_div(cx, c.bc) * ntaps;
-    long long s = ceil_div(512, tiles);
+    // The loop is a 2-stage ring with a drain per 32-pixel chunk: a wave hides its DMA latency only behind OTHER waves of
+    // its SIMD.  4-wave tiles want ~512 workgroups (two per CU); the one- and two-wave tiles of narrow convs (the 32 / 64
+    // channel encoder / decoder of the dDDPM at up to 262144 pixels) ran 64 splits = 64-513 waves on 1024 SIMDs at 1.5 us
+    // per chunk (235 us for 4.8 GFLOP); they get the same ~2048 waves now (profiles/r03_train_wgrad.txt).
+    const int waves = (c.bn >= 64 && c.bc >= 64) ? 4 : ((c.bn * c.bc) / 1024 >= 4 ? 4 : (c.bn * c.bc) / 1024);
+    long long s = ceil_div(2048 / waves, tiles);
     const long long max_s = M / 256 > 0 ? M / 256 : 1;   // at least 8 k-chunks per split
     if (s > max_s) s = max_s;
-    if (s > 64) s = 64;
+    if (s > 256) s = 256;
     if (s < 1) s = 1;
     c.rows_per = (int)(ceil_div(ceil_div(M, s), 32) * 32);
     c.splits = (int)ceil_div(M, c.rows_per);
@@ -546,9 +583,10 @@ size_t ddk_conv_wgrad_workspace_bytes(int kind, int B, int H, int W, int cx, int
     int Hm, Wm, stride, tapmode, ntaps;
     if (!wgrad_geometry(kind, H, W, Hm, Wm, stride, tapmode, ntaps)) return 0;
     int wc, hs, cps, nch;
-    if (wgrad_halo_plan(kind, B, H, W, cx, N, wc, hs, cps, nch)) return (size_t)hs * N * 9 * cx * sizeof(float);
+    // + [splits][N] for the column sums of dy (ddk_conv_wgrad_bias)
+    if (wgrad_halo_plan(kind, B, H, W, cx, N, wc, hs, cps, nch)) return (size_t)hs * N * (9 * cx + 1) * sizeof(float);
     const WgChoice c = wgrad_choice(N, cx, ntaps, (long long)B * Hm * Wm);
-    return (size_t)c.splits * N * ntaps * cx * sizeof(float);
+    return (size_t)c.splits * N * (ntaps * cx + 1) * sizeof(float);
 }
 
 /* grad_w[(n*cw + c_off + c)*taps + tap] += sum_m dy[m][n] x[pix(m)+tap][c],  c < c_real <= cx.
@@ -558,6 +596,13 @@ size_t ddk_conv_wgrad_workspace_bytes(int kind, int B, int H, int W, int cx, int
  * is laid out like its (I,O,4,4) weight. */
 int ddk_conv_wgrad(int kind, const float* x, const float* dy, float* grad_w, int B, int H, int W, int cx, int c_real, int cw,
                    int c_off, int N, void* workspace, size_t workspace_bytes, ddk_stream_t s) {
+    return ddk_conv_wgrad_bias(kind, x, dy, grad_w, nullptr, B, H, W, cx, c_real, cw, c_off, N, workspace, workspace_bytes, s);
+}
+
+/* ddk_conv_wgrad that also accumulates the bias gradient when grad_b != null: grad_b[n] += sum_m dy[m][n], computed by the same
+ * launches (the column sums ride on the weight-gradient GEMM as dY^T 1; no separate pass over dy). */
+int ddk_conv_wgrad_bias(int kind, const float* x, const float* dy, float* grad_w, float* grad_b, int B, int H, int W, int cx, int c_real,
+                        int cw, int c_off, int N, void* workspace, size_t workspace_bytes, ddk_stream_t s) {
     int Hm, Wm, stride, tapmode, ntaps;
     DDK_REQUIRE(wgrad_geometry(kind, H, W, Hm, Wm, stride, tapmode, ntaps), "conv_wgrad: kind");
     DDK_REQUIRE(x && dy && grad_w && workspace, "conv_wgrad: null pointer");
@@ -571,13 +616,14 @@ int ddk_conv_wgrad(int kind, const float* x, const float* dy, float* grad_w, int
     {
         int wc, hs, cps, nch;
         if (wgrad_halo_plan(kind, B, H, W, cx, N, wc, hs, cps, nch)) {
-            const size_t need_h = (size_t)hs * N * 9 * cx * sizeof(float);
+            const size_t need_h = (size_t)hs * N * (9 * cx + (grad_b ? 1 : 0)) * sizeof(float);
             if (workspace_bytes < need_h) {
                 set_error("conv_wgrad: workspace too small (%zu < %zu)", workspace_bytes, need_h);
                 return DDK_ERR_WORKSPACE;
             }
             WgHaloParams hp{};
             hp.x = x; hp.dy = dy; hp.slab = static_cast<float*>(workspace);
+            hp.bias_slab = grad_b ? hp.slab + (size_t)hs * N * 9 * cx : nullptr;
             hp.cx = cx; hp.N = N; hp.B = B; hp.H = H; hp.W = W; hp.M = (int)M;
             hp.splits = hs; hp.chunks_per_split = cps; hp.n_chunks = nch;
             hp.dH_ = make_fastdiv((unsigned)H); hp.dW_ = make_fastdiv((unsigned)W);
@@ -588,19 +634,21 @@ int ddk_conv_wgrad(int kind, const float* x, const float* dy, float* grad_w, int
             else rc = launch_wgrad_halo<4>(hp, st);
             DDK_TRY(rc);
             const long long total = (long long)N * 9 * cx;
-            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(N * (cx / 32))), dim3(256), 0, st, static_cast<const float*>(workspace),
-                               hs, total, grad_w, N, 9, cx, c_real, cw, c_off, total);
+            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(N * (cx / 32)), grad_b ? 10 : 9), dim3(256), 0, st,
+                               static_cast<const float*>(workspace), hs, total, grad_w, N, 9, cx, c_real, cw, c_off, total,
+                               static_cast<const float*>(hp.bias_slab), grad_b);
             return check_launch("wgrad_reduce_kernel");
         }
     }
     const WgChoice c = wgrad_choice(N, cx, ntaps, M);
-    const size_t need = (size_t)c.splits * N * ntaps * cx * sizeof(float);
+    const size_t need = (size_t)c.splits * N * (ntaps * cx + (grad_b ? 1 : 0)) * sizeof(float);
     if (workspace_bytes < need) {
         set_error("conv_wgrad: workspace too small (%zu < %zu)", workspace_bytes, need);
         return DDK_ERR_WORKSPACE;
     }
     WgradParams p{};
     p.x = x; p.dy = dy; p.slab = static_cast<float*>(workspace);
+    p.bias_slab = grad_b ? p.slab + (size_t)c.splits * N * ntaps * cx : nullptr;
     p.cx = cx; p.N = N; p.H = H; p.W = W; p.Hm = Hm; p.Wm = Wm; p.M = (int)M;
     p.in_stride = stride; p.tapmode = tapmode; p.ntaps = ntaps;
     p.splits = c.splits; p.rows_per_split = c.rows_per;
@@ -620,8 +668,9 @@ int ddk_conv_wgrad(int kind, const float* x, const float* dy, float* grad_w, int
 #undef WG
     DDK_TRY(rc);
     const long long total = (long long)N * ntaps * cx;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(N * (cx / 32))), dim3(256), 0, st, static_cast<const float*>(workspace),
-                       c.splits, total, grad_w, N, ntaps, cx, c_real, cw, c_off, total);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(N * (cx / 32)), (unsigned)(ntaps + (grad_b ? 1 : 0))), dim3(256), 0, st,
+                       static_cast<const float*>(workspace), c.splits, total, grad_w, N, ntaps, cx, c_real, cw, c_off, total,
+                       static_cast<const float*>(p.bias_slab), grad_b);
     return check_launch("wgrad_reduce_kernel");
 }
 

@@ -125,6 +125,7 @@ SIGNATURES = {
     "ddk_zero_stuff2": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "ddk_conv_wgrad_workspace_bytes": (_SZ, [_I, _I, _I, _I, _I, _I]),
     "ddk_conv_wgrad": (_I, [_I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _SZ, _P]),
+    "ddk_conv_wgrad_bias": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _SZ, _P]),
     "ddk_bias_grad": (_I, [_P, _P, _LL, _I, _I, _P, _SZ, _P]),
     "ddk_groupnorm_train_workspace_bytes": (_SZ, [_I, _I, _I, _I]),
     "ddk_dropout_epoch": (_I, [C.c_uint64, _I, _P]),

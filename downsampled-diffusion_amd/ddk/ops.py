@@ -566,15 +566,16 @@ def zero_stuff2(dy, h_out, w_out):
     return out
 
 
-def conv_wgrad_(kind, x, dy, grad_w, c_real, cw, c_off):
-    """grad_w (canonical layout, contiguous) += weight gradient of `kind` for the source x (see csrc/conv_wgrad.hip)."""
+def conv_wgrad_(kind, x, dy, grad_w, c_real, cw, c_off, grad_b=None):
+    """grad_w (canonical layout, contiguous) += weight gradient of `kind` for the source x (see csrc/conv_wgrad.hip);
+    grad_b [N] += column sums of dy when given (the bias gradient, produced by the same launches)."""
     b, h, w, cx = x.shape
     n = dy.shape[-1]
     lib = L.load()
     nbytes = lib.ddk_conv_wgrad_workspace_bytes(kind, b, h, w, cx, n)
     ws = _ws(x.device, nbytes, "wgrad")
-    L.check(lib.ddk_conv_wgrad(kind, L.ptr(_f32(x)), L.ptr(_f32(dy)), L.ptr(grad_w), b, h, w, cx, c_real, cw, c_off, n,
-                               L.ptr(ws), nbytes, L.stream()), "conv_wgrad")
+    L.check(lib.ddk_conv_wgrad_bias(kind, L.ptr(_f32(x)), L.ptr(_f32(dy)), L.ptr(grad_w), L.ptr(grad_b), b, h, w, cx, c_real, cw, c_off, n,
+                                    L.ptr(ws), nbytes, L.stream()), "conv_wgrad")
     return grad_w
 
 

@@ -353,6 +353,10 @@ size_t ddk_conv_wgrad_workspace_bytes(int kind, int B, int H, int W, int cx, int
 /* grad_w[(n*cw + c_off + c)*taps + tap] += sum_m dy[m][n] x[pix(m)+tap][c], c < c_real (see csrc/conv_wgrad.hip) */
 int ddk_conv_wgrad(int kind, const float* x, const float* dy, float* grad_w, int B, int H, int W, int cx, int c_real,
                    int cw, int c_off, int N, void* workspace, size_t workspace_bytes, ddk_stream_t s);
+/* ddk_conv_wgrad that also accumulates the bias gradient: grad_b[n] += sum_m dy[m][n] when grad_b != null (the column sums ride
+ * on the weight-gradient GEMM's launches; same workspace size).  Not for the ConvTranspose2d form (x and dy swapped there). */
+int ddk_conv_wgrad_bias(int kind, const float* x, const float* dy, float* grad_w, float* grad_b, int B, int H, int W, int cx, int c_real,
+                        int cw, int c_off, int N, void* workspace, size_t workspace_bytes, ddk_stream_t s);
 /* grad_b[n] (+)= sum_m dy[m][n]; N % 4 == 0; workspace >= 256*N floats */
 int ddk_bias_grad(const float* dy, float* grad_b, long long M, int N, int accumulate, void* workspace,
                   size_t workspace_bytes, ddk_stream_t s);

@@ -40,6 +40,8 @@ CONV_BWD = [
     ("1x1", 4, 8, 8, 128, 0, 384), ("1x1", 2, 4, 4, 64, 64, 128), ("T", 4, 4, 4, 64, 0, 64), ("T", 2, 8, 8, 128, 0, 128),
     # halo weight-gradient kernel (N % 64 == 0, C % 64 == 0): row chunks at W = 32 / 8 (odd batch) / 64 (row segments)
     ("s1", 2, 32, 32, 64, 0, 64), ("s1", 3, 8, 8, 128, 0, 64), ("s1", 1, 64, 64, 64, 0, 128), ("s1", 6, 4, 4, 64, 64, 128),
+    # the narrow convs of the dDDPM encoder / decoder at many pixels: one- and two-wave tiles, up to 256 pixel splits
+    ("s1", 4, 64, 64, 32, 0, 32), ("1x1", 4, 64, 64, 64, 0, 32), ("1x1", 5, 64, 64, 32, 0, 64), ("1x1", 16, 64, 64, 64, 0, 64),
 ]
 
 
@@ -72,6 +74,20 @@ def test_conv_backward(AG, kind, B, H, W, c0, c1, N):
         assert rel_err(x1.grad.cpu(), gxh[..., c0:]) < 3e-5
     assert rel_err(wd.grad.cpu(), gw) < 3e-5
     assert rel_err(bd.grad.cpu(), gb) < 3e-5
+
+
+def test_conv_backward_accumulates_into_existing_grads(AG):
+    """two backward passes into pre-existing .grad buffers (the optimiser's flat buffer): weight AND bias gradients are added in
+    place by the weight-gradient launches (ddk_conv_wgrad_bias)"""
+    from ddk import ops
+    x, w, b = rnd(3, 64, 16, 16, seed=31), rnd(32, 64, 3, 3, seed=32, scale=0.05), rnd(32, seed=33, scale=0.1)
+    out_ref, g, (gx, gw, gb) = grads_cpu(lambda a, ww, bb: F.conv2d(a, ww, bb, padding=1), x, w, b)
+    wd, bd = w.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+    wd.grad, bd.grad = torch.ones_like(wd), torch.full_like(bd, 2.0)
+    for _ in range(2):
+        xh = to_nhwc(x).to(DEV).requires_grad_(True)
+        AG.conv(ops.CONV3X3_S1, xh, wd, bd).backward(to_nhwc(g).to(DEV))
+    assert rel_err(wd.grad.cpu(), 1 + 2 * gw) < 3e-5 and rel_err(bd.grad.cpu(), 2 + 2 * gb) < 3e-5
 
 
 def test_conv_backward_padded_input_and_residual(AG):
