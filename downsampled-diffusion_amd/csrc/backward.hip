@@ -408,6 +408,29 @@ __global__ __launch_bounds__(256) void rows_sum_kernel(const float* __restrict__
     }
 }
 
+// the same with one target pointer per batch entry (null = skip): the GroupNorm backward's dgamma / dbeta / conv-bias rows go
+// into three different gradient buffers in one launch
+struct RowsTargets { float* out[4]; };
+__global__ __launch_bounds__(256) void rows_sum_targets_kernel(const float* __restrict__ rows, int nrows, long long row_stride,
+                                                               long long batch_stride, RowsTargets tg, int n, int accumulate) {
+    __shared__ float red[4][64];
+    float* out = tg.out[blockIdx.y];
+    if (!out) return;
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+    const float* base = rows + (long long)blockIdx.y * batch_stride;
+    float s = 0.f;
+    if (col < n) {
+#pragma unroll 4
+        for (int r = rg; r < nrows; r += 4) s += base[r * row_stride + col];
+    }
+    red[rg][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (threadIdx.x < 64 && col < n) {
+        const float t = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        out[col] = accumulate ? out[col] + t : t;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Channel LayerNorm backward.  y = d/s*g + b, d = x - mean, s = sqrt(var) + eps:
 //   dx = dyg/s - mean(dyg)/s - d * sum(dyg*d) / (C * sigma * s^2),  dyg = dy*g;  dg = sum_pix dy*d/s;  db = sum_pix dy
@@ -1023,6 +1046,16 @@ int ddk_rows_sum_batched(const float* rows, int nbatch, long long batch_stride, 
     hipLaunchKernelGGL(rows_sum_kernel, dim3((unsigned)ceil_div(n, 64), (unsigned)nbatch), dim3(256), 0, as_stream(s), rows, nrows,
                        row_stride, batch_stride, out, n, accumulate);
     return check_launch("rows_sum_kernel");
+}
+
+/* out_k[n] (+)= sum_r rows[k*batch_stride + r*row_stride + n] for k < nbatch <= 4 with one target per k (null = skipped) */
+int ddk_rows_sum_targets(const float* rows, int nbatch, long long batch_stride, int nrows, long long row_stride, float* out0, float* out1,
+                         float* out2, float* out3, int n, int accumulate, ddk_stream_t s) {
+    DDK_REQUIRE(rows && nbatch > 0 && nbatch <= 4 && nrows > 0 && n > 0, "rows_sum_targets: arguments");
+    RowsTargets tg{{out0, out1, out2, out3}};
+    hipLaunchKernelGGL(rows_sum_targets_kernel, dim3((unsigned)ceil_div(n, 64), (unsigned)nbatch), dim3(256), 0, as_stream(s), rows, nrows,
+                       row_stride, batch_stride, tg, n, accumulate);
+    return check_launch("rows_sum_targets_kernel");
 }
 
 /* Channel LayerNorm backward: dx and partial rows part[2][nparts][C] (dg, db); returns nparts via *nparts_out. */

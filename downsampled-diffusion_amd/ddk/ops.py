@@ -617,10 +617,10 @@ def groupnorm_mish_bwd(x, gamma, beta, dy, drop_p=0.0, seed=0, layer=0, groups=G
             "groupnorm_mish_bwd")
     sums = [None, None, None]
     missing = [k for k in range(3) if acc is None or acc[k] is None]
-    if acc is not None:
-        for k, tgt in enumerate(acc):
-            if tgt is not None:                  # straight into the parameter's gradient (fixed-order row sum, then +=)
-                L.check(lib.ddk_rows_sum(L.ptr(part[1 + k]), b, c, L.ptr(tgt), c, 1, L.stream()), "rows_sum")
+    if acc is not None and any(t is not None for t in acc):
+        # straight into the parameters' gradients (fixed-order row sums, then +=), one launch for the three of them
+        L.check(lib.ddk_rows_sum_targets(L.ptr(part[1]), 3, b * c, b, c, L.ptr(acc[0]), L.ptr(acc[1]), L.ptr(acc[2]), None, c, 1,
+                                         L.stream()), "rows_sum_targets")
     if missing:
         out = torch.empty((3, c), device=x.device, dtype=torch.float32)
         L.check(lib.ddk_rows_sum_batched(L.ptr(part[1]), 3, b * c, b, c, L.ptr(out), c, 0, L.stream()), "rows_sum_batched")
@@ -646,10 +646,9 @@ def chan_layernorm_bwd(x, g, dy, eps=LN_EPS):
     L.check(lib.ddk_chan_layernorm_bwd(L.ptr(_f32(x)), L.ptr(g.reshape(-1)), L.ptr(_f32(dy)), L.ptr(dx), L.ptr(part), max_parts,
                                        C.byref(n), m, c, eps, L.stream()), "chan_layernorm_bwd")
     # the kernel laid the rows out as [2][nparts][C] with nparts = n.value
-    flat = part.reshape(-1)
-    dg = rows_sum(flat[:n.value * c], n.value, c, c)
-    db = rows_sum(flat[n.value * c:2 * n.value * c], n.value, c, c)
-    return dx, dg, db
+    out = torch.empty((2, c), device=x.device, dtype=torch.float32)
+    L.check(lib.ddk_rows_sum_batched(L.ptr(part), 2, n.value * c, n.value, c, L.ptr(out), c, 0, L.stream()), "rows_sum_batched")
+    return dx, out[0], out[1]
 
 
 def linattn_small_from_x(x, w_qkv, ln_g, ln_b, heads=4, eps=LN_EPS):

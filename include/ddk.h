@@ -380,6 +380,10 @@ int ddk_rows_sum(const float* rows, int nrows, long long row_stride, float* out,
 /* out[k][n] (+)= sum_r rows[k*batch_stride + r*row_stride + n], k < nbatch */
 int ddk_rows_sum_batched(const float* rows, int nbatch, long long batch_stride, int nrows, long long row_stride, float* out,
                          int n, int accumulate, ddk_stream_t s);
+/* the same with one target per batch entry, nbatch <= 4, a null target is skipped (dgamma / dbeta / conv-bias gradient of a
+ * GroupNorm backward into their three gradient buffers in one launch) */
+int ddk_rows_sum_targets(const float* rows, int nbatch, long long batch_stride, int nrows, long long row_stride, float* out0, float* out1,
+                         float* out2, float* out3, int n, int accumulate, ddk_stream_t s);
 int ddk_chan_layernorm_bwd(const float* x, const float* g, const float* dy, float* dx, float* part, int max_parts,
                            int* nparts_out, long long M, int C, float eps, ddk_stream_t s);
 int ddk_linattn_stats(const float* qkv, float* stats, int B, int HW, int heads, ddk_stream_t s);
