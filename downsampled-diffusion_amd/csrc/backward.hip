@@ -12,15 +12,6 @@
 
 namespace ddk {
 
-// d/du [u * tanh(softplus(u))]: with e = exp(u), n = e(e+2), t = n/(n+2):  t + u * 4 e (e+1) / (n+2)^2
-__device__ __forceinline__ float mish_grad_f(float u) {
-    if (u > 20.0f) return 1.0f;
-    const float e = expf(u);
-    const float n = e * (e + 2.0f);
-    const float d = n + 2.0f;
-    return n / d + u * (4.0f * e * (e + 1.0f)) / (d * d);
-}
-
 // Philox-based keep mask for Dropout(p): one 32-bit draw per element (4 per call)
 struct U4b { uint32_t x, y, z, w; };
 __device__ __forceinline__ U4b philox_u4(unsigned long long idx4, uint32_t a, uint32_t b, uint64_t seed) {

@@ -38,6 +38,8 @@ struct IgemmParams {
     int splits, kiters, kiters_per_split;
     long long slab_stride;
     int pre_mish, post_mish;
+    float* mish_out;          // optional second output: Mish(out)
+    const float* dmish_src;   // optional: out = (acc + bias) * Mish'(dmish_src) (+ resid)
     int debug;    // tuning only (DDK_DEBUG): 1 skip in-loop DMA, 2 skip barrier, 4 skip output stores
     int tapmode;  // 0: single tap (1x1); 1: 3x3, (dy,dx) = (tap/3-1, tap%3-1); 2: transpose-conv phase taps (py-a, px-b);
                   // 3: 4x4, (dy,dx) = (tap/4-1, tap%4-1)
@@ -226,8 +228,10 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmParams p)
                 const long long o = opix * p.N + gn;
                 if (direct) {
                     if (p.bias) v += p.bias[gn];
+                    if (p.dmish_src) v *= mish_grad_f(p.dmish_src[o]);
                     if (p.resid) v += p.resid[o];
                     if (p.post_mish) v = mish_f(v);
+                    if (p.mish_out) p.mish_out[o] = mish_f(v);
                 }
                 outp[o] = v;
             }
@@ -311,12 +315,19 @@ __device__ __forceinline__ void store_block_via_lds(const IgemmParams& p, f32x16
         }
         v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
         const long long o = opix * p.N + gn;
+        if (direct && p.dmish_src) {
+            const float4 ss = *reinterpret_cast<const float4*>(p.dmish_src + o);
+            v.x *= mish_grad_f(ss.x); v.y *= mish_grad_f(ss.y); v.z *= mish_grad_f(ss.z); v.w *= mish_grad_f(ss.w);
+        }
         if (direct && p.resid) {
             const float4 rr = *reinterpret_cast<const float4*>(p.resid + o);
             v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
         }
         if (direct && p.post_mish) { v.x = mish_f(v.x); v.y = mish_f(v.y); v.z = mish_f(v.z); v.w = mish_f(v.w); }
         *reinterpret_cast<float4*>(outp + o) = v;
+        if (direct && p.mish_out) {
+            *reinterpret_cast<float4*>(p.mish_out + o) = make_float4(mish_f(v.x), mish_f(v.y), mish_f(v.z), mish_f(v.w));
+        }
     }
 }
 
@@ -329,7 +340,7 @@ __device__ __forceinline__ void consume_epilogue_args(const IgemmParams& p) {
     const int sp = p.splits, pm = p.post_mish, MM = p.M, NN = p.N, os = p.out_scale, wm = p.Wm, hm = p.Hm, ho = p.Ho, wo = p.Wo;
     const int le = __float_as_int(p.ln_eps);
     asm volatile("" ::"s"(ss), "s"(sp), "s"(pm), "s"(MM), "s"(NN), "s"(os), "s"(wm), "s"(hm), "s"(ho), "s"(wo), "s"(p.out), "s"(p.bias),
-                 "s"(p.resid), "s"(p.ln_c1), "s"(p.ln_c2), "s"(le));
+                 "s"(p.resid), "s"(p.ln_c1), "s"(p.ln_c2), "s"(le), "s"(p.mish_out), "s"(p.dmish_src));
 }
 
 // im2col implicit GEMM, all waves load and multiply (every conv kind; the 3x3 stride-1 layers with enough pixels use the
@@ -963,7 +974,8 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const IgemmParams p) 
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slabs, int splits,
                                                             long long slab_stride, const float* __restrict__ bias,
                                                             const float* __restrict__ resid, float* __restrict__ out,
-                                                            long long n4, int N, int post_mish) {
+                                                            long long n4, int N, int post_mish, float* __restrict__ mish_out,
+                                                            const float* __restrict__ dmish_src) {
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4;
          i += (long long)gridDim.x * blockDim.x) {
         float4 v = reinterpret_cast<const float4*>(slabs)[i];
@@ -975,12 +987,17 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
             const float4 b = *reinterpret_cast<const float4*>(bias + (i * 4) % N);
             v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
         }
+        if (dmish_src) {
+            const float4 ss = reinterpret_cast<const float4*>(dmish_src)[i];
+            v.x *= mish_grad_f(ss.x); v.y *= mish_grad_f(ss.y); v.z *= mish_grad_f(ss.z); v.w *= mish_grad_f(ss.w);
+        }
         if (resid) {
             const float4 r = reinterpret_cast<const float4*>(resid)[i];
             v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
         }
         if (post_mish) { v.x = mish_f(v.x); v.y = mish_f(v.y); v.z = mish_f(v.z); v.w = mish_f(v.w); }
         reinterpret_cast<float4*>(out)[i] = v;
+        if (mish_out) reinterpret_cast<float4*>(mish_out)[i] = make_float4(mish_f(v.x), mish_f(v.y), mish_f(v.z), mish_f(v.w));
     }
 }
 
@@ -1268,7 +1285,11 @@ int conv_forward(const ddk_conv_args& a, hipStream_t st, const ConvLnFold* ln, c
     DDK_REQUIRE((long long)a.B * g.Ho * g.Wo * a.N < (1LL << 31) && (long long)a.B * a.H * a.W * (a.c0 + a.c1) < (1LL << 31),
                 "conv: tensor too large for 32-bit pixel indexing");
 
-    if (a.weight_wino && !a.pre_mish && conv_wino_ok(a.kind, a.H, a.W, a.c0 + a.c1, a.N)) {
+    DDK_REQUIRE(aligned16(a.mish_out) && aligned16(a.dmish_src), "conv: mish_out / dmish_src alignment");
+    DDK_REQUIRE(!(a.mish_out || a.dmish_src) || !(a.defer_reduce || a.gn_partials || fuse || ln),
+                "conv: mish_out / dmish_src go with a plain conv (no deferred reduce, GroupNorm partials or LayerNorm folding)");
+    const bool act_epilogue = a.mish_out || a.dmish_src;     // only the im2col / halo epilogues and the slab reduce implement these
+    if (a.weight_wino && !a.pre_mish && !act_epilogue && conv_wino_ok(a.kind, a.H, a.W, a.c0 + a.c1, a.N)) {
         // Winograd F(2x2, 3x3) path (conv_wino.hip): same slab / reduce conventions as the direct kernels
         DDK_REQUIRE(aligned16(a.weight_wino), "conv: weight_wino alignment");
         DDK_TRY(ensure_device_init());
@@ -1288,12 +1309,12 @@ int conv_forward(const ddk_conv_args& a, hipStream_t st, const ConvLnFold* ln, c
             const long long n4 = slab / 4;
             const int blocks = (int)(ceil_div(n4, 256) < 2048 ? ceil_div(n4, 256) : 2048);
             hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, static_cast<const float*>(a.workspace), ws, slab, a.bias,
-                               a.resid, a.out, n4, a.N, a.post_mish);
+                               a.resid, a.out, n4, a.N, a.post_mish, static_cast<float*>(nullptr), static_cast<const float*>(nullptr));
             DDK_TRY(check_launch("splitk_reduce_kernel"));
         }
         return DDK_OK;
     }
-    if (a.kind == DDK_CONV1X1 && a.c1 == 0 && !ln && !a.pre_mish && !a.post_mish && !a.defer_reduce && !a.gn_partials && !fuse &&
+    if (a.kind == DDK_CONV1X1 && a.c1 == 0 && !ln && !a.pre_mish && !a.post_mish && !a.defer_reduce && !a.gn_partials && !fuse && !act_epilogue &&
         !tuning_flag("DDK_NO_CONV1X1_WS") && conv1x1_ws_ok((long long)a.B * a.H * a.W, a.c0, a.N) &&
         ((long long)a.B * a.H * a.W / 64) * (a.N / 128) >= 256) {
         // 128 input channels on a large map: weights-stationary streaming kernel (conv1x1_ws.hip).  Measured in a cfg4 step
@@ -1317,6 +1338,7 @@ int conv_forward(const ddk_conv_args& a, hipStream_t st, const ConvLnFold* ln, c
     p.pre_mish = a.pre_mish;
     p.debug = tuning_int("DDK_DEBUG", 0);   // diagnostic instantiations of the halo kernel (DDK_TUNING build only)
     p.post_mish = a.post_mish;
+    p.mish_out = a.mish_out; p.dmish_src = a.dmish_src;
     p.slab_stride = (long long)a.B * g.Ho * g.Wo * a.N;
     p.dWm = make_fastdiv_u((unsigned)g.Wm);
     p.dHm = make_fastdiv_u((unsigned)g.Hm);
@@ -1361,7 +1383,7 @@ int conv_forward(const ddk_conv_args& a, hipStream_t st, const ConvLnFold* ln, c
         const long long n4 = p.slab_stride / 4;
         const int blocks = (int)(ceil_div(n4, 256) < 2048 ? ceil_div(n4, 256) : 2048);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, static_cast<const float*>(a.workspace),
-                           c.splits, p.slab_stride, a.bias, a.resid, final_out, n4, p.N, p.post_mish);
+                           c.splits, p.slab_stride, a.bias, a.resid, final_out, n4, p.N, p.post_mish, a.mish_out, a.dmish_src);
         DDK_TRY(check_launch("splitk_reduce_kernel"));
     }
     return DDK_OK;

@@ -65,6 +65,17 @@ __device__ __forceinline__ float mish_f(float x) {
     return x * (n * __frcp_rn(n + 2.0f));
 }
 
+// d/du [u * tanh(softplus(u))]: with e = exp(u), n = e(e+2), t = n/(n+2):  t + u * 4 e (e+1) / (n+2)^2
+// (hardware exp / reciprocal as in mish_f: one v_exp_f32 + one v_rcp_f32 instead of a library exp and two IEEE divides -- this
+// runs per element in conv epilogues (ddk_conv_args.dmish_src) and in the GroupNorm backward)
+__device__ __forceinline__ float mish_grad_f(float u) {
+    if (u > 20.0f) return 1.0f;
+    const float e = __expf(u);
+    const float n = e * (e + 2.0f);
+    const float r = __frcp_rn(n + 2.0f);
+    return n * r + u * (4.0f * e * (e + 1.0f)) * (r * r);
+}
+
 // u / upr for the float4-units-per-pixel count of a GroupNorm group (1, 2, 4 or 8 in every reference configuration): a
 // shift when upr is a power of two -- the integer divide is ~30 VALU ops and these kernels do it per element, per pass.
 __device__ __forceinline__ int div_upr(int u, int upr) {

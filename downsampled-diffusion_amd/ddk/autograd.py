@@ -24,10 +24,11 @@ def _grad_slot(p):
     return None
 
 
-def _conv_backward(kind, x, x2, weight, bias, dy, needs, gb_ready=False):
+def _conv_backward(kind, x, x2, weight, bias, dy, needs, gb_ready=False, dmish_src=None):
     """Shared backward of the conv family.  needs = (x, x2, weight, bias).  Returns (dx, dx2, gw, gb); gw / gb are None
     when they were accumulated straight into ``.grad``.  gb_ready: the bias gradient was already produced elsewhere
-    (by the GroupNorm backward that follows the conv)."""
+    (by the GroupNorm backward that follows the conv).  dmish_src: x is Mish(dmish_src) and dx is wanted with respect to
+    dmish_src -- the input-gradient conv multiplies by Mish' in its epilogue (single-source convs)."""
     need_x, need_x2, need_w, need_b = needs
     c0 = x.shape[-1]
     c1 = 0 if x2 is None else x2.shape[-1]
@@ -67,9 +68,9 @@ def _conv_backward(kind, x, x2, weight, bias, dy, needs, gb_ready=False):
             if kind == ops.CONV3X3_S2:
                 src = ops.zero_stuff2(dy, x.shape[1], x.shape[2])
             # 3x3 input gradients (also the zero-stuffed stride-2 one) run as Winograd F(2x2,3x3) where the shape allows
-            wino = k == ops.CONV3X3_S1
+            wino = k == ops.CONV3X3_S1 and dmish_src is None
             if need_x:
-                dx = ops.conv(k, src, wd[:c0], n_out=c0,
+                dx = ops.conv(k, src, wd[:c0], n_out=c0, dmish_src=dmish_src,
                               w_wino=ops.wino_weight(weight, src.shape, 0, min(c0, weight.shape[1]), dgrad=True) if wino and c0 <= weight.shape[1] else None)
             if need_x2:
                 dx2 = ops.conv(k, src, wd[c0:], n_out=c1, w_wino=ops.wino_weight(weight, src.shape, c0, c0 + c1, dgrad=True) if wino else None)
@@ -106,6 +107,41 @@ class ConvFn(torch.autograd.Function):
 
 def conv(kind, x, weight, bias=None, x2=None, resid=None):
     return ConvFn.apply(kind, x, x2, weight, bias, resid)
+
+
+class PreActConvFn(torch.autograd.Function):
+    """out = conv(Mish(h)) (+ resid) as a function of the PRE-activation h, for chains conv -> Mish -> conv (the dDDPM encoder /
+    decoder blocks, convblocks.py:112-130).  a = Mish(h) is handed in already materialised -- by the producing conv's epilogue
+    (ddk_conv_args.mish_out), which this Function's forward also fills for ITS consumer when want_act -- and the backward's
+    input-gradient conv multiplies by Mish'(h) in its epilogue (ddk_conv_args.dmish_src): no Mish forward / backward launches."""
+
+    @staticmethod
+    def forward(ctx, kind, h, a, weight, bias, resid, want_act):
+        wp = ops.cached_pack("fwd", weight, ops.pack_conv_weight)
+        n = weight.shape[0]
+        a_out = torch.empty((a.shape[0], a.shape[1], a.shape[2], n), device=a.device, dtype=torch.float32) if want_act else None
+        out = ops.conv(kind, a, wp, None if bias is None else bias.detach(), n_out=n, resid=resid, mish_out=a_out)
+        ctx.kind = kind
+        ctx.save_for_backward(h, a, weight, bias)
+        ctx.has_resid = resid is not None
+        if want_act:
+            ctx.mark_non_differentiable(a_out)
+            return out, a_out
+        return out, out.new_empty(0)
+
+    @staticmethod
+    def backward(ctx, dy, _unused):
+        h, a, weight, bias = ctx.saved_tensors
+        dy = _c(dy)
+        need = ctx.needs_input_grad
+        dh, _, gw, gb = _conv_backward(ctx.kind, a, None, weight, bias, dy, (need[1], False, need[3], need[4]), dmish_src=h)
+        return None, dh, None, gw, gb, (dy if ctx.has_resid else None), None
+
+
+def preact_conv(kind, h, a, weight, bias=None, resid=None, want_act=True):
+    """-> (out, Mish(out) or None); see PreActConvFn"""
+    out, a_out = PreActConvFn.apply(kind, h, a, weight, bias, resid, want_act)
+    return out, (a_out if want_act else None)
 
 
 class GNMishFn(torch.autograd.Function):

@@ -23,7 +23,7 @@ class ConvArgs(C.Structure):
         ("weight", C.c_void_p), ("bias", C.c_void_p), ("resid", C.c_void_p), ("out", C.c_void_p),
         ("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("N", C.c_int), ("pre_mish", C.c_int), ("post_mish", C.c_int), ("defer_reduce", C.c_int),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("weight_wino", C.c_void_p),
-        ("gn_partials", C.c_void_p), ("gn_groups", C.c_int),
+        ("gn_partials", C.c_void_p), ("gn_groups", C.c_int), ("mish_out", C.c_void_p), ("dmish_src", C.c_void_p),
     ]
 
 

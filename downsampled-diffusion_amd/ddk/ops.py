@@ -149,9 +149,11 @@ def wino_weight(weight, x_shape, c_lo=None, c_hi=None, dgrad=False):
 
 
 # ------------------------------------------------------------------ conv family
-def conv(kind, x, w_packed, bias=None, n_out=None, x2=None, resid=None, pre_mish=False, post_mish=False, w_wino=None):
+def conv(kind, x, w_packed, bias=None, n_out=None, x2=None, resid=None, pre_mish=False, post_mish=False, w_wino=None, mish_out=None,
+         dmish_src=None):
     """Implicit-GEMM conv on NHWC x (optionally channel-concatenated with x2 without materialising it).
-    w_wino: the same 3x3 filter in the Winograd domain -> the F(2x2,3x3) kernel runs when the shape is eligible."""
+    w_wino: the same 3x3 filter in the Winograd domain -> the F(2x2,3x3) kernel runs when the shape is eligible.
+    mish_out: tensor that also receives Mish(out); dmish_src: out = (conv + bias) * Mish'(dmish_src) (+ resid) (ddk_conv_args)."""
     b, h, w_, c0 = x.shape
     c1 = 0 if x2 is None else x2.shape[-1]
     n = n_out if n_out is not None else (w_packed.shape[1] if kind == CONVT4X4_S2 else w_packed.shape[0])
@@ -166,13 +168,16 @@ def conv(kind, x, w_packed, bias=None, n_out=None, x2=None, resid=None, pre_mish
     out = torch.empty((b, ho, wo, n), device=x.device, dtype=torch.float32)
     lib = L.load()
     ws_bytes = lib.ddk_conv_workspace_bytes(kind, b, h, w_, c0 + c1, n)
+    if mish_out is not None or dmish_src is not None:
+        w_wino = None                                   # these epilogues live on the im2col kernels
     if w_wino is not None and kind == CONV3X3_S1 and not pre_mish:
         wsplits = lib.ddk_conv_wino_splits(b, h, w_, c0 + c1, n)
         if wsplits > 0:
             ws_bytes = wsplits * out.numel() * 4 if wsplits > 1 else 0
     ws = torch.empty(max(ws_bytes, 16) // 4, device=x.device, dtype=torch.float32) if ws_bytes else None
     a = L.ConvArgs(kind, L.ptr(_f32(x)), L.ptr(x2), c0, c1, L.ptr(w_packed), L.ptr(bias), L.ptr(resid), L.ptr(out),
-                   b, h, w_, n, int(pre_mish), int(post_mish), 0, L.ptr(ws), ws_bytes, L.ptr(w_wino))
+                   b, h, w_, n, int(pre_mish), int(post_mish), 0, L.ptr(ws), ws_bytes, L.ptr(w_wino), None, 0, L.ptr(mish_out),
+                   L.ptr(dmish_src))
     L.check(lib.ddk_conv_forward(C.byref(a), L.stream()), "conv_forward")
     return out
 

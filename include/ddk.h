@@ -87,6 +87,10 @@ typedef struct ddk_conv_args {
                           * (128-pixel tile, GroupNorm group), {mean, M2} of its output: B*H*W/128 * gn_groups float pairs, which
                           * ddk_groupnorm_mish_partials turns into GroupNorm+Mish with one read and one write of the tensor */
     int gn_groups;
+    float* mish_out;     /* optional: the launch also writes Mish(out) here (same shape as out): the next conv's input activation,
+                          * while `out` keeps the pre-activation its backward needs (training path of convblocks.py:112-130) */
+    const float* dmish_src; /* optional [B][Ho][Wo][N]: out = (conv + bias) * Mish'(dmish_src) (+ resid): an input-gradient conv that
+                             * hands back the gradient of the PRE-activation (replaces a separate Mish-backward launch) */
 } ddk_conv_args;
 
 /* Conv2d 3x3 weight OIHW -> Winograd-domain filter U = G g G^T, [I_pad/32][16 positions][O][32] (blocks.py:78). */

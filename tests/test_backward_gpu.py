@@ -90,6 +90,36 @@ def test_conv_backward_accumulates_into_existing_grads(AG):
     assert rel_err(wd.grad.cpu(), 1 + 2 * gw) < 3e-5 and rel_err(bd.grad.cpu(), 2 + 2 * gb) < 3e-5
 
 
+@pytest.mark.parametrize("B,H,W,C,M", [(2, 16, 16, 64, 32), (3, 8, 12, 32, 32), (1, 64, 64, 64, 32), (64, 4, 4, 128, 64)])
+def test_preact_conv_chain(AG, B, H, W, C, M):
+    """conv1x1(mish(x)) -> conv3x3(mish(.)) -> conv1x1(mish(.)) + x with the Mish forward written by the producing conv's epilogue
+    (ddk_conv_args.mish_out) and Mish' applied by the input-gradient convs (dmish_src) == torch autograd of the same chain
+    (the dDDPM encoder / decoder block, convblocks.py:112-130)"""
+    from ddk import ops
+    x = rnd(B, C, H, W, seed=41)
+    w1, b1 = rnd(M, C, 1, 1, seed=42, scale=C ** -0.5), rnd(M, seed=43, scale=0.1)
+    w2, b2 = rnd(M, M, 3, 3, seed=44, scale=(9 * M) ** -0.5), rnd(M, seed=45, scale=0.1)
+    w3, b3 = rnd(C, M, 1, 1, seed=46, scale=M ** -0.5), rnd(C, seed=47, scale=0.1)
+
+    def ref(xx, a1, c1, a2, c2, a3, c3):
+        h = F.conv2d(F.mish(xx), a1, c1)
+        h = F.conv2d(F.mish(h), a2, c2, padding=1)
+        return F.conv2d(F.mish(h), a3, c3) + xx
+    out_ref, g, grads = grads_cpu(ref, x, w1, b1, w2, b2, w3, b3)
+    xd = to_nhwc(x).to(DEV).requires_grad_(True)
+    ps = [t.to(DEV).requires_grad_(True) for t in (w1, b1, w2, b2, w3, b3)]
+    a = ops.mish(xd.detach())
+    h, a = AG.preact_conv(ops.CONV1X1, xd, a, ps[0], ps[1])
+    assert rel_err(a.cpu(), F.mish(h.detach().cpu())) < 5e-6
+    h, a = AG.preact_conv(ops.CONV3X3_S1, h, a, ps[2], ps[3])
+    out, none = AG.preact_conv(ops.CONV1X1, h, a, ps[4], ps[5], resid=xd, want_act=False)
+    assert none is None and rel_err(to_nchw(out.detach().cpu()), out_ref) < 2e-5
+    out.backward(to_nhwc(g).to(DEV))
+    assert rel_err(xd.grad.cpu(), to_nhwc(grads[0])) < 3e-5
+    for got, want in zip(ps, grads[1:]):
+        assert rel_err(got.grad.cpu(), want) < 3e-5
+
+
 def test_conv_backward_padded_input_and_residual(AG):
     """first UNet conv: 8 real channels inside a 32-channel padded tensor; to_out-style fused residual"""
     from ddk import ops
