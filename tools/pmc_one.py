@@ -3,7 +3,8 @@
 (`rocprofv3 --kernel-trace --pmc ... -- python3 tools/pmc_one.py <case>`; counters and --stats in separate passes).
 cases: wino (conv3x3 128->128 @32x32 B=32, Winograd), gn (GroupNorm-apply from partials, 32x32x32x128), local4 (conv+GroupNorm+Mish
 one launch, 256->256 @4x4), wlocal8 (the same @8x8, Winograd form), first (conv_first 8->128 @32x32), tail (final_tail_kernel),
-cluster16 (conv3x3 256->256 @16x16 with GroupNorm finished in the launch)."""
+cluster16 (conv3x3 256->256 @16x16 with GroupNorm finished in the launch), ws (to_out 1x1 128->128 + bias + residual @32x32,
+weights-stationary kernel)."""
 import os
 import sys
 
@@ -53,6 +54,10 @@ elif case == "tail":
     t = torch.full((B,), 500, device=dev, dtype=torch.long)
     tab = {k: torch.rand(1000, device=dev) for k in ("c_recip", "c_recipm1", "c1", "c2", "sigma")}
     fn = lambda: ops.final_tail(raw, part, tiles, gam, bet, wo, bo, x=xs, t=t, tables=tab, seed=3, want_eps=False)
+elif case == "ws":
+    x, w = torch.randn(B, 32, 32, 128, device=dev), torch.randn(128, 128, device=dev) * 128 ** -0.5
+    b, r = torch.zeros(128, device=dev), torch.randn(B, 32, 32, 128, device=dev)
+    fn = lambda: ops.conv1x1_ws(x, w, b, r)
 elif case == "cluster16":
     x, w = torch.randn(B, 16, 16, 256, device=dev), rw(256, 256)
     wu, b = ops.pack_conv_weight_wino(w), torch.zeros(256, device=dev)
