@@ -40,7 +40,7 @@ int ensure_device_init() {
 }
 }  // namespace ddk
 
-extern "C" int ddk_version(void) { return 200; }  // 0.2.0
+extern "C" int ddk_version(void) { return 300; }  // 0.3.0: ddk_conv_args grew mish_out / dmish_src
 
 extern "C" const char* ddk_last_error(void) { return ddk::g_err; }
 

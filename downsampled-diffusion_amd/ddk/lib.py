@@ -17,6 +17,9 @@ class DDKError(RuntimeError):
     pass
 
 
+ABI_VERSION = 300   # ddk_version(): 0.3.0 -- ddk_conv_args grew mish_out / dmish_src
+
+
 class ConvArgs(C.Structure):
     _fields_ = [
         ("kind", C.c_int), ("src0", C.c_void_p), ("src1", C.c_void_p), ("c0", C.c_int), ("c1", C.c_int),
@@ -169,6 +172,9 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the .so is stale
         fn.restype = res
         fn.argtypes = args
+    if lib.ddk_version() != ABI_VERSION:   # the argument structs (ddk_conv_args) are laid out per ABI version
+        raise DDKError(f"{LIB_PATH} has ABI version {lib.ddk_version()}, this Python layer needs {ABI_VERSION}: rebuild it "
+                       f"(`make -C {os.path.dirname(LIB_PATH)}`)")
     _lib = lib
     return lib
 

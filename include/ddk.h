@@ -33,7 +33,7 @@ typedef void* ddk_stream_t; /* hipStream_t */
 #define DDK_ERR_HIP (-2)     /* a HIP runtime call failed */
 #define DDK_ERR_WORKSPACE (-3)
 
-int ddk_version(void);
+int ddk_version(void);   /* 300 = 0.3.0; bumped whenever an argument struct changes layout */
 const char* ddk_last_error(void);
 /* 1 when a gfx950 device is visible to this process. */
 int ddk_device_ok(void);
