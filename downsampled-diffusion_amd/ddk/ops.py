@@ -682,7 +682,10 @@ def linattn_train(qkv, heads=4):
     out, ctx = linattn(qkv, heads)
     b, h, w, _ = qkv.shape
     stats = torch.empty((b, heads, 2, 32), device=qkv.device, dtype=torch.float32)
-    L.check(L.load().ddk_linattn_stats(L.ptr(qkv), L.ptr(stats), b, h * w, heads, L.stream()), "linattn_stats")
+    lib = L.load()
+    nbytes = lib.ddk_linattn_train_workspace_bytes(b, h * w, heads)
+    ws = _ws(qkv.device, nbytes, "linattn_train") if nbytes else None
+    L.check(lib.ddk_linattn_stats(L.ptr(qkv), L.ptr(stats), b, h * w, heads, L.ptr(ws), nbytes, L.stream()), "linattn_stats")
     return out, ctx, stats
 
 
@@ -690,8 +693,11 @@ def linattn_bwd(qkv, dout, ctx, stats, heads=4):
     b, h, w, _ = qkv.shape
     dctx = torch.empty_like(ctx)
     dqkv = torch.empty_like(qkv)
-    L.check(L.load().ddk_linattn_bwd(L.ptr(qkv), L.ptr(_f32(dout)), L.ptr(ctx), L.ptr(stats), L.ptr(dctx), L.ptr(dqkv), b, h * w,
-                                     heads, L.stream()), "linattn_bwd")
+    lib = L.load()
+    nbytes = lib.ddk_linattn_train_workspace_bytes(b, h * w, heads)
+    ws = _ws(qkv.device, nbytes, "linattn_train") if nbytes else None
+    L.check(lib.ddk_linattn_bwd(L.ptr(qkv), L.ptr(_f32(dout)), L.ptr(ctx), L.ptr(stats), L.ptr(dctx), L.ptr(dqkv), b, h * w,
+                                heads, L.ptr(ws), nbytes, L.stream()), "linattn_bwd")
     return dqkv
 
 

@@ -390,9 +390,12 @@ int ddk_rows_sum_targets(const float* rows, int nbatch, long long batch_stride, 
                          float* out2, float* out3, int n, int accumulate, ddk_stream_t s);
 int ddk_chan_layernorm_bwd(const float* x, const float* g, const float* dy, float* dx, float* part, int max_parts,
                            int* nparts_out, long long M, int C, float eps, ddk_stream_t s);
-int ddk_linattn_stats(const float* qkv, float* stats, int B, int HW, int heads, ddk_stream_t s);
+/* training-path linear attention: softmax statistics of k (column max, sum of exp) and the backward.  Their reductions over the
+ * pixels are split over workgroups on large maps; `workspace` holds the partials (ddk_linattn_train_workspace_bytes, may be 0). */
+size_t ddk_linattn_train_workspace_bytes(int B, int HW, int heads);
+int ddk_linattn_stats(const float* qkv, float* stats, int B, int HW, int heads, void* workspace, size_t workspace_bytes, ddk_stream_t s);
 int ddk_linattn_bwd(const float* qkv, const float* dout, const float* ctx, const float* stats, float* dctx,
-                    float* dqkv, int B, int HW, int heads, ddk_stream_t s);
+                    float* dqkv, int B, int HW, int heads, void* workspace, size_t workspace_bytes, ddk_stream_t s);
 int ddk_mish_bwd(const float* x, const float* dy, float* dx, long long n, ddk_stream_t s);
 int ddk_tanh_bwd(const float* y, const float* dy, float* dx, long long n, ddk_stream_t s);
 int ddk_avgpool2_bwd(const float* dy, float* dx, int B, int H, int W, int C, ddk_stream_t s);

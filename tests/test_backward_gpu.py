@@ -204,7 +204,8 @@ def test_chan_layernorm_backward(AG, C):
     assert rel_err(gd.grad.cpu(), gg) < 3e-5 and rel_err(bd.grad.cpu(), gb) < 3e-5
 
 
-@pytest.mark.parametrize("B,H,W", [(2, 4, 4), (3, 8, 8), (2, 16, 16), (1, 10, 13)])
+@pytest.mark.parametrize("B,H,W", [(2, 4, 4), (3, 8, 8), (2, 16, 16), (1, 10, 13),
+                                   (1, 64, 64), (2, 48, 40), (1, 128, 96)])     # pixel-split statistics / dctx (16, 7 ragged, 48 splits)
 def test_linattn_backward(AG, B, H, W):
     qkv = rnd(B, 384, H, W, seed=40, scale=1.2)
 
