@@ -40,6 +40,16 @@ def run(name, model, B, steps=100):
 
 
 if __name__ == "__main__":
+    only = sys.argv[1] if len(sys.argv) > 1 else None     # e.g. "cfg5": that configuration alone (for a rocprofv3 --stats run)
+    if only == "cfg5":
+        c = cfg(3, 256); run("cfg5-shape DDPM 256x256 bs8      ", DDPM(c, Unet(c), DEV, 3), 8, steps=20)
+        sys.exit(0)
+    if only == "cfg2":
+        c = cfg(3, 32); run("cfg2 CIFAR-10 DDPM 32x32 bs64   ", DDPM(c, Unet(c), DEV, 3), 64)
+        sys.exit(0)
+    if only == "cfg3":
+        c = cfg(8, 64, down=2); run("cfg3 CelebA-64 dDDPM-x2 bs64     ", DownsampleDDPM(c, Unet(c), DEV, 3), 64)
+        sys.exit(0)
     c = cfg(1, 32, T=200); run("cfg1 MNIST DDPM 32x32 bs16      ", DDPM(c, Unet(c), DEV, 1), 16)
     c = cfg(3, 32); run("cfg2 CIFAR-10 DDPM 32x32 bs64   ", DDPM(c, Unet(c), DEV, 3), 64)
     c = cfg(8, 64, down=2); run("cfg3 CelebA-64 dDDPM-x2 bs64     ", DownsampleDDPM(c, Unet(c), DEV, 3), 64)
