@@ -528,6 +528,8 @@ struct Ctx {
     const float* temb;            // [B][temb_total], or the sampler's per-timestep table [t_start+1][temb_total]
     const long long* temb_rows;   // nullptr: row b;  sampler: row = t_cur[b] (device), so one table serves every step
     int n_cluster = 0;            // cluster launches issued so far in this forward
+    const float* x_first = nullptr;   // the network input, unpadded, and its padded copy: the first conv may take the small-C_in
+    const float* x_padded = nullptr;  // kernel on maps the one-launch first block does not cover (run_conv_gn)
 };
 
 static int run_conv(Ctx& c, int kind, const ConvW& cw, const float* src0, int c0, const float* src1, int c1, const float* resid,
@@ -568,6 +570,15 @@ static int run_conv_gn(Ctx& c, const ConvW& cw, const float* src0, int c0, const
         return conv_gn_wlocal(src0, c0, src1, c1, c.P + cw.wwl, cw.has_bias ? c.P + cw.b : nullptr, c.P + n.g, c.P + n.b, temb,
                               c.u.temb_total, c.temb_rows, addend, out, c.B, H, W, N, GROUPS, GN_EPS, c.st, as);
     if (as.n > 1) return fail_arg("run_conv_gn: slab addend on a path that cannot sum it");
+    if (cw.has_wf && c.x_first && src0 == c.x_padded && !src1 && conv_first_ok(c.u.cfg.in_ch, N, H, W, GROUPS)) {
+        // the network's first conv on a map too large for the one-launch first block (256x256: 512 statistics tiles per image):
+        // still the K = 9 C_in kernel on the unpadded input instead of a 32-channel im2col conv (724 -> ~70 us at 8 x 256 x 256),
+        // followed by the generic GroupNorm
+        DDK_TRY(conv_first(c.x_first, c.P + cw.wf, cw.has_bias ? c.P + cw.b : nullptr, raw, nullptr, c.B, H, W, c.u.cfg.in_ch, N, GROUPS,
+                           nullptr, nullptr, c.st));
+        return groupnorm_mish(raw, c.P + n.g, c.P + n.b, temb, c.u.temb_total, addend, out, c.B, H * W, N, GROUPS, GN_EPS,
+                              c.W + c.ly.off_gn, c.ly.gn_ws * sizeof(float), c.st, c.temb_rows);
+    }
     if (c.u.cluster_gn && cw.has_wu && conv_wino_cluster_np(c.B, H, W, c0 + c1, N, GROUPS) > 0 && c.n_cluster++ < c.u.cluster_limit) {
         // one launch: the workgroups of an image exchange their tile statistics and normalise their own tile in registers
         ddk_conv_args a{};
@@ -771,6 +782,7 @@ static int forward_core(const ddk_unet& u, const float* P, const float* x, int64
     }
     static_assert(sizeof(long long) == sizeof(int64_t), "timestep rows are read as long long");
     Ctx c{u, P, ws, ly, B, st, temb_table ? temb_table : temb, temb_table ? reinterpret_cast<const long long*>(t) : nullptr};
+    if (!fast0) { c.x_first = x; c.x_padded = xpad; }
     float* bufA = ws + ly.off_A;
     float* bufB = ws + ly.off_B;
     float* bufC = ws + ly.off_C;
