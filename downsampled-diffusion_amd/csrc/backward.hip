@@ -810,16 +810,20 @@ __global__ __launch_bounds__(256) void conv1x1_small_n_bwd_kernel(const float* _
 // through LDS (coalesced loads for every mode), each of the 256 threads owns a 1x4 strip.
 //   mode 0: C[M][N]  = A[M][K]   B[K][N]            mode 1: C[M][N] = A[M][K] B[N][K]^T
 //   mode 2: C[M][N] (+)= A[K][M]^T B[K][N]   (accumulating, for weight gradients)
+// gridDim.z > 1: the contraction is split, workgroup z takes k in [z * kper, (z + 1) * kper) and writes its partial tile to slab z
+// of Cm ([z][M][ldc], not accumulating); the host sums the slabs in order (a long-K product on a 2 x 16 grid of tiles took 380 us).
 __global__ __launch_bounds__(256) void small_gemm_kernel(int mode, const float* __restrict__ A, const float* __restrict__ Bm,
                                                          float* __restrict__ Cm, int M, int N, int K, int lda, int ldb, int ldc,
-                                                         int accumulate) {
+                                                         int accumulate, int kper) {
     __shared__ float As[32][33];   // [k][m]
     __shared__ float Bs[32][33];   // [k][n]
     const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+    const int k_lo = blockIdx.z * kper;
+    if (gridDim.z > 1) { Cm += (long long)blockIdx.z * M * ldc; K = min(K, k_lo + kper); }
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // ty: 0..7
     const int mrow = threadIdx.x >> 3, nq = (threadIdx.x & 7) * 4;   // output strip: row mrow, columns nq..nq+3
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int k0 = 0; k0 < K; k0 += 32) {
+    for (int k0 = k_lo; k0 < K; k0 += 32) {
         // stage A as [k][m] and B as [k][n]; the fast thread index follows the operand's contiguous dimension
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -1225,12 +1229,36 @@ int ddk_conv1x1_small_n_bwd(const float* a, const float* w, const float* dy, flo
 }
 
 /* C = op(A) op(B) for the tiny time-embedding matrices; see small_gemm_kernel for the modes */
+static int small_gemm_splits(int M, int N, int K, int ldc) {
+    const long long tiles = ceil_div(N, 32) * ceil_div(M, 32);
+    if (ldc != N || tiles >= 128 || K < 1024) return 1;
+    long long s = ceil_div(256, tiles);
+    if (s > K / 256) s = K / 256;
+    return (int)(s < 1 ? 1 : (s > 64 ? 64 : s));
+}
+size_t ddk_small_gemm_workspace_bytes(int M, int N, int K, int ldc) {
+    const int sp = small_gemm_splits(M, N, K, ldc);
+    return sp > 1 ? (size_t)sp * M * N * sizeof(float) : 0;
+}
 int ddk_small_gemm(int mode, const float* A, const float* Bm, float* Cm, int M, int N, int K, int lda, int ldb, int ldc, int accumulate,
-                   ddk_stream_t s) {
+                   void* workspace, size_t workspace_bytes, ddk_stream_t s) {
     DDK_REQUIRE(A && Bm && Cm && M > 0 && N > 0 && K > 0 && mode >= 0 && mode <= 2, "small_gemm: arguments");
-    hipLaunchKernelGGL(small_gemm_kernel, dim3((unsigned)ceil_div(N, 32), (unsigned)ceil_div(M, 32)), dim3(256), 0, as_stream(s), mode, A,
-                       Bm, Cm, M, N, K, lda, ldb, ldc, accumulate);
-    return check_launch("small_gemm_kernel");
+    const int sp = small_gemm_splits(M, N, K, ldc);
+    if (sp == 1 || !workspace || workspace_bytes < (size_t)sp * M * N * sizeof(float)) {
+        hipLaunchKernelGGL(small_gemm_kernel, dim3((unsigned)ceil_div(N, 32), (unsigned)ceil_div(M, 32), 1), dim3(256), 0, as_stream(s), mode,
+                           A, Bm, Cm, M, N, K, lda, ldb, ldc, accumulate, K);
+        return check_launch("small_gemm_kernel");
+    }
+    const int kper = (int)(ceil_div(ceil_div(K, sp), 32) * 32);
+    const int zs = (int)ceil_div(K, kper);
+    float* part = static_cast<float*>(workspace);
+    hipLaunchKernelGGL(small_gemm_kernel, dim3((unsigned)ceil_div(N, 32), (unsigned)ceil_div(M, 32), (unsigned)zs), dim3(256), 0, as_stream(s),
+                       mode, A, Bm, part, M, N, K, lda, ldb, N, 0, kper);
+    DDK_TRY(check_launch("small_gemm_kernel"));
+    const int n = M * N;
+    hipLaunchKernelGGL(rows_sum_kernel, dim3((unsigned)ceil_div(n, 64), 1), dim3(256), 0, as_stream(s), static_cast<const float*>(part), zs,
+                       (long long)n, 0LL, Cm, n, accumulate);
+    return check_launch("rows_sum_kernel");
 }
 int ddk_sincos_embed(const int64_t* t, const float* freqs, float* e, int B, int dim, ddk_stream_t s) {
     DDK_REQUIRE(t && freqs && e && B > 0 && dim > 0 && dim % 2 == 0, "sincos_embed: arguments");

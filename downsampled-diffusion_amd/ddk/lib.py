@@ -148,7 +148,8 @@ SIGNATURES = {
     "ddk_sq_err_grad": (_I, [_P, _P, _P, _P, _I, _LL, _P]),
     "ddk_scale_per_sample": (_I, [_P, _P, _P, _I, _LL, _P]),
     "ddk_conv1x1_small_n_bwd": (_I, [_P, _P, _P, _P, _P, _I, C.POINTER(C.c_int), _LL, _I, _I, _P]),
-    "ddk_small_gemm": (_I, [_I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "ddk_small_gemm_workspace_bytes": (_SZ, [_I, _I, _I, _I]),
+    "ddk_small_gemm": (_I, [_I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _SZ, _P]),
     "ddk_sincos_embed": (_I, [_P, _P, _P, _I, _I, _P]),
     "ddk_bias_act": (_I, [_P, _P, _P, _LL, _I, _P]),
     "ddk_grad_norm_clip": (_I, [_P, _LL, _F, _P, _P, _SZ, _P]),

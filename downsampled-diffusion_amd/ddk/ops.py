@@ -760,8 +760,11 @@ def conv1x1_small_n_bwd(a, w, dy):
 
 
 def small_gemm(mode, a, b, out, m, n, k, lda, ldb, ldc, accumulate=False):
-    L.check(L.load().ddk_small_gemm(mode, a.data_ptr(), b.data_ptr(), out.data_ptr(), m, n, k, lda, ldb, ldc, int(accumulate), L.stream()),
-            "small_gemm")
+    lib = L.load()
+    nbytes = lib.ddk_small_gemm_workspace_bytes(m, n, k, ldc)
+    ws = _ws(out.device, nbytes, "small_gemm") if nbytes else None
+    L.check(lib.ddk_small_gemm(mode, a.data_ptr(), b.data_ptr(), out.data_ptr(), m, n, k, lda, ldb, ldc, int(accumulate), L.ptr(ws), nbytes,
+                               L.stream()), "small_gemm")
     return out
 
 

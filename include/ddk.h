@@ -405,8 +405,10 @@ int ddk_sq_err_grad(const float* a, const float* b, const float* scale, float* o
 int ddk_scale_per_sample(const float* x, const float* scale, float* out, int B, long long per, ddk_stream_t s);
 int ddk_conv1x1_small_n_bwd(const float* a, const float* w, const float* dy, float* da, float* part, int max_rows,
                             int* nrows_out, long long M, int C, int n_out, ddk_stream_t s);
-int ddk_small_gemm(int mode, const float* A, const float* Bm, float* Cm, int M, int N, int K, int lda, int ldb,
-                   int ldc, int accumulate, ddk_stream_t s);
+/* workspace of ddk_small_gemm when it splits a long contraction over workgroups (0: it does not) */
+size_t ddk_small_gemm_workspace_bytes(int M, int N, int K, int ldc);
+int ddk_small_gemm(int mode, const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
+                   int accumulate, void* workspace, size_t workspace_bytes, ddk_stream_t s);
 int ddk_sincos_embed(const int64_t* t, const float* freqs, float* e, int B, int dim, ddk_stream_t s);
 int ddk_bias_act(float* y, const float* bias, float* act, long long M, int N, ddk_stream_t s);
 /* optimiser on flat fp32 buffers (trainer_ddpm.py:142-148, trainers/ema.py:36-44) */

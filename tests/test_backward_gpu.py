@@ -241,6 +241,26 @@ def test_small_n_conv_and_elementwise_backward(AG):
         assert rel_err(xd.grad.cpu(), to_nhwc(gx)) < 1e-5
 
 
+@pytest.mark.parametrize("mode,M,N,K", [(0, 64, 128, 4096), (0, 64, 512, 4736), (1, 64, 96, 2048), (0, 8, 32, 1000), (2, 96, 64, 64)])
+def test_small_gemm_long_contraction(mode, M, N, K):
+    """the time-embedding products: C = A B / A B^T / A^T B; a long contraction on few tiles is split over workgroups with a
+    fixed-order sum (dact = dout Wcat has K = all block channels, ~5000)"""
+    from ddk import ops
+    a = rnd(K, M, seed=51) if mode == 2 else rnd(M, K, seed=51)
+    b = rnd(N, K, seed=52) if mode == 1 else rnd(K, N, seed=52)
+    ref = (a.t().double() @ b.double()) if mode == 2 else (a.double() @ (b.t().double() if mode == 1 else b.double()))
+    ad, bd = a.to(DEV), b.to(DEV)
+    out = torch.empty(M, N, device=DEV)
+    ops.small_gemm(mode, ad, bd, out, M, N, K, ad.shape[1], bd.shape[1], N)
+    assert rel_err(out.cpu().double(), ref) < 1e-5
+    out2 = torch.empty(M, N, device=DEV)
+    ops.small_gemm(mode, ad, bd, out2, M, N, K, ad.shape[1], bd.shape[1], N)
+    assert torch.equal(out, out2)
+    acc = torch.ones(M, N, device=DEV)
+    ops.small_gemm(mode, ad, bd, acc, M, N, K, ad.shape[1], bd.shape[1], N, accumulate=True)
+    assert rel_err(acc.cpu().double(), ref + 1) < 1e-5
+
+
 def test_time_embedding_backward(AG):
     from ddk.plan import sinusoidal_freqs
     dim, B = 32, 5
