@@ -45,6 +45,7 @@ struct LocalParams {
     int addend_slabs;            // > 1: `addend` is still in split-K form: that many slabs, `addend_stride` floats apart, summed in
     long long addend_stride;     // order, plus addend_bias[c] (the skip conv's reduce pass folded into this load)
     const float* addend_bias;
+    int ipb;                     // images per 16-row block: 1 (4x4 maps) or 4 (2x2 maps: four 4-pixel images share an M block)
 };
 
 constexpr int LOC_PP = 36;   // pitch (floats) of a partial-accumulator row: 4 rows apart = 16 banks apart
@@ -92,7 +93,7 @@ __device__ __forceinline__ TailPre<NV> tail_prefetch(const long long (&o)[NV], i
 
 template <int NV, typename P>
 __device__ __forceinline__ void gn_mish_tail(const float (&v)[NV], const long long (&o)[NV], int col, int c, int b, int hw, int lane, int wave,
-                                             float* red, const P& p, const TailPre<NV>& pre) {
+                                             float* red, const P& p, const TailPre<NV>& pre, int ipb = 1) {
     const int gl = col / p.cpg;                 // group within the tile: 0 .. 32/cpg - 1
     // Sum over the lanes of the group (cpg consecutive columns, both 32-lane halves), then over the 8 waves through `rd` (two
     // disjoint regions for the two passes, so one barrier per pass).  Inside a 16-lane row the tree runs on DPP (quad permutes,
@@ -110,6 +111,7 @@ __device__ __forceinline__ void gn_mish_tail(const float (&v)[NV], const long lo
         s += __shfl_xor(s, 32, 64);
         if ((lane & 32) == 0 && (col & (p.cpg - 1)) == 0) rd[wave * 4 + gl] = s;
         __syncthreads();
+        if (ipb == 4) return rd[(wave & ~1) * 4 + gl] + rd[(wave | 1) * 4 + gl];   // 4 images x 4 rows: an image = 2 waves' rows
         float t = rd[gl];
 #pragma unroll
         for (int w = 1; w < 8; ++w) t += rd[w * 4 + gl];
@@ -177,9 +179,10 @@ __global__ __launch_bounds__(512) void conv3x3_gn_local_kernel(const LocalParams
     long long o_t[MB];
 #pragma unroll
     for (int i = 0; i < MB; ++i) o_t[i] = ((long long)b * MT + row + 16 * i) * p.N + c;
-    const TailPre<MB> pre = tail_prefetch<MB>(o_t, c, b, p);
+    const int hwi = MT / p.ipb;                                  // pixels per image (ipb > 1 only with MT == 16)
+    const TailPre<MB> pre = tail_prefetch<MB>(o_t, c, b * p.ipb + row / hwi, p);
 
-    // ---- the image: [MT rows][cin] into LDS, row MT = zeros
+    // ---- the image(s): [MT rows][cin] into LDS, row MT = zeros
     {
         const int q4 = cin >> 2;
         const long long row0 = (long long)b * MT;
@@ -197,12 +200,14 @@ __global__ __launch_bounds__(512) void conv3x3_gn_local_kernel(const LocalParams
     f32x4 acc[MB][2];
 #pragma unroll
     for (int i = 0; i < MB; ++i) acc[i][0] = acc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-    int py[MB], px[MB];
+    int py[MB], px[MB], pbase[MB];
 #pragma unroll
     for (int i = 0; i < MB; ++i) {
         const int r = i * 16 + m;
-        py[i] = r / p.W;
-        px[i] = r - py[i] * p.W;
+        pbase[i] = (r / hwi) * hwi;                              // first row of this pixel's image inside the block
+        const int pr = r - pbase[i];
+        py[i] = pr / p.W;
+        px[i] = pr - py[i] * p.W;
     }
     int ctap = 0, cchunk = wave;      // (tap, chunk) of the next unit to COMPUTE
     norm(ctap, cchunk);
@@ -214,7 +219,7 @@ __global__ __launch_bounds__(512) void conv3x3_gn_local_kernel(const LocalParams
         for (int i = 0; i < MB; ++i) {
             const int yy = py[i] + dy, xx = px[i] + dx;
             const bool ok = (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
-            const int srow = ok ? yy * p.W + xx : MT;
+            const int srow = ok ? pbase[i] + yy * p.W + xx : MT;
             const float* ap = lds + srow * pitch + (cchunk << 5) + kq * 8;
             a[i][0] = *reinterpret_cast<const float4*>(ap);
             a[i][1] = *reinterpret_cast<const float4*>(ap + 4);
@@ -264,7 +269,7 @@ __global__ __launch_bounds__(512) void conv3x3_gn_local_kernel(const LocalParams
         v[i] = s + cb;
     }
 
-    gn_mish_tail<MB>(v, o_t, col, c, b, MT, lane, wave, red, p, pre);
+    gn_mish_tail<MB>(v, o_t, col, c, b, hwi, lane, wave, red, p, pre, p.ipb);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -577,11 +582,11 @@ int conv_gn_wlocal(const float* src0, int c0, const float* src1, int c1, const f
 
 bool conv_gn_local_ok(int H, int W, int cin, int c0, int N, int groups) {
     const int HW = H * W;
-    if (HW != 16 && HW != 64) return false;
+    if (HW != 16 && HW != 64 && !(H == 2 && W == 2)) return false;      // 2x2: four images per 16-row block (needs B % 4 == 0)
     if (cin % 32 || c0 % 4 || (cin - c0) % 4 || N % 32 || N % groups) return false;
     const int cpg = N / groups;
     if (cpg != 8 && cpg != 16 && cpg != 32) return false;
-    return local_lds_bytes(HW, cin) <= 160 * 1024;
+    return local_lds_bytes(HW < 16 ? 16 : HW, cin) <= 160 * 1024;
 }
 
 int conv_gn_local_init_device() {
@@ -605,12 +610,14 @@ int conv_gn_local(const float* src0, int c0, const float* src1, int c1, const fl
                 "cin % 32 == 0, N % 32 == 0, channels per group in {8, 16, 32})");
     DDK_REQUIRE(aligned16(src0) && aligned16(src1) && aligned16(w), "conv_gn_local: sources and weights must be 16-byte aligned");
     DDK_TRY(ensure_device_init());
-    LocalParams p{src0, src1, c0, c1, w, bias, gamma, beta, temb, temb_stride, temb_rows, addend, out, H, W, N, N / groups, eps,
-                  as.n, as.stride, as.bias};
     const int HW = H * W;
-    const size_t ldsb = local_lds_bytes(HW, c0 + c1);
-    const dim3 grid((unsigned)((long long)B * (N / 32)));
-    if (HW == 16)
+    const int ipb = HW == 4 ? 4 : 1;
+    DDK_REQUIRE(B % ipb == 0, "conv_gn_local: 2x2 maps need a batch that is a multiple of 4 (four images share an M block)");
+    LocalParams p{src0, src1, c0, c1, w, bias, gamma, beta, temb, temb_stride, temb_rows, addend, out, H, W, N, N / groups, eps,
+                  as.n, as.stride, as.bias, ipb};
+    const size_t ldsb = local_lds_bytes(HW < 16 ? 16 : HW, c0 + c1);
+    const dim3 grid((unsigned)((long long)(B / ipb) * (N / 32)));
+    if (HW <= 16)
         hipLaunchKernelGGL(conv3x3_gn_local_kernel<16>, grid, dim3(512), ldsb, st, p);
     else
         hipLaunchKernelGGL(conv3x3_gn_local_kernel<64>, grid, dim3(512), ldsb, st, p);

@@ -553,15 +553,15 @@ static int run_conv(Ctx& c, int kind, const ConvW& cw, const float* src0, int c0
 
 // conv3x3 -> GroupNorm+Mish(+shift)(+residual).  When the conv splits k, its slabs stay in the workspace and the
 // GroupNorm kernel sums them (plus the conv bias) while loading: one kernel and one HBM round trip fewer.
-static bool conv_gn_is_local(const ConvW& cw, int H, int W, int c0, int c1, int N) {
-    return (cw.has_wl && H * W == 16 && conv_gn_local_ok(H, W, c0 + c1, c0, N, GROUPS)) ||
+static bool conv_gn_is_local(const ConvW& cw, int B, int H, int W, int c0, int c1, int N) {
+    return (cw.has_wl && (H * W == 16 || (H * W == 4 && B % 4 == 0)) && conv_gn_local_ok(H, W, c0 + c1, c0, N, GROUPS)) ||
            (cw.has_wwl && H * W == 64 && conv_gn_wlocal_ok(H, W, c0 + c1, c0, N, GROUPS));
 }
 
 static int run_conv_gn(Ctx& c, const ConvW& cw, const float* src0, int c0, const float* src1, int c1, float* raw, const NormW& n,
                        const float* temb, const float* addend, float* out, int H, int W, int N, const AddendSlabs& as = AddendSlabs()) {
-    if (cw.has_wl && H * W == 16 && conv_gn_local_ok(H, W, c0 + c1, c0, N, GROUPS))
-        // 4x4 maps: one image x 32 channels per workgroup, k reduced inside it -> statistics, Mish, shift and residual in the
+    if (cw.has_wl && (H * W == 16 || (H * W == 4 && c.B % 4 == 0)) && conv_gn_local_ok(H, W, c0 + c1, c0, N, GROUPS))
+        // 4x4 maps (and 2x2 maps, four images to a block): one image x 32 channels per workgroup, k reduced inside it -> statistics, Mish, shift and residual in the
         // conv's own epilogue, no slabs and no GroupNorm launch (conv_local.hip)
         return conv_gn_local(src0, c0, src1, c1, c.P + cw.wl, cw.has_bias ? c.P + cw.b : nullptr, c.P + n.g, c.P + n.b, temb,
                              c.u.temb_total, c.temb_rows, addend, out, c.B, H, W, N, GROUPS, GN_EPS, c.st, as);
@@ -650,7 +650,7 @@ static int run_res(Ctx& c, const ResW& r, const float* src0, int c0, const float
     AddendSlabs as;
     if (r.has_res) {
         const int rs = conv_splits(DDK_CONV1X1, c.B, H, W, c0 + c1, r.co);
-        if (rs > 1 && conv_gn_is_local(r.c1, H, W, c0, c1, r.co) && conv_gn_is_local(r.c2, H, W, r.co, 0, r.co)) {
+        if (rs > 1 && conv_gn_is_local(r.c1, c.B, H, W, c0, c1, r.co) && conv_gn_is_local(r.c2, c.B, H, W, r.co, 0, r.co)) {
             // neither Block conv touches the split-K workspace on these maps: the skip conv leaves its slabs there and the
             // second Block's epilogue sums them (+ bias) while it adds the residual -- no reduce launch
             ddk_conv_args a{};

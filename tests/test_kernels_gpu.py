@@ -184,6 +184,10 @@ LOCAL_CASES = [    # B, H, W, c0, c1, N   (GroupNorm groups = 8)
     (2, 2, 8, 96, 0, 96),          # non-square 16-pixel map, 3 chunks, 12 channels/group is not eligible -> see below
     (3, 2, 8, 64, 32, 64),         # non-square 16-pixel map, concat, 8 channels per group
     (1, 8, 2, 32, 0, 64),          # batch 1
+    (64, 2, 2, 256, 0, 256),       # cfg3 2x2 level (16x16 latents, 3 downsamples): four 4-pixel images share a 16-row block
+    (8, 2, 2, 256, 256, 256),      # ... with the concat source of the up path
+    (4, 2, 2, 64, 0, 128),         # one block, 16 channels per group
+    (12, 2, 2, 32, 0, 64),         # three blocks, 8 channels per group
 ]
 
 
