@@ -135,7 +135,7 @@ __device__ __forceinline__ void gn_mish_tail(const float (&v)[NV], const long lo
     }
 }
 
-template <int MT>
+template <int MT, int IPB = 1>     // IPB images per block: 1, or 4 on 2x2 maps (MT == 16)
 __global__ __launch_bounds__(512) void conv3x3_gn_local_kernel(const LocalParams p) {
     extern __shared__ __align__(16) float lds[];
     constexpr int MB = MT / 16;
@@ -179,8 +179,8 @@ __global__ __launch_bounds__(512) void conv3x3_gn_local_kernel(const LocalParams
     long long o_t[MB];
 #pragma unroll
     for (int i = 0; i < MB; ++i) o_t[i] = ((long long)b * MT + row + 16 * i) * p.N + c;
-    const int hwi = MT / p.ipb;                                  // pixels per image (ipb > 1 only with MT == 16)
-    const TailPre<MB> pre = tail_prefetch<MB>(o_t, c, b * p.ipb + row / hwi, p);
+    constexpr int hwi = MT / IPB;                                // pixels per image
+    const TailPre<MB> pre = tail_prefetch<MB>(o_t, c, IPB == 1 ? b : b * IPB + row / hwi, p);
 
     // ---- the image(s): [MT rows][cin] into LDS, row MT = zeros
     {
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(512) void conv3x3_gn_local_kernel(const LocalParams
 #pragma unroll
     for (int i = 0; i < MB; ++i) {
         const int r = i * 16 + m;
-        pbase[i] = (r / hwi) * hwi;                              // first row of this pixel's image inside the block
+        pbase[i] = IPB == 1 ? 0 : (r / hwi) * hwi;               // first row of this pixel's image inside the block
         const int pr = r - pbase[i];
         py[i] = pr / p.W;
         px[i] = pr - py[i] * p.W;
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(512) void conv3x3_gn_local_kernel(const LocalParams
         v[i] = s + cb;
     }
 
-    gn_mish_tail<MB>(v, o_t, col, c, b, hwi, lane, wave, red, p, pre, p.ipb);
+    gn_mish_tail<MB>(v, o_t, col, c, b, hwi, lane, wave, red, p, pre, IPB);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -592,6 +592,8 @@ bool conv_gn_local_ok(int H, int W, int cin, int c0, int N, int groups) {
 int conv_gn_local_init_device() {
     DDK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_gn_local_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 160 * 1024));
+    DDK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_gn_local_kernel<16, 4>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024));
     DDK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_gn_local_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 160 * 1024));
     DDK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_gn_wlocal_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -617,7 +619,9 @@ int conv_gn_local(const float* src0, int c0, const float* src1, int c1, const fl
                   as.n, as.stride, as.bias, ipb};
     const size_t ldsb = local_lds_bytes(HW < 16 ? 16 : HW, c0 + c1);
     const dim3 grid((unsigned)((long long)(B / ipb) * (N / 32)));
-    if (HW <= 16)
+    if (HW == 4)
+        hipLaunchKernelGGL((conv3x3_gn_local_kernel<16, 4>), grid, dim3(512), ldsb, st, p);
+    else if (HW == 16)
         hipLaunchKernelGGL(conv3x3_gn_local_kernel<16>, grid, dim3(512), ldsb, st, p);
     else
         hipLaunchKernelGGL(conv3x3_gn_local_kernel<64>, grid, dim3(512), ldsb, st, p);
