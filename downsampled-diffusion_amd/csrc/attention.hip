@@ -19,17 +19,19 @@ constexpr int DH = 32;  // dim_head (blocks.py:119)
 // softmax is invariant to the subtracted constant, so partials rescale by exp(m_s - max_s m_s).
 constexpr int PART = DH + DH + DH * DH;  // floats per partial: max[32], den[32], acc[32][32]
 
+// kv_only: the rows are [k | v] (2 * heads * 32 floats) instead of [q | k | v] -- the folded-attention path projects k and v only
 __global__ __launch_bounds__(256) void linattn_context_kernel(const float* __restrict__ qkv, float* __restrict__ ctx,
-                                                              float* __restrict__ part, int HW, int heads, int splits, int rows_per_split) {
+                                                              float* __restrict__ part, int HW, int heads, int splits, int rows_per_split,
+                                                              int kv_only) {
     __shared__ __attribute__((aligned(16))) float kexp[64 * DH];
     __shared__ __attribute__((aligned(16))) float vs[64 * DH];
     __shared__ float smax[8 * DH];
     const int bh = blockIdx.x / splits, sp = blockIdx.x % splits;
     const int b = bh / heads, h = bh % heads;
-    const int HC = heads * DH, RS = 3 * HC;
+    const int HC = heads * DH, RS = (kv_only ? 2 : 3) * HC;
     const float* base = qkv + (long long)b * HW * RS;
-    const float* kp = base + HC + h * DH;
-    const float* vp = base + 2 * HC + h * DH;
+    const float* kp = base + (kv_only ? 0 : HC) + h * DH;
+    const float* vp = kp + HC;
     const int tid = threadIdx.x;
     const int n_begin = sp * rows_per_split, n_end = min(HW, n_begin + rows_per_split);
 
@@ -535,7 +537,8 @@ size_t linattn_context_workspace_bytes(int B, int HW, int heads) {
     return s > 1 ? (size_t)B * heads * s * PART * sizeof(float) : 0;
 }
 
-int linattn_context(const float* qkv, float* ctx, int B, int HW, int heads, void* workspace, size_t workspace_bytes, hipStream_t st) {
+int linattn_context(const float* qkv, float* ctx, int B, int HW, int heads, void* workspace, size_t workspace_bytes, hipStream_t st,
+                    bool kv_only) {
     DDK_REQUIRE(qkv && ctx && B > 0 && HW > 0 && heads > 0, "linattn_context: arguments");
     DDK_REQUIRE(aligned16(qkv) && aligned16(ctx) && aligned16(workspace), "linattn_context: alignment");
     int s, rows;
@@ -548,7 +551,8 @@ int linattn_context(const float* qkv, float* ctx, int B, int HW, int heads, void
         s = 1;
         rows = HW;
     }
-    hipLaunchKernelGGL(linattn_context_kernel, dim3(B * heads * s), dim3(256), 0, st, qkv, ctx, static_cast<float*>(workspace), HW, heads, s, rows);
+    hipLaunchKernelGGL(linattn_context_kernel, dim3(B * heads * s), dim3(256), 0, st, qkv, ctx, static_cast<float*>(workspace), HW, heads, s, rows,
+                       kv_only ? 1 : 0);
     DDK_TRY(check_launch("linattn_context_kernel"));
     if (s > 1) {
         hipLaunchKernelGGL(linattn_merge_kernel, dim3(B * heads), dim3(256), 0, st, static_cast<const float*>(workspace), ctx, s);
@@ -571,7 +575,104 @@ int linattn_fused_small(const float* qkv, float* ctx, float* out, int B, int HW,
 
 bool linattn_small_qkv_ok(int HW, int C) { return HW > 0 && HW <= 64 && C % 32 == 0 && C >= 32 && small_qkv_lds_bytes(HW <= 16 ? 1 : 4, C) <= 160 * 1024; }
 
+// ------------------------------------------------------------------------------------------------
+// Folded attention output for maps with HW >> C (blocks.py:126-134 + to_out + the PreNorm LayerNorm of :57-60, C = hidden = 128).
+// q is LINEAR in this attention (only k is soft-maxed), so with the LayerNorm folded into W_q (Wqg = W_q o g, c1q = W_q g,
+// c2q = W_q b; r = 1 / (std + eps) per pixel):
+//   y_n = W_out ctx^T q_n + b_out + x_n = r_n (A x_n) - r_n mean_n a1 + a2 + x_n,
+//   A = W_out T,  T[h 32 + e][c] = sum_d ctx[h][d][e] Wqg[h 32 + d][c]            (one C x C matrix per IMAGE)
+//   a1 = W_out (ctx^T c1q),  a2 = W_out (ctx^T c2q) + b_out
+// i.e. to_qkv's q third, the apply kernel and to_out collapse into a 1x1 conv of x with per-image weights (2.6 M MACs per image
+// to build A instead of (128 + 32) x 128 per PIXEL); conv1x1_ws_kernel<LN, RES> with per-image weights evaluates it.
+// grid (B, 4) x 4 waves: workgroup (b, quarter) builds T (redundantly) and rows [32 quarter, +32) of A, both on the matrix pipe.
+constexpr int FOLD_C = 128;
+constexpr int FOLD_LDS_FLOATS = FOLD_C * FOLD_C + 32 * (FOLD_C + 1) + 2 * FOLD_C;
+typedef float f32x16_att __attribute__((ext_vector_type(16)));
+__global__ __launch_bounds__(256) void attn_fold_kernel(const float* __restrict__ ctx, const float* __restrict__ wqg,
+                                                        const float* __restrict__ c1q, const float* __restrict__ c2q,
+                                                        const float* __restrict__ wout, const float* __restrict__ bout,
+                                                        float* __restrict__ A, float* __restrict__ a1, float* __restrict__ a2) {
+    extern __shared__ __align__(16) float sm[];
+    float* T = sm;                              // [128 (h, e)][128 c]
+    float* Wq = T + FOLD_C * FOLD_C;            // W_out rows of this quarter, [32 n][128 he + 1]: the A-phase row operand
+    float* t1 = Wq + 32 * (FOLD_C + 1);         // ctx^T c1q, ctx^T c2q
+    float* t2 = t1 + FOLD_C;
+    const int b = blockIdx.x, nq = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, kh = lane >> 5;
+    // Both products on the matrix pipe (v_mfma_f32_32x32x2_f32; VALU forms of this kernel took 19-34 us: one shared-operand read
+    // per FMA).  T phase: wave = head h, T_h [32 e][128 c] = ctx_h^T [32 e][32 d] . Wqg_h [32 d][128 c]: 4 column blocks x 16 k-pairs.
+    {
+        const float* cp = ctx + ((long long)b * 4 + wave) * DH * DH;          // [d][e]: row operand (e = lane & 31, d = 2 s + kh)
+        const float* wp = wqg + (long long)wave * DH * FOLD_C;                // [d][c]: column operand
+        f32x16_att acc[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+        // all 80 operand words of the lane first (one memory latency for the phase, not one per unrolled batch), then the 64 MFMAs
+        float av[DH / 2], bv[DH / 2][4];
+#pragma unroll
+        for (int s2 = 0; s2 < DH / 2; ++s2) {
+            const int d = 2 * s2 + kh;
+            av[s2] = cp[d * DH + l31];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bv[s2][j] = wp[d * FOLD_C + j * 32 + l31];
+        }
+        __builtin_amdgcn_sched_barrier(0);      // hipcc otherwise sinks every load to its MFMA: 4 in flight, one latency per k-pair
+#pragma unroll
+        for (int s2 = 0; s2 < DH / 2; ++s2)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s2], bv[s2][j], acc[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) T[(wave * DH + (r & 3) + 8 * (r >> 2) + 4 * kh) * FOLD_C + j * 32 + l31] = acc[j][r];
+    }
+    for (int i = tid; i < 32 * FOLD_C; i += 256) Wq[(i >> 7) * (FOLD_C + 1) + (i & 127)] = wout[(long long)nq * 32 * FOLD_C + i];
+    if (tid < FOLD_C) {
+        const int h = tid >> 5, e = tid & 31;
+        const float* ch = ctx + ((long long)b * 4 + h) * DH * DH;
+        float u1 = 0.f, u2 = 0.f;
+#pragma unroll
+        for (int d = 0; d < DH; ++d) {
+            const float cv = ch[d * DH + e];
+            u1 += cv * c1q[h * DH + d];
+            u2 += cv * c2q[h * DH + d];
+        }
+        t1[tid] = u1;
+        t2[tid] = u2;
+    }
+    __syncthreads();
+    {   // A phase: rows [32 nq, +32) x column block `wave`: A = W_out [32 n][128 he] . T [128 he][32 c], 64 k-pairs
+        f32x16_att acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll 8
+        for (int s2 = 0; s2 < FOLD_C / 2; ++s2) {
+            const int he = 2 * s2 + kh;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Wq[l31 * (FOLD_C + 1) + he], T[he * FOLD_C + wave * 32 + l31], acc, 0, 0, 0);
+        }
+        float* Ab = A + ((long long)b * FOLD_C + nq * 32) * FOLD_C + wave * 32 + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Ab[((r & 3) + 8 * (r >> 2) + 4 * kh) * FOLD_C] = acc[r];
+        if (tid < 32) {
+            float u1 = 0.f, u2 = 0.f;
+#pragma unroll 16
+            for (int he = 0; he < FOLD_C; ++he) {
+                u1 += Wq[tid * (FOLD_C + 1) + he] * t1[he];
+                u2 += Wq[tid * (FOLD_C + 1) + he] * t2[he];
+            }
+            const int n = nq * 32 + tid;
+            a1[(long long)b * FOLD_C + n] = u1;
+            a2[(long long)b * FOLD_C + n] = u2 + (bout ? bout[n] : 0.f);
+        }
+    }
+}
+
 int linattn_small_qkv_init_device() {
+    DDK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fold_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(FOLD_LDS_FLOATS * sizeof(float))));
     DDK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(linattn_small_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     DDK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(linattn_small_qkv_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     DDK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(linattn_small_qkv_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -602,6 +703,21 @@ int linattn_small_qkv(const float* x, const float* wop, const float* c1, const f
     return check_launch("linattn_small_qkv_kernel");
 }
 
+bool attn_fold_ok(int C, int heads) { return C == FOLD_C && heads * DH == FOLD_C; }
+size_t attn_fold_out_floats(int B) { return (size_t)B * (FOLD_C * FOLD_C + 2 * FOLD_C); }
+
+// ctx [B][4][32][32]; wqg [128][128] = rows 0..127 of the LayerNorm-folded to_qkv weight, c1q / c2q its fold vectors; wout [128][128]
+// the packed to_out weight, bout its bias -> A [B][128][128], a1, a2 [B][128]
+int attn_fold(const float* ctx, const float* wqg, const float* c1q, const float* c2q, const float* wout, const float* bout, float* A,
+              float* a1, float* a2, int B, int C, int heads, hipStream_t st) {
+    DDK_REQUIRE(ctx && wqg && c1q && c2q && wout && A && a1 && a2 && B > 0, "attn_fold: arguments");
+    DDK_REQUIRE(attn_fold_ok(C, heads), "attn_fold: C == 128 and heads * 32 == 128 only");
+    DDK_REQUIRE(aligned16(ctx) && aligned16(wout) && aligned16(A), "attn_fold: alignment");
+    DDK_TRY(ensure_device_init());
+    hipLaunchKernelGGL(attn_fold_kernel, dim3(B, 4), dim3(256), FOLD_LDS_FLOATS * sizeof(float), st, ctx, wqg, c1q, c2q, wout, bout, A, a1, a2);
+    return check_launch("attn_fold_kernel");
+}
+
 int linattn_apply(const float* qkv, const float* ctx, float* out, int B, int HW, int heads, hipStream_t st) {
     DDK_REQUIRE(qkv && ctx && out && B > 0 && HW > 0, "linattn_apply: arguments");
     DDK_REQUIRE(heads >= 1 && heads <= 8, "linattn_apply: heads must be in 1..8");
@@ -617,7 +733,14 @@ int linattn_apply(const float* qkv, const float* ctx, float* out, int B, int HW,
 extern "C" {
 size_t ddk_linattn_context_workspace_bytes(int B, int HW, int heads) { return ddk::linattn_context_workspace_bytes(B, HW, heads); }
 int ddk_linattn_context(const float* qkv, float* ctx, int B, int HW, int heads, void* workspace, size_t workspace_bytes, ddk_stream_t s) {
-    return ddk::linattn_context(qkv, ctx, B, HW, heads, workspace, workspace_bytes, ddk::as_stream(s));
+    return ddk::linattn_context(qkv, ctx, B, HW, heads, workspace, workspace_bytes, ddk::as_stream(s), false);
+}
+int ddk_linattn_context_kv(const float* kv, float* ctx, int B, int HW, int heads, void* workspace, size_t workspace_bytes, ddk_stream_t s) {
+    return ddk::linattn_context(kv, ctx, B, HW, heads, workspace, workspace_bytes, ddk::as_stream(s), true);
+}
+int ddk_attention_fold(const float* ctx, const float* wqg, const float* c1q, const float* c2q, const float* wout, const float* bout, float* A,
+                       float* a1, float* a2, int B, int C, int heads, ddk_stream_t s) {
+    return ddk::attn_fold(ctx, wqg, c1q, c2q, wout, bout, A, a1, a2, B, C, heads, ddk::as_stream(s));
 }
 int ddk_linattn_fused_small(const float* qkv, float* ctx, float* out, int B, int HW, int heads, ddk_stream_t s) {
     return ddk::linattn_fused_small(qkv, ctx, out, B, HW, heads, ddk::as_stream(s));

@@ -39,6 +39,8 @@ struct WsParams {
     float* out;           // [M][N]
     int N, MT, G;         // output channels, 64-pixel tiles, workgroups per 128-channel slice
     long long resid_bytes;
+    int tpi;              // > 0: PER-IMAGE weights (N == 128): w is [images][128][128], ln_c1 / ln_c2 / bias [images][128], an image is
+                          // tpi consecutive tiles and "slice" below is the image index (the folded attention output, attention.hip)
 };
 
 typedef int ws_i32x4 __attribute__((ext_vector_type(4)));
@@ -57,7 +59,10 @@ __global__ __launch_bounds__(512) void conv1x1_ws_kernel(const WsParams p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int slice = blockIdx.x / p.G, g = blockIdx.x - slice * p.G;
-    const int n0 = slice * WS_BN;
+    const bool per_img = p.tpi > 0;
+    const int n0 = per_img ? 0 : slice * WS_BN;
+    const int vec0 = per_img ? slice * WS_BN : 0;       // offset of this workgroup's per-channel vectors (bias, LayerNorm fold)
+    const int tile_end = per_img ? (slice + 1) * p.tpi : p.MT;
     const int wm = wid & 1, wn = wid >> 1;              // this wave: pixels [32 wm, +32), channels [32 wn, +32) of the slice
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) float*)smem;
 
@@ -77,7 +82,7 @@ __global__ __launch_bounds__(512) void conv1x1_ws_kernel(const WsParams p) {
         avoff[j] = (unsigned)((r * WS_K + dchunk * 32 + ((ppos ^ ((r >> 1) & 7)) << 2)) * 4);
     }
     {   // the weight slice: 8 pieces per wave, once
-        const float* wb = p.w + (long long)n0 * WS_K;
+        const float* wb = p.w + (long long)(per_img ? slice * WS_BN : n0) * WS_K;
         const unsigned dst = lds_base + (unsigned)((dchunk * (WS_BN * 32) + dhalf * 2048) * 4);
 #pragma unroll
         for (int j = 0; j < 8; ++j) lds_dma16_s(wb, wvoff[j], dst + (unsigned)(j * 1024));
@@ -88,8 +93,8 @@ __global__ __launch_bounds__(512) void conv1x1_ws_kernel(const WsParams p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) lds_dma16_s(xb, avoff[j], a_dst + (unsigned)(buf * WS_A_FLOATS * 4 + j * 1024));
     };
-    int tile = g;
-    if (tile < p.MT) issue_a(tile, 0);
+    int tile = (per_img ? slice * p.tpi : 0) + g;
+    if (tile < tile_end) issue_a(tile, 0);
 
     // ---- per-wave constants of the epilogue: this lane's 4 channel quads: channel n0 + 32 wn + 8 q + 4 h
     const int pl = lane & 31, h = lane >> 5;
@@ -97,7 +102,7 @@ __global__ __launch_bounds__(512) void conv1x1_ws_kernel(const WsParams p) {
     float4 e1[4], e2[4];                                // LN: (c1, c2 + bias); plain: (unused, bias)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const int c = cbase + 8 * q;
+        const int c = vec0 + cbase + 8 * q;
         float4 b4 = p.bias ? *reinterpret_cast<const float4*>(p.bias + c) : make_float4(0.f, 0.f, 0.f, 0.f);
         if (LN) {
             e1[q] = *reinterpret_cast<const float4*>(p.ln_c1 + c);
@@ -126,7 +131,7 @@ __global__ __launch_bounds__(512) void conv1x1_ws_kernel(const WsParams p) {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
     int buf = 0;
-    for (; tile < p.MT; tile += p.G, buf ^= 1) {
+    for (; tile < tile_end; tile += p.G, buf ^= 1) {
         const float* Ab = As + buf * WS_A_FLOATS;
         const long long m0 = (long long)tile * WS_BM;
         if (LN) {
@@ -168,7 +173,7 @@ __global__ __launch_bounds__(512) void conv1x1_ws_kernel(const WsParams p) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) ws_buf_load16(rr[q], row_off, rsrd, (unsigned)(8 * q * 4));
         }
-        const bool more = tile + p.G < p.MT;             // wave-uniform
+        const bool more = tile + p.G < tile_end;         // wave-uniform
         const float* xnext = p.x + (long long)(tile + p.G) * WS_BM * WS_K;
         const unsigned dnext = a_dst + (unsigned)((buf ^ 1) * WS_A_FLOATS * 4);
 
@@ -248,9 +253,11 @@ int conv1x1_ws_init_device() {
 
 // x [M][128], w [N][128] (the packed 1x1 weight: row pitch 128), out [M][N].  ln != nullptr: w holds W o g and (c1, c2) = (W g, W b).
 int conv1x1_ws(const float* x, const float* w, const float* bias, const float* resid, float* out, long long M, int N, const ConvLnFold* ln,
-               hipStream_t st) {
+               hipStream_t st, int images) {
     DDK_REQUIRE(x && w && out, "conv1x1_ws: null pointer");
     DDK_REQUIRE(conv1x1_ws_ok(M, WS_K, N), "conv1x1_ws: needs K == 128, N % 128 == 0, M % 64 == 0, M >= 2048");
+    DDK_REQUIRE(images == 0 || (images > 0 && N == WS_BN && M % images == 0 && (M / images) % WS_BM == 0),
+                "conv1x1_ws: per-image weights need N == 128 and whole 64-pixel tiles per image");
     DDK_REQUIRE(aligned16(x) && aligned16(w) && aligned16(out) && aligned16(bias) && aligned16(resid), "conv1x1_ws: alignment");
     DDK_REQUIRE(!ln || (ln->c1 && ln->c2 && aligned16(ln->c1) && aligned16(ln->c2)), "conv1x1_ws: LayerNorm folding vectors");
     DDK_TRY(ensure_device_init());
@@ -258,9 +265,11 @@ int conv1x1_ws(const float* x, const float* w, const float* bias, const float* r
     p.x = x; p.w = w; p.bias = bias; p.resid = resid; p.out = out;
     p.ln_c1 = ln ? ln->c1 : nullptr; p.ln_c2 = ln ? ln->c2 : nullptr; p.ln_eps = ln ? ln->eps : 0.f;
     p.N = N; p.MT = (int)(M / WS_BM);
-    const int NS = N / WS_BN;
+    const int NS = images > 0 ? images : N / WS_BN;     // weight slices: 128-channel slices of one filter, or one filter per image
+    p.tpi = images > 0 ? (int)(M / images / WS_BM) : 0;
     int G = 256 / NS;                                   // one workgroup per CU (132 KB of LDS)
-    if (G > p.MT) G = p.MT;
+    if (G < 1) G = 1;
+    if (G > (images > 0 ? p.tpi : p.MT)) G = images > 0 ? p.tpi : p.MT;
     p.G = G;
     p.resid_bytes = M * N * 4;
     const dim3 grid((unsigned)(NS * G));
@@ -280,4 +289,10 @@ extern "C" int ddk_conv1x1_ws(const float* x, const float* w, const float* bias,
                               const float* ln_c1, const float* ln_c2, float ln_eps, ddk_stream_t s) {
     const ddk::ConvLnFold ln{ln_c1, ln_c2, ln_eps};
     return ddk::conv1x1_ws(x, w, bias, resid, out, M, N, ln_c1 ? &ln : nullptr, ddk::as_stream(s));
+}
+
+extern "C" int ddk_conv1x1_ws_images(const float* x, const float* w, const float* bias, const float* resid, float* out, long long M, int N,
+                                     const float* ln_c1, const float* ln_c2, float ln_eps, int images, ddk_stream_t s) {
+    const ddk::ConvLnFold ln{ln_c1, ln_c2, ln_eps};
+    return ddk::conv1x1_ws(x, w, bias, resid, out, M, N, ln_c1 ? &ln : nullptr, ddk::as_stream(s), images);
 }

@@ -1316,10 +1316,13 @@ int conv_forward(const ddk_conv_args& a, hipStream_t st, const ConvLnFold* ln, c
     }
     // (the LayerNorm-folded form only where every workgroup walks >= 16 tiles: its ragged last round and per-tile statistics pass
     //  lose to the tile kernel at cfg4's 6 tiles per workgroup -- 44.6 vs 42.2 us -- and win on the full-resolution maps: 128x128
-    //  x 8 images 264 -> ~140 us)
+    //  x 8 images 264 -> ~140 us; or where the tiles divide evenly over the workgroups, e.g. the 256-channel k, v projection of the
+    //  folded attention block: 512 tiles over 2 x 128 workgroups, 30.2 -> ~26 us)
     if (a.kind == DDK_CONV1X1 && a.c1 == 0 && !a.pre_mish && !a.post_mish && !a.defer_reduce && !a.gn_partials && !fuse && !act_epilogue &&
         !tuning_flag("DDK_NO_CONV1X1_WS") && conv1x1_ws_ok((long long)a.B * a.H * a.W, a.c0, a.N) &&
-        ((long long)a.B * a.H * a.W / 64) * (a.N / 128) >= (ln ? 16 * 256 : 256)) {
+        ((long long)a.B * a.H * a.W / 64) * (a.N / 128) >= 256 &&
+        (!ln || ((long long)a.B * a.H * a.W / 64) * (a.N / 128) >= 16 * 256 ||
+         (256 % (a.N / 128) == 0 && ((long long)a.B * a.H * a.W / 64) % (256 / (a.N / 128)) == 0))) {
         // 128 input channels on a large map: weights-stationary streaming kernel (conv1x1_ws.hip).  Measured in a cfg4 step
         // (profiles/r03_sampler_step_breakdown.txt): to_out 17.2 -> 15.4 us at 32x32, 11.0 -> 9.3 at 16x16 (256 out), res_conv
         // 9.7 -> 9.4; with fewer than 256 (tile, slice) pairs the chip is half empty and the tile kernel wins (9.0 vs 10.0 us).

@@ -171,8 +171,9 @@ int conv_first_init_device();
 // conv1x1_ws.hip: 1x1 conv with 128 input channels on a large map as a weights-stationary, pixel-streaming GEMM
 // (w = the packed 1x1 weight [N][128]; ln as in conv_forward)
 bool conv1x1_ws_ok(long long M, int K, int N);
+// images > 0: PER-IMAGE weights -- w is [images][128][128], the LayerNorm vectors [images][128], N == 128, M / images pixels per image
 int conv1x1_ws(const float* x, const float* w, const float* bias, const float* resid, float* out, long long M, int N, const ConvLnFold* ln,
-               hipStream_t st);
+               hipStream_t st, int images = 0);
 int conv1x1_ws_init_device();
 // conv_local.hip: conv3x3 + GroupNorm + Mish (+shift, +residual) in one launch for 4x4 / 8x8 maps
 // the addend of the image-local kernels may still be in split-K form (the 1x1 skip conv's slabs): n slabs `stride` floats apart,
@@ -214,7 +215,13 @@ int avgpool2(const float* x, float* out, int B, int H, int W, int C, hipStream_t
 int upsample_nearest2(const float* x, float* out, int B, int H, int W, int C, hipStream_t st);
 // attention.hip
 size_t linattn_context_workspace_bytes(int B, int HW, int heads);
-int linattn_context(const float* qkv, float* ctx, int B, int HW, int heads, void* workspace, size_t workspace_bytes, hipStream_t st);
+int linattn_context(const float* qkv, float* ctx, int B, int HW, int heads, void* workspace, size_t workspace_bytes, hipStream_t st,
+                    bool kv_only = false);
+// folded attention output (attention.hip): per-image C x C matrix A and fold vectors from the context
+bool attn_fold_ok(int C, int heads);
+size_t attn_fold_out_floats(int B);
+int attn_fold(const float* ctx, const float* wqg, const float* c1q, const float* c2q, const float* wout, const float* bout, float* A,
+              float* a1, float* a2, int B, int C, int heads, hipStream_t st);
 int linattn_apply(const float* qkv, const float* ctx, float* out, int B, int HW, int heads, hipStream_t st);
 int linattn_fused_small(const float* qkv, float* ctx, float* out, int B, int HW, int heads, hipStream_t st);
 bool linattn_small_qkv_ok(int HW, int C);

@@ -94,6 +94,7 @@ struct ddk_unet {
     ddk_unet_config cfg;
     bool cluster_gn = true;                  // GroupNorm finished inside the Winograd conv launch where eligible (ddk_unet_set_option)
     int cluster_limit = 1 << 30;             // diagnostic: only the first so many eligible launches of a forward take that path
+    bool attn_fold = true;                   // attention on maps with HW > 256, C = 128: q projection + apply + to_out as ONE per-image C x C conv
     std::vector<Slot> slots;
     size_t packed_floats = 0;
     int L = 0;
@@ -323,6 +324,13 @@ extern "C" int ddk_unet_set_option(ddk_unet* u, int option, int value) {
         if (!u->graphs.empty()) DDK_HIP(hipDeviceSynchronize());
         drop_graphs(u);                          // a captured step bakes the choice in
         u->cluster_gn = value != 0;
+        return DDK_OK;
+    }
+    if (option == DDK_OPT_ATTENTION_FOLD) {
+        std::lock_guard<std::mutex> lock(u->mu);
+        if (!u->graphs.empty()) DDK_HIP(hipDeviceSynchronize());
+        drop_graphs(u);
+        u->attn_fold = value != 0;
         return DDK_OK;
     }
     if (option == 2) {   // diagnostic (not in ddk.h): cap on the cluster launches per forward
@@ -676,6 +684,13 @@ static int run_res(Ctx& c, const ResW& r, const float* src0, int c0, const float
     return run_conv_gn(c, r.c2, a1, r.co, nullptr, 0, raw, r.n2, nullptr, addend, out, H, W, r.co, as);
 }
 
+// The folded form of the attention block (attention.hip, attn_fold_kernel): maps with many more pixels than channels, C = 128
+static bool attn_fold_eligible(const ddk_unet& u, const AttnW& a, int B, int H, int W) {
+    const long long M = (long long)B * H * W;
+    return u.attn_fold && H * W > 256 && (H * W) % 64 == 0 && attn_fold_ok(a.c, HEADS) && conv1x1_ws_ok(M, a.c, a.c) &&
+           conv_ln_fold_ok(B, H, W, a.c, 2 * HIDDEN) && B <= 256;
+}
+
 // blocks.py:8-14,63-71,126-134: out = to_out(attn(to_qkv(LN(x)))) + x
 static int run_attn(Ctx& c, const AttnW& a, const float* x, float* out, int H, int W) {
     float* xn = c.W + c.ly.off_xn;
@@ -689,6 +704,22 @@ static int run_attn(Ctx& c, const AttnW& a, const float* x, float* out, int H, i
         // chip, one wave per SIMD: 25.5 us against 12.5 + 5.7 for the two launches, so those keep the im2col kernel.)
         DDK_TRY(linattn_small_qkv(x, c.P + a.qkv_op, c.P + a.ln_c1, c.P + a.ln_c2, LN_EPS, ctx, o, c.B, H * W, a.c, HEADS, c.st));
         return run_conv(c, DDK_CONV1X1, a.out, o, HIDDEN, nullptr, 0, x, out, H, W, a.c);
+    }
+    if (attn_fold_eligible(c.u, a, c.B, H, W)) {
+        // q is linear in this attention: project k and v only, build the context, fold to_out . ctx^T . W_q (and the LayerNorm)
+        // into one C x C matrix per image and apply it to x as a per-image 1x1 conv with the residual -- no q third of to_qkv, no
+        // apply kernel, no separate to_out
+        const ConvLnFold lnkv{c.P + a.ln_c1 + HIDDEN, c.P + a.ln_c2 + HIDDEN, LN_EPS};
+        DDK_TRY(run_conv(c, DDK_CONV1X1, a.qkv, x, a.c, nullptr, 0, nullptr, qkv, H, W, 2 * HIDDEN, c.P + a.qkv_lnw + (size_t)HIDDEN * a.c,
+                         &lnkv));
+        DDK_TRY(linattn_context(qkv, ctx, c.B, H * W, HEADS, c.W + c.ly.off_splitk, c.ly.splitk * sizeof(float), c.st, true));
+        float* A = o;                                   // [B][C][C], then a1, a2 [B][C] (the apply output buffer is free on this path)
+        float* a1 = A + (size_t)c.B * a.c * a.c;
+        float* a2 = a1 + (size_t)c.B * a.c;
+        DDK_TRY(attn_fold(ctx, c.P + a.qkv_lnw, c.P + a.ln_c1, c.P + a.ln_c2, c.P + a.out.w, a.out.has_bias ? c.P + a.out.b : nullptr, A, a1,
+                          a2, c.B, a.c, HEADS, c.st));
+        const ConvLnFold lnA{a1, a2, LN_EPS};
+        return conv1x1_ws(x, A, nullptr, x, out, M, a.c, &lnA, c.st, c.B);
     }
     if (conv_ln_fold_ok(c.B, H, W, a.c, 3 * HIDDEN)) {
         // LayerNorm folded into the projection: no LayerNorm launch, no normalised copy of x
@@ -957,7 +988,8 @@ extern "C" double ddk_unet_flops_executed(const ddk_unet* u, int B, int H0, int 
     double f = 0;
     auto conv3 = [&](const ConvW& cw, int H, int W, int c0, int c1, int N, bool gn) {
         const int cin = c0 + c1;
-        if (gn && cw.has_wl && H * W == 16 && conv_gn_local_ok(H, W, cin, c0, N, GROUPS)) return 2.0 * B * H * W * 9.0 * cin * N;
+        if (gn && cw.has_wl && (H * W == 16 || (H * W == 4 && B % 4 == 0)) && conv_gn_local_ok(H, W, cin, c0, N, GROUPS))
+            return 2.0 * B * H * W * 9.0 * cin * N;
         if (gn && cw.has_wwl && H * W == 64 && conv_gn_wlocal_ok(H, W, cin, c0, N, GROUPS)) return 2.0 * B * (H * W / 4) * 16.0 * cin * N;
         if (use_wino(cw, H, W, cin, N)) return 2.0 * (double)(ceil_div((long long)B * (H / 2) * (W / 2), 32) * 32) * 16.0 * cin * N;
         return 2.0 * B * H * W * 9.0 * cin * N;
@@ -973,6 +1005,12 @@ extern "C" double ddk_unet_flops_executed(const ddk_unet* u, int B, int H0, int 
         f += conv3(r.c2, H, W, r.co, 0, r.co, true);
     };
     auto attn = [&](const AttnW& a, int H, int W) {
+        if (attn_fold_eligible(*u, a, B, H, W)) {
+            // k, v projection + context + the per-image fold (T four times per image, A once) + the per-image C x C conv
+            f += conv_flops(DDK_CONV1X1, B, H, W, a.c, 2 * HIDDEN) + 2.0 * B * HEADS * 32.0 * 32.0 * H * W;
+            f += 2.0 * B * (4.0 * HIDDEN * 32.0 * a.c + (double)a.c * HIDDEN * a.c) + conv_flops(DDK_CONV1X1, B, H, W, a.c, a.c);
+            return;
+        }
         f += conv_flops(DDK_CONV1X1, B, H, W, a.c, 3 * HIDDEN) + conv_flops(DDK_CONV1X1, B, H, W, HIDDEN, a.c);
         f += 2.0 * 2.0 * B * HEADS * 32.0 * 32.0 * H * W;
     };

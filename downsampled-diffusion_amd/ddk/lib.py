@@ -67,6 +67,9 @@ SIGNATURES = {
     "ddk_conv_first": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "ddk_conv1x1_ws_ok": (_I, [C.c_longlong, _I, _I]),
     "ddk_conv1x1_ws": (_I, [_P, _P, _P, _P, _P, C.c_longlong, _I, _P, _P, _F, _P]),
+    "ddk_conv1x1_ws_images": (_I, [_P, _P, _P, _P, _P, C.c_longlong, _I, _P, _P, _F, _I, _P]),
+    "ddk_linattn_context_kv": (_I, [_P, _P, _I, _I, _I, _P, _SZ, _P]),
+    "ddk_attention_fold": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "ddk_groupnorm_mish_partials_res1x1": (_I, [_P, _P, _I, _P, _P, _P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _F, _P]),
     "ddk_final_tail": (_I, [_P, _P, _I, _P, _P, _F, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_uint64, C.c_uint32, _I, _I, _I, _I, _P]),
     "ddk_pack_conv_weight_local": (_I, [_P, _P, _I, _I, _I, _P]),

@@ -251,6 +251,38 @@ def conv1x1_ws(x, w_packed, bias=None, resid=None, ln=None, eps=1e-5):
     return out
 
 
+def attention_folded(x, w_qkv, ln_g, ln_b, w_out, b_out, heads=4, eps=LN_EPS):
+    """PreNorm(LinearAttention) + Residual (blocks.py:8-14,57-71,116-134) on a map with more than 256 pixels and C = heads * 32 = 128,
+    in the folded form: k, v projection -> context -> per-image matrix W_out ctx^T W_q (ddk_attention_fold) -> one per-image 1x1 conv
+    of x with the LayerNorm folded in and the residual added (ddk_conv1x1_ws_images).  x [B,H,W,128]; w_qkv [384,128(,1,1)], w_out
+    [128,128(,1,1)], b_out [128] canonical; ln_g / ln_b the channel LayerNorm's g, b."""
+    b, h, w_, c = x.shape
+    hc = heads * 32
+    wq = w_qkv.reshape(3 * hc, c).to(torch.float32)
+    g, be = ln_g.reshape(-1).to(torch.float32), ln_b.reshape(-1).to(torch.float32)
+    wg = (wq * g.view(1, c)).contiguous()                   # W o g
+    c1, c2 = (wq @ g).contiguous(), (wq @ be).contiguous()  # W g, W b
+    lib = L.load()
+    m = b * h * w_
+    kv = torch.empty((b, h, w_, 2 * hc), device=x.device, dtype=torch.float32)
+    L.check(lib.ddk_conv1x1_ws(L.ptr(_f32(x)), L.ptr(wg[hc:].contiguous()), None, None, L.ptr(kv), m, 2 * hc, L.ptr(c1[hc:].contiguous()),
+                               L.ptr(c2[hc:].contiguous()), eps, L.stream()), "conv1x1_ws(kv)")
+    ctx = torch.empty((b, heads, 32, 32), device=x.device, dtype=torch.float32)
+    nbytes = lib.ddk_linattn_context_workspace_bytes(b, h * w_, heads)
+    ws = _ws(x.device, nbytes, "linattn") if nbytes else None
+    L.check(lib.ddk_linattn_context_kv(L.ptr(kv), L.ptr(ctx), b, h * w_, heads, L.ptr(ws), nbytes, L.stream()), "linattn_context_kv")
+    a_mat = torch.empty((b, c, c), device=x.device, dtype=torch.float32)
+    a1 = torch.empty((b, c), device=x.device, dtype=torch.float32)
+    a2 = torch.empty((b, c), device=x.device, dtype=torch.float32)
+    L.check(lib.ddk_attention_fold(L.ptr(ctx), L.ptr(wg[:hc].contiguous()), L.ptr(c1[:hc].contiguous()), L.ptr(c2[:hc].contiguous()),
+                                   L.ptr(w_out.reshape(c, hc).contiguous()), L.ptr(b_out), L.ptr(a_mat), L.ptr(a1), L.ptr(a2), b, c, heads,
+                                   L.stream()), "attention_fold")
+    out = torch.empty_like(x)
+    L.check(lib.ddk_conv1x1_ws_images(L.ptr(x), L.ptr(a_mat), None, L.ptr(x), L.ptr(out), m, c, L.ptr(a1), L.ptr(a2), eps, b, L.stream()),
+            "conv1x1_ws_images")
+    return out
+
+
 def groupnorm_mish_from_partials_res1x1(x, part, tiles_per_image, gamma, beta, res_x, res_w, res_b, temb=None, groups=GN_GROUPS,
                                         eps=GN_EPS):
     """groupnorm_mish_from_partials with the addend res_b + res_x @ res_w^T (a 1x1 conv of a <= 8-channel tensor) computed on the

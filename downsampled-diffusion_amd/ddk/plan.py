@@ -94,6 +94,7 @@ class UnetPlan:
         return buf
 
     OPT_CLUSTER_GROUPNORM = 1
+    OPT_ATTENTION_FOLD = 3
 
     def set_option(self, option, value):
         """ddk_unet_set_option: e.g. (OPT_CLUSTER_GROUPNORM, 0) keeps conv + GroupNorm-apply as two launches."""

@@ -154,6 +154,10 @@ int ddk_conv_first(const float* x, const float* w_first, const float* bias, floa
 int ddk_conv1x1_ws_ok(long long M, int K, int N);
 int ddk_conv1x1_ws(const float* x, const float* w, const float* bias, const float* resid, float* out, long long M, int N,
                    const float* ln_c1, const float* ln_c2, float ln_eps, ddk_stream_t s);
+/* The same with PER-IMAGE weights: w [images][128][128], bias / ln_c1 / ln_c2 [images][128], N == 128, M / images pixels per image
+ * (a multiple of 64).  With ddk_attention_fold this evaluates a whole attention block's output on maps with HW >> C. */
+int ddk_conv1x1_ws_images(const float* x, const float* w, const float* bias, const float* resid, float* out, long long M, int N,
+                          const float* ln_c1, const float* ln_c2, float ln_eps, int images, ddk_stream_t s);
 /* ddk_groupnorm_mish_partials whose addend is a 1x1 conv of a narrow tensor, evaluated on the fly (the first ResnetBlock's
  * res_conv, blocks.py:103,115): out = Mish(GN(x)) [+ temb] + (res_b[c] + sum_k res_x[pix][k] res_w[c][k]), res_x [B*HW][res_cin],
  * res_w [C][res_cin] (the OIHW 1x1 weight as is), 1 <= res_cin <= 8; C/4 must divide 256. */
@@ -197,6 +201,16 @@ int ddk_add(const float* a, const float* b, float* out, long long n, ddk_stream_
 size_t ddk_linattn_context_workspace_bytes(int B, int HW, int heads);
 int ddk_linattn_context(const float* qkv, float* ctx, int B, int HW, int heads, void* workspace, size_t workspace_bytes, ddk_stream_t s);
 /* Both steps in one launch for maps with HW <= 64 (also writes ctx, which the backward needs). */
+/* ddk_linattn_context on rows [k | v] (2 * heads * 32 floats per pixel) instead of [q | k | v] */
+int ddk_linattn_context_kv(const float* kv, float* ctx, int B, int HW, int heads, void* workspace, size_t workspace_bytes, ddk_stream_t s);
+/* Folded attention output (blocks.py:126-134 + to_out :124 + the PreNorm LayerNorm :57-60; C = heads * 32 = 128): q is linear in this
+ * attention, so y = to_out(ctx^T q) + b collapses to a per-image matrix applied to LayerNorm(x):
+ *   A[b] = W_out . blockdiag(ctx[b]^T) . (W_q o g)   [128][128],   a1[b] = W_out ctx^T (W_q g),   a2[b] = W_out ctx^T (W_q beta) + b_out
+ * so that y = r (A x) - r mean a1 + a2 with r = 1 / (std + eps) per pixel -- ddk_conv1x1_ws_images(x, A, NULL, resid = x, ..., a1, a2).
+ * ctx [B][4][32][32] from ddk_linattn_context(_kv); wqg = rows 0..127 of the LayerNorm-folded to_qkv weight [384][128], c1q / c2q the
+ * first 128 entries of its fold vectors; wout [128][128] = ddk_pack_conv_weight(to_out), bout [128] or NULL. */
+int ddk_attention_fold(const float* ctx, const float* wqg, const float* c1q, const float* c2q, const float* wout, const float* bout, float* A,
+                       float* a1, float* a2, int B, int C, int heads, ddk_stream_t s);
 int ddk_linattn_fused_small(const float* qkv, float* ctx, float* out, int B, int HW, int heads, ddk_stream_t s);
 /* out[b][n][h*32+e] = sum_d ctx[b][h][d][e] * q[b][n][h*32+d]. */
 int ddk_linattn_apply(const float* qkv, const float* ctx, float* out, int B, int HW, int heads, ddk_stream_t s);
@@ -294,6 +308,10 @@ int ddk_unet_forward(const ddk_unet* u, const void* packed, const float* x, cons
  * workgroups of one image are co-resident, GroupNorm + Mish + shift + residual finish INSIDE that launch (the workgroups exchange
  * their tile statistics through the workspace); 0 keeps the conv + GroupNorm-apply pair.  Changing it drops cached sampler graphs. */
 #define DDK_OPT_CLUSTER_GROUPNORM 1
+/* DDK_OPT_ATTENTION_FOLD (default 1): on maps with more than 256 pixels and 128 channels the attention block's q projection, apply and
+ * to_out run as ONE 1x1 conv of x with a per-image 128x128 matrix W_out . ctx^T . W_q (q is linear in this attention; the
+ * PreNorm LayerNorm is folded in as well); 0 keeps to_qkv / context / apply / to_out.  Same result up to fp32 summation order. */
+#define DDK_OPT_ATTENTION_FOLD 3
 int ddk_unet_set_option(ddk_unet* u, int option, int value);
 /* workgroups that ever gave up waiting for their cluster in this process (0 unless the GPU could not host a whole cluster) */
 unsigned ddk_debug_cluster_timeouts(void);

@@ -299,3 +299,50 @@ def test_conv1x1_ws_eligibility(ops):
     assert not ok(32768, 256, 384) and not ok(32768, 128, 96) and not ok(1024, 128, 128) and not ok(2048 + 32, 128, 128)
     with pytest.raises(lib.DDKError):
         ops.conv1x1_ws(torch.zeros(1, 8, 8, 128, device=DEV), torch.zeros(128, 128, device=DEV))
+
+
+# ---- folded attention (attention.hip attn_fold_kernel + conv1x1_ws per-image weights): blocks.py:8-14,57-71,116-134
+@pytest.mark.parametrize("B,H,W", [(2, 32, 32), (32, 32, 32), (4, 16, 32), (1, 64, 64)])
+def test_attention_folded_vs_torch(ops, B, H, W):
+    """Residual(PreNorm(LinearAttention)) with q projection + apply + to_out folded into one per-image 128x128 conv == the
+    reference formulation in torch (LayerNorm -> to_qkv -> softmax(k) -> two einsums -> to_out -> + x)"""
+    C, heads = 128, 4
+    x = rnd(B, C, H, W, seed=81) * 1.3 + 0.2
+    wq = rnd(3 * C, C, 1, 1, seed=82, scale=C ** -0.5)
+    wo, bo = rnd(C, C, 1, 1, seed=83, scale=C ** -0.5), rnd(C, seed=84, scale=0.1)
+    g, be = 1 + 0.2 * rnd(C, seed=85), 0.1 * rnd(C, seed=86)
+    xd = x.double()
+    std = xd.var(dim=1, unbiased=False, keepdim=True).sqrt()
+    xn = (xd - xd.mean(dim=1, keepdim=True)) / (std + 1e-5) * g.double().view(1, C, 1, 1) + be.double().view(1, C, 1, 1)
+    q, k, v = F.conv2d(xn, wq.double()).reshape(B, 3, heads, 32, H * W).unbind(1)
+    ctx = torch.einsum("bhdn,bhen->bhde", k.softmax(dim=-1), v)
+    o = torch.einsum("bhde,bhdn->bhen", ctx, q).reshape(B, C, H, W)
+    ref = F.conv2d(o, wo.double(), bo.double()) + xd
+    out = ops.attention_folded(to_nhwc(x).to(DEV), wq.to(DEV), g.to(DEV), be.to(DEV), wo.to(DEV), bo.to(DEV))
+    assert rel_err(to_nchw(out.cpu()).double(), ref) < 2e-5
+    out2 = ops.attention_folded(to_nhwc(x).to(DEV), wq.to(DEV), g.to(DEV), be.to(DEV), wo.to(DEV), bo.to(DEV))
+    assert torch.equal(out, out2)
+
+
+def test_attention_fold_option_gives_the_same_unet():
+    """plan option DDK_OPT_ATTENTION_FOLD: the folded attention block at the 32x32 level == to_qkv / context / apply / to_out
+    (<= 2e-5 of the output's max), bit-stable"""
+    from helpers import det_state, unet_cfg
+    from models import Unet
+    from utils import synthetic as syn
+    cfg = unet_cfg(128, 8)
+    net = Unet(cfg)
+    net.load_state_dict(det_state({k: v.shape for k, v in net.state_dict().items()}))
+    net = net.to(DEV).eval()
+    x = syn.synthetic_normal((32, 8, 32, 32), "fold.x").to(DEV)
+    t = torch.arange(32, device=DEV) * 29
+    with torch.no_grad():
+        y_on = net(x, t)
+        plan = net.plan()
+        plan.set_option(plan.OPT_ATTENTION_FOLD, 0)
+        y_off = net(x, t)
+        plan.set_option(plan.OPT_ATTENTION_FOLD, 1)
+        y_on2 = net(x, t)
+    assert torch.equal(y_on, y_on2)
+    assert not torch.equal(y_on, y_off)          # the two formulations round differently: the option really switches paths
+    assert rel_err(y_on.cpu(), y_off.cpu()) < 2e-5
