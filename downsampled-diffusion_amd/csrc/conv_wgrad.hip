@@ -563,6 +563,160 @@ static int launch_wgrad(const WgradParams& p, int ntiles_n, int ntiles_c, hipStr
     return check_launch("wgrad_kernel");
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// The same halo form for the NARROW 3x3 convs (N == 32, C == 32: the dDDPM encoder / decoder blocks at up to 262 144 pixels), where
+// the 64x64 tile above does not apply and the per-tap kernel re-reads both operands nine times (604 MB through the fabric for the
+// 64x64x64-pixel layer, 99 us).  One (n, c) tile = the whole filter, so the grid splits only the pixels: a workgroup is 4 INDEPENDENT
+// waves, each walking its own chunks (32 pixels: dY [32][32] + the chunk's input halo, double-buffered in the wave's private LDS,
+// no workgroup barrier in the loop) with all 9 taps accumulated per chunk (9 accumulators); at the end the four waves' accumulators
+// are summed in order through LDS and leave as ONE slab per workgroup.
+template <int WC>
+struct WgHalo32 {
+    static constexpr int R = 32 / WC, WP = WC + 2, HALO_PX = R * 3 * WP;
+    static constexpr int X_PIECES = (HALO_PX + 7) / 8;                 // 1-KiB pieces of 8 halo pixels x 32 channels
+    static constexpr int STAGE = 32 * 32 + X_PIECES * 8 * 32;          // floats
+    static constexpr size_t lds_bytes = (size_t)4 * 2 * STAGE * sizeof(float);
+};
+
+template <int WC>
+__global__ __launch_bounds__(256) void wgrad3x3_halo32_kernel(const WgHaloParams p) {
+    using G = WgHalo32<WC>;
+    constexpr int WP = G::WP, STAGE = G::STAGE, X_PIECES = G::X_PIECES, HALO_PX = G::HALO_PX;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int split = blockIdx.x;
+    float* wbuf = smem + wave * 2 * STAGE;
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) float*)wbuf;
+    const int g_begin = split * p.chunks_per_split;
+    const int g_end = min(p.n_chunks, g_begin + p.chunks_per_split);
+    const float* zero = g_zero_page_w + (lane & 7) * 4;
+    const int ppx = lane >> 3, pc4 = (lane & 7) * 4;                   // this lane's pixel inside a piece and its channel quad
+
+    auto issue = [&](int stage, int g) {
+        const unsigned st = lds_base + (unsigned)(stage * STAGE * 4);
+        const int m0 = g * 32;
+        int grow0, x0;
+        if (WC == 32) { const unsigned q = fdiv((unsigned)m0, p.dW_); grow0 = (int)q; x0 = m0 - (int)q * p.W; }
+        else { grow0 = m0 / WC; x0 = 0; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {                                  // dY chunk: [32 px][32 n]
+            const int m = m0 + j * 8 + ppx;
+            const float* g_ = m < p.M ? p.dy + (long long)m * 32 + pc4 : zero;
+            lds_dma16_w(g_, (unsigned)__builtin_amdgcn_readfirstlane((int)(st + (unsigned)(j * 1024))));
+        }
+#pragma unroll
+        for (int j = 0; j < X_PIECES; ++j) {                           // the chunk's input halo: [R][3 rows][WC + 2][32 c]
+            const int hp = j * 8 + ppx;
+            const int r = hp / (3 * WP), rem = hp - r * (3 * WP);
+            const int dyi = rem / WP, xx = rem - dyi * WP;
+            const unsigned grow = (unsigned)(grow0 + r);
+            const unsigned b = fdiv(grow, p.dH_);
+            const int yy = (int)(grow - b * (unsigned)p.H) + dyi - 1;
+            const int xc = x0 + xx - 1;
+            const bool ok = hp < HALO_PX && (int)b < p.B && (unsigned)yy < (unsigned)p.H && (unsigned)xc < (unsigned)p.W;
+            const float* g_ = ok ? p.x + (((long long)b * p.H + yy) * p.W + xc) * 32 + pc4 : zero;
+            lds_dma16_w(g_, (unsigned)__builtin_amdgcn_readfirstlane((int)(st + (unsigned)(32 * 32 * 4 + j * 1024))));
+        }
+    };
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    float bsum = 0.f;
+    const bool do_bias = p.bias_slab != nullptr;
+    const int fh = lane >> 5, l31 = lane & 31;
+    int hb_off[16];
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+        const int k = 2 * kk + fh;
+        const int r = k / WC, xl = k - r * WC;
+        hb_off[kk] = 32 * 32 + (r * 3 * WP + xl) * 32 + l31;           // tap (dy, dx) adds ((dy + 1) * WP + dx + 1) * 32
+    }
+    {
+        const int NN = p.N, cxx = p.cx;
+        asm volatile("" ::"s"(p.slab), "s"(p.bias_slab), "s"(NN), "s"(cxx));
+    }
+    int g = g_begin + wave;                                            // this wave's chunks: g_begin + wave, + 4, ...
+    if (g < g_end) issue(0, g);
+    for (int it = 0; g < g_end; g += 4, ++it) {
+        const int stage = it & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this wave's own pieces (its buffers are private)
+        if (g + 4 < g_end) issue(stage ^ 1, g + 4);
+        const float* S = wbuf + stage * STAGE;
+        float a[2], b[2][9];
+        auto load_pair = [&](int slot, int kk) {
+            a[slot] = S[fh * 32 + l31 + kk * 64];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) b[slot][t] = S[hb_off[kk] + ((t / 3) * WP + (t % 3)) * 32];
+        };
+        load_pair(0, 0);
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            const int cur = kk & 1;
+            if (kk + 1 < 16) load_pair(cur ^ 1, kk + 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur], b[cur][t], acc[t], 0, 0, 0);
+            if (do_bias) bsum += a[cur];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+    // the four waves' sums meet in LDS, tap by tap (fixed order: wave 0..3), and leave as slab[split][n][tap][c]
+    __syncthreads();                                                   // every wave is done with its buffers
+    float* red = smem;                                                 // [4 waves][32 n][32 c]
+    float* outp = p.slab + (long long)split * 32 * 9 * 32;
+#pragma unroll                                                         // (a rolled loop would index acc[] dynamically = scratch memory)
+    for (int t = 0; t < 9; ++t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh) * 32 + l31] = acc[t][r];
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = tid + i * 256, n = e >> 5, c = e & 31;
+            const float v = (red[e] + red[1024 + e]) + (red[2048 + e] + red[3072 + e]);
+            outp[((long long)n * 9 + t) * 32 + c] = v;
+        }
+        __syncthreads();
+    }
+    if (do_bias) {
+        const float tsum = bsum + __shfl_xor(bsum, 32, 64);
+        if (lane < 32) red[wave * 32 + lane] = tsum;
+        __syncthreads();
+        if (tid < 32) p.bias_slab[(long long)split * 32 + tid] = (red[tid] + red[32 + tid]) + (red[64 + tid] + red[96 + tid]);
+    }
+}
+
+// plan of the narrow halo kernel: <= 256 workgroups of 4 waves, at least 2 chunks per wave
+static bool wgrad_halo32_plan(int kind, int B, int H, int W, int cx, int N, int& wc, int& splits, int& cps, int& n_chunks) {
+#ifdef DDK_TUNING
+    if (getenv("DDK_NO_WGRAD_HALO32")) return false;
+#endif
+    if (kind != DDK_CONV3X3_S1 || N != 32 || cx != 32) return false;
+    if (W <= 32) { if (W < 8 || 32 % W) return false; wc = W; }
+    else { if (W % 32) return false; wc = 32; }
+    const long long M = (long long)B * H * W;
+    if (M % 32) return false;
+    if (W < 32 && ((long long)B * H) % (32 / W)) return false;
+    n_chunks = (int)(M / 32);
+    if (n_chunks < 256) return false;
+    long long s = n_chunks / 8;
+    if (s > 256) s = 256;
+    cps = (int)ceil_div(n_chunks, s);
+    splits = (int)ceil_div(n_chunks, cps);
+    return true;
+}
+
+template <int WC>
+static int launch_wgrad_halo32(const WgHaloParams& p, hipStream_t st) {
+    hipLaunchKernelGGL((wgrad3x3_halo32_kernel<WC>), dim3((unsigned)p.splits), dim3(256), WgHalo32<WC>::lds_bytes, st, p);
+    return check_launch("wgrad3x3_halo32_kernel");
+}
+
 // > 64 KB of dynamic LDS needs the attribute, once per device (ensure_device_init, core.hip)
 int wgrad_init_device() {
 #define WG_ATTR(WC)                                                                                                               \
@@ -570,6 +724,11 @@ int wgrad_init_device() {
                                 (int)wgrad_halo_lds_bytes<WC>()));
     WG_ATTR(32) WG_ATTR(16) WG_ATTR(8) WG_ATTR(4)
 #undef WG_ATTR
+#define WG_ATTR32(WC)                                                                                                               \
+    DDK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3_halo32_kernel<WC>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                (int)WgHalo32<WC>::lds_bytes));
+    WG_ATTR32(32) WG_ATTR32(16) WG_ATTR32(8)
+#undef WG_ATTR32
     return DDK_OK;
 }
 
@@ -584,6 +743,7 @@ size_t ddk_conv_wgrad_workspace_bytes(int kind, int B, int H, int W, int cx, int
     if (!wgrad_geometry(kind, H, W, Hm, Wm, stride, tapmode, ntaps)) return 0;
     int wc, hs, cps, nch;
     // + [splits][N] for the column sums of dy (ddk_conv_wgrad_bias)
+    if (wgrad_halo32_plan(kind, B, H, W, cx, N, wc, hs, cps, nch)) return (size_t)hs * N * (9 * cx + 1) * sizeof(float);
     if (wgrad_halo_plan(kind, B, H, W, cx, N, wc, hs, cps, nch)) return (size_t)hs * N * (9 * cx + 1) * sizeof(float);
     const WgChoice c = wgrad_choice(N, cx, ntaps, (long long)B * Hm * Wm);
     return (size_t)c.splits * N * (ntaps * cx + 1) * sizeof(float);
@@ -615,7 +775,8 @@ int ddk_conv_wgrad_bias(int kind, const float* x, const float* dy, float* grad_w
     DDK_TRY(ensure_device_init());
     {
         int wc, hs, cps, nch;
-        if (wgrad_halo_plan(kind, B, H, W, cx, N, wc, hs, cps, nch)) {
+        const bool narrow = wgrad_halo32_plan(kind, B, H, W, cx, N, wc, hs, cps, nch);
+        if (narrow || wgrad_halo_plan(kind, B, H, W, cx, N, wc, hs, cps, nch)) {
             const size_t need_h = (size_t)hs * N * (9 * cx + (grad_b ? 1 : 0)) * sizeof(float);
             if (workspace_bytes < need_h) {
                 set_error("conv_wgrad: workspace too small (%zu < %zu)", workspace_bytes, need_h);
@@ -628,7 +789,8 @@ int ddk_conv_wgrad_bias(int kind, const float* x, const float* dy, float* grad_w
             hp.splits = hs; hp.chunks_per_split = cps; hp.n_chunks = nch;
             hp.dH_ = make_fastdiv((unsigned)H); hp.dW_ = make_fastdiv((unsigned)W);
             int rc;
-            if (wc == 32) rc = launch_wgrad_halo<32>(hp, st);
+            if (narrow) rc = wc == 32 ? launch_wgrad_halo32<32>(hp, st) : (wc == 16 ? launch_wgrad_halo32<16>(hp, st) : launch_wgrad_halo32<8>(hp, st));
+            else if (wc == 32) rc = launch_wgrad_halo<32>(hp, st);
             else if (wc == 16) rc = launch_wgrad_halo<16>(hp, st);
             else if (wc == 8) rc = launch_wgrad_halo<8>(hp, st);
             else rc = launch_wgrad_halo<4>(hp, st);

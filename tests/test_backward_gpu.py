@@ -42,6 +42,9 @@ CONV_BWD = [
     ("s1", 2, 32, 32, 64, 0, 64), ("s1", 3, 8, 8, 128, 0, 64), ("s1", 1, 64, 64, 64, 0, 128), ("s1", 6, 4, 4, 64, 64, 128),
     # the narrow convs of the dDDPM encoder / decoder at many pixels: one- and two-wave tiles, up to 256 pixel splits
     ("s1", 4, 64, 64, 32, 0, 32), ("1x1", 4, 64, 64, 64, 0, 32), ("1x1", 5, 64, 64, 32, 0, 64), ("1x1", 16, 64, 64, 64, 0, 64),
+    # narrow halo weight-gradient kernel (N == C == 32, >= 256 chunks): row segments (W = 64), whole rows at W = 32 / 16 / 8, ragged
+    # chunk counts per wave
+    ("s1", 8, 32, 32, 32, 0, 32), ("s1", 64, 16, 16, 32, 0, 32), ("s1", 136, 8, 8, 32, 0, 32), ("s1", 3, 64, 64, 32, 0, 32),
 ]
 
 
