@@ -485,13 +485,22 @@ static WgChoice wgrad_choice(int N, int cx, int ntaps, long long M) {
     WgChoice c;
     c.bn = tile32(N);
     c.bc = tile32(cx);
+    int target_waves = 2048;
+    // Few pixels (the UNet levels below 32x32 at batch 64): a 128x128 tile is one wave per SIMD walking 8 chunks with a drain per chunk;
+    // 64x64 tiles give four times the workgroups to hide that latency behind -- the eight per-tap shapes of the cfg3 step 316 -> 222 us
+    // (tools/wgrad_bench_cfg3.py, profiles/r03_train_wgrad.txt).  From 65536 pixels on the larger tile wins (101 vs 110 us).
+    if (M < 65536) { if (c.bn > 64) c.bn = 64; if (c.bc > 64) c.bc = 64; }
+#ifdef DDK_TUNING
+    if (const char* e = getenv("DDK_WGRAD_TILE")) { const int t = atoi(e); if (c.bn > t) c.bn = t; if (c.bc > t) c.bc = t; }   // A/B knobs
+    if (const char* e = getenv("DDK_WGRAD_WAVES")) target_waves = atoi(e);
+#endif
     const long long tiles = ceil_div(N, c.bn) * ceil_div(cx, c.bc) * ntaps;
     // The loop is a 2-stage ring with a drain per 32-pixel chunk: a wave hides its DMA latency only behind OTHER waves of
     // its SIMD.  4-wave tiles want ~512 workgroups (two per CU); the one- and two-wave tiles of narrow convs (the 32 / 64
     // channel encoder / decoder of the dDDPM at up to 262144 pixels) ran 64 splits = 64-513 waves on 1024 SIMDs at 1.5 us
     // per chunk (235 us for 4.8 GFLOP); they get the same ~2048 waves now (profiles/r03_train_wgrad.txt).
     const int waves = (c.bn >= 64 && c.bc >= 64) ? 4 : ((c.bn * c.bc) / 1024 >= 4 ? 4 : (c.bn * c.bc) / 1024);
-    long long s = ceil_div(2048 / waves, tiles);
+    long long s = ceil_div(target_waves / waves, tiles);
     const long long max_s = M / 256 > 0 ? M / 256 : 1;   // at least 8 k-chunks per split
     if (s > max_s) s = max_s;
     if (s > 256) s = 256;
@@ -528,12 +537,14 @@ static bool wgrad_halo_plan(int kind, int B, int H, int W, int cx, int N, int& w
     if (n_chunks < 128) return false;              // tiny maps: the per-tap kernel's 9x more workgroups win
     const long long tiles = (long long)(N / 64) * (cx / 64);
 #ifdef DDK_TUNING
-    const int target = getenv("DDK_WGRAD_HALO_WGS") ? atoi(getenv("DDK_WGRAD_HALO_WGS")) : 256;
+    const int target = getenv("DDK_WGRAD_HALO_WGS") ? atoi(getenv("DDK_WGRAD_HALO_WGS")) : (n_chunks >= 1024 ? 512 : 256);
 #else
-    const int target = 256;   // 256 and 512 workgroups time the same; 256 halves the slabs
+    // 512 workgroups are 5-8 % faster than 256 on the large maps (19 GFLOP layers: 194 -> 179 us, 186 -> 177; round 2 saw no
+    // difference before the reduce kernel was widened); on small ones 256 halve the slabs for the same time
+    const int target = n_chunks >= 1024 ? 512 : 256;
 #endif
     long long s = ceil_div(target, tiles);
-    const long long max_s = n_chunks / 8 > 0 ? n_chunks / 8 : 1;
+    const long long max_s = n_chunks / 4 > 0 ? n_chunks / 4 : 1;   // at least 4 chunks per split (8 left 128 -> 256 @8x8 at 128 workgroups)
     if (s > max_s) s = max_s;
     if (s > 128) s = 128;
     cps = (int)ceil_div(n_chunks, s);
