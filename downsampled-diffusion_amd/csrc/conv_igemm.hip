@@ -1099,6 +1099,9 @@ static Choice choose_tile(long long M, int N, int nphase, int kiters) {
     else { order = order_wide; n_order = 3; }
     // Rules fitted to tools/conv_bench.py sweeps on MI355X (profiles/r02_conv_sweep.txt):
     // 1. short contractions (1x1 convs, <= 8 k-chunks): smallest tile, no split -- prologue/epilogue bound;
+    //    (32-wide outputs on many pixels -- the dDDPM encoder / decoder 1x1 convs at up to 262144 pixels -- take the 4-wave 128x32
+    //    tile instead of the 2-wave 64x32 one: 15.4 -> 10.6 us at 131072 pixels, profiles/r03_conv_clock_sweep.txt)
+    if (kiters <= 8 && N % 64 != 0 && n_tiles(T128x32) >= 512) return with_splits(T128x32, 1);
     if (kiters <= 8) return with_splits(order[n_order - 1], 1);
     // 2. the largest tile that gives >= 512 workgroups without splitting k;
     for (int i = 0; i < n_order; ++i)
