@@ -4,7 +4,7 @@
 cases: wino (conv3x3 128->128 @32x32 B=32, Winograd), gn (GroupNorm-apply from partials, 32x32x32x128), local4 (conv+GroupNorm+Mish
 one launch, 256->256 @4x4), wlocal8 (the same @8x8, Winograd form), first (conv_first 8->128 @32x32), tail (final_tail_kernel),
 cluster16 (conv3x3 256->256 @16x16 with GroupNorm finished in the launch), ws (to_out 1x1 128->128 + bias + residual @32x32,
-weights-stationary kernel)."""
+weights-stationary kernel), fold (attn_fold_kernel), halo32 (wgrad3x3_halo32_kernel), gnbig (gn_apply_kernel on the 256x256 tensor)."""
 import os
 import sys
 
@@ -58,6 +58,22 @@ elif case == "ws":
     x, w = torch.randn(B, 32, 32, 128, device=dev), torch.randn(128, 128, device=dev) * 128 ** -0.5
     b, r = torch.zeros(128, device=dev), torch.randn(B, 32, 32, 128, device=dev)
     fn = lambda: ops.conv1x1_ws(x, w, b, r)
+elif case == "fold":           # the folded attention block's per-image matrix build at cfg4 (32 images, C = 128)
+    ctx = torch.randn(B, 4, 32, 32, device=dev) * 0.1
+    wq, c1, c2 = torch.randn(128, 128, device=dev) * 0.09, torch.randn(128, device=dev), torch.randn(128, device=dev)
+    wo, bo = torch.randn(128, 128, device=dev) * 0.09, torch.zeros(128, device=dev)
+    A, a1, a2 = torch.empty(B, 128, 128, device=dev), torch.empty(B, 128, device=dev), torch.empty(B, 128, device=dev)
+    from ddk import lib as _L
+    fn = lambda: _L.check(_L.load().ddk_attention_fold(_L.ptr(ctx), _L.ptr(wq), _L.ptr(c1), _L.ptr(c2), _L.ptr(wo), _L.ptr(bo), _L.ptr(A),
+                                                       _L.ptr(a1), _L.ptr(a2), B, 128, 4, _L.stream()), "attention_fold")
+elif case == "halo32":         # narrow weight gradient: 3x3 32->32 on 64 x 64 x 64 pixels (the dDDPM encoder's first block at cfg3)
+    x, dy = torch.randn(64, 64, 64, 32, device=dev), torch.randn(64, 64, 64, 32, device=dev)
+    gw = torch.zeros(32, 32, 3, 3, device=dev)
+    fn = lambda: ops.conv_wgrad_(ops.CONV3X3_S1, x, dy, gw, c_real=32, cw=32, c_off=0)
+elif case == "gnbig":          # large-slab GroupNorm apply pass: 8 x 256 x 256 x 128 (cfg5 top level)
+    x = torch.randn(8, 256, 256, 128, device=dev)
+    gam, bet, temb = torch.ones(128, device=dev), torch.zeros(128, device=dev), torch.randn(8, 128, device=dev)
+    fn = lambda: ops.groupnorm_mish(x, gam, bet, temb=temb)
 elif case == "cluster16":
     x, w = torch.randn(B, 16, 16, 256, device=dev), rw(256, 256)
     wu, b = ops.pack_conv_weight_wino(w), torch.zeros(256, device=dev)
