@@ -28,8 +28,9 @@ import torch  # noqa: E402
 
 FP32_PEAK_TFLOPS = 157.3      # MI355X fp32 matrix = vector peak (MI355X_MICROARCH.md, chip-level parameters)
 T_STEPS = 1000
-WINO_PMC = "r03_wino_pmc.json"      # committed counter summary of the timed Winograd kernel (tools/pmc_summary.py)
+WINO_PMC = "r04_wino_pmc.json"      # committed counter summary of the timed Winograd kernel (tools/pmc_summary.py)
 HBM_PMC = "r03_gn_pmc.json"         # ... of the GroupNorm-apply kernel (FETCH_SIZE / WRITE_SIZE passes)
+LOCAL_PMC = "r04_wlocal8_pmc.json"  # ... of the image-local conv + GroupNorm kernel (8x8 maps)
 
 
 def log(*a):
@@ -129,6 +130,30 @@ def time_conv_roofline(device):
                      "9.664 GFLOP on the same time and may exceed the peak",
                 direct_kernel={"kernel": "conv3x3_halo_kernel<0> (direct implicit GEMM, same shape; used when a shape is not Winograd-eligible)",
                                "launch_us": sec_direct * 1e6, "achieved": flops / sec_direct / 1e12, "frac": flops / sec_direct / 1e12 / FP32_PEAK_TFLOPS})
+
+
+def time_local_roofline(device):
+    """Second-largest kernel family of the step (19 of its launches): conv3x3 + GroupNorm + Mish (+ shift, + residual) in ONE launch on
+    the small maps -- here the 8x8 form (conv3x3_gn_wlocal_kernel, Winograd inside an image-local tiling) at its cfg4 shape
+    256 -> 256, batch 32.  Priced like the dominant kernel: MFMA FLOPs issued (16 multiplies per 2x2 tile and channel pair) over the
+    live launch time against the fp32 MFMA peak."""
+    from ddk import ops
+    B, H, C, N = 32, 8, 256, 256
+    g = torch.Generator(device="cpu").manual_seed(1)
+    x = torch.randn(B, H, H, C, generator=g).to(device)
+    w = (torch.randn(N, C, 3, 3, generator=g) * (C * 9) ** -0.5).to(device)
+    gam, bet, b = torch.ones(N, device=device), torch.zeros(N, device=device), torch.zeros(N, device=device)
+    temb = torch.randn(B, N, generator=g).to(device)
+    wl = ops.pack_conv_weight_wino_local(w)
+    sec = graph_kernel_seconds(device, lambda: ops.conv3x3_gn_mish_wino(x, wl, b, gam, bet, temb=temb))
+    executed = 2.0 * B * (H * H / 4) * 16 * C * N
+    pm = _profile_json(LOCAL_PMC, "downsampled-diffusion_amd/csrc/conv_local.hip")
+    src = f"profiles/{LOCAL_PMC} (rocprofv3 --pmc, separate passes)" if pm else None
+    return dict(kernel="conv3x3_gn_wlocal_kernel: conv3x3 256->256 @8x8 B=32 + GroupNorm + Mish + time shift in one launch",
+                bound="mfma", achieved=executed / sec / 1e12, peak=FP32_PEAK_TFLOPS, unit="TFLOP/s", frac=executed / sec / 1e12 / FP32_PEAK_TFLOPS,
+                traffic=pm["traffic_bytes_per_launch"] if pm else None, traffic_source=src,
+                mfma_busy=pm["mfma_busy"] if pm else None, mfma_busy_source=src, launch_us=sec * 1e6, executed_gflop=executed / 1e9,
+                algorithmic_gflop=2.0 * B * H * H * 9 * C * N / 1e9)
 
 
 def time_hbm_rooflines(device):
@@ -263,6 +288,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true", help="skip the secondary cfg3 training-step timing")
+    ap.add_argument("--no-full-chain", action="store_true", help="skip the one full T=1000 chain + decode behind the timed steps")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -324,12 +350,15 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    clk_steps, clk_chain = ops.ClockProbe(device), ops.ClockProbe(device)
     with torch.no_grad():
         run_steps(max(args.warmup, 1))
         decode()
         fence()
+        clk_steps.probe()
         t0 = time.perf_counter()
         run_steps(args.steps)
+        clk_steps.probe()
         fence()
         elapsed = time.perf_counter() - t0
         dec = []
@@ -341,11 +370,26 @@ def main():
             dec.append(time.perf_counter() - t1)
         t_decode = min(dec)
         assert torch.isfinite(img).all() and img.shape == (B, 3, 256, 256)
+        # ONE real job unit, not an extrapolation: a full T = 1000 chain from fresh x_T plus its decode (what
+        # generate_model_samples.py times per batch, reference generate_model_samples.py:42-58), under a sustained clock
+        full_chain_s = None
+        if not args.no_full_chain:
+            x.copy_(ops.randn((B, S, S, C), device, seed=4321, step=T_STEPS, stream_id=rank))
+            fence()
+            clk_chain.probe()
+            t2 = time.perf_counter()
+            run_steps(T_STEPS)
+            img = decode()
+            clk_chain.probe()
+            fence()
+            full_chain_s = time.perf_counter() - t2
+            assert torch.isfinite(img).all()
 
     if dist_on:
-        tmax = torch.tensor([elapsed, t_decode], device=device, dtype=torch.float64)
+        tmax = torch.tensor([elapsed, t_decode, full_chain_s or 0.0], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         elapsed, t_decode = float(tmax[0]), float(tmax[1])
+        full_chain_s = float(tmax[2]) if full_chain_s is not None else None
 
     t_step = elapsed / args.steps
     images_per_sec = B * world / (T_STEPS * t_step + t_decode)
@@ -364,7 +408,9 @@ def main():
                                    "UNet chan 128 dims (1,2,2,2) + x3 ConvResNet decoder; batch-sharded, no collective in the loop",
                        "batch_per_gpu": B, "global_batch": B * world, "T": T_STEPS, "unet_step_ms": t_step * 1e3,
                        "decode_ms": t_decode * 1e3, "hip_graph": model.use_graph,
-                       "weights_broadcast_bytes": bcast_bytes},
+                       "weights_broadcast_bytes": bcast_bytes,
+                       "shader_clock_ghz_timed_steps": clk_steps.ghz(),
+                       "in_launch_groupnorm": plan._cluster},
             "roofline": roof,
             "roofline_step": {"bound": "mfma", "algorithmic_gflop": flops_step / 1e9, "executed_gflop": flops_exec / 1e9,
                               "ms_per_step": t_step * 1e3, "achieved": flops_exec / t_step / 1e12, "peak": FP32_PEAK_TFLOPS,
@@ -373,7 +419,18 @@ def main():
                               "note": "the whole reverse step: FLOPs issued by every kernel of the plan (Winograd convs at 16/36 of "
                                       "their direct multiplies, ddk_unet_flops_executed) over the measured step time"},
             "roofline_hbm": roof_hbm,
+            "roofline_local": time_local_roofline(device),
         }
+        if full_chain_s is not None:
+            vfc = B * world / full_chain_s
+            out["value_full_chain"] = vfc
+            out["config"]["full_chain_s"] = full_chain_s
+            out["config"]["shader_clock_ghz_full_chain"] = clk_chain.ghz()
+            out["config"]["full_chain_vs_extrapolated"] = vfc / images_per_sec
+            out["config"]["full_chain_agrees_within_3pct"] = bool(abs(vfc / images_per_sec - 1) <= 0.03)
+            if not out["config"]["full_chain_agrees_within_3pct"]:
+                log(f"WARNING: the full T={T_STEPS} chain ({vfc:.2f} images/s) and the value extrapolated from {args.steps} timed steps "
+                    f"({images_per_sec:.2f}) differ by more than 3 %")
         if world == 1 and not args.no_train:
             try:
                 out["config"]["train_step_ms_cfg3_bs64"], out["roofline_train"] = train_step_ms(device)

@@ -26,6 +26,7 @@
 //   one s_barrier per stage: B(S) = V of stages <= S+1 written, U of stages <= S landed, everyone done reading stage S-1;
 //     before it a wave waits only for the DMA it issued one stage earlier (s_waitcnt vmcnt(4)); the matrix waves prefetch
 //     stage S+1's first A fragments in the last quarter of stage S.
+#include <atomic>
 #include <cstdlib>
 
 #include "conv_common.h"
@@ -58,8 +59,9 @@ struct WinoParams {
     const long long* gn_temb_rows; // row of image b (sampler: its timestep), null = b
     int gn_temb_stride;
     float gn_eps;
-    float* cl_rec;                 // [m tile][n tile][16 floats]: 64-byte record, {mean, M2} of up to 8 groups
+    float* cl_rec;                 // [m tile][n tile][32 floats]: 64-byte record, {mean, M2} of up to 8 groups, alone on its 128-byte line
     unsigned* cl_cnt;              // [image][n tile][16]: [0] arrivals, [1] departures (self-resetting)
+    unsigned* cl_fail;             // workgroups of launches on THIS workspace that gave up waiting (sticky; ddk_unet_cluster_check)
     int cl_np;                     // m tiles per image = workgroups per cluster
 };
 
@@ -142,6 +144,7 @@ __device__ __forceinline__ float4 f4sub(float4 a, float4 b) { return make_float4
 __device__ unsigned long long g_wino_stamps[8 * 1024];
 
 __device__ unsigned g_wino_cl_timeouts;       // workgroups that gave up waiting for their cluster (must stay 0; see ddk_debug_cluster_timeouts)
+constexpr unsigned long long CL_TIMEOUT_TICKS = 2000000ull;   // 20 ms of the 100 MHz s_memrealtime clock: a peer is normally < 0.1 ms away
 
 template <int DBG, bool CL = false>
 __global__ __launch_bounds__(512) void conv3x3_wino_kernel(const WinoParams p) {
@@ -499,12 +502,17 @@ __global__ __launch_bounds__(512) void conv3x3_wino_kernel(const WinoParams p) {
             // ---- cluster exchange (MI355X_MICROARCH.md, "Valid forms", first row of the sc1 table): every record byte is stored
             // sc1 by wave 0, which drains its stores (vmcnt(0)) before its lane 0 adds to the cluster's arrival counter (agent
             // scope); lane 0 polls the counter with sc1 loads, the other waves pass a workgroup barrier behind it, and every record
-            // is read with sc1 loads.  One workgroup per CU (144 KB of LDS).  The workgroups of a cluster have consecutive launch
-            // indices inside one XCD's run, so they are co-resident whenever the dispatcher works in order; the spin is bounded
-            // anyway (a give-up leaves wrong numbers and a non-zero g_wino_cl_timeouts, never a hang).
+            // is read with sc1 loads: row 1 of that table (one lane signals for the workgroup's 8-byte sc1 stores, sc1 poll, the
+            // other waves behind a workgroup barrier, 8-byte sc1 loads, hipMalloc memory, ONE workgroup per CU -- 144 KB of LDS).
+            // Measured form, not an architectural guarantee; a record has its 128-byte line to itself.  The workgroups of a
+            // cluster have consecutive launch indices inside one XCD's run, so they are co-resident whenever the dispatcher works
+            // in order on a whole, otherwise idle device (conv_wino_cluster_device_ok gates on that); the wait is bounded by wall
+            // time anyway, and a give-up is never silent: NaN output + sticky counters (ddk_unet_cluster_check).
             const int image = tile_m / p.cl_np;
-            unsigned long long* rec = reinterpret_cast<unsigned long long*>(p.cl_rec) + ((long long)tile_m * gridDim.y + tile_n) * 8;
+            unsigned long long* rec = reinterpret_cast<unsigned long long*>(p.cl_rec) + ((long long)tile_m * gridDim.y + tile_n) * 16;
             unsigned* cnt = p.cl_cnt + ((long long)image * gridDim.y + tile_n) * 16;
+            int* gave_up = reinterpret_cast<int*>(red + 256);       // LDS word: this workgroup's wait timed out
+            if (tid == 0) *gave_up = 0;                             // ordered before its readers by the barrier below
             if (tid < 16 && (cq & (qpg - 1)) == 0) {
                 const unsigned long long bits = (unsigned long long)__float_as_uint(mean) | ((unsigned long long)__float_as_uint(m2) << 32);
                 __hip_atomic_store(rec + gl, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -552,11 +560,20 @@ __global__ __launch_bounds__(512) void conv3x3_wino_kernel(const WinoParams p) {
                 if (lane == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 load_affine();
                 load_resid();
-                if (lane == 0) {
-                    unsigned spins = 0;
-                    while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)p.cl_np) {
+                if (lane == 0 && __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)p.cl_np) {
+                    // peers not all here yet: poll, bounded by WALL time (co-residency of a cluster is an assumption about the
+                    // dispatcher, not a guarantee: a foreign kernel, a CU mask or a partitioned device breaks it).  A give-up is
+                    // sticky and loud: the counters below make ddk_unet_cluster_check() fail and this tile's output is NaN.
+                    const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();
+                    for (;;) {
                         __builtin_amdgcn_s_sleep(4);
-                        if (++spins > (1u << 22)) { atomicAdd(&g_wino_cl_timeouts, 1u); break; }
+                        if (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)p.cl_np) break;
+                        if (__builtin_amdgcn_s_memrealtime() - t_begin > CL_TIMEOUT_TICKS) {
+                            atomicAdd(&g_wino_cl_timeouts, 1u);
+                            if (p.cl_fail) __hip_atomic_fetch_add(p.cl_fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            *gave_up = 1;
+                            break;
+                        }
                     }
                 }
             }
@@ -564,13 +581,14 @@ __global__ __launch_bounds__(512) void conv3x3_wino_kernel(const WinoParams p) {
             // the image's statistics: the np records of this thread's group merged in tile order (the arithmetic of
             // gn_apply_parts_kernel, so both paths give the same bits)
             const unsigned long long* r0 = reinterpret_cast<const unsigned long long*>(p.cl_rec) +
-                                           ((long long)image * p.cl_np * gridDim.y + tile_n) * 8 + gl;
+                                           ((long long)image * p.cl_np * gridDim.y + tile_n) * 16 + gl;
+            const bool poisoned = *gave_up != 0;
             float rm[8], rq[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 rm[i] = 0.f; rq[i] = 0.f;
                 if (i < p.cl_np) {
-                    const unsigned long long bits = __hip_atomic_load(r0 + (long long)i * gridDim.y * 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned long long bits = __hip_atomic_load(r0 + (long long)i * gridDim.y * 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     rm[i] = __uint_as_float((unsigned)bits);
                     rq[i] = __uint_as_float((unsigned)(bits >> 32));
                 }
@@ -585,7 +603,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino_kernel(const WinoParams p) {
             float ms = 0.f;
 #pragma unroll
             for (int i = 0; i < 8; ++i) if (i < p.cl_np) ms += rm[i];
-            const float gmean = ms / (float)p.cl_np;
+            const float gmean = poisoned ? __builtin_nanf("") : ms / (float)p.cl_np;
             float gm2 = 0.f, gd2 = 0.f;
 #pragma unroll
             for (int i = 0; i < 8; ++i) if (i < p.cl_np) { gm2 += rq[i]; gd2 += (rm[i] - gmean) * (rm[i] - gmean); }
@@ -667,7 +685,26 @@ int conv_wino_cluster_np(int B, int H, int W, int cin, int N, int groups) {
 }
 size_t conv_wino_cluster_ws_floats(int B, int H, int W, int N) {
     const long long mt = (long long)B * (H / 2) * (W / 2) / WBT, nt = N / WBN;
-    return (size_t)(mt * nt * 16 + (long long)B * nt * 16);
+    return (size_t)(mt * nt * 32 + (long long)B * nt * 16);
+}
+
+// The co-residency the exchange relies on is only plausible on a whole MI355X in SPX mode with no CU mask: 256 CUs in 8 XCDs.
+// Anything else (CPX / DPX / QPX partitions, HSA_CU_MASK, ROC_GLOBAL_CU_MASK) takes the conv + GroupNorm-apply pair.
+bool conv_wino_cluster_device_ok() {
+    static std::atomic<int> cached[64];                      // 0 unknown, 1 ok, 2 not ok
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+    int v = cached[dev].load(std::memory_order_relaxed);
+    if (v == 0) {
+        int cus = 0, xccs = 0;
+        bool ok = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus == 256;
+        ok = ok && hipDeviceGetAttribute(&xccs, hipDeviceAttributeNumberOfXccs, dev) == hipSuccess && xccs == 8;
+        ok = ok && !getenv("HSA_CU_MASK") && !getenv("ROC_GLOBAL_CU_MASK");
+        (void)hipGetLastError();
+        v = ok ? 1 : 2;
+        cached[dev].store(v, std::memory_order_relaxed);
+    }
+    return v == 1;
 }
 
 // a: validated by conv_forward (shapes, alignment).  Writes the result (or, with splits > 1, the slabs in a.workspace).
@@ -681,7 +718,7 @@ int conv_wino_forward(const ddk_conv_args& a, int splits, hipStream_t st, const 
                     "conv(wino): in-launch GroupNorm arguments");
         p.gn_gamma = fuse->gamma; p.gn_beta = fuse->beta; p.gn_temb = fuse->temb; p.gn_temb_rows = fuse->temb_rows;
         p.gn_temb_stride = fuse->temb_stride; p.gn_eps = fuse->eps;
-        p.cl_rec = fuse->records; p.cl_cnt = fuse->counters; p.cl_np = np;
+        p.cl_rec = fuse->records; p.cl_cnt = fuse->counters; p.cl_fail = fuse->fail; p.cl_np = np;
         p.groups = fuse->groups;
         p.cpg = a.N / fuse->groups;
     }
@@ -722,6 +759,16 @@ int conv_wino_forward(const ddk_conv_args& a, int splits, hipStream_t st, const 
     }
     hipLaunchKernelGGL(conv3x3_wino_kernel<0>, grid, dim3(512), W_LDS_FLOATS * sizeof(float), st, p);
     return check_launch("conv3x3_wino_kernel");
+}
+
+// test support: a "foreign" kernel that holds CUs (through its LDS footprint) for a bounded wall time
+__global__ __launch_bounds__(256) void occupy_kernel(unsigned long long ticks, unsigned* sink) {
+    extern __shared__ float occupy_lds[];
+    occupy_lds[threadIdx.x] = (float)threadIdx.x;
+    __syncthreads();
+    const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t_begin < ticks) __builtin_amdgcn_s_sleep(32);
+    if (occupy_lds[(threadIdx.x + 1) & 255] < 0.f && sink) *sink = 1;
 }
 
 unsigned conv_wino_cluster_timeouts() {
@@ -774,24 +821,49 @@ extern "C" int ddk_conv_wino_splits(int B, int H, int W, int cin, int N) {
 /* Block of models/unet/blocks.py:75-84,110-115 in ONE Winograd launch on maps whose images span several workgroups (32x32,
  * 16x16): see WinoGnFuse / the CL variant above. */
 extern "C" int ddk_conv3x3_gn_mish_cluster_ok(int B, int H, int W, int cin, int N, int groups) {
+    if (!ddk::conv_wino_cluster_device_ok()) return 0;
     return ddk::conv_wino_cluster_np(B, H, W, cin, N, groups);
 }
 extern "C" size_t ddk_conv3x3_gn_mish_cluster_workspace_bytes(int B, int H, int W, int N) {
     if (B <= 0 || H <= 0 || W <= 0 || N <= 0 || N % ddk::WBN) return 0;
-    return ((size_t)B * 8 * 16 + ddk::conv_wino_cluster_ws_floats(B, H, W, N)) * sizeof(float);
+    return ((size_t)B * 8 * 16 + 16 + ddk::conv_wino_cluster_ws_floats(B, H, W, N)) * sizeof(float);
 }
+extern "C" int ddk_conv3x3_gn_mish_cluster_check(void* workspace, int B, ddk_stream_t s) {
+    using namespace ddk;
+    DDK_REQUIRE(workspace && B > 0, "conv3x3_gn_mish_cluster_check: arguments");
+    unsigned* word = reinterpret_cast<unsigned*>(static_cast<float*>(workspace) + (size_t)B * 8 * 16);
+    unsigned v = 0;
+    DDK_HIP(hipMemcpyAsync(&v, word, sizeof(v), hipMemcpyDeviceToHost, as_stream(s)));
+    DDK_HIP(hipStreamSynchronize(as_stream(s)));
+    if (v == 0) return DDK_OK;
+    DDK_HIP(hipMemsetAsync(word, 0, sizeof(v), as_stream(s)));
+    set_error("conv3x3_gn_mish_cluster: %u workgroup(s) gave up waiting for their cluster; the output is invalid (NaN tiles)", v);
+    return DDK_ERR_CLUSTER;
+}
+
+extern "C" int ddk_debug_occupy(int workgroups, int lds_bytes, int microseconds, ddk_stream_t s) {
+    using namespace ddk;
+    DDK_REQUIRE(workgroups > 0 && workgroups <= 4096 && lds_bytes >= 1024 && lds_bytes <= 160 * 1024 && microseconds > 0 &&
+                    microseconds <= 200000, "debug_occupy: 1..4096 workgroups, 1 KiB..160 KiB of LDS, at most 0.2 s");
+    DDK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&occupy_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    hipLaunchKernelGGL(occupy_kernel, dim3((unsigned)workgroups), dim3(256), (size_t)lds_bytes, as_stream(s),
+                       (unsigned long long)microseconds * 100ull, static_cast<unsigned*>(nullptr));
+    return check_launch("occupy_kernel");
+}
+
 extern "C" int ddk_conv3x3_gn_mish_cluster(const float* src0, int c0, const float* src1, int c1, const float* weight_wino, const float* bias,
                                            const float* gamma, const float* beta, const float* temb, int temb_stride, const float* addend,
                                            float* out, int B, int H, int W, int N, int groups, float eps, void* workspace,
                                            size_t workspace_bytes, ddk_stream_t s) {
     using namespace ddk;
     DDK_REQUIRE(src0 && weight_wino && gamma && beta && out && workspace, "conv3x3_gn_mish_cluster: null pointer");
-    DDK_REQUIRE(conv_wino_cluster_np(B, H, W, c0 + c1, N, groups) > 0, "conv3x3_gn_mish_cluster: shape not eligible "
-                "(ddk_conv3x3_gn_mish_cluster_ok)");
+    DDK_REQUIRE(conv_wino_cluster_device_ok() && conv_wino_cluster_np(B, H, W, c0 + c1, N, groups) > 0,
+                "conv3x3_gn_mish_cluster: shape or device not eligible (ddk_conv3x3_gn_mish_cluster_ok)");
     DDK_REQUIRE(workspace_bytes >= ddk_conv3x3_gn_mish_cluster_workspace_bytes(B, H, W, N) && aligned16(workspace),
                 "conv3x3_gn_mish_cluster: workspace");
     float* ws = static_cast<float*>(workspace);
-    DDK_HIP(hipMemsetAsync(ws, 0, (size_t)B * 8 * 16 * sizeof(float), as_stream(s)));
+    // counters + the sticky give-up word behind them: zeroed per call here (a plan zeroes them once per forward / chain)
+    DDK_HIP(hipMemsetAsync(ws, 0, ((size_t)B * 8 * 16 + 16) * sizeof(float), as_stream(s)));
     ddk_conv_args a{};
     a.kind = DDK_CONV3X3_S1;
     a.src0 = src0; a.src1 = src1; a.c0 = c0; a.c1 = c1;
@@ -801,7 +873,8 @@ extern "C" int ddk_conv3x3_gn_mish_cluster(const float* src0, int c0, const floa
     a.resid = addend;
     a.out = out;
     a.B = B; a.H = H; a.W = W; a.N = N;
-    const WinoGnFuse f{gamma, beta, temb, nullptr, temb_stride, eps, groups, ws + (size_t)B * 8 * 16, reinterpret_cast<unsigned*>(ws)};
+    const WinoGnFuse f{gamma, beta, temb, nullptr, temb_stride, eps, groups, ws + (size_t)B * 8 * 16 + 16, reinterpret_cast<unsigned*>(ws),
+                       reinterpret_cast<unsigned*>(ws + (size_t)B * 8 * 16)};
     return conv_forward(a, as_stream(s), nullptr, &f);
 }
 

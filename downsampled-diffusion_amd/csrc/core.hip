@@ -40,7 +40,27 @@ int ensure_device_init() {
 }
 }  // namespace ddk
 
-extern "C" int ddk_version(void) { return 300; }  // 0.3.0: ddk_conv_args grew mish_out / dmish_src
+// Clock probe: one record {XCC id, s_memtime (shader cycles), s_memrealtime (100 MHz ticks)} per workgroup.  Two probes around a
+// timed region give the shader clock the chip held in it: d(memtime) / d(realtime) x 100 MHz, per XCC (the counters of
+// different XCCs are not comparable with each other, their rates are).
+__global__ __launch_bounds__(64) void clock_probe_kernel(unsigned long long* out) {
+    if (threadIdx.x == 0) {
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        out[blockIdx.x * 4 + 0] = xcc & 0xfu;
+        out[blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memtime();
+        out[blockIdx.x * 4 + 2] = __builtin_amdgcn_s_memrealtime();
+        out[blockIdx.x * 4 + 3] = 1;
+    }
+}
+
+extern "C" int ddk_debug_clock_probe(unsigned long long* out, int workgroups, ddk_stream_t s) {
+    DDK_REQUIRE(out && workgroups > 0 && workgroups <= 1024, "debug_clock_probe: arguments");
+    hipLaunchKernelGGL(clock_probe_kernel, dim3((unsigned)workgroups), dim3(64), 0, ddk::as_stream(s), out);
+    return ddk::check_launch("clock_probe_kernel");
+}
+
+extern "C" int ddk_version(void) { return 400; }  // 0.4.0: ddk_unet_cluster_check & co., cluster workspace layout
 
 extern "C" const char* ddk_last_error(void) { return ddk::g_err; }
 

@@ -149,6 +149,7 @@ struct WinoGnFuse {
     int groups;
     float* records;
     unsigned* counters;
+    unsigned* fail;         // sticky count of workgroups that gave up waiting (may be null)
 };
 bool conv_ln_fold_ok(int B, int H, int W, int cin, int N);
 int conv_forward(const ddk_conv_args& a, hipStream_t st, const ConvLnFold* ln = nullptr, const WinoGnFuse* fuse = nullptr);
@@ -158,6 +159,7 @@ bool conv_wino_ok(int kind, int H, int W, int cin, int N);
 int conv_wino_splits(int B, int H, int W, int cin, int N);
 int conv_wino_forward(const ddk_conv_args& a, int splits, hipStream_t st, const WinoGnFuse* fuse = nullptr);
 int conv_wino_cluster_np(int B, int H, int W, int cin, int N, int groups);    // m tiles per image when eligible, else 0
+bool conv_wino_cluster_device_ok();     // a whole MI355X (256 CUs, 8 XCDs, no CU mask): the only place a cluster is co-resident
 size_t conv_wino_cluster_ws_floats(int B, int H, int W, int N);
 unsigned conv_wino_cluster_timeouts();
 int conv_wino_init_device();

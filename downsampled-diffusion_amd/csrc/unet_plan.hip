@@ -92,8 +92,11 @@ struct ddk_unet {
     unsigned long long pack_epoch = 0;       // bumped by every pack / finalize: weights changed
     struct { const void* ws = nullptr; int t_start = -1, B = 0, H = 0, W = 0; unsigned long long pack_epoch = 0; } table;
     ddk_unet_config cfg;
-    bool cluster_gn = true;                  // GroupNorm finished inside the Winograd conv launch where eligible (ddk_unet_set_option)
+    int cluster_gn = 1;                      // GroupNorm finished inside the Winograd conv launch where eligible (ddk_unet_set_option):
+                                             // 0 never, 1 in ddk_sampler_run (whose caller checks ddk_unet_cluster_check at the chain's
+                                             // sync point), 2 in ddk_unet_forward too
     int cluster_limit = 1 << 30;             // diagnostic: only the first so many eligible launches of a forward take that path
+    int cluster_np_max = 8;                  // largest cluster (workgroups per image and n tile) that takes the path
     bool attn_fold = true;                   // attention on maps with HW > 256, C = 128: q projection + apply + to_out as ONE per-image C x C conv
     std::vector<Slot> slots;
     size_t packed_floats = 0;
@@ -317,13 +320,38 @@ extern "C" int ddk_sampler_invalidate(ddk_unet* u) {
     drop_graphs(u);
     return DDK_OK;
 }
+static void destroy_entry(SamplerGraph& g) {
+    if (g.done) { (void)hipEventSynchronize(g.done); (void)hipEventDestroy(g.done); }
+    if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    if (g.graph) (void)hipGraphDestroy(g.graph);
+    if (g.exec_multi) (void)hipGraphExecDestroy(g.exec_multi);
+    if (g.graph_multi) (void)hipGraphDestroy(g.graph_multi);
+}
+
+/* Drops only what points into `workspace` (the caller is about to free or reuse it): the cached graphs captured on it, after
+   waiting for THEIR launches (the per-entry event), and the shift table if it lives there.  Other buffer sets keep their graphs. */
+extern "C" int ddk_sampler_release_workspace(ddk_unet* u, const void* workspace) {
+    DDK_REQUIRE(u && workspace, "sampler_release_workspace: arguments");
+    std::lock_guard<std::mutex> lock(u->mu);
+    for (size_t i = 0; i < u->graphs.size();) {
+        if (u->graphs[i].ws == workspace) {
+            destroy_entry(u->graphs[i]);
+            u->graphs.erase(u->graphs.begin() + (long)i);
+        } else {
+            ++i;
+        }
+    }
+    if (u->table.ws == workspace) u->table.ws = nullptr;
+    return DDK_OK;
+}
+
 extern "C" int ddk_unet_set_option(ddk_unet* u, int option, int value) {
     DDK_REQUIRE(u, "unet_set_option: null plan");
     if (option == DDK_OPT_CLUSTER_GROUPNORM) {
         std::lock_guard<std::mutex> lock(u->mu);
         if (!u->graphs.empty()) DDK_HIP(hipDeviceSynchronize());
         drop_graphs(u);                          // a captured step bakes the choice in
-        u->cluster_gn = value != 0;
+        u->cluster_gn = value < 0 ? 0 : value > 2 ? 2 : value;
         return DDK_OK;
     }
     if (option == DDK_OPT_ATTENTION_FOLD) {
@@ -336,6 +364,13 @@ extern "C" int ddk_unet_set_option(ddk_unet* u, int option, int value) {
     if (option == 2) {   // diagnostic (not in ddk.h): cap on the cluster launches per forward
         std::lock_guard<std::mutex> lock(u->mu);
         u->cluster_limit = value;
+        return DDK_OK;
+    }
+    if (option == 4) {   // diagnostic (not in ddk.h): largest cluster size that takes the in-launch GroupNorm
+        std::lock_guard<std::mutex> lock(u->mu);
+        if (!u->graphs.empty()) DDK_HIP(hipDeviceSynchronize());
+        drop_graphs(u);
+        u->cluster_np_max = value;
         return DDK_OK;
     }
     return fail_arg("unet_set_option: unknown option");
@@ -452,7 +487,9 @@ static size_t conv3_ws_floats(const ConvW& cw, int B, int H, int W, int cin, int
 }
 
 // counters of the cluster GroupNorm: fixed place (16 words per (image, n tile), N <= 512) so every layer re-arms the same words
-static size_t cl_counter_floats(int B) { return (size_t)B * 8 * 16; }
+// ... and behind them one line for the sticky give-up count of this workspace (ddk_unet_cluster_check)
+static size_t cl_counter_floats(int B) { return (size_t)B * 8 * 16 + 16; }
+static size_t cl_fail_offset(int B) { return (size_t)B * 8 * 16; }
 
 static void res_sizes(const ResW& r, int B, int H, int W, Layout& ly) {
     const size_t M = (size_t)B * H * W;
@@ -535,6 +572,7 @@ struct Ctx {
     hipStream_t st;
     const float* temb;            // [B][temb_total], or the sampler's per-timestep table [t_start+1][temb_total]
     const long long* temb_rows;   // nullptr: row b;  sampler: row = t_cur[b] (device), so one table serves every step
+    bool allow_cluster = false;   // this call's owner checks ddk_unet_cluster_check (sampler; forward only with option value 2)
     int n_cluster = 0;            // cluster launches issued so far in this forward
     const float* x_first = nullptr;   // the network input, unpadded, and its padded copy: the first conv may take the small-C_in
     const float* x_padded = nullptr;  // kernel on maps the one-launch first block does not cover (run_conv_gn)
@@ -587,7 +625,8 @@ static int run_conv_gn(Ctx& c, const ConvW& cw, const float* src0, int c0, const
         return groupnorm_mish(raw, c.P + n.g, c.P + n.b, temb, c.u.temb_total, addend, out, c.B, H * W, N, GROUPS, GN_EPS,
                               c.W + c.ly.off_gn, c.ly.gn_ws * sizeof(float), c.st, c.temb_rows);
     }
-    if (c.u.cluster_gn && cw.has_wu && conv_wino_cluster_np(c.B, H, W, c0 + c1, N, GROUPS) > 0 && c.n_cluster++ < c.u.cluster_limit) {
+    const int cl_np = c.allow_cluster && cw.has_wu && conv_wino_cluster_device_ok() ? conv_wino_cluster_np(c.B, H, W, c0 + c1, N, GROUPS) : 0;
+    if (cl_np > 0 && cl_np <= c.u.cluster_np_max && c.n_cluster++ < c.u.cluster_limit) {
         // one launch: the workgroups of an image exchange their tile statistics and normalise their own tile in registers
         ddk_conv_args a{};
         a.kind = DDK_CONV3X3_S1;
@@ -600,7 +639,7 @@ static int run_conv_gn(Ctx& c, const ConvW& cw, const float* src0, int c0, const
         a.B = c.B; a.H = H; a.W = W; a.N = N;
         float* cl = c.W + c.ly.off_cl;
         const WinoGnFuse f{c.P + n.g, c.P + n.b, temb, c.temb_rows, c.u.temb_total, GN_EPS, GROUPS, cl + cl_counter_floats(c.B),
-                           reinterpret_cast<unsigned*>(cl)};
+                           reinterpret_cast<unsigned*>(cl), reinterpret_cast<unsigned*>(cl + cl_fail_offset(c.B))};
         return conv_forward(a, c.st, nullptr, &f);
     }
     const int np = cw.has_wu ? conv_wino_stats_parts(c.B, H, W, c0 + c1, N, GROUPS) : 0;
@@ -791,7 +830,8 @@ static bool first_fast(const ddk_unet& u, int B, int H, int W) {
 // step != nullptr (sampler): t is the t_cur array the step's first kernel fills from step->state, and the forward ends with
 // the update of step->x instead of writing eps_hat to `out`.
 static int forward_core(const ddk_unet& u, const float* P, const float* x, int64_t* t, float* out, int B, int H0, int W0,
-                        float* ws, const Layout& ly, hipStream_t st, const float* temb_table = nullptr, const StepArgs* step = nullptr) {
+                        float* ws, const Layout& ly, hipStream_t st, bool allow_cluster, const float* temb_table = nullptr,
+                        const StepArgs* step = nullptr) {
     float* tact = ws + ly.off_tact;
     float* temb = ws + ly.off_temb;
     float* xpad = ws + ly.off_xpad;
@@ -814,6 +854,7 @@ static int forward_core(const ddk_unet& u, const float* P, const float* x, int64
     static_assert(sizeof(long long) == sizeof(int64_t), "timestep rows are read as long long");
     Ctx c{u, P, ws, ly, B, st, temb_table ? temb_table : temb, temb_table ? reinterpret_cast<const long long*>(t) : nullptr};
     if (!fast0) { c.x_first = x; c.x_padded = xpad; }
+    c.allow_cluster = allow_cluster;
     float* bufA = ws + ly.off_A;
     float* bufB = ws + ly.off_B;
     float* bufC = ws + ly.off_C;
@@ -948,7 +989,27 @@ extern "C" int ddk_unet_forward(const ddk_unet* u, const void* packed, const flo
     DDK_TRY(ensure_device_init());
     // the cluster GroupNorm's arrival / departure counters start at zero (they re-arm themselves after every launch)
     DDK_HIP(hipMemsetAsync(ws + ly.off_cl, 0, cl_counter_floats(B) * sizeof(float), as_stream(s)));
-    return forward_core(*u, static_cast<const float*>(packed), x, const_cast<int64_t*>(t), out, B, H, W, ws, ly, as_stream(s));
+    return forward_core(*u, static_cast<const float*>(packed), x, const_cast<int64_t*>(t), out, B, H, W, ws, ly, as_stream(s),
+                        u->cluster_gn >= 2);
+}
+
+/* The in-launch GroupNorm's workgroups wait for each other; when the device could not host a whole cluster at once (a foreign
+ * kernel, a CU mask the library could not see) a wait times out after 20 ms, the tile is written as NaN and the workspace's
+ * sticky counter moves.  This call waits for `s`, reads and clears that counter: DDK_ERR_CLUSTER means the tensors produced on
+ * `workspace` since the last check are not to be used -- rerun with DDK_OPT_CLUSTER_GROUPNORM = 0. */
+extern "C" int ddk_unet_cluster_check(const ddk_unet* u, void* workspace, int B, int H, int W, ddk_stream_t s) {
+    DDK_TRY(check_shape(u, B, H, W));
+    DDK_REQUIRE(workspace, "unet_cluster_check: null workspace");
+    const Layout ly = make_layout(*u, B, H, W);
+    unsigned* word = reinterpret_cast<unsigned*>(static_cast<float*>(workspace) + ly.off_cl + cl_fail_offset(B));
+    unsigned v = 0;
+    DDK_HIP(hipMemcpyAsync(&v, word, sizeof(v), hipMemcpyDeviceToHost, as_stream(s)));
+    DDK_HIP(hipStreamSynchronize(as_stream(s)));
+    if (v == 0) return DDK_OK;
+    DDK_HIP(hipMemsetAsync(word, 0, sizeof(v), as_stream(s)));
+    set_error("in-launch GroupNorm: %u workgroup(s) gave up waiting for their cluster (the GPU is shared, masked or partitioned); "
+              "results on this workspace are invalid -- rerun with DDK_OPT_CLUSTER_GROUPNORM = 0", v);
+    return DDK_ERR_CLUSTER;
 }
 
 extern "C" double ddk_unet_flops(const ddk_unet* u, int B, int H0, int W0) {
@@ -1095,7 +1156,9 @@ extern "C" int ddk_sampler_run(const ddk_sampler_args* a, ddk_stream_t s) {
                         a->sigma, per};
 
     // one reverse step: bookkeeping (in the forward's first kernel), UNet, update of x (in its last kernel)
-    auto one_step = [&]() -> int { return forward_core(u, P, a->x, t_cur, nullptr, B, H, W, ws, ly, st, temb_table, &step); };
+    auto one_step = [&]() -> int {
+        return forward_core(u, P, a->x, t_cur, nullptr, B, H, W, ws, ly, st, u.cluster_gn >= 1, temb_table, &step);
+    };
 
     auto capture = [&](int steps, hipGraph_t& graph, hipGraphExec_t& exec) -> int {
         hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
@@ -1162,11 +1225,7 @@ extern "C" int ddk_sampler_run(const ddk_sampler_args* a, ddk_stream_t s) {
             for (size_t i = 1; i < u.graphs.size(); ++i)
                 if (u.graphs[i].last_use < u.graphs[lru].last_use) lru = i;
             // wait for the evicted entry's own launches only (not the device: another stream may be mid-capture)
-            if (u.graphs[lru].done) { DDK_HIP(hipEventSynchronize(u.graphs[lru].done)); (void)hipEventDestroy(u.graphs[lru].done); }
-            (void)hipGraphExecDestroy(u.graphs[lru].exec);
-            (void)hipGraphDestroy(u.graphs[lru].graph);
-            if (u.graphs[lru].exec_multi) (void)hipGraphExecDestroy(u.graphs[lru].exec_multi);
-            if (u.graphs[lru].graph_multi) (void)hipGraphDestroy(u.graphs[lru].graph_multi);
+            destroy_entry(u.graphs[lru]);
             u.graphs.erase(u.graphs.begin() + (long)lru);
         }
         DDK_TRY(one_step());

@@ -17,7 +17,8 @@ class DDKError(RuntimeError):
     pass
 
 
-ABI_VERSION = 300   # ddk_version(): 0.3.0 -- ddk_conv_args grew mish_out / dmish_src
+ABI_VERSION = 400   # ddk_version(): 0.4.0 -- cluster check entry points, workspace layout of the in-launch GroupNorm
+ERR_CLUSTER = -4    # DDK_ERR_CLUSTER
 
 
 class ConvArgs(C.Structure):
@@ -122,11 +123,16 @@ SIGNATURES = {
     "ddk_conv3x3_gn_mish_cluster": (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _F, _P, _SZ, _P]),
     "ddk_unet_set_option": (_I, [_P, _I, _I]),
     "ddk_debug_cluster_timeouts": (C.c_uint, []),
+    "ddk_conv3x3_gn_mish_cluster_check": (_I, [_P, _I, _P]),
+    "ddk_unet_cluster_check": (_I, [_P, _P, _I, _I, _I, _P]),
+    "ddk_debug_occupy": (_I, [_I, _I, _I, _P]),
+    "ddk_debug_clock_probe": (_I, [_P, _I, _P]),
     "ddk_unet_flops": (C.c_double, [_P, _I, _I, _I]),
     "ddk_unet_flops_executed": (C.c_double, [_P, _I, _I, _I]),
     "ddk_sampler_workspace_bytes": (_SZ, [_P, _I, _I, _I, _I]),
     "ddk_sampler_run": (_I, [C.POINTER(SamplerArgs), _P]),
     "ddk_sampler_invalidate": (_I, [_P]),
+    "ddk_sampler_release_workspace": (_I, [_P, _P]),
     "ddk_pack_conv_weight_dgrad": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "ddk_zero_stuff2": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "ddk_conv_wgrad_workspace_bytes": (_SZ, [_I, _I, _I, _I, _I, _I]),

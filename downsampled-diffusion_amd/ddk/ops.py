@@ -314,9 +314,11 @@ def final_tail(raw, part, tiles_per_image, gamma, beta, w, bias, x=None, t=None,
     return eps_out
 
 
-def conv3x3_gn_mish_cluster(x, w_wino, bias, gamma, beta, x2=None, temb=None, addend=None, groups=GN_GROUPS, eps=GN_EPS):
+def conv3x3_gn_mish_cluster(x, w_wino, bias, gamma, beta, x2=None, temb=None, addend=None, groups=GN_GROUPS, eps=GN_EPS, check=True):
     """Block (conv3x3 + GroupNorm + Mish + shift + residual) in ONE Winograd launch whose workgroups exchange tile statistics
-    (ddk_conv3x3_gn_mish_cluster); raises when the shape is not eligible."""
+    (ddk_conv3x3_gn_mish_cluster); raises when the shape or the device is not eligible.  check=True (default) waits for the
+    stream and raises DDKError when an exchange timed out (shared GPU): the output then holds NaN tiles and must not be used;
+    timing loops pass check=False and call cluster_check() once at their end."""
     b, h, w_, c0 = x.shape
     c1 = 0 if x2 is None else x2.shape[-1]
     n = w_wino.shape[2]
@@ -330,7 +332,44 @@ def conv3x3_gn_mish_cluster(x, w_wino, bias, gamma, beta, x2=None, temb=None, ad
     L.check(lib.ddk_conv3x3_gn_mish_cluster(L.ptr(_f32(x)), c0, L.ptr(x2), c1, L.ptr(w_wino), L.ptr(bias), L.ptr(gamma), L.ptr(beta),
                                             temb.data_ptr() if temb is not None else None, stride, L.ptr(addend), L.ptr(out), b, h, w_, n,
                                             groups, eps, L.ptr(ws), nbytes, L.stream()), "conv3x3_gn_mish_cluster")
+    if check:
+        L.check(lib.ddk_conv3x3_gn_mish_cluster_check(L.ptr(ws), b, L.stream()), "conv3x3_gn_mish_cluster")
     return out
+
+
+def cluster_check(workspace_tag_device, b):
+    """ddk_conv3x3_gn_mish_cluster_check on the scratch the wrapper above used on `workspace_tag_device` (a torch device)."""
+    ws = _scratch.get((str(workspace_tag_device), "cluster"))
+    if ws is not None:
+        L.check(L.load().ddk_conv3x3_gn_mish_cluster_check(L.ptr(ws), b, L.stream()), "conv3x3_gn_mish_cluster")
+
+
+class ClockProbe:
+    """Shader clock held over a region of a stream: probe() before and after, then ghz().  (ddk_debug_clock_probe: one record per
+    workgroup {XCC, s_memtime, s_memrealtime}; records of the same XCC are differenced, the median over XCCs is returned.)"""
+
+    def __init__(self, device, workgroups=64):
+        self.n = workgroups
+        self.a = torch.zeros((workgroups, 4), device=device, dtype=torch.int64)
+        self.b = torch.zeros((workgroups, 4), device=device, dtype=torch.int64)
+        self._first = True
+
+    def probe(self):
+        buf = self.a if self._first else self.b
+        self._first = False
+        L.check(L.load().ddk_debug_clock_probe(buf.data_ptr(), self.n, L.stream()), "debug_clock_probe")
+
+    def ghz(self):
+        a, b = self.a.cpu().numpy(), self.b.cpu().numpy()
+        rates = []
+        for xcc in set(int(v) for v in a[:, 0]):
+            ra, rb = a[a[:, 0] == xcc], b[b[:, 0] == xcc]
+            if len(ra) and len(rb):
+                dc, dt = int(rb[0, 1]) - int(ra[0, 1]), int(rb[0, 2]) - int(ra[0, 2])
+                if dt > 0 and dc > 0:
+                    rates.append(dc / dt * 0.1)        # cycles per 10 ns tick -> GHz
+        rates.sort()
+        return rates[len(rates) // 2] if rates else None
 
 
 def cluster_timeouts():

@@ -6,6 +6,7 @@ runs a whole forward -- or the whole T-step sampling loop -- from a single C cal
 """
 import ctypes as C
 import math
+import warnings
 
 import torch
 
@@ -34,6 +35,7 @@ class UnetPlan:
         self.packed = None
         self._ws = {}          # (kind, nbytes, device) -> tensor; sampler workspaces are kept (LRU of 3): cached graphs point into them
         self._state = {}       # chain state x per (shape, device): a stable address for the captured sampler graph
+        self._cluster = 1      # DDK_OPT_CLUSTER_GROUPNORM as last set (the library's default is 1: sampler only)
 
     def __deepcopy__(self, memo):
         return None     # a copied module (EMA) builds its own native plan on first use
@@ -81,11 +83,13 @@ class UnetPlan:
             self._ws[key] = self._ws.pop(key)          # most recently used last
             return hit
         if kind == "smp":
-            mine = [k for k in self._ws if k[0] == "smp"]
+            mine = [k for k in self._ws if k[0] == "smp"]       # dict order = least recently used first
             if len(mine) >= 3:
-                L.check(self._lib.ddk_sampler_invalidate(self.handle), "sampler_invalidate")
-                for k in mine:
-                    del self._ws[k]
+                # evict ONLY the least recently used workspace; the plan drops the graphs that point into it (and waits for
+                # their launches), the other two keep theirs
+                old = self._ws[mine[0]]
+                L.check(self._lib.ddk_sampler_release_workspace(self.handle, L.ptr(old)), "sampler_release_workspace")
+                del self._ws[mine[0]]
         else:
             for k in [k for k in self._ws if k[0] == kind]:
                 del self._ws[k]
@@ -97,8 +101,25 @@ class UnetPlan:
     OPT_ATTENTION_FOLD = 3
 
     def set_option(self, option, value):
-        """ddk_unet_set_option: e.g. (OPT_CLUSTER_GROUPNORM, 0) keeps conv + GroupNorm-apply as two launches."""
+        """ddk_unet_set_option: e.g. (OPT_CLUSTER_GROUPNORM, 0) keeps conv + GroupNorm-apply as two launches
+        (1: in-launch GroupNorm inside the sampler, 2: in single forwards too -- both checked after the call, see below)."""
         L.check(self._lib.ddk_unet_set_option(self.handle, option, int(value)), "unet_set_option")
+        if option == self.OPT_CLUSTER_GROUPNORM:
+            self._cluster = max(0, min(2, int(value)))
+
+    def _cluster_failed(self, ws, b, h, w, stream_ptr):
+        """ddk_unet_cluster_check at a sync point.  True when an in-launch GroupNorm exchange timed out on `ws` (the GPU was
+        shared / masked): the caller restores its input and reruns; the option is switched off for the rest of the process'
+        use of this plan, loudly."""
+        rc = self._lib.ddk_unet_cluster_check(self.handle, L.ptr(ws), b, h, w, stream_ptr)
+        if rc == 0:
+            return False
+        if rc != L.ERR_CLUSTER:
+            L.check(rc, "unet_cluster_check")
+        warnings.warn("ddk: " + L.last_error() + " -- switching DDK_OPT_CLUSTER_GROUPNORM off for this plan and rerunning",
+                      RuntimeWarning, stacklevel=3)
+        self.set_option(self.OPT_CLUSTER_GROUPNORM, 0)
+        return True
 
     def cluster_timeouts(self):
         return int(self._lib.ddk_debug_cluster_timeouts())
@@ -125,8 +146,12 @@ class UnetPlan:
             raise L.DDKError(f"unet workspace query failed: {L.last_error()}")
         ws = self._workspace("fwd", nbytes, x.device)
         out = torch.empty_like(x)
-        L.check(lib.ddk_unet_forward(self.handle, L.ptr(self.packed), L.ptr(x), L.ptr(t), L.ptr(out), b, h, w,
-                                     L.ptr(ws), nbytes, L.stream()), "unet_forward")
+        for _ in range(2):
+            L.check(lib.ddk_unet_forward(self.handle, L.ptr(self.packed), L.ptr(x), L.ptr(t), L.ptr(out), b, h, w,
+                                         L.ptr(ws), nbytes, L.stream()), "unet_forward")
+            # option value 2 only (tests / diagnostics): a single forward has no sync point of its own, so this one waits
+            if self._cluster < 2 or not self._cluster_failed(ws, b, h, w, L.stream()):
+                break
         return out
 
     # ---------------------------------------------------------------- sampler
@@ -160,6 +185,8 @@ class UnetPlan:
         if mode["buf"] is not None:
             mode["buf"].copy_(x)
             x = mode["buf"]
+        # the in-launch GroupNorm can fail (loudly) when the GPU is shared: keep x_T so the chain can be rerun without it
+        x_start = x.clone() if self._cluster >= 1 else None
 
         def call(stream_ptr):
             a = L.SamplerArgs(self.handle, L.ptr(self.packed), L.ptr(x), L.ptr(noise), L.ptr(tables["c_recip"]),
@@ -167,16 +194,26 @@ class UnetPlan:
                               b, h, w, t_start, t_end, seed, stream_id, int(use_graph), L.ptr(ws), nbytes)
             L.check(lib.ddk_sampler_run(C.byref(a), stream_ptr), "sampler_run")
 
-        if use_graph and n_steps > 1:
-            # hipGraph capture is illegal on the legacy NULL stream: run on a side stream ordered after the current one
-            cur = torch.cuda.current_stream()
-            side = _side_stream(x.device)
-            side.wait_stream(cur)
-            with torch.cuda.stream(side):
-                call(side.cuda_stream)
-            cur.wait_stream(side)
-        else:
+        def run():
+            """Issues the chain; with the in-launch GroupNorm on, waits for it (the chain's sync point: T steps of work
+            against one stream synchronisation) and says whether it has to be rerun."""
+            if use_graph and n_steps > 1:
+                # hipGraph capture is illegal on the legacy NULL stream: run on a side stream ordered after the current one
+                cur = torch.cuda.current_stream()
+                side = _side_stream(x.device)
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    call(side.cuda_stream)
+                    failed = self._cluster >= 1 and self._cluster_failed(ws, b, h, w, side.cuda_stream)
+                cur.wait_stream(side)
+                return failed
             call(L.stream())
+            return self._cluster >= 1 and self._cluster_failed(ws, b, h, w, L.stream())
+
+        if run():
+            x.copy_(x_start)
+            if run():
+                raise L.DDKError("sampler: in-launch GroupNorm reported a failure with the option off")
         if caller_x.data_ptr() != x.data_ptr():
             caller_x.copy_(x)
         return caller_x

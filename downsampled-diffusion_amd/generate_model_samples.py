@@ -49,6 +49,9 @@ def main():
             raise RuntimeError(f"LOCAL_RANK {local} but only {torch.cuda.device_count()} GPU(s) visible: one process per GPU is "
                                "required with the nccl (RCCL) backend; set DDK_DIST_BACKEND=gloo to rehearse on one GPU")
         local = 0
+    # ranks that share one GPU (the gloo rehearsal above, or a launcher that maps several ranks onto one device) cannot host a whole
+    # cluster of the in-launch GroupNorm: switch that path off up front instead of waiting for its first (loud) give-up
+    shared_gpu = world > 1 and int(os.environ.get("LOCAL_WORLD_SIZE", str(world))) > torch.cuda.device_count()
     torch.cuda.set_device(local)
     device = f"cuda:{local}"
 
@@ -79,6 +82,8 @@ def main():
     model = model.to(device).eval()
     broadcast_module_(model, src=0)
     model.rng_stream_id = 0
+    if shared_gpu:
+        latent_model.plan().set_option(latent_model.plan().OPT_CLUSTER_GROUPNORM, 0)
 
     # the job = ceil(fid_samples / batch) batches; rank r takes a contiguous run of them
     bs = config["batch_size"]

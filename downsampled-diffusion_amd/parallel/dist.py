@@ -91,6 +91,18 @@ def barrier():
         dist.barrier()
 
 
+def all_ranks_agree(ok, detail=None):
+    """Every rank reports whether a step it ran LOCALLY worked (`ok`, with an error text in `detail`); returns
+    (all_ok, first_failure_text) -- the same pair on every rank.  For decisions that must not diverge between ranks (a rank
+    that raises or changes its launch sequence alone leaves the others parked in the next collective)."""
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return bool(ok), (None if ok else detail)
+    box = [None] * dist.get_world_size()
+    dist.all_gather_object(box, None if ok else f"rank {dist.get_rank()}: {detail}")
+    bad = [b for b in box if b is not None]
+    return not bad, (bad[0] if bad else None)
+
+
 def main_rank_does(fn, what="rank-0 work"):
     """Run `fn()` on rank 0 only and make EVERY rank learn whether it worked: rank 0's success / error text is broadcast
     afterwards, and all ranks raise together when it failed.  A bare barrier behind rank-0-only file I/O hangs the other

@@ -11,7 +11,7 @@ import os
 import numpy as np
 import torch
 
-from parallel import all_reduce_flat_, is_main_rank, main_rank_does
+from parallel import all_ranks_agree, all_reduce_flat_, is_main_rank, main_rank_does
 from utils import LOGGING_DIR, min_max_norm_image
 from .ema import EMA
 from .trainer import Trainer
@@ -126,20 +126,28 @@ class TrainerDDPM(Trainer):
         use_graph = self.config.get('graph_train', True) and str(self.device).startswith('cuda')
         if use_graph and self._graph is None:
             from .graph_step import GraphedAccumulation
+            graph, err = None, None
             try:
-                self._graph = GraphedAccumulation(self.model, self.gradient_accumulate_every).capture(batches)
-                self.opt.zero_grad()      # the warm-up / capture passes accumulated gradients of their own
+                graph = GraphedAccumulation(self.model, self.gradient_accumulate_every).capture(batches)
             except Exception as e:       # noqa: BLE001 -- e.g. a model whose forward synchronises with the host
+                err = f"{type(e).__name__}: {e}"
+            # The outcome is agreed on by ALL ranks before anyone acts on it: a rank that raised (or went eager) alone would
+            # leave the others parked in all_reduce_flat_ -- either every rank replays the graph, or every rank raises /
+            # runs eagerly.
+            ok, first_err = all_ranks_agree(err is None, err)
+            if ok:
+                self._graph = graph
+            else:
                 # A silent fall-back to ~3000 eager launches per step is a performance regression nobody would notice:
                 # only config['graph_train'] == 'auto' may degrade; the default (True) treats a failed capture as an error.
                 if self.config.get('graph_train', True) != 'auto':
-                    raise RuntimeError(f"device-graph capture of the training step failed ({type(e).__name__}: {e}); set "
+                    raise RuntimeError(f"device-graph capture of the training step failed ({first_err}); set "
                                        "config['graph_train'] = 'auto' to fall back to eager launches, or False to disable "
-                                       "graph replay") from e
-                print(f"[trainer] device-graph capture of the training step failed ({type(e).__name__}: {e}); running eagerly")
+                                       "graph replay")
+                print(f"[trainer] device-graph capture of the training step failed ({first_err}); running eagerly")
                 self._graph = False
                 torch.cuda.synchronize()
-                self.opt.zero_grad()
+            self.opt.zero_grad()          # the warm-up / capture passes accumulated gradients of their own
         if use_graph and self._graph and all(b.shape == s.shape for b, s in zip(batches, self._graph.static_x)):
             return self._graph.replay(batches)
         rows = []

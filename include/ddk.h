@@ -32,8 +32,9 @@ typedef void* ddk_stream_t; /* hipStream_t */
 #define DDK_ERR_ARG (-1)     /* shape / alignment / null pointer */
 #define DDK_ERR_HIP (-2)     /* a HIP runtime call failed */
 #define DDK_ERR_WORKSPACE (-3)
+#define DDK_ERR_CLUSTER (-4)  /* ddk_unet_cluster_check: an in-launch GroupNorm exchange timed out; results are invalid */
 
-int ddk_version(void);   /* 300 = 0.3.0; bumped whenever an argument struct changes layout */
+int ddk_version(void);   /* 400 = 0.4.0; bumped whenever an argument struct or a workspace contract changes */
 const char* ddk_last_error(void);
 /* 1 when a gfx950 device is visible to this process. */
 int ddk_device_ok(void);
@@ -175,7 +176,11 @@ int ddk_conv3x3_gn_mish_wino(const float* src0, int c0, const float* src1, int c
  * of one image exchange their tile statistics through `workspace` and finish GroupNorm + Mish (+ temb[b][c]) (+ addend) on their own
  * tile in registers (blocks.py:75-84,110-115).  Eligible when ddk_conv3x3_gn_mish_cluster_ok() > 0: one-pass Winograd shape
  * (ddk_conv_gn_partials() > 0), <= 8 tiles per image, whole clusters per dispatch round.  weight_wino: ddk_pack_conv_weight_wino. */
+/* The exchange assumes the cluster's workgroups are resident together (see DDK_OPT_CLUSTER_GROUPNORM); _ok() is 0 on a device where
+ * that is implausible, and after the call ddk_conv3x3_gn_mish_cluster_check(workspace, B, s) -- which waits for `s` -- says whether a
+ * wait timed out (DDK_ERR_CLUSTER: the output has NaN tiles). */
 int ddk_conv3x3_gn_mish_cluster_ok(int B, int H, int W, int cin, int N, int groups);
+int ddk_conv3x3_gn_mish_cluster_check(void* workspace, int B, ddk_stream_t s);
 size_t ddk_conv3x3_gn_mish_cluster_workspace_bytes(int B, int H, int W, int N);
 int ddk_conv3x3_gn_mish_cluster(const float* src0, int c0, const float* src1, int c1, const float* weight_wino, const float* bias,
                                 const float* gamma, const float* beta, const float* temb, int temb_stride, const float* addend,
@@ -306,15 +311,28 @@ int ddk_unet_forward(const ddk_unet* u, const void* packed, const float* x, cons
                      int B, int H, int W, void* workspace, size_t workspace_bytes, ddk_stream_t s);
 /* Plan options.  DDK_OPT_CLUSTER_GROUPNORM (default 1): where a Block's 3x3 conv runs as a one-pass Winograd launch whose
  * workgroups of one image are co-resident, GroupNorm + Mish + shift + residual finish INSIDE that launch (the workgroups exchange
- * their tile statistics through the workspace); 0 keeps the conv + GroupNorm-apply pair.  Changing it drops cached sampler graphs. */
+ * their tile statistics through the workspace); 0 keeps the conv + GroupNorm-apply pair.  1 = in ddk_sampler_run only, 2 = in
+ * ddk_unet_forward as well.  Co-residency is an assumption (whole MI355X: 256 CUs, 8 XCDs, no CU mask -- checked; nothing else
+ * running on the GPU -- not checkable), so the wait is bounded (20 ms) and a give-up is loud: the tile becomes NaN and
+ * ddk_unet_cluster_check() returns DDK_ERR_CLUSTER.  EVERY caller that leaves the option on must call ddk_unet_cluster_check at
+ * its sync point (the end of a chain) and rerun with the option off on error.  Changing it drops cached sampler graphs. */
 #define DDK_OPT_CLUSTER_GROUPNORM 1
 /* DDK_OPT_ATTENTION_FOLD (default 1): on maps with more than 256 pixels and 128 channels the attention block's q projection, apply and
  * to_out run as ONE 1x1 conv of x with a per-image 128x128 matrix W_out . ctx^T . W_q (q is linear in this attention; the
  * PreNorm LayerNorm is folded in as well); 0 keeps to_qkv / context / apply / to_out.  Same result up to fp32 summation order. */
 #define DDK_OPT_ATTENTION_FOLD 3
 int ddk_unet_set_option(ddk_unet* u, int option, int value);
+/* Waits for `s`, then reads and clears the sticky give-up count of the launches issued on `workspace` (a ddk_unet_forward or
+ * ddk_sampler_run workspace of this shape): DDK_OK, or DDK_ERR_CLUSTER when any in-launch GroupNorm exchange timed out. */
+int ddk_unet_cluster_check(const ddk_unet* u, void* workspace, int B, int H, int W, ddk_stream_t s);
 /* workgroups that ever gave up waiting for their cluster in this process (0 unless the GPU could not host a whole cluster) */
 unsigned ddk_debug_cluster_timeouts(void);
+/* Measurement support: `workgroups` records of 4 x uint64 {XCC id, shader-cycle counter, 100 MHz counter, 1} into `out`; two
+ * probes around a region give the shader clock held in it (per XCC: d cycles / d ticks x 100 MHz). */
+int ddk_debug_clock_probe(unsigned long long* out, int workgroups, ddk_stream_t s);
+/* Test support: occupies the device with `workgroups` workgroups of 256 threads holding `lds_bytes` of LDS each for about
+ * `microseconds` (a spin on the 100 MHz clock; bounded), on stream `s` -- the "foreign kernel" of the cluster tests. */
+int ddk_debug_occupy(int workgroups, int lds_bytes, int microseconds, ddk_stream_t s);
 /* FLOPs (2*MAC) of one forward for B samples at HxW: the algorithmic work bench.py prices. */
 double ddk_unet_flops(const ddk_unet* u, int B, int H, int W);
 /* FLOPs the plan's kernels really issue for that forward: 3x3 convs dispatched to a Winograd F(2x2,3x3) kernel count 16/36 of
@@ -356,6 +374,9 @@ size_t ddk_sampler_workspace_bytes(const ddk_unet* u, int B, int H, int W, int t
 int ddk_sampler_run(const ddk_sampler_args* a, ddk_stream_t s);
 /* Drops the plan's cached sampler graphs and shift table (waits for the device when graphs exist). */
 int ddk_sampler_invalidate(ddk_unet* u);
+/* Drops only the cached graphs (and shift table) that live in / point into `workspace`, after waiting for the launches of
+ * those graphs alone; what was captured on other workspaces stays cached.  Call it before freeing or reusing one workspace. */
+int ddk_sampler_release_workspace(ddk_unet* u, const void* workspace);
 
 
 /* ================================================================== training path (backward kernels) ==

@@ -82,7 +82,7 @@ def test_c_abi_exports_every_declared_symbol():
     lib = ctypes.CDLL(L.LIB_PATH)
     for name in declared:
         assert getattr(lib, name) is not None
-    assert L.load().ddk_version() == L.ABI_VERSION == 300
+    assert L.load().ddk_version() == L.ABI_VERSION == 400
 
 
 def test_plan_slots_cover_state_dict():

@@ -106,3 +106,35 @@ def test_rank0_failure_raises_on_every_rank_instead_of_hanging():
     assert res[0][1] == "written" and res[1][1] is None
     for _, _, raised in res:
         assert raised and "save_checkpoint failed on rank 0" in raised and "disk full" in raised
+
+
+def _worker_all_ranks_agree(rank, world, port, q):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path[:0] = [os.path.join(os.path.dirname(here), "downsampled-diffusion_amd")]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from parallel import all_ranks_agree, init_from_env
+    init_from_env("gloo")
+    both = all_ranks_agree(True)
+    one = all_ranks_agree(rank != 1, "HIP error: capture failed")       # only rank 1 failed locally
+    q.put((rank, both, one))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_a_local_failure_is_known_to_every_rank():
+    """parallel.all_ranks_agree: the outcome of a rank-local step (the trainer's device-graph capture) is the same on every rank,
+    so either all ranks replay the graph or all raise / run eagerly -- nobody is left alone in the gradient all-reduce"""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_all_ranks_agree, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for _, both, one in res:
+        assert both == (True, None)
+        assert one[0] is False and one[1] == "rank 1: HIP error: capture failed"

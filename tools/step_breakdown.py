@@ -36,7 +36,7 @@ def main(path, out=sys.stdout):
     print(f"{len(steps)} complete steps of {n} launches", file=out)
     import statistics
     durs = [[] for _ in range(n)]
-    gaps = [[0.0] for _ in range(n)]
+    gaps = [[] for _ in range(n)]
     for s in steps:
         for i, r in enumerate(s):
             durs[i].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
@@ -44,7 +44,7 @@ def main(path, out=sys.stdout):
                 gaps[i].append(int(r["Start_Timestamp"]) - int(s[i - 1]["End_Timestamp"]))
     # medians: one step that borders other work (warm-up / timed boundary, a graph launch) must not smear a gap over all of them
     dur = [statistics.median(d) for d in durs]
-    gap = [statistics.median(g) if len(g) > 1 else 0.0 for g in gaps]
+    gap = [statistics.median(g) if g else 0.0 for g in gaps]
     k = 1
     fam = collections.OrderedDict()
     tot_d = tot_g = 0.0

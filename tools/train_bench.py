@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Training-step timing: cfg3 (CelebA 64x64 dDDPM x2, batch 64), cfg2-like plain DDPM 32x32, cfg5 (full-resolution DDPM
-256x256, batch 8), eager vs device-graph replay.  GPU-box tool: python tools/train_bench.py"""
+256x256, batch 8), eager vs device-graph replay.  An optimiser step = gradient_accumulate_every = 2 micro-batches of a FULL
+batch_size each (reference trainers/trainer_ddpm.py:118-128).  GPU-box tool: python tools/train_bench.py"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(ROOT, "downsampled-diffusion_amd"), ROOT]
@@ -67,7 +68,7 @@ if __name__ == "__main__":
     time_train("cfg3 dDDPM-x2 64x64 bs64", DownsampleDDPMAutoencoder(c, Unet(c), DEV, 3), (64, 3, 64, 64))
     c = cfg(128, 3, 32)
     time_train("cfg2 DDPM 32x32 bs64    ", DDPM(c, Unet(c), DEV, 3), (64, 3, 32, 32))
-    # cfg5: full-resolution DDPM, bs=8 per GPU (2 micro-batches of 4)
+    # cfg5: full-resolution DDPM, -bs 8 per GPU: 2 micro-batches of 8 (round 3 timed 2 x 4 under this label: half the work)
     c = cfg(128, 3, 256)
-    time_train("cfg5 DDPM 256x256 bs8     ", DDPM(c, Unet(c), DEV, 3), (4, 3, 256, 256), steps=3)
+    time_train("cfg5 DDPM 256x256 bs8     ", DDPM(c, Unet(c), DEV, 3), (8, 3, 256, 256), steps=3)
     print(f"peak HBM allocated: {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB", flush=True)
