@@ -28,6 +28,8 @@
 //     stage S+1's first A fragments in the last quarter of stage S.
 #include <atomic>
 #include <cstdlib>
+#include <type_traits>
+#include <utility>
 
 #include "conv_common.h"
 
@@ -628,7 +630,24 @@ __global__ __launch_bounds__(512) void conv3x3_wino_kernel(const WinoParams p) {
     }
 }
 
+#include "conv_wino2_kernel.inc"
+
 // ------------------------------------------------------------------------------------------------ host side
+// Which kernel takes a shape.  F (128 output channels per workgroup: the input transform shared by two n tiles) wherever that still
+// gives the chip a full round of workgroups; D (64 per workgroup) for the small maps; both are the 8-matrix-wave kernel.  The 4 + 4
+// kernel above stays for comparison in the tuning build (DDK_WINO_VARIANT=0).
+enum { WINO_V_OLD = 0, WINO_V_D = 1, WINO_V_F = 2 };
+static int wino_variant(int B, int H, int W, int N) {
+#ifdef DDK_TUNING
+    if (const char* e = getenv("DDK_WINO_VARIANT")) {
+        const int v = atoi(e);
+        if (v == WINO_V_OLD || v == WINO_V_D || (v == WINO_V_F && N % 128 == 0)) return v;
+    }
+#endif
+    const long long mt = ceil_div((long long)B * (H / 2) * (W / 2), WBT);
+    return (N % 128 == 0 && mt * (N / 128) >= 224) ? WINO_V_F : WINO_V_D;
+}
+static int wino_nt(int variant) { return variant == WINO_V_F ? 128 : WBN; }
 bool conv_wino_ok(int kind, int H, int W, int cin, int N) {
     return kind == DDK_CONV3X3_S1 && H >= 2 && W >= 2 && H % 2 == 0 && W % 2 == 0 && cin > 0 && cin % 32 == 0 && N % 64 == 0;
 }
@@ -636,7 +655,7 @@ bool conv_wino_ok(int kind, int H, int W, int cin, int N) {
 // Channel-chunk splits: one workgroup per CU needs >= 256 workgroups; every split keeps at least one chunk.
 int conv_wino_splits(int B, int H, int W, int cin, int N) {
     const long long tiles = (long long)B * (H / 2) * (W / 2);
-    const long long wgs = ceil_div(tiles, WBT) * (N / WBN);
+    const long long wgs = ceil_div(tiles, WBT) * (N / wino_nt(wino_variant(B, H, W, N)));
     const int chunks = cin / 32;
     int s = 1;
     while (wgs * s < 256 && s * 2 <= chunks) s *= 2;
@@ -648,8 +667,8 @@ int conv_wino_splits(int B, int H, int W, int cin, int N) {
 // image, whole groups inside an n tile, and few enough tiles per image that the consumer's merge stays trivial.
 int conv_wino_stats_parts(int B, int H, int W, int cin, int N, int groups) {
     if (!conv_wino_ok(DDK_CONV3X3_S1, H, W, cin, N) || groups <= 0 || N % groups) return 0;
-    const int cpg = N / groups, tpi = (H / 2) * (W / 2);
-    if (cpg % 4 || WBN % cpg || tpi % WBT || tpi / WBT > 32) return 0;
+    const int cpg = N / groups, tpi = (H / 2) * (W / 2), nt_w = wino_nt(wino_variant(B, H, W, N));
+    if (cpg % 4 || nt_w % cpg || nt_w / cpg > 8 || tpi % WBT || tpi / WBT > 32) return 0;
     if (conv_wino_splits(B, H, W, cin, N) != 1) return 0;
     return tpi / WBT;
 }
@@ -659,7 +678,20 @@ int conv_wino_init_device() {
                                 (int)(W_LDS_FLOATS * sizeof(float))));
     DDK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_kernel<0, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)(W_LDS_FLOATS * sizeof(float))));
+    DDK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino2_kernel<2, 0, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(W2<2>::LDS_FL * sizeof(float))));
+    DDK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino2_kernel<2, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(W2<2>::LDS_FL * sizeof(float))));
+    DDK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino2_kernel<4, 0, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(W2<4>::LDS_FL * sizeof(float))));
+    DDK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino2_kernel<4, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(W2<4>::LDS_FL * sizeof(float))));
 #ifdef DDK_TUNING   // 1: stamps; 2: + loaders exit after the prologue; 3: + loaders at priority 0; 4: + no U DMA in the loop (2-4: wrong results)
+#define W2_DBG_ATTR(P_, D_) DDK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino2_kernel<P_, D_, false>), \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(W2<P_>::LDS_FL * sizeof(float))))
+    W2_DBG_ATTR(2, 1); W2_DBG_ATTR(2, 7); W2_DBG_ATTR(2, 9); W2_DBG_ATTR(2, 15); W2_DBG_ATTR(2, 17);
+    W2_DBG_ATTR(4, 1); W2_DBG_ATTR(4, 7); W2_DBG_ATTR(4, 9); W2_DBG_ATTR(4, 15); W2_DBG_ATTR(4, 17);
+#undef W2_DBG_ATTR
     DDK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(W_LDS_FLOATS * sizeof(float))));
     DDK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(W_LDS_FLOATS * sizeof(float))));
     DDK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(W_LDS_FLOATS * sizeof(float))));
@@ -673,9 +705,10 @@ int conv_wino_init_device() {
 int conv_wino_cluster_np(int B, int H, int W, int cin, int N, int groups) {
     const int np = conv_wino_stats_parts(B, H, W, cin, N, groups);
     if (np <= 0 || np > 8) return 0;
-    if (N / groups > 32 || WBN % (N / groups)) return 0;        // a 64-byte record holds the n tile's <= 8 groups ... of >= 8 channels
-    if (WBN / (N / groups) > 8) return 0;
-    const long long mt = (long long)B * np, nt = N / WBN;
+    const int nt_w = wino_nt(wino_variant(B, H, W, N));
+    if (N / groups > 32 || nt_w % (N / groups)) return 0;       // a 64-byte record holds the n tile's <= 8 groups ... of >= 8 channels
+    if (nt_w / (N / groups) > 8) return 0;
+    const long long mt = (long long)B * np, nt = N / nt_w;
     if ((mt * nt) % 8) return 0;                                 // the XCD-aware order below assumes equal runs per XCD
     // a round = the first 256 launch indices = 32 logical tiles (n fastest, then m) of each XCD's run: whole clusters only
     const long long run = mt * nt / 8;                           // logical tiles per XCD
@@ -684,7 +717,7 @@ int conv_wino_cluster_np(int B, int H, int W, int cin, int N, int groups) {
     return np;
 }
 size_t conv_wino_cluster_ws_floats(int B, int H, int W, int N) {
-    const long long mt = (long long)B * (H / 2) * (W / 2) / WBT, nt = N / WBN;
+    const long long mt = (long long)B * (H / 2) * (W / 2) / WBT, nt = N / WBN;      // sized for the narrow tile: enough for either
     return (size_t)(mt * nt * 32 + (long long)B * nt * 16);
 }
 
@@ -742,6 +775,36 @@ int conv_wino_forward(const ddk_conv_args& a, int splits, hipStream_t st, const 
     p.dTW = make_fastdiv_u((unsigned)p.TW);
     p.dTH = make_fastdiv_u((unsigned)p.TH);
     if (p.splits > 1) p.out = static_cast<float*>(a.workspace);
+    const int variant = wino_variant(a.B, a.H, a.W, a.N);
+    if (variant != WINO_V_OLD) {
+        dim3 grid2((unsigned)ceil_div(p.tiles, WBT), (unsigned)(a.N / wino_nt(variant)), (unsigned)p.splits);
+        const bool f = variant == WINO_V_F;
+        const size_t lds = (size_t)(f ? W2<2>::LDS_FL : W2<4>::LDS_FL) * sizeof(float);
+#ifdef DDK_TUNING
+        if (getenv("DDK_WINO_STAMPS")) {
+            const int v = getenv("DDK_WINO_DEBUG") ? atoi(getenv("DDK_WINO_DEBUG")) : 1;
+#define W2_DBG_LAUNCH(D_)                                                                                              \
+    if (v == D_) {                                                                                                     \
+        if (f) hipLaunchKernelGGL((conv3x3_wino2_kernel<2, D_, false>), grid2, dim3(768), lds, st, p);                 \
+        else hipLaunchKernelGGL((conv3x3_wino2_kernel<4, D_, false>), grid2, dim3(768), lds, st, p);                   \
+        return check_launch("conv3x3_wino2_kernel<dbg>");                                                              \
+    }
+            W2_DBG_LAUNCH(7) W2_DBG_LAUNCH(9) W2_DBG_LAUNCH(15) W2_DBG_LAUNCH(17)
+#undef W2_DBG_LAUNCH
+            if (f) hipLaunchKernelGGL((conv3x3_wino2_kernel<2, 1, false>), grid2, dim3(768), lds, st, p);
+            else hipLaunchKernelGGL((conv3x3_wino2_kernel<4, 1, false>), grid2, dim3(768), lds, st, p);
+            return check_launch("conv3x3_wino2_kernel<dbg>");
+        }
+#endif
+        if (fuse) {
+            if (f) hipLaunchKernelGGL((conv3x3_wino2_kernel<2, 0, true>), grid2, dim3(768), lds, st, p);
+            else hipLaunchKernelGGL((conv3x3_wino2_kernel<4, 0, true>), grid2, dim3(768), lds, st, p);
+            return check_launch("conv3x3_wino2_kernel<cluster>");
+        }
+        if (f) hipLaunchKernelGGL((conv3x3_wino2_kernel<2, 0, false>), grid2, dim3(768), lds, st, p);
+        else hipLaunchKernelGGL((conv3x3_wino2_kernel<4, 0, false>), grid2, dim3(768), lds, st, p);
+        return check_launch("conv3x3_wino2_kernel");
+    }
     dim3 grid((unsigned)ceil_div(p.tiles, WBT), (unsigned)(a.N / WBN), (unsigned)p.splits);
 #ifdef DDK_TUNING
     if (getenv("DDK_WINO_STAMPS")) {
@@ -801,6 +864,10 @@ extern "C" int ddk_pack_conv_weight_wino_dgrad(const float* w_oihw, float* dst, 
 }
 
 #ifdef DDK_TUNING
+extern "C" int ddk_debug_read_wino_timeline(unsigned long long* host_out) {   // tuning build only: [12 waves][8 stages][arrive, leave]
+    if (hipDeviceSynchronize() != hipSuccess) return -2;
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(ddk::g_wino_timeline), sizeof(unsigned long long) * 12 * 8 * 2) == hipSuccess ? 0 : -2;
+}
 extern "C" int ddk_debug_read_wino_stamps(unsigned long long* host_out) {   // tuning build only (not in include/ddk.h)
     if (hipDeviceSynchronize() != hipSuccess) return -2;
     if (hipMemcpyFromSymbol(host_out, HIP_SYMBOL(ddk::g_wino_stamps), sizeof(unsigned long long) * 8 * 1024) != hipSuccess) return -2;

@@ -242,7 +242,7 @@ def test_cluster_groupnorm_option_gives_identical_unet():
     assert plan._cluster == 2, "a give-up would have switched the option off"
     assert torch.equal(y_on, y_on2)
     assert torch.equal(y_default, y_off)
-    assert not torch.equal(y_on, y_off), "the option really switches paths"
+    # (same statistics, same merge order, same finishing arithmetic: with the round-4 kernels the two paths agree bit for bit)
     assert rel_err(y_on.cpu(), y_off.cpu()) < 2e-5
 
 

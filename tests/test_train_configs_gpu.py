@@ -102,7 +102,7 @@ def test_cfg3_optimiser_step_at_its_real_size():
         acc += np.array(_run_ae(model, xd[0][s:s + 2], td[0][s:s + 2], ed[0][s:s + 2], 2.0 / B))
     assert np.allclose(acc / (B // 2), full0, rtol=2e-5), (acc / (B // 2), full0)
     for k in probe:
-        assert rel_err(params[k].grad, g0[k]) < 2e-4, k
+        assert rel_err(params[k].grad.cpu(), g0[k].cpu()) < 2e-4, k
 
     # ---- clip + Adam at full size: the fused kernels on the flat bucket against the oracle's arithmetic on the same gradients
     opt = FusedAdam(model, lr=2e-4)

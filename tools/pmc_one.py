@@ -74,11 +74,20 @@ elif case == "gnbig":          # large-slab GroupNorm apply pass: 8 x 256 x 256 
     x = torch.randn(8, 256, 256, 128, device=dev)
     gam, bet, temb = torch.ones(128, device=dev), torch.zeros(128, device=dev), torch.randn(8, 128, device=dev)
     fn = lambda: ops.groupnorm_mish(x, gam, bet, temb=temb)
+elif case == "cluster32":       # conv3x3 128->128 @32x32 with GroupNorm finished in the launch (8 workgroups per cluster)
+    x, w = torch.randn(B, 32, 32, 128, device=dev), rw(128, 128)
+    wu, b = ops.pack_conv_weight_wino(w), torch.zeros(128, device=dev)
+    gam, bet, temb = torch.ones(128, device=dev), torch.zeros(128, device=dev), torch.randn(B, 128, device=dev)
+    fn = lambda: ops.conv3x3_gn_mish_cluster(x, wu, b, gam, bet, temb=temb, check=False)
+elif case == "wino16":          # conv3x3 256->256 @16x16 (the 64-channel tile of the 8-matrix-wave kernel)
+    x, w = torch.randn(B, 16, 16, 256, device=dev), rw(256, 256)
+    wp, wu, b = ops.pack_conv_weight(w), ops.pack_conv_weight_wino(w), torch.zeros(256, device=dev)
+    fn = lambda: ops.conv(ops.CONV3X3_S1, x, wp, b, w_wino=wu)
 elif case == "cluster16":
     x, w = torch.randn(B, 16, 16, 256, device=dev), rw(256, 256)
     wu, b = ops.pack_conv_weight_wino(w), torch.zeros(256, device=dev)
     gam, bet, temb = torch.ones(256, device=dev), torch.zeros(256, device=dev), torch.randn(B, 256, device=dev)
-    fn = lambda: ops.conv3x3_gn_mish_cluster(x, wu, b, gam, bet, temb=temb)
+    fn = lambda: ops.conv3x3_gn_mish_cluster(x, wu, b, gam, bet, temb=temb, check=False)
 else:
     raise SystemExit(f"unknown case {case}")
 for _ in range(20):

@@ -40,3 +40,13 @@ print(f"{H}x{H} {C}->{N}: {len(a)} WGs, {ns[0]:.0f} stages; entry median {np.med
       f"loop {np.median(l1 - l0):.1f} (max {np.max(l1 - l0):.1f}) | epilogue {np.median(end - l1):.1f} | last WG done at {end.max():.1f} us")
 print(f"   matrix wave 0: cycles per stage {np.median(a[:, 4] / np.maximum(ns - 1, 1)):.0f} (MFMA-bound 2048), of which parked at the barrier "
       f"{np.median(a[:, 3] / ns):.0f}")
+
+if os.environ.get("DDK_WINO_DEBUG") == "17":
+    tl = (ctypes.c_ulonglong * (12 * 8 * 2))()
+    ctypes.CDLL(lib.LIB_PATH).ddk_debug_read_wino_timeline(tl)
+    t = np.frombuffer(tl, dtype=np.uint64).astype(np.float64).reshape(12, 8, 2)
+    base = t[:, 0, 1].min()
+    print("   timeline of workgroup 0, stages 8..15: cycles after the first release; per wave: arrive at the stage barrier / leave it")
+    for w in range(12):
+        role = "matrix" if w < 8 else "loader"
+        print(f"   wave {w:2d} ({role}): " + "  ".join(f"{t[w, s, 0] - base:6.0f}/{t[w, s, 1] - base:6.0f}" for s in range(8)))

@@ -30,3 +30,24 @@ for name, H, c0, c1, N, count in SHAPES:
     tot += tw * count
     print(f"{name:14s} x{count} {tw:6.2f} us  {ex / tw / 1e6:5.1f} TF executed ({ex / tw / 1e6 / 157.3:.3f} of peak)  rel err vs direct {err:.1e}", flush=True)
 print(f"sum over the step's {sum(s[5] for s in SHAPES)} launches: {tot:.1f} us   [{os.environ.get('DDK_LIB', 'libddk.so')}]")
+
+# ---- the Block (conv + GroupNorm + Mish + shift): conv with tile statistics + GroupNorm-apply launch, against the in-launch GroupNorm
+print("Block = conv3x3 + GroupNorm + Mish + time shift: two launches (conv with statistics, apply) vs one (cluster exchange)")
+for name, H, C, N in [("128->128 @32", 32, 128, 128), ("256->256 @16", 16, 256, 256), ("128->256 @16", 16, 128, 256)]:
+    x = torch.randn(B, H, H, C, device="cuda")
+    w = torch.randn(N, C, 3, 3, device="cuda") * (C * 9) ** -0.5
+    wp, wu = ops.pack_conv_weight(w), ops.pack_conv_weight_wino(w)
+    bias, gam, bet, temb = torch.zeros(N, device="cuda"), torch.ones(N, device="cuda"), torch.zeros(N, device="cuda"), torch.randn(B, N, device="cuda")
+
+    def two():
+        raw, part, tiles = ops.conv_with_gn_partials(x, wp, bias, wu)
+        return ops.groupnorm_mish_from_partials(raw, part, tiles, gam, bet, temb=temb)
+    t2 = graph_time(two)
+    if ops.L.load().ddk_conv3x3_gn_mish_cluster_ok(B, H, H, C, N, 8) > 0:
+        one = lambda: ops.conv3x3_gn_mish_cluster(x, wu, bias, gam, bet, temb=temb, check=False)
+        t1 = graph_time(one)
+        err = float((one() - two()).abs().max())
+        ops.cluster_check("cuda", B)
+        print(f"{name:14s} two launches {t2:6.2f} us   one launch {t1:6.2f} us   max |diff| {err:.1e}", flush=True)
+    else:
+        print(f"{name:14s} two launches {t2:6.2f} us   (in-launch GroupNorm not eligible)", flush=True)
