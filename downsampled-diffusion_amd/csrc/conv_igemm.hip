@@ -1261,8 +1261,13 @@ size_t conv_workspace_bytes(int kind, int B, int H, int W, int cin, int N) {
     Geometry g;
     if (!conv_geometry(kind, H, W, g) || cin <= 0 || cin % 32) return 0;
     const Choice c = plan_conv(kind, B, H, W, cin, N, g).c;
-    if (c.splits == 1) return 0;
-    return (size_t)c.splits * B * g.Ho * g.Wo * N * sizeof(float);
+    size_t need = c.splits == 1 ? 0 : (size_t)c.splits * B * g.Ho * g.Wo * N * sizeof(float);
+    if (kind == DDK_CONVT4X4_S2 && convT_wino_ok(H, W, cin, N)) {        // the Winograd form may split differently: room for either
+        const int s = convT_wino_splits(B, H, W, cin, N);
+        const size_t w = s == 1 ? 0 : (size_t)s * B * g.Ho * g.Wo * N * sizeof(float);
+        if (w > need) need = w;
+    }
+    return need;
 }
 
 bool conv_ln_fold_ok(int B, int H, int W, int cin, int N) {
@@ -1308,6 +1313,32 @@ int conv_forward(const ddk_conv_args& a, hipStream_t st, const ConvLnFold* ln, c
         }
         DDK_REQUIRE((long long)a.B * a.H * a.W * (a.c0 > a.c1 ? a.c0 : a.c1) * 4 < (1LL << 31), "conv(wino): a source of 2 GiB or more");
         DDK_TRY(conv_wino_forward(a, ws, st, fuse));
+        if (ws > 1 && !a.defer_reduce) {
+            const long long n4 = slab / 4;
+            const int blocks = (int)(ceil_div(n4, 256) < 2048 ? ceil_div(n4, 256) : 2048);
+            hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, static_cast<const float*>(a.workspace), ws, slab, a.bias,
+                               a.resid, a.out, n4, a.N, a.post_mish, static_cast<float*>(nullptr), static_cast<const float*>(nullptr));
+            DDK_TRY(check_launch("splitk_reduce_kernel"));
+        }
+        return DDK_OK;
+    }
+    if (a.kind == DDK_CONVT4X4_S2 && a.weight_wino && a.c1 == 0 && !a.pre_mish && !a.post_mish && !a.resid && !act_epilogue && !a.gn_partials &&
+        !fuse && !ln && convT_wino_ok(a.H, a.W, a.c0, a.N)) {
+        // transpose conv as Winograd F(2x2, 2x2) per output phase (conv_winoT_kernel.inc): 9/16 of the direct multiplies
+        DDK_REQUIRE(aligned16(a.weight_wino), "conv: weight_wino alignment");
+        DDK_TRY(ensure_device_init());
+        const int ws = convT_wino_splits(a.B, a.H, a.W, a.c0, a.N);
+        const long long slab = (long long)a.B * g.Ho * g.Wo * a.N;
+        if (ws > 1) {
+            const size_t need = (size_t)ws * slab * sizeof(float);
+            if (!a.workspace || a.workspace_bytes < need) {
+                set_error("conv(winoT): split-K workspace too small (%zu < %zu)", a.workspace_bytes, need);
+                return DDK_ERR_WORKSPACE;
+            }
+            DDK_REQUIRE(aligned16(a.workspace), "conv: workspace alignment");
+        }
+        DDK_REQUIRE((long long)a.B * a.H * a.W * a.c0 * 4 < (1LL << 31), "conv(winoT): a source of 2 GiB or more");
+        DDK_TRY(convT_wino_forward(a, ws, st));
         if (ws > 1 && !a.defer_reduce) {
             const long long n4 = slab / 4;
             const int blocks = (int)(ceil_div(n4, 256) < 2048 ? ceil_div(n4, 256) : 2048);

@@ -631,6 +631,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino_kernel(const WinoParams p) {
 }
 
 #include "conv_wino2_kernel.inc"
+#include "conv_winoT_kernel.inc"
 
 // ------------------------------------------------------------------------------------------------ host side
 // Which kernel takes a shape.  F (128 output channels per workgroup: the input transform shared by two n tiles) wherever that still
@@ -673,7 +674,51 @@ int conv_wino_stats_parts(int B, int H, int W, int cin, int N, int groups) {
     return tpi / WBT;
 }
 
+// ---- transpose conv (conv_winoT_kernel.inc)
+bool convT_wino_ok(int H, int W, int cin, int N) {
+    return H >= 2 && W >= 2 && H % 2 == 0 && W % 2 == 0 && cin > 0 && cin % 32 == 0 && N > 0 && N % WT_NT == 0;
+}
+// channel-chunk splits: (m tiles) x (n tiles) x 4 phases workgroups, one per CU
+int convT_wino_splits(int B, int H, int W, int cin, int N) {
+    const long long wgs = ceil_div((long long)B * (H / 2) * (W / 2), WBT) * (N / WT_NT) * 4;
+    const int chunks = cin / 32;
+    int s = 1;
+    while (wgs * s < 256 && s * 2 <= chunks) s *= 2;
+    const int cps = (int)ceil_div(chunks, s);
+    return (int)ceil_div(chunks, cps);
+}
+// a: validated by conv_forward.  Writes the result, or (splits > 1) the slabs in a.workspace
+int convT_wino_forward(const ddk_conv_args& a, int splits, hipStream_t st) {
+    WinoParams p{};
+    p.src0 = a.src0; p.wu = a.weight_wino; p.bias = a.bias; p.out = a.out;
+    p.c0 = a.c0; p.c1 = 0; p.cin = a.c0;
+    p.B = a.B; p.H = a.H; p.W = a.W; p.TH = a.H / 2; p.TW = a.W / 2;
+    p.N = a.N; p.tiles = a.B * p.TH * p.TW;
+    p.chunks = p.cin / 32;
+    p.chunks_per_split = (int)ceil_div(p.chunks, splits);
+    p.splits = (int)ceil_div(p.chunks, p.chunks_per_split);
+    p.slab_stride = (long long)a.B * (2 * a.H) * (2 * a.W) * a.N;
+    p.dTW = make_fastdiv_u((unsigned)p.TW);
+    p.dTH = make_fastdiv_u((unsigned)p.TH);
+    if (p.splits > 1) p.out = static_cast<float*>(a.workspace);
+    dim3 grid((unsigned)ceil_div(p.tiles, WBT), (unsigned)(a.N / WT_NT), (unsigned)(4 * p.splits));
+#ifdef DDK_TUNING
+    if (getenv("DDK_WINO_STAMPS")) {
+        hipLaunchKernelGGL(convT_wino_kernel<1>, grid, dim3(1024), WT_LDS_FL * sizeof(float), st, p);
+        return check_launch("convT_wino_kernel<dbg>");
+    }
+#endif
+    hipLaunchKernelGGL(convT_wino_kernel<0>, grid, dim3(1024), WT_LDS_FL * sizeof(float), st, p);
+    return check_launch("convT_wino_kernel");
+}
+
 int conv_wino_init_device() {
+    DDK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&convT_wino_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(WT_LDS_FL * sizeof(float))));
+#ifdef DDK_TUNING
+    DDK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&convT_wino_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(WT_LDS_FL * sizeof(float))));
+#endif
     DDK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)(W_LDS_FLOATS * sizeof(float))));
     DDK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_kernel<0, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -850,6 +895,20 @@ extern "C" int ddk_pack_conv_weight_wino(const float* w_oihw, float* dst, int O,
     hipLaunchKernelGGL(pack_conv_weight_wino_kernel<false>, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, as_stream(s), w_oihw,
                        dst, O, I, i_pad, total, 0, I);
     return check_launch("pack_conv_weight_wino_kernel");
+}
+
+extern "C" int ddk_pack_convT_weight_wino(const float* w_iohw, float* dst, int I, int O, int i_pad, ddk_stream_t s) {
+    using namespace ddk;
+    DDK_REQUIRE(w_iohw && dst && O > 0 && I > 0 && i_pad >= I && i_pad % 32 == 0, "pack_convT_weight_wino: arguments (i_pad % 32 == 0)");
+    const long long total = (long long)O * i_pad;
+    const long long blocks = ceil_div(total, 256);
+    hipLaunchKernelGGL(pack_convT_weight_wino_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, as_stream(s), w_iohw, dst,
+                       I, O, i_pad, total);
+    return check_launch("pack_convT_weight_wino_kernel");
+}
+extern "C" int ddk_convT_wino_splits(int B, int H, int W, int cin, int N) {
+    if (!ddk::convT_wino_ok(H, W, cin, N)) return 0;
+    return ddk::convT_wino_splits(B, H, W, cin, N);
 }
 
 extern "C" int ddk_pack_conv_weight_wino_dgrad(const float* w_oihw, float* dst, int O, int I, int c_lo, int c_hi, int o_pad, ddk_stream_t s) {

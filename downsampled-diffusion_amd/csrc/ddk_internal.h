@@ -162,6 +162,10 @@ int conv_wino_cluster_np(int B, int H, int W, int cin, int N, int groups);    //
 bool conv_wino_cluster_device_ok();     // a whole MI355X (256 CUs, 8 XCDs, no CU mask): the only place a cluster is co-resident
 size_t conv_wino_cluster_ws_floats(int B, int H, int W, int N);
 unsigned conv_wino_cluster_timeouts();
+// transpose conv 4x4 stride 2 as Winograd F(2x2, 2x2) per output phase (weight_wino = ddk_pack_convT_weight_wino)
+bool convT_wino_ok(int H, int W, int cin, int N);
+int convT_wino_splits(int B, int H, int W, int cin, int N);
+int convT_wino_forward(const ddk_conv_args& a, int splits, hipStream_t st);
 int conv_wino_init_device();
 int conv_wino_stats_parts(int B, int H, int W, int cin, int N, int groups);   // tiles per image, or 0
 // conv_first.hip: Conv2d(C_in <= 8, N, 3, padding=1) on the unpadded input, GroupNorm partials in the epilogue; with

@@ -24,7 +24,7 @@ constexpr float GN_EPS = 1e-5f, LN_EPS = 1e-5f;
 
 static inline int pad32(int c) { return (c + 31) / 32 * 32; }
 
-enum PackKind { PK_COPY = 0, PK_CONV = 1, PK_CONVT = 2, PK_LINEAR_T = 3, PK_WINO = 4, PK_LOCAL = 5, PK_WLOCAL = 6, PK_FIRST = 7 };
+enum PackKind { PK_COPY = 0, PK_CONV = 1, PK_CONVT = 2, PK_LINEAR_T = 3, PK_WINO = 4, PK_LOCAL = 5, PK_WLOCAL = 6, PK_FIRST = 7, PK_CONVT_WINO = 8 };
 
 struct Slot {
     std::string name;
@@ -159,6 +159,12 @@ struct ddk_unet {
         slots.push_back(Slot{prefix + "weight", (long long)16 * ch * ch, PK_CONVT, c.w, ch, ch, 4, 4, ch, 0, 0});
         c.has_bias = true;
         c.b = add_copy(prefix + "bias", ch);
+        if (ch % 128 == 0) {
+            // the same tensor's Winograd F(2x2, 2x2) form, four phases x 9 positions (conv_winoT_kernel.inc)
+            c.wu = alloc((size_t)36 * ch * ch);
+            c.has_wu = true;
+            slots.push_back(Slot{prefix + "weight", (long long)16 * ch * ch, PK_CONVT_WINO, c.wu, ch, ch, 4, 4, ch, 0, 0});
+        }
         return c;
     }
     NormW add_norm(const std::string& wname, const std::string& bname, int c) {
@@ -443,6 +449,7 @@ extern "C" int ddk_unet_pack_slot(const ddk_unet* u, int slot, const float* cano
         case PK_LOCAL: rc = ddk_pack_conv_weight_local(canonical, dst, sl.O, sl.I, sl.i_pad, s); break;
         case PK_WLOCAL: rc = ddk_pack_conv_weight_wino_local(canonical, dst, sl.O, sl.I, sl.i_pad, s); break;
         case PK_FIRST: rc = ddk_pack_conv_weight_first(canonical, dst, sl.O, sl.I, s); break;
+        case PK_CONVT_WINO: rc = ddk_pack_convT_weight_wino(canonical, dst, sl.I, sl.O, sl.i_pad, s); break;
         default: return fail_arg("unet_pack_slot: slot kind");
     }
     DDK_TRY(rc);
@@ -474,6 +481,9 @@ static void upd(size_t& m, size_t v) { if (v > m) m = v; }
 
 // The 3x3 stride-1 convs run as Winograd F(2x2,3x3) wherever the shape allows (conv_wino.hip); their split count and slab
 // workspace follow that kernel's plan.
+static bool convT_wino_use(int B, int H, int W, int cin, int N) {
+    return convT_wino_ok(H, W, cin, N) && convT_wino_splits(B, H, W, cin, N) <= 2;
+}
 static bool use_wino(const ConvW& cw, int H, int W, int cin, int N) {
     return cw.has_wu && conv_wino_ok(DDK_CONV3X3_S1, H, W, cin, N);
 }
@@ -594,6 +604,9 @@ static int run_conv(Ctx& c, int kind, const ConvW& cw, const float* src0, int c0
     a.workspace = c.W + c.ly.off_splitk;
     a.workspace_bytes = c.ly.splitk * sizeof(float);
     if (kind == DDK_CONV3X3_S1 && !weight_override && use_wino(cw, H, W, c0 + c1, N)) a.weight_wino = c.P + cw.wu;
+    // (measured, B = 32: 128 ch 16 -> 32: 47.8 -> 28.0 us; 256 ch 8 -> 16 (2 slabs): 49.4 -> 37.0; 256 ch 4 -> 8 would need 8 slabs of one
+    //  chunk each and loses, 20.7 -> 21.9: the direct kernel keeps the maps that small)
+    if (kind == DDK_CONVT4X4_S2 && !weight_override && cw.has_wu && !src1 && convT_wino_use(c.B, H, W, c0, N)) a.weight_wino = c.P + cw.wu;
     return conv_forward(a, c.st, ln);
 }
 
@@ -1090,7 +1103,10 @@ extern "C" double ddk_unet_flops_executed(const ddk_unet* u, int B, int H0, int 
         res(u->up_res[2 * i], H, W, cur_c, dout, false);
         res(u->up_res[2 * i + 1], H, W, din, 0, false);
         attn(u->up_attn[i], H, W);
-        f += conv_flops(DDK_CONVT4X4_S2, B, H, W, din, din);
+        if (u->up_conv[i].has_wu && convT_wino_use(B, H, W, din, din))  // Winograd F(2x2, 2x2) per phase: 36 position GEMMs per 2x2 input tile
+            f += 2.0 * (double)(ceil_div((long long)B * (H / 2) * (W / 2), 32) * 32) * 36.0 * din * din;
+        else
+            f += conv_flops(DDK_CONVT4X4_S2, B, H, W, din, din);
         H *= 2; W *= 2;
         cur_c = din;
     }

@@ -61,6 +61,8 @@ SIGNATURES = {
     "ddk_pack_conv_weight_wino": (_I, [_P, _P, _I, _I, _I, _P]),
     "ddk_pack_conv_weight_wino_dgrad": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "ddk_conv_wino_splits": (_I, [_I, _I, _I, _I, _I]),
+    "ddk_pack_convT_weight_wino": (_I, [_P, _P, _I, _I, _I, _P]),
+    "ddk_convT_wino_splits": (_I, [_I, _I, _I, _I, _I]),
     "ddk_conv_gn_partials": (_I, [_I, _I, _I, _I, _I, _I]),
     "ddk_groupnorm_mish_partials": (_I, [_P, _P, _I, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _F, _P]),
     "ddk_pack_conv_weight_first": (_I, [_P, _P, _I, _I, _P]),

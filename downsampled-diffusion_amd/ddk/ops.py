@@ -102,6 +102,17 @@ def pack_conv_weight_wino(w):
     return out
 
 
+def pack_convT_weight_wino(w):
+    """ConvTranspose2d weight (I, O, 4, 4) -> Winograd F(2x2, 2x2) filters per output phase [4][pad32(I)/32][9][O][32]
+    (ddk_pack_convT_weight_wino); pass as conv(CONVT4X4_S2, ..., w_wino=...)."""
+    i, o, kh, kw = w.shape
+    if (kh, kw) != (4, 4):
+        raise L.DDKError("pack_convT_weight_wino: kernel must be 4x4")
+    out = torch.empty((4, pad32(i) // 32, 9, o, 32), device=w.device, dtype=torch.float32)
+    L.check(L.load().ddk_pack_convT_weight_wino(L.ptr(_f32(w.contiguous())), L.ptr(out), i, o, pad32(i), L.stream()), "pack_convT_weight_wino")
+    return out
+
+
 def pack_conv_weight_local(w):
     """OIHW 3x3 -> the operand order of conv3x3_gn_mish (ddk_pack_conv_weight_local): [O/32][9][pad32(I)/32][1024]."""
     o, i, kh, kw = w.shape

@@ -387,6 +387,12 @@ int ddk_sampler_release_workspace(ddk_unet* u, const void* workspace);
  * dY with g'[n][c][a][b] = w[c][c_lo + n][2-a][2-b] -> [o_pad/32][16][c_hi - c_lo][32] (o_pad = O rounded up to 32), the layout
  * ddk_conv_args.weight_wino takes; w is the forward OIHW tensor (O, I, 3, 3).  Flip, transpose and pack in one kernel. */
 int ddk_pack_conv_weight_wino_dgrad(const float* w_oihw, float* dst, int O, int I, int c_lo, int c_hi, int o_pad, ddk_stream_t s);
+/* ConvTranspose2d(C, N, 4, stride 2, padding 1) weight (I, O, 4, 4) (blocks.py:35) -> its Winograd F(2x2, 2x2) form, one 3x3 set of
+ * position filters per output phase: dst[4][i_pad / 32][9][O][32] (36 * O * i_pad floats).  Passed as ddk_conv_args.weight_wino with
+ * kind DDK_CONVT4X4_S2 (c1 == 0, no resid / Mish, N % 128 == 0, even H and W) the conv runs 9/16 of the direct multiplies;
+ * ddk_convT_wino_splits() > 0 says the shape is eligible and how many channel-chunk slabs it leaves in the workspace. */
+int ddk_pack_convT_weight_wino(const float* w_iohw, float* dst, int I, int O, int i_pad, ddk_stream_t s);
+int ddk_convT_wino_splits(int B, int H, int W, int cin, int N);
 /* input gradient of conv3x3 s1 / 1x1: run ddk_conv_forward on dY with this operand; [I_pad][taps][O_pad], taps flipped */
 int ddk_pack_conv_weight_dgrad(const float* w_oihw, float* dst, int O, int I, int KH, int KW, int i_pad, int o_pad,
                                ddk_stream_t s);

@@ -85,6 +85,41 @@ def test_conv(ops, kind, B, H, W, c0, c1, N):
     assert torch.equal(out, ops.conv(code, x0, wp, bias.to(DEV), x2=x1))
 
 
+CONVT_WINO_CASES = [  # B, H, W, C, N  (ConvTranspose2d 4x4 s2 p1 as Winograd F(2x2,2x2) per phase: even H, W; C % 32 == 0; N % 128 == 0)
+    (32, 16, 16, 128, 128),        # ups.2.3 at cfg4: 256 workgroups, no split
+    (32, 8, 8, 256, 256),          # ups.1.3: two channel-chunk slabs + reduce
+    (32, 4, 4, 256, 256),          # ups.0.3: eight slabs of one chunk
+    (3, 6, 10, 96, 128),           # ragged tile block (45 tiles), odd chunk count
+    (1, 2, 2, 32, 128),            # one tile: every patch pixel but the centre is padding
+    (2, 34, 18, 64, 256),          # borders on non-square maps, two n tiles
+    (8, 64, 64, 128, 128),         # many rounds (1024 tile blocks x 4 phases)
+]
+
+
+@pytest.mark.parametrize("B,H,W,C,N", CONVT_WINO_CASES)
+def test_conv_transpose_winograd(ops, B, H, W, C, N):
+    """reference models/unet/blocks.py:32-39 (Upsample = ConvTranspose2d(dim, dim, 4, 2, 1)): the Winograd F(2x2, 2x2)-per-phase kernel
+    == F.conv_transpose2d (2e-5 of the tensor's max, the bar of the direct kernels), == the direct im2col kernel to the same bar,
+    bit-stable run to run"""
+    x = rnd(B, C, H, W, seed=11)
+    w = rnd(C, N, 4, 4, seed=12, scale=(C * 4) ** -0.5)
+    bias = rnd(N, seed=13, scale=0.1)
+    ref = F.conv_transpose2d(x, w, bias, stride=2, padding=1)
+    wd = w.to(DEV)
+    wp, wu = ops.pack_convT_weight(wd), ops.pack_convT_weight_wino(wd)
+    assert ops.L.load().ddk_convT_wino_splits(B, H, W, C, N) > 0
+    xh = to_nhwc(x).to(DEV)
+    out = ops.conv(ops.CONVT4X4_S2, xh, wp, bias.to(DEV), w_wino=wu)
+    assert out.shape == (B, 2 * H, 2 * W, N)
+    assert rel_err(to_nchw(out.cpu()), ref) < 2e-5
+    direct = ops.conv(ops.CONVT4X4_S2, xh, wp, bias.to(DEV))
+    assert rel_err(out.cpu(), direct.cpu()) < 2e-5
+    assert not torch.equal(out, direct), "the Winograd form really ran (it sums in another order)"
+    assert torch.equal(out, ops.conv(ops.CONVT4X4_S2, xh, wp, bias.to(DEV), w_wino=wu))
+    out_nb = ops.conv(ops.CONVT4X4_S2, xh, wp, None, w_wino=wu)
+    assert rel_err(to_nchw(out_nb.cpu()), ref - bias[None, :, None, None]) < 2e-5
+
+
 WINO_CASES = [  # B, H, W, c0, c1, N  (Winograd F(2x2,3x3): even H, W; cin % 32 == 0; N % 64 == 0)
     (2, 8, 8, 32, 0, 64),          # one chunk, 32 tiles exactly
     (2, 4, 4, 64, 0, 64),          # 8 tiles < 32: ragged tile block, channel-chunk splits

@@ -51,3 +51,17 @@ for name, H, C, N in [("128->128 @32", 32, 128, 128), ("256->256 @16", 16, 256, 
         print(f"{name:14s} two launches {t2:6.2f} us   one launch {t1:6.2f} us   max |diff| {err:.1e}", flush=True)
     else:
         print(f"{name:14s} two launches {t2:6.2f} us   (in-launch GroupNorm not eligible)", flush=True)
+
+# ---- transpose conv 4x4 stride 2 (Upsample): Winograd F(2x2,2x2) per phase against the direct im2col kernel
+print("ConvTranspose2d 4x4 s2 p1: direct im2col (+ slab reduce) vs Winograd F(2x2,2x2) per phase")
+for name, H, C in [("128 @16->32", 16, 128), ("256 @8->16", 8, 256), ("256 @4->8", 4, 256)]:
+    x = torch.randn(B, H, H, C, device="cuda")
+    w = torch.randn(C, C, 4, 4, device="cuda") * (C * 4) ** -0.5
+    wp, wu, bias = ops.pack_convT_weight(w), ops.pack_convT_weight_wino(w), torch.zeros(C, device="cuda")
+    ref = ops.conv(ops.CONVT4X4_S2, x, wp, bias)
+    out = ops.conv(ops.CONVT4X4_S2, x, wp, bias, w_wino=wu)
+    err = float((ref - out).abs().max() / ref.abs().max())
+    td = graph_time(lambda: ops.conv(ops.CONVT4X4_S2, x, wp, bias))
+    tw = graph_time(lambda: ops.conv(ops.CONVT4X4_S2, x, wp, bias, w_wino=wu))
+    ex = 2.0 * B * (H * H / 4) * 36 * C * C
+    print(f"{name:14s} direct {td:6.2f} us   Winograd {tw:6.2f} us  ({ex / tw / 1e6:5.1f} TF executed, {ex / tw / 1e6 / 157.3:.3f} of peak)  rel err {err:.1e}", flush=True)
