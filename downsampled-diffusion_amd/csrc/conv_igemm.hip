@@ -1293,6 +1293,20 @@ int conv_forward(const ddk_conv_args& a, hipStream_t st, const ConvLnFold* ln, c
     DDK_REQUIRE((long long)a.B * g.Ho * g.Wo * a.N < (1LL << 31) && (long long)a.B * a.H * a.W * (a.c0 + a.c1) < (1LL << 31),
                 "conv: tensor too large for 32-bit pixel indexing");
 
+#ifdef DDK_HOST_SANITIZE
+    {   // base + extent of every tensor the conv will touch (host_sanitize.h)
+        const long long pix_in = (long long)a.B * a.H * a.W, pix_out = (long long)a.B * g.Ho * g.Wo;
+        san::extent("conv src0", a.src0, pix_in * a.c0 * 4);
+        san::extent("conv src1", a.src1, pix_in * a.c1 * 4);
+        if (!a.defer_reduce) san::extent("conv out", a.out, pix_out * a.N * 4);
+        san::extent("conv resid", a.resid, pix_out * a.N * 4);
+        san::extent("conv bias", a.bias, (long long)a.N * 4);
+        san::extent("conv workspace", a.workspace, (long long)a.workspace_bytes);
+        san::extent("conv mish_out", a.mish_out, pix_out * a.N * 4);
+        san::extent("conv dmish_src", a.dmish_src, pix_out * a.N * 4);
+        if (a.gn_partials && a.gn_groups > 0) san::extent("conv gn_partials", a.gn_partials, (pix_out / 128) * a.gn_groups * 8);
+    }
+#endif
     DDK_REQUIRE(aligned16(a.mish_out) && aligned16(a.dmish_src), "conv: mish_out / dmish_src alignment");
     DDK_REQUIRE(!(a.mish_out || a.dmish_src) || !(a.defer_reduce || a.gn_partials || fuse || ln),
                 "conv: mish_out / dmish_src go with a plain conv (no deferred reduce, GroupNorm partials or LayerNorm folding)");

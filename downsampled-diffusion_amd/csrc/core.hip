@@ -40,6 +40,47 @@ int ensure_device_init() {
 }
 }  // namespace ddk
 
+#ifdef DDK_HOST_SANITIZE
+// ---- state of the host-sanitizer build (host_sanitize.h)
+#include <string>
+#include <vector>
+namespace ddk { namespace san {
+struct Arena { uintptr_t base; size_t bytes; std::string name; };
+static std::vector<Arena> g_arenas;
+static long g_launches = 0, g_errors = 0;
+static char g_first[512] = "";
+void fail(const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (g_errors++ == 0) std::snprintf(g_first, sizeof(g_first), "%s", buf);
+    std::fprintf(stderr, "[ddk host sanitize] %s\n", buf);
+}
+bool inside(const void* p, size_t bytes) {
+    const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+    for (const Arena& r : g_arenas)
+        if (a >= r.base && a <= r.base + r.bytes && bytes <= r.base + r.bytes - a) return true;
+    return false;
+}
+bool near_arenas(uint64_t v) {
+    if (g_arenas.empty()) return false;
+    uintptr_t lo = ~(uintptr_t)0, hi = 0;
+    for (const Arena& r : g_arenas) { if (r.base < lo) lo = r.base; if (r.base + r.bytes > hi) hi = r.base + r.bytes; }
+    const uintptr_t slack = (uintptr_t)1 << 30;
+    return v + slack >= lo && v <= hi + slack;
+}
+void count_launch() { ++g_launches; }
+}}  // namespace ddk::san
+extern "C" void ddk_san_register(const void* base, size_t bytes, const char* name) {
+    ddk::san::g_arenas.push_back({reinterpret_cast<uintptr_t>(base), bytes, name ? name : ""});
+}
+extern "C" void ddk_san_clear(void) { ddk::san::g_arenas.clear(); }
+extern "C" void ddk_san_stats(long* launches, long* errors) { *launches = ddk::san::g_launches; *errors = ddk::san::g_errors; }
+extern "C" const char* ddk_san_first_error(void) { return ddk::san::g_first; }
+#endif
+
 // Clock probe: one record {XCC id, s_memtime (shader cycles), s_memrealtime (100 MHz ticks)} per workgroup.  Two probes around a
 // timed region give the shader clock the chip held in it: d(memtime) / d(realtime) x 100 MHz, per XCC (the counters of
 // different XCCs are not comparable with each other, their rates are).

@@ -8,6 +8,10 @@
 
 #include "ddk.h"
 
+#ifdef DDK_HOST_SANITIZE      // `make asan`: the host half checked on a GPU-less machine (host_sanitize.h); never part of libddk.so
+#include "host_sanitize.h"
+#endif
+
 namespace ddk {
 
 void set_error(const char* fmt, ...);

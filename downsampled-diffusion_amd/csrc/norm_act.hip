@@ -249,6 +249,15 @@ int groupnorm_mish_parts(const float* x, const float* part, int np, const float*
                 "groupnorm_mish_partials: C must split into <= 128 groups of a multiple of 4 channels");
     DDK_REQUIRE(np > 0 && HW == np * 128 && np * groups <= 1024, "groupnorm_mish_partials: tiles_per_image * 128 must equal H*W "
                 "(and tiles_per_image * groups <= 1024)");
+#ifdef DDK_HOST_SANITIZE
+    {
+        const long long e = (long long)B * HW * C * 4;
+        san::extent("groupnorm_parts x", x, e); san::extent("groupnorm_parts out", out, e); san::extent("groupnorm_parts addend", addend, e);
+        san::extent("groupnorm_parts partials", part, (long long)B * np * groups * 8);
+        san::extent("groupnorm_parts gamma", gamma, (long long)C * 4); san::extent("groupnorm_parts beta", beta, (long long)C * 4);
+        san::extent("groupnorm_parts res x", rc_x, (long long)B * HW * rc_cin * 4);
+    }
+#endif
     DDK_REQUIRE(aligned16(x) && aligned16(out) && aligned16(gamma) && aligned16(beta) && aligned16(addend) && aligned16(temb) &&
                     temb_stride % 4 == 0, "groupnorm_mish_partials: pointers must be 16-byte aligned");
     const int units = HW * (C / 4);
@@ -465,6 +474,15 @@ int groupnorm_mish_ex(const float* x, int nslab, long long slab_stride, const fl
                 "groupnorm: alignment");
     DDK_REQUIRE(temb == nullptr || temb_stride % 4 == 0, "groupnorm: temb_stride % 4");
     DDK_REQUIRE(nslab >= 1 && (nslab == 1 || slab_stride % 4 == 0), "groupnorm: slabs");
+#ifdef DDK_HOST_SANITIZE
+    {
+        const long long e = (long long)B * HW * C * 4;
+        san::extent("groupnorm x (slabs)", x, (long long)(nslab - 1) * slab_stride * 4 + e);
+        san::extent("groupnorm out", out, e); san::extent("groupnorm addend", addend, e);
+        san::extent("groupnorm gamma", gamma, (long long)C * 4); san::extent("groupnorm beta", beta, (long long)C * 4);
+        san::extent("groupnorm conv bias", cbias, (long long)C * 4); san::extent("groupnorm workspace", ws, (long long)ws_bytes);
+    }
+#endif
     const int cpg = C / groups;
     const int ns = gn_nsplit(HW, cpg);
     if (ns == 0) {

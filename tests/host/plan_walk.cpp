@@ -1,0 +1,138 @@
+// plan_walk.cpp -- driver of the host-sanitizer build (csrc/host_sanitize.h, `make -C downsampled-diffusion_amd/csrc asan`).
+// No GPU: libddk's host half runs under ASan + UBSan with every kernel launch replaced by a checker that validates the launch
+// geometry and that every pointer it would hand to the device lies inside an arena registered here.  For each BASELINE.json
+// configuration (reference models/unet/unet.py:19-72 shapes): create the plan, pack every slot, run one ddk_unet_forward and a
+// three-step eager ddk_sampler_run, and check the size queries against the arenas they size.
+#include <sys/mman.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "ddk.h"
+
+extern "C" void ddk_san_register(const void* base, size_t bytes, const char* name);
+extern "C" void ddk_san_clear(void);
+extern "C" void ddk_san_stats(long* launches, long* errors);
+extern "C" const char* ddk_san_first_error(void);
+
+struct Arena {
+    void* p = nullptr;
+    size_t bytes = 0;
+    Arena(size_t n, const char* name) : bytes(n ? n : 16) {
+        // untouched pages cost nothing: cfg5's workspace is several GiB of address space, a few KiB of it are ever written
+        p = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+        if (p == MAP_FAILED) { std::perror("mmap"); std::exit(2); }
+        ddk_san_register(p, bytes, name);
+    }
+    ~Arena() { munmap(p, bytes); }
+    float* f() const { return static_cast<float*>(p); }
+};
+
+static int failures = 0;
+#define CHECK(cond, ...)                                      \
+    do {                                                      \
+        if (!(cond)) { ++failures; std::printf("FAIL %s:%d: ", __FILE__, __LINE__); std::printf(__VA_ARGS__); std::printf("\n"); } \
+    } while (0)
+
+static void walk(const char* name, int in_ch, int chan, std::vector<int> mults, int B, int H, int W, int T) {
+    ddk_san_clear();
+    ddk_unet_config cfg{};
+    cfg.in_ch = in_ch; cfg.chan = chan; cfg.n_levels = (int)mults.size();
+    for (size_t i = 0; i < mults.size(); ++i) cfg.mults[i] = mults[i];
+    ddk_unet* u = ddk_unet_create(&cfg);
+    CHECK(u != nullptr, "%s: ddk_unet_create: %s", name, ddk_last_error());
+    if (!u) return;
+    const size_t packed_bytes = ddk_unet_packed_bytes(u);
+    const size_t ws_bytes = ddk_unet_workspace_bytes(u, B, H, W);
+    const size_t smp_bytes = ddk_sampler_workspace_bytes(u, B, H, W, T - 1);
+    CHECK(packed_bytes > 0 && ws_bytes > 0 && smp_bytes >= ws_bytes, "%s: size queries %zu %zu %zu", name, packed_bytes, ws_bytes, smp_bytes);
+    Arena packed(packed_bytes, "packed"), ws(ws_bytes, "unet workspace"), smp(smp_bytes, "sampler workspace");
+    long long max_slot = 0;
+    const int n_slots = ddk_unet_num_slots(u);
+    for (int i = 0; i < n_slots; ++i) max_slot = std::max(max_slot, ddk_unet_slot_numel(u, i));
+    Arena canonical((size_t)max_slot * 4, "canonical weight");
+    for (int i = 0; i < n_slots; ++i) {
+        const int rc = ddk_unet_pack_slot(u, i, canonical.f(), packed.p, nullptr);
+        CHECK(rc == DDK_OK, "%s: pack slot %d (%s): %s", name, i, ddk_unet_slot_name(u, i), ddk_last_error());
+    }
+    CHECK(ddk_unet_finalize_pack(u, packed.p, nullptr) == DDK_OK, "%s: finalize_pack: %s", name, ddk_last_error());
+    const size_t xb = (size_t)B * H * W * in_ch * 4;
+    Arena x(xb, "x"), out(xb, "eps_hat"), t((size_t)B * 8, "t"), tables((size_t)5 * T * 4, "schedule tables");
+    int rc = ddk_unet_forward(u, packed.p, x.f(), static_cast<const int64_t*>(t.p), out.f(), B, H, W, ws.p, ws_bytes, nullptr);
+    CHECK(rc == DDK_OK, "%s: unet_forward: %s", name, ddk_last_error());
+    // a workspace one float short must be refused, not overrun
+    rc = ddk_unet_forward(u, packed.p, x.f(), static_cast<const int64_t*>(t.p), out.f(), B, H, W, ws.p, ws_bytes - 4, nullptr);
+    CHECK(rc == DDK_ERR_WORKSPACE, "%s: short workspace accepted (%d)", name, rc);
+    for (int opt = 0; opt <= 2; opt += 2) {          // conv + apply pairs, then the in-launch GroupNorm everywhere it is eligible
+        CHECK(ddk_unet_set_option(u, DDK_OPT_CLUSTER_GROUPNORM, opt) == DDK_OK, "%s: set_option", name);
+        rc = ddk_unet_forward(u, packed.p, x.f(), static_cast<const int64_t*>(t.p), out.f(), B, H, W, ws.p, ws_bytes, nullptr);
+        CHECK(rc == DDK_OK, "%s: unet_forward (cluster option %d): %s", name, opt, ddk_last_error());
+        CHECK(ddk_unet_cluster_check(u, ws.p, B, H, W, nullptr) == DDK_OK, "%s: cluster_check: %s", name, ddk_last_error());
+    }
+    CHECK(ddk_unet_set_option(u, DDK_OPT_CLUSTER_GROUPNORM, 1) == DDK_OK, "%s: set_option", name);
+    ddk_sampler_args a{};
+    a.unet = u; a.packed = packed.p; a.x = x.f(); a.noise = nullptr;
+    a.c_recip = tables.f(); a.c_recipm1 = tables.f() + T; a.c1 = tables.f() + 2 * T; a.c2 = tables.f() + 3 * T; a.sigma = tables.f() + 4 * T;
+    a.B = B; a.H = H; a.W = W; a.t_start = T - 1; a.t_end = T - 3; a.seed = 1; a.stream_id = 0; a.use_graph = 0;
+    a.workspace = smp.p; a.workspace_bytes = smp_bytes;
+    rc = ddk_sampler_run(&a, nullptr);
+    CHECK(rc == DDK_OK, "%s: sampler_run: %s", name, ddk_last_error());
+    a.workspace_bytes = smp_bytes - 4;
+    CHECK(ddk_sampler_run(&a, nullptr) == DDK_ERR_WORKSPACE, "%s: short sampler workspace accepted", name);
+    CHECK(ddk_unet_flops(u, B, H, W) > 0 && ddk_unet_flops_executed(u, B, H, W) > 0, "%s: flops", name);
+    CHECK(ddk_unet_workspace_bytes(u, B, H + 1, W) == 0, "%s: indivisible map accepted", name);
+    ddk_unet_destroy(u);
+    long launches = 0, errors = 0;
+    ddk_san_stats(&launches, &errors);
+    std::printf("%-34s packed %8.1f MB  workspace %9.1f MB  sampler %9.1f MB  launches so far %ld  errors %ld\n", name, packed_bytes / 1e6,
+                ws_bytes / 1e6, smp_bytes / 1e6, launches, errors);
+}
+
+int main() {
+    // BASELINE.json configs (unet_chan 128, unet_dims (1,2,2,2)); cfg1 MNIST 32x32 C_in 1 T=200; cfg2 CIFAR C_in 3; cfg3 16x16 latents
+    // of 8; cfg4 32x32 latents of 8; cfg5 the full-resolution UNet
+    walk("cfg1 mnist 1x32x32 bs16", 1, 128, {1, 2, 2, 2}, 16, 32, 32, 200);
+    walk("cfg2 cifar 3x32x32 bs64", 3, 128, {1, 2, 2, 2}, 64, 32, 32, 1000);
+    walk("cfg3 latents 8x16x16 bs64", 8, 128, {1, 2, 2, 2}, 64, 16, 16, 1000);
+    walk("cfg4 latents 8x32x32 bs32", 8, 128, {1, 2, 2, 2}, 32, 32, 32, 1000);
+    walk("cfg5 full-res 3x256x256 bs8", 3, 128, {1, 2, 2, 2}, 8, 256, 256, 1000);
+    // off-config shapes: narrow / wide widths, other depths, odd batches, non-square maps
+    walk("width 32, 2 levels, 3x24x40 b5", 3, 32, {1, 2}, 5, 24, 40, 50);
+    walk("width 64 (1,2,4), 4x48x16 b3", 4, 64, {1, 2, 4}, 3, 48, 16, 100);
+    walk("width 256 (1,1,2,2), 8x8x8 b7", 8, 256, {1, 1, 2, 2}, 7, 8, 8, 100);
+    ddk_unet_config bad{};
+    bad.in_ch = 3; bad.chan = 48; bad.n_levels = 2; bad.mults[0] = 1; bad.mults[1] = 2;
+    CHECK(ddk_unet_create(&bad) == nullptr, "unet_chan 48 accepted");
+    bad.chan = 64; bad.mults[0] = 2;
+    CHECK(ddk_unet_create(&bad) == nullptr, "unet_dims[0] = 2 accepted");
+    long launches = 0, errors = 0;
+    ddk_san_stats(&launches, &errors);
+    // the checker checks: the same forward with the workspace arena registered HALF as large as it is must be flagged
+    long seeded = 0;
+    {
+        ddk_san_clear();
+        ddk_unet_config c{};
+        c.in_ch = 3; c.chan = 32; c.n_levels = 2; c.mults[0] = 1; c.mults[1] = 2;
+        ddk_unet* u = ddk_unet_create(&c);
+        const size_t pb = ddk_unet_packed_bytes(u), wb = ddk_unet_workspace_bytes(u, 2, 8, 8);
+        Arena packed(pb, "packed"), x(2 * 8 * 8 * 3 * 4, "x"), out(2 * 8 * 8 * 3 * 4, "out"), t(16, "t");
+        void* ws = mmap(nullptr, wb, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+        ddk_san_register(ws, wb / 2, "half of the workspace");
+        std::fprintf(stderr, "[plan_walk] seeding an overrun on purpose: the next messages are expected\n");
+        (void)ddk_unet_forward(u, packed.p, x.f(), static_cast<const int64_t*>(t.p), out.f(), 2, 8, 8, ws, wb, nullptr);
+        long l2 = 0, e2 = 0;
+        ddk_san_stats(&l2, &e2);
+        seeded = e2 - errors;
+        CHECK(seeded > 0, "a workspace registered half as large as it is was not flagged");
+        munmap(ws, wb);
+        ddk_unet_destroy(u);
+        launches = l2;
+    }
+    std::printf("seeded overrun: %ld launches / ranges flagged (expected > 0)\n", seeded);
+    std::printf("host walk: %ld launches checked, %ld pointer/geometry errors, %d failed expectations%s%s\n", launches, errors, failures,
+                errors ? "; first: " : "", errors ? ddk_san_first_error() : "");
+    return (errors || failures) ? 1 : 0;
+}
