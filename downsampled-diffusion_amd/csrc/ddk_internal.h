@@ -219,6 +219,10 @@ int groupnorm_mish_parts(const float* x, const float* part, int np, const float*
                          const long long* temb_rows = nullptr, const float* rc_x = nullptr, const float* rc_w = nullptr,
                          const float* rc_b = nullptr, int rc_cin = 0, int rc_ld = 0);
 int chan_layernorm(const float* x, const float* g, const float* b, float* out, long long M, int C, float eps, hipStream_t st);
+// widths that are not multiples of 32: C real channels in rows of pitch CP = pad32(C), padding kept zero
+int groupnorm_mish_generic(const float* x, const float* gamma, const float* beta, const float* temb, int temb_stride, const float* addend,
+                           float* out, int B, int HW, int CP, int C, int groups, float eps, hipStream_t st, const long long* temb_rows = nullptr);
+int chan_layernorm_generic(const float* x, const float* g, const float* b, float* out, long long M, int CP, int C, float eps, hipStream_t st);
 int unary(int op, const float* x, float* out, long long n, hipStream_t st);
 int add(const float* a, const float* b, float* out, long long n, hipStream_t st);
 int avgpool2(const float* x, float* out, int B, int H, int W, int C, hipStream_t st);

@@ -72,6 +72,15 @@ inline hipError_t memcpy_async(void* d, const void* s, size_t n, hipMemcpyKind k
     std::memmove(d, s, n);
     return hipSuccess;
 }
+inline hipError_t memcpy2d_async(void* d, size_t dpitch, const void* s, size_t spitch, size_t width, size_t height, hipMemcpyKind) {
+    if (height == 0 || width == 0) return hipSuccess;
+    if (!inside(d, dpitch * (height - 1) + width) || !inside(s, spitch * (height - 1) + width)) {
+        fail("hipMemcpy2DAsync: a range of %zu rows x %zu bytes leaves its arena", height, width);
+        return hipSuccess;
+    }
+    for (size_t r = 0; r < height; ++r) std::memmove(static_cast<char*>(d) + r * dpitch, static_cast<const char*>(s) + r * spitch, width);
+    return hipSuccess;
+}
 inline hipError_t dev_attr(int* v, hipDeviceAttribute_t a) {
     *v = a == hipDeviceAttributeMultiprocessorCount ? 256 : a == hipDeviceAttributeNumberOfXccs ? 8 : 0;
     return hipSuccess;
@@ -85,6 +94,7 @@ inline hipError_t dev_attr(int* v, hipDeviceAttribute_t a) {
     ::ddk::san::launch(#kernel, dim3(grid), dim3(block), (size_t)(lds), (hipStream_t)(stream), ##__VA_ARGS__)
 #define hipMemsetAsync(p, v, n, s) ::ddk::san::memset_async((p), (v), (n))
 #define hipMemcpyAsync(d, s_, n, kind, st) ::ddk::san::memcpy_async((d), (s_), (n), (kind))
+#define hipMemcpy2DAsync(d, dp, s_, sp, w, h, kind, st) ::ddk::san::memcpy2d_async((d), (dp), (s_), (sp), (w), (h), (kind))
 #define hipGetDevice(pd) (*(pd) = 0, hipSuccess)
 #define hipGetDeviceCount(pn) (*(pn) = 1, hipSuccess)
 #define hipFuncSetAttribute(f, a, v) (hipSuccess)

@@ -44,30 +44,34 @@ __global__ __launch_bounds__(256) void pad_channels_kernel(const float* __restri
     }
 }
 
-// dst[o][tap][i_pad] <- w[o][i][ky][kx]
+// dst[o][tap][i_pad] <- w[o][i][ky][kx].  The input channels may come from TWO sources that are each padded on their own (the concat
+// of unet.py:97 at widths that are not multiples of 32): channels [0, split) sit at [0, split), channels [split, I) at
+// [split_pad, split_pad + I - split); split == I, split_pad == i_pad is the plain single-source layout.
 __global__ __launch_bounds__(256) void pack_conv_weight_kernel(const float* __restrict__ w, float* __restrict__ dst, int O, int I,
-                                                               int taps, int i_pad, long long total) {
+                                                               int taps, int i_pad, long long total, int split, int split_pad) {
     for (long long idx = blockIdx.x * 256LL + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
-        const int i = (int)(idx % i_pad);
+        const int ip = (int)(idx % i_pad);
         const long long r = idx / i_pad;
         const int tap = (int)(r % taps);
         const long long o = r / taps;
-        dst[idx] = i < I ? w[(o * I + i) * taps + tap] : 0.f;
+        const int i = ip < split_pad ? (ip < split ? ip : -1) : (ip - split_pad < I - split ? split + ip - split_pad : -1);
+        dst[idx] = i >= 0 ? w[(o * I + i) * taps + tap] : 0.f;
     }
 }
 
 // dst[phase][o][tap][i] <- w[i][o][ky][kx], ky = 1 - py + 2a, kx = 1 - px + 2b (phase = py*2+px, tap = a*2+b)
+// (Ip, Op: channel counts padded to 32 at widths that are not multiples of 32 -- the padding rows / columns are zero)
 __global__ __launch_bounds__(256) void pack_convT_weight_kernel(const float* __restrict__ w, float* __restrict__ dst, int I, int O,
-                                                                long long total) {
+                                                                long long total, int Ip, int Op) {
     for (long long idx = blockIdx.x * 256LL + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
-        const int i = (int)(idx % I);
-        long long r = idx / I;
+        const int i = (int)(idx % Ip);
+        long long r = idx / Ip;
         const int tap = (int)(r % 4); r /= 4;
-        const int o = (int)(r % O);
-        const int phase = (int)(r / O);
+        const int o = (int)(r % Op);
+        const int phase = (int)(r / Op);
         const int py = phase >> 1, px = phase & 1, a = tap >> 1, b = tap & 1;
         const int ky = 1 - py + 2 * a, kx = 1 - px + 2 * b;
-        dst[idx] = w[(((long long)i * O + o) * 4 + ky) * 4 + kx];
+        dst[idx] = (i < I && o < O) ? w[(((long long)i * O + o) * 4 + ky) * 4 + kx] : 0.f;
     }
 }
 
@@ -194,6 +198,15 @@ int conv1x1_small_n(const float* x, const float* w, const float* bias, float* ou
         case 256: C1_CASE(64, 1);
         case 384: C1_CASE(32, 3);
         case 512: C1_CASE(64, 2);
+        // the other multiples of 32 up to 512 (padded pitches of widths that are not multiples of 32; no tuning)
+        case 160: C1_CASE(8, 5);
+        case 224: C1_CASE(8, 7);
+        case 288: C1_CASE(8, 9);
+        case 320: C1_CASE(16, 5);
+        case 352: C1_CASE(8, 11);
+        case 416: C1_CASE(8, 13);
+        case 448: C1_CASE(16, 7);
+        case 480: C1_CASE(8, 15);
         default: break;
     }
 #undef C1_CASE
@@ -230,14 +243,30 @@ int ddk_pad_channels(const float* src, float* dst, long long M, int C, int c_pad
 int ddk_pack_conv_weight(const float* w, float* dst, int O, int I, int KH, int KW, int i_pad, ddk_stream_t s) {
     DDK_REQUIRE(w && dst && O > 0 && I > 0 && KH > 0 && KW > 0 && i_pad >= I, "pack_conv_weight: arguments");
     const long long total = (long long)O * KH * KW * i_pad;
-    hipLaunchKernelGGL(pack_conv_weight_kernel, dim3(grid1d(total)), dim3(256), 0, as_stream(s), w, dst, O, I, KH * KW, i_pad, total);
+    hipLaunchKernelGGL(pack_conv_weight_kernel, dim3(grid1d(total)), dim3(256), 0, as_stream(s), w, dst, O, I, KH * KW, i_pad, total, I, i_pad);
+    return check_launch("pack_conv_weight_kernel");
+}
+
+int ddk_pack_conv_weight_split(const float* w, float* dst, int O, int I, int KH, int KW, int i_pad, int split, int split_pad, ddk_stream_t s) {
+    DDK_REQUIRE(w && dst && O > 0 && I > 0 && KH > 0 && KW > 0 && split > 0 && split <= I && split_pad >= split &&
+                    i_pad >= split_pad + (I - split), "pack_conv_weight_split: arguments");
+    const long long total = (long long)O * KH * KW * i_pad;
+    hipLaunchKernelGGL(pack_conv_weight_kernel, dim3(grid1d(total)), dim3(256), 0, as_stream(s), w, dst, O, I, KH * KW, i_pad, total, split,
+                       split_pad);
     return check_launch("pack_conv_weight_kernel");
 }
 
 int ddk_pack_convT_weight(const float* w, float* dst, int I, int O, ddk_stream_t s) {
     DDK_REQUIRE(w && dst && I > 0 && O > 0, "pack_convT_weight: arguments");
     const long long total = 16LL * I * O;
-    hipLaunchKernelGGL(pack_convT_weight_kernel, dim3(grid1d(total)), dim3(256), 0, as_stream(s), w, dst, I, O, total);
+    hipLaunchKernelGGL(pack_convT_weight_kernel, dim3(grid1d(total)), dim3(256), 0, as_stream(s), w, dst, I, O, total, I, O);
+    return check_launch("pack_convT_weight_kernel");
+}
+
+int ddk_pack_convT_weight_padded(const float* w, float* dst, int I, int O, int c_pad, ddk_stream_t s) {
+    DDK_REQUIRE(w && dst && I > 0 && O > 0 && c_pad >= I && c_pad >= O && c_pad % 32 == 0, "pack_convT_weight_padded: arguments");
+    const long long total = 16LL * c_pad * c_pad;
+    hipLaunchKernelGGL(pack_convT_weight_kernel, dim3(grid1d(total)), dim3(256), 0, as_stream(s), w, dst, I, O, total, c_pad, c_pad);
     return check_launch("pack_convT_weight_kernel");
 }
 

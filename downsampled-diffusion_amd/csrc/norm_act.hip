@@ -536,6 +536,79 @@ int groupnorm_mish(const float* x, const float* gamma, const float* beta, const 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Generic forms for widths that are not multiples of 32 (reference blocks.py:75: GroupNorm(8, C) accepts any C % 8 == 0, e.g.
+// unet_chan = 24).  Activations keep a padded pitch CP = pad32(C) whose padding is zero, so every conv kernel runs unchanged
+// (zero weight rows / columns); only the normalisations see the real channel count.  Correctness first: three plain passes, no tuning.
+// One workgroup per (image, group); workgroup `groups` of an image zeroes the padding channels of the output.
+__global__ __launch_bounds__(256) void gn_mish_generic_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, const float* __restrict__ temb, int temb_stride,
+                                                              const long long* __restrict__ temb_rows, const float* __restrict__ addend,
+                                                              float* __restrict__ out, int HW, int CP, int C, int groups, float eps) {
+    __shared__ float red[32];
+    const int b = blockIdx.x / (groups + 1), g = blockIdx.x % (groups + 1), tid = threadIdx.x;
+    const float* xb = x + (long long)b * HW * CP;
+    float* ob = out + (long long)b * HW * CP;
+    if (g == groups) {
+        const int np = CP - C;
+        for (long long e = tid; e < (long long)HW * np; e += 256) ob[(e / np) * CP + C + (int)(e % np)] = 0.f;
+        return;
+    }
+    const int cpg = C / groups, c0 = g * cpg;
+    const long long n = (long long)HW * cpg;
+    float s = 0.f;
+    for (long long e = tid; e < n; e += 256) s += xb[(e / cpg) * CP + c0 + (int)(e % cpg)];
+    const float mean = block_sum(s, red) / (float)n;
+    float q = 0.f;
+    for (long long e = tid; e < n; e += 256) {
+        const float d = xb[(e / cpg) * CP + c0 + (int)(e % cpg)] - mean;
+        q += d * d;
+    }
+    const float rstd = 1.0f / sqrtf(block_sum(q, red) / (float)n + eps);
+    const long long trow = temb ? (temb_rows ? temb_rows[b] : b) : 0;
+    for (long long e = tid; e < n; e += 256) {
+        const long long pix = e / cpg;
+        const int c = c0 + (int)(e % cpg);
+        float v = mish_f((xb[pix * CP + c] - mean) * rstd * gamma[c] + beta[c]);
+        if (temb) v += temb[trow * temb_stride + c];
+        if (addend) v += addend[((long long)b * HW + pix) * CP + c];
+        ob[pix * CP + c] = v;
+    }
+}
+
+// per-pixel LayerNorm over the C real channels of a CP-pitched row, eps on the std (blocks.py:57-60); one wave per pixel
+__global__ __launch_bounds__(256) void chan_layernorm_generic_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                                     const float* __restrict__ bta, float* __restrict__ out, long long M, int CP,
+                                                                     int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    for (long long pix = blockIdx.x * 4LL + (threadIdx.x >> 6); pix < M; pix += (long long)gridDim.x * 4) {
+        const float* xr = x + pix * CP;
+        float s = 0.f;
+        for (int c = lane; c < C; c += 64) s += xr[c];
+        const float mean = wave_sum(s) / (float)C;
+        float q = 0.f;
+        for (int c = lane; c < C; c += 64) { const float d = xr[c] - mean; q += d * d; }
+        const float inv = 1.0f / (sqrtf(wave_sum(q) / (float)C) + eps);
+        for (int c = lane; c < CP; c += 64) out[pix * CP + c] = c < C ? (xr[c] - mean) * inv * g[c] + bta[c] : 0.f;
+    }
+}
+
+int groupnorm_mish_generic(const float* x, const float* gamma, const float* beta, const float* temb, int temb_stride, const float* addend,
+                           float* out, int B, int HW, int CP, int C, int groups, float eps, hipStream_t st, const long long* temb_rows) {
+    DDK_REQUIRE(x && gamma && beta && out && B > 0 && HW > 0 && groups > 0 && C > 0 && C % groups == 0 && CP >= C,
+                "groupnorm (generic): arguments");
+    hipLaunchKernelGGL(gn_mish_generic_kernel, dim3((unsigned)(B * (groups + 1))), dim3(256), 0, st, x, gamma, beta, temb, temb_stride, temb_rows,
+                       addend, out, HW, CP, C, groups, eps);
+    return check_launch("gn_mish_generic_kernel");
+}
+
+int chan_layernorm_generic(const float* x, const float* g, const float* b, float* out, long long M, int CP, int C, float eps, hipStream_t st) {
+    DDK_REQUIRE(x && g && b && out && M > 0 && C > 0 && CP >= C, "layernorm (generic): arguments");
+    const long long blocks = ceil_div(M, 4);
+    hipLaunchKernelGGL(chan_layernorm_generic_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, st, x, g, b, out, M, CP, C, eps);
+    return check_launch("chan_layernorm_generic_kernel");
+}
+
+// ------------------------------------------------------------------------------------------------
 // Channel LayerNorm: LPP lanes per pixel (C/4 capped at 64), 64/LPP pixels per wave, the pixel's C
 // floats live in registers, mean and biased variance by xor-shuffles inside the lane group.
 template <int LPP, int VPL>

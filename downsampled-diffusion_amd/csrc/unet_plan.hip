@@ -24,7 +24,8 @@ constexpr float GN_EPS = 1e-5f, LN_EPS = 1e-5f;
 
 static inline int pad32(int c) { return (c + 31) / 32 * 32; }
 
-enum PackKind { PK_COPY = 0, PK_CONV = 1, PK_CONVT = 2, PK_LINEAR_T = 3, PK_WINO = 4, PK_LOCAL = 5, PK_WLOCAL = 6, PK_FIRST = 7, PK_CONVT_WINO = 8 };
+enum PackKind { PK_COPY = 0, PK_CONV = 1, PK_CONVT = 2, PK_LINEAR_T = 3, PK_WINO = 4, PK_LOCAL = 5, PK_WLOCAL = 6, PK_FIRST = 7, PK_CONVT_WINO = 8,
+                PK_ROWS = 9 /* [O][I] rows into rows of pitch ld */ };
 
 struct Slot {
     std::string name;
@@ -32,6 +33,7 @@ struct Slot {
     int kind;
     size_t off;  // float offset into the packed arena
     int O, I, KH, KW, i_pad, ld, col0;
+    int split = 0, split_pad = 0;   // PK_CONV over two separately padded sources (generic widths): see ddk_pack_conv_weight_split
     int attn = -1;  // >= 0: the slot feeds the folded LayerNorm of that attention site (packing it re-derives W o g, W g, W b)
 };
 
@@ -48,15 +50,16 @@ struct ConvW {
     size_t wf = 0;          // conv_first.hip's operand-order copy (the network's first conv, C_in <= 8); has_wf
     bool has_wf = false;
 };
-struct NormW { size_t g = 0, b = 0; };
+struct NormW { size_t g = 0, b = 0; int c_real = 0; };
 struct ResW {
-    int ci = 0, ci_pad = 0, co = 0, temb_off = 0;
+    // ci / co: channel counts as the kernels see them (co is padded to 32 at generic widths); *_real: the reference's
+    int ci = 0, ci_pad = 0, co = 0, temb_off = 0, ci_real = 0, co_real = 0;
     ConvW c1, c2, res;
     NormW n1, n2;
     bool has_res = false;
 };
 struct AttnW {
-    int c = 0;
+    int c = 0, c_real = 0;
     NormW ln;
     ConvW qkv, out;
     // LayerNorm folded into to_qkv (derived at pack time by ddk_unet_finalize_pack): W o g, W g, W b
@@ -98,6 +101,11 @@ struct ddk_unet {
     int cluster_limit = 1 << 30;             // diagnostic: only the first so many eligible launches of a forward take that path
     int cluster_np_max = 8;                  // largest cluster (workgroups per image and n tile) that takes the path
     bool attn_fold = true;                   // attention on maps with HW > 256, C = 128: q projection + apply + to_out as ONE per-image C x C conv
+    // unet_chan % 8 == 0 but not % 32 (reference blocks.py:75 takes any GroupNorm(8, C)): every tensor keeps a pitch of pad32(C) channels
+    // with zero padding, the convs run on the generic im2col kernels over zero-padded weights and the normalisations on their
+    // generic forms (norm_act.hip) -- correct, untuned, none of the fused paths
+    bool generic = false;
+    std::vector<int> dimp;                   // dims padded to 32 (== dims unless generic)
     std::vector<Slot> slots;
     size_t packed_floats = 0;
     int L = 0;
@@ -126,13 +134,21 @@ struct ddk_unet {
     void add_copy_at(const std::string& name, long long n, size_t off) {
         slots.push_back(Slot{name, n, PK_COPY, off, 0, 0, 0, 0, 0, 0, 0});
     }
-    ConvW add_conv(const std::string& prefix, int cout, int cin, int k, bool bias, bool gn_follows = false) {
+    // split > 0: the cin input channels are the concat of two sources of `split` and cin - split channels, each padded to 32 on its own
+    ConvW add_conv(const std::string& prefix, int cout, int cin, int k, bool bias, bool gn_follows = false, int split = 0) {
         ConvW c;
-        c.cin = cin; c.cin_pad = pad32(cin); c.cout = cout;
-        c.w = alloc((size_t)cout * k * k * c.cin_pad);
-        slots.push_back(Slot{prefix + "weight", (long long)cout * cin * k * k, PK_CONV, c.w, cout, cin, k, k, c.cin_pad, 0, 0});
+        c.cin = cin; c.cin_pad = split > 0 ? pad32(split) + pad32(cin - split) : pad32(cin); c.cout = cout;
+        const int cout_rows = pad32(cout);          // rows beyond cout stay zero (the arena is zero-filled): N as the kernels see it
+        c.w = alloc((size_t)cout_rows * k * k * c.cin_pad);
+        Slot sl{prefix + "weight", (long long)cout * cin * k * k, PK_CONV, c.w, cout, cin, k, k, c.cin_pad, 0, 0};
+        if (split > 0 && c.cin_pad != cin) { sl.split = split; sl.split_pad = pad32(split); }
+        slots.push_back(sl);
         c.has_bias = bias;
-        if (bias) c.b = add_copy(prefix + "bias", cout);
+        if (bias) {
+            c.b = alloc((size_t)cout_rows);
+            slots.push_back(Slot{prefix + "bias", cout, PK_COPY, c.b, 0, 0, 0, 0, 0, 0, 0});
+        }
+        if (generic) return c;                      // no Winograd / image-local / first-layer copies: the generic kernels only
         if (k == 3 && cout % 64 == 0) {
             // the same state_dict tensor feeds a second slot: its Winograd-domain form G g G^T for conv3x3_wino_kernel
             c.wu = alloc((size_t)16 * cout * c.cin_pad);
@@ -154,11 +170,12 @@ struct ddk_unet {
     }
     ConvW add_convT(const std::string& prefix, int ch) {
         ConvW c;
-        c.cin = ch; c.cin_pad = ch; c.cout = ch;
-        c.w = alloc((size_t)16 * ch * ch);
-        slots.push_back(Slot{prefix + "weight", (long long)16 * ch * ch, PK_CONVT, c.w, ch, ch, 4, 4, ch, 0, 0});
+        c.cin = ch; c.cin_pad = pad32(ch); c.cout = ch;
+        c.w = alloc((size_t)16 * pad32(ch) * pad32(ch));
+        slots.push_back(Slot{prefix + "weight", (long long)16 * ch * ch, PK_CONVT, c.w, ch, ch, 4, 4, pad32(ch), 0, 0});
         c.has_bias = true;
-        c.b = add_copy(prefix + "bias", ch);
+        c.b = alloc((size_t)pad32(ch));
+        slots.push_back(Slot{prefix + "bias", ch, PK_COPY, c.b, 0, 0, 0, 0, 0, 0, 0});
         if (ch % 128 == 0) {
             // the same tensor's Winograd F(2x2, 2x2) form, four phases x 9 positions (conv_winoT_kernel.inc)
             c.wu = alloc((size_t)36 * ch * ch);
@@ -169,30 +186,37 @@ struct ddk_unet {
     }
     NormW add_norm(const std::string& wname, const std::string& bname, int c) {
         NormW n;
-        n.g = add_copy(wname, c);
-        n.b = add_copy(bname, c);
+        n.c_real = c;
+        n.g = alloc((size_t)pad32(c));              // padding stays zero
+        slots.push_back(Slot{wname, c, PK_COPY, n.g, 0, 0, 0, 0, 0, 0, 0});
+        n.b = alloc((size_t)pad32(c));
+        slots.push_back(Slot{bname, c, PK_COPY, n.b, 0, 0, 0, 0, 0, 0, 0});
         return n;
     }
-    ResW add_res(const std::string& p, int ci, int co, int& temb_cursor) {
+    // ci, co: the reference's channel counts; split > 0: the input is the concat (unet.py:97) of `split` + (ci - split) channels
+    ResW add_res(const std::string& p, int ci, int co, int& temb_cursor, int split = 0) {
         ResW r;
-        r.ci = ci; r.ci_pad = pad32(ci); r.co = co;
+        r.ci_real = ci; r.co_real = co;
+        r.ci = ci; r.ci_pad = split > 0 ? pad32(split) + pad32(ci - split) : pad32(ci); r.co = pad32(co);
+        if (!generic) r.co = co;
         r.temb_off = temb_cursor;
         temb_cursor += co;
         slots.push_back(Slot{p + "mlp.1.weight", (long long)co * time_dim, PK_LINEAR_T, temb_wt, co, time_dim, 0, 0, 0, temb_total, r.temb_off});
         add_copy_at(p + "mlp.1.bias", co, temb_bias + r.temb_off);
-        r.c1 = add_conv(p + "block1.block.0.", co, ci, 3, true, true);
+        r.c1 = add_conv(p + "block1.block.0.", co, ci, 3, true, true, split);
         r.n1 = add_norm(p + "block1.block.1.weight", p + "block1.block.1.bias", co);
         r.c2 = add_conv(p + "block2.block.0.", co, co, 3, true, true);
         r.n2 = add_norm(p + "block2.block.1.weight", p + "block2.block.1.bias", co);
         r.has_res = ci != co;
-        if (r.has_res) r.res = add_conv(p + "res_conv.", co, ci, 1, true);
+        if (r.has_res) r.res = add_conv(p + "res_conv.", co, ci, 1, true, false, split);
         return r;
     }
     int n_attn = 0;
     std::vector<AttnW> attn_all;   // copies in creation order (slot.attn indexes this)
     AttnW add_attn(const std::string& p, int c) {
         AttnW a;
-        a.c = c;
+        a.c = generic ? pad32(c) : c;
+        a.c_real = c;
         const size_t s0 = slots.size();
         a.qkv = add_conv(p + "fn.fn.to_qkv.", 3 * HIDDEN, c, 1, false);
         const size_t s1 = slots.size();
@@ -221,16 +245,20 @@ static int total_temb(const ddk_unet& u) {
 }
 
 extern "C" ddk_unet* ddk_unet_create(const ddk_unet_config* cfg) {
-    if (!cfg || cfg->n_levels < 1 || cfg->n_levels > 8 || cfg->in_ch < 1 || cfg->chan < 32 || cfg->chan % 32 ||
+    if (!cfg || cfg->n_levels < 1 || cfg->n_levels > 8 || cfg->in_ch < 1 || cfg->chan < 8 || cfg->chan % 8 ||
         cfg->chan > 512) {
-        set_error("unet_create: need 1 <= n_levels <= 8, in_ch >= 1, unet_chan a multiple of 32 in [32, 512]");
+        // (GroupNorm(8, C) of blocks.py:75 needs C % 8 == 0 in the reference too; multiples of 32 take the tuned kernels, other
+        //  multiples of 8 the generic ones)
+        set_error("unet_create: need 1 <= n_levels <= 8, in_ch >= 1, unet_chan a multiple of 8 in [8, 512]");
         return nullptr;
     }
     for (int i = 0; i < cfg->n_levels; ++i)
         if (cfg->mults[i] < 1) { set_error("unet_create: unet_dims entries must be >= 1"); return nullptr; }
     if (cfg->mults[0] != 1) {
-        // final_conv is Block(dim, dim) on the last up level's dims[1] channels (unet.py:69-72): only consistent for mult 1
-        set_error("unet_create: unet_dims[0] must be 1 (final Block(dim, dim), unet.py:69)");
+        // final_conv is Block(dim, dim) applied to the last up level's dim * unet_dims[0] channels (unet.py:59-72): the reference
+        // itself cannot run a forward with unet_dims[0] != 1 (its Conv2d raises on the channel mismatch), so this is not a narrowing
+        set_error("unet_create: unet_dims[0] must be 1 (the reference's final Block(dim, dim) meets dim * unet_dims[0] channels "
+                  "otherwise and raises, unet.py:69-72)");
         return nullptr;
     }
     {   // best effort: a plan can be created on a host without a GPU (shape / FLOP queries); launches re-check
@@ -241,8 +269,12 @@ extern "C" ddk_unet* ddk_unet_create(const ddk_unet_config* cfg) {
     ddk_unet* u = new ddk_unet();
     u->cfg = *cfg;
     u->L = cfg->n_levels;
+    u->generic = cfg->chan % 32 != 0;
+    for (int i = 0; i < cfg->n_levels; ++i)
+        if (cfg->chan * cfg->mults[i] > 512) { set_error("unet_create: level widths above 512 channels are not supported"); delete u; return nullptr; }
     u->dims.push_back(cfg->in_ch);
     for (int i = 0; i < u->L; ++i) u->dims.push_back(cfg->chan * cfg->mults[i]);
+    for (int d : u->dims) u->dimp.push_back(u->generic ? pad32(d) : d);
     u->time_dim = cfg->chan;
     u->temb_total = total_temb(*u);
     const int td = u->time_dim;
@@ -262,7 +294,7 @@ extern "C" ddk_unet* ddk_unet_create(const ddk_unet_config* cfg) {
         const std::string p = "downs." + std::to_string(l) + ".";
         const int ci = u->dims[l], co = u->dims[l + 1];
         u->down_res.push_back(u->add_res(p + "0.", ci, co, cur));
-        if (l == 0 && ci <= 8 && co <= 256) {
+        if (l == 0 && ci <= 8 && co <= 256 && !u->generic) {
             // the network's first conv also gets conv_first.hip's layout (K = 9 * C_in exactly, unpadded input)
             ConvW& c1 = u->down_res[0].c1;
             const int K2 = (9 * ci + 1) / 2;
@@ -281,14 +313,20 @@ extern "C" ddk_unet* ddk_unet_create(const ddk_unet_config* cfg) {
     for (int i = 0; i < u->L - 1; ++i) {
         const std::string p = "ups." + std::to_string(i) + ".";
         const int din = u->dims[u->L - 1 - i], dout = u->dims[u->L - i];  // reversed(in_out[1:])[i]
-        u->up_res.push_back(u->add_res(p + "0.", 2 * dout, din, cur));
+        u->up_res.push_back(u->add_res(p + "0.", 2 * dout, din, cur, dout));
         u->up_res.push_back(u->add_res(p + "1.", din, din, cur));
         u->up_attn.push_back(u->add_attn(p + "2.", din));
         u->up_conv.push_back(u->add_convT(p + "3.conv.", din));
     }
     u->final_conv = u->add_conv("final_conv.0.block.0.", cfg->chan, cfg->chan, 3, true, true);
     u->final_norm = u->add_norm("final_conv.0.block.1.weight", "final_conv.0.block.1.bias", cfg->chan);
-    u->final_w = u->add_copy("final_conv.1.weight", (long long)cfg->in_ch * cfg->chan);
+    if (u->generic) {        // rows of pitch pad32(chan): the projection reads the padded activation
+        u->final_w = u->alloc((size_t)cfg->in_ch * pad32(cfg->chan));
+        u->slots.push_back(Slot{"final_conv.1.weight", (long long)cfg->in_ch * cfg->chan, PK_ROWS, u->final_w, cfg->in_ch, cfg->chan, 0, 0, 0,
+                                pad32(cfg->chan), 0});
+    } else {
+        u->final_w = u->add_copy("final_conv.1.weight", (long long)cfg->in_ch * cfg->chan);
+    }
     u->final_b = u->add_copy("final_conv.1.bias", cfg->in_ch);
     if (cur != u->temb_total) {
         set_error("unet_create: internal temb accounting mismatch");
@@ -442,8 +480,17 @@ extern "C" int ddk_unet_pack_slot(const ddk_unet* u, int slot, const float* cano
             DDK_HIP(hipMemcpyAsync(dst, canonical, (size_t)sl.numel * sizeof(float), hipMemcpyDeviceToDevice, as_stream(s)));
             rc = DDK_OK;
             break;
-        case PK_CONV: rc = ddk_pack_conv_weight(canonical, dst, sl.O, sl.I, sl.KH, sl.KW, sl.i_pad, s); break;
-        case PK_CONVT: rc = ddk_pack_convT_weight(canonical, dst, sl.I, sl.O, s); break;
+        case PK_CONV:
+            rc = sl.split > 0 ? ddk_pack_conv_weight_split(canonical, dst, sl.O, sl.I, sl.KH, sl.KW, sl.i_pad, sl.split, sl.split_pad, s)
+                              : ddk_pack_conv_weight(canonical, dst, sl.O, sl.I, sl.KH, sl.KW, sl.i_pad, s);
+            break;
+        case PK_CONVT: rc = sl.i_pad == sl.I ? ddk_pack_convT_weight(canonical, dst, sl.I, sl.O, s)
+                                             : ddk_pack_convT_weight_padded(canonical, dst, sl.I, sl.O, sl.i_pad, s); break;
+        case PK_ROWS:
+            DDK_HIP(hipMemcpy2DAsync(dst, (size_t)sl.ld * sizeof(float), canonical, (size_t)sl.I * sizeof(float), (size_t)sl.I * sizeof(float),
+                                     (size_t)sl.O, hipMemcpyDeviceToDevice, as_stream(s)));
+            rc = DDK_OK;
+            break;
         case PK_LINEAR_T: rc = ddk_pack_linear_T(canonical, dst, sl.O, sl.I, sl.ld, sl.col0, s); break;
         case PK_WINO: rc = ddk_pack_conv_weight_wino(canonical, dst, sl.O, sl.I, sl.i_pad, s); break;
         case PK_LOCAL: rc = ddk_pack_conv_weight_local(canonical, dst, sl.O, sl.I, sl.i_pad, s); break;
@@ -531,11 +578,11 @@ static Layout make_layout(const ddk_unet& u, int B, int H0, int W0) {
         res_sizes(u.down_res[2 * l], B, H, W, ly);
         res_sizes(u.down_res[2 * l + 1], B, H, W, ly);
         attn_sizes(u.down_attn[l], B, H, W, ly);
-        ly.skip[l] = al4((size_t)B * H * W * u.dims[l + 1]);
+        ly.skip[l] = al4((size_t)B * H * W * u.dimp[l + 1]);
         if (l < u.L - 1) {
-            upd(ly.splitk, conv_workspace_bytes(DDK_CONV3X3_S2, B, H, W, u.dims[l + 1], u.dims[l + 1]) / 4);
+            upd(ly.splitk, conv_workspace_bytes(DDK_CONV3X3_S2, B, H, W, u.dimp[l + 1], u.dimp[l + 1]) / 4);
             H /= 2; W /= 2;
-            upd(ly.act, (size_t)B * H * W * u.dims[l + 1]);
+            upd(ly.act, (size_t)B * H * W * u.dimp[l + 1]);
         }
     }
     res_sizes(u.mid1, B, H, W, ly);
@@ -545,14 +592,14 @@ static Layout make_layout(const ddk_unet& u, int B, int H0, int W0) {
         res_sizes(u.up_res[2 * i], B, H, W, ly);
         res_sizes(u.up_res[2 * i + 1], B, H, W, ly);
         attn_sizes(u.up_attn[i], B, H, W, ly);
-        const int c = u.up_conv[i].cout;
+        const int c = pad32(u.up_conv[i].cout);
         upd(ly.splitk, conv_workspace_bytes(DDK_CONVT4X4_S2, B, H, W, c, c) / 4);
         H *= 2; W *= 2;
         upd(ly.act, (size_t)B * H * W * c);
     }
-    upd(ly.act, (size_t)B * H * W * u.cfg.chan);
-    upd(ly.splitk, conv3_ws_floats(u.final_conv, B, H, W, u.cfg.chan, u.cfg.chan));
-    upd(ly.gn_ws, groupnorm_workspace_bytes(B, H * W, u.cfg.chan, GROUPS) / 4);
+    upd(ly.act, (size_t)B * H * W * pad32(u.cfg.chan));
+    upd(ly.splitk, conv3_ws_floats(u.final_conv, B, H, W, pad32(u.cfg.chan), pad32(u.cfg.chan)));
+    upd(ly.gn_ws, groupnorm_workspace_bytes(B, H * W, pad32(u.cfg.chan), GROUPS) / 4);
     upd(ly.gn_ws, (size_t)2 * GROUPS * ((size_t)B * H * W / 128 + 1));
     ly.xpad = al4((size_t)B * H0 * W0 * pad32(u.cfg.in_ch));
     ly.temb = al4((size_t)B * u.temb_total);
@@ -619,6 +666,13 @@ static bool conv_gn_is_local(const ConvW& cw, int B, int H, int W, int c0, int c
 
 static int run_conv_gn(Ctx& c, const ConvW& cw, const float* src0, int c0, const float* src1, int c1, float* raw, const NormW& n,
                        const float* temb, const float* addend, float* out, int H, int W, int N, const AddendSlabs& as = AddendSlabs()) {
+    if (c.u.generic) {
+        // widths that are not multiples of 32: plain conv over the zero-padded weights, then GroupNorm over the REAL channels
+        if (as.n > 1) return fail_arg("run_conv_gn: slab addend on the generic path");
+        DDK_TRY(run_conv(c, DDK_CONV3X3_S1, cw, src0, c0, src1, c1, nullptr, raw, H, W, N));
+        return groupnorm_mish_generic(raw, c.P + n.g, c.P + n.b, temb, c.u.temb_total, addend, out, c.B, H * W, N, n.c_real, GROUPS, GN_EPS,
+                                      c.st, c.temb_rows);
+    }
     if (cw.has_wl && (H * W == 16 || (H * W == 4 && c.B % 4 == 0)) && conv_gn_local_ok(H, W, c0 + c1, c0, N, GROUPS))
         // 4x4 maps (and 2x2 maps, four images to a block): one image x 32 channels per workgroup, k reduced inside it -> statistics, Mish, shift and residual in the
         // conv's own epilogue, no slabs and no GroupNorm launch (conv_local.hip)
@@ -750,6 +804,18 @@ static int run_attn(Ctx& c, const AttnW& a, const float* x, float* out, int H, i
     float* ctx = c.W + c.ly.off_ctx;
     float* o = c.W + c.ly.off_o;
     const long long M = (long long)c.B * H * W;
+    if (c.u.generic) {
+        // LayerNorm over the real channels, then the plain projections over zero-padded weights
+        DDK_TRY(chan_layernorm_generic(x, c.P + a.ln.g, c.P + a.ln.b, xn, M, a.c, a.c_real, LN_EPS, c.st));
+        DDK_TRY(run_conv(c, DDK_CONV1X1, a.qkv, xn, a.c, nullptr, 0, nullptr, qkv, H, W, 3 * HIDDEN));
+        if (H * W <= 256) {
+            DDK_TRY(linattn_fused_small(qkv, ctx, o, c.B, H * W, HEADS, c.st));
+        } else {
+            DDK_TRY(linattn_context(qkv, ctx, c.B, H * W, HEADS, c.W + c.ly.off_splitk, c.ly.splitk * sizeof(float), c.st));
+            DDK_TRY(linattn_apply(qkv, ctx, o, c.B, H * W, HEADS, c.st));
+        }
+        return run_conv(c, DDK_CONV1X1, a.out, o, HIDDEN, nullptr, 0, x, out, H, W, a.c);
+    }
     if (H * W <= 16 && a.c % 32 == 0 && linattn_small_qkv_ok(H * W, a.c)) {
         // 4x4 maps: projection (LayerNorm folded), context and apply of one (image, head) in one workgroup -- no qkv tensor,
         // 14.6 us instead of 11.0 + 5.2.  (On 8x8 maps the projection is 4x the work on the same 128 workgroups -- half the
@@ -881,7 +947,7 @@ static int forward_core(const ddk_unet& u, const float* P, const float* x, int64
     int cur_c = pad32(u.cfg.in_ch);
     for (int l = 0; l < u.L; ++l) {
         float* skip = ws + ly.off_skip[l];
-        const int co = u.dims[l + 1];
+        const int co = u.dimp[l + 1];
         if (l == 0 && fast0) {
             const ResW& r = u.down_res[0];
             DDK_TRY(conv_first(x, P + r.c1.wf, r.c1.has_bias ? P + r.c1.b : nullptr, raw, gnp, B, H, W, r.ci, r.co, GROUPS,
@@ -923,7 +989,7 @@ static int forward_core(const ddk_unet& u, const float* P, const float* x, int64
     for (int i = 0; i < u.L - 1; ++i) {
         const int lvl = u.L - 1 - i;  // skips.pop(): the most recent skip first (unet.py:97)
         const float* skip = ws + ly.off_skip[lvl];
-        const int dout = u.dims[lvl + 1], din = u.dims[lvl];
+        const int dout = u.dimp[lvl + 1], din = u.dimp[lvl];
         DDK_TRY(run_res(c, u.up_res[2 * i], cur, cur_c, skip, dout, bufB, H, W));
         DDK_TRY(run_res(c, u.up_res[2 * i + 1], bufB, din, nullptr, 0, bufC, H, W));
         DDK_TRY(run_attn(c, u.up_attn[i], bufC, bufB, H, W));
@@ -933,7 +999,7 @@ static int forward_core(const ddk_unet& u, const float* P, const float* x, int64
         cur_c = din;
     }
     // final_conv: Block(dim, dim) then 1x1 to in_ch (unet.py:69-72)
-    const int chan = u.cfg.chan, n_out = u.cfg.in_ch;
+    const int chan = u.generic ? pad32(u.cfg.chan) : u.cfg.chan, n_out = u.cfg.in_ch;
     const int npf = u.final_conv.has_wu ? conv_wino_stats_parts(B, H, W, cur_c, chan, GROUPS) : 0;
     if (npf > 0 && final_tail_ok(H * W, chan, GROUPS, n_out, npf) && (!step || step->per == (long long)H * W * n_out)) {
         // one-pass Winograd conv with statistics, then GroupNorm + Mish + projection (+ the update of x) in ONE launch
@@ -1030,12 +1096,12 @@ extern "C" double ddk_unet_flops(const ddk_unet* u, int B, int H0, int W0) {
     if (check_shape(u, B, H0, W0) != DDK_OK) return 0;
     double f = 0;
     auto res = [&](const ResW& r, int H, int W) {
-        f += conv_flops(DDK_CONV3X3_S1, B, H, W, r.ci, r.co) + conv_flops(DDK_CONV3X3_S1, B, H, W, r.co, r.co);
-        if (r.has_res) f += conv_flops(DDK_CONV1X1, B, H, W, r.ci, r.co);
-        f += 2.0 * B * u->time_dim * r.co;  // mlp Linear
+        f += conv_flops(DDK_CONV3X3_S1, B, H, W, r.ci_real, r.co_real) + conv_flops(DDK_CONV3X3_S1, B, H, W, r.co_real, r.co_real);
+        if (r.has_res) f += conv_flops(DDK_CONV1X1, B, H, W, r.ci_real, r.co_real);
+        f += 2.0 * B * u->time_dim * r.co_real;  // mlp Linear
     };
     auto attn = [&](const AttnW& a, int H, int W) {
-        f += conv_flops(DDK_CONV1X1, B, H, W, a.c, 3 * HIDDEN) + conv_flops(DDK_CONV1X1, B, H, W, HIDDEN, a.c);
+        f += conv_flops(DDK_CONV1X1, B, H, W, a.c_real, 3 * HIDDEN) + conv_flops(DDK_CONV1X1, B, H, W, HIDDEN, a.c_real);
         f += 2.0 * 2.0 * B * HEADS * 32.0 * 32.0 * H * W;  // the two einsums
     };
     int H = H0, W = W0;

@@ -57,6 +57,8 @@ SIGNATURES = {
     "ddk_pad_channels": (_I, [_P, _P, _LL, _I, _I, _P]),
     "ddk_pack_conv_weight": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "ddk_pack_convT_weight": (_I, [_P, _P, _I, _I, _P]),
+    "ddk_pack_conv_weight_split": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "ddk_pack_convT_weight_padded": (_I, [_P, _P, _I, _I, _I, _P]),
     "ddk_pack_linear_T": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "ddk_pack_conv_weight_wino": (_I, [_P, _P, _I, _I, _I, _P]),
     "ddk_pack_conv_weight_wino_dgrad": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),

@@ -22,9 +22,10 @@ class Unet(nn.Module):
         in_channels = config['unet_in']
         dim_mults = tuple(config['unet_dims'])
         dropout = config['unet_dropout']
-        if dim % 32 != 0:
-            raise DDKError(f"unet_chan={dim}: the HIP conv kernels contract channels in chunks of 32; "
-                           "use a multiple of 32 (the reference default is 128)")
+        if dim % 8 != 0 or not 8 <= dim <= 512:
+            # the reference's GroupNorm(8, C) (blocks.py:75) needs C % 8 == 0 as well; multiples of 32 run the tuned kernels, other
+            # multiples of 8 the generic ones (channels padded to 32 with zeros inside the plan: correct, untuned, inference only)
+            raise DDKError(f"unet_chan={dim}: must be a multiple of 8 in [8, 512] (GroupNorm(8, C), reference blocks.py:75)")
         self.dim, self.in_channels, self.dim_mults = dim, in_channels, dim_mults
 
         dims = [in_channels] + [dim * m for m in dim_mults]
@@ -104,6 +105,9 @@ class Unet(nn.Module):
     def forward_nhwc(self, x, time):
         """x [B,H,W,C_in] fp32 on the device, time [B] integer -> eps_hat [B,H,W,C_in]."""
         if self._wants_grad(x):
+            if self.dim % 32 != 0:
+                raise DDKError(f"unet_chan={self.dim}: the training path (HIP backward kernels) needs unet_chan % 32 == 0; widths that are "
+                               "other multiples of 8 run inference only (wrap the call in torch.no_grad())")
             from trainers.autograd_unet import unet_forward_autograd   # training path: HIP forward + backward kernels
             return unet_forward_autograd(self, x, time)
         if self.training and self.downs[0][0].dropout.p > 0:

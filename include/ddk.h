@@ -48,9 +48,15 @@ int ddk_nhwc_to_nchw(const float* src, float* dst, int B, int C, int H, int W, i
 int ddk_pad_channels(const float* src, float* dst, long long M, int C, int c_pad, ddk_stream_t s);
 /* Conv2d weight OIHW -> [O][KH*KW][I_pad] (zero padded input channels). */
 int ddk_pack_conv_weight(const float* w_oihw, float* dst, int O, int I, int KH, int KW, int i_pad, ddk_stream_t s);
+/* The same with the input channels of TWO concatenated sources padded separately (unet.py:97 at widths that are not multiples of
+ * 32): channels [0, split) land at [0, split), channels [split, I) at [split_pad, split_pad + I - split); the rest of a row is zero. */
+int ddk_pack_conv_weight_split(const float* w_oihw, float* dst, int O, int I, int KH, int KW, int i_pad, int split, int split_pad,
+                               ddk_stream_t s);
 /* ConvTranspose2d(k4,s2,p1) weight (I,O,4,4) -> [phase 4][O][tap 4][I]; phase = py*2+px, tap = a*2+b
  * with input offset (dy,dx) = (py - a, px - b) and kernel index ky = 1 - py + 2a, kx = 1 - px + 2b. */
 int ddk_pack_convT_weight(const float* w_iohw, float* dst, int I, int O, ddk_stream_t s);
+/* ... with both channel counts padded to c_pad (a multiple of 32; zero rows / columns): dst [4][c_pad][4][c_pad] */
+int ddk_pack_convT_weight_padded(const float* w_iohw, float* dst, int I, int O, int c_pad, ddk_stream_t s);
 /* Linear weight [O][I] -> transposed [I][O] at column offset col0 of a [I][ld] matrix. */
 int ddk_pack_linear_T(const float* w_oi, float* dst, int O, int I, int ld, int col0, ddk_stream_t s);
 

@@ -103,9 +103,13 @@ int main() {
     walk("width 32, 2 levels, 3x24x40 b5", 3, 32, {1, 2}, 5, 24, 40, 50);
     walk("width 64 (1,2,4), 4x48x16 b3", 4, 64, {1, 2, 4}, 3, 48, 16, 100);
     walk("width 256 (1,1,2,2), 8x8x8 b7", 8, 256, {1, 1, 2, 2}, 7, 8, 8, 100);
+    // widths that are not multiples of 32 (GroupNorm(8, C) of the reference takes any C % 8 == 0): the generic path, padded pitches
+    walk("width 24 (1,2,4), 3x16x16 b3", 3, 24, {1, 2, 4}, 3, 16, 16, 100);
+    walk("width 40 (1,2,2,2), 8x32x32 b2", 8, 40, {1, 2, 2, 2}, 2, 32, 32, 100);
+    walk("width 8 (1,2), 1x8x8 b5", 1, 8, {1, 2}, 5, 8, 8, 50);
     ddk_unet_config bad{};
-    bad.in_ch = 3; bad.chan = 48; bad.n_levels = 2; bad.mults[0] = 1; bad.mults[1] = 2;
-    CHECK(ddk_unet_create(&bad) == nullptr, "unet_chan 48 accepted");
+    bad.in_ch = 3; bad.chan = 44; bad.n_levels = 2; bad.mults[0] = 1; bad.mults[1] = 2;
+    CHECK(ddk_unet_create(&bad) == nullptr, "unet_chan 44 accepted");
     bad.chan = 64; bad.mults[0] = 2;
     CHECK(ddk_unet_create(&bad) == nullptr, "unet_dims[0] = 2 accepted");
     long launches = 0, errors = 0;

@@ -70,8 +70,11 @@ def test_sample_shapes_and_attrs():
 
 
 def test_unet_rejects_unsupported_width():
-    with pytest.raises(L.DDKError):
-        Unet(dict(unet_chan=16, unet_in=3, unet_dims=(1, 2), unet_dropout=0.0))
+    """GroupNorm(8, C) (reference blocks.py:75): widths that are not multiples of 8 fail in the reference as well"""
+    for chan in (20, 4, 520):
+        with pytest.raises(L.DDKError):
+            Unet(dict(unet_chan=chan, unet_in=3, unet_dims=(1, 2), unet_dropout=0.0))
+    Unet(dict(unet_chan=16, unet_in=3, unet_dims=(1, 2), unet_dropout=0.0))       # a multiple of 8: accepted (generic kernels)
 
 
 def test_c_abi_exports_every_declared_symbol():

@@ -90,6 +90,50 @@ def test_unet_vs_oracle_other_shape():
     assert rel_err(y.cpu(), ref) < TOL
 
 
+@pytest.mark.parametrize("chan,dims,cin,B,H,W", [(24, (1, 2, 4), 3, 3, 24, 40), (40, (1, 2, 2, 2), 8, 2, 32, 32), (8, (1, 2), 1, 5, 8, 12),
+                                                  (72, (1, 2), 3, 2, 16, 16)])
+def test_unet_widths_that_are_not_multiples_of_32_vs_oracle(chan, dims, cin, B, H, W):
+    """reference models/unet/blocks.py:75 (GroupNorm(8, C)) and unet.py:19-27 accept any unet_chan % 8 == 0: groups of 3, 5, 1 and 9
+    channels here.  These widths run the generic path (every tensor padded to a pitch of 32 channels inside the plan, zero weight
+    rows / columns, GroupNorm and LayerNorm over the real channels): checked against the CPU oracle at the full-forward bar, and
+    run-to-run bit stable.  The sampler takes them too (3 reverse steps against the oracle's loop)."""
+    from models import DDPM, Unet
+    from oracle import diffusion_ref as D
+    from oracle import unet_ref as U
+    cfg = dict(unet_chan=chan, unet_in=cin, unet_dims=dims, unet_dropout=0.0, image_size=H, T=100, loss_type="simple",
+               beta_schedule="linear", loss_flat="sum")
+    u = det_load(Unet(cfg), "odd.").eval()
+    sd = {k: v.clone() for k, v in u.state_dict().items()}
+    x = syn.synthetic_normal((B, cin, H, W), "odd.x")
+    t = torch.tensor([5, 40, 99, 0, 77][:B])
+    ref = U.unet_forward(sd, cfg, x, t)
+    u = u.to(DEV)
+    with torch.no_grad():
+        y = u(x.to(DEV), t.to(DEV))
+        assert torch.equal(y, u(x.to(DEV), t.to(DEV)))
+    assert rel_err(y.cpu(), ref) < TOL
+    if H == W:
+        m = DDPM(cfg, u, DEV, cin).to(DEV).eval()
+        noise = torch.stack([syn.synthetic_normal((B, cin, H, W), f"odd.n{k}") for k in range(3)])
+        got = m.p_sample_loop((B, cin, H, W), early_stop=97, x_T=x, noise=noise).cpu()
+        buf = D.schedule_buffers("linear", 100)
+        want, _ = D.p_sample_loop(buf, lambda a, b: U.unet_forward(sd, cfg, a, b), x, list(noise), 100, 97)
+        assert float((got - want).abs().max()) < 1e-4
+    with pytest.raises(Exception, match="training path"):
+        u.train()(x.to(DEV).requires_grad_(True), t.to(DEV))
+
+
+def test_unet_dims0_not_1_is_rejected_like_the_reference():
+    """unet_dims[0] != 1: the reference builds the module but its forward raises (final Block(dim, dim) meets dim * unet_dims[0]
+    channels, unet.py:59-72); here the plan refuses at its first use.  Not a narrowing of the model surface."""
+    from ddk.lib import DDKError
+    from models import Unet
+    u = Unet(dict(unet_chan=32, unet_in=3, unet_dims=(2, 4), unet_dropout=0.0)).to(DEV).eval()
+    with pytest.raises(DDKError, match="unet_dims"):
+        with torch.no_grad():
+            u(torch.zeros(1, 3, 16, 16, device=DEV), torch.zeros(1, dtype=torch.long, device=DEV))
+
+
 def test_weights_repack_after_update():
     u = build(32, 3)
     x = syn.synthetic_normal((2, 3, 16, 16), "g3.x3").to(DEV)
