@@ -399,6 +399,12 @@ __global__ __launch_bounds__(256) void rows_sum_kernel(const float* __restrict__
     }
 }
 
+__global__ __launch_bounds__(256) void multi_add_kernel(const float* __restrict__ src, const long long* __restrict__ table) {
+    const long long off = table[blockIdx.y * 3], n = table[blockIdx.y * 3 + 2];
+    float* dst = reinterpret_cast<float*>(table[blockIdx.y * 3 + 1]);
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n; i += (long long)gridDim.x * 256) dst[i] += src[off + i];
+}
+
 // the same with one target pointer per batch entry (null = skip): the GroupNorm backward's dgamma / dbeta / conv-bias rows go
 // into three different gradient buffers in one launch
 struct RowsTargets { float* out[4]; };
@@ -1071,6 +1077,17 @@ int ddk_rows_sum_targets(const float* rows, int nbatch, long long batch_stride, 
     hipLaunchKernelGGL(rows_sum_targets_kernel, dim3((unsigned)ceil_div(n, 64), (unsigned)nbatch), dim3(256), 0, as_stream(s), rows, nrows,
                        row_stride, batch_stride, tg, n, accumulate);
     return check_launch("rows_sum_targets_kernel");
+}
+
+/* dst_k[i] += src[off_k + i] for every segment k of `table` ([nseg][3] int64 on the device: {source offset in floats, destination
+ * address, count}): the parameter gradients a backward produced side by side in ONE buffer go into their places in the flat
+ * gradient bucket with one launch (the time MLP alone returns 38 of them: 38 torch adds per micro-batch before). */
+int ddk_multi_add(const float* src, const long long* table, int nseg, long long max_count, ddk_stream_t s) {
+    DDK_REQUIRE(src && table && nseg > 0 && max_count > 0, "multi_add: arguments");
+    long long bx = ceil_div(max_count, 1024);
+    if (bx > 64) bx = 64;
+    hipLaunchKernelGGL(multi_add_kernel, dim3((unsigned)bx, (unsigned)nseg), dim3(256), 0, as_stream(s), src, table);
+    return check_launch("multi_add_kernel");
 }
 
 /* Channel LayerNorm backward: dx and partial rows part[2][nparts][C] (dg, db); returns nparts via *nparts_out. */

@@ -124,6 +124,9 @@ class PreActConvFn(torch.autograd.Function):
         ctx.kind = kind
         ctx.save_for_backward(h, a, weight, bias)
         ctx.has_resid = resid is not None
+        # the second output never carries a gradient: without this autograd fills a zero tensor of its shape for every backward call
+        # (36 fills of 2-33 MB per cfg3 micro-batch)
+        ctx.set_materialize_grads(False)
         if want_act:
             ctx.mark_non_differentiable(a_out)
             return out, a_out
@@ -132,6 +135,8 @@ class PreActConvFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy, _unused):
         h, a, weight, bias = ctx.saved_tensors
+        if dy is None:
+            return None, None, None, None, None, None, None
         dy = _c(dy)
         need = ctx.needs_input_grad
         dh, _, gw, gb = _conv_backward(ctx.kind, a, None, weight, bias, dy, (need[1], False, need[3], need[4]), dmish_src=h)
@@ -204,14 +209,17 @@ def groupnorm_mish(x, gamma, beta, temb=None, addend=None, drop_p=0.0, seed=0, l
 class ChanLayerNormFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, g, b, eps):
-        ctx.save_for_backward(x, g)
+        ctx.save_for_backward(x, g, b)
         ctx.eps = eps
         return ops.chan_layernorm(x, g.detach(), b.detach(), eps)
 
     @staticmethod
     def backward(ctx, dy):
-        x, g = ctx.saved_tensors
-        dx, dg, db = ops.chan_layernorm_bwd(x, g.detach(), _c(dy), ctx.eps)
+        x, g, b = ctx.saved_tensors
+        sg, sb = _grad_slot(g), _grad_slot(b)
+        dx, dg, db = ops.chan_layernorm_bwd(x, g.detach(), _c(dy), ctx.eps, acc=(sg, sb) if sg is not None and sb is not None else None)
+        if dg is None:
+            return dx, None, None, None
         return dx, dg.reshape(g.shape), db.reshape(g.shape), None
 
 
@@ -380,6 +388,7 @@ class TimeEmbedFn(torch.autograd.Function):
         ops.bias_act_(out, bcat, False)
         ctx.save_for_backward(e, u1, h1, tv, act, w1, w2, wcat)
         ctx.couts = [w.shape[0] for w in ws]
+        ctx.params = (w1, b1, w2, b2) + tuple(mlps)          # the leaves themselves: their .grad slots are looked up in the backward
         # one output per block: column ranges (views) of the single [B, sum C_out] product.  Separate outputs so that the
         # backward gets one gradient per block -- slicing a single output would make autograd build a zero-filled
         # [B, sum C_out] tensor per block and add them up.
@@ -399,9 +408,20 @@ class TimeEmbedFn(torch.autograd.Function):
         bsz, ctot = dout.shape
         d = w2.shape[0]
         dev = dout.device
-        gwcat = torch.empty_like(wcat)
+        # all 2 x 17 + 4 parameter gradients side by side in ONE buffer; when every parameter has its place in the flat gradient bucket
+        # they are added there by one launch (ddk_multi_add) instead of 38 autograd accumulation adds
+        params = ctx.params
+        slots = [_grad_slot(p) for p in params]
+        n_w, n_b = wcat.numel(), ctot
+        sizes = [n_w, n_b, w1.numel(), 4 * d, w2.numel(), d]
+        offs = [0]
+        for n in sizes:
+            offs.append(offs[-1] + (n + 3) // 4 * 4)
+        G = torch.empty(offs[-1], device=dev, dtype=torch.float32)
+        gwcat, gw1, gw2 = G[offs[0]:offs[0] + n_w].view(ctot, d), G[offs[2]:offs[2] + sizes[2]].view_as(w1), G[offs[4]:offs[4] + sizes[4]].view_as(w2)
         ops.small_gemm(2, dout, act, gwcat, ctot, d, bsz, ctot, d, d)        # dWcat[ctot][d] = dout^T act
-        gbcat = ops.rows_sum(dout, bsz, ctot, ctot)
+        ops.rows_sum(dout, bsz, ctot, ctot, out=G[offs[1]:offs[1] + n_b])
+        gbcat = G[offs[1]:offs[1] + n_b]
         dact = torch.empty((bsz, d), device=dev, dtype=torch.float32)
         ops.small_gemm(0, dout, wcat, dact, bsz, d, ctot, ctot, d, d)        # dact = dout Wcat
         grads = []
@@ -410,13 +430,20 @@ class TimeEmbedFn(torch.autograd.Function):
             grads += [gwcat[off:off + co], gbcat[off:off + co]]
             off += co
         dtv = ops.mish_bwd(tv, dact)
-        gw2 = torch.empty_like(w2)
         ops.small_gemm(2, dtv, h1, gw2, d, 4 * d, bsz, d, 4 * d, 4 * d)
-        gb2 = ops.rows_sum(dtv, bsz, d, d)
+        gb2 = ops.rows_sum(dtv, bsz, d, d, out=G[offs[5]:offs[5] + d])
         dh1 = torch.empty((bsz, 4 * d), device=dev, dtype=torch.float32)
         ops.small_gemm(0, dtv, w2.detach(), dh1, bsz, 4 * d, d, d, 4 * d, 4 * d)
         du1 = ops.mish_bwd(u1, dh1)
-        gw1 = torch.empty_like(w1)
         ops.small_gemm(2, du1, e, gw1, 4 * d, d, bsz, 4 * d, d, d)
-        gb1 = ops.rows_sum(du1, bsz, 4 * d, 4 * d)
+        gb1 = ops.rows_sum(du1, bsz, 4 * d, 4 * d, out=G[offs[3]:offs[3] + 4 * d])
+        if all(sl is not None for sl in slots):
+            segs = [(offs[2], slots[0]), (offs[3], slots[1]), (offs[4], slots[2]), (offs[5], slots[3])]
+            off = 0
+            for k, co in enumerate(ctx.couts):
+                segs.append((offs[0] + off * d, slots[4 + 2 * k]))
+                segs.append((offs[1] + off, slots[5 + 2 * k]))
+                off += co
+            ops.multi_add_(G, segs)
+            return (None,) * (6 + len(grads))
         return (None, None, gw1, gb1, gw2, gb2, *grads)

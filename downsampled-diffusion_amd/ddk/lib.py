@@ -150,6 +150,7 @@ SIGNATURES = {
     "ddk_rows_sum": (_I, [_P, _I, _LL, _P, _I, _I, _P]),
     "ddk_rows_sum_batched": (_I, [_P, _I, _LL, _I, _LL, _P, _I, _I, _P]),
     "ddk_rows_sum_targets": (_I, [_P, _I, _LL, _I, _LL, _P, _P, _P, _P, _I, _I, _P]),
+    "ddk_multi_add": (_I, [_P, _P, _I, _LL, _P]),
     "ddk_chan_layernorm_bwd": (_I, [_P, _P, _P, _P, _P, _I, C.POINTER(C.c_int), _LL, _I, _F, _P]),
     "ddk_linattn_train_workspace_bytes": (_SZ, [_I, _I, _I]),
     "ddk_linattn_stats": (_I, [_P, _P, _I, _I, _I, _P, _SZ, _P]),

@@ -716,13 +716,32 @@ def groupnorm_mish_bwd(x, gamma, beta, dy, drop_p=0.0, seed=0, layer=0, groups=G
     return dx, part[0], sums
 
 
-def rows_sum(rows, nrows, row_stride, n):
-    out = torch.empty(n, device=rows.device, dtype=torch.float32)
-    L.check(L.load().ddk_rows_sum(rows.data_ptr(), nrows, row_stride, L.ptr(out), n, 0, L.stream()), "rows_sum")
+def rows_sum(rows, nrows, row_stride, n, out=None):
+    if out is None:
+        out = torch.empty(n, device=rows.device, dtype=torch.float32)
+    L.check(L.load().ddk_rows_sum(rows.data_ptr(), nrows, row_stride, out.data_ptr(), n, 0, L.stream()), "rows_sum")
     return out
 
 
-def chan_layernorm_bwd(x, g, dy, eps=LN_EPS):
+_multi_add_tables = {}
+
+
+def multi_add_(src, segments):
+    """ddk_multi_add: dst_k += src[off_k : off_k + n_k] for segments [(offset, dst tensor), ...] in ONE launch.  The device table is
+    cached per (offsets, destination addresses): the destinations are views of the optimiser's flat gradient buffer, stable for its
+    lifetime."""
+    key = (str(src.device),) + tuple((int(o), d.data_ptr(), d.numel()) for o, d in segments)
+    tab = _multi_add_tables.get(key)
+    if tab is None:
+        if len(_multi_add_tables) > 64:
+            _multi_add_tables.clear()
+        host = torch.tensor([[int(o), d.data_ptr(), d.numel()] for o, d in segments], dtype=torch.int64)
+        tab = _multi_add_tables[key] = host.to(src.device)
+    L.check(L.load().ddk_multi_add(L.ptr(src), tab.data_ptr(), len(segments), max(d.numel() for _, d in segments), L.stream()), "multi_add")
+
+
+def chan_layernorm_bwd(x, g, dy, eps=LN_EPS, acc=None):
+    """acc = (g.grad slot, b.grad slot): the row sums are ADDED into them (one launch) and (dx, None, None) is returned"""
     c = x.shape[-1]
     m = x.numel() // c
     dx = torch.empty_like(x)
@@ -733,6 +752,10 @@ def chan_layernorm_bwd(x, g, dy, eps=LN_EPS):
     L.check(lib.ddk_chan_layernorm_bwd(L.ptr(_f32(x)), L.ptr(g.reshape(-1)), L.ptr(_f32(dy)), L.ptr(dx), L.ptr(part), max_parts,
                                        C.byref(n), m, c, eps, L.stream()), "chan_layernorm_bwd")
     # the kernel laid the rows out as [2][nparts][C] with nparts = n.value
+    if acc is not None and acc[0] is not None and acc[1] is not None:
+        L.check(lib.ddk_rows_sum_targets(L.ptr(part), 2, n.value * c, n.value, c, L.ptr(acc[0]), L.ptr(acc[1]), None, None, c, 1, L.stream()),
+                "rows_sum_targets")
+        return dx, None, None
     out = torch.empty((2, c), device=x.device, dtype=torch.float32)
     L.check(lib.ddk_rows_sum_batched(L.ptr(part), 2, n.value * c, n.value, c, L.ptr(out), c, 0, L.stream()), "rows_sum_batched")
     return dx, out[0], out[1]

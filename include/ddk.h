@@ -439,6 +439,9 @@ int ddk_rows_sum_batched(const float* rows, int nbatch, long long batch_stride, 
  * GroupNorm backward into their three gradient buffers in one launch) */
 int ddk_rows_sum_targets(const float* rows, int nbatch, long long batch_stride, int nrows, long long row_stride, float* out0, float* out1,
                          float* out2, float* out3, int n, int accumulate, ddk_stream_t s);
+/* dst_k[i] += src[off_k + i], k < nseg; table [nseg][3] int64 on the device = {source offset (floats), destination address, count};
+ * max_count = the largest count (sizes the grid).  One launch for the many parameter gradients of one backward. */
+int ddk_multi_add(const float* src, const long long* table, int nseg, long long max_count, ddk_stream_t s);
 int ddk_chan_layernorm_bwd(const float* x, const float* g, const float* dy, float* dx, float* part, int max_parts,
                            int* nparts_out, long long M, int C, float eps, ddk_stream_t s);
 /* training-path linear attention: softmax statistics of k (column max, sum of exp) and the backward.  Their reductions over the
