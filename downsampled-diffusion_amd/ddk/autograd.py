@@ -24,7 +24,37 @@ def _grad_slot(p):
     return None
 
 
-def _conv_backward(kind, x, x2, weight, bias, dy, needs, gb_ready=False, dmish_src=None):
+class GradHandoff:
+    """A gradient that would reach a tensor over a SECOND path -- the skip of a residual block -- handed from the Function that
+    produces it to the Function whose input-gradient conv can add it in its epilogue (ddk_conv_args.resid), instead of being
+    returned to autograd, which would sum the two paths with an elementwise add launch (12 of them on 17-67 MB tensors per cfg3
+    micro-batch, ~30 small ones).  Order-safe: a consumer that runs first computes alone and says so; the producer then returns
+    its gradient to autograd as before."""
+    __slots__ = ("g", "g2", "consumer_done")
+
+    def __init__(self):
+        self.g = self.g2 = None
+        self.consumer_done = False
+
+    def give(self, g, g2=None):
+        """producer side: True when the gradient was taken over (return None to autograd)"""
+        if self.consumer_done:
+            self.consumer_done = False
+            return False
+        self.g, self.g2 = g, g2
+        return True
+
+    def take(self):
+        """consumer side: (g, g2) to add, or (None, None)"""
+        if self.g is None and self.g2 is None:
+            self.consumer_done = True
+            return None, None
+        g, g2 = self.g, self.g2
+        self.g = self.g2 = None
+        return g, g2
+
+
+def _conv_backward(kind, x, x2, weight, bias, dy, needs, gb_ready=False, dmish_src=None, dx_resid=None, dx2_resid=None):
     """Shared backward of the conv family.  needs = (x, x2, weight, bias).  Returns (dx, dx2, gw, gb); gw / gb are None
     when they were accumulated straight into ``.grad``.  gb_ready: the bias gradient was already produced elsewhere
     (by the GroupNorm backward that follows the conv).  dmish_src: x is Mish(dmish_src) and dx is wanted with respect to
@@ -70,10 +100,17 @@ def _conv_backward(kind, x, x2, weight, bias, dy, needs, gb_ready=False, dmish_s
             # 3x3 input gradients (also the zero-stuffed stride-2 one) run as Winograd F(2x2,3x3) where the shape allows
             wino = k == ops.CONV3X3_S1 and dmish_src is None
             if need_x:
-                dx = ops.conv(k, src, wd[:c0], n_out=c0, dmish_src=dmish_src,
+                dx = ops.conv(k, src, wd[:c0], n_out=c0, dmish_src=dmish_src, resid=dx_resid,
                               w_wino=ops.wino_weight(weight, src.shape, 0, min(c0, weight.shape[1]), dgrad=True) if wino and c0 <= weight.shape[1] else None)
+                dx_resid = None
             if need_x2:
-                dx2 = ops.conv(k, src, wd[c0:], n_out=c1, w_wino=ops.wino_weight(weight, src.shape, c0, c0 + c1, dgrad=True) if wino else None)
+                dx2 = ops.conv(k, src, wd[c0:], n_out=c1, resid=dx2_resid,
+                               w_wino=ops.wino_weight(weight, src.shape, c0, c0 + c1, dgrad=True) if wino else None)
+                dx2_resid = None
+    if dx_resid is not None:          # a handed-off gradient that no conv epilogue took (transpose conv, or no input gradient wanted)
+        dx = dx_resid if dx is None else ops.add(dx, dx_resid)
+    if dx2_resid is not None:
+        dx2 = dx2_resid if dx2 is None else ops.add(dx2, dx2_resid)
     return dx, dx2, gw, gb
 
 
@@ -81,7 +118,8 @@ class ConvFn(torch.autograd.Function):
     """conv family on NHWC x (optionally channel-concatenated with x2), canonical (OIHW / (I,O,4,4)) weight."""
 
     @staticmethod
-    def forward(ctx, kind, x, x2, weight, bias, resid):
+    def forward(ctx, kind, x, x2, weight, bias, resid, handoff=None):
+        ctx.handoff = handoff
         if kind == ops.CONVT4X4_S2:
             wp = ops.cached_pack("fwdT", weight, ops.pack_convT_weight)
             n = weight.shape[1]
@@ -102,11 +140,13 @@ class ConvFn(torch.autograd.Function):
         x, x2, weight, bias = ctx.saved_tensors
         dy = _c(dy)
         dx, dx2, gw, gb = _conv_backward(ctx.kind, x, x2, weight, bias, dy, ctx.needs_input_grad[1:5])
-        return None, dx, dx2, gw, gb, (dy if ctx.has_resid else None)
+        if ctx.handoff is not None and ctx.handoff.give(dx, dx2):       # the skip conv of a ResnetBlock: Block1's dgrad conv adds these
+            dx = dx2 = None
+        return None, dx, dx2, gw, gb, (dy if ctx.has_resid else None), None
 
 
-def conv(kind, x, weight, bias=None, x2=None, resid=None):
-    return ConvFn.apply(kind, x, x2, weight, bias, resid)
+def conv(kind, x, weight, bias=None, x2=None, resid=None, handoff=None):
+    return ConvFn.apply(kind, x, x2, weight, bias, resid, handoff)
 
 
 class PreActConvFn(torch.autograd.Function):
@@ -116,7 +156,8 @@ class PreActConvFn(torch.autograd.Function):
     input-gradient conv multiplies by Mish'(h) in its epilogue (ddk_conv_args.dmish_src): no Mish forward / backward launches."""
 
     @staticmethod
-    def forward(ctx, kind, h, a, weight, bias, resid, want_act):
+    def forward(ctx, kind, h, a, weight, bias, resid, want_act, handoff=None):
+        ctx.handoff = handoff                       # with resid: gives dy away; without: takes it into the dgrad epilogue
         wp = ops.cached_pack("fwd", weight, ops.pack_conv_weight)
         n = weight.shape[0]
         a_out = torch.empty((a.shape[0], a.shape[1], a.shape[2], n), device=a.device, dtype=torch.float32) if want_act else None
@@ -136,16 +177,22 @@ class PreActConvFn(torch.autograd.Function):
     def backward(ctx, dy, _unused):
         h, a, weight, bias = ctx.saved_tensors
         if dy is None:
-            return None, None, None, None, None, None, None
+            return None, None, None, None, None, None, None, None
         dy = _c(dy)
         need = ctx.needs_input_grad
-        dh, _, gw, gb = _conv_backward(ctx.kind, a, None, weight, bias, dy, (need[1], False, need[3], need[4]), dmish_src=h)
-        return None, dh, None, gw, gb, (dy if ctx.has_resid else None), None
+        skip = None
+        if ctx.handoff is not None and not ctx.has_resid:
+            skip, _ = ctx.handoff.take()
+        dh, _, gw, gb = _conv_backward(ctx.kind, a, None, weight, bias, dy, (need[1], False, need[3], need[4]), dmish_src=h, dx_resid=skip)
+        dres = dy if ctx.has_resid else None
+        if dres is not None and ctx.handoff is not None and ctx.handoff.give(dres):
+            dres = None
+        return None, dh, None, gw, gb, dres, None, None
 
 
-def preact_conv(kind, h, a, weight, bias=None, resid=None, want_act=True):
+def preact_conv(kind, h, a, weight, bias=None, resid=None, want_act=True, handoff=None):
     """-> (out, Mish(out) or None); see PreActConvFn"""
-    out, a_out = PreActConvFn.apply(kind, h, a, weight, bias, resid, want_act)
+    out, a_out = PreActConvFn.apply(kind, h, a, weight, bias, resid, want_act, handoff)
     return out, (a_out if want_act else None)
 
 
@@ -175,7 +222,8 @@ class ConvGNMishFn(torch.autograd.Function):
     has in registers) -- no column-sum pass over dY."""
 
     @staticmethod
-    def forward(ctx, x, x2, weight, bias, gamma, beta, temb, addend, drop_p, seed, layer, groups, eps):
+    def forward(ctx, x, x2, weight, bias, gamma, beta, temb, addend, drop_p, seed, layer, groups, eps, give=None, take=None):
+        ctx.give, ctx.take = give, take           # GradHandoff: `give` the addend's gradient away / `take` one into the dgrad epilogue
         wu = ops.wino_weight(weight, (x.shape[0], x.shape[1], x.shape[2], x.shape[3] + (0 if x2 is None else x2.shape[3])))
         raw = ops.conv(ops.CONV3X3_S1, x, ops.cached_pack("fwd", weight, ops.pack_conv_weight), bias.detach(),
                        n_out=weight.shape[0], x2=x2, w_wino=wu)
@@ -192,14 +240,20 @@ class ConvGNMishFn(torch.autograd.Function):
         need = ctx.needs_input_grad
         acc = (_grad_slot(gamma), _grad_slot(beta), _grad_slot(bias) if need[3] else None)
         draw, dtemb, sums = ops.groupnorm_mish_bwd(raw, gamma.detach(), beta.detach(), dy, drop_p, seed, layer, groups, eps, acc=acc)
-        dx, dx2, gw, _ = _conv_backward(ops.CONV3X3_S1, x, x2, weight, bias, draw, need[0:4], gb_ready=True)
+        r1 = r2 = None
+        if ctx.take is not None:
+            r1, r2 = ctx.take.take()
+        dx, dx2, gw, _ = _conv_backward(ops.CONV3X3_S1, x, x2, weight, bias, draw, need[0:4], gb_ready=True, dx_resid=r1, dx2_resid=r2)
         gb = sums[2] if need[3] else None
-        return (dx, dx2, gw, gb, sums[0], sums[1], (dtemb if has_temb else None), (dy if has_add else None),
-                None, None, None, None, None)
+        dadd = dy if has_add else None
+        if dadd is not None and ctx.give is not None and ctx.give.give(dadd):
+            dadd = None
+        return (dx, dx2, gw, gb, sums[0], sums[1], (dtemb if has_temb else None), dadd, None, None, None, None, None, None, None)
 
 
-def conv_groupnorm_mish(x, weight, bias, gamma, beta, x2=None, temb=None, addend=None, drop_p=0.0, seed=0, layer=0, groups=8, eps=1e-5):
-    return ConvGNMishFn.apply(x, x2, weight, bias, gamma, beta, temb, addend, float(drop_p), int(seed), int(layer), groups, eps)
+def conv_groupnorm_mish(x, weight, bias, gamma, beta, x2=None, temb=None, addend=None, drop_p=0.0, seed=0, layer=0, groups=8, eps=1e-5,
+                        give=None, take=None):
+    return ConvGNMishFn.apply(x, x2, weight, bias, gamma, beta, temb, addend, float(drop_p), int(seed), int(layer), groups, eps, give, take)
 
 
 def groupnorm_mish(x, gamma, beta, temb=None, addend=None, drop_p=0.0, seed=0, layer=0, groups=8, eps=1e-5):

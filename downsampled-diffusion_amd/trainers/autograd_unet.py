@@ -28,21 +28,23 @@ class _Seeds:
         return self.seed, self.layer
 
 
-def _block(blk, x, x2=None, temb=None, addend=None, drop_p=0.0, seeds=None):
+def _block(blk, x, x2=None, temb=None, addend=None, drop_p=0.0, seeds=None, give=None, take=None):
     conv, norm = blk.block[0], blk.block[1]
     seed, layer = seeds.next() if (seeds is not None and drop_p > 0) else (0, 0)
     return AG.conv_groupnorm_mish(x, conv.weight, conv.bias, norm.weight, norm.bias, x2=x2, temb=temb, addend=addend, drop_p=drop_p,
-                                  seed=seed, layer=layer, groups=blk.groups, eps=norm.eps)
+                                  seed=seed, layer=layer, groups=blk.groups, eps=norm.eps, give=give, take=take)
 
 
 def _resnet(rb, x, temb_slice, x2=None, seeds=None):
     """blocks.py:105-115: h = drop(Block1(x) + shift); out = Block2(h) + res(x)"""
     p = rb.dropout.p if rb.training else 0.0
-    h = _block(rb.block1, x, x2=x2, temb=temb_slice, drop_p=p, seeds=seeds)
+    # the gradient of the skip path reaches x (and x2) through Block1's input-gradient conv epilogue, not through an autograd add:
+    # identity skip -> Block2 hands its addend gradient over; 1x1 skip -> the skip conv hands its input gradients over
+    hand = AG.GradHandoff()
+    h = _block(rb.block1, x, x2=x2, temb=temb_slice, drop_p=p, seeds=seeds, take=hand)
     if isinstance(rb.res_conv, nn.Identity):
-        res = x
-    else:
-        res = AG.conv(ops.CONV1X1, x, rb.res_conv.weight, rb.res_conv.bias, x2=x2)
+        return _block(rb.block2, h, addend=x, give=hand)
+    res = AG.conv(ops.CONV1X1, x, rb.res_conv.weight, rb.res_conv.bias, x2=x2, handoff=hand)
     return _block(rb.block2, h, addend=res)
 
 
@@ -125,10 +127,11 @@ def _conv_res_block(blk, x):
     (the next conv's input), every input-gradient conv multiplies by Mish' of the pre-activation -- one Mish launch per block (on the
     block input) instead of four forward and four backward ones."""
     a = ops.mish(x.detach())
-    h, a = AG.preact_conv(ops.CONV1X1, x, a, blk.c1.weight, blk.c1.bias)
+    hand = AG.GradHandoff() if blk.residual else None      # the skip's gradient rides on c1's input-gradient conv (no 17-67 MB add launch)
+    h, a = AG.preact_conv(ops.CONV1X1, x, a, blk.c1.weight, blk.c1.bias, handoff=hand)
     h, a = AG.preact_conv(ops.CONV3X3_S1, h, a, blk.c2.weight, blk.c2.bias)
     h, a = AG.preact_conv(ops.CONV3X3_S1, h, a, blk.c3.weight, blk.c3.bias)
-    out, _ = AG.preact_conv(ops.CONV1X1, h, a, blk.c4.weight, blk.c4.bias, resid=x if blk.residual else None, want_act=False)
+    out, _ = AG.preact_conv(ops.CONV1X1, h, a, blk.c4.weight, blk.c4.bias, resid=x if blk.residual else None, want_act=False, handoff=hand)
     if blk.upsample:
         out = AG.UpNearest2Fn.apply(out)
     elif blk.downsample:
