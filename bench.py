@@ -29,6 +29,7 @@ import torch  # noqa: E402
 FP32_PEAK_TFLOPS = 157.3      # MI355X fp32 matrix = vector peak (MI355X_MICROARCH.md, chip-level parameters)
 T_STEPS = 1000
 WINO_PMC = "r04_wino_pmc.json"      # committed counter summary of the timed Winograd kernel (tools/pmc_summary.py)
+WINO_SRC = "downsampled-diffusion_amd/csrc/conv_wino.hip+downsampled-diffusion_amd/csrc/conv_wino2_kernel.inc"   # what its hash covers
 HBM_PMC = "r03_gn_pmc.json"         # ... of the GroupNorm-apply kernel (FETCH_SIZE / WRITE_SIZE passes)
 LOCAL_PMC = "r04_wlocal8_pmc.json"  # ... of the image-local conv + GroupNorm kernel (8x8 maps)
 
@@ -71,12 +72,16 @@ def graph_kernel_seconds(device, fn, n=50, reps=4):
 
 
 def _sha16(rel):
+    """sha256 (first 16 hex digits) of one source file, or of several '+'-separated ones in the order given"""
     import hashlib
+    h = hashlib.sha256()
     try:
-        with open(os.path.join(ROOT, rel), "rb") as f:
-            return hashlib.sha256(f.read()).hexdigest()[:16]
+        for part in rel.split("+"):
+            with open(os.path.join(ROOT, part), "rb") as f:
+                h.update(f.read())
     except OSError:
         return None
+    return h.hexdigest()[:16]
 
 
 def _profile_json(name, kernel_source=None):
@@ -117,9 +122,10 @@ def time_conv_roofline(device):
     flops = 2.0 * B * H * W * 9 * C * N
     executed = 2.0 * (B * H * W / 4) * 16 * C * N
     bytes_alg = 4.0 * (B * H * W * C + B * H * W * N + N * 9 * C)
-    pm = _profile_json(WINO_PMC, "downsampled-diffusion_amd/csrc/conv_wino.hip")
+    pm = _profile_json(WINO_PMC, WINO_SRC)
     src = f"profiles/{WINO_PMC} (rocprofv3 --pmc, separate passes: SQ_* | FETCH_SIZE x2 | WRITE_SIZE)" if pm else None
-    return dict(kernel="conv3x3_wino_kernel<0> conv3x3 128->128 @32x32 B=32 (Winograd F(2x2,3x3), fp32 MFMA, 4 matrix + 4 loader waves)",
+    return dict(kernel="conv3x3_wino2_kernel<2> conv3x3 128->128 @32x32 B=32 (Winograd F(2x2,3x3), fp32 MFMA, 8 matrix + 4 loader waves, "
+                       "32 tiles x 128 channels per workgroup, one dispatch round)",
                 bound="mfma", achieved=executed / sec / 1e12, peak=FP32_PEAK_TFLOPS, unit="TFLOP/s", frac=executed / sec / 1e12 / FP32_PEAK_TFLOPS,
                 traffic=pm["traffic_bytes_per_launch"] if pm else None, traffic_source=src,
                 mfma_busy=pm["mfma_busy"] if pm else None, mfma_busy_source=src,

@@ -83,6 +83,10 @@ elif case == "wino16":          # conv3x3 256->256 @16x16 (the 64-channel tile o
     x, w = torch.randn(B, 16, 16, 256, device=dev), rw(256, 256)
     wp, wu, b = ops.pack_conv_weight(w), ops.pack_conv_weight_wino(w), torch.zeros(256, device=dev)
     fn = lambda: ops.conv(ops.CONV3X3_S1, x, wp, b, w_wino=wu)
+elif case == "convT":          # ConvTranspose2d 4x4 s2 128 ch 16x16 -> 32x32 (ups.2.3 at cfg4) as Winograd F(2x2,2x2) per phase
+    x, w = torch.randn(B, 16, 16, 128, device=dev), torch.randn(128, 128, 4, 4, device=dev) * (128 * 4) ** -0.5
+    wp, wu, b = ops.pack_convT_weight(w), ops.pack_convT_weight_wino(w), torch.zeros(128, device=dev)
+    fn = lambda: ops.conv(ops.CONVT4X4_S2, x, wp, b, w_wino=wu)
 elif case == "cluster16":
     x, w = torch.randn(B, 16, 16, 256, device=dev), rw(256, 256)
     wu, b = ops.pack_conv_weight_wino(w), torch.zeros(256, device=dev)

@@ -56,9 +56,13 @@ def main():
         res["l2_hit"] = vals["TCC_HIT_sum"] / (vals["TCC_HIT_sum"] + vals["TCC_MISS_sum"])
     if "TCP_TCC_READ_REQ_sum" in vals:
         res["l1_to_l2_read_requests_per_launch"] = vals["TCP_TCC_READ_REQ_sum"]
-    with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), src), "rb") as f:
-        res["kernel_source"] = src
-        res["kernel_source_sha16"] = hashlib.sha256(f.read()).hexdigest()[:16]
+    # a kernel that lives in included files names them all, '+'-separated: the hash covers every one (in the order given)
+    h = hashlib.sha256()
+    for part in src.split("+"):
+        with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), part), "rb") as f:
+            h.update(f.read())
+    res["kernel_source"] = src
+    res["kernel_source_sha16"] = h.hexdigest()[:16]
     res["note"] = ("per-launch averages over the kernel's dispatches of `python3 tools/pmc_one.py <case>` (first two dropped); SQ_BUSY_CYCLES is "
                    "summed over 32 shader engines, SQ_VALU_MFMA_BUSY_CYCLES over 1024 SIMDs; FETCH_SIZE doubled per MI355X_MICROARCH.md")
     with open(out, "w") as f:
