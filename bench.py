@@ -100,7 +100,7 @@ def _profile_json(name, kernel_source=None):
 
 
 def time_conv_roofline(device):
-    """Dominant kernel of the step: the 3x3 conv 128->128 @32x32, batch 32, which the sampler runs as conv3x3_wino_kernel
+    """Dominant kernel of the step: the 3x3 conv 128->128 @32x32, batch 32, which the sampler runs as conv3x3_wino2_kernel
     (Winograd F(2x2,3x3) on the fp32 matrix pipe).  Launch duration is measured live (HIP events on the launch stream, graph
     replay).  `achieved` / `frac` price the MFMA FLOPs the kernel ISSUES -- 16 multiplies per 2x2 output tile and input channel,
     2 * (B*H*W/4) * 16 * Cin * Cout = 16/36 of the direct algorithm's -- against the fp32 MFMA peak, so frac <= 1 by

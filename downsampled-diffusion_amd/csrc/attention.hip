@@ -538,7 +538,7 @@ size_t linattn_context_workspace_bytes(int B, int HW, int heads) {
 }
 
 int linattn_context(const float* qkv, float* ctx, int B, int HW, int heads, void* workspace, size_t workspace_bytes, hipStream_t st,
-                    bool kv_only, int* pending_splits) {
+                    bool kv_only) {
     DDK_REQUIRE(qkv && ctx && B > 0 && HW > 0 && heads > 0, "linattn_context: arguments");
     DDK_REQUIRE(aligned16(qkv) && aligned16(ctx) && aligned16(workspace), "linattn_context: alignment");
     int s, rows;
@@ -554,10 +554,6 @@ int linattn_context(const float* qkv, float* ctx, int B, int HW, int heads, void
     hipLaunchKernelGGL(linattn_context_kernel, dim3(B * heads * s), dim3(256), 0, st, qkv, ctx, static_cast<float*>(workspace), HW, heads, s, rows,
                        kv_only ? 1 : 0);
     DDK_TRY(check_launch("linattn_context_kernel"));
-    if (pending_splits) {            // the consumer (attn_fold) merges the split partials itself: no merge launch
-        *pending_splits = s;
-        return DDK_OK;
-    }
     if (s > 1) {
         hipLaunchKernelGGL(linattn_merge_kernel, dim3(B * heads), dim3(256), 0, st, static_cast<const float*>(workspace), ctx, s);
         DDK_TRY(check_launch("linattn_merge_kernel"));
@@ -590,55 +586,24 @@ bool linattn_small_qkv_ok(int HW, int C) { return HW > 0 && HW <= 64 && C % 32 =
 // to build A instead of (128 + 32) x 128 per PIXEL); conv1x1_ws_kernel<LN, RES> with per-image weights evaluates it.
 // grid (B, 4) x 4 waves: workgroup (b, quarter) builds T (redundantly) and rows [32 quarter, +32) of A, both on the matrix pipe.
 constexpr int FOLD_C = 128;
-constexpr int FOLD_LDS_FLOATS = FOLD_C * FOLD_C + 32 * (FOLD_C + 1) + 2 * FOLD_C + 4 * DH * DH;
+constexpr int FOLD_LDS_FLOATS = FOLD_C * FOLD_C + 32 * (FOLD_C + 1) + 2 * FOLD_C;
 typedef float f32x16_att __attribute__((ext_vector_type(16)));
 __global__ __launch_bounds__(256) void attn_fold_kernel(const float* __restrict__ ctx, const float* __restrict__ wqg,
                                                         const float* __restrict__ c1q, const float* __restrict__ c2q,
                                                         const float* __restrict__ wout, const float* __restrict__ bout,
-                                                        float* __restrict__ A, float* __restrict__ a1, float* __restrict__ a2,
-                                                        const float* __restrict__ part, int splits) {
+                                                        float* __restrict__ A, float* __restrict__ a1, float* __restrict__ a2) {
     extern __shared__ __align__(16) float sm[];
     float* T = sm;                              // [128 (h, e)][128 c]
     float* Wq = T + FOLD_C * FOLD_C;            // W_out rows of this quarter, [32 n][128 he + 1]: the A-phase row operand
     float* t1 = Wq + 32 * (FOLD_C + 1);         // ctx^T c1q, ctx^T c2q
     float* t2 = t1 + FOLD_C;
-    float* cx = t2 + FOLD_C;                    // this image's context [4 heads][32 d][32 e]
     const int b = blockIdx.x, nq = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, kh = lane >> 5;
-    // The context of the image into LDS.  splits > 1: the pixel-split partials of linattn_context_kernel are merged here, in split
-    // order with the arithmetic of linattn_merge_kernel (round 3 spent a 5.5 us launch on that) -- four workgroups per image redo
-    // the same 4 x 8 partial reads from L2, which is cheaper than a kernel boundary.
-    {
-        const int d = tid >> 3, e0 = (tid & 7) * 4;
-#pragma unroll
-        for (int h = 0; h < 4; ++h) {
-            float4 acc;
-            if (splits > 1) {
-                const float* pp = part + ((long long)b * 4 + h) * splits * PART;
-                float M = -INFINITY;
-                for (int sp = 0; sp < splits; ++sp) M = fmaxf(M, pp[sp * PART + d]);
-                acc = make_float4(0.f, 0.f, 0.f, 0.f);
-                float den = 0.f;
-                for (int sp = 0; sp < splits; ++sp) {
-                    const float w = expf(pp[sp * PART + d] - M);
-                    const float4 a = *reinterpret_cast<const float4*>(pp + sp * PART + 2 * DH + d * DH + e0);
-                    den += pp[sp * PART + DH + d] * w;
-                    acc.x += a.x * w; acc.y += a.y * w; acc.z += a.z * w; acc.w += a.w * w;
-                }
-                const float inv = 1.0f / den;
-                acc.x *= inv; acc.y *= inv; acc.z *= inv; acc.w *= inv;
-            } else {
-                acc = *reinterpret_cast<const float4*>(ctx + (((long long)b * 4 + h) * DH + d) * DH + e0);
-            }
-            *reinterpret_cast<float4*>(cx + (h * DH + d) * DH + e0) = acc;
-        }
-    }
-    __syncthreads();
     // Both products on the matrix pipe (v_mfma_f32_32x32x2_f32; VALU forms of this kernel took 19-34 us: one shared-operand read
     // per FMA).  T phase: wave = head h, T_h [32 e][128 c] = ctx_h^T [32 e][32 d] . Wqg_h [32 d][128 c]: 4 column blocks x 16 k-pairs.
     {
-        const float* cp = cx + wave * DH * DH;                                // [d][e]: row operand (e = lane & 31, d = 2 s + kh)
+        const float* cp = ctx + ((long long)b * 4 + wave) * DH * DH;          // [d][e]: row operand (e = lane & 31, d = 2 s + kh)
         const float* wp = wqg + (long long)wave * DH * FOLD_C;                // [d][c]: column operand
         f32x16_att acc[4];
 #pragma unroll
@@ -667,7 +632,7 @@ __global__ __launch_bounds__(256) void attn_fold_kernel(const float* __restrict_
     for (int i = tid; i < 32 * FOLD_C; i += 256) Wq[(i >> 7) * (FOLD_C + 1) + (i & 127)] = wout[(long long)nq * 32 * FOLD_C + i];
     if (tid < FOLD_C) {
         const int h = tid >> 5, e = tid & 31;
-        const float* ch = cx + h * DH * DH;
+        const float* ch = ctx + ((long long)b * 4 + h) * DH * DH;
         float u1 = 0.f, u2 = 0.f;
 #pragma unroll
         for (int d = 0; d < DH; ++d) {
@@ -744,14 +709,12 @@ size_t attn_fold_out_floats(int B) { return (size_t)B * (FOLD_C * FOLD_C + 2 * F
 // ctx [B][4][32][32]; wqg [128][128] = rows 0..127 of the LayerNorm-folded to_qkv weight, c1q / c2q its fold vectors; wout [128][128]
 // the packed to_out weight, bout its bias -> A [B][128][128], a1, a2 [B][128]
 int attn_fold(const float* ctx, const float* wqg, const float* c1q, const float* c2q, const float* wout, const float* bout, float* A,
-              float* a1, float* a2, int B, int C, int heads, hipStream_t st, const float* partials, int splits) {
-    DDK_REQUIRE((ctx || (partials && splits > 1)) && wqg && c1q && c2q && wout && A && a1 && a2 && B > 0, "attn_fold: arguments");
-    DDK_REQUIRE(splits <= 1 || (partials && aligned16(partials)), "attn_fold: split partials");
+              float* a1, float* a2, int B, int C, int heads, hipStream_t st) {
+    DDK_REQUIRE(ctx && wqg && c1q && c2q && wout && A && a1 && a2 && B > 0, "attn_fold: arguments");
     DDK_REQUIRE(attn_fold_ok(C, heads), "attn_fold: C == 128 and heads * 32 == 128 only");
     DDK_REQUIRE(aligned16(ctx) && aligned16(wout) && aligned16(A), "attn_fold: alignment");
     DDK_TRY(ensure_device_init());
-    hipLaunchKernelGGL(attn_fold_kernel, dim3(B, 4), dim3(256), FOLD_LDS_FLOATS * sizeof(float), st, ctx, wqg, c1q, c2q, wout, bout, A, a1, a2,
-                       partials, splits);
+    hipLaunchKernelGGL(attn_fold_kernel, dim3(B, 4), dim3(256), FOLD_LDS_FLOATS * sizeof(float), st, ctx, wqg, c1q, c2q, wout, bout, A, a1, a2);
     return check_launch("attn_fold_kernel");
 }
 

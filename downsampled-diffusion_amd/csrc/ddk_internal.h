@@ -229,15 +229,13 @@ int avgpool2(const float* x, float* out, int B, int H, int W, int C, hipStream_t
 int upsample_nearest2(const float* x, float* out, int B, int H, int W, int C, hipStream_t st);
 // attention.hip
 size_t linattn_context_workspace_bytes(int B, int HW, int heads);
-// pending_splits != nullptr: leave the split partials in `workspace` unmerged and report how many (1 = ctx is final); the consumer
-// (attn_fold with partials) merges them
 int linattn_context(const float* qkv, float* ctx, int B, int HW, int heads, void* workspace, size_t workspace_bytes, hipStream_t st,
-                    bool kv_only = false, int* pending_splits = nullptr);
+                    bool kv_only = false);
 // folded attention output (attention.hip): per-image C x C matrix A and fold vectors from the context
 bool attn_fold_ok(int C, int heads);
 size_t attn_fold_out_floats(int B);
 int attn_fold(const float* ctx, const float* wqg, const float* c1q, const float* c2q, const float* wout, const float* bout, float* A,
-              float* a1, float* a2, int B, int C, int heads, hipStream_t st, const float* partials = nullptr, int splits = 1);
+              float* a1, float* a2, int B, int C, int heads, hipStream_t st);
 int linattn_apply(const float* qkv, const float* ctx, float* out, int B, int HW, int heads, hipStream_t st);
 int linattn_fused_small(const float* qkv, float* ctx, float* out, int B, int HW, int heads, hipStream_t st);
 bool linattn_small_qkv_ok(int HW, int C);

@@ -830,13 +830,14 @@ static int run_attn(Ctx& c, const AttnW& a, const float* x, float* out, int H, i
         const ConvLnFold lnkv{c.P + a.ln_c1 + HIDDEN, c.P + a.ln_c2 + HIDDEN, LN_EPS};
         DDK_TRY(run_conv(c, DDK_CONV1X1, a.qkv, x, a.c, nullptr, 0, nullptr, qkv, H, W, 2 * HIDDEN, c.P + a.qkv_lnw + (size_t)HIDDEN * a.c,
                          &lnkv));
-        int pend = 1;      // the context's pixel-split partials stay in the split-K workspace: attn_fold merges them (no merge launch)
-        DDK_TRY(linattn_context(qkv, ctx, c.B, H * W, HEADS, c.W + c.ly.off_splitk, c.ly.splitk * sizeof(float), c.st, true, &pend));
+        // (round 4: merging the split context partials inside attn_fold_kernel instead of the 5.5 us merge launch made that kernel 13.0 ->
+        //  25.6 us -- each of an image's four workgroups redoes the 4 x 8 partial reads -- so the merge launch stays)
+        DDK_TRY(linattn_context(qkv, ctx, c.B, H * W, HEADS, c.W + c.ly.off_splitk, c.ly.splitk * sizeof(float), c.st, true));
         float* A = o;                                   // [B][C][C], then a1, a2 [B][C] (the apply output buffer is free on this path)
         float* a1 = A + (size_t)c.B * a.c * a.c;
         float* a2 = a1 + (size_t)c.B * a.c;
         DDK_TRY(attn_fold(ctx, c.P + a.qkv_lnw, c.P + a.ln_c1, c.P + a.ln_c2, c.P + a.out.w, a.out.has_bias ? c.P + a.out.b : nullptr, A, a1,
-                          a2, c.B, a.c, HEADS, c.st, c.W + c.ly.off_splitk, pend));
+                          a2, c.B, a.c, HEADS, c.st));
         const ConvLnFold lnA{a1, a2, LN_EPS};
         return conv1x1_ws(x, A, nullptr, x, out, M, a.c, &lnA, c.st, c.B);
     }
