@@ -970,6 +970,8 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const IgemmParams p) 
     }
 }
 
+#include "conv_c32_kernel.inc"
+
 // out[i] = sum_s slab[s][i] (fixed order) + bias[i % N] + resid[i]
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slabs, int splits,
                                                             long long slab_stride, const float* __restrict__ bias,
@@ -1163,6 +1165,37 @@ static bool choose_halo(int kind, int B, int H, int W, int cin, int N, Choice& c
 #define DDK_HALO_VARIANTS(X) X(0)
 #endif
 
+// ---- register-resident 32 -> 32 kernel (conv_c32_kernel.inc): the halo kernel's tile geometry, whole tiles only, and enough tiles
+// to fill the chip (below 256 tiles its once-per-workgroup filter load is not repaid: the im2col tile kernel stays)
+static bool choose_c32(int kind, int B, int H, int W, int cin, int N, int c1, bool pre_mish) {
+    if (tuning_flag("DDK_NO_C32") || kind != DDK_CONV3X3_S1 || cin != 32 || N != 32 || c1 != 0 || pre_mish) return false;
+    if (W != 8 && W != 16 && W != 32 && W != 64) return false;
+    const int TR = 128 / W;
+    if (TR <= H ? (H % TR != 0) : (TR % H != 0)) return false;
+    if (c32_halo_px(W, H) > C32_MAX_PX) return false;
+    const long long M = (long long)B * H * W;
+    if (M % 128 || M * 32 * 4 >= (1LL << 31)) return false;
+    return M / 128 >= tuning_int("DDK_C32_MIN_TILES", 256);
+}
+#define DDK_C32_WIDTHS(X) X(8) X(16) X(32) X(64)
+static int launch_c32(const IgemmParams& p, hipStream_t st) {
+    const int tiles = p.M / 128;
+    const int cap = tuning_int("DDK_C32_GRID", 512);
+    const dim3 grid((unsigned)(tiles < cap ? tiles : cap));
+    const size_t lds = c32_lds_bytes(p.W, p.H);
+    switch (p.W) {
+#define C32_CASE(WW)                                                                                         \
+    case WW:                                                                                                 \
+        if (p.dmish_src) hipLaunchKernelGGL((conv3x3_c32_kernel<WW, true>), grid, dim3(256), lds, st, p);    \
+        else hipLaunchKernelGGL((conv3x3_c32_kernel<WW, false>), grid, dim3(256), lds, st, p);               \
+        break;
+        DDK_C32_WIDTHS(C32_CASE)
+#undef C32_CASE
+        default: DDK_REQUIRE(false, "conv(c32): width");
+    }
+    return check_launch("conv3x3_c32_kernel");
+}
+
 static int launch_halo(const IgemmParams& p, hipStream_t st) {
     constexpr size_t lds = (size_t)HALO_LDS_FLOATS * sizeof(float);
     dim3 grid((unsigned)ceil_div(p.M, 128), (unsigned)ceil_div(p.N, HALO_BN), (unsigned)p.splits);
@@ -1242,6 +1275,11 @@ int conv_init_device() {
 #define HALO_ATTR(V) DDK_TRY(allow_lds(&conv3x3_halo_kernel<V>, (size_t)HALO_LDS_FLOATS * sizeof(float)));
     DDK_HALO_VARIANTS(HALO_ATTR)
 #undef HALO_ATTR
+#define C32_ATTR(WW)                                                                                      \
+    DDK_TRY(allow_lds(&conv3x3_c32_kernel<WW, false>, (size_t)2 * C32_MAX_PX * C32_PITCH4 * 16));          \
+    DDK_TRY(allow_lds(&conv3x3_c32_kernel<WW, true>, (size_t)2 * C32_MAX_PX * C32_PITCH4 * 16));
+    DDK_C32_WIDTHS(C32_ATTR)
+#undef C32_ATTR
 #define DMA_ATTR(BM, BN, WM, WN, NS) DDK_TRY(allow_lds(&igemm_dma_kernel<BM, BN, WM, WN, NS>, dma_lds_bytes<BM, BN, WM, WN, NS>()));
     DMA_ATTR(128, 128, 2, 2, 2)
     DMA_ATTR(128, 64, 2, 2, 2) DMA_ATTR(128, 64, 2, 2, 4)
@@ -1397,6 +1435,16 @@ int conv_forward(const ddk_conv_args& a, hipStream_t st, const ConvLnFold* ln, c
     p.dWm = make_fastdiv_u((unsigned)g.Wm);
     p.dHm = make_fastdiv_u((unsigned)g.Hm);
     p.tapmode = (a.kind == DDK_CONV1X1) ? 0 : (a.kind == DDK_CONVT4X4_S2 ? 2 : (a.kind == DDK_CONV4X4_S2 ? 3 : 1));
+    if (!ln && !a.defer_reduce && choose_c32(a.kind, a.B, a.H, a.W, p.cin, p.N, a.c1, a.pre_mish != 0)) {
+        const int TR = 128 / a.W, TB = TR > a.H ? TR / a.H : 1, rows_img = TB > 1 ? a.H : TR;
+        p.dImg = make_fastdiv_u((unsigned)((rows_img + 2) * (a.W + 2)));
+        p.dWp = make_fastdiv_u((unsigned)(a.W + 2));
+        p.dRows = make_fastdiv_u((unsigned)rows_img);
+        p.splits = 1;
+        p.kiters_per_split = p.kiters;
+        DDK_TRY(ensure_device_init());
+        return launch_c32(p, st);
+    }
     const ConvPlan plan = plan_conv(a.kind, a.B, a.H, a.W, p.cin, p.N, g, a.pre_mish != 0);
     const Choice c = plan.c;
     if (tuning_flag("DDK_TRACE")) {   // tuning aid: one line per conv launch

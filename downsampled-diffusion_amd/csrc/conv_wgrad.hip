@@ -17,6 +17,7 @@
 // order and ACCUMULATES into the canonical (OIHW) gradient tensor -- deterministic, and gradient accumulation over
 // micro-batches (trainer_ddpm.py:118-131) comes for free.
 #include "ddk_internal.h"
+#include "pack_elems.h"
 
 namespace ddk {
 
@@ -447,16 +448,11 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restri
     }
 }
 
-// dst[i][t][o] = w[o][i][T-1-t] (i < I), zero rows up to i_pad; o padded to o_pad with zeros
+// dst[i][t][o] = w[o][i][T-1-t] (i < I), zero rows up to i_pad; o padded to o_pad with zeros: pack_elems.h
 __global__ __launch_bounds__(256) void pack_dgrad_kernel(const float* __restrict__ w, float* __restrict__ dst, int O, int I, int taps,
                                                          int i_pad, int o_pad, long long total) {
-    for (long long idx = blockIdx.x * 256LL + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
-        const int o = (int)(idx % o_pad);
-        long long r = idx / o_pad;
-        const int t = (int)(r % taps);
-        const int i = (int)(r / taps);
-        dst[idx] = (i < I && o < O) ? w[((long long)o * I + i) * taps + (taps - 1 - t)] : 0.f;
-    }
+    for (long long idx = blockIdx.x * 256LL + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256)
+        pack_dgrad_elem(w, dst, idx, O, I, taps, o_pad);
 }
 
 // out[b][2y][2x][c] = in[b][y][x][c], zeros elsewhere; out is [B][Ho][Wo][C] (Ho in {2H-1, 2H})

@@ -32,6 +32,7 @@
 #include <utility>
 
 #include "conv_common.h"
+#include "pack_elems.h"
 
 namespace ddk {
 
@@ -78,41 +79,12 @@ constexpr int W_TP = WBN + 4;                            // epilogue staging pit
 constexpr int W_LP = DDK_WINO_LP;                        // of a U image's 8 DMA pieces per stage, the loader wave issues W_LP, the matrix wave the rest
 static_assert(4 * 2 * WBT * W_TP <= W_LDS_FLOATS, "epilogue staging fits");
 
-// G g G^T for one (n, c): G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
-// DGRAD: the filter of the INPUT-gradient conv for the forward conv's input channels [lo, lo + O): again a 3x3 stride-1 conv, of
-// dY, with g'[n][c][a][b] = w[c][lo + n][2-a][2-b] (taps flipped, channel roles swapped); w is the forward OIHW tensor with
-// `wi` input channels, I = its output channels.  One kernel instead of flip + transpose + contiguous + pack.
+// G g G^T for one (n, c), forward or input-gradient (DGRAD) filter: pack_elems.h
 template <bool DGRAD>
 __global__ __launch_bounds__(256) void pack_conv_weight_wino_kernel(const float* __restrict__ w, float* __restrict__ dst, int O, int I,
                                                                      int i_pad, long long total, int lo, int wi) {
-    for (long long idx = blockIdx.x * 256LL + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
-        const int c = (int)(idx % i_pad);
-        const int n = (int)(idx / i_pad);
-        float g[3][3];
-#pragma unroll
-        for (int a = 0; a < 3; ++a)
-#pragma unroll
-            for (int b = 0; b < 3; ++b) {
-                if (DGRAD) g[a][b] = c < I ? w[(((long long)c * wi + lo + n) * 3 + (2 - a)) * 3 + (2 - b)] : 0.f;
-                else g[a][b] = c < I ? w[(((long long)n * I + c) * 3 + a) * 3 + b] : 0.f;
-            }
-        float t[4][3];
-#pragma unroll
-        for (int b = 0; b < 3; ++b) {
-            t[0][b] = g[0][b];
-            t[1][b] = 0.5f * ((g[0][b] + g[1][b]) + g[2][b]);
-            t[2][b] = 0.5f * ((g[0][b] - g[1][b]) + g[2][b]);
-            t[3][b] = g[2][b];
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float u0 = t[i][0], u1 = 0.5f * ((t[i][0] + t[i][1]) + t[i][2]), u2 = 0.5f * ((t[i][0] - t[i][1]) + t[i][2]), u3 = t[i][2];
-            const float u[4] = {u0, u1, u2, u3};
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                dst[((((long long)(c >> 5)) * 16 + (4 * i + j)) * O + n) * 32 + (c & 31)] = u[j];
-        }
-    }
+    for (long long idx = blockIdx.x * 256LL + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256)
+        pack_wino_elem<DGRAD>(w, dst, idx, O, I, i_pad, lo, wi);
 }
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));

@@ -4,6 +4,7 @@
 // path computes in NHWC with [out][tap][in] weights; the canonical tensors stay what state_dict() holds
 // and these kernels derive the packed copies.
 #include "ddk_internal.h"
+#include "pack_elems.h"
 
 namespace ddk {
 
@@ -44,35 +45,18 @@ __global__ __launch_bounds__(256) void pad_channels_kernel(const float* __restri
     }
 }
 
-// dst[o][tap][i_pad] <- w[o][i][ky][kx].  The input channels may come from TWO sources that are each padded on their own (the concat
-// of unet.py:97 at widths that are not multiples of 32): channels [0, split) sit at [0, split), channels [split, I) at
-// [split_pad, split_pad + I - split); split == I, split_pad == i_pad is the plain single-source layout.
+// dst[o][tap][i_pad] <- w[o][i][ky][kx] (two separately padded sources at generic widths): pack_elems.h
 __global__ __launch_bounds__(256) void pack_conv_weight_kernel(const float* __restrict__ w, float* __restrict__ dst, int O, int I,
                                                                int taps, int i_pad, long long total, int split, int split_pad) {
-    for (long long idx = blockIdx.x * 256LL + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
-        const int ip = (int)(idx % i_pad);
-        const long long r = idx / i_pad;
-        const int tap = (int)(r % taps);
-        const long long o = r / taps;
-        const int i = ip < split_pad ? (ip < split ? ip : -1) : (ip - split_pad < I - split ? split + ip - split_pad : -1);
-        dst[idx] = i >= 0 ? w[(o * I + i) * taps + tap] : 0.f;
-    }
+    for (long long idx = blockIdx.x * 256LL + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256)
+        pack_conv_weight_elem(w, dst, idx, I, taps, i_pad, split, split_pad);
 }
 
-// dst[phase][o][tap][i] <- w[i][o][ky][kx], ky = 1 - py + 2a, kx = 1 - px + 2b (phase = py*2+px, tap = a*2+b)
-// (Ip, Op: channel counts padded to 32 at widths that are not multiples of 32 -- the padding rows / columns are zero)
+// dst[phase][o][tap][i] <- w[i][o][ky][kx]: pack_elems.h
 __global__ __launch_bounds__(256) void pack_convT_weight_kernel(const float* __restrict__ w, float* __restrict__ dst, int I, int O,
                                                                 long long total, int Ip, int Op) {
-    for (long long idx = blockIdx.x * 256LL + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
-        const int i = (int)(idx % Ip);
-        long long r = idx / Ip;
-        const int tap = (int)(r % 4); r /= 4;
-        const int o = (int)(r % Op);
-        const int phase = (int)(r / Op);
-        const int py = phase >> 1, px = phase & 1, a = tap >> 1, b = tap & 1;
-        const int ky = 1 - py + 2 * a, kx = 1 - px + 2 * b;
-        dst[idx] = (i < I && o < O) ? w[(((long long)i * O + o) * 4 + ky) * 4 + kx] : 0.f;
-    }
+    for (long long idx = blockIdx.x * 256LL + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256)
+        pack_convT_weight_elem(w, dst, idx, I, O, Ip, Op);
 }
 
 // dst[i][col0 + o] <- w[o][i]   (dst is [I][ld])

@@ -45,6 +45,12 @@ class SamplerArgs(C.Structure):
     ]
 
 
+class PackJob(C.Structure):
+    """ddk_pack_job (include/ddk.h)"""
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("total", C.c_longlong), ("block0", C.c_longlong), ("kind", C.c_int),
+                ("p", C.c_int * 7)]
+
+
 _P, _I, _LL, _F, _SZ = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_size_t
 
 # name -> (restype, argtypes); every symbol include/ddk.h declares
@@ -151,6 +157,8 @@ SIGNATURES = {
     "ddk_rows_sum_batched": (_I, [_P, _I, _LL, _I, _LL, _P, _I, _I, _P]),
     "ddk_rows_sum_targets": (_I, [_P, _I, _LL, _I, _LL, _P, _P, _P, _P, _I, _I, _P]),
     "ddk_multi_add": (_I, [_P, _P, _I, _LL, _P]),
+    "ddk_pack_jobs_layout": (_LL, [_P, _I]),
+    "ddk_pack_jobs": (_I, [_P, _I, _LL, _P]),
     "ddk_chan_layernorm_bwd": (_I, [_P, _P, _P, _P, _P, _I, C.POINTER(C.c_int), _LL, _I, _F, _P]),
     "ddk_linattn_train_workspace_bytes": (_SZ, [_I, _I, _I]),
     "ddk_linattn_stats": (_I, [_P, _P, _I, _I, _I, _P, _SZ, _P]),

@@ -18,29 +18,115 @@ def pad32(c):
 
 
 # ---------------------------------------------------------------- kernel-layout copies of weights (training path)
-# The autograd Functions repack a canonical weight for every conv forward / input-gradient.  Within one optimiser step the
-# weights do not change between the accumulation micro-batches, so the packed copies are cached, keyed by the parameter's
-# storage + torch version counter + an epoch that every in-place weight update done by OUR kernels bumps
-# (FusedAdam.step, EMA, load_state_dict paths call weights_changed(); torch ops bump the version counter themselves).
-_pack_cache = {}
+# The autograd Functions need a canonical weight in kernel layout for every conv forward / input-gradient.  Within one optimiser
+# step the weights do not change between the accumulation micro-batches, so the copies are cached per live parameter and marked
+# with the state they are current for: the parameter's torch version counter + an epoch that every in-place weight update done by
+# OUR kernels bumps (FusedAdam.step, EMA, load_state_dict paths call weights_changed(); torch ops bump the version counter).
+# A stale copy is not thrown away: its buffer is refreshed in place, and the first stale hit after a weight update refreshes EVERY
+# registered copy with one launch (ddk_pack_jobs: 285 single-tensor pack launches per cfg3 optimiser step before).
+class _PackEntry:
+    __slots__ = ("wref", "out", "job", "fresh", "pooled")
+
+
+_pack_cache = {}              # (tag, data_ptr, shape) -> _PackEntry
 _weights_epoch = [0]
+_pack_table = {}              # "keys": tuple of cache keys in table order, "dev": device table (uint8), "n", "blocks"
+pack_stats = {"single": 0, "batched_launches": 0, "batched_jobs": 0}
+_graph_tables = []            # device tables that a captured graph reads (job tables, multi_add tables): never freed
 
 
 def weights_changed():
+    """Every cached kernel-layout copy is stale from here on.  Copies that were allocated while a graph was being captured live in
+    that graph's private pool (each replay rewrites them): they are dropped, so no eager call is ever served one."""
     _weights_epoch[0] += 1
-    _pack_cache.clear()
+    dead = [k for k, e in _pack_cache.items() if e.pooled or e.wref() is None]
+    for k in dead:
+        del _pack_cache[k]
+    if dead:
+        _pack_table.clear()
+
+
+def _pack_job(tag, w):
+    """(kind, parameters) of ddk_pack_job for the copy `tag` of weight w, or None when the copy has no batched form"""
+    name = tag if isinstance(tag, str) else tag[0]
+    if w.dim() != 4:
+        return None
+    o, i, kh, kw = w.shape
+    if name == "fwd":
+        return (0, [o, i, kh * kw, pad32(i), i, pad32(i)])
+    if name == "fwdT" and (kh, kw) == (4, 4):                 # (I, O, 4, 4)
+        return (1, [o, i, o, i])
+    if name == "dgrad":
+        return (2, [o, i, kh * kw, tag[1], o])
+    if name == "wino" and (kh, kw) == (3, 3):
+        return (3, [o, i, pad32(i)])
+    if name == "wino_dgrad" and (kh, kw) == (3, 3):
+        return (4, [o, i, tag[1], tag[2], pad32(o)])
+    return None
+
+
+def _state(w):
+    return (w._version, _weights_epoch[0])
+
+
+def _repack_stale():
+    """Refresh every stale registered copy in place with ONE launch.  Returns False when that is not possible right now (a new
+    job set while a graph is being captured: building its device table would be a host-to-device copy inside the capture)."""
+    keys, live = [], []
+    for k, e in _pack_cache.items():
+        w = e.wref()
+        if w is None or e.job is None or e.fresh == _state(w):
+            continue
+        keys.append(k)
+        live.append((e, w))
+    if not keys:
+        return True
+    keys = tuple(keys)
+    tab = _pack_table
+    if tab.get("keys") != keys:
+        if torch.cuda.is_current_stream_capturing():
+            return False
+        jobs = (L.PackJob * len(keys))()
+        for j, (e, w) in zip(jobs, live):
+            j.src, j.dst, j.kind = w.data_ptr(), e.out.data_ptr(), e.job[0]
+            for q, v in enumerate(e.job[1]):
+                j.p[q] = int(v)
+        blocks = L.load().ddk_pack_jobs_layout(jobs, len(keys))
+        if blocks < 0:
+            L.check(-1, "pack_jobs_layout")
+        host = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8)
+        tab.clear()
+        tab.update(keys=keys, dev=host.to(live[0][1].device), n=len(keys), blocks=int(blocks))
+    if torch.cuda.is_current_stream_capturing():
+        _graph_tables.append(tab["dev"])        # a captured launch reads this table at every replay: it must outlive the cache
+    L.check(L.load().ddk_pack_jobs(tab["dev"].data_ptr(), tab["n"], tab["blocks"], L.stream()), "pack_jobs")
+    pack_stats["batched_launches"] += 1
+    pack_stats["batched_jobs"] += len(keys)
+    for e, w in live:
+        e.fresh = _state(w)
+    return True
 
 
 def cached_pack(tag, w, fn):
-    """fn(w.detach()) cached per live tensor object `w` (a weakref guards against a new tensor re-using the address)."""
+    """The kernel-layout copy `tag` of the live parameter `w`, current for its present contents (a weakref guards against a new
+    tensor re-using the address).  fn(w.detach()) makes a copy the first time; later refreshes go through ddk_pack_jobs."""
     import weakref
-    key = (tag, w.data_ptr(), tuple(w.shape), w._version, _weights_epoch[0])
-    hit = _pack_cache.get(key)
-    if hit is not None and hit[0]() is w:
-        return hit[1]
-    out = fn(w.detach())
-    _pack_cache[key] = (weakref.ref(w), out)
-    return out
+    key = (tag, w.data_ptr(), tuple(w.shape))
+    e = _pack_cache.get(key)
+    if e is not None and e.wref() is w:
+        if e.fresh == _state(w):
+            return e.out
+        if e.job is not None and w.is_contiguous() and _repack_stale() and e.fresh == _state(w):
+            return e.out
+    e = _PackEntry()
+    e.wref, e.out, e.fresh = weakref.ref(w), fn(w.detach()), _state(w)
+    e.job = _pack_job(tag, w) if w.is_contiguous() and w.dtype == torch.float32 else None
+    e.pooled = bool(w.is_cuda and torch.cuda.is_current_stream_capturing())
+    pack_stats["single"] += 1
+    if key not in _pack_cache:
+        _pack_table.clear()
+    _pack_cache[key] = e
+    return e.out
 
 
 def _f32(t):
@@ -737,6 +823,8 @@ def multi_add_(src, segments):
             _multi_add_tables.clear()
         host = torch.tensor([[int(o), d.data_ptr(), d.numel()] for o, d in segments], dtype=torch.int64)
         tab = _multi_add_tables[key] = host.to(src.device)
+    if torch.cuda.is_current_stream_capturing():
+        _graph_tables.append(tab)
     L.check(L.load().ddk_multi_add(L.ptr(src), tab.data_ptr(), len(segments), max(d.numel() for _, d in segments), L.stream()), "multi_add")
 
 

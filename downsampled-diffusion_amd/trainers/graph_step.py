@@ -8,8 +8,10 @@ What makes the capture valid here:
   * inputs are copied into static buffers; gradients accumulate into the optimiser's flat gradient buffer (static);
   * t ~ randint and eps ~ randn come from torch's graph-safe CUDA generator;
   * dropout masks are keyed by (host seed baked at capture) + (device epoch bumped by a kernel inside the graph);
-  * packed-weight caches are cleared before capture so the repack kernels are part of the graph (weights change every step),
-    and again after it, so the copies that live in the graph's private pool are never handed to eager code;
+  * the kernel-layout weight copies are marked stale before capture, so their refresh is part of the graph (weights change every
+    step): ONE ddk_pack_jobs launch over the persistent buffers the warm-up passes registered (ddk/ops.py:cached_pack); a copy
+    first requested while capturing lives in the graph's private pool and is dropped from the cache afterwards, so no eager call is
+    ever handed a tensor whose contents only a replay keeps current;
   * scratch workspaces requested while capturing come from the graph's private pool (ddk/ops.py:_ws), not from the shared
     per-tag buffers, so a later larger eager request cannot free memory the graph replays into;
   * the optimiser (all-reduce, clip, Adam, EMA) stays outside: its scalars (bias corrections) change per step.
@@ -65,8 +67,7 @@ class GraphedAccumulation:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.outputs = self._run()
-        # packed-weight copies made while capturing live in the graph's private pool (each replay rewrites them); drop them
-        # from the shared cache so no eager call is ever served a tensor whose contents only a replay keeps current
+        # mark the copies stale again (eager code refreshes them before use) and drop those allocated in the graph's private pool
         _invalidate(self.model)
         return self
 

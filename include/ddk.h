@@ -442,6 +442,28 @@ int ddk_rows_sum_targets(const float* rows, int nbatch, long long batch_stride, 
 /* dst_k[i] += src[off_k + i], k < nseg; table [nseg][3] int64 on the device = {source offset (floats), destination address, count};
  * max_count = the largest count (sizes the grid).  One launch for the many parameter gradients of one backward. */
 int ddk_multi_add(const float* src, const long long* table, int nseg, long long max_count, ddk_stream_t s);
+/* round 4: EVERY kernel-layout copy of a model's conv weights refreshed by one launch -- what the optimiser step of
+ * trainers/trainer_ddpm.py:142-144 invalidates and the next forward / backward needs again (285 single-tensor pack launches per
+ * cfg3 step before).  A job = one copy; the element arithmetic is that of the single-tensor entry point of the same kind, so the
+ * bits are the same.  ddk_pack_jobs_layout (host) validates the jobs and fills `total` / `block0`, returning the block count of the
+ * launch; ddk_pack_jobs takes the SAME table in device memory. */
+enum {
+    DDK_PACK_CONV = 0,       /* ddk_pack_conv_weight(_split):   p = O, I, taps, i_pad, split, split_pad (plain: split = I, split_pad = i_pad) */
+    DDK_PACK_CONVT = 1,      /* ddk_pack_convT_weight(_padded): p = I, O, Ip, Op */
+    DDK_PACK_DGRAD = 2,      /* ddk_pack_conv_weight_dgrad:     p = O, I, taps, i_pad, o_pad */
+    DDK_PACK_WINO = 3,       /* ddk_pack_conv_weight_wino:      p = O, I, i_pad */
+    DDK_PACK_WINO_DGRAD = 4  /* ddk_pack_conv_weight_wino_dgrad: p = O, I, c_lo, c_hi, o_pad */
+};
+typedef struct ddk_pack_job {
+    const float* src;        /* canonical weight (device) */
+    float* dst;              /* its kernel-layout copy (device) */
+    long long total;         /* filled by ddk_pack_jobs_layout */
+    long long block0;        /* filled by ddk_pack_jobs_layout */
+    int kind;                /* DDK_PACK_* */
+    int p[7];
+} ddk_pack_job;              /* 64 bytes */
+long long ddk_pack_jobs_layout(ddk_pack_job* jobs_host, int n);
+int ddk_pack_jobs(const ddk_pack_job* jobs_dev, int n, long long blocks, ddk_stream_t s);
 int ddk_chan_layernorm_bwd(const float* x, const float* g, const float* dy, float* dx, float* part, int max_parts,
                            int* nparts_out, long long M, int C, float eps, ddk_stream_t s);
 /* training-path linear attention: softmax statistics of k (column max, sum of exp) and the backward.  Their reductions over the

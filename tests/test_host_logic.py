@@ -88,6 +88,21 @@ def test_c_abi_exports_every_declared_symbol():
     assert L.load().ddk_version() == L.ABI_VERSION == 400
 
 
+def test_pack_jobs_layout_prefix_sums():
+    """ddk_pack_jobs_layout is host arithmetic: totals and first-block prefix sums of the job table (1024 elements per block)"""
+    jobs = (L.PackJob * 3)()
+    for j, (kind, p) in zip(jobs, [(0, [128, 8, 9, 32, 8, 32]), (3, [256, 128, 128]), (2, [128, 256, 9, 256, 128])]):
+        j.src, j.dst, j.kind = 4096, 8192, kind
+        for q, v in enumerate(p):
+            j.p[q] = v
+    blocks = L.load().ddk_pack_jobs_layout(jobs, 3)
+    totals = [128 * 9 * 32, 256 * 128, 256 * 9 * 128]
+    assert [j.total for j in jobs] == totals
+    assert [j.block0 for j in jobs] == [0, 36, 36 + 32] and blocks == 36 + 32 + 288
+    jobs[1].p[2] = 100                                   # i_pad not a multiple of 32
+    assert L.load().ddk_pack_jobs_layout(jobs, 3) < 0
+
+
 def test_plan_slots_cover_state_dict():
     cfg = ddpm_cfg(128, 8, 32)
     u = Unet(cfg)

@@ -322,6 +322,42 @@ def test_conv_pre_post_mish(ops):
     assert rel_err(to_nchw(out3.cpu()), ref3) < 2e-5
 
 
+C32_CASES = [  # B, H, W: conv3x3 32 -> 32 on >= 256 whole 128-pixel tiles -> the register-resident kernel (conv_c32_kernel.inc)
+    (8, 64, 64),      # cfg3 encoder / decoder level 0: 2-row tiles, 4 tiles per workgroup
+    (33, 32, 32),     # 4-row tiles, a tile count (264) that is not a multiple of 8: plain tile order
+    (128, 16, 16),    # 8-row tiles, two per image
+    (512, 8, 8),      # two images per tile
+    (5, 64, 128),     # one row per tile, non-square
+]
+
+
+@pytest.mark.parametrize("B,H,W", C32_CASES)
+def test_conv3x3_32_to_32_register_resident(ops, B, H, W):
+    """the dDDPM encoder / decoder's 3x3 convs (convblocks.py:112-130, d_chans 64) with every epilogue the training path uses:
+    bias, second output Mish(out) (ddk_conv_args.mish_out), Mish' of the pre-activation (dmish_src), residual, Mish"""
+    x = rnd(B, 32, H, W, seed=31)
+    w = rnd(32, 32, 3, 3, seed=32, scale=(32 * 9) ** -0.5)
+    b = rnd(32, seed=33, scale=0.1)
+    ref = F.conv2d(x, w, b, padding=1)
+    xd, wp, bd = to_nhwc(x).to(DEV), ops.pack_conv_weight(w.to(DEV)), b.to(DEV)
+    out = ops.conv(ops.CONV3X3_S1, xd, wp, bd)
+    assert rel_err(to_nchw(out.cpu()), ref) < 2e-5
+    assert torch.equal(out, ops.conv(ops.CONV3X3_S1, xd, wp, bd))
+    a_out = torch.empty_like(out)
+    out2 = ops.conv(ops.CONV3X3_S1, xd, wp, bd, mish_out=a_out)
+    assert torch.equal(out2, out) and rel_err(to_nchw(a_out.cpu()), U.mish(ref)) < 2e-5
+    res = rnd(B, 32, H, W, seed=34)
+    out3 = ops.conv(ops.CONV3X3_S1, xd, wp, bd, resid=to_nhwc(res).to(DEV), post_mish=True)
+    assert rel_err(to_nchw(out3.cpu()), U.mish(ref + res)) < 2e-5
+    # the input-gradient form: dX = conv(dY, flipped / transposed filter) * Mish'(h), against autograd of conv(Mish(h))
+    h = rnd(B, 32, H, W, seed=35).requires_grad_(True)
+    dy = rnd(B, 32, H, W, seed=36)
+    F.conv2d(U.mish(h), w, None, padding=1).backward(dy)
+    wd = ops.pack_conv_weight_dgrad(w.to(DEV), i_pad=32)
+    dx = ops.conv(ops.CONV3X3_S1, to_nhwc(dy).to(DEV), wd, None, n_out=32, dmish_src=to_nhwc(h.detach()).to(DEV))
+    assert rel_err(to_nchw(dx.cpu()), h.grad) < 3e-5
+
+
 def test_conv_small_cin_padding(ops):
     """C_in in {1,3,8}: channels zero-padded to 32 on both operands (first UNet conv / res_conv)."""
     for cin in (1, 3, 8):

@@ -19,7 +19,8 @@ with profile(activities=[ProfilerActivity.CPU], with_stack=True, record_shapes=T
 torch.cuda.synchronize()
 cnt = collections.Counter()
 for ev in prof.events():
-    if ev.name in ("aten::copy_", "aten::contiguous", "aten::clone", "aten::cat", "aten::_to_copy", "aten::zeros", "aten::zeros_like"):
+    if ev.name in ("aten::copy_", "aten::contiguous", "aten::clone", "aten::cat", "aten::_to_copy", "aten::zeros", "aten::zeros_like",
+                   "aten::item", "aten::_local_scalar_dense", "aten::to", "aten::stack", "aten::select", "aten::index"):
         st = [f for f in (ev.stack or []) if "site-packages" not in f and "dist-packages" not in f][:4]
         cnt[(ev.name, str(ev.input_shapes)[:50], " <- ".join(s.split("/")[-1] for s in st))] += 1
 for k, v in cnt.most_common(40):
