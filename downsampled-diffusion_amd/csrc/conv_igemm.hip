@@ -1182,7 +1182,7 @@ static int launch_c32(const IgemmParams& p, hipStream_t st) {
     const int tiles = p.M / 128;
     const int cap = tuning_int("DDK_C32_GRID", 512);
     const dim3 grid((unsigned)(tiles < cap ? tiles : cap));
-    const size_t lds = c32_lds_bytes(p.W, p.H);
+    const size_t lds = C32_LDS_BYTES;
     switch (p.W) {
 #define C32_CASE(WW)                                                                                         \
     case WW:                                                                                                 \
@@ -1276,8 +1276,8 @@ int conv_init_device() {
     DDK_HALO_VARIANTS(HALO_ATTR)
 #undef HALO_ATTR
 #define C32_ATTR(WW)                                                                                      \
-    DDK_TRY(allow_lds(&conv3x3_c32_kernel<WW, false>, (size_t)2 * C32_MAX_PX * C32_PITCH4 * 16));          \
-    DDK_TRY(allow_lds(&conv3x3_c32_kernel<WW, true>, (size_t)2 * C32_MAX_PX * C32_PITCH4 * 16));
+    DDK_TRY(allow_lds(&conv3x3_c32_kernel<WW, false>, (size_t)C32_LDS_BYTES));          \
+    DDK_TRY(allow_lds(&conv3x3_c32_kernel<WW, true>, (size_t)C32_LDS_BYTES));
     DDK_C32_WIDTHS(C32_ATTR)
 #undef C32_ATTR
 #define DMA_ATTR(BM, BN, WM, WN, NS) DDK_TRY(allow_lds(&igemm_dma_kernel<BM, BN, WM, WN, NS>, dma_lds_bytes<BM, BN, WM, WN, NS>()));

@@ -66,6 +66,10 @@ struct WinoParams {
     unsigned* cl_cnt;              // [image][n tile][16]: [0] arrivals, [1] departures (self-resetting)
     unsigned* cl_fail;             // workgroups of launches on THIS workspace that gave up waiting (sticky; ddk_unet_cluster_check)
     int cl_np;                     // m tiles per image = workgroups per cluster
+    const float* r1_x;             // optional addend of the in-launch GroupNorm: a 1x1 conv of this narrow tensor [pixels][r1_cin] ...
+    const float* r1_w;             // ... with weight rows [N][r1_ld] and bias r1_b [N] (WinoGnFuse::res_*)
+    const float* r1_b;
+    int r1_cin, r1_ld;
 };
 
 constexpr int WBT = 32, WBN = 64;                        // tiles and output channels per workgroup
@@ -758,6 +762,8 @@ bool conv_wino_cluster_device_ok() {
 }
 
 // a: validated by conv_forward (shapes, alignment).  Writes the result (or, with splits > 1, the slabs in a.workspace).
+bool conv_wino_variant_new(int B, int H, int W, int N) { return wino_variant(B, H, W, N) != WINO_V_OLD; }
+
 int conv_wino_forward(const ddk_conv_args& a, int splits, hipStream_t st, const WinoGnFuse* fuse) {
     WinoParams p{};
     if (fuse) {
@@ -769,6 +775,12 @@ int conv_wino_forward(const ddk_conv_args& a, int splits, hipStream_t st, const 
         p.gn_gamma = fuse->gamma; p.gn_beta = fuse->beta; p.gn_temb = fuse->temb; p.gn_temb_rows = fuse->temb_rows;
         p.gn_temb_stride = fuse->temb_stride; p.gn_eps = fuse->eps;
         p.cl_rec = fuse->records; p.cl_cnt = fuse->counters; p.cl_fail = fuse->fail; p.cl_np = np;
+        if (fuse->res_x) {
+            DDK_REQUIRE(fuse->res_w && fuse->res_cin > 0 && fuse->res_cin <= 8 && fuse->res_ld >= fuse->res_cin && !a.resid,
+                        "conv(wino, cluster): the 1x1 addend takes <= 8 input channels and excludes a tensor addend");
+            DDK_REQUIRE(wino_variant(a.B, a.H, a.W, a.N) != WINO_V_OLD, "conv(wino, cluster): the 1x1 addend exists in the 8-matrix-wave kernels only");
+            p.r1_x = fuse->res_x; p.r1_w = fuse->res_w; p.r1_b = fuse->res_b; p.r1_cin = fuse->res_cin; p.r1_ld = fuse->res_ld;
+        }
         p.groups = fuse->groups;
         p.cpg = a.N / fuse->groups;
     }

@@ -961,14 +961,26 @@ static int forward_core(const ddk_unet& u, const float* P, const float* x, int64
             a.weight = P + r.c2.w;
             a.weight_wino = P + r.c2.wu;
             a.bias = r.c2.has_bias ? P + r.c2.b : nullptr;
-            a.out = raw;
             a.B = B; a.H = H; a.W = W; a.N = r.co;
-            a.gn_partials = gnp;
-            a.gn_groups = GROUPS;
-            DDK_TRY(conv_forward(a, st));
-            DDK_TRY(groupnorm_mish_parts(raw, gnp, conv_wino_stats_parts(B, H, W, r.co, r.co, GROUPS), P + r.n2.g, P + r.n2.b, nullptr,
-                                         u.temb_total, nullptr, bufB, B, H * W, r.co, GROUPS, GN_EPS, st, nullptr, x, P + r.res.w,
-                                         r.res.has_bias ? P + r.res.b : nullptr, r.ci, r.res.cin_pad));
+            const int cl_np = c.allow_cluster && conv_wino_cluster_device_ok() && r.ci <= 8 ? conv_wino_cluster_np(B, H, W, r.co, r.co, GROUPS) : 0;
+            if (cl_np > 0 && cl_np <= u.cluster_np_max && conv_wino_variant_new(B, H, W, r.co) && c.n_cluster++ < u.cluster_limit) {
+                // round 4: GroupNorm + Mish + the 1x1 res_conv of the input finished in the conv's own launch (in-launch exchange of the
+                // tile statistics; the epilogue evaluates the <= 8-channel 1x1 itself): no raw tensor, no GroupNorm-apply launch
+                a.out = bufB;
+                float* cl = ws + ly.off_cl;
+                WinoGnFuse f{P + r.n2.g, P + r.n2.b, nullptr, nullptr, u.temb_total, GN_EPS, GROUPS, cl + cl_counter_floats(B),
+                             reinterpret_cast<unsigned*>(cl), reinterpret_cast<unsigned*>(cl + cl_fail_offset(B))};
+                f.res_x = x; f.res_w = P + r.res.w; f.res_b = r.res.has_bias ? P + r.res.b : nullptr; f.res_cin = r.ci; f.res_ld = r.res.cin_pad;
+                DDK_TRY(conv_forward(a, st, nullptr, &f));
+            } else {
+                a.out = raw;
+                a.gn_partials = gnp;
+                a.gn_groups = GROUPS;
+                DDK_TRY(conv_forward(a, st));
+                DDK_TRY(groupnorm_mish_parts(raw, gnp, conv_wino_stats_parts(B, H, W, r.co, r.co, GROUPS), P + r.n2.g, P + r.n2.b, nullptr,
+                                             u.temb_total, nullptr, bufB, B, H * W, r.co, GROUPS, GN_EPS, st, nullptr, x, P + r.res.w,
+                                             r.res.has_bias ? P + r.res.b : nullptr, r.ci, r.res.cin_pad));
+            }
         } else {
             DDK_TRY(run_res(c, u.down_res[2 * l], cur, cur_c, nullptr, 0, bufB, H, W));
         }
