@@ -135,10 +135,26 @@ __device__ __forceinline__ void gn_mish_tail(const float (&v)[NV], const long lo
     }
 }
 
+#ifdef DDK_TUNING
+// Diagnostic stamps of conv3x3_gn_wlocal_kernel (tuning build only): per workgroup, in shader cycles (s_memtime) --
+// [0] entry, [1] image staged, [2] k loop done, [3] end of kernel, [4] cycles matrix wave 0 spent parked at the chunk barriers,
+// [5] cycles transform wave 8 spent transforming, [6] chunks, [7] valid.  Written to a buffer nothing else reads.
+__device__ unsigned long long g_wl_stamps[8 * 512];
+#define WL_STAMP(x) do { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(x) :: "memory"); } while (0)
+#else
+#define WL_STAMP(x) do { } while (0)
+#endif
+
 template <int MT, int IPB = 1>     // IPB images per block: 1, or 4 on 2x2 maps (MT == 16)
 __global__ __launch_bounds__(512) void conv3x3_gn_local_kernel(const LocalParams p) {
     extern __shared__ __align__(16) float lds[];
     constexpr int MB = MT / 16;
+    unsigned long long st_entry = 0, st_entry_r = 0, st_img = 0, st_loop = 0, st_red = 0;
+    (void)st_entry; (void)st_entry_r; (void)st_img; (void)st_loop; (void)st_red;
+    WL_STAMP(st_entry);
+#ifdef DDK_TUNING
+    st_entry_r = __builtin_amdgcn_s_memrealtime();
+#endif
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: unit indices and loop control stay scalar
     const int m = lane & 15, kq = lane >> 4;
@@ -195,6 +211,7 @@ __global__ __launch_bounds__(512) void conv3x3_gn_local_kernel(const LocalParams
         for (int i = tid; i < q4; i += 512) *reinterpret_cast<float4*>(lds + MT * pitch + (i << 2)) = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     __syncthreads();
+    WL_STAMP(st_img);
 
     // ---- k loop: this wave's units u = wave, wave + 8, ...
     f32x4 acc[MB][2];
@@ -248,6 +265,7 @@ __global__ __launch_bounds__(512) void conv3x3_gn_local_kernel(const LocalParams
     }
 
     // ---- the 8 waves' partial tiles meet in LDS (the image is no longer needed)
+    WL_STAMP(st_loop);
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < MB; ++i)
@@ -269,7 +287,17 @@ __global__ __launch_bounds__(512) void conv3x3_gn_local_kernel(const LocalParams
         v[i] = s + cb;
     }
 
+    WL_STAMP(st_red);
     gn_mish_tail<MB>(v, o_t, col, c, b, hwi, lane, wave, red, p, pre, IPB);
+#ifdef DDK_TUNING
+    if (tid == 0) {     // [0] entry, [1] image staged, [2] k loop done (wave 0), [3] end, [4] partials summed, [5] entry tick, [6] exit tick, [7] valid
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned long long st_end;
+        WL_STAMP(st_end);
+        unsigned long long* o = g_wl_stamps + (blockIdx.x & 511) * 8;
+        o[0] = st_entry; o[1] = st_img; o[2] = st_loop; o[3] = st_end; o[4] = st_red; o[5] = st_entry_r; o[6] = __builtin_amdgcn_s_memrealtime(); o[7] = 2;
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -300,15 +328,7 @@ struct WLocalParams {
     const float* addend_bias;
 };
 
-#ifdef DDK_TUNING
-// Diagnostic stamps of conv3x3_gn_wlocal_kernel (tuning build only): per workgroup, in shader cycles (s_memtime) --
-// [0] entry, [1] image staged, [2] k loop done, [3] end of kernel, [4] cycles matrix wave 0 spent parked at the chunk barriers,
-// [5] cycles transform wave 8 spent transforming, [6] chunks, [7] valid.  Written to a buffer nothing else reads.
-__device__ unsigned long long g_wl_stamps[8 * 512];
-#define WL_STAMP(x) do { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(x) :: "memory"); } while (0)
-#else
-#define WL_STAMP(x) do { } while (0)
-#endif
+
 
 constexpr int WL_VP = 36;                       // V / M row pitch (floats): 16 rows cover the 64 banks once
 constexpr int WL_VBUF = 16 * 16 * WL_VP;        // one V buffer: [position][tile][36]

@@ -4,7 +4,8 @@
 cases: wino (conv3x3 128->128 @32x32 B=32, Winograd), gn (GroupNorm-apply from partials, 32x32x32x128), local4 (conv+GroupNorm+Mish
 one launch, 256->256 @4x4), wlocal8 (the same @8x8, Winograd form), first (conv_first 8->128 @32x32), tail (final_tail_kernel),
 cluster16 (conv3x3 256->256 @16x16 with GroupNorm finished in the launch), ws (to_out 1x1 128->128 + bias + residual @32x32,
-weights-stationary kernel), fold (attn_fold_kernel), halo32 (wgrad3x3_halo32_kernel), gnbig (gn_apply_kernel on the 256x256 tensor)."""
+weights-stationary kernel), fold (attn_fold_kernel), halo32 (wgrad3x3_halo32_kernel), gnbig (gn_apply_kernel on the 256x256 tensor),
+c32 (conv3x3 32->32 @64x64 B=64 with the filter in registers)."""
 import os
 import sys
 
@@ -87,6 +88,10 @@ elif case == "convT":          # ConvTranspose2d 4x4 s2 128 ch 16x16 -> 32x32 (u
     x, w = torch.randn(B, 16, 16, 128, device=dev), torch.randn(128, 128, 4, 4, device=dev) * (128 * 4) ** -0.5
     wp, wu, b = ops.pack_convT_weight(w), ops.pack_convT_weight_wino(w), torch.zeros(128, device=dev)
     fn = lambda: ops.conv(ops.CONVT4X4_S2, x, wp, b, w_wino=wu)
+elif case == "c32":            # conv3x3 32->32 @64x64, 64 images + second output Mish(out): the dDDPM encoder / decoder conv of cfg3 training
+    x, w = torch.randn(64, 64, 64, 32, device=dev), rw(32, 32)
+    wp, b, ao = ops.pack_conv_weight(w), torch.zeros(32, device=dev), torch.empty(64, 64, 64, 32, device=dev)
+    fn = lambda: ops.conv(ops.CONV3X3_S1, x, wp, b, mish_out=ao)
 elif case == "cluster16":
     x, w = torch.randn(B, 16, 16, 256, device=dev), rw(256, 256)
     wu, b = ops.pack_conv_weight_wino(w), torch.zeros(256, device=dev)

@@ -13,10 +13,13 @@ bash tools/pmc_run.sh wino16 conv3x3_wino2_kernel downsampled-diffusion_amd/csrc
 bash tools/pmc_run.sh cluster32 conv3x3_wino2_kernel downsampled-diffusion_amd/csrc/conv_wino.hip+downsampled-diffusion_amd/csrc/conv_wino2_kernel.inc r04_wino_cluster32_pmc
 bash tools/pmc_run.sh convT convT_wino_kernel downsampled-diffusion_amd/csrc/conv_wino.hip+downsampled-diffusion_amd/csrc/conv_winoT_kernel.inc r04_convT_pmc
 bash tools/pmc_run.sh wlocal8 conv3x3_gn_wlocal_kernel downsampled-diffusion_amd/csrc/conv_local.hip r04_wlocal8_pmc
+bash tools/pmc_run.sh c32 conv3x3_c32_kernel downsampled-diffusion_amd/csrc/conv_igemm.hip+downsampled-diffusion_amd/csrc/conv_c32_kernel.inc r04_c32_pmc
 cp gpurun_out/pmc/r04_*_pmc.json profiles/            # the bench line below reads the counter summaries of THIS tree
 timeout -k 10 500 python bench.py > $o/bench_latest.json 2> $o/bench_latest.err
 timeout -k 10 300 python tools/sample_bench.py > $o/sample_bench.txt 2>&1
 timeout -k 10 400 python tools/train_bench.py > $o/train_bench.txt 2>&1
+timeout -k 10 200 python tools/encdec_bench.py > $o/encdec_bench.txt 2>&1
+(make -C downsampled-diffusion_amd/csrc -j8 tune > /dev/null 2>&1 && for v in plain mo dg; do timeout -k 10 60 python tools/c32_clock.py 64 64 $v; done; timeout -k 10 60 python tools/c32_clock.py 32 64 mo; timeout -k 10 60 python tools/local_clock.py 256; timeout -k 10 60 python tools/wl_clock.py 256) 2>&1 | grep -v amdgpu > $o/clock_stamps.txt
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $o/tprof -- python3 tools/train_profile.py cfg3 > $o/tprof.log 2>&1
 cp $(ls $o/tprof/*/*kernel_stats.csv | head -1) $o/train_cfg3_kernel_stats.csv; rm -rf $o/tprof
 grep "kernel time" $o/step_breakdown.txt; grep -v amdgpu $o/sample_bench.txt $o/train_bench.txt | cut -d: -f2-

@@ -15,7 +15,7 @@ if which == "cfg3":
 elif which == "cfg2":
     c = cfg(128, 3, 32); model = DDPM(c, Unet(c), DEV, 3); xshape = (64, 3, 32, 32)
 else:
-    c = cfg(128, 3, 256); model = DDPM(c, Unet(c), DEV, 3); xshape = (4, 3, 256, 256)
+    c = cfg(128, 3, 256); model = DDPM(c, Unet(c), DEV, 3); xshape = (8, 3, 256, 256)
 model = model.to(DEV).train()
 model.load_state_dict(syn.fill_state_dict(model.state_dict(), skip=syn.SCHEDULE_KEYS))
 opt = FusedAdam(model, lr=2e-4)
