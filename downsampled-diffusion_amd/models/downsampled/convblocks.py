@@ -40,11 +40,32 @@ class ConvResBlock(nn.Module):
         self._packed = _Packed()
 
     def forward_nhwc(self, x):
-        pk = lambda name, conv: self._packed.get(name, conv.weight, ops.pack_conv_weight)
-        h = ops.conv(ops.CONV1X1, x, pk("c1", self.c1), self.c1.bias.detach(), pre_mish=True, post_mish=True)
-        h = ops.conv(ops.CONV3X3_S1, h, pk("c2", self.c2), self.c2.bias.detach(), post_mish=True)
-        h = ops.conv(ops.CONV3X3_S1, h, pk("c3", self.c3), self.c3.bias.detach(), post_mish=True)
-        out = ops.conv(ops.CONV1X1, h, pk("c4", self.c4), self.c4.bias.detach(), resid=x if self.residual else None)
+        mid = self.c1.out_channels
+        mp = ops.pad32(mid)
+        if mp == mid:
+            pk = lambda name, conv: self._packed.get(name, conv.weight, ops.pack_conv_weight)
+            bs = lambda name, conv: conv.bias.detach()
+        else:
+            # d_chans / 2 is not a multiple of 32 (d_chans = 32, 96, ...): the block's inner tensors keep a pitch of pad32(mid) channels.
+            # Output rows and bias entries beyond `mid` are zero, Mish(0) = 0, and the next conv's weights are zero on the padded
+            # inputs (ddk_pack_conv_weight pads the input side itself): the padding stays exactly zero through the block.
+            def pad_o(w):
+                wp = ops.pack_conv_weight(w)
+                if w.shape[0] == mid:
+                    out = wp.new_zeros((mp,) + tuple(wp.shape[1:]))
+                    out[:mid] = wp
+                    return out
+                return wp
+            def pad_b(b):
+                out = b.new_zeros(mp)
+                out[:mid] = b
+                return out
+            pk = lambda name, conv: self._packed.get(name, conv.weight, pad_o)
+            bs = lambda name, conv: self._packed.get(name + ".b", conv.bias, pad_b) if conv.out_channels == mid else conv.bias.detach()
+        h = ops.conv(ops.CONV1X1, x, pk("c1", self.c1), bs("c1", self.c1), pre_mish=True, post_mish=True)
+        h = ops.conv(ops.CONV3X3_S1, h, pk("c2", self.c2), bs("c2", self.c2), post_mish=True)
+        h = ops.conv(ops.CONV3X3_S1, h, pk("c3", self.c3), bs("c3", self.c3), post_mish=True)
+        out = ops.conv(ops.CONV1X1, h, pk("c4", self.c4), bs("c4", self.c4), resid=x if self.residual else None)
         if self.upsample:
             out = ops.upsample_nearest2(out)
         elif self.downsample:
@@ -61,8 +82,9 @@ class ConvResNet(nn.Module):
 
     def __init__(self, dim, in_channels, out_channels, n_downsamples=1, upsample=False, dropout=0, n_blocks=1):
         super().__init__()
-        if dim % 64 != 0:
-            raise DDKError("ConvResNet: d_chans must be a multiple of 64 for the HIP conv kernels (train.py:37 uses 64)")
+        if dim % 32 != 0 or dim <= 0:
+            raise DDKError("ConvResNet: d_chans must be a multiple of 32 for the HIP conv kernels (train.py:37 uses 64); training "
+                           "additionally needs a multiple of 64")
         layers = [get_1x1(in_channels, dim)]
         for _ in range(n_downsamples):
             layers.append(ConvResBlock(int(dim / 2), dim, dim, upsample, not upsample, dropout, residual=True))

@@ -141,6 +141,10 @@ def _conv_res_block(blk, x):
 
 def resnet_forward_autograd(net, x_nchw, final_tanh):
     """ConvResNet (dDDPM encoder / decoder) on an NCHW tensor -> NCHW, differentiable."""
+    if net.dim % 64 != 0:
+        from ddk.lib import DDKError
+        raise DDKError(f"d_chans={net.dim}: the training path (HIP backward kernels) needs d_chans % 64 == 0; other multiples of 32 run "
+                       "inference only (sampling, evaluation under torch.no_grad())")
     h = AG.NchwToNhwcFn.apply(x_nchw.contiguous().float(), ops.pad32(x_nchw.shape[1]))
     first, last = net.conv[0], net.conv[-1]
     h = AG.conv(ops.CONV1X1, h, first.weight, first.bias)

@@ -97,6 +97,31 @@ def test_cfg3_celeba64_latents_and_decoder_vs_oracle():
     assert torch.isfinite(xs).all() and float(xs.abs().max()) <= 1.0
 
 
+@pytest.mark.parametrize("d_chans", [32, 96])
+def test_resamplers_with_d_chans_not_a_multiple_of_64(d_chans):
+    """`d_chans` is free in the reference (`ConvResNet(dim, ...)`, convblocks.py:133-159: the blocks' inner width is int(dim / 2)); the
+    HIP path takes every multiple of 32 for inference -- an inner width of 16 or 48 runs on a padded pitch of 32 / 64 channels whose
+    padding stays exactly zero (zero weight rows, zero bias, Mish(0) = 0).  Encoder and decoder of a tiny dDDPM against the oracle."""
+    from models import DownsampleDDPMAutoencoder, Unet
+    from oracle import resampler_ref as R
+    cfg = dddpm_cfg(32, 32, 2)
+    cfg["d_chans"] = d_chans
+    m = det_load(DownsampleDDPMAutoencoder(cfg, Unet(cfg), DEV, 3)).eval()
+    sd = _cpu_state(m)
+    m = m.to(DEV)
+    x = syn.synthetic_normal((3, 3, 32, 32), f"dch{d_chans}.x").clamp(-1, 1)
+    with torch.no_grad():
+        z = m.rescaled_downsample(x.to(DEV)).cpu()
+        xr = m.rescaled_upsample(z.to(DEV)).cpu()
+    zr = R.rescaled_downsample(sd, cfg, x)
+    assert z.shape == (3, 8, 8, 8) and rel_err(z, zr) < 2e-5
+    assert xr.shape == (3, 3, 32, 32) and rel_err(xr, R.rescaled_upsample(sd, cfg, z)) < 2e-5
+    if d_chans % 64:
+        from ddk.lib import DDKError
+        with pytest.raises(DDKError):        # the backward kernels need d_chans % 64 == 0: loud, not silent
+            m.train()(x.to(DEV))
+
+
 # ---------------------------------------------------------------------------------------------------- cfg5
 def test_cfg5_full_resolution_256_vs_oracle_and_batch8():
     """cfg5: CelebAMask-HQ 256x256 DDPM -downsample 0: the full-resolution UNet (C_in 3, 65536 pixels per sample in the
