@@ -366,38 +366,96 @@ __global__ __launch_bounds__(256) void wgrad3x3_halo_kernel(const WgHaloParams p
 }
 
 // grad[(n*cw + c_off + c)*ntaps + tap] += sum_s slab[s][n][tap][c]   (only the first c_real channels: the input may be padded)
-// One workgroup per (n, 32-channel block, tap): 8 row groups of 32 lanes read the [32 c] row of every 8th slab coalesced, four
-// loads in flight each, and the eight partial sums are added in a fixed order -- deterministic, and wide enough for the 256-split
-// slabs of the narrow convs (one workgroup per (n, block) summing 256 x 9 rows serially took 38 us; profiles/r03_train_wgrad.txt).
+// One workgroup per (n, channel block, tap): row groups of cxb lanes read the [cxb c] row of every G-th slab coalesced, four
+// loads in flight each, and the G partial sums are added in a fixed order -- deterministic.
 // Grid row y == ntaps (present when the launch carries a bias gradient) sums the [splits][N] column-sum slabs into grad_b.
+// Channels of one (n, tap) row a workgroup sums: the widest of 256 / 128 / 64 / 32 that divides cx -- the 256 threads are
+// 256 / cxb row groups x cxb channels.  (Round 4: with 32 channels per workgroup whatever cx, a 256 -> 256 3x3 weight was 18 432
+// workgroups of 32 outputs each and the launch was bound by workgroup dispatch, not by its few MB of slabs: 232 launches of 4-7 us
+// per cfg3 optimiser step, and batching them into one launch changed nothing.)
+// ... but a thread should not walk more than ~16 slabs on its own (4 iterations of 4 loads in flight: one workgroup per (n, block)
+// summing 256 x 9 rows serially took 38 us, profiles/r03_train_wgrad.txt): many splits -> more row groups, narrower blocks.
+__host__ __device__ static inline int wg_cxb(int cx, int splits) {
+    int cxb = splits <= 16 ? 256 : splits <= 32 ? 128 : splits <= 64 ? 64 : 32;
+    while (cx % cxb) cxb >>= 1;
+    return cxb;
+}
+
+__device__ __forceinline__ void wgrad_reduce_block(const float* __restrict__ slab, int splits, long long slab_stride, float* __restrict__ grad,
+                                                   int N, int ntaps, int cx, int c_real, int cw, int c_off,
+                                                   const float* __restrict__ bias_slab, float* __restrict__ grad_b, int bx, int by,
+                                                   float (&part)[256]) {
+    const bool bias_row = by == ntaps;                      // extra grid row: grad_b[n] += sum_s bias_slab[s][n], 32 n per workgroup
+    if (bias_row) {
+        if (bx * 32 >= N) return;
+        const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
+        const float* src = bias_slab + bx * 32 + c;
+        float s = 0.f;
+        for (int k = g; k < splits; k += 8) s += src[(long long)k * N];
+        part[g * 32 + c] = s;
+        __syncthreads();
+        if (threadIdx.x < 32) {
+            float t = part[c];
+#pragma unroll
+            for (int j = 1; j < 8; ++j) t += part[j * 32 + c];
+            grad_b[bx * 32 + c] += t;
+        }
+        return;
+    }
+    const int cxb = wg_cxb(cx, splits), G = 256 / cxb, cblocks = cx / cxb;
+    const int c = threadIdx.x % cxb, g = threadIdx.x / cxb;
+    const int n = bx / cblocks, cb = bx % cblocks, tap = by;
+    const float* src = slab + ((long long)n * ntaps + tap) * cx + cb * cxb + c;
+    float s = 0.f;
+    int k = g;
+    for (; k + 3 * G < splits; k += 4 * G) {                // four loads in flight per thread
+        const float a0 = src[k * slab_stride], a1 = src[(k + G) * slab_stride];
+        const float a2 = src[(k + 2 * G) * slab_stride], a3 = src[(k + 3 * G) * slab_stride];
+        s += (a0 + a1) + (a2 + a3);
+    }
+    for (; k < splits; k += G) s += src[k * slab_stride];
+    part[g * cxb + c] = s;
+    __syncthreads();
+    if (threadIdx.x < cxb) {
+        float t = part[c];
+        for (int j = 1; j < G; ++j) t += part[j * cxb + c];                      // fixed order: deterministic
+        if (cb * cxb + c < c_real) grad[((long long)n * cw + c_off + cb * cxb + c) * ntaps + tap] += t;
+    }
+}
+
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, int splits, long long slab_stride,
                                                            float* __restrict__ grad, int N, int ntaps, int cx, int c_real, int cw,
                                                            int c_off, long long total, const float* __restrict__ bias_slab,
                                                            float* __restrict__ grad_b) {
-    __shared__ float part[8][32];
-    const int cblocks = cx >> 5;
-    const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
+    __shared__ float part[256];
     (void)total;
-    const bool bias_row = (int)blockIdx.y == ntaps;         // extra grid row: grad_b[n] += sum_s bias_slab[s][n], 32 n per workgroup
-    if (bias_row && (int)blockIdx.x * 32 >= N) return;
-    const int n = blockIdx.x / cblocks, cb = blockIdx.x % cblocks, tap = blockIdx.y;
-    const float* src = bias_row ? bias_slab + blockIdx.x * 32 + c : slab + ((long long)n * ntaps + tap) * cx + cb * 32 + c;
-    const long long stride = bias_row ? N : slab_stride;
-    float s = 0.f;
-    int k = g;
-    for (; k + 24 < splits; k += 32) {
-        const float a0 = src[k * stride], a1 = src[(k + 8) * stride];
-        const float a2 = src[(k + 16) * stride], a3 = src[(k + 24) * stride];
-        s += (a0 + a1) + (a2 + a3);
+    wgrad_reduce_block(slab, splits, slab_stride, grad, N, ntaps, cx, c_real, cw, c_off, bias_slab, grad_b, (int)blockIdx.x, (int)blockIdx.y, part);
+}
+
+// The slab reduces of a whole backward pass in ONE launch (ddk_wgrad_reduce_jobs): every weight gradient of the pass left its slabs
+// in a buffer of its own (ddk_conv_wgrad_defer) and a job record; the records travel as KERNEL ARGUMENTS (48 per launch: no device
+// table, nothing to copy inside a graph capture), a block finds its job by binary search over the jobs' first-block prefix sums and
+// then is exactly one block of wgrad_reduce_kernel -- same summation order, same bits.  232 reduce launches of 4-7 us
+// per cfg3 optimiser step before (profiles/r04_train_cfg3_kernel_stats.csv), most of them launch-bound on a few MB of slabs.
+constexpr int WG_JOBS_PER_LAUNCH = 48;      // 48 x 80 B + 8 = 3848 B of kernel arguments (limit 4 KB)
+struct WgradJobPack {
+    int n, pad;
+    ddk_wgrad_reduce_job j[WG_JOBS_PER_LAUNCH];
+};
+__global__ __launch_bounds__(256) void wgrad_reduce_jobs_kernel(const WgradJobPack pk) {
+    __shared__ float part[256];
+    const long long blk = blockIdx.x;
+    int lo = 0, hi = pk.n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (pk.j[mid].block0 <= blk) lo = mid;
+        else hi = mid - 1;
     }
-    for (; k < splits; k += 8) s += src[k * stride];
-    part[g][c] = s;
-    __syncthreads();
-    if (threadIdx.x < 32) {
-        const float t = ((part[0][c] + part[1][c]) + (part[2][c] + part[3][c])) + ((part[4][c] + part[5][c]) + (part[6][c] + part[7][c]));
-        if (bias_row) grad_b[blockIdx.x * 32 + c] += t;
-        else if (cb * 32 + c < c_real) grad[((long long)n * cw + c_off + cb * 32 + c) * ntaps + tap] += t;
-    }
+    const ddk_wgrad_reduce_job& j = pk.j[lo];
+    const int local = (int)(blk - j.block0);
+    const int gx = j.N * (j.cx / wg_cxb(j.cx, j.splits));
+    wgrad_reduce_block(j.slab, j.splits, j.slab_stride, j.grad, j.N, j.ntaps, j.cx, j.c_real, j.cw, j.c_off, j.bias_slab, j.grad_b, local % gx,
+                       local / gx, part);
 }
 
 // bias gradient: partial[s][n] = sum over the s-th row range of dy[m][n]; then grad[n] += sum_s partial
@@ -768,8 +826,46 @@ int ddk_conv_wgrad(int kind, const float* x, const float* dy, float* grad_w, int
 
 /* ddk_conv_wgrad that also accumulates the bias gradient when grad_b != null: grad_b[n] += sum_m dy[m][n], computed by the same
  * launches (the column sums ride on the weight-gradient GEMM as dY^T 1; no separate pass over dy). */
+static int conv_wgrad_impl(int kind, const float* x, const float* dy, float* grad_w, float* grad_b, int B, int H, int W, int cx, int c_real,
+                           int cw, int c_off, int N, void* workspace, size_t workspace_bytes, ddk_stream_t s, ddk_wgrad_reduce_job* job_out);
+
 int ddk_conv_wgrad_bias(int kind, const float* x, const float* dy, float* grad_w, float* grad_b, int B, int H, int W, int cx, int c_real,
                         int cw, int c_off, int N, void* workspace, size_t workspace_bytes, ddk_stream_t s) {
+    return conv_wgrad_impl(kind, x, dy, grad_w, grad_b, B, H, W, cx, c_real, cw, c_off, N, workspace, workspace_bytes, s, nullptr);
+}
+
+/* The same without its reduce launch: the slabs stay in `workspace` (which must then be this call's own until the reduce has run) and
+ * *job_out describes the reduce; ddk_wgrad_reduce_jobs runs the reduces of many such calls in one launch. */
+int ddk_conv_wgrad_defer(int kind, const float* x, const float* dy, float* grad_w, float* grad_b, int B, int H, int W, int cx, int c_real,
+                         int cw, int c_off, int N, void* workspace, size_t workspace_bytes, ddk_wgrad_reduce_job* job_out, ddk_stream_t s) {
+    DDK_REQUIRE(job_out, "conv_wgrad_defer: job_out");
+    return conv_wgrad_impl(kind, x, dy, grad_w, grad_b, B, H, W, cx, c_real, cw, c_off, N, workspace, workspace_bytes, s, job_out);
+}
+
+int ddk_wgrad_reduce_jobs(const ddk_wgrad_reduce_job* jobs, int n, ddk_stream_t s) {
+    DDK_REQUIRE(jobs && n > 0, "wgrad_reduce_jobs: arguments");
+    for (int k0 = 0; k0 < n; k0 += WG_JOBS_PER_LAUNCH) {
+        WgradJobPack pk{};
+        pk.n = n - k0 < WG_JOBS_PER_LAUNCH ? n - k0 : WG_JOBS_PER_LAUNCH;
+        long long blocks = 0;
+        for (int k = 0; k < pk.n; ++k) {
+            ddk_wgrad_reduce_job j = jobs[k0 + k];
+            DDK_REQUIRE(j.slab && j.grad && j.splits > 0 && j.N > 0 && j.ntaps > 0 && j.cx > 0 && j.cx % 32 == 0 && j.c_real > 0 && j.c_real <= j.cx &&
+                            j.c_off >= 0 && j.c_off + j.c_real <= j.cw && (!j.grad_b || j.bias_slab),
+                        "wgrad_reduce_jobs: job");
+            j.block0 = blocks;
+            blocks += (long long)j.N * (j.cx / wg_cxb(j.cx, j.splits)) * (j.ntaps + (j.grad_b ? 1 : 0));
+            pk.j[k] = j;
+        }
+        DDK_REQUIRE(blocks < (1LL << 31), "wgrad_reduce_jobs: too many blocks");
+        hipLaunchKernelGGL(wgrad_reduce_jobs_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(s), pk);
+        DDK_TRY(check_launch("wgrad_reduce_jobs_kernel"));
+    }
+    return DDK_OK;
+}
+
+static int conv_wgrad_impl(int kind, const float* x, const float* dy, float* grad_w, float* grad_b, int B, int H, int W, int cx, int c_real,
+                           int cw, int c_off, int N, void* workspace, size_t workspace_bytes, ddk_stream_t s, ddk_wgrad_reduce_job* job_out) {
     int Hm, Wm, stride, tapmode, ntaps;
     DDK_REQUIRE(wgrad_geometry(kind, H, W, Hm, Wm, stride, tapmode, ntaps), "conv_wgrad: kind");
     DDK_REQUIRE(x && dy && grad_w && workspace, "conv_wgrad: null pointer");
@@ -803,7 +899,12 @@ int ddk_conv_wgrad_bias(int kind, const float* x, const float* dy, float* grad_w
             else rc = launch_wgrad_halo<4>(hp, st);
             DDK_TRY(rc);
             const long long total = (long long)N * 9 * cx;
-            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(N * (cx / 32)), grad_b ? 10 : 9), dim3(256), 0, st,
+            if (job_out) {
+                *job_out = ddk_wgrad_reduce_job{static_cast<const float*>(workspace), grad_w, static_cast<const float*>(hp.bias_slab), grad_b, total, 0,
+                                                hs, N, 9, cx, c_real, cw, c_off, 0};
+                return DDK_OK;
+            }
+            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(N * (cx / wg_cxb(cx, hs))), grad_b ? 10 : 9), dim3(256), 0, st,
                                static_cast<const float*>(workspace), hs, total, grad_w, N, 9, cx, c_real, cw, c_off, total,
                                static_cast<const float*>(hp.bias_slab), grad_b);
             return check_launch("wgrad_reduce_kernel");
@@ -837,7 +938,12 @@ int ddk_conv_wgrad_bias(int kind, const float* x, const float* dy, float* grad_w
 #undef WG
     DDK_TRY(rc);
     const long long total = (long long)N * ntaps * cx;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(N * (cx / 32)), (unsigned)(ntaps + (grad_b ? 1 : 0))), dim3(256), 0, st,
+    if (job_out) {
+        *job_out = ddk_wgrad_reduce_job{static_cast<const float*>(workspace), grad_w, static_cast<const float*>(p.bias_slab), grad_b, total, 0,
+                                        c.splits, N, ntaps, cx, c_real, cw, c_off, 0};
+        return DDK_OK;
+    }
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(N * (cx / wg_cxb(cx, c.splits))), (unsigned)(ntaps + (grad_b ? 1 : 0))), dim3(256), 0, st,
                        static_cast<const float*>(workspace), c.splits, total, grad_w, N, ntaps, cx, c_real, cw, c_off, total,
                        static_cast<const float*>(p.bias_slab), grad_b);
     return check_launch("wgrad_reduce_kernel");

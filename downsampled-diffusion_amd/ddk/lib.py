@@ -45,6 +45,13 @@ class SamplerArgs(C.Structure):
     ]
 
 
+class WgradReduceJob(C.Structure):
+    """ddk_wgrad_reduce_job (include/ddk.h)"""
+    _fields_ = [("slab", C.c_void_p), ("grad", C.c_void_p), ("bias_slab", C.c_void_p), ("grad_b", C.c_void_p), ("slab_stride", C.c_longlong),
+                ("block0", C.c_longlong), ("splits", C.c_int), ("N", C.c_int), ("ntaps", C.c_int), ("cx", C.c_int), ("c_real", C.c_int),
+                ("cw", C.c_int), ("c_off", C.c_int), ("reserved", C.c_int)]
+
+
 class PackJob(C.Structure):
     """ddk_pack_job (include/ddk.h)"""
     _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("total", C.c_longlong), ("block0", C.c_longlong), ("kind", C.c_int),
@@ -157,6 +164,8 @@ SIGNATURES = {
     "ddk_rows_sum_batched": (_I, [_P, _I, _LL, _I, _LL, _P, _I, _I, _P]),
     "ddk_rows_sum_targets": (_I, [_P, _I, _LL, _I, _LL, _P, _P, _P, _P, _I, _I, _P]),
     "ddk_multi_add": (_I, [_P, _P, _I, _LL, _P]),
+    "ddk_conv_wgrad_defer": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _SZ, _P, _P]),
+    "ddk_wgrad_reduce_jobs": (_I, [_P, _I, _P]),
     "ddk_pack_jobs_layout": (_LL, [_P, _I]),
     "ddk_pack_jobs": (_I, [_P, _I, _LL, _P]),
     "ddk_chan_layernorm_bwd": (_I, [_P, _P, _P, _P, _P, _I, C.POINTER(C.c_int), _LL, _I, _F, _P]),

@@ -77,7 +77,7 @@ def _repack_stale():
         w = e.wref()
         if w is None or e.job is None or e.fresh == _state(w):
             continue
-        keys.append(k)
+        keys.append((k, w.data_ptr(), e.out.data_ptr()))     # the cached device table is valid for exactly these buffers
         live.append((e, w))
     if not keys:
         return True
@@ -123,8 +123,7 @@ def cached_pack(tag, w, fn):
     e.job = _pack_job(tag, w) if w.is_contiguous() and w.dtype == torch.float32 else None
     e.pooled = bool(w.is_cuda and torch.cuda.is_current_stream_capturing())
     pack_stats["single"] += 1
-    if key not in _pack_cache:
-        _pack_table.clear()
+    _pack_table.clear()           # a new or replaced copy: the device job table (source / destination addresses) is out of date
     _pack_cache[key] = e
     return e.out
 
@@ -739,6 +738,56 @@ def zero_stuff2(dy, h_out, w_out):
     return out
 
 
+# The slab reduces of a backward pass in one launch.  Inside `with deferred_wgrad():` every conv_wgrad_ keeps its slabs in a buffer of
+# its own and only records the reduce; leaving the block (or flush_wgrad()) runs them all with ddk_wgrad_reduce_jobs -- 232 reduce
+# launches of 4-7 us per cfg3 optimiser step before.  Nothing may read the gradients in between (the trainers wrap exactly one
+# forward + backward); outside the block every call reduces at once, as before.
+_wgrad_pending = None         # None: immediate reduces; list of (job struct, slab tensor) while deferring
+
+
+class deferred_wgrad:
+    def __enter__(self):
+        global _wgrad_pending
+        self._outer = _wgrad_pending
+        if _wgrad_pending is None:
+            _wgrad_pending = []
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        global _wgrad_pending
+        if self._outer is None:
+            try:
+                if exc_type is None:
+                    flush_wgrad()
+            finally:
+                _wgrad_pending = None
+        return False
+
+
+def flush_wgrad():
+    """run the recorded reduces: one launch per set of jobs with pairwise distinct targets (normally one)"""
+    global _wgrad_pending
+    if not _wgrad_pending:
+        return 0
+    pending, _wgrad_pending = _wgrad_pending, []
+    lib = L.load()
+    launches = 0
+    while pending:
+        seen, batch, rest = set(), [], []
+        for job, slab in pending:        # two reduces into the same gradient elements must not share a launch (no such pair in this model)
+            keys = [(job.grad, job.c_off)] + ([("b", job.grad_b)] if job.grad_b else [])
+            if any(k in seen for k in keys):
+                rest.append((job, slab))
+            else:
+                batch.append((job, slab))
+                seen.update(keys)
+        jobs = (L.WgradReduceJob * len(batch))(*[j for j, _ in batch])
+        L.check(lib.ddk_wgrad_reduce_jobs(jobs, len(batch), L.stream()), "wgrad_reduce_jobs")     # records travel as kernel arguments
+        launches += 1
+        pending = rest
+    return launches
+
+
 def conv_wgrad_(kind, x, dy, grad_w, c_real, cw, c_off, grad_b=None):
     """grad_w (canonical layout, contiguous) += weight gradient of `kind` for the source x (see csrc/conv_wgrad.hip);
     grad_b [N] += column sums of dy when given (the bias gradient, produced by the same launches)."""
@@ -746,6 +795,13 @@ def conv_wgrad_(kind, x, dy, grad_w, c_real, cw, c_off, grad_b=None):
     n = dy.shape[-1]
     lib = L.load()
     nbytes = lib.ddk_conv_wgrad_workspace_bytes(kind, b, h, w, cx, n)
+    if _wgrad_pending is not None:
+        slab = torch.empty(max(nbytes, 16) // 4, device=x.device, dtype=torch.float32)
+        job = L.WgradReduceJob()
+        L.check(lib.ddk_conv_wgrad_defer(kind, L.ptr(_f32(x)), L.ptr(_f32(dy)), L.ptr(grad_w), L.ptr(grad_b), b, h, w, cx, c_real, cw, c_off, n,
+                                         L.ptr(slab), nbytes, C.byref(job), L.stream()), "conv_wgrad_defer")
+        _wgrad_pending.append((job, slab))
+        return grad_w
     ws = _ws(x.device, nbytes, "wgrad")
     L.check(lib.ddk_conv_wgrad_bias(kind, L.ptr(_f32(x)), L.ptr(_f32(dy)), L.ptr(grad_w), L.ptr(grad_b), b, h, w, cx, c_real, cw, c_off, n,
                                     L.ptr(ws), nbytes, L.stream()), "conv_wgrad")

@@ -37,13 +37,15 @@ class GraphedAccumulation:
         self.outputs = None
 
     def _run(self):
+        from ddk import ops
         lib = L.load()
         outs = []
         for x in self.static_x:
             L.check(lib.ddk_dropout_epoch(0, 1, L.stream()), "dropout_epoch")
-            out = self.model(x)
-            obj, extra = (out[0], out[1]) if isinstance(out, tuple) else (out, None)
-            (obj / self.accumulate).backward()
+            with ops.deferred_wgrad():             # the slab reduces of this backward pass: one launch when the block ends
+                out = self.model(x)
+                obj, extra = (out[0], out[1]) if isinstance(out, tuple) else (out, None)
+                (obj / self.accumulate).backward()
             rec = [obj.detach()]
             if extra is not None:
                 rec += [extra['latent'].detach(), extra['recon'].detach()]

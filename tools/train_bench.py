@@ -11,6 +11,10 @@ from trainers.optim import FusedAdam
 from utils import synthetic as syn
 
 DEV = "cuda"
+if os.environ.get("TRAIN_BENCH_NO_DEFER"):          # A/B: one reduce launch per weight gradient instead of the deferred few
+    import contextlib
+    from ddk import ops as _ops
+    _ops.deferred_wgrad = contextlib.nullcontext
 
 
 def cfg(chan, cin, size, down=0):
