@@ -8,6 +8,7 @@ from train_bench import cfg, DEV
 from models import DDPM, DownsampleDDPMAutoencoder, Unet
 from trainers.optim import FusedAdam
 from utils import synthetic as syn
+from ddk import ops
 
 which = sys.argv[1] if len(sys.argv) > 1 else "cfg3"
 if which == "cfg3":
@@ -22,9 +23,10 @@ opt = FusedAdam(model, lr=2e-4)
 x = torch.rand(xshape, device=DEV) * 2 - 1
 for step in range(4):
     for _ in range(2):
-        out = model(x)
-        obj = out[0] if isinstance(out, tuple) else out
-        (obj / 2).backward()
+        with ops.deferred_wgrad():          # as the trainers do: the slab reduces of a backward pass in a few launches
+            out = model(x)
+            obj = out[0] if isinstance(out, tuple) else out
+            (obj / 2).backward()
     opt.step(); opt.zero_grad()
     for m in model.modules():
         if hasattr(m, "invalidate_plan"):
