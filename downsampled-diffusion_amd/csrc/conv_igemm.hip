@@ -1416,6 +1416,12 @@ int conv_forward(const ddk_conv_args& a, hipStream_t st, const ConvLnFold* ln, c
         // ragged 512-tiles-over-85-workgroups split cost more than the tile kernel's weight re-reads (44.6 vs 42.2 us at 32x32).
         return conv1x1_ws(a.src0, a.weight, a.bias, a.resid, a.out, (long long)a.B * a.H * a.W, a.N, ln, st);
     }
+    if (a.kind == DDK_CONV1X1 && !a.pre_mish && !a.post_mish && !a.defer_reduce && !a.gn_partials && !fuse && !act_epilogue &&
+        !tuning_flag("DDK_NO_CONV1X1_SM") && conv1x1_sm_ok((long long)a.B * a.H * a.W, a.c0, a.c1, a.N) &&
+        (!ln || (a.c1 == 0 && ((long long)a.B * a.H * a.W / 32) * (a.N / 32) <= 512)))   // (LayerNorm-folded at 768 tiles: 11.9 vs 13.5 / 11.7 vs 11.5 us: a draw)
+        // 1x1 conv on a small map (to_out, res_conv, to_qkv with the LayerNorm folded, at 4x4 / 8x8): 32x32 tiles, the waves split K,
+        // one barrier (conv1x1_sm.hip)
+        return conv1x1_sm(a.src0, a.c0, a.src1, a.c1, a.weight, a.bias, a.resid, a.out, (long long)a.B * a.H * a.W, a.N, ln, st);
     DDK_REQUIRE(!a.gn_partials, "conv: gn_partials is only produced by the Winograd path (weight_wino given, ddk_conv_gn_partials() > 0)");
     DDK_REQUIRE(!fuse, "conv: the in-launch GroupNorm exists on the Winograd path only");
     IgemmParams p{};

@@ -33,6 +33,7 @@ int ensure_device_init() {
     DDK_TRY(conv_gn_local_init_device());
     DDK_TRY(conv_first_init_device());
     DDK_TRY(conv1x1_ws_init_device());
+    DDK_TRY(conv1x1_sm_init_device());
     DDK_TRY(linattn_small_qkv_init_device());
     DDK_TRY(wgrad_init_device());
     done.fetch_or(bit, std::memory_order_release);

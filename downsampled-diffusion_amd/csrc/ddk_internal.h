@@ -187,6 +187,11 @@ int conv_first(const float* x, const float* wp, const float* bias, float* out, f
 int conv_first_init_device();
 // conv1x1_ws.hip: 1x1 conv with 128 input channels on a large map as a weights-stationary, pixel-streaming GEMM
 // (w = the packed 1x1 weight [N][128]; ln as in conv_forward)
+// conv1x1_sm.hip: 1x1 conv + bias + residual on small maps (32x32 tiles, the four waves split K, no ring)
+bool conv1x1_sm_ok(long long M, int c0, int c1, int N);
+int conv1x1_sm(const float* src0, int c0, const float* src1, int c1, const float* w, const float* bias, const float* resid, float* out,
+               long long M, int N, const ConvLnFold* ln, hipStream_t st);
+int conv1x1_sm_init_device();
 bool conv1x1_ws_ok(long long M, int K, int N);
 // images > 0: PER-IMAGE weights -- w is [images][128][128], the LayerNorm vectors [images][128], N == 128, M / images pixels per image
 int conv1x1_ws(const float* x, const float* w, const float* bias, const float* resid, float* out, long long M, int N, const ConvLnFold* ln,

@@ -764,7 +764,8 @@ static int run_res(Ctx& c, const ResW& r, const float* src0, int c0, const float
     AddendSlabs as;
     if (r.has_res) {
         const int rs = conv_splits(DDK_CONV1X1, c.B, H, W, c0 + c1, r.co);
-        if (rs > 1 && conv_gn_is_local(r.c1, c.B, H, W, c0, c1, r.co) && conv_gn_is_local(r.c2, c.B, H, W, r.co, 0, r.co)) {
+        if (rs > 1 && !conv1x1_sm_ok((long long)c.B * H * W, c0, c1, r.co) && conv_gn_is_local(r.c1, c.B, H, W, c0, c1, r.co) &&
+            conv_gn_is_local(r.c2, c.B, H, W, r.co, 0, r.co)) {
             // neither Block conv touches the split-K workspace on these maps: the skip conv leaves its slabs there and the
             // second Block's epilogue sums them (+ bias) while it adds the residual -- no reduce launch
             ddk_conv_args a{};

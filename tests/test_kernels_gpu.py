@@ -358,6 +358,37 @@ def test_conv3x3_32_to_32_register_resident(ops, B, H, W):
     assert rel_err(to_nchw(dx.cpu()), h.grad) < 3e-5
 
 
+SM_CASES = [  # B, H, W, c0, c1, N: 1x1 convs on small maps -> conv1x1_sm_kernel (32x32 tiles, the four waves split K)
+    (32, 4, 4, 128, 0, 256),      # to_out at 4x4 (cfg4)
+    (32, 8, 8, 128, 0, 256),      # to_out at 8x8
+    (32, 4, 4, 256, 256, 256),    # res_conv over the concat at 4x4: K = 512 from two sources
+    (32, 8, 8, 256, 256, 256),    # ... at 8x8
+    (8, 8, 8, 256, 0, 128),       # K = 256, 64 tiles (the smallest grid the kernel takes)
+    (3, 16, 32, 128, 0, 96),      # ragged sizes that still tile by 32
+]
+
+
+@pytest.mark.parametrize("B,H,W,c0,c1,N", SM_CASES)
+def test_conv1x1_small_maps(ops, B, H, W, c0, c1, N):
+    cin = c0 + c1
+    x = rnd(B, cin, H, W, seed=41)
+    w = rnd(N, cin, 1, 1, seed=42, scale=cin ** -0.5)
+    b = rnd(N, seed=43, scale=0.1)
+    res = rnd(B, N, H, W, seed=44)
+    ref = F.conv2d(x, w, b)
+    xh = to_nhwc(x).to(DEV)
+    x0 = xh[..., :c0].contiguous()
+    x1 = xh[..., c0:].contiguous() if c1 else None
+    wp = ops.pack_conv_weight(w.to(DEV))
+    out = ops.conv(ops.CONV1X1, x0, wp, b.to(DEV), x2=x1)
+    assert rel_err(to_nchw(out.cpu()), ref) < 2e-5
+    out_r = ops.conv(ops.CONV1X1, x0, wp, b.to(DEV), x2=x1, resid=to_nhwc(res).to(DEV))
+    assert rel_err(to_nchw(out_r.cpu()), ref + res) < 2e-5
+    out_n = ops.conv(ops.CONV1X1, x0, wp, None, x2=x1)
+    assert rel_err(to_nchw(out_n.cpu()), F.conv2d(x, w)) < 2e-5
+    assert torch.equal(out, ops.conv(ops.CONV1X1, x0, wp, b.to(DEV), x2=x1))
+
+
 def test_conv_small_cin_padding(ops):
     """C_in in {1,3,8}: channels zero-padded to 32 on both operands (first UNet conv / res_conv)."""
     for cin in (1, 3, 8):
