@@ -104,7 +104,6 @@ def test_a_second_model_at_the_same_addresses_gets_its_own_table():
     Parameter objects over the SAME storage."""
     ops.weights_changed()
     store = [w.detach() for w in _weights()[:5]]
-    first_ptrs = None
     for round_ in range(3):
         ws = [torch.nn.Parameter(t) for t in store]              # new tensor objects, same addresses and shapes
         want = _all_copies(ws)
@@ -114,12 +113,8 @@ def test_a_second_model_at_the_same_addresses_gets_its_own_table():
                 w.mul_(1.0 + round_).add_(0.5)
         ops.weights_changed()
         outs = [ops.cached_pack(tag, w, fn) for tag, w, fn in want]              # one batched refresh, into THIS round's copies
-        ptrs = [o.data_ptr() for o in outs]
         for (tag, w, fn), got in zip(want, outs):
             assert torch.equal(got, fn(w.detach())), (round_, tag)
-        if first_ptrs is not None:
-            assert ptrs != first_ptrs or True
-        first_ptrs = ptrs
         del ws, want, outs
         ops.weights_changed()                                                    # prunes the dead entries
 
