@@ -145,7 +145,10 @@ __device__ unsigned long long g_wl_stamps[8 * 512];
 #define WL_STAMP(x) do { } while (0)
 #endif
 
-template <int MT, int IPB = 1>     // IPB images per block: 1, or 4 on 2x2 maps (MT == 16)
+// NU > 0: C_in = 256 NU, so that wave w's units are (tap k / NU, chunk w + 8 (k % NU)), k = 0 .. 9 NU - 1 -- the unit loop unrolls
+// with compile-time taps and the LDS row of a tap's source pixel is one of nine per-lane registers computed once (per unit those selects
+// were ~10 VALU instructions per 16 MFMAs, and VALU work between fp32 MFMAs is matrix time: tools/local_clock.py, k loop 78 % busy)
+template <int MT, int IPB = 1, int NU = 0>     // IPB images per block: 1, or 4 on 2x2 maps (MT == 16)
 __global__ __launch_bounds__(512) void conv3x3_gn_local_kernel(const LocalParams p) {
     extern __shared__ __align__(16) float lds[];
     constexpr int MB = MT / 16;
@@ -255,13 +258,54 @@ __global__ __launch_bounds__(512) void conv3x3_gn_local_kernel(const LocalParams
         cchunk += 8;
         norm(ctap, cchunk);
     };
-    while (ctap < 9) {                // scalar loop control; loads past the end re-read the last unit (no load under a condition)
-        compute(bA);
-        load_b(bA);
-        if (ctap < 9) compute(bB);
-        load_b(bB);
-        if (ctap < 9) compute(bC);
-        load_b(bC);
+    if constexpr (NU > 0) {
+        int a_tap[9][MB];             // float offset of (source pixel row of tap t, this lane's k quarter, this wave's first chunk)
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int i = 0; i < MB; ++i) {
+                const int yy = py[i] + t / 3 - 1, xx = px[i] + t % 3 - 1;
+                const bool ok = (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
+                a_tap[t][i] = (ok ? pbase[i] + yy * p.W + xx : MT) * pitch + kq * 8 + (wave << 5);
+            }
+        auto compute_at = [&](int t, int sub, const float4 (&bq)[2][2]) {      // t, sub: compile-time after unrolling
+            float4 a[MB][2];
+#pragma unroll
+            for (int i = 0; i < MB; ++i) {
+                const float* ap = lds + a_tap[t][i] + sub * 256;
+                a[i][0] = *reinterpret_cast<const float4*>(ap);
+                a[i][1] = *reinterpret_cast<const float4*>(ap + 4);
+            }
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+                const float b0 = reinterpret_cast<const float*>(&bq[0][0])[kk];
+                const float b1 = reinterpret_cast<const float*>(&bq[1][0])[kk];
+#pragma unroll
+                for (int i = 0; i < MB; ++i) {
+                    const float av = reinterpret_cast<const float*>(&a[i][0])[kk];
+                    acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b0, acc[i][0], 0, 0, 0);
+                    acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b1, acc[i][1], 0, 0, 0);
+                }
+            }
+        };
+#pragma unroll
+        for (int k = 0; k < 9 * NU; k += 3) {
+            compute_at(k / NU, k % NU, bA);
+            load_b(bA);
+            if (k + 1 < 9 * NU) compute_at((k + 1) / NU, (k + 1) % NU, bB);
+            load_b(bB);
+            if (k + 2 < 9 * NU) compute_at((k + 2) / NU, (k + 2) % NU, bC);
+            load_b(bC);
+        }
+    } else {
+        while (ctap < 9) {            // scalar loop control; loads past the end re-read the last unit (no load under a condition)
+            compute(bA);
+            load_b(bA);
+            if (ctap < 9) compute(bB);
+            load_b(bB);
+            if (ctap < 9) compute(bC);
+            load_b(bC);
+        }
     }
 
     // ---- the 8 waves' partial tiles meet in LDS (the image is no longer needed)
@@ -614,6 +658,10 @@ int conv_gn_local_init_device() {
                                 160 * 1024));
     DDK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_gn_local_kernel<16, 4>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 160 * 1024));
+    DDK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_gn_local_kernel<16, 1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024));
+    DDK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_gn_local_kernel<16, 1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024));
     DDK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_gn_local_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 160 * 1024));
     DDK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_gn_wlocal_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -642,7 +690,9 @@ int conv_gn_local(const float* src0, int c0, const float* src1, int c1, const fl
     if (HW == 4)
         hipLaunchKernelGGL((conv3x3_gn_local_kernel<16, 4>), grid, dim3(512), ldsb, st, p);
     else if (HW == 16)
-        hipLaunchKernelGGL(conv3x3_gn_local_kernel<16>, grid, dim3(512), ldsb, st, p);
+        if (c0 + c1 == 256) hipLaunchKernelGGL((conv3x3_gn_local_kernel<16, 1, 1>), grid, dim3(512), ldsb, st, p);
+        else if (c0 + c1 == 512) hipLaunchKernelGGL((conv3x3_gn_local_kernel<16, 1, 2>), grid, dim3(512), ldsb, st, p);
+        else hipLaunchKernelGGL(conv3x3_gn_local_kernel<16>, grid, dim3(512), ldsb, st, p);
     else
         hipLaunchKernelGGL(conv3x3_gn_local_kernel<64>, grid, dim3(512), ldsb, st, p);
     return check_launch("conv3x3_gn_local_kernel");
