@@ -6,6 +6,8 @@
 // There is no n x n matrix: per (sample, head) the state is 32x32, so the work is two streaming passes
 // over the [n][3*heads*32] projection (NHWC: a pixel's q|k|v are contiguous).  The 1x1 projections
 // to_qkv / to_out run on the MFMA implicit-GEMM kernel (conv_igemm.hip); this file is the part between.
+#include <cstdlib>
+
 #include "ddk_internal.h"
 
 namespace ddk {
@@ -523,7 +525,13 @@ __global__ __launch_bounds__(512) void linattn_apply_kernel(const float* __restr
 // Pixel-range splits: ~1024 workgroups at most, at least one 64-pixel tile each.
 static void linattn_splits(int B, int HW, int heads, int& splits, int& rows) {
     const int max_s = (int)ceil_div(HW, 64);
-    int s = 1024 / (B * heads);
+#ifdef DDK_TUNING
+    const char* cap_env = getenv("DDK_LINATTN_WGS");
+    const int cap = cap_env ? atoi(cap_env) : 1024;
+#else
+    const int cap = 1024;
+#endif
+    int s = cap / (B * heads);
     if (s < 1) s = 1;
     if (s > max_s) s = max_s;
     rows = (int)(ceil_div(ceil_div(HW, s), 64) * 64);
