@@ -25,8 +25,9 @@ constexpr int PART = DH + DH + DH * DH;  // floats per partial: max[32], den[32]
 __global__ __launch_bounds__(256) void linattn_context_kernel(const float* __restrict__ qkv, float* __restrict__ ctx,
                                                               float* __restrict__ part, int HW, int heads, int splits, int rows_per_split,
                                                               int kv_only) {
-    __shared__ __attribute__((aligned(16))) float kexp[64 * DH];
-    __shared__ __attribute__((aligned(16))) float vs[64 * DH];
+    __shared__ __attribute__((aligned(16))) float stage[4 * 32 * 33];   // kexp [64][32] | vs [64][32]; later the waves' partial tiles
+    float* kexp = stage;
+    float* vs = stage + 64 * DH;
     __shared__ float smax[8 * DH];
     const int bh = blockIdx.x / splits, sp = blockIdx.x % splits;
     const int b = bh / heads, h = bh % heads;
@@ -53,8 +54,16 @@ __global__ __launch_bounds__(256) void linattn_context_kernel(const float* __res
     }
 
     const int d = tid >> 3, e0 = (tid & 7) * 4;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    float den = 0.f;
+    // Round 4: ctx^T-tile = (exp k)^T v on the matrix pipe.  Wave w multiplies pixels [16 w, 16 w + 16) of every 64-pixel tile:
+    // v_mfma_f32_32x32x2_f32 with row operand kexp[n][d] (d = lane & 31, n = 2 s + lane / 32) and column operand v[n][e] -- eight
+    // MFMAs per tile and wave where every thread ran 64 x 5 FMAs behind two LDS reads each (the launch was VALU-bound: fewer or
+    // more pixel splits both lose, tools/attn_ctx_bench.py).  The softmax denominators ride along as sums of the row operand.
+    typedef float ctx_f32x16 __attribute__((ext_vector_type(16)));
+    const int lane = tid & 63, wv = tid >> 6, l31 = lane & 31, kh = lane >> 5;
+    ctx_f32x16 macc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) macc[r] = 0.f;
+    float dsum = 0.f;
     for (int n0 = n_begin; n0 < n_end; n0 += 64) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -73,14 +82,35 @@ __global__ __launch_bounds__(256) void linattn_context_kernel(const float* __res
             *reinterpret_cast<float4*>(vs + row * DH + c) = vv;
         }
         __syncthreads();
-#pragma unroll 8
-        for (int n = 0; n < 64; ++n) {
-            const float kd = kexp[n * DH + d];
-            const float4 v4 = *reinterpret_cast<const float4*>(vs + n * DH + e0);
-            acc.x += kd * v4.x; acc.y += kd * v4.y; acc.z += kd * v4.z; acc.w += kd * v4.w;
-            den += kd;
+#pragma unroll
+        for (int s2 = 0; s2 < 8; ++s2) {
+            const int n = wv * 16 + 2 * s2 + kh;
+            const float a = kexp[n * DH + l31];
+            macc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, vs[n * DH + l31], macc, 0, 0, 0);
+            dsum += a;
         }
         __syncthreads();
+    }
+    // the four waves' partial tiles and denominators meet in LDS
+    float4 acc;
+    float den;
+    {
+        float* pt = stage;                                 // [4 waves][32 d][33] over the tile staging area (the last barrier freed it)
+        static_assert(4 * 32 * 33 >= 2 * 64 * DH, "the staging array holds both tiles");
+#pragma unroll
+        for (int r = 0; r < 16; ++r) pt[(wv * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh) * 33 + l31] = macc[r];
+        dsum += __shfl_xor(dsum, 32, 64);
+        __shared__ float dpart[4 * DH];
+        if (kh == 0) dpart[wv * DH + l31] = dsum;
+        __syncthreads();
+        acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        den = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {                      // fixed order: deterministic
+            const float* q = pt + (w * 32 + d) * 33 + e0;
+            acc.x += q[0]; acc.y += q[1]; acc.z += q[2]; acc.w += q[3];
+            den += dpart[w * DH + d];
+        }
     }
     if (splits == 1) {
         const float inv = 1.0f / den;
