@@ -52,6 +52,12 @@ class WgradReduceJob(C.Structure):
                 ("cw", C.c_int), ("c_off", C.c_int), ("reserved", C.c_int)]
 
 
+class RowsSumJob(C.Structure):
+    """ddk_rows_sum_job (include/ddk.h)"""
+    _fields_ = [("rows", C.c_void_p), ("out", C.c_void_p * 4), ("batch_stride", C.c_longlong), ("row_stride", C.c_longlong),
+                ("block0", C.c_longlong), ("nbatch", C.c_int), ("nrows", C.c_int), ("n", C.c_int), ("reserved", C.c_int)]
+
+
 class PackJob(C.Structure):
     """ddk_pack_job (include/ddk.h)"""
     _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("total", C.c_longlong), ("block0", C.c_longlong), ("kind", C.c_int),
@@ -166,6 +172,7 @@ SIGNATURES = {
     "ddk_multi_add": (_I, [_P, _P, _I, _LL, _P]),
     "ddk_conv_wgrad_defer": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _SZ, _P, _P]),
     "ddk_wgrad_reduce_jobs": (_I, [_P, _I, _P]),
+    "ddk_rows_sum_jobs": (_I, [_P, _I, _P]),
     "ddk_pack_jobs_layout": (_LL, [_P, _I]),
     "ddk_pack_jobs": (_I, [_P, _I, _LL, _P]),
     "ddk_chan_layernorm_bwd": (_I, [_P, _P, _P, _P, _P, _I, C.POINTER(C.c_int), _LL, _I, _F, _P]),

@@ -743,6 +743,7 @@ def zero_stuff2(dy, h_out, w_out):
 # launches of 4-7 us per cfg3 optimiser step before.  Nothing may read the gradients in between (the trainers wrap exactly one
 # forward + backward); outside the block every call reduces at once, as before.
 _wgrad_pending = None         # None: immediate reduces; list of (job struct, slab tensor) while deferring
+_rows_pending = []            # (job struct, rows tensor): the GroupNorm / LayerNorm parameter-gradient row sums deferred alongside
 
 
 class deferred_wgrad:
@@ -761,12 +762,49 @@ class deferred_wgrad:
                     flush_wgrad()
             finally:
                 _wgrad_pending = None
+                del _rows_pending[:]
         return False
+
+
+def _rows_sum_targets(rows, nbatch, batch_stride, nrows, row_stride, targets, n):
+    """targets[k][:n] += sum_r rows[k * batch_stride + r * row_stride + :n] (ddk_rows_sum_targets); inside deferred_wgrad() the sum is
+    only recorded (`rows` is kept alive) and runs with the others when the block ends"""
+    if _wgrad_pending is not None:
+        job = L.RowsSumJob()
+        job.rows = rows.data_ptr()
+        for k in range(4):
+            job.out[k] = targets[k].data_ptr() if k < len(targets) and targets[k] is not None else None
+        job.batch_stride, job.row_stride, job.nbatch, job.nrows, job.n = batch_stride, row_stride, nbatch, nrows, n
+        _rows_pending.append((job, rows))
+        return
+    t = [L.ptr(x) for x in (list(targets) + [None] * 4)[:4]]
+    L.check(L.load().ddk_rows_sum_targets(L.ptr(rows), nbatch, batch_stride, nrows, row_stride, t[0], t[1], t[2], t[3], n, 1, L.stream()),
+            "rows_sum_targets")
+
+
+def _flush_rows():
+    global _rows_pending
+    pending, _rows_pending = _rows_pending, []
+    lib = L.load()
+    while pending:
+        seen, batch, rest = set(), [], []
+        for job, rows in pending:            # two sums into the same gradient must not share a launch
+            keys = [p for p in job.out if p]
+            if any(k in seen for k in keys):
+                rest.append((job, rows))
+            else:
+                batch.append((job, rows))
+                seen.update(keys)
+        jobs = (L.RowsSumJob * len(batch))(*[j for j, _ in batch])
+        L.check(lib.ddk_rows_sum_jobs(jobs, len(batch), L.stream()), "rows_sum_jobs")
+        pending = rest
 
 
 def flush_wgrad():
     """run the recorded reduces: one launch per set of jobs with pairwise distinct targets (normally one)"""
     global _wgrad_pending
+    if _rows_pending:
+        _flush_rows()
     if not _wgrad_pending:
         return 0
     pending, _wgrad_pending = _wgrad_pending, []
@@ -848,8 +886,7 @@ def groupnorm_mish_bwd(x, gamma, beta, dy, drop_p=0.0, seed=0, layer=0, groups=G
     missing = [k for k in range(3) if acc is None or acc[k] is None]
     if acc is not None and any(t is not None for t in acc):
         # straight into the parameters' gradients (fixed-order row sums, then +=), one launch for the three of them
-        L.check(lib.ddk_rows_sum_targets(L.ptr(part[1]), 3, b * c, b, c, L.ptr(acc[0]), L.ptr(acc[1]), L.ptr(acc[2]), None, c, 1,
-                                         L.stream()), "rows_sum_targets")
+        _rows_sum_targets(part[1], 3, b * c, b, c, [acc[0], acc[1], acc[2]], c)
     if missing:
         out = torch.empty((3, c), device=x.device, dtype=torch.float32)
         L.check(lib.ddk_rows_sum_batched(L.ptr(part[1]), 3, b * c, b, c, L.ptr(out), c, 0, L.stream()), "rows_sum_batched")
@@ -897,8 +934,7 @@ def chan_layernorm_bwd(x, g, dy, eps=LN_EPS, acc=None):
                                        C.byref(n), m, c, eps, L.stream()), "chan_layernorm_bwd")
     # the kernel laid the rows out as [2][nparts][C] with nparts = n.value
     if acc is not None and acc[0] is not None and acc[1] is not None:
-        L.check(lib.ddk_rows_sum_targets(L.ptr(part), 2, n.value * c, n.value, c, L.ptr(acc[0]), L.ptr(acc[1]), None, None, c, 1, L.stream()),
-                "rows_sum_targets")
+        _rows_sum_targets(part, 2, n.value * c, n.value, c, [acc[0], acc[1]], c)
         return dx, None, None
     out = torch.empty((2, c), device=x.device, dtype=torch.float32)
     L.check(lib.ddk_rows_sum_batched(L.ptr(part), 2, n.value * c, n.value, c, L.ptr(out), c, 0, L.stream()), "rows_sum_batched")

@@ -439,6 +439,16 @@ int ddk_rows_sum_batched(const float* rows, int nbatch, long long batch_stride, 
  * GroupNorm backward into their three gradient buffers in one launch) */
 int ddk_rows_sum_targets(const float* rows, int nbatch, long long batch_stride, int nrows, long long row_stride, float* out0, float* out1,
                          float* out2, float* out3, int n, int accumulate, ddk_stream_t s);
+/* round 4: ddk_rows_sum_targets (accumulate = 1) of many calls in a few launches -- the per-channel parameter gradients of every
+ * GroupNorm / LayerNorm of one backward pass; records from host memory, 48 to a launch as kernel arguments; same bits */
+typedef struct ddk_rows_sum_job {
+    const float* rows;
+    float* out[4];           /* one target per batch entry, null = skipped */
+    long long batch_stride, row_stride;
+    long long block0;        /* set by ddk_rows_sum_jobs */
+    int nbatch, nrows, n, reserved;
+} ddk_rows_sum_job;          /* 80 bytes */
+int ddk_rows_sum_jobs(const ddk_rows_sum_job* jobs_host, int n, ddk_stream_t s);
 /* dst_k[i] += src[off_k + i], k < nseg; table [nseg][3] int64 on the device = {source offset (floats), destination address, count};
  * max_count = the largest count (sizes the grid).  One launch for the many parameter gradients of one backward. */
 int ddk_multi_add(const float* src, const long long* table, int nseg, long long max_count, ddk_stream_t s);

@@ -463,3 +463,34 @@ def test_deferred_weight_gradient_reduces_are_bit_identical():
         ops.conv_wgrad_(kind, x, dy, gw_b, c_real=c_real, cw=cw, c_off=c_off)
         ops.conv_wgrad_(kind, x, dy, gw_b, c_real=c_real, cw=cw, c_off=c_off)
     assert torch.equal(gw_a, gw_b)
+
+
+def test_deferred_norm_parameter_gradients_are_bit_identical():
+    """inside ops.deferred_wgrad() the GroupNorm / LayerNorm backward kernels only record their parameter-gradient row sums
+    (ddk_rows_sum_jobs runs them 48 to a launch when the block ends) == one rows_sum_targets launch per call, bit for bit"""
+    from ddk import ops
+    g = torch.Generator().manual_seed(5)
+    cases = []
+    for k in range(30):
+        c = (32, 64, 128, 256)[k % 4]
+        b, h = (3, 8) if k % 2 else (5, 4)
+        cases.append((torch.randn(b, h, h, c, generator=g).to(DEV), torch.randn(b, h, h, c, generator=g).to(DEV),
+                      (torch.rand(c, generator=g) + 0.5).to(DEV), torch.randn(c, generator=g).to(DEV)))
+    def run(defer):
+        res = []
+        ctx = ops.deferred_wgrad() if defer else contextlib.nullcontext()
+        with ctx:
+            for x, dy, ga, be in cases:
+                c = x.shape[-1]
+                acc = tuple(torch.full((c,), 0.5, device=DEV) for _ in range(3))
+                dx, dtemb, sums = ops.groupnorm_mish_bwd(x, ga, be, dy, acc=acc)
+                assert sums == [None, None, None]
+                lacc = (torch.full((c,), -1.0, device=DEV), torch.full((c,), 2.0, device=DEV))
+                ldx, _, _ = ops.chan_layernorm_bwd(x, ga.view(1, c, 1, 1), dy, acc=lacc)
+                res.append((dx, dtemb) + acc + (ldx,) + lacc)
+        torch.cuda.synchronize()
+        return res
+    a, b = run(False), run(True)
+    for ra, rb in zip(a, b):
+        for ta, tb in zip(ra, rb):
+            assert torch.equal(ta, tb)
