@@ -32,6 +32,7 @@ struct Arena {
 };
 
 static int failures = 0;
+static long g_expected_errors = 0;      // errors provoked on purpose
 #define CHECK(cond, ...)                                      \
     do {                                                      \
         if (!(cond)) { ++failures; std::printf("FAIL %s:%d: ", __FILE__, __LINE__); std::printf(__VA_ARGS__); std::printf("\n"); } \
@@ -91,6 +92,86 @@ static void walk(const char* name, int in_ch, int chan, std::vector<int> mults, 
                 ws_bytes / 1e6, smp_bytes / 1e6, launches, errors);
 }
 
+// The training-side entry points added in round 4 (job-table launches, deferred reduces, the 32-channel and small-map conv kernels):
+// every pointer a launch carries -- also inside the by-value job packs -- must lie in a registered arena.
+static void walk_training_ops() {
+    ddk_san_clear();
+    struct Shape { int kind, B, H, W, cx, N; };
+    const Shape shapes[] = {{DDK_CONV3X3_S1, 8, 64, 64, 32, 32}, {DDK_CONV3X3_S1, 4, 16, 16, 128, 256}, {DDK_CONV1X1, 4, 8, 8, 256, 384},
+                            {DDK_CONV3X3_S2, 4, 16, 16, 64, 64}, {DDK_CONV1X1, 32, 4, 4, 128, 256}, {DDK_CONV3X3_S1, 2, 32, 32, 32, 32}};
+    std::vector<ddk_wgrad_reduce_job> jobs;
+    std::vector<Arena*> keep;
+    for (const Shape& sh : shapes) {
+        const int k = sh.kind == DDK_CONV1X1 ? 1 : 3, Ho = sh.kind == DDK_CONV3X3_S2 ? sh.H / 2 : sh.H;
+        const size_t xb = (size_t)sh.B * sh.H * sh.W * sh.cx * 4, yb = (size_t)sh.B * Ho * Ho * sh.N * 4, wb = (size_t)sh.N * sh.cx * k * k * 4;
+        Arena* x = new Arena(xb, "x"); Arena* dy = new Arena(yb, "dy"); Arena* gw = new Arena(wb, "grad_w"); Arena* gb = new Arena((size_t)sh.N * 4, "grad_b");
+        const size_t wsb = ddk_conv_wgrad_workspace_bytes(sh.kind, sh.B, sh.H, sh.W, sh.cx, sh.N);
+        CHECK(wsb > 0, "wgrad workspace query");
+        Arena* ws = new Arena(wsb, "wgrad slabs");
+        int rc = ddk_conv_wgrad_bias(sh.kind, x->f(), dy->f(), gw->f(), gb->f(), sh.B, sh.H, sh.W, sh.cx, sh.cx, sh.cx, 0, sh.N, ws->p, wsb, nullptr);
+        CHECK(rc == DDK_OK, "conv_wgrad_bias: %s", ddk_last_error());
+        CHECK(ddk_conv_wgrad_bias(sh.kind, x->f(), dy->f(), gw->f(), gb->f(), sh.B, sh.H, sh.W, sh.cx, sh.cx, sh.cx, 0, sh.N, ws->p, wsb - 4, nullptr) ==
+                  DDK_ERR_WORKSPACE, "short wgrad workspace accepted");
+        ddk_wgrad_reduce_job j{};
+        rc = ddk_conv_wgrad_defer(sh.kind, x->f(), dy->f(), gw->f(), gb->f(), sh.B, sh.H, sh.W, sh.cx, sh.cx, sh.cx, 0, sh.N, ws->p, wsb, &j, nullptr);
+        CHECK(rc == DDK_OK, "conv_wgrad_defer: %s", ddk_last_error());
+        jobs.push_back(j);
+        // the forward / input-gradient convs of the same shape with the epilogues of the training path
+        if (sh.kind != DDK_CONV3X3_S2) {
+            Arena* wp = new Arena((size_t)sh.N * k * k * sh.cx * 4, "packed weight"); Arena* o2 = new Arena(yb, "mish_out"); Arena* h = new Arena(yb, "dmish_src");
+            const size_t cwb = ddk_conv_workspace_bytes(sh.kind, sh.B, sh.H, sh.W, sh.cx, sh.N);
+            Arena* cws = new Arena(cwb, "conv workspace");
+            ddk_conv_args a{};
+            a.kind = sh.kind; a.src0 = x->f(); a.c0 = sh.cx; a.weight = wp->f(); a.bias = gb->f(); a.out = dy->f();
+            a.B = sh.B; a.H = sh.H; a.W = sh.W; a.N = sh.N; a.workspace = cws->p; a.workspace_bytes = cwb;
+            CHECK(ddk_conv_forward(&a, nullptr) == DDK_OK, "conv_forward: %s", ddk_last_error());
+            a.mish_out = o2->f();
+            CHECK(ddk_conv_forward(&a, nullptr) == DDK_OK, "conv_forward (mish_out): %s", ddk_last_error());
+            a.mish_out = nullptr; a.dmish_src = h->f(); a.resid = o2->f();
+            CHECK(ddk_conv_forward(&a, nullptr) == DDK_OK, "conv_forward (dmish_src, resid): %s", ddk_last_error());
+            keep.insert(keep.end(), {wp, o2, h, cws});
+        }
+        keep.insert(keep.end(), {x, dy, gw, gb, ws});
+    }
+    CHECK(ddk_wgrad_reduce_jobs(jobs.data(), (int)jobs.size(), nullptr) == DDK_OK, "wgrad_reduce_jobs: %s", ddk_last_error());
+    {   // a job whose slab pointer is stale (its arena gone) must be flagged by the checker, not slip through inside the by-value pack
+        long l0 = 0, e0 = 0, l1 = 0, e1 = 0;
+        ddk_san_stats(&l0, &e0);
+        ddk_wgrad_reduce_job bad = jobs[0];
+        bad.slab = jobs[0].slab + (512u << 20) / 4;          // 512 MiB past its arena: near the registered range, inside none of it
+        std::fprintf(stderr, "[plan_walk] a stale job pointer on purpose: the next message is expected\n");
+        (void)ddk_wgrad_reduce_jobs(&bad, 1, nullptr);
+        ddk_san_stats(&l1, &e1);
+        CHECK(e1 > e0, "a stale pointer inside a reduce job was not flagged");
+        g_expected_errors += e1 - e0;
+    }
+    {   // GroupNorm / LayerNorm parameter-gradient sums as jobs
+        Arena rows((size_t)3 * 8 * 256 * 4, "rows"), t0(1024, "dgamma"), t1(1024, "dbeta"), t2(1024, "dbias");
+        ddk_rows_sum_job r{};
+        r.rows = rows.f(); r.out[0] = t0.f(); r.out[1] = t1.f(); r.out[2] = t2.f(); r.batch_stride = 8 * 256; r.row_stride = 256;
+        r.nbatch = 3; r.nrows = 8; r.n = 256;
+        std::vector<ddk_rows_sum_job> rj(60, r);
+        CHECK(ddk_rows_sum_jobs(rj.data(), (int)rj.size(), nullptr) == DDK_OK, "rows_sum_jobs: %s", ddk_last_error());
+    }
+    {   // every kernel-layout copy of two weights by one launch
+        Arena w((size_t)256 * 256 * 9 * 4, "weight"), d0((size_t)256 * 9 * 256 * 4, "fwd copy"), d1((size_t)8 * 16 * 256 * 32 * 4, "wino copy"),
+            d2((size_t)256 * 9 * 256 * 4, "dgrad copy");
+        ddk_pack_job pj[3]{};
+        pj[0].src = w.f(); pj[0].dst = d0.f(); pj[0].kind = DDK_PACK_CONV; pj[0].p[0] = 256; pj[0].p[1] = 256; pj[0].p[2] = 9; pj[0].p[3] = 256; pj[0].p[4] = 256; pj[0].p[5] = 256;
+        pj[1].src = w.f(); pj[1].dst = d1.f(); pj[1].kind = DDK_PACK_WINO; pj[1].p[0] = 256; pj[1].p[1] = 256; pj[1].p[2] = 256;
+        pj[2].src = w.f(); pj[2].dst = d2.f(); pj[2].kind = DDK_PACK_DGRAD; pj[2].p[0] = 256; pj[2].p[1] = 256; pj[2].p[2] = 9; pj[2].p[3] = 256; pj[2].p[4] = 256;
+        const long long blocks = ddk_pack_jobs_layout(pj, 3);
+        CHECK(blocks > 0, "pack_jobs_layout: %s", ddk_last_error());
+        Arena table(sizeof(pj), "job table");
+        std::memcpy(table.p, pj, sizeof(pj));
+        CHECK(ddk_pack_jobs(static_cast<const ddk_pack_job*>(table.p), 3, blocks, nullptr) == DDK_OK, "pack_jobs: %s", ddk_last_error());
+    }
+    for (Arena* a : keep) delete a;
+    long launches = 0, errors = 0;
+    ddk_san_stats(&launches, &errors);
+    std::printf("%-34s launches so far %ld  errors %ld (of which %ld seeded)\n", "training-side entry points", launches, errors, g_expected_errors);
+}
+
 int main() {
     // BASELINE.json configs (unet_chan 128, unet_dims (1,2,2,2)); cfg1 MNIST 32x32 C_in 1 T=200; cfg2 CIFAR C_in 3; cfg3 16x16 latents
     // of 8; cfg4 32x32 latents of 8; cfg5 the full-resolution UNet
@@ -107,6 +188,7 @@ int main() {
     walk("width 24 (1,2,4), 3x16x16 b3", 3, 24, {1, 2, 4}, 3, 16, 16, 100);
     walk("width 40 (1,2,2,2), 8x32x32 b2", 8, 40, {1, 2, 2, 2}, 2, 32, 32, 100);
     walk("width 8 (1,2), 1x8x8 b5", 1, 8, {1, 2}, 5, 8, 8, 50);
+    walk_training_ops();
     ddk_unet_config bad{};
     bad.in_ch = 3; bad.chan = 44; bad.n_levels = 2; bad.mults[0] = 1; bad.mults[1] = 2;
     CHECK(ddk_unet_create(&bad) == nullptr, "unet_chan 44 accepted");
@@ -114,6 +196,7 @@ int main() {
     CHECK(ddk_unet_create(&bad) == nullptr, "unet_dims[0] = 2 accepted");
     long launches = 0, errors = 0;
     ddk_san_stats(&launches, &errors);
+    errors -= g_expected_errors;
     // the checker checks: the same forward with the workspace arena registered HALF as large as it is must be flagged
     long seeded = 0;
     {
@@ -129,7 +212,7 @@ int main() {
         (void)ddk_unet_forward(u, packed.p, x.f(), static_cast<const int64_t*>(t.p), out.f(), 2, 8, 8, ws, wb, nullptr);
         long l2 = 0, e2 = 0;
         ddk_san_stats(&l2, &e2);
-        seeded = e2 - errors;
+        seeded = e2 - errors - g_expected_errors;
         CHECK(seeded > 0, "a workspace registered half as large as it is was not flagged");
         munmap(ws, wb);
         ddk_unet_destroy(u);
