@@ -68,19 +68,21 @@ def _conv_backward(kind, x, x2, weight, bias, dy, needs, gb_ready=False, dmish_s
         gw_t = slot if slot is not None else torch.zeros_like(weight, memory_format=torch.contiguous_format)
         if kind == ops.CONVT4X4_S2:
             # dW[i][o][ky][kx] = sum X[i] * dY[o] shifted: wgrad of the 4x4 stride-2 conv with the roles swapped
-            ops.conv_wgrad_(ops.CONV4X4_S2, dy, x, gw_t, c_real=dy.shape[-1], cw=dy.shape[-1], c_off=0)
+            ops.conv_wgrad_(ops.CONV4X4_S2, dy, x, gw_t, c_real=dy.shape[-1], cw=dy.shape[-1], c_off=0, persistent=slot is not None)
         else:
             cin = weight.shape[1]
             gb_t = None
+            keeps = slot is not None              # both targets are `.grad` slots: the reduce may wait for the end of the backward pass
             if bias is not None and need_b and not gb_ready:
                 # the bias gradient (column sums of dy) rides on the weight-gradient launches of the first source
                 bslot = _grad_slot(bias)
                 gb_t = bslot if bslot is not None else torch.zeros_like(bias, memory_format=torch.contiguous_format)
                 gb = None if bslot is not None else gb_t
                 gb_ready = True
-            ops.conv_wgrad_(kind, x, dy, gw_t, c_real=min(c0, cin), cw=cin, c_off=0, grad_b=gb_t)
+                keeps = keeps and bslot is not None
+            ops.conv_wgrad_(kind, x, dy, gw_t, c_real=min(c0, cin), cw=cin, c_off=0, grad_b=gb_t, persistent=keeps)
             if x2 is not None:
-                ops.conv_wgrad_(kind, x2, dy, gw_t, c_real=c1, cw=cin, c_off=c0)
+                ops.conv_wgrad_(kind, x2, dy, gw_t, c_real=c1, cw=cin, c_off=c0, persistent=slot is not None)
         gw = None if slot is not None else gw_t
     if bias is not None and need_b and not gb_ready:
         slot = _grad_slot(bias)

@@ -826,14 +826,16 @@ def flush_wgrad():
     return launches
 
 
-def conv_wgrad_(kind, x, dy, grad_w, c_real, cw, c_off, grad_b=None):
+def conv_wgrad_(kind, x, dy, grad_w, c_real, cw, c_off, grad_b=None, persistent=False):
     """grad_w (canonical layout, contiguous) += weight gradient of `kind` for the source x (see csrc/conv_wgrad.hip);
-    grad_b [N] += column sums of dy when given (the bias gradient, produced by the same launches)."""
+    grad_b [N] += column sums of dy when given (the bias gradient, produced by the same launches).
+    persistent: grad_w / grad_b are buffers that outlive the backward pass (the parameters' `.grad` slots) -- only then may the
+    reduce be deferred inside deferred_wgrad(); a temporary handed back to autograd is reduced at once."""
     b, h, w, cx = x.shape
     n = dy.shape[-1]
     lib = L.load()
     nbytes = lib.ddk_conv_wgrad_workspace_bytes(kind, b, h, w, cx, n)
-    if _wgrad_pending is not None:
+    if _wgrad_pending is not None and persistent:
         slab = torch.empty(max(nbytes, 16) // 4, device=x.device, dtype=torch.float32)
         job = L.WgradReduceJob()
         L.check(lib.ddk_conv_wgrad_defer(kind, L.ptr(_f32(x)), L.ptr(_f32(dy)), L.ptr(grad_w), L.ptr(grad_b), b, h, w, cx, c_real, cw, c_off, n,

@@ -95,6 +95,22 @@ def test_conv_backward_accumulates_into_existing_grads(AG):
     assert rel_err(wd.grad.cpu(), 1 + 2 * gw) < 3e-5 and rel_err(bd.grad.cpu(), 2 + 2 * gb) < 3e-5
 
 
+def test_deferred_reduces_leave_temporaries_alone(AG):
+    """inside ops.deferred_wgrad() (the trainers' accumulation block) only gradients that land in pre-existing `.grad` buffers wait
+    for the end of the pass; a parameter WITHOUT such a buffer gets its gradient through autograd as a temporary, which must be
+    complete when the Function returns -- first pass (no .grad yet) and second pass (.grad exists) both against torch-CPU"""
+    from ddk import ops
+    x, w, b = rnd(3, 64, 16, 16, seed=51), rnd(32, 64, 3, 3, seed=52, scale=0.05), rnd(32, seed=53, scale=0.1)
+    out_ref, g, (gx, gw, gb) = grads_cpu(lambda a, ww, bb: F.conv2d(a, ww, bb, padding=1), x, w, b)
+    wd, bd = w.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+    for k in (1, 2):
+        with ops.deferred_wgrad():
+            xh = to_nhwc(x).to(DEV).requires_grad_(True)
+            AG.conv(ops.CONV3X3_S1, xh, wd, bd).backward(to_nhwc(g).to(DEV))
+        assert rel_err(wd.grad.cpu(), k * gw) < 3e-5 and rel_err(bd.grad.cpu(), k * gb) < 3e-5
+        assert rel_err(to_nchw(xh.grad.cpu()), gx) < 3e-5
+
+
 @pytest.mark.parametrize("B,H,W,C,M", [(2, 16, 16, 64, 32), (3, 8, 12, 32, 32), (1, 64, 64, 64, 32), (64, 4, 4, 128, 64)])
 def test_preact_conv_chain(AG, B, H, W, C, M):
     """conv1x1(mish(x)) -> conv3x3(mish(.)) -> conv1x1(mish(.)) + x with the Mish forward written by the producing conv's epilogue
@@ -446,7 +462,7 @@ def test_deferred_weight_gradient_reduces_are_bit_identical():
             for kind, x, dy, wshape, c_real, cw, c_off, with_b in cases:
                 gw = torch.full(wshape, 0.25, device=DEV)
                 gb = torch.full((wshape[0],), -0.5, device=DEV) if with_b else None
-                ops.conv_wgrad_(kind, x, dy, gw, c_real=c_real, cw=cw, c_off=c_off, grad_b=gb)
+                ops.conv_wgrad_(kind, x, dy, gw, c_real=c_real, cw=cw, c_off=c_off, grad_b=gb, persistent=True)
                 outs.append((gw, gb))
         torch.cuda.synchronize()
         return outs
@@ -460,9 +476,15 @@ def test_deferred_weight_gradient_reduces_are_bit_identical():
     ops.conv_wgrad_(kind, x, dy, gw_a, c_real=c_real, cw=cw, c_off=c_off)
     ops.conv_wgrad_(kind, x, dy, gw_a, c_real=c_real, cw=cw, c_off=c_off)
     with ops.deferred_wgrad():
-        ops.conv_wgrad_(kind, x, dy, gw_b, c_real=c_real, cw=cw, c_off=c_off)
-        ops.conv_wgrad_(kind, x, dy, gw_b, c_real=c_real, cw=cw, c_off=c_off)
+        ops.conv_wgrad_(kind, x, dy, gw_b, c_real=c_real, cw=cw, c_off=c_off, persistent=True)
+        ops.conv_wgrad_(kind, x, dy, gw_b, c_real=c_real, cw=cw, c_off=c_off, persistent=True)
     assert torch.equal(gw_a, gw_b)
+    # a gradient buffer that does NOT outlive the pass (no `.grad` slot: autograd takes the tensor at once) is reduced at once
+    gw_c = torch.zeros(wshape, device=DEV)
+    with ops.deferred_wgrad():
+        ops.conv_wgrad_(kind, x, dy, gw_c, c_real=c_real, cw=cw, c_off=c_off)
+        inside = gw_c.clone()
+    assert torch.equal(inside, gw_c) and float(gw_c.abs().max()) > 0
 
 
 def test_deferred_norm_parameter_gradients_are_bit_identical():
