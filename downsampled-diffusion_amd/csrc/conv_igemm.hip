@@ -1166,7 +1166,7 @@ static bool choose_halo(int kind, int B, int H, int W, int cin, int N, Choice& c
 #endif
 
 // ---- register-resident 32 -> 32 kernel (conv_c32_kernel.inc): the halo kernel's tile geometry, whole tiles only, and enough tiles
-// to fill the chip (below 256 tiles its once-per-workgroup filter load is not repaid: the im2col tile kernel stays)
+// to fill half the chip (below 128 tiles its once-per-workgroup filter load is not repaid: the im2col tile kernel stays)
 static bool choose_c32(int kind, int B, int H, int W, int cin, int N, int c1, bool pre_mish) {
     if (tuning_flag("DDK_NO_C32") || kind != DDK_CONV3X3_S1 || cin != 32 || N != 32 || c1 != 0 || pre_mish) return false;
     if (W != 8 && W != 16 && W != 32 && W != 64) return false;
@@ -1175,7 +1175,7 @@ static bool choose_c32(int kind, int B, int H, int W, int cin, int N, int c1, bo
     if (c32_halo_px(W, H) > C32_MAX_PX) return false;
     const long long M = (long long)B * H * W;
     if (M % 128 || M * 32 * 4 >= (1LL << 31)) return false;
-    return M / 128 >= tuning_int("DDK_C32_MIN_TILES", 256);
+    return M / 128 >= tuning_int("DDK_C32_MIN_TILES", 128);   // (16x16 x 64 images = 128 tiles: 10.4 / 12.0 / 12.2 -> 9.0 / 10.2 / 10.4 us)
 }
 #define DDK_C32_WIDTHS(X) X(8) X(16) X(32) X(64)
 static int launch_c32(const IgemmParams& p, hipStream_t st) {

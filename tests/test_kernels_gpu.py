@@ -322,12 +322,13 @@ def test_conv_pre_post_mish(ops):
     assert rel_err(to_nchw(out3.cpu()), ref3) < 2e-5
 
 
-C32_CASES = [  # B, H, W: conv3x3 32 -> 32 on >= 256 whole 128-pixel tiles -> the register-resident kernel (conv_c32_kernel.inc)
+C32_CASES = [  # B, H, W: conv3x3 32 -> 32 on >= 128 whole 128-pixel tiles -> the register-resident kernel (conv_c32_kernel.inc)
     (8, 64, 64),      # cfg3 encoder / decoder level 0: 2-row tiles, 4 tiles per workgroup
     (33, 32, 32),     # 4-row tiles, a tile count (264) that is not a multiple of 8: plain tile order
     (128, 16, 16),    # 8-row tiles, two per image
     (512, 8, 8),      # two images per tile
     (5, 64, 128),     # one row per tile, non-square
+    (64, 16, 16),     # 128 tiles: the smallest grid the kernel takes (half the chip)
 ]
 
 
