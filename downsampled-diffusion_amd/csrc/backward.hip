@@ -51,6 +51,22 @@ __device__ __forceinline__ float4 dropout_scale4(long long elem4, float p, uint6
 // backward (x recomputed from the saved conv output, nothing else is stored):
 //   g1 = dy * dropmask;  dtemb[b][c] = sum_hw g1;  du = g1 * mish'(u);  dbeta += sum du;  dgamma += sum du * xhat
 //   dx = rstd * (du*gamma - mean_g(du*gamma) - xhat * mean_g(du*gamma*xhat))
+// v += slab 1 + slab 2 + ... (in that order) of the float4 at p; four loads are in flight at a time (a (sample, group) workgroup has
+// little else to hide their latency behind)
+__device__ __forceinline__ void add_slabs(float4& v, const float* __restrict__ p, int nslab, long long slab_stride) {
+    for (int sl = 1; sl < nslab; sl += 4) {
+        float4 t[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int q = sl + j < nslab ? sl + j : nslab - 1;
+            t[j] = *reinterpret_cast<const float4*>(p + q * slab_stride);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (sl + j < nslab) { v.x += t[j].x; v.y += t[j].y; v.z += t[j].z; v.w += t[j].w; }
+    }
+}
+
 template <int VPT, int NT, bool BWD>
 __global__ __launch_bounds__(NT) void gn_train_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                       const float* __restrict__ beta, const float* __restrict__ temb,
@@ -58,7 +74,11 @@ __global__ __launch_bounds__(NT) void gn_train_kernel(const float* __restrict__ 
                                                       uint64_t seed, uint32_t layer, const float* __restrict__ dy,
                                                       float* __restrict__ out /* fwd: y; bwd: dx */,
                                                       float* __restrict__ part /* bwd: [4][B][C] dtemb, dgamma, dbeta, sum dx */, int B, int HW,
-                                                      int C, int groups, float eps) {
+                                                      int C, int groups, float eps, int nslab, long long slab_stride,
+                                                      const float* __restrict__ conv_bias, float* __restrict__ raw_out) {
+    // nslab > 1: the tensor this kernel reads first (fwd: x, bwd: dy) still lies as `nslab` split-K partial slabs of the conv that
+    // produced it; they are summed in slab order while loading (the order of splitk_reduce_kernel), fwd adds conv_bias and also
+    // writes the sum to raw_out -- the pre-normalisation tensor the backward reads.
     __shared__ float red[32];
     __shared__ float csum[16][8][16];  // [wave][cu][4 ch x {dtemb, dgamma, dbeta, dx}]
     const int b = blockIdx.x / groups, g = blockIdx.x % groups;
@@ -74,7 +94,16 @@ __global__ __launch_bounds__(NT) void gn_train_kernel(const float* __restrict__ 
         const int u = threadIdx.x + i * NT;
         if (u < units) {
             const int row = div_upr(u, upr), cu = u - row * upr;
-            v[i] = *reinterpret_cast<const float4*>(x + base + (long long)row * C + cu * 4);
+            const long long o = base + (long long)row * C + cu * 4;
+            v[i] = *reinterpret_cast<const float4*>(x + o);
+            if (!BWD && nslab > 1) {
+                add_slabs(v[i], x + o, nslab, slab_stride);
+                if (conv_bias) {
+                    const float4 cb = *reinterpret_cast<const float4*>(conv_bias + g * cpg + cu * 4);
+                    v[i].x += cb.x; v[i].y += cb.y; v[i].z += cb.z; v[i].w += cb.w;
+                }
+                *reinterpret_cast<float4*>(raw_out + o) = v[i];
+            }
             s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
         } else {
             v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -138,6 +167,7 @@ __global__ __launch_bounds__(NT) void gn_train_kernel(const float* __restrict__ 
             const int row = div_upr(u, upr);
             const long long o = base + (long long)row * C + cu_t * 4;
             float4 g1 = *reinterpret_cast<const float4*>(dy + o);
+            if (nslab > 1) add_slabs(g1, dy + o, nslab, slab_stride);
             if (drop_p > 0.f) {
                 const float4 m = dropout_scale4(o >> 2, drop_p, seed, layer);
                 g1.x *= m.x; g1.y *= m.y; g1.z *= m.z; g1.w *= m.w;
@@ -1000,8 +1030,15 @@ static size_t gn_train_ws_floats(int B, int HW, int C, int groups, int& ns) {
 
 static int gn_train_launch(bool bwd, const float* x, const float* gamma, const float* beta, const float* temb, int temb_stride,
                            const float* addend, float drop_p, uint64_t seed, uint32_t layer, const float* dy, float* out, float* part,
-                           int B, int HW, int C, int groups, float eps, void* ws, size_t ws_bytes, hipStream_t st) {
+                           int B, int HW, int C, int groups, float eps, void* ws, size_t ws_bytes, hipStream_t st, int nslab = 1,
+                           long long slab_stride = 0, const float* conv_bias = nullptr, float* raw_out = nullptr) {
     DDK_REQUIRE(x && gamma && beta && out, "groupnorm_train: null pointer");
+    DDK_REQUIRE(nslab >= 1 && nslab <= 256, "groupnorm_train: slab count");
+    if (nslab > 1) {
+        DDK_REQUIRE(slab_stride >= (long long)B * HW * C && slab_stride % 4 == 0, "groupnorm_train: slab stride");
+        DDK_REQUIRE(bwd || (raw_out && aligned16(raw_out)), "groupnorm_train: the slab form of the forward needs raw_out");
+        DDK_REQUIRE(!conv_bias || aligned16(conv_bias), "groupnorm_train: conv_bias alignment");
+    }
     DDK_REQUIRE(B > 0 && HW > 0 && groups > 0 && C % groups == 0 && (C / groups) % 4 == 0, "groupnorm_train: C/groups % 4");
     DDK_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "groupnorm_train: dropout p");
     const int cpg = C / groups, upr = cpg / 4;
@@ -1010,6 +1047,8 @@ static int gn_train_launch(bool bwd, const float* x, const float* gamma, const f
     int ns = 0;
     const size_t need = gn_train_ws_floats(B, HW, C, groups, ns) * sizeof(float);
     if (ns > 0) {
+        DDK_REQUIRE(nslab == 1, "groupnorm_train: the slab forms exist only for group slabs the register-resident kernel takes "
+                                "(ddk_groupnorm_train_workspace_bytes() == 0)");
         if (!ws || ws_bytes < need) {
             set_error("groupnorm_train: workspace too small (%zu < %zu)", ws_bytes, need);
             return DDK_ERR_WORKSPACE;
@@ -1051,9 +1090,9 @@ static int gn_train_launch(bool bwd, const float* x, const float* gamma, const f
 #define GT(V, NT)                                                                                                                 \
     do {                                                                                                                          \
         if (bwd) hipLaunchKernelGGL((gn_train_kernel<V, NT, true>), grid, dim3(NT), 0, st, x, gamma, beta, temb, temb_stride, addend, \
-                                    drop_p, seed, layer, dy, out, part, B, HW, C, groups, eps);                                  \
+                                    drop_p, seed, layer, dy, out, part, B, HW, C, groups, eps, nslab, slab_stride, conv_bias, raw_out); \
         else hipLaunchKernelGGL((gn_train_kernel<V, NT, false>), grid, dim3(NT), 0, st, x, gamma, beta, temb, temb_stride, addend,   \
-                                drop_p, seed, layer, dy, out, part, B, HW, C, groups, eps);                                      \
+                                drop_p, seed, layer, dy, out, part, B, HW, C, groups, eps, nslab, slab_stride, conv_bias, raw_out);  \
     } while (0)
     if (units <= 256) GT(1, 256);
     else if (units <= 512) GT(2, 256);
@@ -1088,6 +1127,26 @@ int ddk_groupnorm_mish_bwd(const float* x, const float* gamma, const float* beta
     DDK_REQUIRE(dy && part, "groupnorm_bwd: null pointer");
     return gn_train_launch(true, x, gamma, beta, nullptr, 0, nullptr, drop_p, seed, layer, dy, dx, part, B, HW, C, groups, eps,
                            workspace, workspace_bytes, as_stream(s));
+}
+
+/* The two above with the tensor they read first still in `nslab` split-K slabs (ddk_conv_args.defer_reduce): the forward sums
+ * x = sum slabs + conv_bias while loading and also writes it to raw_out; the backward sums dy.  Register-resident slabs only. */
+int ddk_groupnorm_mish_train_fwd_slabs(const float* slabs, int nslab, long long slab_stride, const float* conv_bias, float* raw_out,
+                                       const float* gamma, const float* beta, const float* temb, int temb_stride, const float* addend,
+                                       float drop_p, uint64_t seed, uint32_t layer, float* out, int B, int HW, int C, int groups, float eps,
+                                       ddk_stream_t s) {
+    DDK_REQUIRE(nslab >= 2, "groupnorm_train_fwd_slabs: fewer than two slabs (use ddk_groupnorm_mish_train_fwd)");
+    return gn_train_launch(false, slabs, gamma, beta, temb, temb_stride, addend, drop_p, seed, layer, nullptr, out, nullptr, B, HW, C, groups,
+                           eps, nullptr, 0, as_stream(s), nslab, slab_stride, conv_bias, raw_out);
+}
+
+int ddk_groupnorm_mish_bwd_slabs(const float* x, const float* gamma, const float* beta, float drop_p, uint64_t seed, uint32_t layer,
+                                 const float* dy_slabs, int nslab, long long slab_stride, float* dx, float* part, int B, int HW, int C,
+                                 int groups, float eps, ddk_stream_t s) {
+    DDK_REQUIRE(dy_slabs && part, "groupnorm_bwd_slabs: null pointer");
+    DDK_REQUIRE(nslab >= 2, "groupnorm_bwd_slabs: fewer than two slabs (use ddk_groupnorm_mish_bwd)");
+    return gn_train_launch(true, x, gamma, beta, nullptr, 0, nullptr, drop_p, seed, layer, dy_slabs, dx, part, B, HW, C, groups, eps,
+                           nullptr, 0, as_stream(s), nslab, slab_stride, nullptr, nullptr);
 }
 
 /* out[n] (+)= sum_r rows[r*row_stride + n] */

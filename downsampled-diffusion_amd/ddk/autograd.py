@@ -54,7 +54,38 @@ class GradHandoff:
         return g, g2
 
 
-def _conv_backward(kind, x, x2, weight, bias, dy, needs, gb_ready=False, dmish_src=None, dx_resid=None, dx2_resid=None):
+# The split-K slabs of a conv whose only consumer is a GroupNorm stay unreduced and the GroupNorm sums them while it loads (forward:
+# ConvGNMishFn; backward: SlabLink).  The tests switch this off to compare with the separate reduce launches, bit for bit.
+FOLD_SLABS = True
+
+
+class SlabLink:
+    """Joins the input-gradient conv of one Block to the GroupNorm backward of the Block before it when the tensor between them has
+    exactly that one consumer (h of a ResnetBlock): the conv leaves its split-K partial slabs unreduced, the GroupNorm backward sums
+    them while it loads dy -- one reduce launch less per ResnetBlock.  The tensor autograd carries between the two Functions is
+    then only a placeholder (slab 0); the consumer checks it received that very tensor and fails loudly otherwise."""
+    __slots__ = ("slabs", "placeholder_ptr")
+
+    def __init__(self):
+        self.slabs = None
+        self.placeholder_ptr = 0
+
+    def put(self, slabs):
+        self.slabs, self.placeholder_ptr = slabs, slabs.data_ptr()
+        return slabs[0]
+
+    def take(self, dy):
+        """the slabs that stand for dy, or None when dy is an ordinary tensor"""
+        slabs, self.slabs = self.slabs, None
+        if slabs is None:
+            return None
+        if dy.data_ptr() != self.placeholder_ptr or dy.shape != slabs.shape[1:]:
+            raise RuntimeError("SlabLink: the gradient that reached the GroupNorm backward is not the placeholder its producer returned "
+                               "(the tensor between the two Blocks has a second consumer?)")
+        return slabs
+
+
+def _conv_backward(kind, x, x2, weight, bias, dy, needs, gb_ready=False, dmish_src=None, dx_resid=None, dx2_resid=None, dx_link=None):
     """Shared backward of the conv family.  needs = (x, x2, weight, bias).  Returns (dx, dx2, gw, gb); gw / gb are None
     when they were accumulated straight into ``.grad``.  gb_ready: the bias gradient was already produced elsewhere
     (by the GroupNorm backward that follows the conv).  dmish_src: x is Mish(dmish_src) and dx is wanted with respect to
@@ -102,8 +133,14 @@ def _conv_backward(kind, x, x2, weight, bias, dy, needs, gb_ready=False, dmish_s
             # 3x3 input gradients (also the zero-stuffed stride-2 one) run as Winograd F(2x2,3x3) where the shape allows
             wino = k == ops.CONV3X3_S1 and dmish_src is None
             if need_x:
-                dx = ops.conv(k, src, wd[:c0], n_out=c0, dmish_src=dmish_src, resid=dx_resid,
-                              w_wino=ops.wino_weight(weight, src.shape, 0, min(c0, weight.shape[1]), dgrad=True) if wino and c0 <= weight.shape[1] else None)
+                ww = ops.wino_weight(weight, src.shape, 0, min(c0, weight.shape[1]), dgrad=True) if wino and c0 <= weight.shape[1] else None
+                if (FOLD_SLABS and dx_link is not None and dx_resid is None and dmish_src is None and x2 is None
+                        and ops.gn_train_resident(x.shape[0], x.shape[1] * x.shape[2], c0)):
+                    dx, slabs = ops.conv(k, src, wd[:c0], n_out=c0, w_wino=ww, leave_slabs=True)
+                    if slabs is not None:
+                        dx = dx_link.put(slabs)
+                else:
+                    dx = ops.conv(k, src, wd[:c0], n_out=c0, dmish_src=dmish_src, resid=dx_resid, w_wino=ww)
                 dx_resid = None
             if need_x2:
                 dx2 = ops.conv(k, src, wd[c0:], n_out=c1, resid=dx2_resid,
@@ -224,15 +261,22 @@ class ConvGNMishFn(torch.autograd.Function):
     has in registers) -- no column-sum pass over dY."""
 
     @staticmethod
-    def forward(ctx, x, x2, weight, bias, gamma, beta, temb, addend, drop_p, seed, layer, groups, eps, give=None, take=None):
+    def forward(ctx, x, x2, weight, bias, gamma, beta, temb, addend, drop_p, seed, layer, groups, eps, give=None, take=None, dy_link=None,
+                dx_link=None):
         ctx.give, ctx.take = give, take           # GradHandoff: `give` the addend's gradient away / `take` one into the dgrad epilogue
+        ctx.dy_link, ctx.dx_link = dy_link, dx_link     # SlabLink: this Block's dy arrives as slabs / its dx leaves as slabs
         wu = ops.wino_weight(weight, (x.shape[0], x.shape[1], x.shape[2], x.shape[3] + (0 if x2 is None else x2.shape[3])))
+        # a conv that splits k leaves its partial slabs for the GroupNorm to sum while it loads (which also writes `raw`)
+        fold = FOLD_SLABS and ops.gn_train_resident(x.shape[0], x.shape[1] * x.shape[2], weight.shape[0], groups)
         raw = ops.conv(ops.CONV3X3_S1, x, ops.cached_pack("fwd", weight, ops.pack_conv_weight), bias.detach(),
-                       n_out=weight.shape[0], x2=x2, w_wino=wu)
+                       n_out=weight.shape[0], x2=x2, w_wino=wu, leave_slabs=fold)
+        slabs = None
+        if fold:
+            raw, slabs = raw
         ctx.save_for_backward(x, x2, weight, bias, raw, gamma, beta)
         ctx.cfg = (drop_p, seed, layer, groups, eps, temb is not None, addend is not None)
         return ops.groupnorm_mish_train(raw, gamma.detach(), beta.detach(), temb=temb, addend=addend, drop_p=drop_p, seed=seed,
-                                        layer=layer, groups=groups, eps=eps)
+                                        layer=layer, groups=groups, eps=eps, slabs=slabs, conv_bias=bias.detach())
 
     @staticmethod
     def backward(ctx, dy):
@@ -241,21 +285,27 @@ class ConvGNMishFn(torch.autograd.Function):
         dy = _c(dy)
         need = ctx.needs_input_grad
         acc = (_grad_slot(gamma), _grad_slot(beta), _grad_slot(bias) if need[3] else None)
-        draw, dtemb, sums = ops.groupnorm_mish_bwd(raw, gamma.detach(), beta.detach(), dy, drop_p, seed, layer, groups, eps, acc=acc)
+        dy_slabs = ctx.dy_link.take(dy) if ctx.dy_link is not None else None
+        if dy_slabs is not None and has_add:
+            raise RuntimeError("ConvGNMishFn: a Block with an addend cannot take its output gradient as slabs")
+        draw, dtemb, sums = ops.groupnorm_mish_bwd(raw, gamma.detach(), beta.detach(), dy, drop_p, seed, layer, groups, eps, acc=acc,
+                                                   dy_slabs=dy_slabs)
         r1 = r2 = None
         if ctx.take is not None:
             r1, r2 = ctx.take.take()
-        dx, dx2, gw, _ = _conv_backward(ops.CONV3X3_S1, x, x2, weight, bias, draw, need[0:4], gb_ready=True, dx_resid=r1, dx2_resid=r2)
+        dx, dx2, gw, _ = _conv_backward(ops.CONV3X3_S1, x, x2, weight, bias, draw, need[0:4], gb_ready=True, dx_resid=r1, dx2_resid=r2,
+                                        dx_link=ctx.dx_link)
         gb = sums[2] if need[3] else None
         dadd = dy if has_add else None
         if dadd is not None and ctx.give is not None and ctx.give.give(dadd):
             dadd = None
-        return (dx, dx2, gw, gb, sums[0], sums[1], (dtemb if has_temb else None), dadd, None, None, None, None, None, None, None)
+        return (dx, dx2, gw, gb, sums[0], sums[1], (dtemb if has_temb else None), dadd, None, None, None, None, None, None, None, None, None)
 
 
 def conv_groupnorm_mish(x, weight, bias, gamma, beta, x2=None, temb=None, addend=None, drop_p=0.0, seed=0, layer=0, groups=8, eps=1e-5,
-                        give=None, take=None):
-    return ConvGNMishFn.apply(x, x2, weight, bias, gamma, beta, temb, addend, float(drop_p), int(seed), int(layer), groups, eps, give, take)
+                        give=None, take=None, dy_link=None, dx_link=None):
+    return ConvGNMishFn.apply(x, x2, weight, bias, gamma, beta, temb, addend, float(drop_p), int(seed), int(layer), groups, eps, give, take,
+                              dy_link, dx_link)
 
 
 def groupnorm_mish(x, gamma, beta, temb=None, addend=None, drop_p=0.0, seed=0, layer=0, groups=8, eps=1e-5):

@@ -166,6 +166,9 @@ SIGNATURES = {
     "ddk_dropout_epoch": (_I, [C.c_uint64, _I, _P]),
     "ddk_groupnorm_mish_train_fwd": (_I, [_P, _P, _P, _P, _I, _P, _F, C.c_uint64, C.c_uint32, _P, _I, _I, _I, _I, _F, _P, _SZ, _P]),
     "ddk_groupnorm_mish_bwd": (_I, [_P, _P, _P, _F, C.c_uint64, C.c_uint32, _P, _P, _P, _I, _I, _I, _I, _F, _P, _SZ, _P]),
+    "ddk_groupnorm_mish_train_fwd_slabs": (_I, [_P, _I, _LL, _P, _P, _P, _P, _P, _I, _P, _F, C.c_uint64, C.c_uint32, _P, _I, _I, _I, _I,
+                                                _F, _P]),
+    "ddk_groupnorm_mish_bwd_slabs": (_I, [_P, _P, _P, _F, C.c_uint64, C.c_uint32, _P, _I, _LL, _P, _P, _I, _I, _I, _I, _F, _P]),
     "ddk_rows_sum": (_I, [_P, _I, _LL, _P, _I, _I, _P]),
     "ddk_rows_sum_batched": (_I, [_P, _I, _LL, _I, _LL, _P, _I, _I, _P]),
     "ddk_rows_sum_targets": (_I, [_P, _I, _LL, _I, _LL, _P, _P, _P, _P, _I, _I, _P]),

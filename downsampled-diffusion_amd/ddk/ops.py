@@ -246,10 +246,13 @@ def wino_weight(weight, x_shape, c_lo=None, c_hi=None, dgrad=False):
 
 # ------------------------------------------------------------------ conv family
 def conv(kind, x, w_packed, bias=None, n_out=None, x2=None, resid=None, pre_mish=False, post_mish=False, w_wino=None, mish_out=None,
-         dmish_src=None):
+         dmish_src=None, leave_slabs=False):
     """Implicit-GEMM conv on NHWC x (optionally channel-concatenated with x2 without materialising it).
     w_wino: the same 3x3 filter in the Winograd domain -> the F(2x2,3x3) kernel runs when the shape is eligible.
-    mish_out: tensor that also receives Mish(out); dmish_src: out = (conv + bias) * Mish'(dmish_src) (+ resid) (ddk_conv_args)."""
+    mish_out: tensor that also receives Mish(out); dmish_src: out = (conv + bias) * Mish'(dmish_src) (+ resid) (ddk_conv_args).
+    leave_slabs (plain convs only: no resid / Mish): returns (out, slabs) -- when the launch splits k, `slabs` [S,B,Ho,Wo,N] holds the
+    S >= 2 partial sums WITHOUT the bias and `out` is unwritten (ddk_conv_args.defer_reduce: the GroupNorm that follows sums them
+    while it loads, ops.groupnorm_mish_train / groupnorm_mish_bwd); otherwise slabs is None and `out` is complete."""
     b, h, w_, c0 = x.shape
     c1 = 0 if x2 is None else x2.shape[-1]
     n = n_out if n_out is not None else (w_packed.shape[1] if kind == CONVT4X4_S2 else w_packed.shape[0])
@@ -266,15 +269,25 @@ def conv(kind, x, w_packed, bias=None, n_out=None, x2=None, resid=None, pre_mish
     ws_bytes = lib.ddk_conv_workspace_bytes(kind, b, h, w_, c0 + c1, n)
     if mish_out is not None or dmish_src is not None:
         w_wino = None                                   # these epilogues live on the im2col kernels
+    wsplits = 0
     if w_wino is not None and kind == CONV3X3_S1 and not pre_mish:
         wsplits = lib.ddk_conv_wino_splits(b, h, w_, c0 + c1, n)
         if wsplits > 0:
             ws_bytes = wsplits * out.numel() * 4 if wsplits > 1 else 0
+    nslab = 1
+    if leave_slabs:
+        if resid is not None or pre_mish or post_mish or mish_out is not None or dmish_src is not None:
+            raise L.DDKError("conv(leave_slabs): only for a plain conv (bias is the consumer's to add)")
+        nslab = wsplits if (w_wino is not None and kind == CONV3X3_S1 and wsplits > 0) else lib.ddk_conv_splits(kind, b, h, w_, c0 + c1, n)
+        if nslab > 1 and ws_bytes < nslab * out.numel() * 4:
+            raise L.DDKError("conv(leave_slabs): internal: workspace smaller than the slabs")
     ws = torch.empty(max(ws_bytes, 16) // 4, device=x.device, dtype=torch.float32) if ws_bytes else None
     a = L.ConvArgs(kind, L.ptr(_f32(x)), L.ptr(x2), c0, c1, L.ptr(w_packed), L.ptr(bias), L.ptr(resid), L.ptr(out),
-                   b, h, w_, n, int(pre_mish), int(post_mish), 0, L.ptr(ws), ws_bytes, L.ptr(w_wino), None, 0, L.ptr(mish_out),
-                   L.ptr(dmish_src))
+                   b, h, w_, n, int(pre_mish), int(post_mish), int(leave_slabs and nslab > 1), L.ptr(ws), ws_bytes, L.ptr(w_wino), None, 0,
+                   L.ptr(mish_out), L.ptr(dmish_src))
     L.check(lib.ddk_conv_forward(C.byref(a), L.stream()), "conv_forward")
+    if leave_slabs:
+        return out, (ws[:nslab * out.numel()].view(nslab, b, ho, wo, n) if nslab > 1 else None)
     return out
 
 
@@ -857,11 +870,24 @@ def bias_grad(dy, accumulate_into=None):
     return out
 
 
-def groupnorm_mish_train(x, gamma, beta, temb=None, addend=None, drop_p=0.0, seed=0, layer=0, groups=GN_GROUPS, eps=GN_EPS):
+def gn_train_resident(b, hw, c, groups=GN_GROUPS):
+    """the training GroupNorm keeps a (sample, group) slab in registers (and so takes the slab forms) when this holds"""
+    return L.load().ddk_groupnorm_train_workspace_bytes(b, hw, c, groups) == 0
+
+
+def groupnorm_mish_train(x, gamma, beta, temb=None, addend=None, drop_p=0.0, seed=0, layer=0, groups=GN_GROUPS, eps=GN_EPS, slabs=None,
+                         conv_bias=None):
+    """slabs [S,B,H,W,C] (ops.conv(leave_slabs=True)): x = sum(slabs) + conv_bias is formed while loading and WRITTEN into `x`"""
     b, h, w, c = x.shape
     out = torch.empty_like(x)
     stride = temb.stride(0) if temb is not None else 0
     lib = L.load()
+    if slabs is not None:
+        L.check(lib.ddk_groupnorm_mish_train_fwd_slabs(L.ptr(slabs), slabs.shape[0], slabs.stride(0), L.ptr(conv_bias), L.ptr(x), L.ptr(gamma),
+                                                       L.ptr(beta), temb.data_ptr() if temb is not None else None, stride, L.ptr(addend),
+                                                       float(drop_p), seed, layer, L.ptr(out), b, h * w, c, groups, eps, L.stream()),
+                "groupnorm_mish_train_fwd_slabs")
+        return out
     nbytes = lib.ddk_groupnorm_train_workspace_bytes(b, h * w, c, groups)
     ws = _ws(x.device, nbytes, "gn_train") if nbytes else None
     L.check(lib.ddk_groupnorm_mish_train_fwd(L.ptr(_f32(x)), L.ptr(gamma), L.ptr(beta),
@@ -872,18 +898,24 @@ def groupnorm_mish_train(x, gamma, beta, temb=None, addend=None, drop_p=0.0, see
     return out
 
 
-def groupnorm_mish_bwd(x, gamma, beta, dy, drop_p=0.0, seed=0, layer=0, groups=GN_GROUPS, eps=GN_EPS, acc=None):
+def groupnorm_mish_bwd(x, gamma, beta, dy, drop_p=0.0, seed=0, layer=0, groups=GN_GROUPS, eps=GN_EPS, acc=None, dy_slabs=None):
     """-> dx, dtemb [B,C], sums [3][C] = (dgamma, dbeta, sum over all pixels of dx -- the bias gradient of the conv that
-    produced x).  `acc`: optional (gamma.grad, beta.grad, conv_bias.grad) accumulated into directly (entries may be None)."""
+    produced x).  `acc`: optional (gamma.grad, beta.grad, conv_bias.grad) accumulated into directly (entries may be None).
+    dy_slabs [S,B,H,W,C]: dy = sum(dy_slabs), formed while loading (`dy` itself is not read)."""
     b, h, w, c = x.shape
     dx = torch.empty_like(x)
     part = torch.empty((4, b, c), device=x.device, dtype=torch.float32)
     lib = L.load()
-    nbytes = lib.ddk_groupnorm_train_workspace_bytes(b, h * w, c, groups)
-    ws = _ws(x.device, nbytes, "gn_train") if nbytes else None
-    L.check(lib.ddk_groupnorm_mish_bwd(L.ptr(_f32(x)), L.ptr(gamma), L.ptr(beta), float(drop_p), seed, layer, L.ptr(_f32(dy)),
-                                       L.ptr(dx), L.ptr(part), b, h * w, c, groups, eps, L.ptr(ws), nbytes, L.stream()),
-            "groupnorm_mish_bwd")
+    if dy_slabs is not None:
+        L.check(lib.ddk_groupnorm_mish_bwd_slabs(L.ptr(_f32(x)), L.ptr(gamma), L.ptr(beta), float(drop_p), seed, layer, L.ptr(dy_slabs),
+                                                 dy_slabs.shape[0], dy_slabs.stride(0), L.ptr(dx), L.ptr(part), b, h * w, c, groups, eps,
+                                                 L.stream()), "groupnorm_mish_bwd_slabs")
+    else:
+        nbytes = lib.ddk_groupnorm_train_workspace_bytes(b, h * w, c, groups)
+        ws = _ws(x.device, nbytes, "gn_train") if nbytes else None
+        L.check(lib.ddk_groupnorm_mish_bwd(L.ptr(_f32(x)), L.ptr(gamma), L.ptr(beta), float(drop_p), seed, layer, L.ptr(_f32(dy)),
+                                           L.ptr(dx), L.ptr(part), b, h * w, c, groups, eps, L.ptr(ws), nbytes, L.stream()),
+                "groupnorm_mish_bwd")
     sums = [None, None, None]
     missing = [k for k in range(3) if acc is None or acc[k] is None]
     if acc is not None and any(t is not None for t in acc):

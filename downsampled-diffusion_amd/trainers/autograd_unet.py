@@ -28,11 +28,12 @@ class _Seeds:
         return self.seed, self.layer
 
 
-def _block(blk, x, x2=None, temb=None, addend=None, drop_p=0.0, seeds=None, give=None, take=None):
+def _block(blk, x, x2=None, temb=None, addend=None, drop_p=0.0, seeds=None, give=None, take=None, dy_link=None, dx_link=None):
     conv, norm = blk.block[0], blk.block[1]
     seed, layer = seeds.next() if (seeds is not None and drop_p > 0) else (0, 0)
     return AG.conv_groupnorm_mish(x, conv.weight, conv.bias, norm.weight, norm.bias, x2=x2, temb=temb, addend=addend, drop_p=drop_p,
-                                  seed=seed, layer=layer, groups=blk.groups, eps=norm.eps, give=give, take=take)
+                                  seed=seed, layer=layer, groups=blk.groups, eps=norm.eps, give=give, take=take, dy_link=dy_link,
+                                  dx_link=dx_link)
 
 
 def _resnet(rb, x, temb_slice, x2=None, seeds=None):
@@ -41,11 +42,14 @@ def _resnet(rb, x, temb_slice, x2=None, seeds=None):
     # the gradient of the skip path reaches x (and x2) through Block1's input-gradient conv epilogue, not through an autograd add:
     # identity skip -> Block2 hands its addend gradient over; 1x1 skip -> the skip conv hands its input gradients over
     hand = AG.GradHandoff()
-    h = _block(rb.block1, x, x2=x2, temb=temb_slice, drop_p=p, seeds=seeds, take=hand)
+    # h has one consumer (Block2's conv): its gradient may travel from that conv's input-gradient launch to Block1's GroupNorm
+    # backward as unreduced split-K slabs
+    link = AG.SlabLink()
+    h = _block(rb.block1, x, x2=x2, temb=temb_slice, drop_p=p, seeds=seeds, take=hand, dy_link=link)
     if isinstance(rb.res_conv, nn.Identity):
-        return _block(rb.block2, h, addend=x, give=hand)
+        return _block(rb.block2, h, addend=x, give=hand, dx_link=link)
     res = AG.conv(ops.CONV1X1, x, rb.res_conv.weight, rb.res_conv.bias, x2=x2, handoff=hand)
-    return _block(rb.block2, h, addend=res)
+    return _block(rb.block2, h, addend=res, dx_link=link)
 
 
 def _attention(res_mod, x):

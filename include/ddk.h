@@ -431,6 +431,17 @@ int ddk_groupnorm_mish_train_fwd(const float* x, const float* gamma, const float
 int ddk_groupnorm_mish_bwd(const float* x, const float* gamma, const float* beta, float drop_p, uint64_t seed,
                            uint32_t layer, const float* dy, float* dx, float* part, int B, int HW, int C, int groups,
                            float eps, void* workspace, size_t workspace_bytes, ddk_stream_t s);
+/* round 4: the two above with the tensor they read first still in `nslab` >= 2 split-K slabs of the conv that produced it
+ * (ddk_conv_args.defer_reduce; stride slab_stride floats): the forward takes x = sum of the slabs (in slab order) + conv_bias while
+ * loading and also writes it to raw_out (what the backward reads as x); the backward takes dy = sum of the slabs.  One launch less
+ * per conv.  Only group slabs of the register-resident path (ddk_groupnorm_train_workspace_bytes() == 0). */
+int ddk_groupnorm_mish_train_fwd_slabs(const float* slabs, int nslab, long long slab_stride, const float* conv_bias, float* raw_out,
+                                       const float* gamma, const float* beta, const float* temb, int temb_stride,
+                                       const float* addend, float drop_p, uint64_t seed, uint32_t layer, float* out, int B, int HW,
+                                       int C, int groups, float eps, ddk_stream_t s);
+int ddk_groupnorm_mish_bwd_slabs(const float* x, const float* gamma, const float* beta, float drop_p, uint64_t seed, uint32_t layer,
+                                 const float* dy_slabs, int nslab, long long slab_stride, float* dx, float* part, int B, int HW,
+                                 int C, int groups, float eps, ddk_stream_t s);
 int ddk_rows_sum(const float* rows, int nrows, long long row_stride, float* out, int n, int accumulate, ddk_stream_t s);
 /* out[k][n] (+)= sum_r rows[k*batch_stride + r*row_stride + n], k < nbatch */
 int ddk_rows_sum_batched(const float* rows, int nbatch, long long batch_stride, int nrows, long long row_stride, float* out,

@@ -9,7 +9,7 @@ import contextlib
 import torch
 import torch.nn.functional as F
 
-from helpers import ddpm_cfg, dddpm_cfg, det_load, golden, rel_err, to_nchw, to_nhwc
+from helpers import ddpm_cfg, dddpm_cfg, det_load, golden, rel_err, to_nchw, to_nhwc, unet_cfg
 from oracle import unet_ref as U
 from utils import synthetic as syn
 
@@ -516,3 +516,70 @@ def test_deferred_norm_parameter_gradients_are_bit_identical():
     for ra, rb in zip(a, b):
         for ta, tb in zip(ra, rb):
             assert torch.equal(ta, tb)
+
+
+@pytest.mark.parametrize("B,H,W,C,S", [(4, 16, 16, 128, 2), (64, 2, 2, 256, 8), (3, 8, 8, 256, 4), (2, 32, 32, 128, 3)])
+def test_groupnorm_train_slab_forms_are_bit_identical(B, H, W, C, S):
+    """ddk_groupnorm_mish_train_fwd_slabs / ddk_groupnorm_mish_bwd_slabs: the tensor still in S split-K slabs, summed while loading
+    == the slabs reduced first (slab order, then the conv bias), bit for bit; the forward also writes the reduced tensor."""
+    from ddk import ops
+    g = torch.Generator().manual_seed(5)
+    slabs = torch.randn(S, B, H, W, C, generator=g).to(DEV)
+    bias, gamma, beta = (torch.randn(C, generator=g).to(DEV) for _ in range(3))
+    temb = torch.randn(B, C, generator=g).to(DEV)
+    x = slabs[0].clone()
+    for s_ in range(1, S):
+        x += slabs[s_]
+    x += bias
+    for drop in (0.0, 0.1):
+        y0 = ops.groupnorm_mish_train(x, gamma, beta, temb=temb, drop_p=drop, seed=7, layer=3)
+        raw = torch.empty_like(x)
+        y1 = ops.groupnorm_mish_train(raw, gamma, beta, temb=temb, drop_p=drop, seed=7, layer=3, slabs=slabs, conv_bias=bias)
+        assert torch.equal(raw, x) and torch.equal(y0, y1)
+        dy = slabs[0].clone()
+        for s_ in range(1, S):
+            dy += slabs[s_]
+        dx0, dt0, sums0 = ops.groupnorm_mish_bwd(x, gamma, beta, dy, drop, 7, 3)
+        dx1, dt1, sums1 = ops.groupnorm_mish_bwd(x, gamma, beta, slabs[0], drop, 7, 3, dy_slabs=slabs)
+        assert torch.equal(dx0, dx1) and torch.equal(dt0, dt1)
+        assert all(torch.equal(a, b) for a, b in zip(sums0, sums1))
+    with pytest.raises(Exception):          # a group slab too large for the register-resident kernel has no slab form
+        big = torch.zeros(2, 1, 256, 256, 128, device=DEV)
+        ops.groupnorm_mish_train(torch.empty_like(big[0]), gamma[:128], beta[:128], slabs=big, conv_bias=bias[:128])
+
+
+def test_unet_training_with_slab_folds_is_bit_identical():
+    """One forward + backward of the UNet (cfg3 shape: 16x16 latent, dims (1,2,2,2), batch 16, dropout on) with the split-K slabs
+    summed inside the GroupNorm kernels == with one reduce launch per conv: loss and every gradient bit for bit.  Also: the
+    placeholder check of the backward link."""
+    from ddk import autograd as AG
+    from models import Unet
+    from trainers.autograd_unet import unet_forward_autograd
+    cfg = unet_cfg(128, 8)
+    cfg["unet_dims"] = (1, 2, 2, 2)
+    cfg["unet_dropout"] = 0.1
+    u = det_load(Unet(cfg), "latent_model.").to(DEV).train()
+    x = syn.synthetic_normal((16, 16, 16, 8), "fold.x").to(DEV)
+    t = (torch.arange(16, device=DEV) * 61) % 1000
+    def run(fold):
+        AG.FOLD_SLABS = fold
+        try:
+            for p in u.parameters():
+                p.grad = None
+            torch.manual_seed(3)
+            out = unet_forward_autograd(u, x, t)
+            loss = (out * out).mean()
+            loss.backward()
+            torch.cuda.synchronize()
+            return loss.detach().clone(), [p.grad.clone() for p in u.parameters()]
+        finally:
+            AG.FOLD_SLABS = True
+    l0, g0 = run(False)
+    l1, g1 = run(True)
+    assert torch.equal(l0, l1)
+    for a, b in zip(g0, g1):
+        assert torch.equal(a, b)
+    link = AG.SlabLink()
+    ph = link.put(torch.zeros(2, 1, 4, 4, 32, device=DEV))
+    with pytest.raises(RuntimeError):
+        link.take(ph + 1)                      # not the placeholder: some other gradient was mixed in

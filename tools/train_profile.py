@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""A few optimiser steps of one training config for rocprofv3 --kernel-trace --stats: python tools/train_profile.py [cfg3|cfg2|cfg5]"""
+"""A few optimiser steps of one training config for rocprofv3 --kernel-trace --stats: python tools/train_profile.py [cfg3|cfg2|cfg5] [graph]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(ROOT, "downsampled-diffusion_amd"), ROOT, os.path.join(ROOT, "tools")]
@@ -21,6 +21,16 @@ model = model.to(DEV).train()
 model.load_state_dict(syn.fill_state_dict(model.state_dict(), skip=syn.SCHEDULE_KEYS))
 opt = FusedAdam(model, lr=2e-4)
 x = torch.rand(xshape, device=DEV) * 2 - 1
+if len(sys.argv) > 2 and sys.argv[2] == "graph":      # the captured step the trainers replay (tools/train_breakdown.py reads its trace)
+    from trainers.graph_step import GraphedAccumulation
+    g = GraphedAccumulation(model, 2).capture([x, x])
+    opt.zero_grad()
+    for step in range(6):
+        out = g.replay([x, x])
+        opt.step(); opt.zero_grad()
+    torch.cuda.synchronize()
+    print("done", float(out[-1][0]))
+    sys.exit(0)
 for step in range(4):
     for _ in range(2):
         with ops.deferred_wgrad():          # as the trainers do: the slab reduces of a backward pass in a few launches
