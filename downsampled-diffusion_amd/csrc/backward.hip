@@ -674,77 +674,78 @@ __global__ __launch_bounds__(256) void linattn_dctx_kernel(const float* __restri
     *reinterpret_cast<float4*>(out + (((long long)blockIdx.y * gridDim.x + blockIdx.x) * DHB + d) * DHB + e0) = acc;
 }
 
-// per (pixel, head): dq, dk, dv -> dqkv [B][HW][3*heads*32]
+// per (pixel, head): dq, dk, dv -> dqkv [B][HW][3*heads*32].  A workgroup takes 16 pixels of one sample; 8 lanes share a (pixel, head):
+// lane j of them owns rows d = j + 8r (r < 4) of ctx / dctx in pass 1 and columns e = 4j..4j+3 of dctx in pass 2 (one thread per
+// (pixel, head) walked 3 x 32 x 32 products alone: 24-40 us on the 64-workgroup grids of the small maps at batch 64).  Rows are pitched
+// 36 floats in LDS so that the 8 lanes' float4 reads of 8 different rows fall into different banks.  Same sums in the same order.
 __global__ __launch_bounds__(256) void linattn_bwd_apply_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
                                                                 const float* __restrict__ ctx, const float* __restrict__ dctx,
                                                                 const float* __restrict__ stats, float* __restrict__ dqkv, int HW,
                                                                 int heads, int tiles_per_sample) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    constexpr int HP = DHB * DHB + 4;
-    float* cs = sm;                      // ctx   [heads][HP]
-    float* dcs = sm + heads * HP;        // dctx  [heads][HP]
+    constexpr int RP = DHB + 4, HP = DHB * RP;
+    float* cs = sm;                      // ctx   [heads][32][RP]
+    float* dcs = sm + heads * HP;        // dctx  [heads][32][RP]
     float* S = sm + 2 * heads * HP;      // [heads][32]
     const int b = blockIdx.x / tiles_per_sample, tile = blockIdx.x % tiles_per_sample;
     const int HC = heads * DHB, RS = 3 * HC, nthreads = 64 * heads;
     for (int i = threadIdx.x; i < heads * DHB * DHB / 4; i += nthreads) {
         const int hh = (i * 4) / (DHB * DHB), r = (i * 4) % (DHB * DHB);
-        *reinterpret_cast<float4*>(cs + hh * HP + r) = *reinterpret_cast<const float4*>(ctx + ((long long)b * heads + hh) * DHB * DHB + r);
-        *reinterpret_cast<float4*>(dcs + hh * HP + r) = *reinterpret_cast<const float4*>(dctx + ((long long)b * heads + hh) * DHB * DHB + r);
+        const int o = hh * HP + (r / DHB) * RP + (r % DHB);
+        *reinterpret_cast<float4*>(cs + o) = *reinterpret_cast<const float4*>(ctx + ((long long)b * heads + hh) * DHB * DHB + r);
+        *reinterpret_cast<float4*>(dcs + o) = *reinterpret_cast<const float4*>(dctx + ((long long)b * heads + hh) * DHB * DHB + r);
     }
     __syncthreads();
     for (int i = threadIdx.x; i < heads * DHB; i += nthreads) {
         const int hh = i / DHB, d = i % DHB;
         float t = 0.f;
-        for (int e = 0; e < DHB; ++e) t += dcs[hh * HP + d * DHB + e] * cs[hh * HP + d * DHB + e];
+        for (int e = 0; e < DHB; ++e) t += dcs[hh * HP + d * RP + e] * cs[hh * HP + d * RP + e];
         S[i] = t;
     }
     __syncthreads();
-    const int h = threadIdx.x % heads, pl = threadIdx.x / heads;
-    const int n = tile * 64 + pl;
-    if (n >= HW) return;
-    const float* base = qkv + ((long long)b * HW + n) * RS;
-    const float* dop = dout + ((long long)b * HW + n) * HC + h * DHB;
+    const int lane = threadIdx.x & 63, j = threadIdx.x & 7, h = (threadIdx.x >> 3) % heads;
     const float* st = stats + ((long long)b * heads + h) * 2 * DHB;
     const float* ch = cs + h * HP;
     const float* dch = dcs + h * HP;
-    float* outp = dqkv + ((long long)b * HW + n) * RS;
-    float ks[DHB];
-    {   // pass 1 (over d): dq[d] = dout . ctx[d][:],  dks[d] = v . dctx[d][:],  dk[d] = ks[d] (dks[d] - S[d])
-        float dO[DHB], vv[DHB];
+    for (int pl = threadIdx.x / (8 * heads); pl < 16; pl += 8) {
+        const int n = tile * 16 + pl;
+        if (n >= HW) break;
+        const float* base = qkv + ((long long)b * HW + n) * RS;
+        const float* dop = dout + ((long long)b * HW + n) * HC + h * DHB;
+        float* outp = dqkv + ((long long)b * HW + n) * RS;
+        float dO[DHB], vv[DHB], ksl[4];
 #pragma unroll
         for (int i = 0; i < DHB / 4; ++i) {
             const float4 a = *reinterpret_cast<const float4*>(dop + i * 4);
-            const float4 k4 = *reinterpret_cast<const float4*>(base + HC + h * DHB + i * 4);
             const float4 v4 = *reinterpret_cast<const float4*>(base + 2 * HC + h * DHB + i * 4);
             dO[4 * i] = a.x; dO[4 * i + 1] = a.y; dO[4 * i + 2] = a.z; dO[4 * i + 3] = a.w;
-            ks[4 * i] = k4.x; ks[4 * i + 1] = k4.y; ks[4 * i + 2] = k4.z; ks[4 * i + 3] = k4.w;
             vv[4 * i] = v4.x; vv[4 * i + 1] = v4.y; vv[4 * i + 2] = v4.z; vv[4 * i + 3] = v4.w;
         }
+        // pass 1 (rows d): dq[d] = dout . ctx[d][:],  dks[d] = v . dctx[d][:],  dk[d] = ks[d] (dks[d] - S[d])
 #pragma unroll
-        for (int d = 0; d < DHB; ++d) {
+        for (int r = 0; r < 4; ++r) {
+            const int d = j + 8 * r;
             float dq = 0.f, dks = 0.f;
-            ks[d] = expf(ks[d] - st[d]) / st[DHB + d];
+            ksl[r] = expf(base[HC + h * DHB + d] - st[d]) / st[DHB + d];
 #pragma unroll
             for (int i = 0; i < DHB / 4; ++i) {
-                const float4 c4 = *reinterpret_cast<const float4*>(ch + d * DHB + i * 4);
-                const float4 g4 = *reinterpret_cast<const float4*>(dch + d * DHB + i * 4);
+                const float4 c4 = *reinterpret_cast<const float4*>(ch + d * RP + i * 4);
+                const float4 g4 = *reinterpret_cast<const float4*>(dch + d * RP + i * 4);
                 dq += (dO[4 * i] * c4.x + dO[4 * i + 1] * c4.y) + (dO[4 * i + 2] * c4.z + dO[4 * i + 3] * c4.w);
                 dks += (vv[4 * i] * g4.x + vv[4 * i + 1] * g4.y) + (vv[4 * i + 2] * g4.z + vv[4 * i + 3] * g4.w);
             }
             outp[h * DHB + d] = dq;
-            outp[HC + h * DHB + d] = ks[d] * (dks - S[h * DHB + d]);
+            outp[HC + h * DHB + d] = ksl[r] * (dks - S[h * DHB + d]);
         }
-    }
-    // pass 2 (over e): dv[e] = sum_d ks[d] dctx[d][e]
-#pragma unroll
-    for (int i = 0; i < DHB / 4; ++i) {
+        // pass 2 (columns e = 4j..4j+3): dv[e] = sum_d ks[d] dctx[d][e]; ks[d] lives in lane (d & 7) of this lane's group of 8
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int d = 0; d < DHB; ++d) {
-            const float4 g4 = *reinterpret_cast<const float4*>(dch + d * DHB + i * 4);
-            acc.x += ks[d] * g4.x; acc.y += ks[d] * g4.y; acc.z += ks[d] * g4.z; acc.w += ks[d] * g4.w;
+            const float kd = __shfl(ksl[d >> 3], (lane & ~7) | (d & 7), 64);
+            const float4 g4 = *reinterpret_cast<const float4*>(dch + d * RP + j * 4);
+            acc.x += kd * g4.x; acc.y += kd * g4.y; acc.z += kd * g4.z; acc.w += kd * g4.w;
         }
-        *reinterpret_cast<float4*>(outp + 2 * HC + h * DHB + i * 4) = acc;
+        *reinterpret_cast<float4*>(outp + 2 * HC + h * DHB + j * 4) = acc;
     }
 }
 
@@ -830,33 +831,47 @@ __global__ __launch_bounds__(256) void conv1x1_small_n_bwd_kernel(const float* _
         for (int i = 0; i < VPL; ++i) dw[co][i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     const long long waves_total = (long long)gridDim.x * 4;
-    for (long long wv = blockIdx.x * 4LL + wid;; wv += waves_total) {
-        const long long pix0 = wv * PPW;
-        if (pix0 >= M) break;
-        const long long pix = pix0 + lane / LPP;
-        const bool ok = pix < M;
-        float4 av[VPL], r[VPL];
+    // four pixel groups per trip, their loads issued together: a wave walks 64 groups of the 64x64x64-pixel decoder output with nothing
+    // else on its SIMD to hide a load behind (70 us with one group per trip).  Same accumulation order.
+    constexpr int UNR = 4;
+    for (long long wv0 = blockIdx.x * 4LL + wid;; wv0 += waves_total * UNR) {
+        if (wv0 * PPW >= M) break;
+        float4 av[UNR][VPL];
+        float g[UNR][NOUT_MAX];
+        long long pix[UNR];
 #pragma unroll
-        for (int i = 0; i < VPL; ++i) {
-            av[i] = ok ? *reinterpret_cast<const float4*>(a + pix * C + (sub + i * LPP) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-            r[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int u = 0; u < UNR; ++u) {
+            pix[u] = (wv0 + u * waves_total) * PPW + lane / LPP;
+            const bool ok = pix[u] < M;
+#pragma unroll
+            for (int i = 0; i < VPL; ++i)
+                av[u][i] = ok ? *reinterpret_cast<const float4*>(a + pix[u] * C + (sub + i * LPP) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int co = 0; co < NOUT_MAX; ++co) g[u][co] = (ok && co < n_out) ? dy[pix[u] * n_out + co] : 0.f;
         }
 #pragma unroll
-        for (int co = 0; co < NOUT_MAX; ++co) {
-            if (co < n_out) {
-                const float g = ok ? dy[pix * n_out + co] : 0.f;
-                if (sub == 0) dbv[co] += g;
+        for (int u = 0; u < UNR; ++u) {
+            float4 r[VPL];
 #pragma unroll
-                for (int i = 0; i < VPL; ++i) {
-                    const float4 ww = *reinterpret_cast<const float4*>(w + (long long)co * C + (sub + i * LPP) * 4);
-                    r[i].x += g * ww.x; r[i].y += g * ww.y; r[i].z += g * ww.z; r[i].w += g * ww.w;
-                    dw[co][i].x += g * av[i].x; dw[co][i].y += g * av[i].y; dw[co][i].z += g * av[i].z; dw[co][i].w += g * av[i].w;
+            for (int i = 0; i < VPL; ++i) r[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int co = 0; co < NOUT_MAX; ++co) {
+                if (co < n_out) {
+                    const float gg = g[u][co];
+                    if (sub == 0) dbv[co] += gg;
+#pragma unroll
+                    for (int i = 0; i < VPL; ++i) {
+                        const float4 ww = *reinterpret_cast<const float4*>(w + (long long)co * C + (sub + i * LPP) * 4);
+                        r[i].x += gg * ww.x; r[i].y += gg * ww.y; r[i].z += gg * ww.z; r[i].w += gg * ww.w;
+                        dw[co][i].x += gg * av[u][i].x; dw[co][i].y += gg * av[u][i].y; dw[co][i].z += gg * av[u][i].z;
+                        dw[co][i].w += gg * av[u][i].w;
+                    }
                 }
             }
-        }
-        if (ok)
+            if (pix[u] < M)
 #pragma unroll
-            for (int i = 0; i < VPL; ++i) *reinterpret_cast<float4*>(da + pix * C + (sub + i * LPP) * 4) = r[i];
+                for (int i = 0; i < VPL; ++i) *reinterpret_cast<float4*>(da + pix[u] * C + (sub + i * LPP) * 4) = r[i];
+        }
     }
     // fold the PPW pixel slots of the wave by xor shuffles over lane bits >= log2(LPP); one partial row per wave
     const int row = blockIdx.x * 4 + wid;
@@ -1291,8 +1306,8 @@ int ddk_linattn_bwd(const float* qkv, const float* dout, const float* ctx, const
                            (long long)n, 0LL, dctx, n, 0);
         DDK_TRY(check_launch("rows_sum_kernel"));
     }
-    const int tiles = (int)ceil_div(HW, 64);
-    const size_t lds = ((size_t)2 * heads * (DHB * DHB + 4) + heads * DHB) * sizeof(float);
+    const int tiles = (int)ceil_div(HW, 16);
+    const size_t lds = ((size_t)2 * heads * DHB * (DHB + 4) + heads * DHB) * sizeof(float);
     hipLaunchKernelGGL(linattn_bwd_apply_kernel, dim3(B * tiles), dim3(64 * heads), lds, st, qkv, dout, ctx, dctx, stats, dqkv, HW, heads,
                        tiles);
     return check_launch("linattn_bwd_apply_kernel");
@@ -1367,9 +1382,11 @@ int ddk_conv1x1_small_n_bwd(const float* a, const float* w, const float* dy, flo
 /* C = op(A) op(B) for the tiny time-embedding matrices; see small_gemm_kernel for the modes */
 static int small_gemm_splits(int M, int N, int K, int ldc) {
     const long long tiles = ceil_div(N, 32) * ceil_div(M, 32);
-    if (ldc != N || tiles >= 128 || K < 1024) return 1;
+    // a workgroup walks its k range 32 at a time with the load latency exposed (nothing else runs on its CU): ~3.8 us per step on the
+    // 4 x 2 tiles of the [64][512] x [512][128] product of the time MLP (62 us); from K = 256 on the range is cut into pieces of >= 64
+    if (ldc != N || tiles >= 128 || K < 256) return 1;
     long long s = ceil_div(256, tiles);
-    if (s > K / 256) s = K / 256;
+    if (s > K / 64) s = K / 64;
     return (int)(s < 1 ? 1 : (s > 64 ? 64 : s));
 }
 size_t ddk_small_gemm_workspace_bytes(int M, int N, int K, int ldc) {
