@@ -1422,6 +1422,12 @@ int conv_forward(const ddk_conv_args& a, hipStream_t st, const ConvLnFold* ln, c
         // 1x1 conv on a small map (to_out, res_conv, to_qkv with the LayerNorm folded, at 4x4 / 8x8): 32x32 tiles, the waves split K,
         // one barrier (conv1x1_sm.hip)
         return conv1x1_sm(a.src0, a.c0, a.src1, a.c1, a.weight, a.bias, a.resid, a.out, (long long)a.B * a.H * a.W, a.N, ln, st);
+    if (a.kind == DDK_CONV1X1 && a.c1 == 0 && !a.defer_reduce && !a.gn_partials && !fuse && !ln && !tuning_flag("DDK_NO_CONV1X1_STREAM") &&
+        conv1x1_stream_ok((long long)a.B * a.H * a.W, a.c0, a.N))
+        // 32 / 64 channels on both sides of a large map (the encoder / decoder blocks of the dDDPM and their input-gradient convs): a
+        // memory stream -- weights in registers, no LDS, float4 epilogue (conv1x1_stream.hip)
+        return conv1x1_stream(a.src0, a.c0, a.weight, a.bias, a.dmish_src, a.resid, a.out, a.mish_out, (long long)a.B * a.H * a.W, a.N,
+                              a.pre_mish, a.post_mish, st);
     DDK_REQUIRE(!a.gn_partials, "conv: gn_partials is only produced by the Winograd path (weight_wino given, ddk_conv_gn_partials() > 0)");
     DDK_REQUIRE(!fuse, "conv: the in-launch GroupNorm exists on the Winograd path only");
     IgemmParams p{};

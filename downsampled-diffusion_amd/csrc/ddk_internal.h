@@ -192,6 +192,10 @@ bool conv1x1_sm_ok(long long M, int c0, int c1, int N);
 int conv1x1_sm(const float* src0, int c0, const float* src1, int c1, const float* w, const float* bias, const float* resid, float* out,
                long long M, int N, const ConvLnFold* ln, hipStream_t st);
 int conv1x1_sm_init_device();
+// conv1x1_stream.hip: 1x1 conv between 32 / 64-channel tensors on large maps as a memory stream (weights in registers, no LDS)
+bool conv1x1_stream_ok(long long M, int cin, int N);
+int conv1x1_stream(const float* x, int cin, const float* w, const float* bias, const float* dmish_src, const float* resid, float* out,
+                   float* mish_out, long long M, int N, int pre_mish, int post_mish, hipStream_t st);
 bool conv1x1_ws_ok(long long M, int K, int N);
 // images > 0: PER-IMAGE weights -- w is [images][128][128], the LayerNorm vectors [images][128], N == 128, M / images pixels per image
 int conv1x1_ws(const float* x, const float* w, const float* bias, const float* resid, float* out, long long M, int N, const ConvLnFold* ln,

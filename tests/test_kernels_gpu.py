@@ -390,6 +390,43 @@ def test_conv1x1_small_maps(ops, B, H, W, c0, c1, N):
     assert torch.equal(out, ops.conv(ops.CONV1X1, x0, wp, b.to(DEV), x2=x1))
 
 
+STREAM_CASES = [  # B, H, W, cin, N: 1x1 convs between 32 / 64-channel tensors on >= 16384 pixels -> conv1x1_stream_kernel
+    (16, 32, 32, 64, 32),     # c1 of an encoder block at 32x32
+    (16, 32, 32, 32, 64),     # c4
+    (4, 64, 64, 64, 64),
+    (8, 64, 64, 32, 32),
+    (1, 128, 130, 64, 32),    # 1040 tiles: the last round of the grid-stride walk is ragged
+    (64, 16, 16, 3, 64),      # first 1x1 of the encoder: 3 input channels padded to 32
+]
+
+
+@pytest.mark.parametrize("B,H,W,cin,N", STREAM_CASES)
+def test_conv1x1_stream(ops, B, H, W, cin, N):
+    """conv1x1_stream.hip (weights in registers, no LDS, float4 epilogue): every epilogue of ddk_conv_args against torch"""
+    x = rnd(B, cin, H, W, seed=51)
+    w = rnd(N, cin, 1, 1, seed=52, scale=cin ** -0.5)
+    b = rnd(N, seed=53, scale=0.1)
+    res = rnd(B, N, H, W, seed=54)
+    src = rnd(B, N, H, W, seed=55)
+    cp = ops.pad32(cin)
+    xd = ops.nchw_to_nhwc(x.to(DEV), cp)
+    wp = ops.pack_conv_weight(w.to(DEV))
+    bd, rd, sd = b.to(DEV), to_nhwc(res).to(DEV), to_nhwc(src).to(DEV)
+    ref = F.conv2d(x, w, b)
+    assert rel_err(to_nchw(ops.conv(ops.CONV1X1, xd, wp, bd).cpu()), ref) < 2e-5
+    assert rel_err(to_nchw(ops.conv(ops.CONV1X1, xd, wp, None, resid=rd).cpu()), F.conv2d(x, w) + res) < 2e-5
+    pm = ops.conv(ops.CONV1X1, xd, wp, bd, pre_mish=True, post_mish=True)
+    assert rel_err(to_nchw(pm.cpu()), F.mish(F.conv2d(F.mish(x), w, b))) < 2e-5
+    a_out = torch.empty(B, H, W, N, device=DEV)
+    h = ops.conv(ops.CONV1X1, xd, wp, bd, mish_out=a_out)
+    assert rel_err(to_nchw(h.cpu()), ref) < 2e-5 and rel_err(to_nchw(a_out.cpu()), F.mish(ref)) < 2e-5
+    sg = src.clone().requires_grad_(True)
+    F.mish(sg).sum().backward()                     # sg.grad = Mish'(src)
+    dg = ops.conv(ops.CONV1X1, xd, wp, bd, dmish_src=sd, resid=rd)
+    assert rel_err(to_nchw(dg.cpu()), ref * sg.grad + res) < 2e-5
+    assert torch.equal(dg, ops.conv(ops.CONV1X1, xd, wp, bd, dmish_src=sd, resid=rd))
+
+
 def test_conv_small_cin_padding(ops):
     """C_in in {1,3,8}: channels zero-padded to 32 on both operands (first UNet conv / res_conv)."""
     for cin in (1, 3, 8):
