@@ -88,6 +88,7 @@ __global__ __launch_bounds__(NT) void gn_train_kernel(const float* __restrict__ 
     const long long base = (long long)b * HW * C + g * cpg;
 
     float4 v[VPT];
+    float4 gin[BWD ? VPT : 1];       // backward: dy, requested together with x (one memory round trip, not two)
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < VPT; ++i) {
@@ -96,6 +97,10 @@ __global__ __launch_bounds__(NT) void gn_train_kernel(const float* __restrict__ 
             const int row = div_upr(u, upr), cu = u - row * upr;
             const long long o = base + (long long)row * C + cu * 4;
             v[i] = *reinterpret_cast<const float4*>(x + o);
+            if (BWD) {
+                gin[i] = *reinterpret_cast<const float4*>(dy + o);
+                if (nslab > 1) add_slabs(gin[i], dy + o, nslab, slab_stride);
+            }
             if (!BWD && nslab > 1) {
                 add_slabs(v[i], x + o, nslab, slab_stride);
                 if (conv_bias) {
@@ -166,8 +171,7 @@ __global__ __launch_bounds__(NT) void gn_train_kernel(const float* __restrict__ 
         if (u < units) {
             const int row = div_upr(u, upr);
             const long long o = base + (long long)row * C + cu_t * 4;
-            float4 g1 = *reinterpret_cast<const float4*>(dy + o);
-            if (nslab > 1) add_slabs(g1, dy + o, nslab, slab_stride);
+            float4 g1 = gin[BWD ? i : 0];
             if (drop_p > 0.f) {
                 const float4 m = dropout_scale4(o >> 2, drop_p, seed, layer);
                 g1.x *= m.x; g1.y *= m.y; g1.z *= m.z; g1.w *= m.w;
@@ -512,7 +516,7 @@ template <int LPP, int VPL>
 __global__ __launch_bounds__(256) void chan_layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ g,
                                                                  const float* __restrict__ dy, float* __restrict__ dx,
                                                                  float* __restrict__ part /* [2][gridDim][C] */, long long M, int C,
-                                                                 float eps) {
+                                                                 float eps, const float* __restrict__ addend /* optional: dx += addend */) {
     constexpr int PPW = 64 / LPP;
     __shared__ float acc_s[4][64][VPL * 8];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, sub = lane % LPP;
@@ -567,6 +571,10 @@ __global__ __launch_bounds__(256) void chan_layernorm_bwd_kernel(const float* __
                 r.y = d4[i].y * ga[i].y * inv_s - k1 - v[i].y * k2;
                 r.z = d4[i].z * ga[i].z * inv_s - k1 - v[i].z * k2;
                 r.w = d4[i].w * ga[i].w * inv_s - k1 - v[i].w * k2;
+                if (addend) {
+                    const float4 ad = *reinterpret_cast<const float4*>(addend + pix * C + (sub + i * LPP) * 4);
+                    r.x += ad.x; r.y += ad.y; r.z += ad.z; r.w += ad.w;
+                }
                 *reinterpret_cast<float4*>(dx + pix * C + (sub + i * LPP) * 4) = r;
                 sgm[i].x += d4[i].x * v[i].x * inv_s; sgm[i].y += d4[i].y * v[i].y * inv_s;
                 sgm[i].z += d4[i].z * v[i].z * inv_s; sgm[i].w += d4[i].w * v[i].w * inv_s;
@@ -1235,8 +1243,14 @@ int ddk_multi_add(const float* src, const long long* table, int nseg, long long 
 /* Channel LayerNorm backward: dx and partial rows part[2][nparts][C] (dg, db); returns nparts via *nparts_out. */
 int ddk_chan_layernorm_bwd(const float* x, const float* g, const float* dy, float* dx, float* part, int max_parts, int* nparts_out,
                            long long M, int C, float eps, ddk_stream_t s) {
+    return ddk_chan_layernorm_bwd_add(x, g, dy, nullptr, dx, part, max_parts, nparts_out, M, C, eps, s);
+}
+
+/* the same with dx += addend (the gradient that reaches x over the Residual around PreNorm, blocks.py:13-14: no separate add launch) */
+int ddk_chan_layernorm_bwd_add(const float* x, const float* g, const float* dy, const float* addend, float* dx, float* part, int max_parts,
+                               int* nparts_out, long long M, int C, float eps, ddk_stream_t s) {
     DDK_REQUIRE(x && g && dy && dx && part && nparts_out && M > 0 && max_parts > 0, "layernorm_bwd: arguments");
-    DDK_REQUIRE(aligned16(x) && aligned16(g) && aligned16(dy) && aligned16(dx), "layernorm_bwd: alignment");
+    DDK_REQUIRE(aligned16(x) && aligned16(g) && aligned16(dy) && aligned16(dx) && (!addend || aligned16(addend)), "layernorm_bwd: alignment");
     hipStream_t st = as_stream(s);
 #define LB(LPP, VPL)                                                                                                     \
     do {                                                                                                                 \
@@ -1244,7 +1258,7 @@ int ddk_chan_layernorm_bwd(const float* x, const float* g, const float* dy, floa
         if (blocks > max_parts) blocks = max_parts;                                                                      \
         if (blocks > 512) blocks = 512;                                                                                  \
         *nparts_out = (int)blocks;                                                                                       \
-        hipLaunchKernelGGL((chan_layernorm_bwd_kernel<LPP, VPL>), dim3((unsigned)blocks), dim3(256), 0, st, x, g, dy, dx, part, M, C, eps); \
+        hipLaunchKernelGGL((chan_layernorm_bwd_kernel<LPP, VPL>), dim3((unsigned)blocks), dim3(256), 0, st, x, g, dy, dx, part, M, C, eps, addend); \
         return check_launch("chan_layernorm_bwd_kernel");                                                                \
     } while (0)
     switch (C) {

@@ -157,8 +157,9 @@ class ConvFn(torch.autograd.Function):
     """conv family on NHWC x (optionally channel-concatenated with x2), canonical (OIHW / (I,O,4,4)) weight."""
 
     @staticmethod
-    def forward(ctx, kind, x, x2, weight, bias, resid, handoff=None):
+    def forward(ctx, kind, x, x2, weight, bias, resid, handoff=None, resid_handoff=None):
         ctx.handoff = handoff
+        ctx.resid_handoff = resid_handoff     # GradHandoff that takes the residual's gradient (dy itself) to another Function's kernel
         if kind == ops.CONVT4X4_S2:
             wp = ops.cached_pack("fwdT", weight, ops.pack_convT_weight)
             n = weight.shape[1]
@@ -181,11 +182,14 @@ class ConvFn(torch.autograd.Function):
         dx, dx2, gw, gb = _conv_backward(ctx.kind, x, x2, weight, bias, dy, ctx.needs_input_grad[1:5])
         if ctx.handoff is not None and ctx.handoff.give(dx, dx2):       # the skip conv of a ResnetBlock: Block1's dgrad conv adds these
             dx = dx2 = None
-        return None, dx, dx2, gw, gb, (dy if ctx.has_resid else None), None
+        dres = dy if ctx.has_resid else None
+        if dres is not None and ctx.resid_handoff is not None and ctx.resid_handoff.give(dres):
+            dres = None
+        return None, dx, dx2, gw, gb, dres, None, None
 
 
-def conv(kind, x, weight, bias=None, x2=None, resid=None, handoff=None):
-    return ConvFn.apply(kind, x, x2, weight, bias, resid, handoff)
+def conv(kind, x, weight, bias=None, x2=None, resid=None, handoff=None, resid_handoff=None):
+    return ConvFn.apply(kind, x, x2, weight, bias, resid, handoff, resid_handoff)
 
 
 class PreActConvFn(torch.autograd.Function):
@@ -314,19 +318,22 @@ def groupnorm_mish(x, gamma, beta, temb=None, addend=None, drop_p=0.0, seed=0, l
 
 class ChanLayerNormFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, g, b, eps):
+    def forward(ctx, x, g, b, eps, take=None):
         ctx.save_for_backward(x, g, b)
         ctx.eps = eps
+        ctx.take = take               # GradHandoff: the gradient that reaches x over the Residual around this PreNorm, added by the kernel
         return ops.chan_layernorm(x, g.detach(), b.detach(), eps)
 
     @staticmethod
     def backward(ctx, dy):
         x, g, b = ctx.saved_tensors
         sg, sb = _grad_slot(g), _grad_slot(b)
-        dx, dg, db = ops.chan_layernorm_bwd(x, g.detach(), _c(dy), ctx.eps, acc=(sg, sb) if sg is not None and sb is not None else None)
+        extra = ctx.take.take()[0] if ctx.take is not None else None
+        dx, dg, db = ops.chan_layernorm_bwd(x, g.detach(), _c(dy), ctx.eps, acc=(sg, sb) if sg is not None and sb is not None else None,
+                                            addend=extra)
         if dg is None:
-            return dx, None, None, None
-        return dx, dg.reshape(g.shape), db.reshape(g.shape), None
+            return dx, None, None, None, None
+        return dx, dg.reshape(g.shape), db.reshape(g.shape), None, None
 
 
 class LinAttnFn(torch.autograd.Function):

@@ -955,8 +955,9 @@ def multi_add_(src, segments):
     L.check(L.load().ddk_multi_add(L.ptr(src), tab.data_ptr(), len(segments), max(d.numel() for _, d in segments), L.stream()), "multi_add")
 
 
-def chan_layernorm_bwd(x, g, dy, eps=LN_EPS, acc=None):
-    """acc = (g.grad slot, b.grad slot): the row sums are ADDED into them (one launch) and (dx, None, None) is returned"""
+def chan_layernorm_bwd(x, g, dy, eps=LN_EPS, acc=None, addend=None):
+    """acc = (g.grad slot, b.grad slot): the row sums are ADDED into them (one launch) and (dx, None, None) is returned;
+    addend: added to dx by the same launch"""
     c = x.shape[-1]
     m = x.numel() // c
     dx = torch.empty_like(x)
@@ -964,8 +965,8 @@ def chan_layernorm_bwd(x, g, dy, eps=LN_EPS, acc=None):
     part = torch.empty((2, max_parts, c), device=x.device, dtype=torch.float32)
     n = C.c_int(0)
     lib = L.load()
-    L.check(lib.ddk_chan_layernorm_bwd(L.ptr(_f32(x)), L.ptr(g.reshape(-1)), L.ptr(_f32(dy)), L.ptr(dx), L.ptr(part), max_parts,
-                                       C.byref(n), m, c, eps, L.stream()), "chan_layernorm_bwd")
+    L.check(lib.ddk_chan_layernorm_bwd_add(L.ptr(_f32(x)), L.ptr(g.reshape(-1)), L.ptr(_f32(dy)), L.ptr(addend), L.ptr(dx), L.ptr(part),
+                                           max_parts, C.byref(n), m, c, eps, L.stream()), "chan_layernorm_bwd")
     # the kernel laid the rows out as [2][nparts][C] with nparts = n.value
     if acc is not None and acc[0] is not None and acc[1] is not None:
         _rows_sum_targets(part, 2, n.value * c, n.value, c, [acc[0], acc[1]], c)

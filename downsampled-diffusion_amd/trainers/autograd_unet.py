@@ -56,10 +56,11 @@ def _attention(res_mod, x):
     """Residual(PreNorm(LinearAttention)): blocks.py:8-14,63-71,126-134"""
     pre = res_mod.fn
     att = pre.fn
-    xn = AG.ChanLayerNormFn.apply(x, pre.norm.g, pre.norm.b, pre.norm.eps)
+    hand = AG.GradHandoff()        # the Residual's gradient reaches x inside the LayerNorm backward kernel, not through an autograd add
+    xn = AG.ChanLayerNormFn.apply(x, pre.norm.g, pre.norm.b, pre.norm.eps, hand)
     qkv = AG.conv(ops.CONV1X1, xn, att.to_qkv.weight)
     o = AG.LinAttnFn.apply(qkv, att.heads)
-    return AG.conv(ops.CONV1X1, o, att.to_out.weight, att.to_out.bias, resid=x)
+    return AG.conv(ops.CONV1X1, o, att.to_out.weight, att.to_out.bias, resid=x, resid_handoff=hand)
 
 
 def _resnet_blocks(unet):

@@ -504,6 +504,9 @@ long long ddk_pack_jobs_layout(ddk_pack_job* jobs_host, int n);
 int ddk_pack_jobs(const ddk_pack_job* jobs_dev, int n, long long blocks, ddk_stream_t s);
 int ddk_chan_layernorm_bwd(const float* x, const float* g, const float* dy, float* dx, float* part, int max_parts,
                            int* nparts_out, long long M, int C, float eps, ddk_stream_t s);
+/* round 4: the same with dx += addend -- the gradient that reaches x over the Residual around the PreNorm (blocks.py:13-14) */
+int ddk_chan_layernorm_bwd_add(const float* x, const float* g, const float* dy, const float* addend, float* dx, float* part,
+                               int max_parts, int* nparts_out, long long M, int C, float eps, ddk_stream_t s);
 /* training-path linear attention: softmax statistics of k (column max, sum of exp) and the backward.  Their reductions over the
  * pixels are split over workgroups on large maps; `workspace` holds the partials (ddk_linattn_train_workspace_bytes, may be 0). */
 size_t ddk_linattn_train_workspace_bytes(int B, int HW, int heads);

@@ -223,6 +223,12 @@ def test_chan_layernorm_backward(AG, C):
     out.backward(to_nhwc(go).to(DEV))
     assert rel_err(xd.grad.cpu(), to_nhwc(gx)) < 3e-5
     assert rel_err(gd.grad.cpu(), gg) < 3e-5 and rel_err(bd.grad.cpu(), gb) < 3e-5
+    # ddk_chan_layernorm_bwd_add: the Residual's gradient added by the same launch == a separate add, bit for bit
+    from ddk import ops
+    dy, extra = to_nhwc(go).to(DEV), to_nhwc(rnd(3, C, 6, 5, seed=33)).to(DEV)
+    dx0, _, _ = ops.chan_layernorm_bwd(xd.detach(), gd.detach(), dy)
+    dx1, _, _ = ops.chan_layernorm_bwd(xd.detach(), gd.detach(), dy, addend=extra)
+    assert torch.equal(dx1, dx0 + extra)
 
 
 @pytest.mark.parametrize("B,H,W", [(2, 4, 4), (3, 8, 8), (2, 16, 16), (1, 10, 13),
