@@ -1319,7 +1319,8 @@ bool conv_ln_fold_ok(int B, int H, int W, int cin, int N) {
 int conv_forward(const ddk_conv_args& a, hipStream_t st, const ConvLnFold* ln, const WinoGnFuse* fuse) {
     Geometry g;
     DDK_REQUIRE(conv_geometry(a.kind, a.H, a.W, g), "conv kind");
-    DDK_REQUIRE(a.src0 && a.weight && a.out, "conv: null src0/weight/out");
+    DDK_REQUIRE(a.src0 && a.out, "conv: null src0/out");
+    DDK_REQUIRE(a.weight || a.weight_wino, "conv: null weight");     // the Winograd copy alone will do where that path is taken (checked below)
     DDK_REQUIRE(a.c0 > 0 && a.c0 % 32 == 0, "conv: c0 must be a positive multiple of 32");
     DDK_REQUIRE((a.src1 == nullptr) == (a.c1 == 0), "conv: src1/c1 mismatch");
     DDK_REQUIRE(a.c1 % 32 == 0, "conv: c1 must be a multiple of 32");
@@ -1400,6 +1401,8 @@ int conv_forward(const ddk_conv_args& a, hipStream_t st, const ConvLnFold* ln, c
         }
         return DDK_OK;
     }
+    DDK_REQUIRE(a.weight, "conv: weight is null and the shape / arguments do not take the Winograd path (ddk_conv_wino_splits() == 0, "
+                          "pre_mish, mish_out or dmish_src)");
     // (the LayerNorm-folded form only where every workgroup walks >= 16 tiles: its ragged last round and per-tile statistics pass
     //  lose to the tile kernel at cfg4's 6 tiles per workgroup -- 44.6 vs 42.2 us -- and win on the full-resolution maps: 128x128
     //  x 8 images 264 -> ~140 us; or where the tiles divide evenly over the workgroups, e.g. the 256-channel k, v projection of the

@@ -971,6 +971,7 @@ int ddk_bias_grad(const float* dy, float* grad_b, long long M, int N, int accumu
 int ddk_pack_conv_weight_dgrad(const float* w_oihw, float* dst, int O, int I, int KH, int KW, int i_pad, int o_pad, ddk_stream_t s) {
     DDK_REQUIRE(w_oihw && dst && O > 0 && I > 0 && KH > 0 && KW > 0 && i_pad >= I && o_pad >= O, "pack_conv_weight_dgrad: arguments");
     const long long total = (long long)i_pad * KH * KW * o_pad;
+    DDK_REQUIRE(total < (1LL << 31), "pack_conv_weight_dgrad: 2^31 elements or more");
     const int blocks = (int)(ceil_div(total, 256) < 4096 ? ceil_div(total, 256) : 4096);
     hipLaunchKernelGGL(pack_dgrad_kernel, dim3(blocks), dim3(256), 0, as_stream(s), w_oihw, dst, O, I, KH * KW, i_pad, o_pad, total);
     return check_launch("pack_dgrad_kernel");

@@ -875,6 +875,7 @@ extern "C" int ddk_pack_conv_weight_wino(const float* w_oihw, float* dst, int O,
     using namespace ddk;
     DDK_REQUIRE(w_oihw && dst && O > 0 && I > 0 && i_pad >= I && i_pad % 32 == 0, "pack_conv_weight_wino: arguments (i_pad % 32 == 0)");
     const long long total = (long long)O * i_pad;
+    DDK_REQUIRE(total < (1LL << 31), "pack_conv_weight_wino: 2^31 (n, c) pairs or more");
     const long long blocks = ceil_div(total, 256);
     hipLaunchKernelGGL(pack_conv_weight_wino_kernel<false>, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, as_stream(s), w_oihw,
                        dst, O, I, i_pad, total, 0, I);
@@ -900,6 +901,7 @@ extern "C" int ddk_pack_conv_weight_wino_dgrad(const float* w_oihw, float* dst, 
     DDK_REQUIRE(w_oihw && dst && O > 0 && I > 0 && c_lo >= 0 && c_hi > c_lo && c_hi <= I && o_pad >= O && o_pad % 32 == 0,
                 "pack_conv_weight_wino_dgrad: arguments (0 <= c_lo < c_hi <= I, o_pad % 32 == 0)");
     const long long total = (long long)(c_hi - c_lo) * o_pad;
+    DDK_REQUIRE(total < (1LL << 31), "pack_conv_weight_wino_dgrad: 2^31 (n, c) pairs or more");
     const long long blocks = ceil_div(total, 256);
     hipLaunchKernelGGL(pack_conv_weight_wino_kernel<true>, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, as_stream(s), w_oihw,
                        dst, c_hi - c_lo, O, o_pad, total, c_lo, I);

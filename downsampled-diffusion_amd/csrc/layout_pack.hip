@@ -227,6 +227,7 @@ int ddk_pad_channels(const float* src, float* dst, long long M, int C, int c_pad
 int ddk_pack_conv_weight(const float* w, float* dst, int O, int I, int KH, int KW, int i_pad, ddk_stream_t s) {
     DDK_REQUIRE(w && dst && O > 0 && I > 0 && KH > 0 && KW > 0 && i_pad >= I, "pack_conv_weight: arguments");
     const long long total = (long long)O * KH * KW * i_pad;
+    DDK_REQUIRE(total < (1LL << 31), "pack_conv_weight: 2^31 elements or more");
     hipLaunchKernelGGL(pack_conv_weight_kernel, dim3(grid1d(total)), dim3(256), 0, as_stream(s), w, dst, O, I, KH * KW, i_pad, total, I, i_pad);
     return check_launch("pack_conv_weight_kernel");
 }
@@ -235,6 +236,7 @@ int ddk_pack_conv_weight_split(const float* w, float* dst, int O, int I, int KH,
     DDK_REQUIRE(w && dst && O > 0 && I > 0 && KH > 0 && KW > 0 && split > 0 && split <= I && split_pad >= split &&
                     i_pad >= split_pad + (I - split), "pack_conv_weight_split: arguments");
     const long long total = (long long)O * KH * KW * i_pad;
+    DDK_REQUIRE(total < (1LL << 31), "pack_conv_weight_split: 2^31 elements or more");
     hipLaunchKernelGGL(pack_conv_weight_kernel, dim3(grid1d(total)), dim3(256), 0, as_stream(s), w, dst, O, I, KH * KW, i_pad, total, split,
                        split_pad);
     return check_launch("pack_conv_weight_kernel");
@@ -243,6 +245,7 @@ int ddk_pack_conv_weight_split(const float* w, float* dst, int O, int I, int KH,
 int ddk_pack_convT_weight(const float* w, float* dst, int I, int O, ddk_stream_t s) {
     DDK_REQUIRE(w && dst && I > 0 && O > 0, "pack_convT_weight: arguments");
     const long long total = 16LL * I * O;
+    DDK_REQUIRE(total < (1LL << 31), "pack_convT_weight: 2^31 elements or more");
     hipLaunchKernelGGL(pack_convT_weight_kernel, dim3(grid1d(total)), dim3(256), 0, as_stream(s), w, dst, I, O, total, I, O);
     return check_launch("pack_convT_weight_kernel");
 }

@@ -76,6 +76,7 @@ extern "C" long long ddk_pack_jobs_layout(ddk_pack_job* jobs, int n) {
             default:
                 DDK_REQUIRE(false, "pack_jobs_layout: unknown kind");
         }
+        DDK_REQUIRE(j.total > 0 && j.total < (1LL << 31), "pack_jobs_layout: a copy of 2^31 elements or more");
         j.block0 = blocks;
         blocks += ceil_div(j.total, (long long)PJ_PER_BLOCK);
     }

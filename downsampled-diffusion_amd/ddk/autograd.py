@@ -124,8 +124,8 @@ def _conv_backward(kind, x, x2, weight, bias, dy, needs, gb_ready=False, dmish_s
         if kind == ops.CONVT4X4_S2:
             dx = ops.conv(ops.CONV4X4_S2, dy, ops.cached_pack("fwd", weight, ops.pack_conv_weight))   # (I,O,4,4) read as OIHW
         else:
-            wd = ops.cached_pack(("dgrad", c0 + c1), weight,
-                                 lambda w: ops.pack_conv_weight_dgrad(w, i_pad=c0 + c1))       # [c0+c1][taps][N]
+            def wd(lo, hi):        # [c0+c1][taps][N], made only for a launch the Winograd kernel does not take
+                return ops.cached_pack(("dgrad", c0 + c1), weight, lambda w: ops.pack_conv_weight_dgrad(w, i_pad=c0 + c1))[lo:hi]
             src = dy
             k = ops.CONV1X1 if kind == ops.CONV1X1 else ops.CONV3X3_S1
             if kind == ops.CONV3X3_S2:
@@ -136,15 +136,15 @@ def _conv_backward(kind, x, x2, weight, bias, dy, needs, gb_ready=False, dmish_s
                 ww = ops.wino_weight(weight, src.shape, 0, min(c0, weight.shape[1]), dgrad=True) if wino and c0 <= weight.shape[1] else None
                 if (FOLD_SLABS and dx_link is not None and dx_resid is None and dmish_src is None and x2 is None
                         and ops.gn_train_resident(x.shape[0], x.shape[1] * x.shape[2], c0)):
-                    dx, slabs = ops.conv(k, src, wd[:c0], n_out=c0, w_wino=ww, leave_slabs=True)
+                    dx, slabs = ops.conv(k, src, None if ww is not None else wd(0, c0), n_out=c0, w_wino=ww, leave_slabs=True)
                     if slabs is not None:
                         dx = dx_link.put(slabs)
                 else:
-                    dx = ops.conv(k, src, wd[:c0], n_out=c0, dmish_src=dmish_src, resid=dx_resid, w_wino=ww)
+                    dx = ops.conv(k, src, None if ww is not None else wd(0, c0), n_out=c0, dmish_src=dmish_src, resid=dx_resid, w_wino=ww)
                 dx_resid = None
             if need_x2:
-                dx2 = ops.conv(k, src, wd[c0:], n_out=c1, resid=dx2_resid,
-                               w_wino=ops.wino_weight(weight, src.shape, c0, c0 + c1, dgrad=True) if wino else None)
+                ww2 = ops.wino_weight(weight, src.shape, c0, c0 + c1, dgrad=True) if wino else None
+                dx2 = ops.conv(k, src, None if ww2 is not None else wd(c0, c0 + c1), n_out=c1, resid=dx2_resid, w_wino=ww2)
                 dx2_resid = None
     if dx_resid is not None:          # a handed-off gradient that no conv epilogue took (transpose conv, or no input gradient wanted)
         dx = dx_resid if dx is None else ops.add(dx, dx_resid)
@@ -160,15 +160,15 @@ class ConvFn(torch.autograd.Function):
     def forward(ctx, kind, x, x2, weight, bias, resid, handoff=None, resid_handoff=None):
         ctx.handoff = handoff
         ctx.resid_handoff = resid_handoff     # GradHandoff that takes the residual's gradient (dy itself) to another Function's kernel
+        wu = None
+        if kind == ops.CONV3X3_S1:
+            wu = ops.wino_weight(weight, (x.shape[0], x.shape[1], x.shape[2], x.shape[3] + (0 if x2 is None else x2.shape[3])))
         if kind == ops.CONVT4X4_S2:
             wp = ops.cached_pack("fwdT", weight, ops.pack_convT_weight)
             n = weight.shape[1]
         else:
-            wp = ops.cached_pack("fwd", weight, ops.pack_conv_weight)
+            wp = None if wu is not None else ops.cached_pack("fwd", weight, ops.pack_conv_weight)
             n = weight.shape[0]
-        wu = None
-        if kind == ops.CONV3X3_S1:
-            wu = ops.wino_weight(weight, (x.shape[0], x.shape[1], x.shape[2], x.shape[3] + (0 if x2 is None else x2.shape[3])))
         out = ops.conv(kind, x, wp, None if bias is None else bias.detach(), n_out=n, x2=x2, resid=resid, w_wino=wu)
         ctx.kind = kind
         ctx.save_for_backward(x, x2, weight, bias)
@@ -272,7 +272,8 @@ class ConvGNMishFn(torch.autograd.Function):
         wu = ops.wino_weight(weight, (x.shape[0], x.shape[1], x.shape[2], x.shape[3] + (0 if x2 is None else x2.shape[3])))
         # a conv that splits k leaves its partial slabs for the GroupNorm to sum while it loads (which also writes `raw`)
         fold = FOLD_SLABS and ops.gn_train_resident(x.shape[0], x.shape[1] * x.shape[2], weight.shape[0], groups)
-        raw = ops.conv(ops.CONV3X3_S1, x, ops.cached_pack("fwd", weight, ops.pack_conv_weight), bias.detach(),
+        # (the im2col copy of the filter is made -- and refreshed every step -- only where the Winograd kernel does not take the shape)
+        raw = ops.conv(ops.CONV3X3_S1, x, None if wu is not None else ops.cached_pack("fwd", weight, ops.pack_conv_weight), bias.detach(),
                        n_out=weight.shape[0], x2=x2, w_wino=wu, leave_slabs=fold)
         slabs = None
         if fold:

@@ -74,7 +74,8 @@ typedef struct ddk_conv_args {
     const float* src0;   /* NHWC [B][H][W][c0] */
     const float* src1;   /* optional second source (channel concat without materialising it, unet.py:97) */
     int c0, c1;          /* channels of each source, multiples of 32 (c1 = 0 when src1 is NULL) */
-    const float* weight; /* packed by ddk_pack_conv_weight / ddk_pack_convT_weight, I = c0 + c1 */
+    const float* weight; /* packed by ddk_pack_conv_weight / ddk_pack_convT_weight, I = c0 + c1; may be NULL when weight_wino is given
+                          * and the launch takes the Winograd path (ddk_conv_wino_splits() > 0, no pre_mish / mish_out / dmish_src) */
     const float* bias;   /* [N] or NULL */
     const float* resid;  /* optional [B][Ho][Wo][N] added in the epilogue (Residual, blocks.py:13-14) */
     float* out;          /* NHWC [B][Ho][Wo][N] */
