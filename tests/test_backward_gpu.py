@@ -567,23 +567,32 @@ def test_unet_training_with_slab_folds_is_bit_identical():
     u = det_load(Unet(cfg), "latent_model.").to(DEV).train()
     x = syn.synthetic_normal((16, 16, 16, 8), "fold.x").to(DEV)
     t = (torch.arange(16, device=DEV) * 61) % 1000
-    def run(fold):
+    from ddk import ops
+    def run(fold, side=False):
         AG.FOLD_SLABS = fold
+        ops.WGRAD_SIDE_STREAM = side
         try:
             for p in u.parameters():
-                p.grad = None
+                p.grad = torch.zeros_like(p) if side else None     # `.grad` slots: the weight gradients are deferred (and forked)
             torch.manual_seed(3)
-            out = unet_forward_autograd(u, x, t)
-            loss = (out * out).mean()
-            loss.backward()
+            with (ops.deferred_wgrad() if side else contextlib.nullcontext()):
+                out = unet_forward_autograd(u, x, t)
+                loss = (out * out).mean()
+                loss.backward()
             torch.cuda.synchronize()
             return loss.detach().clone(), [p.grad.clone() for p in u.parameters()]
         finally:
             AG.FOLD_SLABS = True
+            ops.WGRAD_SIDE_STREAM = True
     l0, g0 = run(False)
     l1, g1 = run(True)
     assert torch.equal(l0, l1)
     for a, b in zip(g0, g1):
+        assert torch.equal(a, b)
+    # the deferred weight-gradient launches on their side stream (fork after their operands, join before the reduce): same bits
+    l2, g2 = run(True, side=True)
+    assert torch.equal(l0, l2)
+    for a, b in zip(g0, g2):
         assert torch.equal(a, b)
     link = AG.SlabLink()
     ph = link.put(torch.zeros(2, 1, 4, 4, 32, device=DEV))

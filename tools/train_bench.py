@@ -17,6 +17,12 @@ if os.environ.get("TRAIN_BENCH_NO_DEFER"):          # A/B: one reduce launch per
     _ops.deferred_wgrad = contextlib.nullcontext
 
 
+if os.environ.get("TRAIN_BENCH_SIDE_BATCH"):        # A/B: weight-gradient launches per fork of the side stream (0: caller's stream)
+    from ddk import ops as _ops
+    _ops.WGRAD_SIDE_BATCH = int(os.environ["TRAIN_BENCH_SIDE_BATCH"])
+    _ops.WGRAD_SIDE_STREAM = _ops.WGRAD_SIDE_BATCH > 0
+
+
 def cfg(chan, cin, size, down=0):
     c = dict(unet_chan=chan, unet_in=cin, unet_dims=(1, 2, 2, 2), unet_dropout=0.1, image_size=size, T=1000, loss_type="simple",
              beta_schedule="linear", loss_flat="sum", ema_decay=0.995)
