@@ -612,14 +612,23 @@ constexpr int DHB = 32;
 // handles pixels [sp * per, (sp + 1) * per) and writes a partial; a fixed-order finish combines them.  gridDim.y == 1 writes the
 // final result directly.
 //   stats partial [bh][sp][2][32] = (max over the range, sum of exp(k - that max))
+// (the body is shared with linattn_dctx_kernel, which computes the statistics itself where one workgroup covers all pixels)
+__device__ __forceinline__ void linattn_stats_body(const float* __restrict__ qkv, float* __restrict__ o, int HW, int heads, int b, int h,
+                                                   int n_lo, int n_hi, float* sm /* [8 * 32] */);
+
 __global__ __launch_bounds__(256) void linattn_stats_kernel(const float* __restrict__ qkv, float* __restrict__ out, int HW, int heads,
                                                             int per) {
     __shared__ float sm[8 * DHB];
     const int b = blockIdx.x / heads, h = blockIdx.x % heads;
+    const int n_lo = blockIdx.y * per, n_hi = min(HW, n_lo + per);
+    linattn_stats_body(qkv, out + ((long long)blockIdx.x * gridDim.y + blockIdx.y) * 2 * DHB, HW, heads, b, h, n_lo, n_hi, sm);
+}
+
+__device__ __forceinline__ void linattn_stats_body(const float* __restrict__ qkv, float* __restrict__ o, int HW, int heads, int b, int h,
+                                                   int n_lo, int n_hi, float* sm) {
     const int HC = heads * DHB, RS = 3 * HC;
     const float* kp = qkv + (long long)b * HW * RS + HC + h * DHB;
     const int d = threadIdx.x & 31, ng = threadIdx.x >> 5;
-    const int n_lo = blockIdx.y * per, n_hi = min(HW, n_lo + per);
     float m = -INFINITY;
     for (int n = n_lo + ng; n < n_hi; n += 8) m = fmaxf(m, kp[(long long)n * RS + d]);
     sm[ng * DHB + d] = m;
@@ -636,7 +645,6 @@ __global__ __launch_bounds__(256) void linattn_stats_kernel(const float* __restr
         float t = 0.f;
 #pragma unroll
         for (int j = 0; j < 8; ++j) t += sm[j * DHB + threadIdx.x];
-        float* o = out + ((long long)blockIdx.x * gridDim.y + blockIdx.y) * 2 * DHB;
         o[threadIdx.x] = mm;
         o[DHB + threadIdx.x] = t;
     }
@@ -655,11 +663,18 @@ __global__ __launch_bounds__(64) void linattn_stats_merge_kernel(const float* __
 }
 
 // dctx[b][h][d][e] = sum_n q[n][h*32+d] * dout[n][h*32+e]; partial [sp][bh][32][32] when gridDim.y > 1
+// stats_out != null (gridDim.y == 1 only): this workgroup also leaves the softmax statistics of k for its (image, head) -- the backward
+// then needs nothing from the forward but qkv and ctx, and the forward no statistics launch
 __global__ __launch_bounds__(256) void linattn_dctx_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
-                                                           float* __restrict__ out, int HW, int heads, int per) {
+                                                           float* __restrict__ out, int HW, int heads, int per,
+                                                           float* __restrict__ stats_out) {
     __shared__ __attribute__((aligned(16))) float qs[64 * DHB];
     __shared__ __attribute__((aligned(16))) float ds[64 * DHB];
     const int b = blockIdx.x / heads, h = blockIdx.x % heads;
+    if (stats_out) {
+        linattn_stats_body(qkv, stats_out + (long long)blockIdx.x * 2 * DHB, HW, heads, b, h, 0, HW, qs);
+        __syncthreads();
+    }
     const int HC = heads * DHB, RS = 3 * HC, tid = threadIdx.x;
     const float* qp = qkv + (long long)b * HW * RS + h * DHB;
     const float* dp = dout + (long long)b * HW * HC + h * DHB;
@@ -1307,22 +1322,43 @@ int ddk_linattn_stats(const float* qkv, float* stats, int B, int HW, int heads, 
 }
 
 /* dqkv from dout (grad of the attention output before to_out); dctx is scratch [B][heads][32][32] */
+static int linattn_bwd_impl(const float* qkv, const float* dout, const float* ctx, const float* stats, float* stats_scratch, float* dctx,
+                            float* dqkv, int B, int HW, int heads, void* workspace, size_t workspace_bytes, ddk_stream_t s);
 int ddk_linattn_bwd(const float* qkv, const float* dout, const float* ctx, const float* stats, float* dctx, float* dqkv, int B, int HW,
                     int heads, void* workspace, size_t workspace_bytes, ddk_stream_t s) {
-    DDK_REQUIRE(qkv && dout && ctx && stats && dctx && dqkv && B > 0 && HW > 0 && heads >= 1 && heads <= 4, "linattn_bwd: arguments (heads <= 4)");
+    DDK_REQUIRE(stats, "linattn_bwd: null stats");
+    return linattn_bwd_impl(qkv, dout, ctx, stats, nullptr, dctx, dqkv, B, HW, heads, workspace, workspace_bytes, s);
+}
+/* the same without statistics saved by the forward: they are recomputed from qkv into stats_scratch [B][heads][2][32] -- inside the dctx
+ * launch where one workgroup covers the pixels of an (image, head), by ddk_linattn_stats' launches on large maps */
+int ddk_linattn_bwd_recompute(const float* qkv, const float* dout, const float* ctx, float* stats_scratch, float* dctx, float* dqkv, int B,
+                              int HW, int heads, void* workspace, size_t workspace_bytes, ddk_stream_t s) {
+    DDK_REQUIRE(stats_scratch, "linattn_bwd_recompute: null stats_scratch");
+    return linattn_bwd_impl(qkv, dout, ctx, nullptr, stats_scratch, dctx, dqkv, B, HW, heads, workspace, workspace_bytes, s);
+}
+static int linattn_bwd_impl(const float* qkv, const float* dout, const float* ctx, const float* stats, float* stats_scratch, float* dctx,
+                            float* dqkv, int B, int HW, int heads, void* workspace, size_t workspace_bytes, ddk_stream_t s) {
+    DDK_REQUIRE(qkv && dout && ctx && dctx && dqkv && B > 0 && HW > 0 && heads >= 1 && heads <= 4, "linattn_bwd: arguments (heads <= 4)");
     DDK_REQUIRE(aligned16(qkv) && aligned16(dout) && aligned16(ctx) && aligned16(dctx) && aligned16(dqkv) && aligned16(workspace),
                 "linattn_bwd: alignment");
     hipStream_t st = as_stream(s);
     const int sp = linattn_train_splits(B, HW, heads);
     const int per = (int)(ceil_div(ceil_div(HW, sp), 64) * 64);
     if (sp == 1) {
-        hipLaunchKernelGGL(linattn_dctx_kernel, dim3(B * heads, 1), dim3(256), 0, st, qkv, dout, dctx, HW, heads, per);
+        hipLaunchKernelGGL(linattn_dctx_kernel, dim3(B * heads, 1), dim3(256), 0, st, qkv, dout, dctx, HW, heads, per,
+                           stats ? static_cast<float*>(nullptr) : stats_scratch);
         DDK_TRY(check_launch("linattn_dctx_kernel"));
+        if (!stats) stats = stats_scratch;
     } else {
+        if (!stats) {
+            DDK_TRY(ddk_linattn_stats(qkv, stats_scratch, B, HW, heads, workspace, workspace_bytes, s));
+            stats = stats_scratch;
+        }
         const int n = B * heads * DHB * DHB;
         DDK_REQUIRE(workspace && workspace_bytes >= (size_t)sp * n * sizeof(float), "linattn_bwd: workspace too small");
         float* part = static_cast<float*>(workspace);
-        hipLaunchKernelGGL(linattn_dctx_kernel, dim3(B * heads, sp), dim3(256), 0, st, qkv, dout, part, HW, heads, per);
+        hipLaunchKernelGGL(linattn_dctx_kernel, dim3(B * heads, sp), dim3(256), 0, st, qkv, dout, part, HW, heads, per,
+                           static_cast<float*>(nullptr));
         DDK_TRY(check_launch("linattn_dctx_kernel"));
         hipLaunchKernelGGL(rows_sum_kernel, dim3((unsigned)ceil_div(n, 64), 1), dim3(256), 0, st, static_cast<const float*>(part), sp,
                            (long long)n, 0LL, dctx, n, 0);

@@ -342,15 +342,15 @@ class LinAttnFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, qkv, heads):
-        out, cx, stats = ops.linattn_train(qkv, heads)
-        ctx.save_for_backward(qkv, cx, stats)
+        out, cx = ops.linattn(qkv, heads)           # (the softmax statistics of k are the backward's to recompute: no launch for them here)
+        ctx.save_for_backward(qkv, cx)
         ctx.heads = heads
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        qkv, cx, stats = ctx.saved_tensors
-        return ops.linattn_bwd(qkv, _c(dout), cx, stats, ctx.heads), None
+        qkv, cx = ctx.saved_tensors
+        return ops.linattn_bwd(qkv, _c(dout), cx, None, ctx.heads), None
 
 
 class SmallNConvFn(torch.autograd.Function):

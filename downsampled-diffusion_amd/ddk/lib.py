@@ -183,6 +183,7 @@ SIGNATURES = {
     "ddk_linattn_train_workspace_bytes": (_SZ, [_I, _I, _I]),
     "ddk_linattn_stats": (_I, [_P, _P, _I, _I, _I, _P, _SZ, _P]),
     "ddk_linattn_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _SZ, _P]),
+    "ddk_linattn_bwd_recompute": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _SZ, _P]),
     "ddk_mish_bwd": (_I, [_P, _P, _P, _LL, _P]),
     "ddk_tanh_bwd": (_I, [_P, _P, _P, _LL, _P]),
     "ddk_avgpool2_bwd": (_I, [_P, _P, _I, _I, _I, _I, _P]),

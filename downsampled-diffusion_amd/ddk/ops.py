@@ -1073,12 +1073,18 @@ def linattn_train(qkv, heads=4):
 
 
 def linattn_bwd(qkv, dout, ctx, stats, heads=4):
+    """stats None: the softmax statistics of k are recomputed from qkv by the backward's own launches (ddk_linattn_bwd_recompute)"""
     b, h, w, _ = qkv.shape
     dctx = torch.empty_like(ctx)
     dqkv = torch.empty_like(qkv)
     lib = L.load()
     nbytes = lib.ddk_linattn_train_workspace_bytes(b, h * w, heads)
     ws = _ws(qkv.device, nbytes, "linattn_train") if nbytes else None
+    if stats is None:
+        scratch = torch.empty((b, heads, 2, 32), device=qkv.device, dtype=torch.float32)
+        L.check(lib.ddk_linattn_bwd_recompute(L.ptr(qkv), L.ptr(_f32(dout)), L.ptr(ctx), L.ptr(scratch), L.ptr(dctx), L.ptr(dqkv), b, h * w,
+                                              heads, L.ptr(ws), nbytes, L.stream()), "linattn_bwd_recompute")
+        return dqkv
     L.check(lib.ddk_linattn_bwd(L.ptr(qkv), L.ptr(_f32(dout)), L.ptr(ctx), L.ptr(stats), L.ptr(dctx), L.ptr(dqkv), b, h * w,
                                 heads, L.ptr(ws), nbytes, L.stream()), "linattn_bwd")
     return dqkv

@@ -127,21 +127,25 @@ def sq_err_sum_autograd(a, b):
     return AG.SqErrSumFn.apply(a.contiguous(), b.contiguous())
 
 
-def _conv_res_block(blk, x):
+def _conv_res_block(blk, x, a=None, want_next_act=False):
     """convblocks.py:112-130 with the pre-activations kept for the backward: every conv's epilogue writes its output AND Mish of it
     (the next conv's input), every input-gradient conv multiplies by Mish' of the pre-activation -- one Mish launch per block (on the
-    block input) instead of four forward and four backward ones."""
-    a = ops.mish(x.detach())
+    block input) instead of four forward and four backward ones; and none where the block before handed Mish of its output over
+    (`a`, written by its c4 epilogue: want_next_act, for a block that neither pools nor upsamples).  -> (out, Mish(out) or None)"""
+    if a is None:
+        a = ops.mish(x.detach())
     hand = AG.GradHandoff() if blk.residual else None      # the skip's gradient rides on c1's input-gradient conv (no 17-67 MB add launch)
     h, a = AG.preact_conv(ops.CONV1X1, x, a, blk.c1.weight, blk.c1.bias, handoff=hand)
     h, a = AG.preact_conv(ops.CONV3X3_S1, h, a, blk.c2.weight, blk.c2.bias)
     h, a = AG.preact_conv(ops.CONV3X3_S1, h, a, blk.c3.weight, blk.c3.bias)
-    out, _ = AG.preact_conv(ops.CONV1X1, h, a, blk.c4.weight, blk.c4.bias, resid=x if blk.residual else None, want_act=False, handoff=hand)
+    hand_over = want_next_act and not (blk.upsample or blk.downsample)
+    out, a_next = AG.preact_conv(ops.CONV1X1, h, a, blk.c4.weight, blk.c4.bias, resid=x if blk.residual else None, want_act=hand_over,
+                                 handoff=hand)
     if blk.upsample:
         out = AG.UpNearest2Fn.apply(out)
     elif blk.downsample:
         out = AG.AvgPool2Fn.apply(out)
-    return out
+    return out, a_next
 
 
 def resnet_forward_autograd(net, x_nchw, final_tanh):
@@ -153,8 +157,10 @@ def resnet_forward_autograd(net, x_nchw, final_tanh):
     h = AG.NchwToNhwcFn.apply(x_nchw.contiguous().float(), ops.pad32(x_nchw.shape[1]))
     first, last = net.conv[0], net.conv[-1]
     h = AG.conv(ops.CONV1X1, h, first.weight, first.bias)
-    for blk in list(net.conv)[1:-1]:
-        h = _conv_res_block(blk, h)
+    blocks = list(net.conv)[1:-1]
+    a = None
+    for k, blk in enumerate(blocks):
+        h, a = _conv_res_block(blk, h, a, want_next_act=k + 1 < len(blocks))
     out = AG.SmallNConvFn.apply(h, last.weight, last.bias)
     if final_tanh:
         out = AG.TanhFn.apply(out)

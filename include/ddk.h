@@ -514,6 +514,10 @@ size_t ddk_linattn_train_workspace_bytes(int B, int HW, int heads);
 int ddk_linattn_stats(const float* qkv, float* stats, int B, int HW, int heads, void* workspace, size_t workspace_bytes, ddk_stream_t s);
 int ddk_linattn_bwd(const float* qkv, const float* dout, const float* ctx, const float* stats, float* dctx,
                     float* dqkv, int B, int HW, int heads, void* workspace, size_t workspace_bytes, ddk_stream_t s);
+/* round 4: ddk_linattn_bwd without statistics saved by the forward: recomputed from qkv into stats_scratch [B][heads][2][32] -- inside
+ * the dctx launch where one workgroup covers the pixels of an (image, head), by ddk_linattn_stats' launches on large maps */
+int ddk_linattn_bwd_recompute(const float* qkv, const float* dout, const float* ctx, float* stats_scratch, float* dctx, float* dqkv,
+                              int B, int HW, int heads, void* workspace, size_t workspace_bytes, ddk_stream_t s);
 int ddk_mish_bwd(const float* x, const float* dy, float* dx, long long n, ddk_stream_t s);
 int ddk_tanh_bwd(const float* y, const float* dy, float* dx, long long n, ddk_stream_t s);
 int ddk_avgpool2_bwd(const float* dy, float* dx, int B, int H, int W, int C, ddk_stream_t s);

@@ -246,6 +246,11 @@ def test_linattn_backward(AG, B, H, W):
     out.backward(to_nhwc(go).to(DEV))
     assert rel_err(to_nchw(out.detach().cpu()), out_ref) < 1e-5
     assert rel_err(qd.grad.cpu(), to_nhwc(gq)) < 3e-5
+    # the statistics recomputed by the backward's own launches (ddk_linattn_bwd_recompute) == saved by a forward launch, bit for bit
+    from ddk import ops
+    _, cx, stats = ops.linattn_train(qd.detach(), 4)
+    dq_saved = ops.linattn_bwd(qd.detach(), to_nhwc(go).to(DEV), cx, stats, 4)
+    assert torch.equal(dq_saved, qd.grad)
 
 
 def test_small_n_conv_and_elementwise_backward(AG):

@@ -22,5 +22,8 @@ timeout -k 10 200 python tools/encdec_bench.py > $o/encdec_bench.txt 2>&1
 (make -C downsampled-diffusion_amd/csrc -j8 tune > /dev/null 2>&1 && for v in plain mo dg; do timeout -k 10 60 python tools/c32_clock.py 64 64 $v; done; timeout -k 10 60 python tools/c32_clock.py 32 64 mo; timeout -k 10 60 python tools/local_clock.py 256; timeout -k 10 60 python tools/wl_clock.py 256) 2>&1 | grep -v amdgpu > $o/clock_stamps.txt
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $o/tprof -- python3 tools/train_profile.py cfg3 > $o/tprof.log 2>&1
 cp $(ls $o/tprof/*/*kernel_stats.csv | head -1) $o/train_cfg3_kernel_stats.csv; rm -rf $o/tprof
+timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $o/tg -- python3 tools/train_profile.py cfg3 graph > $o/tg.log 2>&1
+python tools/train_breakdown.py $(ls $o/tg/*/*kernel_trace.csv | head -1) -v > $o/train_step_breakdown.txt; rm -rf $o/tg
+head -1 $o/train_step_breakdown.txt
 grep "kernel time" $o/step_breakdown.txt; grep -v amdgpu $o/sample_bench.txt $o/train_bench.txt | cut -d: -f2-
 head -c 300 $o/bench_latest.json; echo
