@@ -778,6 +778,7 @@ def _side_stream(device):
 
 
 WGRAD_SIDE_BATCH = 16            # 8 .. 64 measure alike (16.2 - 16.6 ms per cfg3 step against 16.7 - 16.8 on the caller's stream)
+WGRAD_SIDE_MAX_PIXELS = 65536    # larger maps fill the chip by themselves: nothing to overlap, and the forks cost (cfg5 115.4 -> 117.1 ms)
 _wgrad_queue = []             # deferred weight-gradient launches not yet issued
 
 
@@ -907,7 +908,7 @@ def conv_wgrad_(kind, x, dy, grad_w, c_real, cw, c_off, grad_b=None, persistent=
         slab = torch.empty(max(nbytes, 16) // 4, device=x.device, dtype=torch.float32)
         job = L.WgradReduceJob()
         x, dy = _f32(x), _f32(dy)
-        if WGRAD_SIDE_STREAM:
+        if WGRAD_SIDE_STREAM and b * h * w <= WGRAD_SIDE_MAX_PIXELS:
             # queued; every WGRAD_SIDE_BATCH of them leave together behind ONE fork (a cross-stream edge per launch cost more than the
             # overlap gave: 16.7 -> 18.2 ms per cfg3 step)
             _wgrad_queue.append((kind, x, dy, grad_w, grad_b, (b, h, w, cx, c_real, cw, c_off, n), slab, nbytes, job))
