@@ -725,7 +725,7 @@ def _ws(device, nbytes, tag="ws"):
     n = max(nbytes, 16) // 4 + 4
     if device is not None and torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
         return torch.empty(n, device=device, dtype=torch.float32)
-    key = (str(device), tag)
+    key = (str(device), tag, torch.cuda.current_stream().cuda_stream)     # per stream: two branches of a step may run side by side
     buf = _scratch.get(key)
     if buf is None or buf.numel() < n:
         buf = torch.empty(n, device=device, dtype=torch.float32)
@@ -789,9 +789,14 @@ def _launch_side_queue():
         return
     lib = L.load()
     side = _side_stream(_wgrad_queue[0][1].device)
-    side.wait_stream(torch.cuda.current_stream())              # operands and slab buffers are ready on the caller's stream
+    seen = set()
+    for entry in _wgrad_queue:                                 # operands and slab buffers are ready on the stream(s) that queued them
+        st = entry[-1]
+        if st.cuda_stream not in seen:
+            seen.add(st.cuda_stream)
+            side.wait_stream(st)
     with torch.cuda.stream(side):
-        for kind, x, dy, grad_w, grad_b, dims, slab, nbytes, job in _wgrad_queue:
+        for kind, x, dy, grad_w, grad_b, dims, slab, nbytes, job, _ in _wgrad_queue:
             L.check(lib.ddk_conv_wgrad_defer(kind, L.ptr(x), L.ptr(dy), L.ptr(grad_w), L.ptr(grad_b), *dims, L.ptr(slab), nbytes,
                                              C.byref(job), L.stream()), "conv_wgrad_defer")
             _wgrad_keep.append((x, dy))
@@ -911,7 +916,8 @@ def conv_wgrad_(kind, x, dy, grad_w, c_real, cw, c_off, grad_b=None, persistent=
         if WGRAD_SIDE_STREAM and b * h * w <= WGRAD_SIDE_MAX_PIXELS:
             # queued; every WGRAD_SIDE_BATCH of them leave together behind ONE fork (a cross-stream edge per launch cost more than the
             # overlap gave: 16.7 -> 18.2 ms per cfg3 step)
-            _wgrad_queue.append((kind, x, dy, grad_w, grad_b, (b, h, w, cx, c_real, cw, c_off, n), slab, nbytes, job))
+            _wgrad_queue.append((kind, x, dy, grad_w, grad_b, (b, h, w, cx, c_real, cw, c_off, n), slab, nbytes, job,
+                                 torch.cuda.current_stream()))
             if len(_wgrad_queue) >= WGRAD_SIDE_BATCH:
                 _launch_side_queue()
         else:

@@ -96,6 +96,10 @@ class DownsampleDDPM(DDPM):
         return self.test_losses_(self.rescaled_downsample(x))
 
 
+RECON_SIDE_STREAM = True          # see DownsampleDDPMAutoencoder.losses; the tests switch it off to compare
+_recon_streams = {}               # device -> torch.cuda.Stream (module level: a stream must not end up in a deepcopy of the model)
+
+
 class DownsampleDDPMAutoencoder(DownsampleDDPM):
     """Reconstruction loss taken directly through the autoencoder, latent detached for the DDPM term
     (dddpm.py:151-177; selected by ae_loss=True, train.py:44)."""
@@ -105,11 +109,26 @@ class DownsampleDDPMAutoencoder(DownsampleDDPM):
 
     def losses(self, x, t):
         z = self.rescaled_downsample(x)
-        L_rec = self.loss_recon(x, z, t)
+        # The reconstruction branch (decoder + loss, and with it the backward of both) does not meet the denoiser branch before the two
+        # losses are added (the latent is detached): in training on the device it runs on its own stream -- its large memory-bound
+        # launches beside the UNet's small latency-bound ones.  autograd runs each backward on the stream of its forward.
+        fork = RECON_SIDE_STREAM and x.is_cuda and torch.is_grad_enabled()
+        if fork:
+            main = torch.cuda.current_stream()
+            side = _recon_streams.get(x.device)
+            if side is None:
+                side = _recon_streams[x.device] = torch.cuda.Stream(device=x.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                L_rec = self.loss_recon(x, z, t)
+        else:
+            L_rec = self.loss_recon(x, z, t)
         z = z.detach()
         eps = torch.randn_like(z)
         z_t = self.q_sample(z, t, eps)
         eps_hat = self.latent_model(z_t, t)
         L_ddpm = self.loss_ddpm(eps, eps_hat, t)
+        if fork:
+            main.wait_stream(side)
         obj = (L_ddpm + L_rec).mean()
         return obj, {'latent': L_ddpm.mean(), 'recon': L_rec.mean()}

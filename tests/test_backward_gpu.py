@@ -381,6 +381,39 @@ def test_objective_and_grads_vs_reference(tag):
     assert abs(float(total) / float(g[f"{tag}_gradnorm0"]) - 1) < 1e-3
 
 
+def test_reconstruction_branch_on_its_own_stream_is_bit_identical():
+    """DownsampleDDPMAutoencoder.losses in training: decoder + reconstruction loss (and their backward) on a second stream, beside the
+    denoiser branch == everything on one stream: objective and every gradient bit for bit, eager with `.grad` slots + deferred reduces."""
+    from models.diffusion import dddpm as D
+    from ddk import ops
+    model, xshape, eshape = _g6_model("dddpm_ae")
+    x = syn.synthetic_input(xshape, "fork.x").to(DEV)
+    tt = torch.tensor([0, 40, 500, 999], device=DEV)
+    eps = syn.synthetic_normal(eshape, "fork.eps").to(DEV)
+    model.t_sample = lambda n: tt
+    def run(fork):
+        D.RECON_SIDE_STREAM = fork
+        orig = torch.randn_like
+        torch.randn_like = lambda z: eps
+        try:
+            for p in model.parameters():
+                p.grad = torch.zeros_like(p)
+            torch.manual_seed(5)
+            with ops.deferred_wgrad():
+                obj, extra = model(x)
+                obj.backward()
+            torch.cuda.synchronize()
+            return obj.detach().clone(), extra["recon"].detach().clone(), [p.grad.clone() for p in model.parameters()]
+        finally:
+            torch.randn_like = orig
+            D.RECON_SIDE_STREAM = True
+    o0, r0, g0 = run(False)
+    o1, r1, g1 = run(True)
+    assert torch.equal(o0, o1) and torch.equal(r0, r1)
+    for a, b in zip(g0, g1):
+        assert torch.equal(a, b)
+
+
 def test_unet_grads_large_resolution_vs_oracle():
     """Full-resolution-style training (cfg5 shape class): 64x64 maps at 64 channels put 32768 elements in a GroupNorm
     group, i.e. the streamed large-slab kernels; 4096 pixels per sample in the linear attention.  Gradients of a
