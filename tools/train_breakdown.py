@@ -38,8 +38,18 @@ def main(path, verbose):
         e = fam.setdefault(short(r["Kernel_Name"]), [0, 0])
         e[0] += 1
         e[1] += d
-    print(f"one optimiser step: {n} launches, {busy / 1e3:.0f} us of kernel time in a span of {(t1 - t0) / 1e3:.0f} us "
-          f"(idle {(t1 - t0 - busy) / 1e3:.0f} us); steps seen {[len(s) for s in steps]}")
+    # kernels of different branches of the captured step (side streams) run side by side: the union of the busy intervals, not their sum
+    iv = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in step)
+    covered, cur_s, cur_e = 0, iv[0][0], iv[0][1]
+    for a, b in iv[1:]:
+        if a > cur_e:
+            covered += cur_e - cur_s
+            cur_s, cur_e = a, b
+        else:
+            cur_e = max(cur_e, b)
+    covered += cur_e - cur_s
+    print(f"one optimiser step: {n} launches, {busy / 1e3:.0f} us of kernel time ({(busy - covered) / 1e3:.0f} us of it beside another "
+          f"kernel) in a span of {(t1 - t0) / 1e3:.0f} us (idle {(t1 - t0 - covered) / 1e3:.0f} us); steps seen {[len(s) for s in steps]}")
     for name, (c, d) in sorted(fam.items(), key=lambda kv: -kv[1][1]):
         print(f"  {name:60s} x{c:4d} {d / 1e3:9.1f} us  {100 * d / busy:5.1f} %   avg {d / c / 1e3:7.2f}")
     if verbose:
