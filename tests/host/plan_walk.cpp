@@ -98,7 +98,8 @@ static void walk_training_ops() {
     ddk_san_clear();
     struct Shape { int kind, B, H, W, cx, N; };
     const Shape shapes[] = {{DDK_CONV3X3_S1, 8, 64, 64, 32, 32}, {DDK_CONV3X3_S1, 4, 16, 16, 128, 256}, {DDK_CONV1X1, 4, 8, 8, 256, 384},
-                            {DDK_CONV3X3_S2, 4, 16, 16, 64, 64}, {DDK_CONV1X1, 32, 4, 4, 128, 256}, {DDK_CONV3X3_S1, 2, 32, 32, 32, 32}};
+                            {DDK_CONV3X3_S2, 4, 16, 16, 64, 64}, {DDK_CONV1X1, 32, 4, 4, 128, 256}, {DDK_CONV3X3_S1, 2, 32, 32, 32, 32},
+                            {DDK_CONV1X1, 8, 64, 64, 64, 32}, {DDK_CONV1X1, 16, 32, 32, 32, 64}};      // the last two: conv1x1_stream.hip
     std::vector<ddk_wgrad_reduce_job> jobs;
     std::vector<Arena*> keep;
     for (const Shape& sh : shapes) {
@@ -152,6 +153,32 @@ static void walk_training_ops() {
         r.nbatch = 3; r.nrows = 8; r.n = 256;
         std::vector<ddk_rows_sum_job> rj(60, r);
         CHECK(ddk_rows_sum_jobs(rj.data(), (int)rj.size(), nullptr) == DDK_OK, "rows_sum_jobs: %s", ddk_last_error());
+    }
+    {   // round 4: a conv that leaves its split-K slabs to the GroupNorm (forward and backward forms), the LayerNorm backward with the
+        // Residual's gradient, the attention backward that recomputes its statistics
+        const int B = 4, H = 16, W = 16, C = 128, N = 128;
+        const int S = ddk_conv_wino_splits(B, H, W, C, N) > 1 ? ddk_conv_wino_splits(B, H, W, C, N) : 2;
+        const size_t tb = (size_t)B * H * W * N * 4;
+        Arena slabs(tb * S, "slabs"), raw(tb, "raw"), y(tb, "y"), cb(N * 4, "conv bias"), ga(N * 4, "gamma"), be(N * 4, "beta"), te((size_t)B * N * 4, "temb");
+        Arena dx(tb, "dx"), part((size_t)4 * B * N * 4, "gn part");
+        CHECK(ddk_groupnorm_train_workspace_bytes(B, H * W, N, 8) == 0, "register-resident GroupNorm shape expected");
+        CHECK(ddk_groupnorm_mish_train_fwd_slabs(slabs.f(), S, (long long)B * H * W * N, cb.f(), raw.f(), ga.f(), be.f(), te.f(), N, nullptr, 0.1f, 7, 3,
+                                                 y.f(), B, H * W, N, 8, 1e-5f, nullptr) == DDK_OK, "groupnorm_train_fwd_slabs: %s", ddk_last_error());
+        CHECK(ddk_groupnorm_mish_bwd_slabs(raw.f(), ga.f(), be.f(), 0.1f, 7, 3, slabs.f(), S, (long long)B * H * W * N, dx.f(), part.f(), B, H * W, N, 8,
+                                           1e-5f, nullptr) == DDK_OK, "groupnorm_bwd_slabs: %s", ddk_last_error());
+        CHECK(ddk_groupnorm_mish_train_fwd_slabs(slabs.f(), 1, (long long)B * H * W * N, cb.f(), raw.f(), ga.f(), be.f(), nullptr, 0, nullptr, 0.f, 0, 0,
+                                                 y.f(), B, H * W, N, 8, 1e-5f, nullptr) != DDK_OK, "a single slab accepted by the slab form");
+        Arena lpart((size_t)2 * 512 * N * 4, "ln part");
+        int nparts = 0;
+        CHECK(ddk_chan_layernorm_bwd_add(raw.f(), ga.f(), y.f(), slabs.f(), dx.f(), lpart.f(), 512, &nparts, (long long)B * H * W, N, 1e-5f, nullptr) == DDK_OK &&
+                  nparts > 0, "chan_layernorm_bwd_add: %s", ddk_last_error());
+        const int heads = 4;
+        Arena qkv((size_t)B * H * W * 384 * 4, "qkv"), dout((size_t)B * H * W * 128 * 4, "dout"), ctx((size_t)B * heads * 1024 * 4, "ctx"),
+            dctx((size_t)B * heads * 1024 * 4, "dctx"), dqkv((size_t)B * H * W * 384 * 4, "dqkv"), st((size_t)B * heads * 64 * 4, "stats");
+        const size_t lw = ddk_linattn_train_workspace_bytes(B, H * W, heads);
+        Arena lws(lw ? lw : 16, "linattn workspace");
+        CHECK(ddk_linattn_bwd_recompute(qkv.f(), dout.f(), ctx.f(), st.f(), dctx.f(), dqkv.f(), B, H * W, heads, lws.p, lw, nullptr) == DDK_OK,
+              "linattn_bwd_recompute: %s", ddk_last_error());
     }
     {   // every kernel-layout copy of two weights by one launch
         Arena w((size_t)256 * 256 * 9 * 4, "weight"), d0((size_t)256 * 9 * 256 * 4, "fwd copy"), d1((size_t)8 * 16 * 256 * 32 * 4, "wino copy"),
