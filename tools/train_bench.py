@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Training-step timing: cfg3 (CelebA 64x64 dDDPM x2, batch 64), cfg2-like plain DDPM 32x32, cfg5 (full-resolution DDPM
-256x256, batch 8), eager vs device-graph replay.  An optimiser step = gradient_accumulate_every = 2 micro-batches of a FULL
+256x256, batch 8), eager vs device-graph replay; `cfg4`: the headline configuration as a training step.  An optimiser step = gradient_accumulate_every = 2 micro-batches of a FULL
 batch_size each (reference trainers/trainer_ddpm.py:118-128).  GPU-box tool: python tools/train_bench.py"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -74,6 +74,12 @@ def time_train(name, model, xshape, steps=5):
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "cfg4":
+        # the headline sampling configuration as a TRAINING step: CelebA-HQ 256x256 dDDPM -downsample 3 (32x32 latents of 8), -bs 32
+        c = cfg(128, 8, 256, down=3)
+        time_train("cfg4 dDDPM-x3 256x256 bs32", DownsampleDDPMAutoencoder(c, Unet(c), DEV, 3), (32, 3, 256, 256), steps=3)
+        print(f"peak HBM allocated: {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB", flush=True)
+        sys.exit(0)
     c = cfg(128, 8, 64, down=2)
     time_train("cfg3 dDDPM-x2 64x64 bs64", DownsampleDDPMAutoencoder(c, Unet(c), DEV, 3), (64, 3, 64, 64))
     c = cfg(128, 3, 32)
