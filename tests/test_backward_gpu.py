@@ -592,6 +592,36 @@ def test_groupnorm_train_slab_forms_are_bit_identical(B, H, W, C, S):
         ops.groupnorm_mish_train(torch.empty_like(big[0]), gamma[:128], beta[:128], slabs=big, conv_bias=bias[:128])
 
 
+@pytest.mark.parametrize("B,H,W,C,N", [(2, 5, 5, 256, 256), (3, 7, 6, 128, 64), (2, 8, 8, 256, 128)])
+def test_block_with_slab_fold_on_the_im2col_kernels_is_bit_identical(B, H, W, C, N):
+    """ConvGNMishFn where the conv is NOT Winograd-eligible (odd maps) or is, with a k split: the slabs of the im2col / Winograd launch
+    summed by the GroupNorm == reduced first; output and all gradients bit for bit."""
+    from ddk import autograd as AG
+    from ddk import ops
+    g = torch.Generator().manual_seed(9)
+    x0 = torch.randn(B, H, W, C, generator=g).to(DEV)
+    w0 = (torch.randn(N, C, 3, 3, generator=g) * (9 * C) ** -0.5).to(DEV)
+    b0, ga0, be0 = (torch.randn(N, generator=g).to(DEV) * 0.1 for _ in range(3))
+    te = torch.randn(B, N, generator=g).to(DEV)
+    dy = torch.randn(B, H, W, N, generator=g).to(DEV)
+    def run(fold):
+        AG.FOLD_SLABS = fold
+        try:
+            x, w, b, ga, be = (t.clone().requires_grad_(True) for t in (x0, w0, b0, ga0 + 1, be0))
+            y = AG.conv_groupnorm_mish(x, w, b, ga, be, temb=te)
+            y.backward(dy)
+            torch.cuda.synchronize()
+            return [y.detach()] + [t.grad for t in (x, w, b, ga, be)]
+        finally:
+            AG.FOLD_SLABS = True
+    for a, bb in zip(run(False), run(True)):
+        assert torch.equal(a, bb)
+    lib = __import__("ddk.lib", fromlist=["load"]).load()
+    wino = H % 2 == 0 and W % 2 == 0 and lib.ddk_conv_wino_splits(B, H, W, C, N) > 0
+    splits = lib.ddk_conv_wino_splits(B, H, W, C, N) if wino else lib.ddk_conv_splits(ops.CONV3X3_S1, B, H, W, C, N)
+    assert splits > 1, "the case is meant to split k"
+
+
 def test_unet_training_with_slab_folds_is_bit_identical():
     """One forward + backward of the UNet (cfg3 shape: 16x16 latent, dims (1,2,2,2), batch 16, dropout on) with the split-K slabs
     summed inside the GroupNorm kernels == with one reduce launch per conv: loss and every gradient bit for bit.  Also: the

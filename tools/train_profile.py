@@ -13,6 +13,8 @@ from ddk import ops
 which = sys.argv[1] if len(sys.argv) > 1 else "cfg3"
 if which == "cfg3":
     c = cfg(128, 8, 64, down=2); model = DownsampleDDPMAutoencoder(c, Unet(c), DEV, 3); xshape = (64, 3, 64, 64)
+elif which == "cfg4":
+    c = cfg(128, 8, 256, down=3); model = DownsampleDDPMAutoencoder(c, Unet(c), DEV, 3); xshape = (32, 3, 256, 256)
 elif which == "cfg2":
     c = cfg(128, 3, 32); model = DDPM(c, Unet(c), DEV, 3); xshape = (64, 3, 32, 32)
 else:
