@@ -5,7 +5,7 @@ cases: wino (conv3x3 128->128 @32x32 B=32, Winograd), gn (GroupNorm-apply from p
 one launch, 256->256 @4x4), wlocal8 (the same @8x8, Winograd form), first (conv_first 8->128 @32x32), tail (final_tail_kernel),
 cluster16 (conv3x3 256->256 @16x16 with GroupNorm finished in the launch), ws (to_out 1x1 128->128 + bias + residual @32x32,
 weights-stationary kernel), fold (attn_fold_kernel), halo32 (wgrad3x3_halo32_kernel), gnbig (gn_apply_kernel on the 256x256 tensor),
-c32 (conv3x3 32->32 @64x64 B=64 with the filter in registers)."""
+c32 (conv3x3 32->32 @64x64 B=64 with the filter in registers), stream (conv1x1 32->64 @64x64 B=64 with Mish' and residual: conv1x1_stream.hip)."""
 import os
 import sys
 
@@ -92,6 +92,11 @@ elif case == "c32":            # conv3x3 32->32 @64x64, 64 images + second outpu
     x, w = torch.randn(64, 64, 64, 32, device=dev), rw(32, 32)
     wp, b, ao = ops.pack_conv_weight(w), torch.zeros(32, device=dev), torch.empty(64, 64, 64, 32, device=dev)
     fn = lambda: ops.conv(ops.CONV3X3_S1, x, wp, b, mish_out=ao)
+elif case == "stream":         # conv1x1 32->64 @64x64, 64 images, x Mish'(src) + residual: the c1 input-gradient conv of the dDDPM blocks (235 MB)
+    x, w = torch.randn(64, 64, 64, 32, device=dev), rw(64, 32, 1)
+    wp, b = ops.pack_conv_weight(w), torch.zeros(64, device=dev)
+    src, res = torch.randn(64, 64, 64, 64, device=dev), torch.randn(64, 64, 64, 64, device=dev)
+    fn = lambda: ops.conv(ops.CONV1X1, x, wp, b, dmish_src=src, resid=res)
 elif case == "cluster16":
     x, w = torch.randn(B, 16, 16, 256, device=dev), rw(256, 256)
     wu, b = ops.pack_conv_weight_wino(w), torch.zeros(256, device=dev)

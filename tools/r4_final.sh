@@ -14,6 +14,7 @@ bash tools/pmc_run.sh cluster32 conv3x3_wino2_kernel downsampled-diffusion_amd/c
 bash tools/pmc_run.sh convT convT_wino_kernel downsampled-diffusion_amd/csrc/conv_wino.hip+downsampled-diffusion_amd/csrc/conv_winoT_kernel.inc r04_convT_pmc
 bash tools/pmc_run.sh wlocal8 conv3x3_gn_wlocal_kernel downsampled-diffusion_amd/csrc/conv_local.hip r04_wlocal8_pmc
 bash tools/pmc_run.sh c32 conv3x3_c32_kernel downsampled-diffusion_amd/csrc/conv_igemm.hip+downsampled-diffusion_amd/csrc/conv_c32_kernel.inc r04_c32_pmc
+bash tools/pmc_run.sh stream conv1x1_stream_kernel downsampled-diffusion_amd/csrc/conv1x1_stream.hip r04_stream_pmc
 cp gpurun_out/pmc/r04_*_pmc.json profiles/            # the bench line below reads the counter summaries of THIS tree
 timeout -k 10 500 python bench.py > $o/bench_latest.json 2> $o/bench_latest.err
 timeout -k 10 300 python tools/sample_bench.py > $o/sample_bench.txt 2>&1
