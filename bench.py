@@ -32,6 +32,7 @@ WINO_PMC = "r04_wino_pmc.json"      # committed counter summary of the timed Win
 WINO_SRC = "downsampled-diffusion_amd/csrc/conv_wino.hip+downsampled-diffusion_amd/csrc/conv_wino2_kernel.inc"   # what its hash covers
 HBM_PMC = "r03_gn_pmc.json"         # ... of the GroupNorm-apply kernel (FETCH_SIZE / WRITE_SIZE passes)
 LOCAL_PMC = "r04_wlocal8_pmc.json"  # ... of the image-local conv + GroupNorm kernel (8x8 maps)
+STREAM_PMC = "r04_stream_pmc.json"  # ... of the streaming 1x1 conv of the dDDPM encoder / decoder blocks
 
 
 def log(*a):
@@ -187,6 +188,21 @@ def time_hbm_rooflines(device):
     out.append(dict(kernel="gn_mish_resident_kernel<4,1024> (statistics + apply in one kernel; shapes whose conv splits channel chunks), "
                            "same tensor", bound="hbm", achieved=nbytes / sec / 1e9, peak=HBM_PEAK_GBPS, unit="GB/s",
                     frac=nbytes / sec / 1e9 / HBM_PEAK_GBPS, traffic=None, launch_us=sec * 1e6, algorithmic_mbytes=nbytes / 1e6))
+    # the largest memory stream of the training path: the c1 input-gradient conv of a dDDPM encoder / decoder block at 64x64x64 pixels
+    # (1x1 32 -> 64, x Mish'(src), + residual): reads dy [M][32], src and residual [M][64], writes [M][64]
+    Bs, Ss = 64, 64
+    xs1 = torch.randn(Bs, Ss, Ss, 32, device=device)
+    ws1 = ops.pack_conv_weight(torch.randn(64, 32, 1, 1, device=device) * 32 ** -0.5)
+    src1, res1, bs1 = torch.randn(Bs, Ss, Ss, 64, device=device), torch.randn(Bs, Ss, Ss, 64, device=device), torch.zeros(64, device=device)
+    sec = graph_kernel_seconds(device, lambda: ops.conv(ops.CONV1X1, xs1, ws1, bs1, dmish_src=src1, resid=res1))
+    nbytes = 4.0 * Bs * Ss * Ss * (32 + 3 * 64)
+    pm = _profile_json(STREAM_PMC, "downsampled-diffusion_amd/csrc/conv1x1_stream.hip")
+    out.append(dict(kernel="conv1x1_stream_kernel<32,64> 1x1 conv 32->64 x Mish'(src) + residual @64x64 B=64 (weights in registers, no LDS)",
+                    bound="hbm", achieved=nbytes / sec / 1e9, peak=HBM_PEAK_GBPS, unit="GB/s", frac=nbytes / sec / 1e9 / HBM_PEAK_GBPS,
+                    traffic=pm["traffic_bytes_per_launch"] if pm else None,
+                    traffic_source=f"profiles/{STREAM_PMC} (rocprofv3 --pmc: FETCH_SIZE x2 | WRITE_SIZE)" if pm else None,
+                    launch_us=sec * 1e6, algorithmic_mbytes=nbytes / 1e6))
+    del xs1, src1, res1
     Bz, S, Cz = 32, 32, 8
     xs = torch.randn(Bz, S, S, Cz, device=device)
     eps = torch.randn(Bz, S, S, Cz, device=device)
