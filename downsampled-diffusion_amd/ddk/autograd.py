@@ -359,12 +359,16 @@ class SmallNConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, weight, bias):
         ctx.save_for_backward(a, weight)
+        ctx.bias_ref = bias                    # only to find its `.grad` slot in the backward
         return ops.conv1x1_small_n(a, weight.detach(), bias.detach())
 
     @staticmethod
     def backward(ctx, dy):
         a, weight = ctx.saved_tensors
-        da, dw, db = ops.conv1x1_small_n_bwd(a, weight.detach(), _c(dy))
+        sw, sb = _grad_slot(weight), _grad_slot(ctx.bias_ref)
+        da, dw, db = ops.conv1x1_small_n_bwd(a, weight.detach(), _c(dy), acc=(sw, sb) if sw is not None and sb is not None else None)
+        if dw is None:
+            return da, None, None
         return da, dw.reshape(weight.shape), db
 
 

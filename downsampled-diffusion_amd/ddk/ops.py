@@ -1139,8 +1139,9 @@ def scale_per_sample(x, scale):
     return out
 
 
-def conv1x1_small_n_bwd(a, w, dy):
-    """-> da, dw [n_out, C], db [n_out]"""
+def conv1x1_small_n_bwd(a, w, dy, acc=None):
+    """-> da, dw [n_out, C], db [n_out].  acc = (weight.grad slot, bias.grad slot): the partial rows are summed straight INTO them
+    (two row-sum jobs, deferred with the others inside deferred_wgrad()) and (da, None, None) is returned"""
     c = a.shape[-1]
     n_out = w.shape[0]
     m = a.numel() // c
@@ -1151,6 +1152,11 @@ def conv1x1_small_n_bwd(a, w, dy):
     n = C.c_int(0)
     L.check(L.load().ddk_conv1x1_small_n_bwd(L.ptr(_f32(a)), L.ptr(w.reshape(n_out, c).contiguous()), L.ptr(_f32(dy)), L.ptr(da),
                                              L.ptr(part), max_rows, C.byref(n), m, c, n_out, L.stream()), "conv1x1_small_n_bwd")
+    if acc is not None and acc[0] is not None and acc[1] is not None:
+        flat = part.view(-1)
+        _rows_sum_targets(flat, 1, 0, n.value, rowlen, [acc[0]], n_out * c)
+        _rows_sum_targets(flat[n_out * c:], 1, 0, n.value, rowlen, [acc[1]], n_out)
+        return da, None, None
     tot = rows_sum(part, n.value, rowlen, rowlen)
     return da, tot[:n_out * c].reshape(n_out, c), tot[n_out * c:]
 
