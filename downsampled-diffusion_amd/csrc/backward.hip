@@ -834,6 +834,32 @@ __global__ __launch_bounds__(256) void sq_err_grad_kernel(const float* __restric
     }
 }
 
+// objective of the dDDPM autoencoder from the per-sample losses (see ddk_ae_objective)
+__global__ __launch_bounds__(256) void ae_objective_kernel(const float* __restrict__ l_ddpm, const float* __restrict__ l_rec,
+                                                           const int64_t* __restrict__ t, int t_rec_max, int B, float* __restrict__ out) {
+    __shared__ float red[32];
+    float a = 0.f, r = 0.f;
+    for (int b = threadIdx.x; b < B; b += 256) {
+        a += l_ddpm[b];
+        r += t[b] < t_rec_max ? l_rec[b] : 0.f;
+    }
+    const float sa = block_sum(a, red), sr = block_sum(r, red);
+    if (threadIdx.x == 0) {
+        const float latent = sa / (float)B, recon = sr / (float)B;
+        out[0] = latent + recon;
+        out[1] = latent;
+        out[2] = recon;
+    }
+}
+__global__ __launch_bounds__(256) void ae_objective_bwd_kernel(const float* __restrict__ g, const int64_t* __restrict__ t, int t_rec_max, int B,
+                                                               float* __restrict__ d_ddpm, float* __restrict__ d_rec) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= B) return;
+    const float v = g[0] / (float)B;
+    d_ddpm[b] = v;
+    d_rec[b] = t[b] < t_rec_max ? v : 0.f;
+}
+
 // out[i] = x[i] * scale[i / per]   (q_sample backward wrt x: sqrt_acp[t_b] * dy; also generic per-sample scaling)
 __global__ __launch_bounds__(256) void scale_per_sample_kernel(const float* __restrict__ x, const float* __restrict__ scale,
                                                                float* __restrict__ out, long long per4, long long total4) {
@@ -1401,6 +1427,19 @@ int ddk_sq_err_grad(const float* a, const float* b, const float* scale, float* o
     const long long total4 = B * per / 4;
     hipLaunchKernelGGL(sq_err_grad_kernel, dim3(grid_for(total4)), dim3(256), 0, as_stream(s), a, b, scale, out, per / 4, total4);
     return check_launch("sq_err_grad");
+}
+/* The dDDPM autoencoder objective of the 'simple' loss (dddpm.py:155-177) from the two per-sample losses: out[0] = obj = latent + recon,
+ * out[1] = latent = mean_b l_ddpm[b], out[2] = recon = mean_b (t[b] < t_rec_max ? l_rec[b] : 0); one workgroup, sums in index order per
+ * lane then a fixed tree (ten tiny torch launches before).  Backward: d l_ddpm[b] = g / B, d l_rec[b] = (t[b] < t_rec_max) g / B. */
+int ddk_ae_objective(const float* l_ddpm, const float* l_rec, const int64_t* t, int t_rec_max, int B, float* out, ddk_stream_t s) {
+    DDK_REQUIRE(l_ddpm && l_rec && t && out && B > 0, "ae_objective: arguments");
+    hipLaunchKernelGGL(ae_objective_kernel, dim3(1), dim3(256), 0, as_stream(s), l_ddpm, l_rec, t, t_rec_max, B, out);
+    return check_launch("ae_objective_kernel");
+}
+int ddk_ae_objective_bwd(const float* g, const int64_t* t, int t_rec_max, int B, float* d_ddpm, float* d_rec, ddk_stream_t s) {
+    DDK_REQUIRE(g && t && d_ddpm && d_rec && B > 0, "ae_objective_bwd: arguments");
+    hipLaunchKernelGGL(ae_objective_bwd_kernel, dim3((unsigned)ceil_div(B, 256)), dim3(256), 0, as_stream(s), g, t, t_rec_max, B, d_ddpm, d_rec);
+    return check_launch("ae_objective_bwd_kernel");
 }
 int ddk_scale_per_sample(const float* x, const float* scale, float* out, int B, long long per, ddk_stream_t s) {
     DDK_REQUIRE(x && scale && out && B > 0 && per > 0 && per % 4 == 0, "scale_per_sample: arguments");

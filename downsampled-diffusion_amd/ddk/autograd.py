@@ -390,6 +390,29 @@ class SqErrSumFn(torch.autograd.Function):
         return ga, gb
 
 
+class AEObjectiveFn(torch.autograd.Function):
+    """(objective, latent, recon) of DownsampleDDPMAutoencoder.losses for the 'simple' loss from the two per-sample losses [B]; the
+    objective carries the gradient, the two report values do not (the trainers only log them)."""
+
+    @staticmethod
+    def forward(ctx, l_ddpm, l_rec, t, t_rec_max):
+        out = ops.ae_objective(l_ddpm, l_rec, t, t_rec_max)
+        ctx.save_for_backward(t)
+        ctx.t_rec_max = t_rec_max
+        obj, latent, recon = out[0], out[1], out[2]
+        ctx.mark_non_differentiable(latent, recon)
+        ctx.set_materialize_grads(False)
+        return obj, latent, recon
+
+    @staticmethod
+    def backward(ctx, g, _g1, _g2):
+        (t,) = ctx.saved_tensors
+        if g is None:
+            return None, None, None, None
+        d1, d2 = ops.ae_objective_bwd(_c(g).reshape(1), t, ctx.t_rec_max)
+        return d1, d2, None, None
+
+
 class MishFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):

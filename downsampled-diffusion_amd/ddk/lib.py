@@ -189,6 +189,8 @@ SIGNATURES = {
     "ddk_avgpool2_bwd": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "ddk_upsample_nearest2_bwd": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "ddk_sq_err_grad": (_I, [_P, _P, _P, _P, _I, _LL, _P]),
+    "ddk_ae_objective": (_I, [_P, _P, _P, _I, _I, _P, _P]),
+    "ddk_ae_objective_bwd": (_I, [_P, _P, _I, _I, _P, _P, _P]),
     "ddk_scale_per_sample": (_I, [_P, _P, _P, _I, _LL, _P]),
     "ddk_conv1x1_small_n_bwd": (_I, [_P, _P, _P, _P, _P, _I, C.POINTER(C.c_int), _LL, _I, _I, _P]),
     "ddk_small_gemm_workspace_bytes": (_SZ, [_I, _I, _I, _I]),

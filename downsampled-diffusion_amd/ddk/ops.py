@@ -1097,6 +1097,22 @@ def linattn_bwd(qkv, dout, ctx, stats, heads=4):
     return dqkv
 
 
+def ae_objective(l_ddpm, l_rec, t, t_rec_max):
+    """-> [3] = (objective, latent, recon) of the dDDPM autoencoder's 'simple' loss from the per-sample losses (ddk_ae_objective)"""
+    out = torch.empty(3, device=l_ddpm.device, dtype=torch.float32)
+    L.check(L.load().ddk_ae_objective(L.ptr(_f32(l_ddpm)), L.ptr(_f32(l_rec)), t.data_ptr(), int(t_rec_max), l_ddpm.numel(), L.ptr(out),
+                                      L.stream()), "ae_objective")
+    return out
+
+
+def ae_objective_bwd(g, t, t_rec_max):
+    d1 = torch.empty(t.numel(), device=g.device, dtype=torch.float32)
+    d2 = torch.empty_like(d1)
+    L.check(L.load().ddk_ae_objective_bwd(L.ptr(_f32(g)), t.data_ptr(), int(t_rec_max), t.numel(), L.ptr(d1), L.ptr(d2), L.stream()),
+            "ae_objective_bwd")
+    return d1, d2
+
+
 def mish_bwd(x, dy):
     dx = torch.empty_like(x)
     L.check(L.load().ddk_mish_bwd(L.ptr(_f32(x)), L.ptr(_f32(dy)), L.ptr(dx), x.numel(), L.stream()), "mish_bwd")

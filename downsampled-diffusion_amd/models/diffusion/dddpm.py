@@ -97,6 +97,7 @@ class DownsampleDDPM(DDPM):
 
 
 RECON_SIDE_STREAM = True          # see DownsampleDDPMAutoencoder.losses; the tests switch it off to compare
+FUSED_OBJECTIVE = True            # idem: the objective of the 'simple' loss in one launch
 _recon_streams = {}               # device -> torch.cuda.Stream (module level: a stream must not end up in a deepcopy of the model)
 
 
@@ -113,6 +114,10 @@ class DownsampleDDPMAutoencoder(DownsampleDDPM):
         # losses are added (the latent is detached): in training on the device it runs on its own stream -- its large memory-bound
         # launches beside the UNet's small latency-bound ones.  autograd runs each backward on the stream of its forward.
         fork = RECON_SIDE_STREAM and x.is_cuda and torch.is_grad_enabled()
+        # 'simple' loss in training on the device: objective and the two report values from the per-sample losses in one launch
+        # (ddk_ae_objective) instead of where / add / three means and their autograd counterparts
+        fused = FUSED_OBJECTIVE and self.L == 'simple' and x.is_cuda and torch.is_grad_enabled()
+        recon = (lambda: self._per_sample_sq_err(x, self.rescaled_upsample(z))) if fused else (lambda: self.loss_recon(x, z, t))
         if fork:
             main = torch.cuda.current_stream()
             side = _recon_streams.get(x.device)
@@ -120,15 +125,19 @@ class DownsampleDDPMAutoencoder(DownsampleDDPM):
                 side = _recon_streams[x.device] = torch.cuda.Stream(device=x.device)
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                L_rec = self.loss_recon(x, z, t)
+                L_rec = recon()
         else:
-            L_rec = self.loss_recon(x, z, t)
+            L_rec = recon()
         z = z.detach()
         eps = torch.randn_like(z)
         z_t = self.q_sample(z, t, eps)
         eps_hat = self.latent_model(z_t, t)
-        L_ddpm = self.loss_ddpm(eps, eps_hat, t)
+        L_ddpm = self._per_sample_sq_err(eps, eps_hat) if fused else self.loss_ddpm(eps, eps_hat, t)
         if fork:
             main.wait_stream(side)
+        if fused:
+            from ddk import autograd as AG
+            obj, latent, rec = AG.AEObjectiveFn.apply(L_ddpm, L_rec, t.contiguous(), int(self.t_rec_max))
+            return obj, {'latent': latent, 'recon': rec}
         obj = (L_ddpm + L_rec).mean()
         return obj, {'latent': L_ddpm.mean(), 'recon': L_rec.mean()}

@@ -522,6 +522,11 @@ int ddk_mish_bwd(const float* x, const float* dy, float* dx, long long n, ddk_st
 int ddk_tanh_bwd(const float* y, const float* dy, float* dx, long long n, ddk_stream_t s);
 int ddk_avgpool2_bwd(const float* dy, float* dx, int B, int H, int W, int C, ddk_stream_t s);
 int ddk_upsample_nearest2_bwd(const float* dy, float* dx, int B, int H, int W, int C, ddk_stream_t s);
+/* round 4: the dDDPM autoencoder objective of the 'simple' loss (dddpm.py:155-177) from the two per-sample losses in ONE launch:
+ * out[0] = latent + recon, out[1] = latent = mean_b l_ddpm[b], out[2] = recon = mean_b (t[b] < t_rec_max ? l_rec[b] : 0); and its
+ * backward d l_ddpm[b] = g[0] / B, d l_rec[b] = (t[b] < t_rec_max) g[0] / B */
+int ddk_ae_objective(const float* l_ddpm, const float* l_rec, const int64_t* t, int t_rec_max, int B, float* out, ddk_stream_t s);
+int ddk_ae_objective_bwd(const float* g, const int64_t* t, int t_rec_max, int B, float* d_ddpm, float* d_rec, ddk_stream_t s);
 int ddk_sq_err_grad(const float* a, const float* b, const float* scale, float* out, int B, long long per,
                     ddk_stream_t s);
 int ddk_scale_per_sample(const float* x, const float* scale, float* out, int B, long long per, ddk_stream_t s);

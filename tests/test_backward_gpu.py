@@ -414,6 +414,38 @@ def test_reconstruction_branch_on_its_own_stream_is_bit_identical():
         assert torch.equal(a, b)
 
 
+def test_fused_autoencoder_objective_matches_the_torch_expression():
+    """ddk_ae_objective / AEObjectiveFn: objective, report values and every gradient of DownsampleDDPMAutoencoder.losses == the
+    where / add / mean expression of dddpm.py:155-177 (samples on both sides of t_rec_max)."""
+    from models.diffusion import dddpm as D
+    model, xshape, eshape = _g6_model("dddpm_ae")
+    x = syn.synthetic_input(xshape, "obj.x").to(DEV)
+    tt = torch.tensor([0, 40, 500, 999], device=DEV)
+    assert int((tt < model.t_rec_max).sum()) not in (0, 4)
+    eps = syn.synthetic_normal(eshape, "obj.eps").to(DEV)
+    model.t_sample = lambda n: tt
+    def run(fused):
+        D.FUSED_OBJECTIVE = fused
+        orig = torch.randn_like
+        torch.randn_like = lambda z: eps
+        try:
+            for p in model.parameters():
+                p.grad = None
+            obj, extra = model(x)
+            obj.backward()
+            torch.cuda.synchronize()
+            return [obj.detach(), extra["latent"].detach(), extra["recon"].detach()], [p.grad.clone() for p in model.parameters()]
+        finally:
+            torch.randn_like = orig
+            D.FUSED_OBJECTIVE = True
+    v0, g0 = run(False)
+    v1, g1 = run(True)
+    for a, b in zip(v0, v1):
+        assert abs(float(a) / float(b) - 1) < 1e-6
+    for a, b in zip(g0, g1):
+        assert rel_err(b.cpu(), a.cpu()) < 1e-6
+
+
 def test_unet_grads_large_resolution_vs_oracle():
     """Full-resolution-style training (cfg5 shape class): 64x64 maps at 64 channels put 32768 elements in a GroupNorm
     group, i.e. the streamed large-slab kernels; 4096 pixels per sample in the linear attention.  Gradients of a
