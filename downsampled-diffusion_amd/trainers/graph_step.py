@@ -45,7 +45,8 @@ class GraphedAccumulation:
             with ops.deferred_wgrad():             # the slab reduces of this backward pass: one launch when the block ends
                 out = self.model(x)
                 obj, extra = (out[0], out[1]) if isinstance(out, tuple) else (out, None)
-                (obj / self.accumulate).backward()
+                # d(obj / accumulate): the scale goes in as the seed gradient (a division launch and its backward less; the same bits for a power of two such as the reference's 2)
+                obj.backward(torch.full_like(obj, 1.0 / self.accumulate))
             rec = [obj.detach()]
             if extra is not None:
                 rec += [extra['latent'].detach(), extra['recon'].detach()]

@@ -117,7 +117,7 @@ class TrainerDDPM(Trainer):
         with ops.deferred_wgrad():                 # the slab reduces of this backward pass: one launch when the block ends
             out = self.model(x)
             obj, extra = (out[0], out[1]) if isinstance(out, tuple) else (out, None)
-            (obj / self.gradient_accumulate_every).backward()
+            obj.backward(torch.full_like(obj, 1.0 / self.gradient_accumulate_every))    # = (obj / accumulate).backward(), two launches less
         return obj.detach(), extra
 
     def _accumulate(self):
