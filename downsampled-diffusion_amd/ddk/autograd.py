@@ -57,6 +57,9 @@ class GradHandoff:
 # The split-K slabs of a conv whose only consumer is a GroupNorm stay unreduced and the GroupNorm sums them while it loads (forward:
 # ConvGNMishFn; backward: SlabLink).  The tests switch this off to compare with the separate reduce launches, bit for bit.
 FOLD_SLABS = True
+# The gradient of a UNet skip tensor from the up path travels to the Downsample conv's input-gradient launch (its other consumer) and
+# is added in that epilogue instead of by an autograd add (same switch for the tests).
+SKIP_HANDOFF = True
 
 
 class SlabLink:
@@ -157,9 +160,10 @@ class ConvFn(torch.autograd.Function):
     """conv family on NHWC x (optionally channel-concatenated with x2), canonical (OIHW / (I,O,4,4)) weight."""
 
     @staticmethod
-    def forward(ctx, kind, x, x2, weight, bias, resid, handoff=None, resid_handoff=None):
+    def forward(ctx, kind, x, x2, weight, bias, resid, handoff=None, resid_handoff=None, take=None):
         ctx.handoff = handoff
         ctx.resid_handoff = resid_handoff     # GradHandoff that takes the residual's gradient (dy itself) to another Function's kernel
+        ctx.take = take                       # GradHandoff whose gradient (x's second consumer) the input-gradient conv adds in its epilogue
         wu = None
         if kind == ops.CONV3X3_S1:
             wu = ops.wino_weight(weight, (x.shape[0], x.shape[1], x.shape[2], x.shape[3] + (0 if x2 is None else x2.shape[3])))
@@ -179,17 +183,18 @@ class ConvFn(torch.autograd.Function):
     def backward(ctx, dy):
         x, x2, weight, bias = ctx.saved_tensors
         dy = _c(dy)
-        dx, dx2, gw, gb = _conv_backward(ctx.kind, x, x2, weight, bias, dy, ctx.needs_input_grad[1:5])
+        extra = ctx.take.take()[0] if (ctx.take is not None and SKIP_HANDOFF) else None
+        dx, dx2, gw, gb = _conv_backward(ctx.kind, x, x2, weight, bias, dy, ctx.needs_input_grad[1:5], dx_resid=extra)
         if ctx.handoff is not None and ctx.handoff.give(dx, dx2):       # the skip conv of a ResnetBlock: Block1's dgrad conv adds these
             dx = dx2 = None
         dres = dy if ctx.has_resid else None
         if dres is not None and ctx.resid_handoff is not None and ctx.resid_handoff.give(dres):
             dres = None
-        return None, dx, dx2, gw, gb, dres, None, None
+        return None, dx, dx2, gw, gb, dres, None, None, None
 
 
-def conv(kind, x, weight, bias=None, x2=None, resid=None, handoff=None, resid_handoff=None):
-    return ConvFn.apply(kind, x, x2, weight, bias, resid, handoff, resid_handoff)
+def conv(kind, x, weight, bias=None, x2=None, resid=None, handoff=None, resid_handoff=None, take=None):
+    return ConvFn.apply(kind, x, x2, weight, bias, resid, handoff, resid_handoff, take)
 
 
 class PreActConvFn(torch.autograd.Function):
@@ -266,8 +271,9 @@ class ConvGNMishFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, x2, weight, bias, gamma, beta, temb, addend, drop_p, seed, layer, groups, eps, give=None, take=None, dy_link=None,
-                dx_link=None):
+                dx_link=None, give2=None):
         ctx.give, ctx.take = give, take           # GradHandoff: `give` the addend's gradient away / `take` one into the dgrad epilogue
+        ctx.give2 = give2                         # GradHandoff that carries x2's gradient (the UNet skip) to x2's other consumer's dgrad conv
         ctx.dy_link, ctx.dx_link = dy_link, dx_link     # SlabLink: this Block's dy arrives as slabs / its dx leaves as slabs
         wu = ops.wino_weight(weight, (x.shape[0], x.shape[1], x.shape[2], x.shape[3] + (0 if x2 is None else x2.shape[3])))
         # a conv that splits k leaves its partial slabs for the GroupNorm to sum while it loads (which also writes `raw`)
@@ -304,13 +310,16 @@ class ConvGNMishFn(torch.autograd.Function):
         dadd = dy if has_add else None
         if dadd is not None and ctx.give is not None and ctx.give.give(dadd):
             dadd = None
-        return (dx, dx2, gw, gb, sums[0], sums[1], (dtemb if has_temb else None), dadd, None, None, None, None, None, None, None, None, None)
+        if dx2 is not None and ctx.give2 is not None and SKIP_HANDOFF and ctx.give2.give(dx2):
+            dx2 = None
+        return (dx, dx2, gw, gb, sums[0], sums[1], (dtemb if has_temb else None), dadd, None, None, None, None, None, None, None, None, None,
+                None)
 
 
 def conv_groupnorm_mish(x, weight, bias, gamma, beta, x2=None, temb=None, addend=None, drop_p=0.0, seed=0, layer=0, groups=8, eps=1e-5,
-                        give=None, take=None, dy_link=None, dx_link=None):
+                        give=None, take=None, dy_link=None, dx_link=None, give2=None):
     return ConvGNMishFn.apply(x, x2, weight, bias, gamma, beta, temb, addend, float(drop_p), int(seed), int(layer), groups, eps, give, take,
-                              dy_link, dx_link)
+                              dy_link, dx_link, give2)
 
 
 def groupnorm_mish(x, gamma, beta, temb=None, addend=None, drop_p=0.0, seed=0, layer=0, groups=8, eps=1e-5):

@@ -28,15 +28,15 @@ class _Seeds:
         return self.seed, self.layer
 
 
-def _block(blk, x, x2=None, temb=None, addend=None, drop_p=0.0, seeds=None, give=None, take=None, dy_link=None, dx_link=None):
+def _block(blk, x, x2=None, temb=None, addend=None, drop_p=0.0, seeds=None, give=None, take=None, dy_link=None, dx_link=None, give2=None):
     conv, norm = blk.block[0], blk.block[1]
     seed, layer = seeds.next() if (seeds is not None and drop_p > 0) else (0, 0)
     return AG.conv_groupnorm_mish(x, conv.weight, conv.bias, norm.weight, norm.bias, x2=x2, temb=temb, addend=addend, drop_p=drop_p,
                                   seed=seed, layer=layer, groups=blk.groups, eps=norm.eps, give=give, take=take, dy_link=dy_link,
-                                  dx_link=dx_link)
+                                  dx_link=dx_link, give2=give2)
 
 
-def _resnet(rb, x, temb_slice, x2=None, seeds=None):
+def _resnet(rb, x, temb_slice, x2=None, seeds=None, give2=None):
     """blocks.py:105-115: h = drop(Block1(x) + shift); out = Block2(h) + res(x)"""
     p = rb.dropout.p if rb.training else 0.0
     # the gradient of the skip path reaches x (and x2) through Block1's input-gradient conv epilogue, not through an autograd add:
@@ -45,7 +45,7 @@ def _resnet(rb, x, temb_slice, x2=None, seeds=None):
     # h has one consumer (Block2's conv): its gradient may travel from that conv's input-gradient launch to Block1's GroupNorm
     # backward as unreduced split-K slabs
     link = AG.SlabLink()
-    h = _block(rb.block1, x, x2=x2, temb=temb_slice, drop_p=p, seeds=seeds, take=hand, dy_link=link)
+    h = _block(rb.block1, x, x2=x2, temb=temb_slice, drop_p=p, seeds=seeds, take=hand, dy_link=link, give2=give2)
     if isinstance(rb.res_conv, nn.Identity):
         return _block(rb.block2, h, addend=x, give=hand, dx_link=link)
     res = AG.conv(ops.CONV1X1, x, rb.res_conv.weight, rb.res_conv.bias, x2=x2, handoff=hand)
@@ -105,15 +105,19 @@ def unet_forward_autograd(unet, x, time):
         h = _resnet(rb1, h, shift(rb1), seeds=seeds)
         h = _resnet(rb2, h, shift(rb2), seeds=seeds)
         h = _attention(attn, h)
-        skips.append(h)
+        # the skip tensor has two consumers: the Downsample conv here and the up path's first Block; the latter's gradient is added by the
+        # former's input-gradient launch (the last level has no Downsample: autograd adds there)
+        carry = None if isinstance(down, nn.Identity) else AG.GradHandoff()
+        skips.append((h, carry))
         if not isinstance(down, nn.Identity):
-            h = AG.conv(ops.CONV3X3_S2, h, down.conv.weight, down.conv.bias)
+            h = AG.conv(ops.CONV3X3_S2, h, down.conv.weight, down.conv.bias, take=carry)
     h = _resnet(unet.mid_block1, h, shift(unet.mid_block1), seeds=seeds)
     h = _attention(unet.mid_attn, h)
     h = _resnet(unet.mid_block2, h, shift(unet.mid_block2), seeds=seeds)
     for lvl in unet.ups:
         rb1, rb2, attn, up = lvl
-        h = _resnet(rb1, h, shift(rb1), x2=skips.pop(), seeds=seeds)
+        skip, carry = skips.pop()
+        h = _resnet(rb1, h, shift(rb1), x2=skip, seeds=seeds, give2=carry)
         h = _resnet(rb2, h, shift(rb2), seeds=seeds)
         h = _attention(attn, h)
         h = AG.conv(ops.CONVT4X4_S2, h, up.conv.weight, up.conv.bias)

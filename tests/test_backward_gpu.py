@@ -668,8 +668,9 @@ def test_unet_training_with_slab_folds_is_bit_identical():
     x = syn.synthetic_normal((16, 16, 16, 8), "fold.x").to(DEV)
     t = (torch.arange(16, device=DEV) * 61) % 1000
     from ddk import ops
-    def run(fold, side=False):
+    def run(fold, side=False, skip=True):
         AG.FOLD_SLABS = fold
+        AG.SKIP_HANDOFF = skip
         ops.WGRAD_SIDE_STREAM = side
         try:
             for p in u.parameters():
@@ -683,6 +684,7 @@ def test_unet_training_with_slab_folds_is_bit_identical():
             return loss.detach().clone(), [p.grad.clone() for p in u.parameters()]
         finally:
             AG.FOLD_SLABS = True
+            AG.SKIP_HANDOFF = True
             ops.WGRAD_SIDE_STREAM = True
     l0, g0 = run(False)
     l1, g1 = run(True)
@@ -693,6 +695,11 @@ def test_unet_training_with_slab_folds_is_bit_identical():
     l2, g2 = run(True, side=True)
     assert torch.equal(l0, l2)
     for a, b in zip(g0, g2):
+        assert torch.equal(a, b)
+    # the up path's gradient of a skip tensor added by the Downsample conv's input-gradient launch == added by autograd
+    l3, g3 = run(True, skip=False)
+    assert torch.equal(l0, l3)
+    for a, b in zip(g0, g3):
         assert torch.equal(a, b)
     link = AG.SlabLink()
     ph = link.put(torch.zeros(2, 1, 4, 4, 32, device=DEV))
