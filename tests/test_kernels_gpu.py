@@ -442,6 +442,16 @@ def test_conv_argument_errors(ops):
     x = torch.zeros(1, 4, 4, 48, device=DEV)
     with pytest.raises(DDKError):
         ops.conv(ops.CONV1X1, x, torch.zeros(32, 1, 64, device=DEV))      # c0 not a multiple of 32
+    # the im2col copy of a filter may be omitted only where the Winograd copy is given AND the launch takes that path
+    x = torch.randn(2, 8, 8, 64, device=DEV)
+    w = torch.randn(64, 64, 3, 3, device=DEV) * 0.05
+    wu = ops.pack_conv_weight_wino(w)
+    ref = ops.conv(ops.CONV3X3_S1, x, ops.pack_conv_weight(w), None, n_out=64, w_wino=wu)
+    assert torch.equal(ops.conv(ops.CONV3X3_S1, x, None, None, n_out=64, w_wino=wu), ref)
+    with pytest.raises(DDKError):
+        ops.conv(ops.CONV3X3_S1, x, None, None, n_out=64, w_wino=wu, pre_mish=True)       # pre_mish lives on the im2col kernels
+    with pytest.raises(DDKError):
+        ops.conv(ops.CONV3X3_S1, torch.randn(2, 7, 7, 64, device=DEV), None, None, n_out=64, w_wino=wu)   # odd map: not Winograd-eligible
 
 
 # ---------------------------------------------------------------- norms
