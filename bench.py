@@ -10,6 +10,8 @@ Synthetic: closed-form weights (utils/synthetic.py), x_T and per-step noise from
     python bench.py --gpus 1 --steps 200 --warmup 10
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N ...            # no launcher: this file starts the N rank processes itself (launch_ranks)
+    python bench.py --gpus N --train-dp     # data-parallel training line: cfg5 optimiser step with the C2 gradient all-reduce
 
 Rank 0 prints ONE JSON line on stdout; diagnostics go to stderr.
 """
@@ -29,6 +31,7 @@ import torch  # noqa: E402
 FP32_PEAK_TFLOPS = 157.3      # MI355X fp32 matrix = vector peak (MI355X_MICROARCH.md, chip-level parameters)
 T_STEPS = 1000
 WINO_PMC = "r04_wino_pmc.json"      # committed counter summary of the timed Winograd kernel (tools/pmc_summary.py)
+CLUSTER_PMC = "r04_wino_cluster32_pmc.json"   # ... of its in-launch-GroupNorm variant (three launches per step at 32x32)
 WINO_SRC = "downsampled-diffusion_amd/csrc/conv_wino.hip+downsampled-diffusion_amd/csrc/conv_wino2_kernel.inc"   # what its hash covers
 HBM_PMC = "r03_gn_pmc.json"         # ... of the GroupNorm-apply kernel (FETCH_SIZE / WRITE_SIZE passes)
 LOCAL_PMC = "r04_wlocal8_pmc.json"  # ... of the image-local conv + GroupNorm kernel (8x8 maps)
@@ -217,6 +220,71 @@ def time_hbm_rooflines(device):
     return out
 
 
+def time_conv_cluster_roofline(device):
+    """The variant of the dominant kernel that runs THREE times per step at 32x32 (the plain one above runs once): the same conv
+    with GroupNorm + Mish + time shift finished inside the launch (conv3x3_wino2_kernel<P, 0, true>: tile statistics exchanged
+    between the workgroups of an image).  Priced the same way: issued MFMA FLOPs / live launch time / fp32 MFMA peak."""
+    from ddk import ops
+    B, H, W, C, N = 32, 32, 32, 128, 128
+    g = torch.Generator(device="cpu").manual_seed(0)
+    x = torch.randn(B, H, W, C, generator=g).to(device)
+    w = (torch.randn(N, C, 3, 3, generator=g) * (C * 9) ** -0.5).to(device)
+    b, gam, bet = torch.zeros(N, device=device), torch.ones(N, device=device), torch.zeros(N, device=device)
+    temb = torch.randn(B, N, generator=g).to(device)
+    wu = ops.pack_conv_weight_wino(w)
+    from ddk import lib
+    if lib.load().ddk_conv3x3_gn_mish_cluster_ok(B, H, W, C, N, 8) <= 0:
+        return None
+    try:
+        gave_up = lib.load().ddk_debug_cluster_timeouts()          # process-wide count of exchanges that timed out
+        fn = lambda: ops.conv3x3_gn_mish_cluster(x, wu, b, gam, bet, temb=temb, check=False)   # noqa: E731
+        fn()
+        sec = graph_kernel_seconds(device, fn)
+        torch.cuda.synchronize()
+        if lib.load().ddk_debug_cluster_timeouts() != gave_up:
+            raise RuntimeError("an in-launch GroupNorm exchange gave up during the timed launches (GPU shared?)")
+    except Exception as e:   # noqa: BLE001 -- secondary figure
+        log(f"roofline_cluster: {type(e).__name__}: {e}")
+        return None
+    executed = 2.0 * (B * H * W / 4) * 16 * C * N
+    pm = _profile_json(CLUSTER_PMC, WINO_SRC)
+    src = f"profiles/{CLUSTER_PMC} (rocprofv3 --pmc, separate passes)" if pm else None
+    return dict(kernel="conv3x3_wino2_kernel<2,0,true> conv3x3 128->128 @32x32 B=32 + GroupNorm + Mish + time shift in the same launch "
+                       "(3 launches per step)", bound="mfma", achieved=executed / sec / 1e12, peak=FP32_PEAK_TFLOPS, unit="TFLOP/s",
+                frac=executed / sec / 1e12 / FP32_PEAK_TFLOPS, traffic=pm["traffic_bytes_per_launch"] if pm else None, traffic_source=src,
+                mfma_busy=pm["mfma_busy"] if pm else None, mfma_busy_source=src, launch_us=sec * 1e6, executed_gflop=executed / 1e9)
+
+
+def time_b192(model, plan, tables, device, rank, fence, steps=24):
+    """Secondary figure at the batch the reference's sampler CLI defaults to (generate_model_samples.py:16: batch_size = 192):
+    `steps` timed reverse steps + the x3 decoder at B = 192, extrapolated like the headline value."""
+    from ddk import ops
+    B, C, S = 192, 8, 32
+    try:
+        with torch.no_grad():
+            x = ops.randn((B, S, S, C), device, seed=99, step=T_STEPS, stream_id=rank)
+            plan.sample_nhwc(x, tables, T_STEPS - 1, T_STEPS - 20, seed=99, stream_id=rank, use_graph=True)
+            img = model.rescaled_upsample(ops.nhwc_to_nchw(x))
+            fence()
+            t0 = time.perf_counter()
+            plan.sample_nhwc(x, tables, T_STEPS - 1, T_STEPS - steps, seed=99, stream_id=rank, use_graph=True)
+            torch.cuda.synchronize()
+            t_step = (time.perf_counter() - t0) / steps
+            t1 = time.perf_counter()
+            img = model.rescaled_upsample(ops.nhwc_to_nchw(x))
+            torch.cuda.synchronize()
+            t_dec = time.perf_counter() - t1
+            ok = bool(torch.isfinite(img).all()) and tuple(img.shape) == (B, 3, 256, 256)
+            del img, x
+        torch.cuda.empty_cache()
+        assert ok
+        return {"batch_per_gpu": B, "ms_per_step": t_step * 1e3, "decode_ms": t_dec * 1e3, "steps": steps,
+                "value": B / (T_STEPS * t_step + t_dec)}
+    except Exception as e:   # noqa: BLE001 -- secondary figure: report the failure, keep the headline line
+        log(f"B=192 secondary figure failed: {type(e).__name__}: {e}")
+        return None
+
+
 def usable_cores():
     """Host cores this process may actually use: affinity mask capped by the cgroup CPU quota (a 1-GPU box
     shows all 256 hardware threads in os.cpu_count() but grants a 16-core share)."""
@@ -233,7 +301,7 @@ def usable_cores():
 
 def cpu_baseline(cfg, state_dict, batch):
     """The CPU oracle (torch-CPU restatement, pinned to the reference by tests/golden) timed on the host cores on the SAME
-    work the GPU line measures: the cfg4 UNet step at the full batch (1 warm-up + 2 timed steps, extrapolated to T=1000)
+    work the GPU line measures: the cfg4 UNet step at the full batch (1 warm-up + 3 timed steps, extrapolated to T=1000)
     plus one pass of the x3 ConvResNet decoder + tanh at the full batch."""
     from oracle import resampler_ref as R
     from oracle import unet_ref as U
@@ -247,7 +315,7 @@ def cpu_baseline(cfg, state_dict, batch):
     with torch.no_grad():
         U.unet_forward(sd, cfg, x, t)
         t0 = time.perf_counter()
-        reps = 2
+        reps = 3          # 1 warm-up + >= 3 timed UNet steps
         for _ in range(reps):
             U.unet_forward(sd, cfg, x, t)
         dt = (time.perf_counter() - t0) / reps
@@ -301,24 +369,258 @@ def train_step_ms(device, steps=5):
                         "input-gradient convs of eligible shapes run as Winograd, so the FLOPs issued are lower than this"}
 
 
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` with N > 1 and no launcher in front (WORLD_SIZE unset): start the N rank processes here.
+
+    This parent NEVER touches the GPU (no torch.cuda call that initialises HIP, no libddk load): it only counts devices, picks a
+    free rendezvous port, starts N fresh children of this file with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set (one process per
+    GPU, child r bound to cuda:r), relays rank 0's JSON line to stdout (everything else of the children goes to stderr) and exits
+    non-zero when any child fails or the job exceeds DDK_BENCH_TIMEOUT seconds -- the remaining children are then killed by the
+    exact process groups started here.  Nothing is ever re-exec'd."""
+    import signal
+    import socket
+    import subprocess
+    import threading
+    n = args.gpus
+    same = bool(os.environ.get("DDK_BENCH_SAME_DEVICE"))
+    have = torch.cuda.device_count()           # counting devices does not initialise the GPU
+    if have < n and not same:
+        log(f"bench.py: --gpus {n} but only {have} GPU(s) visible (one process per GPU over RCCL); "
+            "DDK_BENCH_SAME_DEVICE=1 rehearses N ranks on cuda:0 over gloo")
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    base = dict(os.environ, WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # the host driver only supports dmabuf IPC (RCCL between processes)
+    timeout = float(os.environ.get("DDK_BENCH_TIMEOUT", "1500"))
+    procs, lines = [], []
+    for r in range(n):
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env, text=True,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, start_new_session=True))
+
+    def relay():
+        for ln in procs[0].stdout:
+            lines.append(ln)
+    th = threading.Thread(target=relay, daemon=True)
+    th.start()
+
+    def kill_all():
+        for p in procs:
+            if p.poll() is None:
+                try:
+                    os.killpg(p.pid, signal.SIGKILL)       # the session this function started for exactly that child
+                except OSError:
+                    pass
+        for p in procs:
+            try:
+                p.wait(timeout=30)
+            except Exception:   # noqa: BLE001
+                pass
+
+    deadline = time.monotonic() + timeout
+    rc = 0
+    try:
+        while True:
+            codes = [p.poll() for p in procs]
+            bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+            if bad:
+                log(f"bench.py: rank {bad[0][0]} exited with code {bad[0][1]}; stopping the other ranks")
+                rc = 1
+                break
+            if all(c == 0 for c in codes):
+                break
+            if time.monotonic() > deadline:
+                log(f"bench.py: the {n}-rank job exceeded DDK_BENCH_TIMEOUT = {timeout:.0f} s; stopping it")
+                rc = 3
+                break
+            time.sleep(0.2)
+    finally:
+        kill_all()
+    th.join(timeout=10)
+    out = [ln for ln in lines if ln.lstrip().startswith("{")]
+    for ln in lines:
+        if ln not in out:
+            sys.stderr.write(ln)
+    if rc == 0 and not out:
+        log("bench.py: rank 0 printed no JSON line")
+        rc = 4
+    if rc == 0:
+        sys.stdout.write(out[-1])
+        sys.stdout.flush()
+    return rc
+
+
+def rank_report(device, world, payload):
+    """What the line says about the job's ranks, learnt over the process group itself: a REAL all-reduce of (rank + 1) must sum
+    to world (world + 1) / 2 -- `rccl_world` is the group size that all-reduce ran over -- and every rank's own figures
+    (`payload`: ms per step, the in-launch GroupNorm option it ended with, its device) are gathered, not assumed from rank 0."""
+    import torch.distributed as dist
+    tok = torch.tensor([float(dist.get_rank() + 1)], device=device, dtype=torch.float64)
+    dist.all_reduce(tok, op=dist.ReduceOp.SUM)
+    w = dist.get_world_size()
+    if abs(float(tok[0]) - w * (w + 1) / 2) > 1e-9:
+        raise RuntimeError(f"all-reduce over {w} ranks summed to {float(tok[0])}, expected {w * (w + 1) / 2}")
+    box = [None] * w
+    dist.all_gather_object(box, payload)
+    return {"rccl_world": w if dist.get_backend() == "nccl" else None, "world": w, "backend": dist.get_backend(), "ranks": box}
+
+
+def cfg5_train():
+    """BASELINE.json config 5 as train.py builds it (reference train.py:19-46 + -d celeba_hq -bs 8 -is 256): the full-resolution DDPM"""
+    return dict(model="ddpm", dataset="celeba_hq", batch_size=8, image_size=256, n_steps=10 ** 9, lr=2e-4, unet_chan=128,
+                unet_dims=(1, 2, 2, 2), unet_dropout=0.1, T=T_STEPS, loss_type="simple", beta_schedule="linear", ema_decay=0.995,
+                loss_flat="sum", val_split=0, n_downsamples=0, n_samples=4, rnd_flip=False)
+
+
+def cfg3_train():
+    return dict(model="dddpm", dataset="celeba", batch_size=64, image_size=64, n_steps=10 ** 9, lr=2e-4, unet_chan=128,
+                unet_dims=(1, 2, 2, 2), unet_dropout=0.1, T=T_STEPS, loss_type="simple", beta_schedule="linear", ema_decay=0.995,
+                loss_flat="sum", val_split=0, n_downsamples=2, n_samples=4, rnd_flip=False, d_mode="convolutional_res",
+                u_mode="convolutional_res", d_dropout=0, d_chans=64, d_n_blocks=3, u_n_blocks=3, unet_in=8, ae_loss=True,
+                t_rec_max=100, force_latent=True)
+
+
+def train_dp(args, rank, world, device, dist_on, fence):
+    """--train-dp: the data-parallel training line (BASELINE.json config 5: 256x256 DDPM, -bs 8 per GPU; reference loop
+    trainers/trainer_ddpm.py:113-158).  Every rank is ONE product trainer (trainers.setup_trainer: model build, C1 weight broadcast,
+    FusedAdam on the flat buckets); a step = TrainerDDPM._accumulate (2 micro-batches of 8, captured device graph) ->
+    optimizer_step (C2: ONE all-reduce of the flat fp32 gradient bucket, then clip + Adam) -> update_ema.  Inputs are synthetic
+    batches resident in HBM.  Timed three ways over K steps each: the whole step, the step with the all-reduce skipped, and the
+    all-reduce of the bucket alone."""
+    import torch.distributed as dist
+    from parallel import all_reduce_flat_
+    from trainers import setup_trainer
+    from trainers.trainer_ddpm import _invalidate
+    cfg = {"cfg5": cfg5_train, "cfg3": cfg3_train}[args.train_config]()
+    if args.train_batch:
+        cfg["batch_size"] = args.train_batch
+    if args.train_image_size:
+        cfg["image_size"] = args.train_image_size
+    trainer, cfg = setup_trainer(cfg, True, None, "bench_dp", seed=0)
+    B, S = cfg["batch_size"], cfg["image_size"]
+    g = torch.Generator(device="cpu").manual_seed(4321 + rank)
+    pool = [((torch.rand((B, 3, S, S), generator=g) * 2 - 1).to(device), 0) for _ in range(4)]
+
+    def resident():
+        while True:
+            yield from pool
+    trainer.train_loader = resident()
+    opt = trainer.opt
+
+    def step(allreduce=True):
+        trainer.model.train()
+        trainer._accumulate()
+        if allreduce:
+            trainer.optimizer_step()
+        else:
+            opt.step()
+            opt.zero_grad()
+            _invalidate(trainer.model)
+        if trainer.use_ema:
+            trainer.update_ema()
+        trainer.step += 1
+
+    def timed(fn, k):
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            fn()
+        fence()
+        dt = (time.perf_counter() - t0) / k
+        if dist_on:
+            tm = torch.tensor([dt], device=device, dtype=torch.float64)
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+            return dt, float(tm[0])
+        return dt, dt
+
+    for _ in range(max(args.warmup, 2)):          # the first call captures the accumulation graph
+        step()
+    own_ms, t_full = timed(step, args.steps)
+    _, t_noar = timed(lambda: step(False), args.steps)
+    bucket = opt.fp.grad
+    _, t_ar = timed(lambda: all_reduce_flat_(bucket, average=True, force=dist_on), args.steps) if dist_on else (0.0, 0.0)
+    opt.zero_grad()
+    model = trainer.model
+    if cfg["model"] == "ddpm":
+        fwd = model.latent_model.flops(B, S, S)
+    else:
+        lat = S >> cfg["n_downsamples"]
+        fwd = model.downsample.flops(B, S, S) + model.latent_model.flops(B, lat, lat) + model.upsample.flops(B, lat, lat)
+    acc = trainer.gradient_accumulate_every
+    gflop = acc * 3 * fwd / 1e9
+    info = rank_report(device, world, {"rank": rank, "device": str(device), "ms_per_step": own_ms * 1e3}) if dist_on else None
+    if rank != 0:
+        return
+    nbytes = bucket.numel() * 4
+    out = {"metric": f"training images/sec, {args.train_config} data-parallel optimiser step (gradient all-reduce included)",
+           "value": acc * B * world / t_full, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": max(args.warmup, 2),
+           "ms_per_step": t_full * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+           "data": "synthetic",
+           "config": {"workload": (f"{args.train_config}: {cfg['dataset']} {S}x{S} {cfg['model']} -downsample {cfg['n_downsamples']}, "
+                                   f"-bs {B} per GPU, one optimiser step = {acc} micro-batches of {B} (captured device graph) + ONE "
+                                   "all-reduce of the flat fp32 gradient bucket + clip + Adam + EMA, through trainers.setup_trainer / "
+                                   "TrainerDDPM.optimizer_step"),
+                      "batch_per_gpu": B, "global_batch": B * world, "accumulate": acc,
+                      "ms_per_step_no_allreduce": t_noar * 1e3, "allreduce_alone_ms": t_ar * 1e3 if dist_on else None,
+                      "grad_bucket_bytes": nbytes,
+                      "allreduce_bus_gbps": (2 * (world - 1) / world * nbytes / t_ar / 1e9) if dist_on and world > 1 and t_ar > 0 else None,
+                      "n_params": int(bucket.numel()), "graph_train": bool(trainer._graph)},
+           "roofline_train": {"kernel": "one optimiser step: forward + input-gradient + weight-gradient passes of every conv / projection "
+                                        "/ attention product, clip, Adam, EMA", "bound": "mfma", "algorithmic_gflop": gflop,
+                              "achieved": gflop / (t_full * 1e3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                              "frac": gflop / (t_full * 1e3) / FP32_PEAK_TFLOPS, "per": "GPU"}}
+    if info:
+        out["rccl_world"], out["dist"] = info["rccl_world"], info
+    print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 200 reverse steps; 5 optimiser steps with --train-dp)")
+    ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--batch", type=int, default=32, help="latents per GPU (cfg4: 32)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true", help="skip the secondary cfg3 training-step timing")
     ap.add_argument("--no-full-chain", action="store_true", help="skip the one full T=1000 chain + decode behind the timed steps")
+    ap.add_argument("--no-b192", action="store_true", help="skip the secondary figure at the reference CLI's default batch of 192")
+    ap.add_argument("--train-dp", action="store_true", help="data-parallel TRAINING line instead of the sampling line")
+    ap.add_argument("--train-config", choices=("cfg5", "cfg3"), default="cfg5")
+    ap.add_argument("--train-batch", type=int, default=None, help="override -bs of --train-config (tests)")
+    ap.add_argument("--train-image-size", type=int, default=None, help="override -is of --train-config (tests)")
     args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 5 if args.train_dp else 200
+    if args.warmup is None:
+        args.warmup = 2 if args.train_dp else 10
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args, sys.argv[1:]))     # the parent: no GPU call before or after this line
 
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    probe = os.environ.get("DDK_BENCH_LAUNCH_PROBE")
+    if probe:
+        # launcher self-test (tests/test_host_logic.py, no GPU): a rank reports the environment it was started with and leaves;
+        # "fail<r>" makes rank r exit 7 while the others would run for a minute, "hang" makes every rank outlive the timeout
+        if probe == f"fail{rank}":
+            sys.exit(7)
+        if probe.startswith("fail") or probe == "hang":
+            time.sleep(60)
+        if rank == 0:
+            print(json.dumps({"probe": True, "n_gpus": world, "rank": rank, "local_rank": local, "argv": sys.argv[1:],
+                              "master": [os.environ.get("MASTER_ADDR"), os.environ.get("MASTER_PORT")]}), flush=True)
+        else:
+            print(f"probe rank {rank} of {world}", flush=True)      # relayed to stderr by the parent
+        return
     if world != args.gpus:
         log(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}; using WORLD_SIZE")
-    if os.environ.get("DDK_BENCH_SAME_DEVICE"):       # rehearsal of the N>1 path on a 1-GPU box (gloo, all ranks on cuda:0)
+    same_device = bool(os.environ.get("DDK_BENCH_SAME_DEVICE"))
+    if same_device:       # rehearsal of the N>1 path on a 1-GPU box (gloo, all ranks on cuda:0)
         local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
@@ -329,11 +631,29 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        backend = os.environ.get("DDK_BENCH_BACKEND", "nccl")
+        # RCCL wants one device per rank: several ranks on cuda:0 can only rendezvous over gloo
+        backend = os.environ.get("DDK_BENCH_BACKEND", "gloo" if (same_device and world > 1) else "nccl")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist_on:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    if args.train_dp:
+        from ddk import lib
+        assert lib.load().ddk_device_ok() == 1, lib.last_error()
+        with_env = dict(LOCAL_RANK=str(local))
+        os.environ.update(with_env)              # setup_trainer binds cuda:LOCAL_RANK (0 in the same-device rehearsal)
+        train_dp(args, rank, world, device, dist_on, fence)
+        if dist_on:
+            torch.distributed.barrier()
+            torch.distributed.destroy_process_group()
+        return
 
     from ddk import lib, ops
     assert lib.load().ddk_device_ok() == 1, lib.last_error()
@@ -353,6 +673,9 @@ def main():
     B, C, S = args.batch, 8, 32
     unet = model.latent_model
     plan = unet.plan()
+    if same_device and world > 1:
+        # ranks that share one GPU cannot host a whole cluster of the in-launch GroupNorm (generate_model_samples.py does the same)
+        plan.set_option(plan.OPT_CLUSTER_GROUPNORM, 0)
     tables = model._tables()
     x = ops.randn((B, S, S, C), device, seed=1234, step=T_STEPS, stream_id=rank)
 
@@ -365,12 +688,6 @@ def main():
 
     def decode():
         return model.rescaled_upsample(ops.nhwc_to_nchw(x))
-
-    def fence():
-        torch.cuda.synchronize()
-        if dist_on:
-            torch.distributed.barrier()
-        torch.cuda.synchronize()
 
     clk_steps, clk_chain = ops.ClockProbe(device), ops.ClockProbe(device)
     with torch.no_grad():
@@ -407,11 +724,19 @@ def main():
             full_chain_s = time.perf_counter() - t2
             assert torch.isfinite(img).all()
 
+    b192 = None
+    if not args.no_b192 and not same_device:
+        b192 = time_b192(model, plan, tables, device, rank, fence)
+
+    dist_info = None
     if dist_on:
+        own = {"rank": rank, "device": str(device), "ms_per_step": elapsed / args.steps * 1e3, "decode_ms": t_decode * 1e3,
+               "full_chain_s": full_chain_s, "in_launch_groupnorm": plan._cluster, "cluster_timeouts": plan.cluster_timeouts()}
         tmax = torch.tensor([elapsed, t_decode, full_chain_s or 0.0], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         elapsed, t_decode = float(tmax[0]), float(tmax[1])
         full_chain_s = float(tmax[2]) if full_chain_s is not None else None
+        dist_info = rank_report(device, world, own)
 
     t_step = elapsed / args.steps
     images_per_sec = B * world / (T_STEPS * t_step + t_decode)
@@ -434,6 +759,7 @@ def main():
                        "shader_clock_ghz_timed_steps": clk_steps.ghz(),
                        "in_launch_groupnorm": plan._cluster},
             "roofline": roof,
+            "roofline_cluster": time_conv_cluster_roofline(device),
             "roofline_step": {"bound": "mfma", "algorithmic_gflop": flops_step / 1e9, "executed_gflop": flops_exec / 1e9,
                               "ms_per_step": t_step * 1e3, "achieved": flops_exec / t_step / 1e12, "peak": FP32_PEAK_TFLOPS,
                               "unit": "TFLOP/s", "frac": flops_exec / t_step / 1e12 / FP32_PEAK_TFLOPS,
@@ -453,6 +779,15 @@ def main():
             if not out["config"]["full_chain_agrees_within_3pct"]:
                 log(f"WARNING: the full T={T_STEPS} chain ({vfc:.2f} images/s) and the value extrapolated from {args.steps} timed steps "
                     f"({images_per_sec:.2f}) differ by more than 3 %")
+        if dist_info:
+            ms = [r["ms_per_step"] for r in dist_info["ranks"]]
+            out["rccl_world"] = dist_info["rccl_world"]
+            out["dist"] = dist_info
+            out["config"]["ms_per_step_min_rank"], out["config"]["ms_per_step_max_rank"] = min(ms), max(ms)
+            out["config"]["in_launch_groupnorm_per_rank"] = [r["in_launch_groupnorm"] for r in dist_info["ranks"]]
+        if b192:
+            out["value_b192"] = b192["value"] * world
+            out["config"]["b192"] = b192
         if world == 1 and not args.no_train:
             try:
                 out["config"]["train_step_ms_cfg3_bs64"], out["roofline_train"] = train_step_ms(device)

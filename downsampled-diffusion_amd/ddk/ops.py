@@ -32,7 +32,26 @@ _pack_cache = {}              # (tag, data_ptr, shape) -> _PackEntry
 _weights_epoch = [0]
 _pack_table = {}              # "keys": tuple of cache keys in table order, "dev": device table (uint8), "n", "blocks"
 pack_stats = {"single": 0, "batched_launches": 0, "batched_jobs": 0}
-_graph_tables = []            # device tables that a captured graph reads (job tables, multi_add tables): never freed
+_graph_tables = []            # what captured launches point at when no owner is registered (kept for the process' life)
+_graph_keep = [_graph_tables]  # innermost registered owner list last; graph_owner() pushes the capturing object's own list
+
+
+class graph_owner:
+    """`with ops.graph_owner(keep):` around a stream capture: every buffer a captured launch of this module addresses through a
+    device-side table -- the job table of ddk_pack_jobs AND the weights / kernel-layout copies its jobs read and write, multi_add
+    tables -- is appended to `keep`.  The object that owns the captured graph keeps that list for as long as it may replay, so a
+    replay never writes through memory another model (or a replaced cache entry) has given back; when the graph goes, so do they."""
+
+    def __init__(self, keep):
+        self.keep = keep
+
+    def __enter__(self):
+        _graph_keep.append(self.keep)
+        return self.keep
+
+    def __exit__(self, *exc):
+        _graph_keep.remove(self.keep)
+        return False
 
 
 def weights_changed():
@@ -98,7 +117,9 @@ def _repack_stale():
         tab.clear()
         tab.update(keys=keys, dev=host.to(live[0][1].device), n=len(keys), blocks=int(blocks))
     if torch.cuda.is_current_stream_capturing():
-        _graph_tables.append(tab["dev"])        # a captured launch reads this table at every replay: it must outlive the cache
+        # a captured launch reads this table at every replay and writes through the addresses in it: the graph's owner keeps the
+        # table, every source weight and every destination copy alive (the cache may drop or replace its entries meanwhile)
+        _graph_keep[-1].append((tab["dev"], [(w, e.out) for e, w in live]))
     L.check(L.load().ddk_pack_jobs(tab["dev"].data_ptr(), tab["n"], tab["blocks"], L.stream()), "pack_jobs")
     pack_stats["batched_launches"] += 1
     pack_stats["batched_jobs"] += len(keys)
@@ -446,11 +467,14 @@ def conv3x3_gn_mish_cluster(x, w_wino, bias, gamma, beta, x2=None, temb=None, ad
     return out
 
 
-def cluster_check(workspace_tag_device, b):
-    """ddk_conv3x3_gn_mish_cluster_check on the scratch the wrapper above used on `workspace_tag_device` (a torch device)."""
-    ws = _scratch.get((str(workspace_tag_device), "cluster"))
-    if ws is not None:
-        L.check(L.load().ddk_conv3x3_gn_mish_cluster_check(L.ptr(ws), b, L.stream()), "conv3x3_gn_mish_cluster")
+def cluster_check(device, b):
+    """ddk_conv3x3_gn_mish_cluster_check on the scratch the wrapper above used on `device` (a tensor's .device) and the current
+    stream: raises DDKError if any launch since the last check gave up, and if no such scratch exists (nothing to check is an
+    error in a timing loop, not a pass)."""
+    ws = _scratch.get((str(device), "cluster", torch.cuda.current_stream().cuda_stream))
+    if ws is None:
+        raise L.DDKError(f"cluster_check: no cluster workspace on {device} for the current stream")
+    L.check(L.load().ddk_conv3x3_gn_mish_cluster_check(L.ptr(ws), b, L.stream()), "conv3x3_gn_mish_cluster")
 
 
 class ClockProbe:
@@ -1021,7 +1045,7 @@ def multi_add_(src, segments):
         host = torch.tensor([[int(o), d.data_ptr(), d.numel()] for o, d in segments], dtype=torch.int64)
         tab = _multi_add_tables[key] = host.to(src.device)
     if torch.cuda.is_current_stream_capturing():
-        _graph_tables.append(tab)
+        _graph_keep[-1].append((tab, [d for _, d in segments]))
     L.check(L.load().ddk_multi_add(L.ptr(src), tab.data_ptr(), len(segments), max(d.numel() for _, d in segments), L.stream()), "multi_add")
 
 

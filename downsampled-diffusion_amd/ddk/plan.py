@@ -36,6 +36,7 @@ class UnetPlan:
         self._ws = {}          # (kind, nbytes, device) -> tensor; sampler workspaces are kept (LRU of 3): cached graphs point into them
         self._state = {}       # chain state x per (shape, device): a stable address for the captured sampler graph
         self._cluster = 1      # DDK_OPT_CLUSTER_GROUPNORM as last set (the library's default is 1: sampler only)
+        self._cluster_dev = None   # whether THIS device can host the in-launch GroupNorm at all (asked once, at the first chain)
 
     def __deepcopy__(self, memo):
         return None     # a copied module (EMA) builds its own native plan on first use
@@ -185,8 +186,13 @@ class UnetPlan:
         if mode["buf"] is not None:
             mode["buf"].copy_(x)
             x = mode["buf"]
-        # the in-launch GroupNorm can fail (loudly) when the GPU is shared: keep x_T so the chain can be rerun without it
-        x_start = x.clone() if self._cluster >= 1 else None
+        # the in-launch GroupNorm can fail (loudly) when the GPU is shared: keep x_T so the chain can be rerun without it.  On a
+        # device that never takes that path (masked / partitioned: no launch is issued, csrc/unet_plan.hip gates on the same
+        # device test) there is nothing to check: no clone of x_T, no stream wait behind the chain
+        if self._cluster_dev is None:
+            self._cluster_dev = lib.ddk_conv3x3_gn_mish_cluster_ok(32, 32, 32, 128, 128, 8) > 0
+        guard = self._cluster >= 1 and self._cluster_dev
+        x_start = x.clone() if guard else None
 
         def call(stream_ptr):
             a = L.SamplerArgs(self.handle, L.ptr(self.packed), L.ptr(x), L.ptr(noise), L.ptr(tables["c_recip"]),
@@ -204,11 +210,11 @@ class UnetPlan:
                 side.wait_stream(cur)
                 with torch.cuda.stream(side):
                     call(side.cuda_stream)
-                    failed = self._cluster >= 1 and self._cluster_failed(ws, b, h, w, side.cuda_stream)
+                    failed = guard and self._cluster >= 1 and self._cluster_failed(ws, b, h, w, side.cuda_stream)
                 cur.wait_stream(side)
                 return failed
             call(L.stream())
-            return self._cluster >= 1 and self._cluster_failed(ws, b, h, w, L.stream())
+            return guard and self._cluster >= 1 and self._cluster_failed(ws, b, h, w, L.stream())
 
         if run():
             x.copy_(x_start)

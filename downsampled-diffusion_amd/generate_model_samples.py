@@ -51,7 +51,10 @@ def main():
         local = 0
     # ranks that share one GPU (the gloo rehearsal above, or a launcher that maps several ranks onto one device) cannot host a whole
     # cluster of the in-launch GroupNorm: switch that path off up front instead of waiting for its first (loud) give-up
-    shared_gpu = world > 1 and int(os.environ.get("LOCAL_WORLD_SIZE", str(world))) > torch.cuda.device_count()
+    shared_gpu = world > 1 and (int(os.environ.get("LOCAL_RANK", "0")) >= torch.cuda.device_count()
+                                or int(os.environ.get("LOCAL_WORLD_SIZE", "0")) > torch.cuda.device_count())
+    if shared_gpu:
+        print(f"[rank {rank}] several ranks share one GPU: the in-launch GroupNorm is switched off", flush=True)
     torch.cuda.set_device(local)
     device = f"cuda:{local}"
 

@@ -2,6 +2,8 @@
 decoded by a ConvResNet decoder (reference models/diffusion/dddpm.py:11-177).  Same constructor and
 return conventions: ``sample`` -> (x, z), ``forward`` -> (objective, {'latent', 'recon'}).
 """
+import math
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -137,7 +139,7 @@ class DownsampleDDPMAutoencoder(DownsampleDDPM):
             main.wait_stream(side)
         if fused:
             from ddk import autograd as AG
-            obj, latent, rec = AG.AEObjectiveFn.apply(L_ddpm, L_rec, t.contiguous(), int(self.t_rec_max))
+            obj, latent, rec = AG.AEObjectiveFn.apply(L_ddpm, L_rec, t.contiguous(), math.ceil(self.t_rec_max))    # t < t_rec_max for integer t, also for a fractional setting
             return obj, {'latent': latent, 'recon': rec}
         obj = (L_ddpm + L_rec).mean()
         return obj, {'latent': L_ddpm.mean(), 'recon': L_rec.mean()}

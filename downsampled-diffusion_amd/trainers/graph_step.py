@@ -35,6 +35,7 @@ class GraphedAccumulation:
         self.graph = None
         self.static_x = None
         self.outputs = None
+        self._keep = []        # buffers the captured launches address through device tables (ddk.ops.graph_owner)
 
     def _run(self):
         from ddk import ops
@@ -67,8 +68,10 @@ class GraphedAccumulation:
         cur.wait_stream(side)
         torch.cuda.synchronize()
         _invalidate(self.model)
+        from ddk import ops
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        self._keep.clear()
+        with ops.graph_owner(self._keep), torch.cuda.graph(self.graph):
             self.outputs = self._run()
         # mark the copies stale again (eager code refreshes them before use) and drop those allocated in the graph's private pool
         _invalidate(self.model)

@@ -161,3 +161,40 @@ def test_fix_samples_format():
     out = fix_samples(x)
     assert out.shape == (3, 8, 8, 3) and out.dtype == np.float32
     assert np.allclose(out, ref_fix(x), atol=1e-4) and out.min() == 0 and abs(out.max() - 255) < 1e-3
+
+
+def _bench(env, *argv, timeout=120):
+    import subprocess
+    import sys
+    e = dict(os.environ, **env)
+    e.pop("WORLD_SIZE", None)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], env=e, capture_output=True, text=True, timeout=timeout)
+
+
+def test_bench_starts_its_own_ranks_when_no_launcher_did():
+    """`python bench.py --gpus N` as the driver may call it (no torchrun in front): the parent -- which never touches the GPU, this
+    container has none -- starts N rank processes with the torchrun environment and relays rank 0's ONE JSON line."""
+    import json
+    p = _bench({"DDK_BENCH_SAME_DEVICE": "1", "DDK_BENCH_LAUNCH_PROBE": "1"}, "--gpus", "3", "--steps", "4")
+    assert p.returncode == 0, p.stderr[-2000:]
+    out = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(out) == 1                                      # one line on stdout, the other ranks' output went to stderr
+    line = json.loads(out[0])
+    assert line["n_gpus"] == 3 and line["rank"] == 0 and line["argv"] == ["--gpus", "3", "--steps", "4"]
+    assert line["master"][0] == "127.0.0.1" and int(line["master"][1]) > 0
+    assert "probe rank 1 of 3" in p.stderr and "probe rank 2 of 3" in p.stderr
+
+
+def test_bench_launcher_fails_loudly():
+    """a rank that dies takes the job down (the others are killed, exit code non-zero), a job that outlives its limit is stopped,
+    and more ranks than GPUs is refused unless it is the same-device rehearsal"""
+    import time
+    t0 = time.monotonic()
+    p = _bench({"DDK_BENCH_SAME_DEVICE": "1", "DDK_BENCH_LAUNCH_PROBE": "fail1"}, "--gpus", "2")
+    assert p.returncode != 0 and "rank 1 exited with code 7" in p.stderr and p.stdout.strip() == ""
+    assert time.monotonic() - t0 < 40                         # rank 0 (sleeping for a minute) was killed, not waited for
+    p = _bench({"DDK_BENCH_SAME_DEVICE": "1", "DDK_BENCH_LAUNCH_PROBE": "hang", "DDK_BENCH_TIMEOUT": "2"}, "--gpus", "2")
+    assert p.returncode != 0 and "DDK_BENCH_TIMEOUT" in p.stderr
+    if not torch.cuda.is_available():
+        p = _bench({"DDK_BENCH_LAUNCH_PROBE": "1"}, "--gpus", "2")
+        assert p.returncode == 2 and "only 0 GPU(s) visible" in p.stderr

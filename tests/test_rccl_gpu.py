@@ -45,3 +45,40 @@ def test_bench_distributed_branch_over_rccl(tmp_path):
     line = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 1 and line["config"]["weights_broadcast_bytes"] > 90e6
     assert line["value"] > 1 and line["roofline"]["frac"] <= 1.0
+
+
+def _bench_unaided(tmp_path, *argv, timeout=1100):
+    """bench.py exactly as the driver may call it: no torchrun, no RANK / WORLD_SIZE in the environment"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(DDK_BENCH_SAME_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0", DDK_BENCH_TIMEOUT="1000")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], env=env, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+    assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    return json.loads(lines[0])
+
+
+def test_bench_gpus_2_launches_two_ranks_itself(tmp_path):
+    """`python bench.py --gpus 2` unaided: two rank processes (gloo, both on cuda:0 -- the only two-rank world a one-GPU box hosts),
+    C1 broadcast, per-rank figures gathered over the process group, value = both ranks' images over the slower rank's time."""
+    line = _bench_unaided(tmp_path, "--gpus", "2", "--steps", "8", "--warmup", "2", "--no-full-chain")
+    assert line["n_gpus"] == 2 and line["dist"]["world"] == 2 and line["dist"]["backend"] == "gloo"
+    assert line["rccl_world"] is None                        # gloo rehearsal: no RCCL world is claimed
+    ranks = line["dist"]["ranks"]
+    assert [r["rank"] for r in ranks] == [0, 1] and all(r["ms_per_step"] > 0 for r in ranks)
+    assert line["config"]["global_batch"] == 64 and line["config"]["weights_broadcast_bytes"] > 90e6
+    assert line["config"]["in_launch_groupnorm_per_rank"] == [0, 0]       # shared GPU: the in-launch exchange is switched off up front
+    assert abs(line["ms_per_step"] - max(r["ms_per_step"] for r in ranks)) < 1e-6
+    assert "cpu_baseline" not in line and line["value"] > 1
+
+
+def test_bench_train_dp_two_ranks(tmp_path):
+    """`python bench.py --gpus 2 --train-dp` unaided: the cfg5 optimiser step (2 micro-batches of 8 images of 256x256 per rank) through
+    trainers.setup_trainer / TrainerDDPM.optimizer_step with the C2 all-reduce of the 89 MB gradient bucket between two ranks."""
+    line = _bench_unaided(tmp_path, "--gpus", "2", "--train-dp", "--steps", "2", "--warmup", "2")
+    assert line["n_gpus"] == 2 and line["dist"]["world"] == 2 and len(line["dist"]["ranks"]) == 2
+    c = line["config"]
+    assert c["batch_per_gpu"] == 8 and c["global_batch"] == 16 and c["accumulate"] == 2 and c["graph_train"]
+    assert c["grad_bucket_bytes"] == 4 * c["n_params"] and c["n_params"] == 22254723        # SURVEY section 2: the UNet at C_in = 3 (a plain DDPM has no other parameters)
+    assert c["allreduce_alone_ms"] > 0 and line["ms_per_step"] >= c["ms_per_step_no_allreduce"] * 0.9
+    assert line["value"] == pytest.approx(2 * 8 * 2 / (line["ms_per_step"] / 1e3), rel=1e-6)

@@ -47,7 +47,7 @@ for name, H, C, N in [("128->128 @32", 32, 128, 128), ("256->256 @16", 16, 256, 
         one = lambda: ops.conv3x3_gn_mish_cluster(x, wu, bias, gam, bet, temb=temb, check=False)
         t1 = graph_time(one)
         err = float((one() - two()).abs().max())
-        ops.cluster_check("cuda", B)
+        ops.cluster_check(x.device, B)     # the unchecked eager call above used this stream's scratch
         print(f"{name:14s} two launches {t2:6.2f} us   one launch {t1:6.2f} us   max |diff| {err:.1e}", flush=True)
     else:
         print(f"{name:14s} two launches {t2:6.2f} us   (in-launch GroupNorm not eligible)", flush=True)
