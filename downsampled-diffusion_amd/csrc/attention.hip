@@ -467,7 +467,9 @@ __global__ __launch_bounds__(256) void linattn_small_qkv_kernel(const float* __r
             for (int r = 0; r < 4; ++r) xs[((wave * ROWS) + i * 16 + kq * 4 + r) * QP_PITCH + nb * 16 + m] = acc[i][nb][r];
     __syncthreads();
     // ---- sum of the 4 partials (fixed order) + folded LayerNorm -> q | k | v of the core (rows >= HW: k = -inf, q = v = 0)
-    for (int e = tid; e < 64 * 96; e += 256) {
+    // (only the ROWS rows the core reads: on a 4x4 map that is 16, not the arrays' 64 -- every phase of this kernel is a dependent
+    //  LDS pass behind a barrier, so padding rows are time, not just work)
+    for (int e = tid; e < ROWS * 96; e += 256) {
         const int row = e / 96, n = e - row * 96;
         const int sel = n >> 5, d = n & 31;             // 0: q, 1: k, 2: v
         float v = sel == 1 ? -INFINITY : 0.f;
@@ -482,7 +484,7 @@ __global__ __launch_bounds__(256) void linattn_small_qkv_kernel(const float* __r
         else vs[row * DH + d] = v;
     }
     __syncthreads();
-    linattn_small_core<64>(ks, vs, qs, cs, smax, ctx, out, b, h, HW, heads);
+    linattn_small_core<ROWS>(ks, vs, qs, cs, smax, ctx, out, b, h, HW, heads);
 }
 
 // wop[head][chunk][n block 0..5][k half][lane][j] = lnw[o][i]: o = (nb / 2) * HC + head * 32 + (nb % 2) * 16 + lane % 16 (q, k, v

@@ -46,7 +46,30 @@ struct LocalParams {
     long long addend_stride;     // order, plus addend_bias[c] (the skip conv's reduce pass folded into this load)
     const float* addend_bias;
     int ipb;                     // images per 16-row block: 1 (4x4 maps) or 4 (2x2 maps: four 4-pixel images share an M block)
+    int src_slabs;               // > 1: `src0` is still in split-K form (the stride-2 conv in front left its slabs): that many slabs,
+    long long src_stride;        // `src_stride` floats apart, summed in slab order, plus src_bias[c] -- the arithmetic and the order of
+    const float* src_bias;       // splitk_reduce_kernel, done while the image is staged (no reduce launch, no reduced tensor)
 };
+
+// One float4 of a staged source row: channels [c, c + 4) of pixel row `r` (global row index), from src0 -- plain, or the fixed-order
+// sum of its split-K slabs plus the producing conv's bias -- or from the concat's second source.
+template <typename P>
+__device__ __forceinline__ float4 staged_src4(const P& p, long long r, int c) {
+    if (c >= p.c0) return *reinterpret_cast<const float4*>(p.src1 + r * p.c1 + (c - p.c0));
+    const float* s0 = p.src0 + r * p.c0 + c;
+    float4 v = *reinterpret_cast<const float4*>(s0);
+    if (p.src_slabs > 1) {
+        for (int sl = 1; sl < p.src_slabs; ++sl) {
+            const float4 u = *reinterpret_cast<const float4*>(s0 + sl * p.src_stride);
+            v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+        }
+        if (p.src_bias) {
+            const float4 bb = *reinterpret_cast<const float4*>(p.src_bias + c);
+            v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
+        }
+    }
+    return v;
+}
 
 constexpr int LOC_PP = 36;   // pitch (floats) of a partial-accumulator row: 4 rows apart = 16 banks apart
 
@@ -207,8 +230,7 @@ __global__ __launch_bounds__(512) void conv3x3_gn_local_kernel(const LocalParams
         const long long row0 = (long long)b * MT;
         for (int i = tid; i < MT * q4; i += 512) {
             const int row = i / q4, c = (i - row * q4) << 2;
-            const float4 v = c < p.c0 ? *reinterpret_cast<const float4*>(p.src0 + (row0 + row) * p.c0 + c)
-                                      : *reinterpret_cast<const float4*>(p.src1 + (row0 + row) * p.c1 + (c - p.c0));
+            const float4 v = staged_src4(p, row0 + row, c);
             *reinterpret_cast<float4*>(lds + row * pitch + c) = v;
         }
         for (int i = tid; i < q4; i += 512) *reinterpret_cast<float4*>(lds + MT * pitch + (i << 2)) = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -370,9 +392,10 @@ struct WLocalParams {
     int addend_slabs;
     long long addend_stride;
     const float* addend_bias;
+    int src_slabs;               // as in LocalParams: src0 in split-K form, summed (+ bias) while the image is staged
+    long long src_stride;
+    const float* src_bias;
 };
-
-
 
 constexpr int WL_VP = 36;                       // V / M row pitch (floats): 16 rows cover the 64 banks once
 constexpr int WL_VBUF = 16 * 16 * WL_VP;        // one V buffer: [position][tile][36]
@@ -430,8 +453,7 @@ __global__ __launch_bounds__(1024) void conv3x3_gn_wlocal_kernel(const WLocalPar
         const long long row0 = (long long)b * 64;
         for (int i = tid; i < 64 * q4; i += 1024) {
             const int row = i / q4, c = (i - row * q4) << 2;
-            const float4 v = c < p.c0 ? *reinterpret_cast<const float4*>(p.src0 + (row0 + row) * p.c0 + c)
-                                      : *reinterpret_cast<const float4*>(p.src1 + (row0 + row) * p.c1 + (c - p.c0));
+            const float4 v = staged_src4(p, row0 + row, c);
             *reinterpret_cast<float4*>(lds + row * pitch + c) = v;
         }
         for (int i = tid; i < q4; i += 1024) *reinterpret_cast<float4*>(lds + 64 * pitch + (i << 2)) = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -629,9 +651,10 @@ bool conv_gn_wlocal_ok(int H, int W, int cin, int c0, int N, int groups) {
 
 int conv_gn_wlocal(const float* src0, int c0, const float* src1, int c1, const float* w, const float* bias, const float* gamma,
                    const float* beta, const float* temb, int temb_stride, const long long* temb_rows, const float* addend, float* out,
-                   int B, int H, int W, int N, int groups, float eps, hipStream_t st, const AddendSlabs& as) {
+                   int B, int H, int W, int N, int groups, float eps, hipStream_t st, const AddendSlabs& as, const AddendSlabs& ss) {
     DDK_REQUIRE(src0 && w && gamma && beta && out, "conv_gn_wlocal: null pointer");
     DDK_REQUIRE(as.n >= 1 && (as.n == 1 || addend), "conv_gn_wlocal: addend slabs");
+    DDK_REQUIRE(ss.n >= 1 && (ss.n == 1 || (ss.stride > 0 && ss.stride % 4 == 0 && aligned16(ss.bias))), "conv_gn_wlocal: source slabs");
     DDK_REQUIRE(B > 0 && groups > 0, "conv_gn_wlocal: B and groups must be positive");
     DDK_REQUIRE(c1 == 0 || src1, "conv_gn_wlocal: second source missing");
     DDK_REQUIRE(conv_gn_wlocal_ok(H, W, c0 + c1, c0, N, groups), "conv_gn_wlocal: shape not eligible (needs H*W == 64 with even H, W; "
@@ -639,7 +662,7 @@ int conv_gn_wlocal(const float* src0, int c0, const float* src1, int c1, const f
     DDK_REQUIRE(aligned16(src0) && aligned16(src1) && aligned16(w), "conv_gn_wlocal: sources and weights must be 16-byte aligned");
     DDK_TRY(ensure_device_init());
     WLocalParams p{src0, src1, c0, c1, w, bias, gamma, beta, temb, temb_stride, temb_rows, addend, out, H, W, N, N / groups, eps,
-                   as.n, as.stride, as.bias};
+                   as.n, as.stride, as.bias, ss.n, ss.stride, ss.bias};
     hipLaunchKernelGGL(conv3x3_gn_wlocal_kernel, dim3((unsigned)((long long)B * (N / 32))), dim3(1024), wlocal_lds_bytes(c0 + c1), st, p);
     return check_launch("conv3x3_gn_wlocal_kernel");
 }
@@ -671,9 +694,10 @@ int conv_gn_local_init_device() {
 
 int conv_gn_local(const float* src0, int c0, const float* src1, int c1, const float* w, const float* bias, const float* gamma,
                   const float* beta, const float* temb, int temb_stride, const long long* temb_rows, const float* addend, float* out,
-                  int B, int H, int W, int N, int groups, float eps, hipStream_t st, const AddendSlabs& as) {
+                  int B, int H, int W, int N, int groups, float eps, hipStream_t st, const AddendSlabs& as, const AddendSlabs& ss) {
     DDK_REQUIRE(src0 && w && gamma && beta && out, "conv_gn_local: null pointer");
     DDK_REQUIRE(as.n >= 1 && (as.n == 1 || addend), "conv_gn_local: addend slabs");
+    DDK_REQUIRE(ss.n >= 1 && (ss.n == 1 || (ss.stride > 0 && ss.stride % 4 == 0 && aligned16(ss.bias))), "conv_gn_local: source slabs");
     DDK_REQUIRE(B > 0 && groups > 0, "conv_gn_local: B and groups must be positive");
     DDK_REQUIRE(c1 == 0 || src1, "conv_gn_local: second source missing");
     DDK_REQUIRE(conv_gn_local_ok(H, W, c0 + c1, c0, N, groups), "conv_gn_local: shape not eligible (needs H*W in {16, 64}, "
@@ -684,7 +708,7 @@ int conv_gn_local(const float* src0, int c0, const float* src1, int c1, const fl
     const int ipb = HW == 4 ? 4 : 1;
     DDK_REQUIRE(B % ipb == 0, "conv_gn_local: 2x2 maps need a batch that is a multiple of 4 (four images share an M block)");
     LocalParams p{src0, src1, c0, c1, w, bias, gamma, beta, temb, temb_stride, temb_rows, addend, out, H, W, N, N / groups, eps,
-                  as.n, as.stride, as.bias, ipb};
+                  as.n, as.stride, as.bias, ipb, ss.n, ss.stride, ss.bias};
     const size_t ldsb = local_lds_bytes(HW < 16 ? 16 : HW, c0 + c1);
     const dim3 grid((unsigned)((long long)(B / ipb) * (N / 32)));
     if (HW == 4)
@@ -722,6 +746,22 @@ int ddk_pack_conv_weight_wino_local(const float* w_oihw, float* dst, int O, int 
     hipLaunchKernelGGL(pack_conv_weight_wlocal_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, as_stream(s), w_oihw,
                        dst, O, I, i_pad, total);
     return check_launch("pack_conv_weight_wlocal_kernel");
+}
+
+int ddk_conv3x3_gn_mish_slabs(const float* src, int src_slabs, long long src_stride, const float* src_bias, int c0, const float* weight,
+                              const float* bias, const float* gamma, const float* beta, const float* temb, int temb_stride,
+                              const float* addend, int addend_slabs, long long addend_stride, const float* addend_bias, float* out, int B,
+                              int H, int W, int N, int groups, float eps, ddk_stream_t s) {
+    using namespace ddk;
+    DDK_REQUIRE(src_slabs >= 1 && addend_slabs >= 1, "conv3x3_gn_mish_slabs: slab counts start at 1");
+    AddendSlabs ss, as;
+    ss.n = src_slabs; ss.stride = src_stride; ss.bias = src_slabs > 1 ? src_bias : nullptr;
+    as.n = addend_slabs; as.stride = addend_stride; as.bias = addend_slabs > 1 ? addend_bias : nullptr;
+    if (H * W == 64)
+        return conv_gn_wlocal(src, c0, nullptr, 0, weight, bias, gamma, beta, temb, temb_stride, nullptr, addend, out, B, H, W, N, groups, eps,
+                              as_stream(s), as, ss);
+    return conv_gn_local(src, c0, nullptr, 0, weight, bias, gamma, beta, temb, temb_stride, nullptr, addend, out, B, H, W, N, groups, eps,
+                         as_stream(s), as, ss);
 }
 
 int ddk_conv3x3_gn_mish_wino_ok(int H, int W, int cin, int c0, int N, int groups) {

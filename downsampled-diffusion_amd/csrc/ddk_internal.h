@@ -212,12 +212,14 @@ struct AddendSlabs {
 bool conv_gn_local_ok(int H, int W, int cin, int c0, int N, int groups);
 int conv_gn_local(const float* src0, int c0, const float* src1, int c1, const float* w, const float* bias, const float* gamma,
                   const float* beta, const float* temb, int temb_stride, const long long* temb_rows, const float* addend, float* out,
-                  int B, int H, int W, int N, int groups, float eps, hipStream_t st, const AddendSlabs& as = AddendSlabs());
+                  int B, int H, int W, int N, int groups, float eps, hipStream_t st, const AddendSlabs& as = AddendSlabs(),
+                  const AddendSlabs& src_slabs = AddendSlabs());      // src_slabs.n > 1: src0 is in split-K form (summed while staged)
 int conv_gn_local_init_device();
 bool conv_gn_wlocal_ok(int H, int W, int cin, int c0, int N, int groups);     // 64-pixel maps: the same in Winograd form
 int conv_gn_wlocal(const float* src0, int c0, const float* src1, int c1, const float* w, const float* bias, const float* gamma,
                    const float* beta, const float* temb, int temb_stride, const long long* temb_rows, const float* addend, float* out,
-                   int B, int H, int W, int N, int groups, float eps, hipStream_t st, const AddendSlabs& as = AddendSlabs());
+                   int B, int H, int W, int N, int groups, float eps, hipStream_t st, const AddendSlabs& as = AddendSlabs(),
+                   const AddendSlabs& src_slabs = AddendSlabs());
 double conv_flops(int kind, int B, int H, int W, int cin, int N);
 // norm_act.hip
 size_t groupnorm_workspace_bytes(int B, int HW, int C, int groups);

@@ -100,6 +100,7 @@ struct ddk_unet {
                                              // sync point), 2 in ddk_unet_forward too
     int cluster_limit = 1 << 30;             // diagnostic: only the first so many eligible launches of a forward take that path
     int cluster_np_max = 8;                  // largest cluster (workgroups per image and n tile) that takes the path
+    bool fold_down_reduce = true;            // Downsample conv's split-K slabs summed by the image-local ResnetBlock behind it (no reduce launch)
     bool attn_fold = true;                   // attention on maps with HW > 256, C = 128: q projection + apply + to_out as ONE per-image C x C conv
     // unet_chan % 8 == 0 but not % 32 (reference blocks.py:75 takes any GroupNorm(8, C)): every tensor keeps a pitch of pad32(C) channels
     // with zero padding, the convs run on the generic im2col kernels over zero-padded weights and the normalisations on their
@@ -405,6 +406,13 @@ extern "C" int ddk_unet_set_option(ddk_unet* u, int option, int value) {
         u->attn_fold = value != 0;
         return DDK_OK;
     }
+    if (option == DDK_OPT_FOLD_DOWNSAMPLE_REDUCE) {
+        std::lock_guard<std::mutex> lock(u->mu);
+        if (!u->graphs.empty()) DDK_HIP(hipDeviceSynchronize());
+        drop_graphs(u);
+        u->fold_down_reduce = value != 0;
+        return DDK_OK;
+    }
     if (option == 2) {   // diagnostic (not in ddk.h): cap on the cluster launches per forward
         std::lock_guard<std::mutex> lock(u->mu);
         u->cluster_limit = value;
@@ -665,10 +673,12 @@ static bool conv_gn_is_local(const ConvW& cw, int B, int H, int W, int c0, int c
 }
 
 static int run_conv_gn(Ctx& c, const ConvW& cw, const float* src0, int c0, const float* src1, int c1, float* raw, const NormW& n,
-                       const float* temb, const float* addend, float* out, int H, int W, int N, const AddendSlabs& as = AddendSlabs()) {
+                       const float* temb, const float* addend, float* out, int H, int W, int N, const AddendSlabs& as = AddendSlabs(),
+                       const AddendSlabs& ss = AddendSlabs()) {
+    if (ss.n > 1 && !conv_gn_is_local(cw, c.B, H, W, c0, c1, N)) return fail_arg("run_conv_gn: slab source on a path that cannot sum it");
     if (c.u.generic) {
         // widths that are not multiples of 32: plain conv over the zero-padded weights, then GroupNorm over the REAL channels
-        if (as.n > 1) return fail_arg("run_conv_gn: slab addend on the generic path");
+        if (as.n > 1 || ss.n > 1) return fail_arg("run_conv_gn: slab addend / source on the generic path");
         DDK_TRY(run_conv(c, DDK_CONV3X3_S1, cw, src0, c0, src1, c1, nullptr, raw, H, W, N));
         return groupnorm_mish_generic(raw, c.P + n.g, c.P + n.b, temb, c.u.temb_total, addend, out, c.B, H * W, N, n.c_real, GROUPS, GN_EPS,
                                       c.st, c.temb_rows);
@@ -677,11 +687,11 @@ static int run_conv_gn(Ctx& c, const ConvW& cw, const float* src0, int c0, const
         // 4x4 maps (and 2x2 maps, four images to a block): one image x 32 channels per workgroup, k reduced inside it -> statistics, Mish, shift and residual in the
         // conv's own epilogue, no slabs and no GroupNorm launch (conv_local.hip)
         return conv_gn_local(src0, c0, src1, c1, c.P + cw.wl, cw.has_bias ? c.P + cw.b : nullptr, c.P + n.g, c.P + n.b, temb,
-                             c.u.temb_total, c.temb_rows, addend, out, c.B, H, W, N, GROUPS, GN_EPS, c.st, as);
+                             c.u.temb_total, c.temb_rows, addend, out, c.B, H, W, N, GROUPS, GN_EPS, c.st, as, ss);
     if (cw.has_wwl && H * W == 64 && conv_gn_wlocal_ok(H, W, c0 + c1, c0, N, GROUPS))
         // 8x8 maps: the same image-local tiling in Winograd form
         return conv_gn_wlocal(src0, c0, src1, c1, c.P + cw.wwl, cw.has_bias ? c.P + cw.b : nullptr, c.P + n.g, c.P + n.b, temb,
-                              c.u.temb_total, c.temb_rows, addend, out, c.B, H, W, N, GROUPS, GN_EPS, c.st, as);
+                              c.u.temb_total, c.temb_rows, addend, out, c.B, H, W, N, GROUPS, GN_EPS, c.st, as, ss);
     if (as.n > 1) return fail_arg("run_conv_gn: slab addend on a path that cannot sum it");
     if (cw.has_wf && c.x_first && src0 == c.x_padded && !src1 && conv_first_ok(c.u.cfg.in_ch, N, H, W, GROUPS)) {
         // the network's first conv on a map too large for the one-launch first block (256x256: 512 statistics tiles per image):
@@ -755,13 +765,24 @@ static int run_gn(Ctx& c, const float* x, const NormW& n, const float* temb, con
 }
 
 // blocks.py:105-115 (eval): out = Mish(GN(conv2(Mish(GN(conv1(x))) + temb))) + res(x)
-static int run_res(Ctx& c, const ResW& r, const float* src0, int c0, const float* src1, int c1, float* out, int H, int W) {
+// ss.n > 1 (res_takes_slab_source only): src0 is the split-K slab area the stride-2 conv in front left; both its readers -- the first
+// Block's staging loop and the second Block's residual -- sum the slabs (+ that conv's bias) in splitk_reduce_kernel's order
+static bool res_takes_slab_source(const ddk_unet& u, const ResW& r, int B, int H, int W, int c0) {
+    return !u.generic && !r.has_res && conv_gn_is_local(r.c1, B, H, W, c0, 0, r.co) && conv_gn_is_local(r.c2, B, H, W, r.co, 0, r.co);
+}
+
+static int run_res(Ctx& c, const ResW& r, const float* src0, int c0, const float* src1, int c1, float* out, int H, int W,
+                   const AddendSlabs& ss = AddendSlabs()) {
     float* raw = c.W + c.ly.off_raw;
     float* a1 = c.W + c.ly.off_a1;
     float* res = c.W + c.ly.off_res;
     // the 1x1 skip first: the second conv's split-K slabs and the skip conv's would otherwise share the workspace
     const float* addend = src0;
     AddendSlabs as;
+    if (ss.n > 1) {
+        if (r.has_res || src1) return fail_arg("run_res: slab source with a skip conv or a second source");
+        as = ss;
+    }
     if (r.has_res) {
         const int rs = conv_splits(DDK_CONV1X1, c.B, H, W, c0 + c1, r.co);
         if (rs > 1 && !conv1x1_sm_ok((long long)c.B * H * W, c0, c1, r.co) && conv_gn_is_local(r.c1, c.B, H, W, c0, c1, r.co) &&
@@ -787,7 +808,7 @@ static int run_res(Ctx& c, const ResW& r, const float* src0, int c0, const float
             addend = res;
         }
     }
-    DDK_TRY(run_conv_gn(c, r.c1, src0, c0, src1, c1, raw, r.n1, c.temb + r.temb_off, nullptr, a1, H, W, r.co));
+    DDK_TRY(run_conv_gn(c, r.c1, src0, c0, src1, c1, raw, r.n1, c.temb + r.temb_off, nullptr, a1, H, W, r.co, AddendSlabs(), ss));
     return run_conv_gn(c, r.c2, a1, r.co, nullptr, 0, raw, r.n2, nullptr, addend, out, H, W, r.co, as);
 }
 
@@ -947,6 +968,7 @@ static int forward_core(const ddk_unet& u, const float* P, const float* x, int64
     int H = H0, W = W0;
     const float* cur = xpad;
     int cur_c = pad32(u.cfg.in_ch);
+    AddendSlabs cur_ss;           // > 1 slab: `cur` is the split-K area a Downsample conv left for the next ResnetBlock to sum
     for (int l = 0; l < u.L; ++l) {
         float* skip = ws + ly.off_skip[l];
         const int co = u.dimp[l + 1];
@@ -983,14 +1005,36 @@ static int forward_core(const ddk_unet& u, const float* P, const float* x, int64
                                              r.res.has_bias ? P + r.res.b : nullptr, r.ci, r.res.cin_pad));
             }
         } else {
-            DDK_TRY(run_res(c, u.down_res[2 * l], cur, cur_c, nullptr, 0, bufB, H, W));
+            DDK_TRY(run_res(c, u.down_res[2 * l], cur, cur_c, nullptr, 0, bufB, H, W, cur_ss));
+            cur_ss = AddendSlabs();
         }
         DDK_TRY(run_res(c, u.down_res[2 * l + 1], bufB, co, nullptr, 0, bufC, H, W));
         DDK_TRY(run_attn(c, u.down_attn[l], bufC, skip, H, W));
         if (l < u.L - 1) {
-            DDK_TRY(run_conv(c, DDK_CONV3X3_S2, u.down_conv[l], skip, co, nullptr, 0, nullptr, bufA, H, W, co));
-            H /= 2; W /= 2;
-            cur = bufA;
+            const int s2 = conv_splits(DDK_CONV3X3_S2, B, H, W, co, co);
+            if (u.fold_down_reduce && s2 > 1 && res_takes_slab_source(u, u.down_res[2 * l + 2], B, H / 2, W / 2, co)) {
+                // the Downsample conv splits k and the ResnetBlock behind it is image-local (8x8 / 4x4 maps, no skip conv): the conv leaves
+                // its slabs in the split-K area and that block's two readers sum them -- no reduce launch, no reduced tensor
+                ddk_conv_args a{};
+                a.kind = DDK_CONV3X3_S2;
+                a.src0 = skip; a.c0 = co;
+                a.weight = P + u.down_conv[l].w;
+                a.out = bufA;                 // unused: the slabs are the result
+                a.B = B; a.H = H; a.W = W; a.N = co;
+                a.defer_reduce = 1;
+                a.workspace = ws + ly.off_splitk;
+                a.workspace_bytes = ly.splitk * sizeof(float);
+                DDK_TRY(conv_forward(a, st));
+                cur_ss.n = s2;
+                cur_ss.stride = (long long)B * (H / 2) * (W / 2) * co;
+                cur_ss.bias = u.down_conv[l].has_bias ? P + u.down_conv[l].b : nullptr;
+                H /= 2; W /= 2;
+                cur = ws + ly.off_splitk;
+            } else {
+                DDK_TRY(run_conv(c, DDK_CONV3X3_S2, u.down_conv[l], skip, co, nullptr, 0, nullptr, bufA, H, W, co));
+                H /= 2; W /= 2;
+                cur = bufA;
+            }
         } else {
             cur = skip;
         }

@@ -591,6 +591,23 @@ def conv3x3_gn_mish_wino(x, w_wl, bias, gamma, beta, temb=None, addend=None, x2=
     return out
 
 
+def conv3x3_gn_mish_slabs(src_slabs, src_bias, w_packed, bias, gamma, beta, temb=None, addend_slabs=None, addend_bias=None, groups=GN_GROUPS,
+                          eps=GN_EPS):
+    """The one-launch Block of the 4x4 / 8x8 maps on operands still in split-K form (ddk_conv3x3_gn_mish_slabs): src_slabs [S][B][H][W][C]
+    partial sums of the input (+ src_bias[c]), addend_slabs [S'][B][H][W][N] of the residual (+ addend_bias[c]) or None.  w_packed:
+    pack_conv_weight_local (H*W == 16) / pack_conv_weight_wino_local (H*W == 64)."""
+    s_, b, h, w, c0 = src_slabs.shape
+    n = w_packed.shape[0] * 32
+    out = torch.empty((b, h, w, n), device=src_slabs.device, dtype=torch.float32)
+    stride = temb.stride(0) if temb is not None else 0
+    a_n, a_stride = (addend_slabs.shape[0], addend_slabs.stride(0)) if addend_slabs is not None else (1, 0)
+    L.check(L.load().ddk_conv3x3_gn_mish_slabs(L.ptr(_f32(src_slabs)), s_, src_slabs.stride(0), L.ptr(src_bias), c0, L.ptr(w_packed), L.ptr(bias),
+                                               L.ptr(gamma), L.ptr(beta), temb.data_ptr() if temb is not None else None, stride,
+                                               L.ptr(addend_slabs), a_n, a_stride, L.ptr(addend_bias), L.ptr(out), b, h, w, n, groups, eps,
+                                               L.stream()), "conv3x3_gn_mish_slabs")
+    return out
+
+
 def chan_layernorm(x, g, b, eps=LN_EPS):
     c = x.shape[-1]
     out = torch.empty_like(x)

@@ -179,6 +179,15 @@ int ddk_conv3x3_gn_mish_wino_ok(int H, int W, int cin, int c0, int N, int groups
 int ddk_conv3x3_gn_mish_wino(const float* src0, int c0, const float* src1, int c1, const float* weight, const float* bias,
                              const float* gamma, const float* beta, const float* temb, int temb_stride, const float* addend,
                              float* out, int B, int H, int W, int N, int groups, float eps, ddk_stream_t s);
+/* The two one-launch Blocks above (H*W == 16: `weight` = ddk_pack_conv_weight_local; H*W == 64: ddk_pack_conv_weight_wino_local) reading
+ * operands that are still in split-K form: src_slabs > 1 -- `src` is that many partial slabs of the input, src_stride floats apart
+ * (what a conv left with ddk_conv_args.defer_reduce), summed in slab order + src_bias[c] while the image is staged; addend_slabs > 1 -- the
+ * same for the residual.  Sum order and arithmetic are the split-K reduce's, so the result equals the Block of the reduced tensors bit
+ * for bit.  How the UNet plan drops the reduce launch behind a Downsample conv (blocks.py:41-47, DDK_OPT_FOLD_DOWNSAMPLE_REDUCE). */
+int ddk_conv3x3_gn_mish_slabs(const float* src, int src_slabs, long long src_stride, const float* src_bias, int c0, const float* weight,
+                              const float* bias, const float* gamma, const float* beta, const float* temb, int temb_stride,
+                              const float* addend, int addend_slabs, long long addend_stride, const float* addend_bias, float* out, int B,
+                              int H, int W, int N, int groups, float eps, ddk_stream_t s);
 /* The same Block in ONE launch on maps whose images span several 128-pixel tiles (32x32, 16x16): the Winograd conv's workgroups
  * of one image exchange their tile statistics through `workspace` and finish GroupNorm + Mish (+ temb[b][c]) (+ addend) on their own
  * tile in registers (blocks.py:75-84,110-115).  Eligible when ddk_conv3x3_gn_mish_cluster_ok() > 0: one-pass Winograd shape
@@ -328,6 +337,11 @@ int ddk_unet_forward(const ddk_unet* u, const void* packed, const float* x, cons
  * to_out run as ONE 1x1 conv of x with a per-image 128x128 matrix W_out . ctx^T . W_q (q is linear in this attention; the
  * PreNorm LayerNorm is folded in as well); 0 keeps to_qkv / context / apply / to_out.  Same result up to fp32 summation order. */
 #define DDK_OPT_ATTENTION_FOLD 3
+/* DDK_OPT_FOLD_DOWNSAMPLE_REDUCE (default 1): where a Downsample conv (blocks.py:41-47) splits its contraction and the ResnetBlock
+ * behind it runs on the image-local kernels (8x8 / 4x4 maps, no skip conv), the conv leaves its split-K slabs and that block's two
+ * readers -- the first Block's staging loop, the second Block's residual -- sum them in slab order (+ bias): no reduce launch.
+ * 0 keeps the reduce launch; bit-identical results either way. */
+#define DDK_OPT_FOLD_DOWNSAMPLE_REDUCE 5
 int ddk_unet_set_option(ddk_unet* u, int option, int value);
 /* Waits for `s`, then reads and clears the sticky give-up count of the launches issued on `workspace` (a ddk_unet_forward or
  * ddk_sampler_run workspace of this shape): DDK_OK, or DDK_ERR_CLUSTER when any in-launch GroupNorm exchange timed out. */

@@ -229,3 +229,31 @@ def test_cfg2_cifar_batch64_cin3_properties():
         part = m.p_sample_loop((8, 3, 32, 32), early_stop=990, x_T=x[40:48].contiguous(), noise=noise[:, 40:48].contiguous())
         assert (full[40:48] - part).abs().max() < 1e-4
 
+
+
+def test_sampler_default_batch_192_properties():
+    """The drop-in sampler's own default batch (reference generate_model_samples.py:16: batch_size = 192) at cfg4: 192 latents of
+    8x32x32 through a 6-step chain and the x3 decoder (its 64-channel 256x256 tensors are 3.2 GB each at this batch).  Size-independent
+    properties: the chain and the decoded images of the samples two batch compositions share are equal to those of a batch of 2 with the
+    same x_T / noise (no cross-sample coupling, reference models/diffusion/dddpm.py:76-90), and the whole run is bit-stable."""
+    from models import DownsampleDDPM, Unet
+    cfg = dddpm_cfg(128, 256, 3)
+    m = det_load(DownsampleDDPM(cfg, Unet(cfg), DEV, 3)).to(DEV).eval()
+    B, steps = 192, 6
+    shape = (B, 8, 32, 32)
+    x_T = syn.synthetic_normal(shape, "b192.x").to(DEV)
+    noise = torch.stack([syn.synthetic_normal(shape, f"b192.n{k}") for k in range(steps)]).to(DEV)
+    with torch.no_grad():
+        z = m.p_sample_loop(shape, early_stop=1000 - steps, x_T=x_T, noise=noise)
+        img = m.rescaled_upsample(z)
+        assert tuple(img.shape) == (B, 3, 256, 256) and bool(torch.isfinite(img).all())
+        z_again = m.p_sample_loop(shape, early_stop=1000 - steps, x_T=x_T, noise=noise)
+        assert torch.equal(z, z_again) and torch.equal(img, m.rescaled_upsample(z_again))
+        for lo in (0, 95, 190):
+            zp = m.p_sample_loop((2, 8, 32, 32), early_stop=1000 - steps, x_T=x_T[lo:lo + 2].contiguous(),
+                                 noise=noise[:, lo:lo + 2].contiguous())
+            assert (z[lo:lo + 2] - zp).abs().max() < 1e-4
+            ip = m.rescaled_upsample(z[lo:lo + 2].contiguous())
+            assert rel_err(img[lo:lo + 2].cpu(), ip.cpu()) < 2e-5
+        del img
+    torch.cuda.empty_cache()

@@ -663,3 +663,36 @@ def test_sq_err_sum(ops):
     out = ops.sq_err_sum(a.to(DEV), b.to(DEV)).cpu()
     ref = ((a - b).double() ** 2).sum(dim=(1, 2, 3))
     assert rel_err(out, ref) < 2e-6
+
+
+@pytest.mark.parametrize("B,H,S,SA", [(32, 4, 8, 1), (32, 8, 4, 1), (5, 4, 3, 2), (3, 8, 2, 4)])
+def test_one_launch_block_reads_split_k_slabs(ops, B, H, S, SA):
+    """ddk_conv3x3_gn_mish_slabs: the image-local Block kernels (4x4 direct, 8x8 Winograd) summing the split-K slabs a Downsample conv left
+    for their input (and for the residual) while they load -- equal, bit for bit, to the same Block on the reduced tensors (the
+    fixed-order sum + bias of splitk_reduce_kernel); blocks.py:41-47 followed by blocks.py:75-84,105-115."""
+    C = N = 256
+    slabs = torch.stack([to_nhwc(rnd(B, C, H, H, seed=300 + k)) for k in range(S)]).to(DEV).contiguous()
+    sbias = rnd(C, seed=320, scale=0.3).to(DEV)
+    w = (rnd(N, C, 3, 3, seed=321, scale=(C * 9) ** -0.5)).to(DEV)
+    bias, gamma, beta = rnd(N, seed=322, scale=0.1).to(DEV), (1 + rnd(N, seed=323, scale=0.2)).to(DEV), rnd(N, seed=324, scale=0.2).to(DEV)
+    temb = rnd(B, N, seed=325).to(DEV)
+    wp = ops.pack_conv_weight_local(w) if H == 4 else ops.pack_conv_weight_wino_local(w)
+    plain = ops.conv3x3_gn_mish if H == 4 else ops.conv3x3_gn_mish_wino
+    red = slabs[0].clone()
+    for k in range(1, S):
+        red += slabs[k]
+    red += sbias
+    a_sl = torch.stack([to_nhwc(rnd(B, N, H, H, seed=340 + k)) for k in range(SA)]).to(DEV).contiguous()
+    abias = rnd(N, seed=350, scale=0.3).to(DEV)
+    ared = a_sl[0].clone()
+    for k in range(1, SA):
+        ared += a_sl[k]
+    if SA > 1:
+        ared += abias
+    want = plain(red, wp, bias, gamma, beta, temb=temb, addend=ared)
+    got = ops.conv3x3_gn_mish_slabs(slabs, sbias, wp, bias, gamma, beta, temb=temb, addend_slabs=a_sl, addend_bias=abias)
+    assert torch.equal(got, want)
+    # the residual a ResnetBlock without a skip conv adds is its own input: the same slabs on both ports
+    want2 = plain(red, wp, bias, gamma, beta, addend=red)
+    got2 = ops.conv3x3_gn_mish_slabs(slabs, sbias, wp, bias, gamma, beta, addend_slabs=slabs, addend_bias=sbias)
+    assert torch.equal(got2, want2)

@@ -417,3 +417,29 @@ def test_attention_fold_option_gives_the_same_unet():
     assert torch.equal(y_on, y_on2)
     assert not torch.equal(y_on, y_off)          # the two formulations round differently: the option really switches paths
     assert rel_err(y_on.cpu(), y_off.cpu()) < 2e-5
+
+
+def test_downsample_reduce_fold_option_gives_the_same_unet_bits():
+    """plan option DDK_OPT_FOLD_DOWNSAMPLE_REDUCE: at batch 32 the Downsample convs of the 16x16 -> 8x8 and 8x8 -> 4x4 transitions split k;
+    with the option on their slabs are summed by the image-local ResnetBlock behind them (two launches less per forward), with it off by
+    the reduce launch -- the same sums in the same order, so the network output is bit-identical (blocks.py:41-47, unet.py:83-90)."""
+    from helpers import det_state, unet_cfg
+    from models import Unet
+    from utils import synthetic as syn
+    cfg = unet_cfg(128, 8)
+    net = Unet(cfg)
+    net.load_state_dict(det_state({k: v.shape for k, v in net.state_dict().items()}))
+    net = net.to(DEV).eval()
+    x = syn.synthetic_normal((32, 8, 32, 32), "downfold.x").to(DEV)
+    t = torch.arange(32, device=DEV) * 31
+    from ddk import lib as L
+    lib = L.load()
+    assert lib.ddk_conv_splits(1, 32, 16, 16, 256, 256) > 1 and lib.ddk_conv_splits(1, 32, 8, 8, 256, 256) > 1   # kind 1 = 3x3 stride 2
+    with torch.no_grad():
+        y_on = net(x, t)
+        plan = net.plan()
+        plan.set_option(plan.OPT_FOLD_DOWNSAMPLE_REDUCE, 0)
+        y_off = net(x, t)
+        plan.set_option(plan.OPT_FOLD_DOWNSAMPLE_REDUCE, 1)
+        y_on2 = net(x, t)
+    assert torch.equal(y_on, y_off) and torch.equal(y_on, y_on2)

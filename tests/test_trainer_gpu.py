@@ -274,3 +274,25 @@ def test_train_cli(tmp_path):
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-2500:])
     assert "train.py script finished!" in r.stdout
     assert "capture of the training step failed" not in r.stdout
+
+
+def test_train_cli_cfg1_as_baseline_states_it(tmp_path):
+    """BASELINE.json config 1 through its command line: `train.py -d mnist -bs 16 -is 32 -T 200 --n_samples 16` -- MNIST
+    (one colour channel), plain DDPM (-downsample 0), T = 200; two optimiser steps, then the checkpoint the reference's schema asks for."""
+    import glob, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=os.path.join(root, "downsampled-diffusion_amd"), DDPM_WORK_DIR=str(tmp_path) + "/",
+               DDPM_LOGGING_DIR=str(tmp_path))
+    r = subprocess.run([sys.executable, os.path.join(root, "downsampled-diffusion_amd", "train.py"), "-m", "ddpm", "-d", "mnist",
+                        "-bs", "16", "-is", "32", "-T", "200", "--n_samples", "16", "-e", "2", "-mute"],
+                       capture_output=True, text=True, env=env, timeout=600, cwd=str(tmp_path))
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-2500:])
+    assert "train.py script finished!" in r.stdout and "capture of the training step failed" not in r.stdout
+    ck = glob.glob(os.path.join(str(tmp_path), "checkpoint_*.pt"))
+    assert len(ck) == 1, ck
+    data = torch.load(ck[0], weights_only=False)
+    assert set(data) >= {"optimizer", "model", "config", "train_losses", "step", "ema_model"}
+    assert data["step"] == 2 and len(data["train_losses"]) == 2 and all(np.isfinite(v) for v in data["train_losses"])
+    c = data["config"]
+    assert (c["dataset"], c["batch_size"], c["image_size"], c["T"], c["n_downsamples"], c["unet_in"]) == ("mnist", 16, 32, 200, 0, 1)
+    assert data["model"]["betas"].numel() == 200 and data["model"]["latent_model.final_conv.1.weight"].shape[0] == 1
