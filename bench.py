@@ -330,7 +330,10 @@ def cpu_baseline(cfg, state_dict, batch):
 
 def train_step_ms(device, steps=5):
     """Secondary figure: one optimiser step of cfg3 (CelebA 64x64 dDDPM -downsample 2, batch 64:
-    2 accumulation micro-batches, clip, Adam) with the accumulation passes replayed as one device graph."""
+    2 accumulation micro-batches, clip, Adam) with the accumulation passes replayed as one device graph.  Timed in the form the
+    product trainer runs by default -- the step's two micro-batches as ONE pass over their 128 samples (trainers/trainer_ddpm.py,
+    merge_micro_batches: the objective is a mean of per-sample terms, so the gradient is the same) -- and, next to it, as the
+    reference's two passes."""
     from models import DownsampleDDPMAutoencoder, Unet
     from trainers.graph_step import GraphedAccumulation
     from trainers.optim import FusedAdam
@@ -342,129 +345,38 @@ def train_step_ms(device, steps=5):
     model.load_state_dict(syn.fill_state_dict(model.state_dict(), skip=syn.SCHEDULE_KEYS))
     opt = FusedAdam(model, lr=2e-4)
     xs = [torch.rand((64, 3, 64, 64), device=device) * 2 - 1 for _ in range(2)]
-    ga = GraphedAccumulation(model, 2).capture(xs)
-    opt.zero_grad()
 
-    def step():
-        ga.replay(xs)
-        opt.step()
+    def timed(batches):
+        ga = GraphedAccumulation(model, len(batches)).capture(batches)
         opt.zero_grad()
-    for _ in range(2):
-        step()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
-    torch.cuda.synchronize()
-    ms = (time.perf_counter() - t0) / steps * 1e3
+
+        def step():
+            ga.replay(batches)
+            opt.step()
+            opt.zero_grad()
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps * 1e3
+    ms_two = timed(xs)
+    ms = timed([torch.cat(xs)])
     # forward + input-gradient + weight-gradient passes of encoder, UNet (16x16 latents) and decoder, 2 micro-batches of 64
     fwd = model.downsample.flops(64, 64, 64) + model.latent_model.flops(64, 16, 16) + model.upsample.flops(64, 16, 16)
     gflop = 2 * 3 * fwd / 1e9
     return ms, {"kernel": "one optimiser step of cfg3 (CelebA 64x64 dDDPM -downsample 2, batch 64 = 2 micro-batches): encoder + UNet + "
                           "decoder forward and backward, clip, Adam, EMA",
                 "bound": "mfma", "algorithmic_gflop": gflop, "ms_per_step": ms, "achieved": gflop / ms, "peak": FP32_PEAK_TFLOPS,
-                "unit": "TFLOP/s", "frac": gflop / ms / FP32_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": gflop / ms / FP32_PEAK_TFLOPS, "ms_per_step_two_passes": ms_two,
+                "frac_two_passes": gflop / ms_two / FP32_PEAK_TFLOPS,
                 "note": "algorithmic FLOPs = 2 micro-batches x 3 (forward, input gradient, weight gradient) x 2 MAC of every conv / "
                         "projection / attention product over the measured step time (wall clock incl. the optimiser); the 3x3 forward and "
-                        "input-gradient convs of eligible shapes run as Winograd, so the FLOPs issued are lower than this"}
-
-
-def launch_ranks(args, argv):
-    """`python bench.py --gpus N` with N > 1 and no launcher in front (WORLD_SIZE unset): start the N rank processes here.
-
-    This parent NEVER touches the GPU (no torch.cuda call that initialises HIP, no libddk load): it only counts devices, picks a
-    free rendezvous port, starts N fresh children of this file with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set (one process per
-    GPU, child r bound to cuda:r), relays rank 0's JSON line to stdout (everything else of the children goes to stderr) and exits
-    non-zero when any child fails or the job exceeds DDK_BENCH_TIMEOUT seconds -- the remaining children are then killed by the
-    exact process groups started here.  Nothing is ever re-exec'd."""
-    import signal
-    import socket
-    import subprocess
-    import threading
-    n = args.gpus
-    same = bool(os.environ.get("DDK_BENCH_SAME_DEVICE"))
-    have = torch.cuda.device_count()           # counting devices does not initialise the GPU
-    if have < n and not same:
-        log(f"bench.py: --gpus {n} but only {have} GPU(s) visible (one process per GPU over RCCL); "
-            "DDK_BENCH_SAME_DEVICE=1 rehearses N ranks on cuda:0 over gloo")
-        return 2
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    base = dict(os.environ, WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # the host driver only supports dmabuf IPC (RCCL between processes)
-    timeout = float(os.environ.get("DDK_BENCH_TIMEOUT", "1500"))
-    procs, lines = [], []
-    for r in range(n):
-        env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env, text=True,
-                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, start_new_session=True))
-
-    def relay():
-        for ln in procs[0].stdout:
-            lines.append(ln)
-    th = threading.Thread(target=relay, daemon=True)
-    th.start()
-
-    def kill_all():
-        for p in procs:
-            if p.poll() is None:
-                try:
-                    os.killpg(p.pid, signal.SIGKILL)       # the session this function started for exactly that child
-                except OSError:
-                    pass
-        for p in procs:
-            try:
-                p.wait(timeout=30)
-            except Exception:   # noqa: BLE001
-                pass
-
-    deadline = time.monotonic() + timeout
-    rc = 0
-    try:
-        while True:
-            codes = [p.poll() for p in procs]
-            bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
-            if bad:
-                log(f"bench.py: rank {bad[0][0]} exited with code {bad[0][1]}; stopping the other ranks")
-                rc = 1
-                break
-            if all(c == 0 for c in codes):
-                break
-            if time.monotonic() > deadline:
-                log(f"bench.py: the {n}-rank job exceeded DDK_BENCH_TIMEOUT = {timeout:.0f} s; stopping it")
-                rc = 3
-                break
-            time.sleep(0.2)
-    finally:
-        kill_all()
-    th.join(timeout=10)
-    out = [ln for ln in lines if ln.lstrip().startswith("{")]
-    for ln in lines:
-        if ln not in out:
-            sys.stderr.write(ln)
-    if rc == 0 and not out:
-        log("bench.py: rank 0 printed no JSON line")
-        rc = 4
-    if rc == 0:
-        sys.stdout.write(out[-1])
-        sys.stdout.flush()
-    return rc
-
-
-def rank_report(device, world, payload):
-    """What the line says about the job's ranks, learnt over the process group itself: a REAL all-reduce of (rank + 1) must sum
-    to world (world + 1) / 2 -- `rccl_world` is the group size that all-reduce ran over -- and every rank's own figures
-    (`payload`: ms per step, the in-launch GroupNorm option it ended with, its device) are gathered, not assumed from rank 0."""
-    import torch.distributed as dist
-    tok = torch.tensor([float(dist.get_rank() + 1)], device=device, dtype=torch.float64)
-    dist.all_reduce(tok, op=dist.ReduceOp.SUM)
-    w = dist.get_world_size()
-    if abs(float(tok[0]) - w * (w + 1) / 2) > 1e-9:
-        raise RuntimeError(f"all-reduce over {w} ranks summed to {float(tok[0])}, expected {w * (w + 1) / 2}")
-    box = [None] * w
-    dist.all_gather_object(box, payload)
-    return {"rccl_world": w if dist.get_backend() == "nccl" else None, "world": w, "backend": dist.get_backend(), "ranks": box}
+                        "input-gradient convs of eligible shapes run as Winograd, so the FLOPs issued are lower than this.  ms_per_step: the "
+                        "two micro-batches as one pass over their 128 samples (the trainer's default; same gradient); "
+                        "ms_per_step_two_passes: the reference's pass-by-pass sequence"}
 
 
 def cfg5_train():

@@ -109,28 +109,40 @@ class TrainerDDPM(Trainer):
             self.ema.update(self.model)
 
     # ------------------------------------------------------------------ one optimiser step
-    def _micro_batch(self, x=None):
+    def _micro_batch(self, x=None, passes=None):
+        """One forward + backward; `passes` = how many such passes make up the optimiser step (the objective enters the gradient
+        bucket as obj / passes; default: gradient_accumulate_every)."""
         if x is None:
             x, _ = next(self.train_loader)
             x = x.to(self.device, non_blocking=True)
+        passes = self.gradient_accumulate_every if passes is None else passes
         from ddk import ops
         with ops.deferred_wgrad():                 # the slab reduces of this backward pass: one launch when the block ends
             out = self.model(x)
             obj, extra = (out[0], out[1]) if isinstance(out, tuple) else (out, None)
-            obj.backward(torch.full_like(obj, 1.0 / self.gradient_accumulate_every))    # = (obj / accumulate).backward(), two launches less
+            obj.backward(torch.full_like(obj, 1.0 / passes))    # = (obj / passes).backward(), two launches less
         return obj.detach(), extra
 
     def _accumulate(self):
         """The `gradient_accumulate_every` forward/backward passes of one step -> tensor [accumulate, 1 or 3] of
         (objective[, latent, recon]) per micro-batch.  On the GPU the passes are captured once into a device graph
         (trainers/graph_step.py) and replayed; config['graph_train'] = False keeps the eager sequence."""
-        batches = [next(self.train_loader)[0].to(self.device, non_blocking=True) for _ in range(self.gradient_accumulate_every)]
+        acc = self.gradient_accumulate_every
+        batches = [next(self.train_loader)[0].to(self.device, non_blocking=True) for _ in range(acc)]
+        # The objective is a MEAN of per-sample terms (ddpm.py:290-315, dddpm.py:152-177: no batch statistics anywhere -- GroupNorm,
+        # LayerNorm and the attention are per sample), so sum_k d(obj_k / acc) over the `acc` micro-batches IS d(obj of their
+        # concatenation): the micro-batches of a step go through ONE forward + backward as one batch of acc x batch_size samples --
+        # the same gradient up to fp32 summation order (tests/test_trainer_gpu.py), half the launches, kernels twice as full.
+        # config['merge_micro_batches'] = False keeps the reference's pass-by-pass sequence (trainer_ddpm.py:118-128).
+        merged = bool(self.config.get('merge_micro_batches', True)) and acc > 1 and all(b.shape == batches[0].shape for b in batches)
+        if merged:
+            batches = [torch.cat(batches)]
         use_graph = self.config.get('graph_train', True) and str(self.device).startswith('cuda')
         if use_graph and self._graph is None:
             from .graph_step import GraphedAccumulation
             graph, err = None, None
             try:
-                graph = GraphedAccumulation(self.model, self.gradient_accumulate_every).capture(batches)
+                graph = GraphedAccumulation(self.model, len(batches)).capture(batches)
             except Exception as e:       # noqa: BLE001 -- e.g. a model whose forward synchronises with the host
                 err = f"{type(e).__name__}: {e}"
             # The outcome is agreed on by ALL ranks before anyone acts on it: a rank that raised (or went eager) alone would
@@ -150,14 +162,18 @@ class TrainerDDPM(Trainer):
                 self._graph = False
                 torch.cuda.synchronize()
             self.opt.zero_grad()          # the warm-up / capture passes accumulated gradients of their own
-        if use_graph and self._graph and all(b.shape == s.shape for b, s in zip(batches, self._graph.static_x)):
-            return self._graph.replay(batches)
-        rows = []
-        for x in batches:
-            obj, extra = self._micro_batch(x)
-            rec = [obj] if extra is None else [obj, extra['latent'].detach(), extra['recon'].detach()]
-            rows.append(torch.stack([r.reshape(()) for r in rec]))
-        return torch.stack(rows)
+        if (use_graph and self._graph and len(batches) == len(self._graph.static_x)
+                and all(b.shape == s.shape for b, s in zip(batches, self._graph.static_x))):
+            rows = self._graph.replay(batches)
+        else:
+            rows = []
+            for x in batches:
+                obj, extra = self._micro_batch(x, passes=len(batches))
+                rec = [obj] if extra is None else [obj, extra['latent'].detach(), extra['recon'].detach()]
+                rows.append(torch.stack([r.reshape(()) for r in rec]))
+            rows = torch.stack(rows)
+        # one row per micro-batch as the loggers expect; a merged pass reports the mean over all its samples in each
+        return rows.expand(acc, -1) if merged else rows
 
     def optimizer_step(self):
         """all-reduce (data parallel) -> clip_grad_norm_(1.0) -> Adam -> zero_grad (trainer_ddpm.py:142-144)"""

@@ -29,8 +29,30 @@ def _run_micro_batch(model, tag, step, mb, xshape, eshape):
     return float(obj)
 
 
+def _run_merged(model, tag, step, xshape, eshape):
+    """The two micro-batches of a step as ONE pass over their concatenation (trainers/trainer_ddpm.py, merge_micro_batches): the
+    objective is a mean of per-sample terms, so its gradient is the sum of the two (obj / 2) gradients the reference accumulates."""
+    x = torch.cat([syn.synthetic_input(xshape, f"g6.{tag}.x{step}{mb}") for mb in range(2)]).to(DEV)
+    tt = torch.cat([torch.tensor([0, 40 + step, 500, 999 - mb]) for mb in range(2)]).to(DEV)
+    eps = torch.cat([syn.synthetic_normal(eshape, f"g6.{tag}.eps{step}{mb}") for mb in range(2)]).to(DEV)
+    model.t_sample = lambda n, tt=tt: tt
+    orig = torch.randn_like
+    torch.randn_like = lambda z, eps=eps: eps
+    try:
+        res = model(x)
+    finally:
+        torch.randn_like = orig
+    obj = res[0] if isinstance(res, tuple) else res
+    obj.backward()
+    return float(obj)
+
+
+@pytest.mark.parametrize("merged", [False, True])
 @pytest.mark.parametrize("tag", ["ddpm", "dddpm_ae"])
-def test_two_optimizer_steps_vs_reference(tag):
+def test_two_optimizer_steps_vs_reference(tag, merged):
+    """objective, global gradient norm, parameters after each of two optimiser steps and the EMA against what the REFERENCE produced
+    with its own loop (golden g6: 2 micro-batches per step, (obj / 2).backward() each; trainers/trainer_ddpm.py:113-158) -- for the
+    pass-by-pass sequence and for the merged pass the trainer runs by default"""
     from models import DDPM, DownsampleDDPMAutoencoder, Unet
     from trainers.ema import EMA
     from trainers.optim import FusedAdam
@@ -51,8 +73,12 @@ def test_two_optimizer_steps_vs_reference(tag):
     probe = [str(n) for n in g[f"{tag}_probe_names"]]
     params = dict(model.named_parameters())
     for step in range(2):
-        objs = [_run_micro_batch(model, tag, step, mb, xshape, eshape) for mb in range(2)]
-        assert np.allclose(objs, g[f"{tag}_obj{step}"], rtol=2e-4), (step, objs, g[f"{tag}_obj{step}"])
+        if merged:
+            obj = _run_merged(model, tag, step, xshape, eshape)
+            assert np.allclose(obj, np.mean(g[f"{tag}_obj{step}"]), rtol=2e-4), (step, obj, g[f"{tag}_obj{step}"])
+        else:
+            objs = [_run_micro_batch(model, tag, step, mb, xshape, eshape) for mb in range(2)]
+            assert np.allclose(objs, g[f"{tag}_obj{step}"], rtol=2e-4), (step, objs, g[f"{tag}_obj{step}"])
         norm = opt.step()
         opt.zero_grad()
         assert abs(float(norm[0]) / float(g[f"{tag}_gradnorm{step}"]) - 1) < 1e-3
@@ -296,3 +322,58 @@ def test_train_cli_cfg1_as_baseline_states_it(tmp_path):
     c = data["config"]
     assert (c["dataset"], c["batch_size"], c["image_size"], c["T"], c["n_downsamples"], c["unet_in"]) == ("mnist", 16, 32, 200, 0, 1)
     assert data["model"]["betas"].numel() == 200 and data["model"]["latent_model.final_conv.1.weight"].shape[0] == 1
+
+
+def test_trainer_merges_the_micro_batches_of_a_step(tmp_path, monkeypatch):
+    """TrainerDDPM._accumulate: by default the two micro-batches of an optimiser step run as one pass over their concatenation;
+    config['merge_micro_batches'] = False keeps the reference's two passes (trainer_ddpm.py:118-128).  Same draws injected into
+    both: the flat gradient buckets agree to fp32 summation order, the logged rows have one row per micro-batch either way, and the
+    merged form issues ONE forward."""
+    import trainers.trainer as T
+    import trainers.trainer_ddpm as TD
+    for mod in (T, TD):
+        monkeypatch.setattr(mod, "LOGGING_DIR", str(tmp_path) + "/", raising=True)
+    from trainers import setup_trainer
+    B = 4
+    base = dict(model="dddpm", dataset="celeba", n_steps=1, batch_size=B, image_size=32, n_downsamples=2, lr=2e-4, unet_chan=32,
+                unet_dims=(1, 2, 2, 2), unet_dropout=0.0, T=1000, loss_type="simple", beta_schedule="linear", ema_decay=0.995,
+                loss_flat="sum", val_split=0, n_samples=4, d_mode="convolutional_res", u_mode="convolutional_res", d_dropout=0,
+                d_chans=64, d_n_blocks=3, u_n_blocks=3, unet_in=8, ae_loss=True, t_rec_max=100, force_latent=True, graph_train=False)
+    xs = [syn.synthetic_input((B, 3, 32, 32), f"merge.x{k}").to(DEV) for k in range(2)]
+    t_all = torch.tensor([3, 50, 99, 100, 640, 7, 999, 320], device=DEV)
+    eps_all = syn.synthetic_normal((2 * B, 8, 8, 8), "merge.eps").to(DEV)
+    grads, rows, calls = {}, {}, {}
+    for merged in (False, True):
+        trainer, _ = setup_trainer(dict(base, merge_micro_batches=merged), True, str(tmp_path), "unit", seed=0)
+        trainer.train_loader = iter([(x, 0) for x in xs])
+        state = {"t": 0, "e": 0, "fwd": 0}
+
+        def t_sample(n, state=state):
+            lo = state["t"]
+            state["t"] += n
+            state["fwd"] += 1
+            return t_all[lo:lo + n]
+
+        def randn_like(z, state=state):
+            if tuple(z.shape[1:]) != (8, 8, 8):
+                return orig(z)
+            lo = state["e"]
+            state["e"] += z.shape[0]
+            return eps_all[lo:lo + z.shape[0]]
+        trainer.model.t_sample = t_sample
+        orig = torch.randn_like
+        torch.randn_like = randn_like
+        try:
+            trainer.model.train()
+            trainer.opt.zero_grad()
+            rows[merged] = trainer._accumulate().cpu()
+        finally:
+            torch.randn_like = orig
+        grads[merged] = trainer.opt.fp.grad.detach().cpu().clone()
+        calls[merged] = state["fwd"]
+        assert state["t"] == 2 * B and state["e"] == 2 * B
+    assert calls == {False: 2, True: 1}
+    assert rows[False].shape == rows[True].shape == (2, 3)
+    assert torch.allclose(rows[True][0], rows[False].mean(dim=0), rtol=2e-5)
+    scale = float(grads[False].abs().max())
+    assert float((grads[True] - grads[False]).abs().max()) < 2e-4 * scale
