@@ -1071,6 +1071,145 @@ __global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ pe, const 
         pe[i] = pe[i] * decay + (1.0f - decay) * p[i];
 }
 
+// ------------------------------------------------------------------------------------------------
+// Training at widths that are not multiples of 32 (reference blocks.py:75: GroupNorm(8, C) takes any C % 8 == 0; blocks.py:57-60).
+// Activations keep a pitch CP = pad32(C) with zero padding, so every conv kernel -- forward, input gradient, weight gradient -- runs
+// unchanged on zero-padded weights; only the two normalisations see the real channel count.  Plain passes over global memory, one
+// workgroup per (image, group); the same arithmetic as gn_train_kernel, correctness first.
+//   thread = (channel cc = tid % CG, row r = tid / CG) with CG the power of two >= C / groups: a thread's elements all lie in ONE
+//   channel, so the per-channel sums of the backward are per-thread registers, folded over the rows in fixed order through LDS.
+template <bool BWD>
+__global__ __launch_bounds__(256) void gn_generic_train_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, const float* __restrict__ temb, int temb_stride,
+                                                               const float* __restrict__ addend, float drop_p, uint64_t seed, uint32_t layer,
+                                                               const float* __restrict__ dy, float* __restrict__ out /* fwd: y; bwd: dx */,
+                                                               float* __restrict__ part /* bwd: [4][B][C] dtemb, dgamma, dbeta, sum dx */,
+                                                               int B, int HW, int CP, int C, int groups, float eps, int CG) {
+    __shared__ float red[32];
+    __shared__ float chs[256][4];
+    const int b = blockIdx.x / (groups + 1), g = blockIdx.x % (groups + 1), tid = threadIdx.x;
+    const long long img = (long long)b * HW * CP;
+    if (g == groups) {                                   // the padding channels of the output stay exactly zero
+        const int np = CP - C;
+        for (long long e = tid; e < (long long)HW * np; e += 256) out[img + (e / np) * CP + C + (int)(e % np)] = 0.f;
+        return;
+    }
+    const int cpg = C / groups, c0 = g * cpg;
+    const int cc = tid % CG, r0 = tid / CG, R = 256 / CG;
+    const bool act = cc < cpg;
+    const int c = c0 + (act ? cc : 0);
+    const float n = (float)((long long)HW * cpg);
+    float s = 0.f;
+    if (act) for (int px = r0; px < HW; px += R) s += x[img + (long long)px * CP + c];
+    const float mean = block_sum(s, red) / n;
+    float q = 0.f;
+    if (act) for (int px = r0; px < HW; px += R) { const float d = x[img + (long long)px * CP + c] - mean; q += d * d; }
+    const float rstd = 1.0f / sqrtf(block_sum(q, red) / n + eps);
+    const float ga = gamma[c], be = beta[c];
+    auto keep = [&](long long o) -> float {             // the Dropout scale of element o (the mask gn_train_kernel draws for it)
+        const float4 m = dropout_scale4(o >> 2, drop_p, seed, layer);
+        const int k = (int)(o & 3);
+        return k == 0 ? m.x : k == 1 ? m.y : k == 2 ? m.z : m.w;
+    };
+    if (!BWD) {
+        const float tb = temb ? temb[(long long)b * temb_stride + c] : 0.f;
+        if (act) for (int px = r0; px < HW; px += R) {
+            const long long o = img + (long long)px * CP + c;
+            float y = mish_f((x[o] - mean) * rstd * ga + be) + tb;
+            if (drop_p > 0.f) y *= keep(o);
+            if (addend) y += addend[o];
+            out[o] = y;
+        }
+        return;
+    }
+    float st = 0.f, sg = 0.f, sb = 0.f, sdx = 0.f, s1 = 0.f, s2 = 0.f;
+    if (act) for (int px = r0; px < HW; px += R) {
+        const long long o = img + (long long)px * CP + c;
+        float g1 = dy[o];
+        if (drop_p > 0.f) g1 *= keep(o);
+        st += g1;
+        const float xh = (x[o] - mean) * rstd;
+        const float d = g1 * mish_grad_f(xh * ga + be);
+        sb += d;
+        sg += d * xh;
+        s1 += d * ga;
+        s2 += d * ga * xh;
+    }
+    const float m1 = block_sum(s1, red) / n, m2 = block_sum(s2, red) / n;
+    if (act) for (int px = r0; px < HW; px += R) {
+        const long long o = img + (long long)px * CP + c;
+        float g1 = dy[o];
+        if (drop_p > 0.f) g1 *= keep(o);
+        const float xh = (x[o] - mean) * rstd;
+        const float dxh = g1 * mish_grad_f(xh * ga + be) * ga;
+        const float dxv = rstd * (dxh - m1 - xh * m2);
+        out[o] = dxv;
+        sdx += dxv;
+    }
+    chs[tid][0] = st; chs[tid][1] = sg; chs[tid][2] = sb; chs[tid][3] = sdx;
+    __syncthreads();
+    if (tid < cpg) {                                     // fixed-order fold over the R rows of this channel
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        for (int r = 0; r < R; ++r) {
+            a0 += chs[r * CG + tid][0]; a1 += chs[r * CG + tid][1]; a2 += chs[r * CG + tid][2]; a3 += chs[r * CG + tid][3];
+        }
+        const long long bc = (long long)b * C + c0 + tid, BC = (long long)B * C;
+        part[bc] = a0; part[BC + bc] = a1; part[2 * BC + bc] = a2; part[3 * BC + bc] = a3;
+    }
+}
+
+// Channel LayerNorm backward over the C real channels of CP-pitched rows (the arithmetic of chan_layernorm_bwd_kernel): one wave
+// per pixel, a lane owns channels lane, lane + 64, ... (C <= 512); per-workgroup partial rows of dg, db.
+__global__ __launch_bounds__(256) void chan_layernorm_generic_bwd_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                                         const float* __restrict__ dy, const float* __restrict__ addend,
+                                                                         float* __restrict__ dx, float* __restrict__ part /* [2][grid][C] */,
+                                                                         long long M, int CP, int C, float eps) {
+    __shared__ float acc[4][2][512];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    float sg[8], sb[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) sg[i] = sb[i] = 0.f;
+    for (long long pix = blockIdx.x * 4LL + wid; pix < M; pix += (long long)gridDim.x * 4) {
+        const float* xr = x + pix * CP;
+        const float* dr = dy + pix * CP;
+        float s = 0.f;
+        for (int c = lane; c < C; c += 64) s += xr[c];
+        const float mean = wave_sum(s) / (float)C;
+        float q = 0.f, t1 = 0.f, t2 = 0.f;
+        for (int c = lane; c < C; c += 64) {
+            const float d = xr[c] - mean, a = dr[c] * g[c];
+            q += d * d; t1 += a; t2 += a * d;
+        }
+        q = wave_sum(q); t1 = wave_sum(t1); t2 = wave_sum(t2);
+        const float sigma = sqrtf(q / (float)C), sden = sigma + eps, inv_s = 1.0f / sden;
+        const float k1 = t1 / (float)C * inv_s, k2 = t2 / ((float)C * sigma * sden * sden);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int c = lane + 64 * i;
+            if (c < CP) {
+                float rv = 0.f;
+                if (c < C) {
+                    const float d = xr[c] - mean;
+                    rv = dr[c] * g[c] * inv_s - k1 - d * k2;
+                    sg[i] += dr[c] * d * inv_s;
+                    sb[i] += dr[c];
+                }
+                if (addend) rv += addend[pix * CP + c];      // (the Residual's gradient: zero in the padding like everything else)
+                dx[pix * CP + c] = rv;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { acc[wid][0][lane + 64 * i] = sg[i]; acc[wid][1][lane + 64 * i] = sb[i]; }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        part[(long long)blockIdx.x * C + c] = (acc[0][0][c] + acc[1][0][c]) + (acc[2][0][c] + acc[3][0][c]);
+        part[((long long)gridDim.x + blockIdx.x) * C + c] = (acc[0][1][c] + acc[1][1][c]) + (acc[2][1][c] + acc[3][1][c]);
+    }
+}
+
+static int gn_generic_cg(int cpg) { int cg = 1; while (cg < cpg) cg <<= 1; return cg; }
+
 static int grid_for(long long n) {
     const long long b = ceil_div(n > 0 ? n : 1, 256);
     return (int)(b < 4096 ? b : 4096);
@@ -1173,6 +1312,51 @@ static int gn_train_launch(bool bwd, const float* x, const float* gamma, const f
     else GT(4, 1024);
 #undef GT
     return check_launch("gn_train_kernel");
+}
+
+/* GroupNorm(groups, C) + Mish (+ temb[b][c]) (+ Dropout) (+ addend) on CP-pitched NHWC rows whose channels [C, CP) are zero padding
+ * (blocks.py:75-84,106-111 at widths that are not multiples of 32): training forward (the input is what the backward recomputes from). */
+int ddk_groupnorm_mish_generic_train_fwd(const float* x, const float* gamma, const float* beta, const float* temb, int temb_stride,
+                                         const float* addend, float drop_p, unsigned long long seed, unsigned layer, float* out, int B, int HW,
+                                         int CP, int C, int groups, float eps, ddk_stream_t s) {
+    DDK_REQUIRE(x && gamma && beta && out && B > 0 && HW > 0 && groups > 0 && C > 0 && C % groups == 0 && CP >= C && C / groups <= 256,
+                "groupnorm_generic_train_fwd: arguments");
+    DDK_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "groupnorm_generic_train_fwd: dropout probability");
+    hipLaunchKernelGGL((gn_generic_train_kernel<false>), dim3((unsigned)(B * (groups + 1))), dim3(256), 0, as_stream(s), x, gamma, beta, temb,
+                       temb_stride, addend, drop_p, (uint64_t)seed, (uint32_t)layer, static_cast<const float*>(nullptr), out,
+                       static_cast<float*>(nullptr), B, HW, CP, C, groups, eps, gn_generic_cg(C / groups));
+    return check_launch("gn_generic_train_kernel");
+}
+
+/* its backward: dx (padding zero) and part [4][B][C] = per (image, channel) sums (dtemb, dgamma, dbeta, sum of dx over the pixels) */
+int ddk_groupnorm_mish_generic_bwd(const float* x, const float* gamma, const float* beta, float drop_p, unsigned long long seed, unsigned layer,
+                                   const float* dy, float* dx, float* part, int B, int HW, int CP, int C, int groups, float eps,
+                                   ddk_stream_t s) {
+    DDK_REQUIRE(x && gamma && beta && dy && dx && part && B > 0 && HW > 0 && groups > 0 && C > 0 && C % groups == 0 && CP >= C &&
+                    C / groups <= 256, "groupnorm_generic_bwd: arguments");
+    hipLaunchKernelGGL((gn_generic_train_kernel<true>), dim3((unsigned)(B * (groups + 1))), dim3(256), 0, as_stream(s), x, gamma, beta,
+                       static_cast<const float*>(nullptr), 0, static_cast<const float*>(nullptr), drop_p, (uint64_t)seed, (uint32_t)layer, dy, dx,
+                       part, B, HW, CP, C, groups, eps, gn_generic_cg(C / groups));
+    return check_launch("gn_generic_train_kernel");
+}
+
+/* channel LayerNorm over the C real channels of CP-pitched rows (padding written as zero), and its backward: dx (+ addend) and the
+ * partial rows part [2][nparts][C] of (dg, db); *nparts_out workgroups were used (<= max_parts) */
+int ddk_chan_layernorm_generic(const float* x, const float* g, const float* b, float* out, long long M, int CP, int C, float eps,
+                               ddk_stream_t s) {
+    return chan_layernorm_generic(x, g, b, out, M, CP, C, eps, as_stream(s));
+}
+int ddk_chan_layernorm_generic_bwd(const float* x, const float* g, const float* dy, const float* addend, float* dx, float* part,
+                                   int max_parts, int* nparts_out, long long M, int CP, int C, float eps, ddk_stream_t s) {
+    DDK_REQUIRE(x && g && dy && dx && part && nparts_out && M > 0 && max_parts > 0 && C > 0 && C <= 512 && CP >= C && CP <= 512,
+                "layernorm_generic_bwd: arguments");
+    long long blocks = ceil_div(M, 4);
+    if (blocks > max_parts) blocks = max_parts;
+    if (blocks > 512) blocks = 512;
+    *nparts_out = (int)blocks;
+    hipLaunchKernelGGL(chan_layernorm_generic_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(s), x, g, dy, addend, dx, part, M,
+                       CP, C, eps);
+    return check_launch("chan_layernorm_generic_bwd_kernel");
 }
 
 int ddk_dropout_epoch(unsigned long long set_to, int bump, ddk_stream_t s) {

@@ -326,6 +326,96 @@ def groupnorm_mish(x, gamma, beta, temb=None, addend=None, drop_p=0.0, seed=0, l
     return GNMishFn.apply(x, gamma, beta, temb, addend, float(drop_p), int(seed), int(layer), groups, eps)
 
 
+# ---------------------------------------------------------------- widths that are not multiples of 32
+class PadParamFn(torch.autograd.Function):
+    """A parameter zero-padded into the channel pitch the kernels want.  dims: for each of the (first two) axes a list of
+    (dst_offset, src_offset, length) blocks -- one block for a plain axis, two for the input axis of a conv that reads a concat
+    (each source keeps its own padded pitch).  Forward: zeros + block copies; backward: the blocks of the gradient copied back.
+    Memory plumbing only (no arithmetic); the padded copy is what the conv / weight-gradient kernels see."""
+
+    @staticmethod
+    def forward(ctx, w, shape, dims):
+        ctx.dims, ctx.wshape = dims, tuple(w.shape)
+        wp = torch.zeros(shape, device=w.device, dtype=torch.float32)
+        src = w.detach()
+        if len(dims) == 1:
+            for (d0, s0, n0) in dims[0]:
+                wp[d0:d0 + n0] = src[s0:s0 + n0]
+        else:
+            for (d0, s0, n0) in dims[0]:
+                for (d1, s1, n1) in dims[1]:
+                    wp[d0:d0 + n0, d1:d1 + n1] = src[s0:s0 + n0, s1:s1 + n1]
+        return wp
+
+    @staticmethod
+    def backward(ctx, g):
+        dims = ctx.dims
+        gw = torch.empty(ctx.wshape, device=g.device, dtype=torch.float32)
+        if len(dims) == 1:
+            for (d0, s0, n0) in dims[0]:
+                gw[s0:s0 + n0] = g[d0:d0 + n0]
+        else:
+            for (d0, s0, n0) in dims[0]:
+                for (d1, s1, n1) in dims[1]:
+                    gw[s0:s0 + n0, s1:s1 + n1] = g[d0:d0 + n0, d1:d1 + n1]
+        return gw, None, None
+
+
+def pad_param(w, out_real=None, in_real=None):
+    """w [O, I, ...] (or [O]) -> zero-padded copy with O -> pad32(O) and the input axis laid out as the padded segments of
+    in_real = [c_a, c_b, ...] (default: one segment).  out_real / in_real None: that axis is left as it is."""
+    o = w.shape[0]
+    d0 = [(0, 0, o)]
+    shape = [ops.pad32(o) if out_real is not None else o] + list(w.shape[1:])
+    if w.dim() == 1:
+        return PadParamFn.apply(w, tuple(shape), (d0,))
+    d1, dst, src = [], 0, 0
+    if in_real is None:
+        d1 = [(0, 0, w.shape[1])]
+        dst = w.shape[1]
+    else:
+        for n in in_real:
+            d1.append((dst, src, n))
+            dst += ops.pad32(n)
+            src += n
+        assert src == w.shape[1], (in_real, tuple(w.shape))
+    shape[1] = dst
+    return PadParamFn.apply(w, tuple(shape), (d0, d1))
+
+
+class GNMishGenericFn(torch.autograd.Function):
+    """GNMishFn on CP-pitched rows with C = gamma.numel() real channels (zero padding behind them): blocks.py:79-80,106-111"""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, temb, addend, drop_p, seed, layer, groups, eps):
+        ctx.save_for_backward(x, gamma, beta)
+        ctx.cfg = (drop_p, seed, layer, groups, eps, temb is not None, addend is not None)
+        return ops.groupnorm_mish_generic_train(x, gamma.detach(), beta.detach(), temb=temb, addend=addend, drop_p=drop_p, seed=seed,
+                                                layer=layer, groups=groups, eps=eps)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, beta = ctx.saved_tensors
+        drop_p, seed, layer, groups, eps, has_temb, has_add = ctx.cfg
+        dy = _c(dy)
+        dx, dtemb, sums = ops.groupnorm_mish_generic_bwd(x, gamma.detach(), beta.detach(), dy, drop_p, seed, layer, groups, eps)
+        return dx, sums[0], sums[1], (dtemb if has_temb else None), (dy if has_add else None), None, None, None, None, None
+
+
+class ChanLayerNormGenericFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, g, b, eps):
+        ctx.save_for_backward(x, g)
+        ctx.eps = eps
+        return ops.chan_layernorm_generic(x, g.detach(), b.detach(), eps)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, g = ctx.saved_tensors
+        dx, dg, db = ops.chan_layernorm_generic_bwd(x, g.detach(), _c(dy), ctx.eps)
+        return dx, dg.reshape(g.shape), db.reshape(g.shape), None
+
+
 class ChanLayerNormFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, g, b, eps, take=None):

@@ -181,6 +181,10 @@ SIGNATURES = {
     "ddk_pack_jobs": (_I, [_P, _I, _LL, _P]),
     "ddk_chan_layernorm_bwd": (_I, [_P, _P, _P, _P, _P, _I, C.POINTER(C.c_int), _LL, _I, _F, _P]),
     "ddk_chan_layernorm_bwd_add": (_I, [_P, _P, _P, _P, _P, _P, _I, C.POINTER(C.c_int), _LL, _I, _F, _P]),
+    "ddk_groupnorm_mish_generic_train_fwd": (_I, [_P, _P, _P, _P, _I, _P, _F, C.c_uint64, C.c_uint32, _P, _I, _I, _I, _I, _I, _F, _P]),
+    "ddk_groupnorm_mish_generic_bwd": (_I, [_P, _P, _P, _F, C.c_uint64, C.c_uint32, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
+    "ddk_chan_layernorm_generic": (_I, [_P, _P, _P, _P, _LL, _I, _I, _F, _P]),
+    "ddk_chan_layernorm_generic_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, C.POINTER(C.c_int), _LL, _I, _I, _F, _P]),
     "ddk_linattn_train_workspace_bytes": (_SZ, [_I, _I, _I]),
     "ddk_linattn_stats": (_I, [_P, _P, _I, _I, _I, _P, _SZ, _P]),
     "ddk_linattn_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _SZ, _P]),

@@ -1040,6 +1040,60 @@ def groupnorm_mish_bwd(x, gamma, beta, dy, drop_p=0.0, seed=0, layer=0, groups=G
     return dx, part[0], sums
 
 
+# ---------------------------------------------------------------- widths that are not multiples of 32 (training)
+def groupnorm_mish_generic_train(x, gamma, beta, temb=None, addend=None, drop_p=0.0, seed=0, layer=0, groups=GN_GROUPS, eps=GN_EPS):
+    """x [B,H,W,CP] with zero padding behind the C = gamma.numel() real channels -> Dropout(Mish(GN(x)) + temb[b]) + addend, padding zero"""
+    b, h, w, cp = x.shape
+    c = gamma.numel()
+    out = torch.empty_like(x)
+    stride = temb.stride(0) if temb is not None else 0
+    L.check(L.load().ddk_groupnorm_mish_generic_train_fwd(L.ptr(_f32(x)), L.ptr(gamma), L.ptr(beta), temb.data_ptr() if temb is not None else None,
+                                                          stride, L.ptr(addend), float(drop_p), seed, layer, L.ptr(out), b, h * w, cp, c, groups,
+                                                          eps, L.stream()), "groupnorm_mish_generic_train_fwd")
+    return out
+
+
+def groupnorm_mish_generic_bwd(x, gamma, beta, dy, drop_p=0.0, seed=0, layer=0, groups=GN_GROUPS, eps=GN_EPS):
+    """-> dx [B,H,W,CP], dtemb [B,C], (dgamma, dbeta, sum of dx over batch and pixels) [3][C]"""
+    b, h, w, cp = x.shape
+    c = gamma.numel()
+    dx = torch.empty_like(x)
+    part = torch.empty((4, b, c), device=x.device, dtype=torch.float32)
+    lib = L.load()
+    L.check(lib.ddk_groupnorm_mish_generic_bwd(L.ptr(_f32(x)), L.ptr(gamma), L.ptr(beta), float(drop_p), seed, layer, L.ptr(_f32(dy)), L.ptr(dx),
+                                               L.ptr(part), b, h * w, cp, c, groups, eps, L.stream()), "groupnorm_mish_generic_bwd")
+    sums = torch.empty((3, c), device=x.device, dtype=torch.float32)
+    L.check(lib.ddk_rows_sum_batched(L.ptr(part[1]), 3, b * c, b, c, L.ptr(sums), c, 0, L.stream()), "rows_sum_batched")
+    return dx, part[0], sums
+
+
+def chan_layernorm_generic(x, g, b, eps=LN_EPS):
+    """LayerNorm over the C = g.numel() real channels of CP-pitched rows; padding written as zero"""
+    cp, c = x.shape[-1], g.numel()
+    out = torch.empty_like(x)
+    L.check(L.load().ddk_chan_layernorm_generic(L.ptr(_f32(x)), L.ptr(g.reshape(-1)), L.ptr(b.reshape(-1)), L.ptr(out), x.numel() // cp, cp, c,
+                                                eps, L.stream()), "chan_layernorm_generic")
+    return out
+
+
+def chan_layernorm_generic_bwd(x, g, dy, eps=LN_EPS, addend=None):
+    """-> dx (+ addend), dg [C], db [C]"""
+    cp, c = x.shape[-1], g.numel()
+    m = x.numel() // cp
+    dx = torch.empty_like(x)
+    max_parts = 512
+    part = torch.empty((2, max_parts, c), device=x.device, dtype=torch.float32)
+    n = C.c_int(0)
+    lib = L.load()
+    L.check(lib.ddk_chan_layernorm_generic_bwd(L.ptr(_f32(x)), L.ptr(g.reshape(-1)), L.ptr(_f32(dy)), L.ptr(addend), L.ptr(dx), L.ptr(part),
+                                               max_parts, C.byref(n), m, cp, c, eps, L.stream()), "chan_layernorm_generic_bwd")
+    # the kernel wrote rows [0, n) of dg and rows [n, 2n) of db, contiguously
+    flat = part.view(-1)
+    dg = rows_sum(flat[:n.value * c], n.value, c, c)
+    db = rows_sum(flat[n.value * c:2 * n.value * c], n.value, c, c)
+    return dx, dg, db
+
+
 def rows_sum(rows, nrows, row_stride, n, out=None):
     if out is None:
         out = torch.empty(n, device=rows.device, dtype=torch.float32)

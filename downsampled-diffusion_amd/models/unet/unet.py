@@ -24,7 +24,7 @@ class Unet(nn.Module):
         dropout = config['unet_dropout']
         if dim % 8 != 0 or not 8 <= dim <= 512:
             # the reference's GroupNorm(8, C) (blocks.py:75) needs C % 8 == 0 as well; multiples of 32 run the tuned kernels, other
-            # multiples of 8 the generic ones (channels padded to 32 with zeros inside the plan: correct, untuned, inference only)
+            # multiples of 8 the generic ones (channels padded to 32 with zeros: correct, untuned; inference and training)
             raise DDKError(f"unet_chan={dim}: must be a multiple of 8 in [8, 512] (GroupNorm(8, C), reference blocks.py:75)")
         self.dim, self.in_channels, self.dim_mults = dim, in_channels, dim_mults
 
@@ -106,8 +106,9 @@ class Unet(nn.Module):
         """x [B,H,W,C_in] fp32 on the device, time [B] integer -> eps_hat [B,H,W,C_in]."""
         if self._wants_grad(x):
             if self.dim % 32 != 0:
-                raise DDKError(f"unet_chan={self.dim}: the training path (HIP backward kernels) needs unet_chan % 32 == 0; widths that are "
-                               "other multiples of 8 run inference only (wrap the call in torch.no_grad())")
+                # other multiples of 8 (blocks.py:75): the same HIP kernels on a zero-padded channel pitch, generic normalisations
+                from trainers.autograd_unet import unet_forward_autograd_generic
+                return unet_forward_autograd_generic(self, x, time)
             from trainers.autograd_unet import unet_forward_autograd   # training path: HIP forward + backward kernels
             return unet_forward_autograd(self, x, time)
         if self.training and self.downs[0][0].dropout.p > 0:

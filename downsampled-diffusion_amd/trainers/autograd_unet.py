@@ -126,6 +126,87 @@ def unet_forward_autograd(unet, x, time):
     return AG.SmallNConvFn.apply(h, last.weight, last.bias)
 
 
+# ---------------------------------------------------------------- widths that are not multiples of 32 (blocks.py:75: any C % 8 == 0)
+# Every tensor keeps a pitch of pad32(C) channels with zero padding; the conv family runs unchanged on zero-padded copies of the
+# parameters (AG.pad_param: the padding rows / columns get no gradient back), GroupNorm and the channel LayerNorm on kernels that
+# see the real channel count.  The tuned path's hand-offs (gradients riding on conv epilogues, split-K slabs summed by their
+# consumer) are not used here: autograd adds where two gradients meet.  Correct and complete, untuned.
+def _gblock(blk, x, c_in, x2=None, c_in2=None, temb=None, addend=None, drop_p=0.0, seeds=None):
+    conv, norm = blk.block[0], blk.block[1]
+    seed, layer = seeds.next() if (seeds is not None and drop_p > 0) else (0, 0)
+    w = AG.pad_param(conv.weight, out_real=True, in_real=[c_in] if c_in2 is None else [c_in, c_in2])
+    raw = AG.conv(ops.CONV3X3_S1, x, w, AG.pad_param(conv.bias, out_real=True), x2=x2)
+    return AG.GNMishGenericFn.apply(raw, norm.weight, norm.bias, temb, addend, float(drop_p), int(seed), int(layer), blk.groups, norm.eps)
+
+
+def _gresnet(rb, x, c_in, temb_slice, x2=None, c_in2=None, seeds=None):
+    p = rb.dropout.p if rb.training else 0.0
+    h = _gblock(rb.block1, x, c_in, x2=x2, c_in2=c_in2, temb=temb_slice, drop_p=p, seeds=seeds)
+    c_out = rb.block1.block[0].weight.shape[0]
+    if isinstance(rb.res_conv, nn.Identity):
+        res = x
+    else:
+        w = AG.pad_param(rb.res_conv.weight, out_real=True, in_real=[c_in] if c_in2 is None else [c_in, c_in2])
+        res = AG.conv(ops.CONV1X1, x, w, AG.pad_param(rb.res_conv.bias, out_real=True), x2=x2)
+    return _gblock(rb.block2, h, c_out, addend=res), c_out
+
+
+def _gattention(res_mod, x, c):
+    pre = res_mod.fn
+    att = pre.fn
+    xn = AG.ChanLayerNormGenericFn.apply(x, pre.norm.g, pre.norm.b, pre.norm.eps)
+    qkv = AG.conv(ops.CONV1X1, xn, AG.pad_param(att.to_qkv.weight, in_real=[c]))
+    o = AG.LinAttnFn.apply(qkv, att.heads)
+    return AG.conv(ops.CONV1X1, o, AG.pad_param(att.to_out.weight, out_real=True), AG.pad_param(att.to_out.bias, out_real=True), resid=x)
+
+
+def unet_forward_autograd_generic(unet, x, time):
+    """unet_forward_autograd for unet_chan % 8 == 0 that is not a multiple of 32 (24, 40, 72, ...): same network, padded pitch."""
+    dev = x.device
+    seeds = _Seeds(unet.training)
+    rbs = _resnet_blocks(unet)
+    freqs = getattr(unet, "_freqs_dev", None)
+    if freqs is None or freqs.device != dev:
+        freqs = sinusoidal_freqs(unet.dim).to(dev)
+        unet._freqs_dev = freqs
+    mlp_args = []
+    for rb in rbs:
+        mlp_args += [rb.mlp[1].weight, rb.mlp[1].bias]
+    shifts = AG.TimeEmbedFn.apply(time.to(torch.int64).contiguous(), freqs, unet.time_mlp[1].weight, unet.time_mlp[1].bias,
+                                  unet.time_mlp[3].weight, unet.time_mlp[3].bias, *mlp_args)
+    shift_of = {id(rb): sft for rb, sft in zip(rbs, shifts)}      # [B, C_out] REAL channels per block (the GroupNorm kernel indexes them so)
+    c = x.shape[-1]
+    if c % 32:
+        h = AG.NhwcToNchwFn.apply(x, c)
+        h = AG.NchwToNhwcFn.apply(h, ops.pad32(c))
+    else:
+        h = x
+    skips = []
+    for lvl in unet.downs:
+        rb1, rb2, attn, down = lvl
+        h, c = _gresnet(rb1, h, c, shift_of[id(rb1)], seeds=seeds)
+        h, c = _gresnet(rb2, h, c, shift_of[id(rb2)], seeds=seeds)
+        h = _gattention(attn, h, c)
+        skips.append((h, c))
+        if not isinstance(down, nn.Identity):
+            h = AG.conv(ops.CONV3X3_S2, h, AG.pad_param(down.conv.weight, out_real=True, in_real=[c]), AG.pad_param(down.conv.bias, out_real=True))
+    h, c = _gresnet(unet.mid_block1, h, c, shift_of[id(unet.mid_block1)], seeds=seeds)
+    h = _gattention(unet.mid_attn, h, c)
+    h, c = _gresnet(unet.mid_block2, h, c, shift_of[id(unet.mid_block2)], seeds=seeds)
+    for lvl in unet.ups:
+        rb1, rb2, attn, up = lvl
+        skip, cs = skips.pop()
+        h, c = _gresnet(rb1, h, c, shift_of[id(rb1)], x2=skip, c_in2=cs, seeds=seeds)
+        h, c = _gresnet(rb2, h, c, shift_of[id(rb2)], seeds=seeds)
+        h = _gattention(attn, h, c)
+        # ConvTranspose2d weight is (in, out, 4, 4): both channel axes padded
+        h = AG.conv(ops.CONVT4X4_S2, h, AG.pad_param(up.conv.weight, out_real=True, in_real=[c]).contiguous(),
+                    AG.pad_param(up.conv.bias, out_real=True))
+    h = _gblock(unet.final_conv[0], h, c)
+    last = unet.final_conv[1]
+    return AG.SmallNConvFn.apply(h, AG.pad_param(last.weight, in_real=[c]), last.bias)
+
+
 def sq_err_sum_autograd(a, b):
     """per-sample sum over C,H,W of (a-b)^2 (ddpm.py:279 + utils/utils.py:34-40)"""
     return AG.SqErrSumFn.apply(a.contiguous(), b.contiguous())
@@ -139,11 +220,20 @@ def _conv_res_block(blk, x, a=None, want_next_act=False):
     if a is None:
         a = ops.mish(x.detach())
     hand = AG.GradHandoff() if blk.residual else None      # the skip's gradient rides on c1's input-gradient conv (no 17-67 MB add launch)
-    h, a = AG.preact_conv(ops.CONV1X1, x, a, blk.c1.weight, blk.c1.bias, handoff=hand)
-    h, a = AG.preact_conv(ops.CONV3X3_S1, h, a, blk.c2.weight, blk.c2.bias)
-    h, a = AG.preact_conv(ops.CONV3X3_S1, h, a, blk.c3.weight, blk.c3.bias)
+    w1, b1, w2, b2, w3, b3, w4 = blk.c1.weight, blk.c1.bias, blk.c2.weight, blk.c2.bias, blk.c3.weight, blk.c3.bias, blk.c4.weight
+    inner = w1.shape[0]
+    if inner % 32:
+        # d_chans / 2 = 16, 48, ...: the block's inner tensors keep a pitch of pad32(inner) channels (zero weight rows and bias entries
+        # keep the padding exactly zero through Mish and both 3x3 convs); the kernels see zero-padded copies of the parameters
+        w1, b1 = AG.pad_param(w1, out_real=True), AG.pad_param(b1, out_real=True)
+        w2, b2 = AG.pad_param(w2, out_real=True, in_real=[inner]), AG.pad_param(b2, out_real=True)
+        w3, b3 = AG.pad_param(w3, out_real=True, in_real=[inner]), AG.pad_param(b3, out_real=True)
+        w4 = AG.pad_param(w4, in_real=[inner])
+    h, a = AG.preact_conv(ops.CONV1X1, x, a, w1, b1, handoff=hand)
+    h, a = AG.preact_conv(ops.CONV3X3_S1, h, a, w2, b2)
+    h, a = AG.preact_conv(ops.CONV3X3_S1, h, a, w3, b3)
     hand_over = want_next_act and not (blk.upsample or blk.downsample)
-    out, a_next = AG.preact_conv(ops.CONV1X1, h, a, blk.c4.weight, blk.c4.bias, resid=x if blk.residual else None, want_act=hand_over,
+    out, a_next = AG.preact_conv(ops.CONV1X1, h, a, w4, blk.c4.bias, resid=x if blk.residual else None, want_act=hand_over,
                                  handoff=hand)
     if blk.upsample:
         out = AG.UpNearest2Fn.apply(out)
@@ -154,10 +244,9 @@ def _conv_res_block(blk, x, a=None, want_next_act=False):
 
 def resnet_forward_autograd(net, x_nchw, final_tanh):
     """ConvResNet (dDDPM encoder / decoder) on an NCHW tensor -> NCHW, differentiable."""
-    if net.dim % 64 != 0:
+    if net.dim % 32 != 0:
         from ddk.lib import DDKError
-        raise DDKError(f"d_chans={net.dim}: the training path (HIP backward kernels) needs d_chans % 64 == 0; other multiples of 32 run "
-                       "inference only (sampling, evaluation under torch.no_grad())")
+        raise DDKError(f"d_chans={net.dim}: the HIP path needs d_chans % 32 == 0")
     h = AG.NchwToNhwcFn.apply(x_nchw.contiguous().float(), ops.pad32(x_nchw.shape[1]))
     first, last = net.conv[0], net.conv[-1]
     h = AG.conv(ops.CONV1X1, h, first.weight, first.bias)

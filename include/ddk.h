@@ -511,7 +511,24 @@ typedef struct ddk_wgrad_reduce_job {
     long long slab_stride;
     long long block0;        /* set by ddk_wgrad_reduce_jobs */
     int splits, N, ntaps, cx, c_real, cw, c_off, reserved;
-} ddk_wgrad_reduce_job;      /* 80 bytes */
+} ddk_wgrad_reduce_job;      /* Training at widths that are not multiples of 32 (blocks.py:75: GroupNorm(8, C) takes any C % 8 == 0): activations keep a pitch
+ * CP = pad32(C) whose channels [C, CP) are ZERO, so the conv kernels (forward, input gradient, weight gradient) run unchanged on
+ * zero-padded weights and only the two normalisations see the real channel count.  GroupNorm + Mish (+ temb[b][c], temb_stride floats
+ * per image) (+ Dropout(drop_p), mask = f(seed, layer, element)) (+ addend): training forward; backward: dx and part [4][B][C] = per
+ * (image, channel) sums (dtemb, dgamma, dbeta, sum of dx over the pixels = the bias gradient of the conv in front). */
+int ddk_groupnorm_mish_generic_train_fwd(const float* x, const float* gamma, const float* beta, const float* temb, int temb_stride,
+                                         const float* addend, float drop_p, unsigned long long seed, unsigned layer, float* out, int B, int HW,
+                                         int CP, int C, int groups, float eps, ddk_stream_t s);
+int ddk_groupnorm_mish_generic_bwd(const float* x, const float* gamma, const float* beta, float drop_p, unsigned long long seed, unsigned layer,
+                                   const float* dy, float* dx, float* part, int B, int HW, int CP, int C, int groups, float eps,
+                                   ddk_stream_t s);
+/* Channel LayerNorm (blocks.py:57-60, eps on the std) over the C real channels of CP-pitched rows (padding written as zero), and its
+ * backward: dx (+ addend) and the partial rows part [2][nparts][C] of (dg, db); *nparts_out workgroups were used (<= max_parts). */
+int ddk_chan_layernorm_generic(const float* x, const float* g, const float* b, float* out, long long M, int CP, int C, float eps,
+                               ddk_stream_t s);
+int ddk_chan_layernorm_generic_bwd(const float* x, const float* g, const float* dy, const float* addend, float* dx, float* part,
+                                   int max_parts, int* nparts_out, long long M, int CP, int C, float eps, ddk_stream_t s);
+/* 80 bytes */
 int ddk_conv_wgrad_defer(int kind, const float* x, const float* dy, float* grad_w, float* grad_b, int B, int H, int W, int cx, int c_real,
                          int cw, int c_off, int N, void* workspace, size_t workspace_bytes, ddk_wgrad_reduce_job* job_out, ddk_stream_t s);
 int ddk_wgrad_reduce_jobs(const ddk_wgrad_reduce_job* jobs_host, int n, ddk_stream_t s);
