@@ -1654,10 +1654,16 @@ int ddk_conv1x1_small_n_bwd(const float* a, const float* w, const float* dy, flo
         case 64: CB(16, 1);
         case 128: CB(32, 1);
         case 256: CB(64, 1);
+        case 96: CB(8, 3);       // d_chans = 96, 160, 192, ...: the dDDPM decoder's last 1x1 at widths that are multiples of 32 only
+        case 160: CB(8, 5);
+        case 192: CB(16, 3);
+        case 320: CB(16, 5);
+        case 384: CB(32, 3);
+        case 512: CB(64, 2);
         default: break;
     }
 #undef CB
-    return fail_arg("conv1x1_small_n_bwd: unsupported channel count (32, 64, 128, 256)");
+    return fail_arg("conv1x1_small_n_bwd: unsupported channel count (32, 64, 96, 128, 160, 192, 256, 320, 384, 512)");
 }
 
 /* C = op(A) op(B) for the tiny time-embedding matrices; see small_gemm_kernel for the modes */
