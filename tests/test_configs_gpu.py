@@ -100,7 +100,7 @@ def test_cfg3_celeba64_latents_and_decoder_vs_oracle():
 @pytest.mark.parametrize("d_chans", [32, 96])
 def test_resamplers_with_d_chans_not_a_multiple_of_64(d_chans):
     """`d_chans` is free in the reference (`ConvResNet(dim, ...)`, convblocks.py:133-159: the blocks' inner width is int(dim / 2)); the
-    HIP path takes every multiple of 32 for inference -- an inner width of 16 or 48 runs on a padded pitch of 32 / 64 channels whose
+    HIP path takes every multiple of 32 -- an inner width of 16 or 48 runs on a padded pitch of 32 / 64 channels whose
     padding stays exactly zero (zero weight rows, zero bias, Mish(0) = 0).  Encoder and decoder of a tiny dDDPM against the oracle."""
     from models import DownsampleDDPMAutoencoder, Unet
     from oracle import resampler_ref as R
@@ -117,9 +117,10 @@ def test_resamplers_with_d_chans_not_a_multiple_of_64(d_chans):
     assert z.shape == (3, 8, 8, 8) and rel_err(z, zr) < 2e-5
     assert xr.shape == (3, 3, 32, 32) and rel_err(xr, R.rescaled_upsample(sd, cfg, z)) < 2e-5
     if d_chans % 64:
-        from ddk.lib import DDKError
-        with pytest.raises(DDKError):        # the backward kernels need d_chans % 64 == 0: loud, not silent
-            m.train()(x.to(DEV))
+        # round 5: these widths train as well (padded parameter copies; gradients vs torch autograd in test_generic_width_train_gpu.py)
+        obj, extra = m.train()(x.to(DEV))
+        obj.backward()
+        assert bool(torch.isfinite(obj)) and all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in m.downsample.parameters())
 
 
 # ---------------------------------------------------------------------------------------------------- cfg5
