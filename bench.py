@@ -379,6 +379,104 @@ def train_step_ms(device, steps=5):
                         "ms_per_step_two_passes: the reference's pass-by-pass sequence"}
 
 
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` with N > 1 and no launcher in front (WORLD_SIZE unset): start the N rank processes here.
+
+    This parent NEVER touches the GPU (no torch.cuda call that initialises HIP, no libddk load): it only counts devices, picks a
+    free rendezvous port, starts N fresh children of this file with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set (one process per
+    GPU, child r bound to cuda:r), relays rank 0's JSON line to stdout (everything else of the children goes to stderr) and exits
+    non-zero when any child fails or the job exceeds DDK_BENCH_TIMEOUT seconds -- the remaining children are then killed by the
+    exact process groups started here.  Nothing is ever re-exec'd."""
+    import signal
+    import socket
+    import subprocess
+    import threading
+    n = args.gpus
+    same = bool(os.environ.get("DDK_BENCH_SAME_DEVICE"))
+    have = torch.cuda.device_count()           # counting devices does not initialise the GPU
+    if have < n and not same:
+        log(f"bench.py: --gpus {n} but only {have} GPU(s) visible (one process per GPU over RCCL); "
+            "DDK_BENCH_SAME_DEVICE=1 rehearses N ranks on cuda:0 over gloo")
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    base = dict(os.environ, WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # the host driver only supports dmabuf IPC (RCCL between processes)
+    timeout = float(os.environ.get("DDK_BENCH_TIMEOUT", "1500"))
+    procs, lines = [], []
+    for r in range(n):
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env, text=True,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, start_new_session=True))
+
+    def relay():
+        for ln in procs[0].stdout:
+            lines.append(ln)
+    th = threading.Thread(target=relay, daemon=True)
+    th.start()
+
+    def kill_all():
+        for p in procs:
+            if p.poll() is None:
+                try:
+                    os.killpg(p.pid, signal.SIGKILL)       # the session this function started for exactly that child
+                except OSError:
+                    pass
+        for p in procs:
+            try:
+                p.wait(timeout=30)
+            except Exception:   # noqa: BLE001
+                pass
+
+    deadline = time.monotonic() + timeout
+    rc = 0
+    try:
+        while True:
+            codes = [p.poll() for p in procs]
+            bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+            if bad:
+                log(f"bench.py: rank {bad[0][0]} exited with code {bad[0][1]}; stopping the other ranks")
+                rc = 1
+                break
+            if all(c == 0 for c in codes):
+                break
+            if time.monotonic() > deadline:
+                log(f"bench.py: the {n}-rank job exceeded DDK_BENCH_TIMEOUT = {timeout:.0f} s; stopping it")
+                rc = 3
+                break
+            time.sleep(0.2)
+    finally:
+        kill_all()
+    th.join(timeout=10)
+    out = [ln for ln in lines if ln.lstrip().startswith("{")]
+    for ln in lines:
+        if ln not in out:
+            sys.stderr.write(ln)
+    if rc == 0 and not out:
+        log("bench.py: rank 0 printed no JSON line")
+        rc = 4
+    if rc == 0:
+        sys.stdout.write(out[-1])
+        sys.stdout.flush()
+    return rc
+
+
+def rank_report(device, world, payload):
+    """What the line says about the job's ranks, learnt over the process group itself: a REAL all-reduce of (rank + 1) must sum
+    to world (world + 1) / 2 -- `rccl_world` is the group size that all-reduce ran over -- and every rank's own figures
+    (`payload`: ms per step, the in-launch GroupNorm option it ended with, its device) are gathered, not assumed from rank 0."""
+    import torch.distributed as dist
+    tok = torch.tensor([float(dist.get_rank() + 1)], device=device, dtype=torch.float64)
+    dist.all_reduce(tok, op=dist.ReduceOp.SUM)
+    w = dist.get_world_size()
+    if abs(float(tok[0]) - w * (w + 1) / 2) > 1e-9:
+        raise RuntimeError(f"all-reduce over {w} ranks summed to {float(tok[0])}, expected {w * (w + 1) / 2}")
+    box = [None] * w
+    dist.all_gather_object(box, payload)
+    return {"rccl_world": w if dist.get_backend() == "nccl" else None, "world": w, "backend": dist.get_backend(), "ranks": box}
+
+
 def cfg5_train():
     """BASELINE.json config 5 as train.py builds it (reference train.py:19-46 + -d celeba_hq -bs 8 -is 256): the full-resolution DDPM"""
     return dict(model="ddpm", dataset="celeba_hq", batch_size=8, image_size=256, n_steps=10 ** 9, lr=2e-4, unet_chan=128,

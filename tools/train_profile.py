@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""A few optimiser steps of one training config for rocprofv3 --kernel-trace --stats: python tools/train_profile.py [cfg3|cfg2|cfg5] [graph]"""
+"""A few optimiser steps of one training config for rocprofv3 --kernel-trace --stats: python tools/train_profile.py [cfg3|cfg2|cfg5] [graph|merged]
+(graph: the step's two micro-batches captured as two passes; merged: as ONE pass over their concatenation -- the trainer's default since round 5)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(ROOT, "downsampled-diffusion_amd"), ROOT, os.path.join(ROOT, "tools")]
@@ -23,12 +24,13 @@ model = model.to(DEV).train()
 model.load_state_dict(syn.fill_state_dict(model.state_dict(), skip=syn.SCHEDULE_KEYS))
 opt = FusedAdam(model, lr=2e-4)
 x = torch.rand(xshape, device=DEV) * 2 - 1
-if len(sys.argv) > 2 and sys.argv[2] == "graph":      # the captured step the trainers replay (tools/train_breakdown.py reads its trace)
+if len(sys.argv) > 2 and sys.argv[2] in ("graph", "merged"):      # the captured step the trainers replay (tools/train_breakdown.py reads its trace)
     from trainers.graph_step import GraphedAccumulation
-    g = GraphedAccumulation(model, 2).capture([x, x])
+    xs = [x, x] if sys.argv[2] == "graph" else [torch.cat([x, x])]
+    g = GraphedAccumulation(model, len(xs)).capture(xs)
     opt.zero_grad()
     for step in range(6):
-        out = g.replay([x, x])
+        out = g.replay(xs)
         opt.step(); opt.zero_grad()
     torch.cuda.synchronize()
     print("done", float(out[-1][0]))
