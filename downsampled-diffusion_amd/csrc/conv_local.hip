@@ -59,9 +59,18 @@ __device__ __forceinline__ float4 staged_src4(const P& p, long long r, int c) {
     const float* s0 = p.src0 + r * p.c0 + c;
     float4 v = *reinterpret_cast<const float4*>(s0);
     if (p.src_slabs > 1) {
-        for (int sl = 1; sl < p.src_slabs; ++sl) {
-            const float4 u = *reinterpret_cast<const float4*>(s0 + sl * p.src_stride);
-            v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+        // four slab loads in flight at a time (clamped index, no load under a condition), added in slab order: a workgroup has nothing else
+        // to hide these behind -- issued one by one (first version) eight slabs cost the 4x4 Block 5.9 us, more than the reduce launch
+        for (int sl = 1; sl < p.src_slabs; sl += 4) {
+            float4 t[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int q = sl + j < p.src_slabs ? sl + j : p.src_slabs - 1;
+                t[j] = *reinterpret_cast<const float4*>(s0 + q * p.src_stride);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (sl + j < p.src_slabs) { v.x += t[j].x; v.y += t[j].y; v.z += t[j].z; v.w += t[j].w; }
         }
         if (p.src_bias) {
             const float4 bb = *reinterpret_cast<const float4*>(p.src_bias + c);
@@ -106,7 +115,14 @@ __device__ __forceinline__ TailPre<NV> tail_prefetch(const long long (&o)[NV], i
         float r = 0.f;
         if (p.addend) {
             r = p.addend[o[i]];
-            for (int sl = 1; sl < p.addend_slabs; ++sl) r += p.addend[sl * p.addend_stride + o[i]];
+            for (int sl = 1; sl < p.addend_slabs; sl += 4) {       // four loads in flight, added in slab order
+                float u[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) u[j] = p.addend[(sl + j < p.addend_slabs ? sl + j : p.addend_slabs - 1) * p.addend_stride + o[i]];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (sl + j < p.addend_slabs) r += u[j];
+            }
             if (p.addend_bias) r += p.addend_bias[c];
         }
         t.add[i] = r;
