@@ -100,7 +100,9 @@ struct ddk_unet {
                                              // sync point), 2 in ddk_unet_forward too
     int cluster_limit = 1 << 30;             // diagnostic: only the first so many eligible launches of a forward take that path
     int cluster_np_max = 8;                  // largest cluster (workgroups per image and n tile) that takes the path
-    bool fold_down_reduce = true;            // Downsample conv's split-K slabs summed by the image-local ResnetBlock behind it (no reduce launch)
+    bool fold_down_reduce = false;           // Downsample conv's split-K slabs summed by the image-local ResnetBlock behind it (no reduce launch).
+                                             // OFF by default: measured 6 us per step SLOWER (each of an image's eight workgroups re-sums the slabs:
+                                             // +6.3 / +5.9 us on the two consumers against reduce launches of 5.2 / 4.9 us; tools/fold_ab.py)
     bool attn_fold = true;                   // attention on maps with HW > 256, C = 128: q projection + apply + to_out as ONE per-image C x C conv
     // unet_chan % 8 == 0 but not % 32 (reference blocks.py:75 takes any GroupNorm(8, C)): every tensor keeps a pitch of pad32(C) channels
     // with zero padding, the convs run on the generic im2col kernels over zero-padded weights and the normalisations on their

@@ -337,10 +337,11 @@ int ddk_unet_forward(const ddk_unet* u, const void* packed, const float* x, cons
  * to_out run as ONE 1x1 conv of x with a per-image 128x128 matrix W_out . ctx^T . W_q (q is linear in this attention; the
  * PreNorm LayerNorm is folded in as well); 0 keeps to_qkv / context / apply / to_out.  Same result up to fp32 summation order. */
 #define DDK_OPT_ATTENTION_FOLD 3
-/* DDK_OPT_FOLD_DOWNSAMPLE_REDUCE (default 1): where a Downsample conv (blocks.py:41-47) splits its contraction and the ResnetBlock
+/* DDK_OPT_FOLD_DOWNSAMPLE_REDUCE (default 0: measured slower on MI355X at batch 32 -- every one of an image's eight workgroups re-sums the
+ * slabs; kept as an option and as ddk_conv3x3_gn_mish_slabs): where a Downsample conv (blocks.py:41-47) splits its contraction and the ResnetBlock
  * behind it runs on the image-local kernels (8x8 / 4x4 maps, no skip conv), the conv leaves its split-K slabs and that block's two
  * readers -- the first Block's staging loop, the second Block's residual -- sum them in slab order (+ bias): no reduce launch.
- * 0 keeps the reduce launch; bit-identical results either way. */
+ * 0 keeps the reduce launch; bit-identical results either way (tests/test_step_edges_gpu.py). */
 #define DDK_OPT_FOLD_DOWNSAMPLE_REDUCE 5
 int ddk_unet_set_option(ddk_unet* u, int option, int value);
 /* Waits for `s`, then reads and clears the sticky give-up count of the launches issued on `workspace` (a ddk_unet_forward or
