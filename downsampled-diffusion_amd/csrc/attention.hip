@@ -8,7 +8,7 @@
 // to_qkv / to_out run on the MFMA implicit-GEMM kernel (conv_igemm.hip); this file is the part between.
 #include <cstdlib>
 
-#include "ddk_internal.h"
+#include "conv_common.h"
 
 namespace ddk {
 
@@ -140,6 +140,249 @@ __global__ __launch_bounds__(256) void linattn_merge_kernel(const float* __restr
     const float inv = 1.0f / den;
     acc.x *= inv; acc.y *= inv; acc.z *= inv; acc.w *= inv;
     *reinterpret_cast<float4*>(ctx + ((long long)bh * DH + d) * DH + e0) = acc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k, v projection + context in ONE launch (round 5), for the folded attention block on maps with HW >> C (C = 128, 4 heads):
+// blocks.py:57-60 (PreNorm LayerNorm, folded into the weights), :123 (to_qkv's k and v thirds), :129-131 (softmax over the pixels of
+// k, ctx = k v^T).  The two-launch form writes the [M][256] kv tensor (33.5 MB at 32x32, batch 32) and reads it back; here a
+// workgroup keeps the k and v rows of TWO heads (128 rows of the LayerNorm-folded weight, all of K = 128: 64 KB) in LDS for its life,
+// streams 64-pixel tiles of x through a double buffer exactly like conv1x1_ws_kernel<true, false> (weights as the MFMA row operand,
+// the next tile's DMA under the 64 MFMAs of this one), and instead of storing the tile it
+//   * parks k and v of the tile in the LDS buffer the tile came from (4 x [64 pixels][32], the library's XOR swizzle),
+//   * keeps a running column maximum M[d] of k over its pixels (online softmax: when a tile raises M, the partial context and the
+//     denominators are rescaled by exp(M_old - M_new)),
+//   * accumulates ctx^T += (exp(k - M))^T v on the matrix pipe, wave = (head of the pair, 16 pixels of the tile),
+// and leaves ONE partial record {M, denominator, unnormalised ctx} per (image, head, pixel split) in the format of
+// linattn_context_kernel, which linattn_merge_kernel combines in split order.  grid = B x 2 head pairs x splits (256 workgroups at
+// batch 32: 4 splits of 4 tiles); 512 threads, 132 KB of LDS.
+constexpr int KC_K = 128, KC_BM = 64;
+constexpr int KC_W_FLOATS = 128 * KC_K, KC_A_FLOATS = KC_BM * KC_K;
+constexpr int KC_LDS_FLOATS = KC_W_FLOATS + 2 * KC_A_FLOATS + 2 * KC_BM + 64 + 64 + 8 * 64 + 8 * DH;
+
+struct KvCtxParams {
+    const float* x;      // [B * HW][128]
+    const float* w;      // [256][128]: LayerNorm-folded k rows (4 heads x 32), then v rows
+    const float* c1;     // [256] fold vectors W g and W b of those rows
+    const float* c2;
+    float eps;
+    float* part;         // [(b * 4 + head) * splits + split][PART]
+    int tiles_per_image, tiles_per_split, splits;
+};
+
+__global__ __launch_bounds__(512) void attn_kvctx_kernel(const KvCtxParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Ws = smem;                                   // [4 chunks][128 rows][32]
+    float* As = smem + KC_W_FLOATS;                     // [2 buffers][4 chunks][64 rows][32]; a consumed buffer holds the tile's k | v
+    float* rowstat = As + 2 * KC_A_FLOATS;              // [64][2]: (r, r * mean) of the tile's pixels
+    float* Mx = rowstat + 2 * KC_BM;                    // [64] running maximum of the k columns (head of the pair, d)
+    float* Sc = Mx + 64;                                // [64] exp(M_old - M_new) of the current tile
+    float* cmx = Sc + 64;                               // [8][64] column-maximum partials
+    float* dpart = cmx + 8 * 64;                        // [8][32] the waves' denominators
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int sp = blockIdx.x, hp = blockIdx.y, b = blockIdx.z;         // grid (splits, 2 head pairs, B): scalar without a division
+    const int wm = wid & 1, wn = wid >> 1;              // projection: pixels [32 wm, +32), slice rows [32 wn, +32): k h0 | k h1 | v h0 | v h1
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) float*)smem;
+    const int prow = lane >> 3, ppos = lane & 7;
+    const int dchunk = wid & 3, dhalf = wid >> 2;
+    unsigned wvoff[8], avoff[4];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int r = (dhalf * 8 + j) * 8 + prow;                                       // row of the slice
+        const int src = r < 64 ? 64 * hp + r : 128 + 64 * hp + (r - 64);                // row of the [k | v] weight
+        wvoff[j] = (unsigned)((src * KC_K + dchunk * 32 + ((ppos ^ ((r >> 1) & 7)) << 2)) * 4);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = (dhalf * 4 + j) * 8 + prow;
+        avoff[j] = (unsigned)((r * KC_K + dchunk * 32 + ((ppos ^ ((r >> 1) & 7)) << 2)) * 4);
+    }
+    {
+        const unsigned dst = lds_base + (unsigned)((dchunk * (128 * 32) + dhalf * 2048) * 4);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) lds_dma16_s(p.w, wvoff[j], dst + (unsigned)(j * 1024));
+    }
+    const unsigned a_dst = lds_base + (unsigned)((KC_W_FLOATS + dchunk * (KC_BM * 32) + dhalf * 1024) * 4);
+    const int tile0 = b * p.tiles_per_image + sp * p.tiles_per_split;       // 32-bit: stays on the scalar unit
+    {
+        const float* xb = p.x + (long long)tile0 * (KC_BM * KC_K);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) lds_dma16_s(xb, avoff[j], a_dst + (unsigned)(j * 1024));
+    }
+    // epilogue constants: accumulator register 4q + i = slice row 32 wn + 8 q + 4 h + i of pixel pl
+    const int pl = lane & 31, h = lane >> 5;
+    float4 e1[4], e2[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int r = 32 * wn + 8 * q + 4 * h;
+        const int col = r < 64 ? 64 * hp + r : 128 + 64 * hp + (r - 64);
+        e1[q] = *reinterpret_cast<const float4*>(p.c1 + col);
+        e2[q] = *reinterpret_cast<const float4*>(p.c2 + col);
+    }
+    const int fsw = (pl >> 1) & 7;
+    int foff[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) foff[q] = pl * 32 + (((2 * q + h) ^ fsw) << 2);
+    if (tid < 64) Mx[tid] = -INFINITY;
+
+    // context accumulators of this wave: head hh of the pair, pixels [16 qr, +16) of every tile
+    const int hh = wid >> 2, qr = wid & 3, l31 = lane & 31, kh = lane >> 5;
+    f32x16 macc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) macc[r] = 0.f;
+    float dsum = 0.f;
+    auto tswz = [](int n, int d) { return n * 32 + ((((d >> 2) ^ ((n >> 1) & 7)) << 2) | (d & 3)); };   // float offset of (pixel n, column d) in a parked tile
+
+    wait_vmcnt<0>();
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+    int buf = 0;
+    for (int ti = 0; ti < p.tiles_per_split; ++ti, buf ^= 1) {
+        float* Ab = As + buf * KC_A_FLOATS;
+        {   // LayerNorm statistics of the tile's 64 pixel rows (conv1x1_ws_kernel: 8 threads per row, two passes over the resident row)
+            const int row = tid >> 3, part = tid & 7;
+            const float4* rp = reinterpret_cast<const float4*>(Ab + (part >> 1) * (KC_BM * 32) + row * 32);
+            float4 v[4];
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                v[i] = rp[(4 * (part & 1) + i + (row >> 1)) & 7];
+                s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+            }
+            s += __shfl_xor(s, 1, 64);
+            s += __shfl_xor(s, 2, 64);
+            s += __shfl_xor(s, 4, 64);
+            const float mean = s * (1.0f / KC_K);
+            float qq = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float a = v[i].x - mean, bb = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+                qq += (a * a + bb * bb) + (c * c + d * d);
+            }
+            qq += __shfl_xor(qq, 1, 64);
+            qq += __shfl_xor(qq, 2, 64);
+            qq += __shfl_xor(qq, 4, 64);
+            if (part == 0) {
+                const float r = 1.0f / (sqrtf(qq * (1.0f / KC_K)) + p.eps);
+                rowstat[2 * row] = r;
+                rowstat[2 * row + 1] = r * mean;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+        const bool more = ti + 1 < p.tiles_per_split;
+        const float* xnext = p.x + (long long)(tile0 + ti + 1) * (KC_BM * KC_K);
+        const unsigned dnext = a_dst + (unsigned)((buf ^ 1) * KC_A_FLOATS * 4);
+        // ---- projection: D[slice row][pixel] += W[row][k] X[pixel][k]
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        const float* Ap = Ab + (wm * 32) * 32;
+        const float* Wp = Ws + (wn * 32) * 32;
+        float4 w0[2], xb[2];
+        w0[0] = *reinterpret_cast<const float4*>(Wp + foff[0]);
+        xb[0] = *reinterpret_cast<const float4*>(Ap + foff[0]);
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int cur = it & 1, nxt = cur ^ 1;
+            if (it < 15) {
+                const int c = (it + 1) >> 2, q = (it + 1) & 3;
+                w0[nxt] = *reinterpret_cast<const float4*>(Wp + c * (128 * 32) + foff[q]);
+                xb[nxt] = *reinterpret_cast<const float4*>(Ap + c * (KC_BM * 32) + foff[q]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float xv = e == 0 ? xb[cur].x : e == 1 ? xb[cur].y : e == 2 ? xb[cur].z : xb[cur].w;
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(e == 0 ? w0[cur].x : e == 1 ? w0[cur].y : e == 2 ? w0[cur].z : w0[cur].w, xv, acc, 0, 0, 0);
+                if (e == 0 && it < 4 && more) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    lds_dma16_s(xnext, avoff[it], dnext + (unsigned)(it * 1024));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        const float r = rowstat[2 * (32 * wm + pl)], rm = rowstat[2 * (32 * wm + pl) + 1];
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // every wave has read its fragments of this tile: the buffer is free
+        // ---- park k | v of the tile (LayerNorm fold applied) where x was: array wn = k h0 | k h1 | v h0 | v h1, row = pixel
+        {
+            float* T = Ab + wn * (KC_BM * 32);
+            const int row = 32 * wm + pl, sw = (row >> 1) & 7;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float4 v;
+                v.x = r * acc[4 * q] - rm * e1[q].x + e2[q].x;
+                v.y = r * acc[4 * q + 1] - rm * e1[q].y + e2[q].y;
+                v.z = r * acc[4 * q + 2] - rm * e1[q].z + e2[q].z;
+                v.w = r * acc[4 * q + 3] - rm * e1[q].w + e2[q].w;
+                *reinterpret_cast<float4*>(T + row * 32 + (((2 * q + h) ^ sw) << 2)) = v;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        {   // column maxima of k over the tile's 64 pixels: thread = (column c of 64, row group of 8)
+            const int c = tid & 63, ng = tid >> 6;
+            const float* Tk = Ab + (c >> 5) * (KC_BM * 32);
+            float m = -INFINITY;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) m = fmaxf(m, Tk[tswz(ng + 8 * j, c & 31)]);
+            cmx[ng * 64 + c] = m;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (tid < 64) {
+            float mm = cmx[tid];
+#pragma unroll
+            for (int j = 1; j < 8; ++j) mm = fmaxf(mm, cmx[j * 64 + tid]);
+            const float mo = Mx[tid], mn = fmaxf(mo, mm);
+            Sc[tid] = expf(mo - mn);                    // first tile: exp(-inf) = 0 against accumulators that are zero
+            Mx[tid] = mn;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {                    // exp(k - M) in place
+            const int idx = tid + j * 512;
+            const int n = idx >> 6, c = idx & 63;
+            float* q = Ab + (c >> 5) * (KC_BM * 32) + tswz(n, c & 31);
+            *q = expf(*q - Mx[c]);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        {   // ---- ctx^T += (exp k)^T v on the matrix pipe; a raised maximum first rescales what was accumulated
+            const float* Tk = Ab + hh * (KC_BM * 32);
+            const float* Tv = Ab + (2 + hh) * (KC_BM * 32);
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) macc[rr] *= Sc[hh * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * kh];
+            dsum *= Sc[hh * 32 + l31];
+#pragma unroll
+            for (int s2 = 0; s2 < 8; ++s2) {
+                const int n = qr * 16 + 2 * s2 + kh;
+                const float a = Tk[tswz(n, l31)];
+                macc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, Tv[tswz(n, l31)], macc, 0, 0, 0);
+                dsum += a;
+            }
+        }
+        wait_vmcnt<0>();                                 // this wave's pieces of the next tile
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // ... everyone's; and the parked tile is consumed
+    }
+    // ---- the four pixel quarters of a head meet in LDS (both tile buffers are free), fixed order
+    {
+        float* pt = As;                                  // [8 waves][32 d][33]
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) pt[(wid * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * kh) * 33 + l31] = macc[rr];
+        dsum += __shfl_xor(dsum, 32, 64);
+        if (kh == 0) dpart[wid * DH + l31] = dsum;
+        __syncthreads();
+        const int oh = tid >> 8, d = (tid >> 3) & 31, e0 = (tid & 7) * 4;
+        float4 acc4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        float den = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float* q = pt + ((oh * 4 + w) * 32 + d) * 33 + e0;
+            acc4.x += q[0]; acc4.y += q[1]; acc4.z += q[2]; acc4.w += q[3];
+            den += dpart[(oh * 4 + w) * DH + d];
+        }
+        float* pp = p.part + (((long long)b * 4 + 2 * hp + oh) * p.splits + sp) * PART;
+        if (e0 == 0) { pp[d] = Mx[oh * 32 + d]; pp[DH + d] = den; }
+        *reinterpret_cast<float4*>(pp + 2 * DH + d * DH + e0) = acc4;
+    }
 }
 
 // Core of the small-map kernels (256 threads): k (ROWS x 32, rows >= HW hold -inf), v (ROWS x 32), q (ROWS x 33 pitch) of one
@@ -711,6 +954,8 @@ __global__ __launch_bounds__(256) void attn_fold_kernel(const float* __restrict_
 }
 
 int linattn_small_qkv_init_device() {
+    DDK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_kvctx_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(KC_LDS_FLOATS * sizeof(float))));
     DDK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fold_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)(FOLD_LDS_FLOATS * sizeof(float))));
     DDK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(linattn_small_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -741,6 +986,37 @@ int linattn_small_qkv(const float* x, const float* wop, const float* c1, const f
         hipLaunchKernelGGL(linattn_small_qkv_kernel<4>, dim3(B * heads), dim3(256), small_qkv_lds_bytes(4, C), st, x, wop, c1, c2, ln_eps, ctx, out,
                            HW, C, heads);
     return check_launch("linattn_small_qkv_kernel");
+}
+
+// ---- k, v projection + context in one launch (attn_kvctx_kernel)
+bool attn_kvctx_ok(int B, int HW, int C, int heads) { return B > 0 && C == KC_K && heads == 4 && HW >= 4 * KC_BM && HW % KC_BM == 0; }
+int attn_kvctx_splits(int B, int HW) {
+    const int tiles = HW / KC_BM;
+    int s = 1;
+    while (s * 2 <= tiles && tiles % (s * 2) == 0 && (long long)B * 2 * (s * 2) <= 256) s *= 2;     // fill the chip, whole tiles per split
+    return s;
+}
+size_t attn_kvctx_workspace_bytes(int B, int HW) { return (size_t)B * 4 * attn_kvctx_splits(B, HW) * PART * sizeof(float); }
+
+// x [B*HW][128]; w_kv [256][128] = the k and v rows of the LayerNorm-folded to_qkv weight (W o g), c1 / c2 [256] = (W g, W b) of those
+// rows -> ctx [B][4][32][32] (softmax over the pixels of k, then k v^T), bit-stable; workspace: attn_kvctx_workspace_bytes
+int attn_kvctx(const float* x, const float* w_kv, const float* c1, const float* c2, float ln_eps, float* ctx, int B, int HW, void* workspace,
+               size_t workspace_bytes, hipStream_t st) {
+    DDK_REQUIRE(x && w_kv && c1 && c2 && ctx && workspace, "attn_kvctx: null pointer");
+    DDK_REQUIRE(attn_kvctx_ok(B, HW, KC_K, 4), "attn_kvctx: needs 128 channels, 4 heads, H*W a multiple of 64 and >= 256");
+    DDK_REQUIRE(aligned16(x) && aligned16(w_kv) && aligned16(c1) && aligned16(c2) && aligned16(ctx) && aligned16(workspace), "attn_kvctx: alignment");
+    DDK_REQUIRE((long long)B * HW * KC_K * 4 < (1LL << 32) && B <= 65535, "attn_kvctx: input of 4 GiB or more, or more than 65535 images");
+    const int s = attn_kvctx_splits(B, HW);
+    if (workspace_bytes < attn_kvctx_workspace_bytes(B, HW)) {
+        set_error("attn_kvctx: workspace too small (%zu < %zu)", workspace_bytes, attn_kvctx_workspace_bytes(B, HW));
+        return DDK_ERR_WORKSPACE;
+    }
+    DDK_TRY(ensure_device_init());
+    KvCtxParams p{x, w_kv, c1, c2, ln_eps, static_cast<float*>(workspace), HW / KC_BM, HW / KC_BM / s, s};
+    hipLaunchKernelGGL(attn_kvctx_kernel, dim3((unsigned)s, 2, (unsigned)B), dim3(512), KC_LDS_FLOATS * sizeof(float), st, p);
+    DDK_TRY(check_launch("attn_kvctx_kernel"));
+    hipLaunchKernelGGL(linattn_merge_kernel, dim3(B * 4), dim3(256), 0, st, static_cast<const float*>(workspace), ctx, s);
+    return check_launch("linattn_merge_kernel");
 }
 
 bool attn_fold_ok(int C, int heads) { return C == FOLD_C && heads * DH == FOLD_C; }
@@ -777,6 +1053,12 @@ int ddk_linattn_context(const float* qkv, float* ctx, int B, int HW, int heads, 
 }
 int ddk_linattn_context_kv(const float* kv, float* ctx, int B, int HW, int heads, void* workspace, size_t workspace_bytes, ddk_stream_t s) {
     return ddk::linattn_context(kv, ctx, B, HW, heads, workspace, workspace_bytes, ddk::as_stream(s), true);
+}
+size_t ddk_attention_kv_context_workspace_bytes(int B, int HW) { return ddk::attn_kvctx_workspace_bytes(B, HW); }
+int ddk_attention_kv_context_ok(int B, int HW, int C, int heads) { return ddk::attn_kvctx_ok(B, HW, C, heads) ? 1 : 0; }
+int ddk_attention_kv_context(const float* x, const float* w_kv, const float* c1, const float* c2, float ln_eps, float* ctx, int B, int HW,
+                             void* workspace, size_t workspace_bytes, ddk_stream_t s) {
+    return ddk::attn_kvctx(x, w_kv, c1, c2, ln_eps, ctx, B, HW, workspace, workspace_bytes, ddk::as_stream(s));
 }
 int ddk_attention_fold(const float* ctx, const float* wqg, const float* c1q, const float* c2q, const float* wout, const float* bout, float* A,
                        float* a1, float* a2, int B, int C, int heads, ddk_stream_t s) {

@@ -251,6 +251,10 @@ int linattn_context(const float* qkv, float* ctx, int B, int HW, int heads, void
                     bool kv_only = false);
 // folded attention output (attention.hip): per-image C x C matrix A and fold vectors from the context
 bool attn_fold_ok(int C, int heads);
+bool attn_kvctx_ok(int B, int HW, int C, int heads);     // k, v projection + context in one launch (attention.hip, attn_kvctx_kernel)
+size_t attn_kvctx_workspace_bytes(int B, int HW);
+int attn_kvctx(const float* x, const float* w_kv, const float* c1, const float* c2, float ln_eps, float* ctx, int B, int HW, void* workspace,
+               size_t workspace_bytes, hipStream_t st);
 size_t attn_fold_out_floats(int B);
 int attn_fold(const float* ctx, const float* wqg, const float* c1q, const float* c2q, const float* wout, const float* bout, float* A,
               float* a1, float* a2, int B, int C, int heads, hipStream_t st);

@@ -100,6 +100,7 @@ struct ddk_unet {
                                              // sync point), 2 in ddk_unet_forward too
     int cluster_limit = 1 << 30;             // diagnostic: only the first so many eligible launches of a forward take that path
     int cluster_np_max = 8;                  // largest cluster (workgroups per image and n tile) that takes the path
+    bool attn_kvctx = true;                  // folded attention block: k, v projection + context in one launch (no kv tensor)
     bool fold_down_reduce = false;           // Downsample conv's split-K slabs summed by the image-local ResnetBlock behind it (no reduce launch).
                                              // OFF by default: measured 6 us per step SLOWER (each of an image's eight workgroups re-sums the slabs:
                                              // +6.3 / +5.9 us on the two consumers against reduce launches of 5.2 / 4.9 us; tools/fold_ab.py)
@@ -408,6 +409,13 @@ extern "C" int ddk_unet_set_option(ddk_unet* u, int option, int value) {
         u->attn_fold = value != 0;
         return DDK_OK;
     }
+    if (option == DDK_OPT_ATTENTION_KV_CONTEXT) {
+        std::lock_guard<std::mutex> lock(u->mu);
+        if (!u->graphs.empty()) DDK_HIP(hipDeviceSynchronize());
+        drop_graphs(u);
+        u->attn_kvctx = value != 0;
+        return DDK_OK;
+    }
     if (option == DDK_OPT_FOLD_DOWNSAMPLE_REDUCE) {
         std::lock_guard<std::mutex> lock(u->mu);
         if (!u->graphs.empty()) DDK_HIP(hipDeviceSynchronize());
@@ -576,6 +584,7 @@ static void attn_sizes(const AttnW& a, int B, int H, int W, Layout& ly) {
     upd(ly.o, M * HIDDEN);
     upd(ly.ctx, (size_t)B * HEADS * 32 * 32);
     upd(ly.splitk, linattn_context_workspace_bytes(B, H * W, HEADS) / 4);   // the context partials reuse the split-K slab area
+    if (attn_kvctx_ok(B, H * W, a.c, HEADS)) upd(ly.splitk, attn_kvctx_workspace_bytes(B, H * W) / 4);
     upd(ly.splitk, conv_workspace_bytes(DDK_CONV1X1, B, H, W, a.c, 3 * HIDDEN) / 4);
     upd(ly.splitk, conv_workspace_bytes(DDK_CONV1X1, B, H, W, HIDDEN, a.c) / 4);
 }
@@ -851,12 +860,18 @@ static int run_attn(Ctx& c, const AttnW& a, const float* x, float* out, int H, i
         // q is linear in this attention: project k and v only, build the context, fold to_out . ctx^T . W_q (and the LayerNorm)
         // into one C x C matrix per image and apply it to x as a per-image 1x1 conv with the residual -- no q third of to_qkv, no
         // apply kernel, no separate to_out
-        const ConvLnFold lnkv{c.P + a.ln_c1 + HIDDEN, c.P + a.ln_c2 + HIDDEN, LN_EPS};
-        DDK_TRY(run_conv(c, DDK_CONV1X1, a.qkv, x, a.c, nullptr, 0, nullptr, qkv, H, W, 2 * HIDDEN, c.P + a.qkv_lnw + (size_t)HIDDEN * a.c,
-                         &lnkv));
-        // (round 4: merging the split context partials inside attn_fold_kernel instead of the 5.5 us merge launch made that kernel 13.0 ->
-        //  25.6 us -- each of an image's four workgroups redoes the 4 x 8 partial reads -- so the merge launch stays)
-        DDK_TRY(linattn_context(qkv, ctx, c.B, H * W, HEADS, c.W + c.ly.off_splitk, c.ly.splitk * sizeof(float), c.st, true));
+        if (c.u.attn_kvctx && attn_kvctx_ok(c.B, H * W, a.c, HEADS) && c.ly.splitk * sizeof(float) >= attn_kvctx_workspace_bytes(c.B, H * W)) {
+            // round 5: projection and context in one launch -- the 33.5 MB kv tensor of the 32x32 level is never written
+            DDK_TRY(attn_kvctx(x, c.P + a.qkv_lnw + (size_t)HIDDEN * a.c, c.P + a.ln_c1 + HIDDEN, c.P + a.ln_c2 + HIDDEN, LN_EPS, ctx, c.B, H * W,
+                               c.W + c.ly.off_splitk, c.ly.splitk * sizeof(float), c.st));
+        } else {
+            const ConvLnFold lnkv{c.P + a.ln_c1 + HIDDEN, c.P + a.ln_c2 + HIDDEN, LN_EPS};
+            DDK_TRY(run_conv(c, DDK_CONV1X1, a.qkv, x, a.c, nullptr, 0, nullptr, qkv, H, W, 2 * HIDDEN, c.P + a.qkv_lnw + (size_t)HIDDEN * a.c,
+                             &lnkv));
+            // (round 4: merging the split context partials inside attn_fold_kernel instead of the 5.5 us merge launch made that kernel 13.0 ->
+            //  25.6 us -- each of an image's four workgroups redoes the 4 x 8 partial reads -- so the merge launch stays)
+            DDK_TRY(linattn_context(qkv, ctx, c.B, H * W, HEADS, c.W + c.ly.off_splitk, c.ly.splitk * sizeof(float), c.st, true));
+        }
         float* A = o;                                   // [B][C][C], then a1, a2 [B][C] (the apply output buffer is free on this path)
         float* a1 = A + (size_t)c.B * a.c * a.c;
         float* a2 = a1 + (size_t)c.B * a.c;

@@ -101,6 +101,9 @@ SIGNATURES = {
     "ddk_conv3x3_gn_mish_wino_ok": (_I, [_I, _I, _I, _I, _I, _I]),
     "ddk_conv3x3_gn_mish_wino": (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
     "ddk_conv3x3_gn_mish_slabs": (_I, [_P, _I, _LL, _P, _I, _P, _P, _P, _P, _P, _I, _P, _I, _LL, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
+    "ddk_attention_kv_context_workspace_bytes": (_SZ, [_I, _I]),
+    "ddk_attention_kv_context_ok": (_I, [_I, _I, _I, _I]),
+    "ddk_attention_kv_context": (_I, [_P, _P, _P, _P, _F, _P, _I, _I, _P, _SZ, _P]),
     "ddk_pack_qkv_operand": (_I, [_P, _P, _I, _I, _P]),
     "ddk_linattn_small_from_x": (_I, [_P, _P, _P, _P, _F, _P, _P, _I, _I, _I, _I, _P]),
     "ddk_conv3x3_gn_mish_ok": (_I, [_I, _I, _I, _I, _I, _I]),

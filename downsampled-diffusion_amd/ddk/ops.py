@@ -50,7 +50,10 @@ class graph_owner:
         return self.keep
 
     def __exit__(self, *exc):
-        _graph_keep.remove(self.keep)
+        for i in range(len(_graph_keep) - 1, 0, -1):       # by identity (two empty lists compare equal); entry 0 is the process-wide list
+            if _graph_keep[i] is self.keep:
+                del _graph_keep[i]
+                break
         return False
 
 
@@ -411,6 +414,27 @@ def attention_folded(x, w_qkv, ln_g, ln_b, w_out, b_out, heads=4, eps=LN_EPS):
     L.check(lib.ddk_conv1x1_ws_images(L.ptr(x), L.ptr(a_mat), None, L.ptr(x), L.ptr(out), m, c, L.ptr(a1), L.ptr(a2), eps, b, L.stream()),
             "conv1x1_ws_images")
     return out
+
+
+def attention_kv_context(x, w_qkv, ln_g, ln_b, heads=4, eps=LN_EPS):
+    """ctx [B,4,32,32] of PreNorm(LinearAttention) (blocks.py:57-60,123,129-131) from x [B,H,W,128] in ONE launch + the split merge
+    (ddk_attention_kv_context): the k and v thirds of to_qkv with the LayerNorm folded in, softmax over the pixels of k, k v^T -- no kv
+    tensor.  w_qkv [384,128(,1,1)] canonical; ln_g / ln_b the channel LayerNorm's g, b."""
+    b, h, w_, c = x.shape
+    hc = heads * 32
+    lib = L.load()
+    if not lib.ddk_attention_kv_context_ok(b, h * w_, c, heads):
+        raise L.DDKError(f"attention_kv_context: shape {tuple(x.shape)} with {heads} heads not eligible (C = 128, 4 heads, H*W % 64 == 0)")
+    wq = w_qkv.reshape(3 * hc, c).to(torch.float32)
+    g, be = ln_g.reshape(-1).to(torch.float32), ln_b.reshape(-1).to(torch.float32)
+    wkv = (wq * g.view(1, c))[hc:].contiguous()
+    c1, c2 = (wq @ g)[hc:].contiguous(), (wq @ be)[hc:].contiguous()
+    ctx = torch.empty((b, heads, 32, 32), device=x.device, dtype=torch.float32)
+    nbytes = lib.ddk_attention_kv_context_workspace_bytes(b, h * w_)
+    ws = _ws(x.device, nbytes, "kvctx")
+    L.check(lib.ddk_attention_kv_context(L.ptr(_f32(x)), L.ptr(wkv), L.ptr(c1), L.ptr(c2), eps, L.ptr(ctx), b, h * w_, L.ptr(ws), nbytes,
+                                         L.stream()), "attention_kv_context")
+    return ctx
 
 
 def groupnorm_mish_from_partials_res1x1(x, part, tiles_per_image, gamma, beta, res_x, res_w, res_b, temb=None, groups=GN_GROUPS,

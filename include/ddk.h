@@ -232,6 +232,13 @@ int ddk_linattn_context_kv(const float* kv, float* ctx, int B, int HW, int heads
  * first 128 entries of its fold vectors; wout [128][128] = ddk_pack_conv_weight(to_out), bout [128] or NULL. */
 int ddk_attention_fold(const float* ctx, const float* wqg, const float* c1q, const float* c2q, const float* wout, const float* bout, float* A,
                        float* a1, float* a2, int B, int C, int heads, ddk_stream_t s);
+/* The k and v thirds of to_qkv (PreNorm LayerNorm folded in) + the context of the block in ONE launch, for C = 128, 4 heads, H*W a multiple
+ * of 64 (>= 256): no [M][256] kv tensor is written (blocks.py:57-60, 123, 129-131).  x [B*HW][128]; w_kv [256][128] = rows 128..383 of the
+ * folded weight W o g (k rows, then v rows); c1 / c2 [256] = W g / W b of those rows; ctx [B][4][32][32] as ddk_linattn_context_kv writes it. */
+size_t ddk_attention_kv_context_workspace_bytes(int B, int HW);
+int ddk_attention_kv_context_ok(int B, int HW, int C, int heads);
+int ddk_attention_kv_context(const float* x, const float* w_kv, const float* c1, const float* c2, float ln_eps, float* ctx, int B, int HW,
+                             void* workspace, size_t workspace_bytes, ddk_stream_t s);
 int ddk_linattn_fused_small(const float* qkv, float* ctx, float* out, int B, int HW, int heads, ddk_stream_t s);
 /* out[b][n][h*32+e] = sum_d ctx[b][h][d][e] * q[b][n][h*32+d]. */
 int ddk_linattn_apply(const float* qkv, const float* ctx, float* out, int B, int HW, int heads, ddk_stream_t s);
@@ -343,6 +350,9 @@ int ddk_unet_forward(const ddk_unet* u, const void* packed, const float* x, cons
  * readers -- the first Block's staging loop, the second Block's residual -- sum them in slab order (+ bias): no reduce launch.
  * 0 keeps the reduce launch; bit-identical results either way (tests/test_step_edges_gpu.py). */
 #define DDK_OPT_FOLD_DOWNSAMPLE_REDUCE 5
+/* DDK_OPT_ATTENTION_KV_CONTEXT (default 1): inside the folded attention block the k, v projection and the context run as one launch
+ * (ddk_attention_kv_context) instead of a 1x1 conv that writes the kv tensor + the context kernel that reads it back. */
+#define DDK_OPT_ATTENTION_KV_CONTEXT 6
 int ddk_unet_set_option(ddk_unet* u, int option, int value);
 /* Waits for `s`, then reads and clears the sticky give-up count of the launches issued on `workspace` (a ddk_unet_forward or
  * ddk_sampler_run workspace of this shape): DDK_OK, or DDK_ERR_CLUSTER when any in-launch GroupNorm exchange timed out. */

@@ -419,6 +419,68 @@ def test_attention_fold_option_gives_the_same_unet():
     assert rel_err(y_on.cpu(), y_off.cpu()) < 2e-5
 
 
+@pytest.mark.parametrize("B,H,W,shift", [(2, 32, 32, 0.0), (32, 32, 32, 0.0), (3, 16, 32, 0.0), (1, 64, 64, 0.0), (5, 16, 16, 0.0), (2, 32, 32, 30.0)])
+def test_attention_kv_projection_and_context_in_one_launch(ops, B, H, W, shift):
+    """ddk_attention_kv_context (attn_kvctx_kernel + the split merge): ctx = softmax_pixels(k) v^T with k, v = the k / v thirds of
+    to_qkv(LayerNorm(x)) (blocks.py:57-60,123,129-131) against torch in fp64, against the two-launch path (1x1 conv that writes kv +
+    linattn_context_kv), and bit-stable.  shift != 0: k columns whose maximum moves from tile to tile by tens (the online rescale of
+    the accumulated context is exercised: a per-pixel ramp is added to x along one channel direction)."""
+    C, heads = 128, 4
+    x = rnd(B, C, H, W, seed=181) * 1.3 + 0.2
+    if shift:
+        ramp = torch.linspace(0, 1, H * W).reshape(1, 1, H, W)
+        x = x + shift * ramp * rnd(1, C, 1, 1, seed=187)
+    wq = rnd(3 * C, C, 1, 1, seed=182, scale=C ** -0.5 * (3.0 if shift else 1.0))
+    g, be = 1 + 0.2 * rnd(C, seed=185), 0.1 * rnd(C, seed=186)
+    xd = x.double()
+    std = xd.var(dim=1, unbiased=False, keepdim=True).sqrt()
+    xn = (xd - xd.mean(dim=1, keepdim=True)) / (std + 1e-5) * g.double().view(1, C, 1, 1) + be.double().view(1, C, 1, 1)
+    q, k, v = F.conv2d(xn, wq.double()).reshape(B, 3, heads, 32, H * W).unbind(1)
+    ref = torch.einsum("bhdn,bhen->bhde", k.softmax(dim=-1), v)
+    xh = to_nhwc(x).to(DEV)
+    ctx = ops.attention_kv_context(xh, wq.to(DEV), g.to(DEV), be.to(DEV))
+    assert rel_err(ctx.cpu().double(), ref) < 2e-5
+    assert torch.equal(ctx, ops.attention_kv_context(xh, wq.to(DEV), g.to(DEV), be.to(DEV)))
+    # the two-launch path it replaces in the plan
+    hc = heads * 32
+    wqf = wq.reshape(3 * hc, C)
+    wg = (wqf * g.view(1, C)).to(DEV)
+    c1, c2 = (wqf @ g).to(DEV), (wqf @ be).to(DEV)
+    lib = ops.L.load()
+    kv = torch.empty((B, H, W, 2 * hc), device=DEV)
+    ops.L.check(lib.ddk_conv1x1_ws(ops.L.ptr(xh), ops.L.ptr(wg[hc:].contiguous()), None, None, ops.L.ptr(kv), B * H * W, 2 * hc,
+                                   ops.L.ptr(c1[hc:].contiguous()), ops.L.ptr(c2[hc:].contiguous()), 1e-5, ops.L.stream()), "conv1x1_ws(kv)")
+    two = torch.empty((B, heads, 32, 32), device=DEV)
+    nbytes = lib.ddk_linattn_context_workspace_bytes(B, H * W, heads)
+    ws = torch.empty(max(nbytes, 16) // 4, device=DEV)
+    ops.L.check(lib.ddk_linattn_context_kv(ops.L.ptr(kv), ops.L.ptr(two), B, H * W, heads, ops.L.ptr(ws), nbytes, ops.L.stream()), "context_kv")
+    assert rel_err(ctx.cpu(), two.cpu()) < 2e-5
+
+
+def test_attention_kv_context_option_gives_the_same_unet():
+    """plan option DDK_OPT_ATTENTION_KV_CONTEXT: the folded attention block of the 32x32 level with the k, v projection + context as one
+    launch == as a 1x1 conv + the context kernel (<= 2e-5 of the output's max; the two round differently), bit-stable"""
+    from helpers import det_state, unet_cfg
+    from models import Unet
+    from utils import synthetic as syn
+    cfg = unet_cfg(128, 8)
+    net = Unet(cfg)
+    net.load_state_dict(det_state({k: v.shape for k, v in net.state_dict().items()}))
+    net = net.to(DEV).eval()
+    x = syn.synthetic_normal((32, 8, 32, 32), "kvctx.x").to(DEV)
+    t = torch.arange(32, device=DEV) * 29
+    with torch.no_grad():
+        y_on = net(x, t)
+        plan = net.plan()
+        plan.set_option(plan.OPT_ATTENTION_KV_CONTEXT, 0)
+        y_off = net(x, t)
+        plan.set_option(plan.OPT_ATTENTION_KV_CONTEXT, 1)
+        y_on2 = net(x, t)
+    assert torch.equal(y_on, y_on2)
+    assert not torch.equal(y_on, y_off)
+    assert rel_err(y_on.cpu(), y_off.cpu()) < 2e-5
+
+
 def test_downsample_reduce_fold_option_gives_the_same_unet_bits():
     """plan option DDK_OPT_FOLD_DOWNSAMPLE_REDUCE: at batch 32 the Downsample convs of the 16x16 -> 8x8 and 8x8 -> 4x4 transitions split k;
     with the option on their slabs are summed by the image-local ResnetBlock behind them (two launches less per forward), with it off by
