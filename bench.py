@@ -34,7 +34,7 @@ WINO_PMC = "r04_wino_pmc.json"      # committed counter summary of the timed Win
 CLUSTER_PMC = "r04_wino_cluster32_pmc.json"   # ... of its in-launch-GroupNorm variant (three launches per step at 32x32)
 WINO_SRC = "downsampled-diffusion_amd/csrc/conv_wino.hip+downsampled-diffusion_amd/csrc/conv_wino2_kernel.inc"   # what its hash covers
 HBM_PMC = "r05_gn_pmc.json"         # ... of the GroupNorm-apply kernel (FETCH_SIZE / WRITE_SIZE passes)
-LOCAL_PMC = "r04_wlocal8_pmc.json"  # ... of the image-local conv + GroupNorm kernel (8x8 maps)
+LOCAL_PMC = "r05_wlocal8_pmc.json"  # ... of the image-local conv + GroupNorm kernel (8x8 maps)
 STREAM_PMC = "r04_stream_pmc.json"  # ... of the streaming 1x1 conv of the dDDPM encoder / decoder blocks
 
 

@@ -73,10 +73,10 @@ __global__ __launch_bounds__(256) void linattn_context_kernel(const float* __res
             if (n0 + row < n_end) {
                 kv = *reinterpret_cast<const float4*>(kp + (long long)(n0 + row) * RS + c);
                 vv = *reinterpret_cast<const float4*>(vp + (long long)(n0 + row) * RS + c);
-                kv.x = expf(kv.x - smax[c]);
-                kv.y = expf(kv.y - smax[c + 1]);
-                kv.z = expf(kv.z - smax[c + 2]);
-                kv.w = expf(kv.w - smax[c + 3]);
+                kv.x = __expf(kv.x - smax[c]);
+                kv.y = __expf(kv.y - smax[c + 1]);
+                kv.z = __expf(kv.z - smax[c + 2]);
+                kv.w = __expf(kv.w - smax[c + 3]);
             }
             *reinterpret_cast<float4*>(kexp + row * DH + c) = kv;
             *reinterpret_cast<float4*>(vs + row * DH + c) = vv;
@@ -333,7 +333,7 @@ __global__ __launch_bounds__(512) void attn_kvctx_kernel(const KvCtxParams p) {
 #pragma unroll
             for (int j = 1; j < 8; ++j) mm = fmaxf(mm, cmx[j * 64 + tid]);
             const float mo = Mx[tid], mn = fmaxf(mo, mm);
-            Sc[tid] = expf(mo - mn);                    // first tile: exp(-inf) = 0 against accumulators that are zero
+            Sc[tid] = __expf(mo - mn);                  // first tile: exp(-inf) = 0 against accumulators that are zero
             Mx[tid] = mn;
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -342,7 +342,7 @@ __global__ __launch_bounds__(512) void attn_kvctx_kernel(const KvCtxParams p) {
             const int idx = tid + j * 512;
             const int n = idx >> 6, c = idx & 63;
             float* q = Ab + (c >> 5) * (KC_BM * 32) + tswz(n, c & 31);
-            *q = expf(*q - Mx[c]);
+            *q = __expf(*q - Mx[c]);                     // hardware exp2 (1 ulp): the library expf is ~40 instructions, 8 per thread and tile
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         {   // ---- ctx^T += (exp k)^T v on the matrix pipe; a raised maximum first rescales what was accumulated
@@ -409,7 +409,7 @@ __device__ __forceinline__ void linattn_small_core(float* ks, float* vs, float* 
 #pragma unroll 8
     for (int j = 0; j < ROWS / 8; ++j) {                // exp(k - max) in place; padding rows -> exp(-inf) = 0
         const int i = tid + j * 256;
-        ks[i] = expf(ks[i] - smax[i & 31]);
+        ks[i] = __expf(ks[i] - smax[i & 31]);
     }
     __syncthreads();
     {
@@ -476,7 +476,7 @@ __device__ __forceinline__ void linattn_core_mfma(float* ks, float* vs, float* q
 #pragma unroll 8
     for (int j = 0; j < ROWS / 8; ++j) {                // exp(k - max) in place; padding rows -> exp(-inf) = 0
         const int i = tid + j * 256;
-        ks[i] = expf(ks[i] - smax[i & 31]);
+        ks[i] = __expf(ks[i] - smax[i & 31]);
     }
     __syncthreads();
     {   // softmax denominators: den[d] = sum_n exp k[n][d], 8 strided partials per column summed in fixed order
