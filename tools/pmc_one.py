@@ -5,7 +5,7 @@ cases: wino (conv3x3 128->128 @32x32 B=32, Winograd), gn (GroupNorm-apply from p
 one launch, 256->256 @4x4), wlocal8 (the same @8x8, Winograd form), first (conv_first 8->128 @32x32), tail (final_tail_kernel),
 cluster16 (conv3x3 256->256 @16x16 with GroupNorm finished in the launch), ws (to_out 1x1 128->128 + bias + residual @32x32,
 weights-stationary kernel), fold (attn_fold_kernel), halo32 (wgrad3x3_halo32_kernel), gnbig (gn_apply_kernel on the 256x256 tensor),
-c32 (conv3x3 32->32 @64x64 B=64 with the filter in registers), stream (conv1x1 32->64 @64x64 B=64 with Mish' and residual: conv1x1_stream.hip)."""
+kvctx (attn_kvctx_kernel: k, v projection + context @32x32), c32 (conv3x3 32->32 @64x64 B=64 with the filter in registers), stream (conv1x1 32->64 @64x64 B=64 with Mish' and residual: conv1x1_stream.hip)."""
 import os
 import sys
 
@@ -59,6 +59,10 @@ elif case == "ws":
     x, w = torch.randn(B, 32, 32, 128, device=dev), torch.randn(128, 128, device=dev) * 128 ** -0.5
     b, r = torch.zeros(128, device=dev), torch.randn(B, 32, 32, 128, device=dev)
     fn = lambda: ops.conv1x1_ws(x, w, b, r)
+elif case == "kvctx":          # k, v projection + context of the folded attention block in one launch (32 images, 32x32, C = 128)
+    x = torch.randn(B, 32, 32, 128, device=dev)
+    wq, g, be = torch.randn(384, 128, device=dev) * 128 ** -0.5, torch.ones(128, device=dev), torch.zeros(128, device=dev)
+    fn = lambda: ops.attention_kv_context(x, wq, g, be)
 elif case == "fold":           # the folded attention block's per-image matrix build at cfg4 (32 images, C = 128)
     ctx = torch.randn(B, 4, 32, 32, device=dev) * 0.1
     wq, c1, c2 = torch.randn(128, 128, device=dev) * 0.09, torch.randn(128, device=dev), torch.randn(128, device=dev)

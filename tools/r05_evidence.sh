@@ -16,4 +16,5 @@ f=$(ls $out/train/*/*kernel_trace.csv | head -1); python3 tools/train_breakdown.
 echo train breakdown done
 bash tools/pmc_run.sh wlocal8 conv3x3_gn_wlocal_kernel downsampled-diffusion_amd/csrc/conv_local.hip r05_wlocal8_pmc > $out/pmc_wlocal8.log 2>&1
 bash tools/pmc_run.sh local4 conv3x3_gn_local_kernel downsampled-diffusion_amd/csrc/conv_local.hip r05_local4_pmc > $out/pmc_local4.log 2>&1
+bash tools/pmc_run.sh kvctx attn_kvctx_kernel downsampled-diffusion_amd/csrc/attention.hip r05_kvctx_pmc > $out/pmc_kvctx.log 2>&1
 echo pmc done
