@@ -160,6 +160,9 @@ constexpr int KC_K = 128, KC_BM = 64;
 constexpr int KC_W_FLOATS = 128 * KC_K, KC_A_FLOATS = KC_BM * KC_K;
 constexpr int KC_LDS_FLOATS = KC_W_FLOATS + 2 * KC_A_FLOATS + 2 * KC_BM + 64 + 64 + 8 * 64 + 8 * DH;
 
+#ifndef DDK_KVCTX_ABL
+#define DDK_KVCTX_ABL 0      // tuning experiments only (wrong results): 1 no exp pass, 2 no maximum phases, 4 no context MFMAs, 8 nothing behind the projection, 16 no LayerNorm statistics
+#endif
 struct KvCtxParams {
     const float* x;      // [B * HW][128]
     const float* w;      // [256][128]: LayerNorm-folded k rows (4 heads x 32), then v rows
@@ -240,7 +243,7 @@ __global__ __launch_bounds__(512) void attn_kvctx_kernel(const KvCtxParams p) {
     int buf = 0;
     for (int ti = 0; ti < p.tiles_per_split; ++ti, buf ^= 1) {
         float* Ab = As + buf * KC_A_FLOATS;
-        {   // LayerNorm statistics of the tile's 64 pixel rows (conv1x1_ws_kernel: 8 threads per row, two passes over the resident row)
+        if (!(DDK_KVCTX_ABL & 16)) {   // LayerNorm statistics of the tile's 64 pixel rows (conv1x1_ws_kernel: 8 threads per row, two passes over the resident row)
             const int row = tid >> 3, part = tid & 7;
             const float4* rp = reinterpret_cast<const float4*>(Ab + (part >> 1) * (KC_BM * 32) + row * 32);
             float4 v[4];
@@ -305,7 +308,7 @@ __global__ __launch_bounds__(512) void attn_kvctx_kernel(const KvCtxParams p) {
         const float r = rowstat[2 * (32 * wm + pl)], rm = rowstat[2 * (32 * wm + pl) + 1];
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // every wave has read its fragments of this tile: the buffer is free
         // ---- park k | v of the tile (LayerNorm fold applied) where x was: array wn = k h0 | k h1 | v h0 | v h1, row = pixel
-        {
+        if (!(DDK_KVCTX_ABL & 8)) {
             float* T = Ab + wn * (KC_BM * 32);
             const int row = 32 * wm + pl, sw = (row >> 1) & 7;
 #pragma unroll
@@ -319,7 +322,7 @@ __global__ __launch_bounds__(512) void attn_kvctx_kernel(const KvCtxParams p) {
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        {   // column maxima of k over the tile's 64 pixels: thread = (column c of 64, row group of 8)
+        if (!(DDK_KVCTX_ABL & (8 | 2))) {   // column maxima of k over the tile's 64 pixels: thread = (column c of 64, row group of 8)
             const int c = tid & 63, ng = tid >> 6;
             const float* Tk = Ab + (c >> 5) * (KC_BM * 32);
             float m = -INFINITY;
@@ -328,7 +331,7 @@ __global__ __launch_bounds__(512) void attn_kvctx_kernel(const KvCtxParams p) {
             cmx[ng * 64 + c] = m;
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        if (tid < 64) {
+        if (tid < 64 && !(DDK_KVCTX_ABL & (8 | 2))) {
             float mm = cmx[tid];
 #pragma unroll
             for (int j = 1; j < 8; ++j) mm = fmaxf(mm, cmx[j * 64 + tid]);
@@ -338,14 +341,14 @@ __global__ __launch_bounds__(512) void attn_kvctx_kernel(const KvCtxParams p) {
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {                    // exp(k - M) in place
+        for (int j = 0; j < ((DDK_KVCTX_ABL & (8 | 1)) ? 0 : 8); ++j) {                    // exp(k - M) in place
             const int idx = tid + j * 512;
             const int n = idx >> 6, c = idx & 63;
             float* q = Ab + (c >> 5) * (KC_BM * 32) + tswz(n, c & 31);
             *q = __expf(*q - Mx[c]);                     // hardware exp2 (1 ulp): the library expf is ~40 instructions, 8 per thread and tile
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        {   // ---- ctx^T += (exp k)^T v on the matrix pipe; a raised maximum first rescales what was accumulated
+        if (!(DDK_KVCTX_ABL & (8 | 4))) {   // ---- ctx^T += (exp k)^T v on the matrix pipe; a raised maximum first rescales what was accumulated
             const float* Tk = Ab + hh * (KC_BM * 32);
             const float* Tv = Ab + (2 + hh) * (KC_BM * 32);
 #pragma unroll
