@@ -198,3 +198,20 @@ def test_bench_launcher_fails_loudly():
     if not torch.cuda.is_available():
         p = _bench({"DDK_BENCH_LAUNCH_PROBE": "1"}, "--gpus", "2")
         assert p.returncode == 2 and "only 0 GPU(s) visible" in p.stderr
+
+
+def test_graph_owner_registers_and_unregisters_by_identity():
+    """ddk.ops.graph_owner: while a capture runs, what captured launches address through device tables is appended to the capturing
+    object's own list; lists are told apart by identity (two empty lists compare equal), nesting unwinds in order, and the
+    process-wide list at the bottom is never removed"""
+    from ddk import ops
+    base = ops._graph_keep[0]
+    depth = len(ops._graph_keep)
+    a, b = [], []
+    with ops.graph_owner(a):
+        assert ops._graph_keep[-1] is a
+        with ops.graph_owner(b):
+            assert ops._graph_keep[-1] is b and ops._graph_keep[-2] is a
+            ops._graph_keep[-1].append("x")
+        assert ops._graph_keep[-1] is a and b == ["x"] and a == []
+    assert len(ops._graph_keep) == depth and ops._graph_keep[0] is base
