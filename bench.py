@@ -508,7 +508,9 @@ def train_dp(args, rank, world, device, dist_on, fence):
         cfg["batch_size"] = args.train_batch
     if args.train_image_size:
         cfg["image_size"] = args.train_image_size
-    trainer, cfg = setup_trainer(cfg, True, None, "bench_dp", seed=0)
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):          # the trainer's own prints are diagnostics here: stdout carries ONE JSON line
+        trainer, cfg = setup_trainer(cfg, True, None, "bench_dp", seed=0)
     B, S = cfg["batch_size"], cfg["image_size"]
     g = torch.Generator(device="cpu").manual_seed(4321 + rank)
     pool = [((torch.rand((B, 3, S, S), generator=g) * 2 - 1).to(device), 0) for _ in range(4)]
