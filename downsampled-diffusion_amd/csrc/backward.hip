@@ -958,17 +958,26 @@ __global__ __launch_bounds__(256) void conv1x1_small_n_bwd_kernel(const float* _
 //   mode 2: C[M][N] (+)= A[K][M]^T B[K][N]   (accumulating, for weight gradients)
 // gridDim.z > 1: the contraction is split, workgroup z takes k in [z * kper, (z + 1) * kper) and writes its partial tile to slab z
 // of Cm ([z][M][ldc], not accumulating); the host sums the slabs in order (a long-K product on a 2 x 16 grid of tiles took 380 us).
+typedef float sg_f32x16 __attribute__((ext_vector_type(16)));
 __global__ __launch_bounds__(256) void small_gemm_kernel(int mode, const float* __restrict__ A, const float* __restrict__ Bm,
                                                          float* __restrict__ Cm, int M, int N, int K, int lda, int ldb, int ldc,
                                                          int accumulate, int kper) {
+    // Round 5: the products run on the matrix pipe.  The VALU form read 160 LDS words per thread and 32-chunk for 128 FMAs (LDS-bound:
+    // 8 launches of ~40 us in the merged cfg3 step); here wave w multiplies the k rows [8 w, 8 w + 8) of every staged chunk with four
+    // v_mfma_f32_32x32x2_f32 (8 LDS words per lane and chunk) and the four waves' partial tiles meet in LDS once, at the end, in wave
+    // order -- deterministic.
     __shared__ float As[32][33];   // [k][m]
     __shared__ float Bs[32][33];   // [k][n]
+    __shared__ float Pt[4 * 32 * 33];
     const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
     const int k_lo = blockIdx.z * kper;
     if (gridDim.z > 1) { Cm += (long long)blockIdx.z * M * ldc; K = min(K, k_lo + kper); }
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // ty: 0..7
     const int mrow = threadIdx.x >> 3, nq = (threadIdx.x & 7) * 4;   // output strip: row mrow, columns nq..nq+3
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, l31 = lane & 31, kh = lane >> 5;
+    sg_f32x16 macc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) macc[r] = 0.f;
     for (int k0 = k_lo; k0 < K; k0 += 32) {
         // stage A as [k][m] and B as [k][n]; the fast thread index follows the operand's contiguous dimension
 #pragma unroll
@@ -991,13 +1000,19 @@ __global__ __launch_bounds__(256) void small_gemm_kernel(int mode, const float* 
         }
         __syncthreads();
 #pragma unroll
-        for (int k = 0; k < 32; ++k) {
-            const float a = As[k][mrow];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[j] += a * Bs[k][nq + j];
+        for (int j = 0; j < 4; ++j) {
+            const int k = wv * 8 + 2 * j + kh;
+            macc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[k][l31], Bs[k][l31], macc, 0, 0, 0);
         }
         __syncthreads();
     }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) Pt[(wv * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh) * 33 + l31] = macc[r];
+    __syncthreads();
+    float acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        acc[j] = ((Pt[mrow * 33 + nq + j] + Pt[(32 + mrow) * 33 + nq + j]) + Pt[(64 + mrow) * 33 + nq + j]) + Pt[(96 + mrow) * 33 + nq + j];
     const int m = m0 + mrow;
     if (m < M) {
 #pragma unroll
