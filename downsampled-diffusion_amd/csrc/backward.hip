@@ -1320,9 +1320,10 @@ static int gn_train_launch(bool bwd, const float* x, const float* gamma, const f
         else hipLaunchKernelGGL((gn_train_kernel<V, NT, false>), grid, dim3(NT), 0, st, x, gamma, beta, temb, temb_stride, addend,   \
                                 drop_p, seed, layer, dy, out, part, B, HW, C, groups, eps, nslab, slab_stride, conv_bias, raw_out);  \
     } while (0)
+    const bool many = (long long)B * groups >= 512;      // a training batch: several 256-thread workgroups per CU instead of one of 1024
     if (units <= 256) GT(1, 256);
     else if (units <= 512) GT(2, 256);
-    else if (units <= 1024) GT(1, 1024);
+    else if (units <= 1024) { if (many) GT(4, 256); else GT(1, 1024); }
     else if (units <= 2048) GT(2, 1024);
     else GT(4, 1024);
 #undef GT
