@@ -26,7 +26,18 @@ for p in (os.path.join(ROOT, "downsampled-diffusion_amd"), ROOT):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-import torch  # noqa: E402
+torch = None   # imported by main() AFTER the launcher decision: the parent of `--gpus N` never loads torch, HIP or libddk
+
+
+def _import_torch():
+    global torch
+    import torch as _t
+    torch = _t
+    return _t
+
+
+if __name__ != "__main__":     # imported for its helpers (tools/*.py): no launcher decision to wait for
+    _import_torch()
 
 FP32_PEAK_TFLOPS = 157.3      # MI355X fp32 matrix = vector peak (MI355X_MICROARCH.md, chip-level parameters)
 T_STEPS = 1000
@@ -255,9 +266,60 @@ def time_conv_cluster_roofline(device):
                 mfma_busy=pm["mfma_busy"] if pm else None, mfma_busy_source=src, launch_us=sec * 1e6, executed_gflop=executed / 1e9)
 
 
-def time_b192(model, plan, tables, device, rank, fence, steps=24):
+WINO_STEP_SHAPES = (          # every conv3x3_wino2_kernel launch of one cfg4 reverse step (profiles/r0N_sampler_step_breakdown.txt)
+    # (name, H, C_in, C_out, launches per step, GroupNorm finished inside the launch)
+    ("128->128 @32x32 + GroupNorm in the launch", 32, 128, 128, 3, True),
+    ("128->256 @16x16 + GroupNorm in the launch", 16, 128, 256, 1, True),
+    ("256->256 @16x16 + GroupNorm in the launch", 16, 256, 256, 3, True),
+    ("512->256 @8x8 (k split, slabs summed by the GroupNorm launch behind it)", 8, 512, 256, 1, False),
+    ("512->128 @16x16 (k split)", 16, 512, 128, 1, False),
+    ("128->128 @16x16 (k split)", 16, 128, 128, 3, False),
+    ("128->128 @32x32", 32, 128, 128, 1, False),
+)
+
+
+def time_wino_variants(device, B=32):
+    """`roofline.variants`: every shape the step runs on the Winograd kernel family, each timed live like the headline kernel
+    (graph replay, HIP events on the launch stream) and priced on the MFMA FLOPs it ISSUES (16 multiplies per 2x2 output tile and
+    channel pair, m tiles padded to 32) against the fp32 MFMA peak; `family_frac` weights them by their launches per step."""
+    from ddk import lib, ops
+    L = lib.load()
+    out, tot_f, tot_t = [], 0.0, 0.0
+    g = torch.Generator(device="cpu").manual_seed(7)
+    for name, H, C, N, count, gn in WINO_STEP_SHAPES:
+        try:
+            x = torch.randn(B, H, H, C, generator=g).to(device)
+            w = (torch.randn(N, C, 3, 3, generator=g) * (C * 9) ** -0.5).to(device)
+            b, gam, bet = torch.zeros(N, device=device), torch.ones(N, device=device), torch.zeros(N, device=device)
+            temb = torch.randn(B, N, generator=g).to(device)
+            wp, wu = ops.pack_conv_weight(w), ops.pack_conv_weight_wino(w)
+            in_launch = gn and L.ddk_conv3x3_gn_mish_cluster_ok(B, H, H, C, N, 8) > 0
+            if in_launch:
+                fn = lambda: ops.conv3x3_gn_mish_cluster(x, wu, b, gam, bet, temb=temb, check=False)   # noqa: E731
+            else:
+                if L.ddk_conv_wino_splits(B, H, H, C, N) <= 0:
+                    continue
+                fn = lambda: ops.conv(ops.CONV3X3_S1, x, wp, b, w_wino=wu, leave_slabs=True)           # noqa: E731
+            fn()
+            sec = graph_kernel_seconds(device, fn, n=40, reps=3)
+            tiles = -(-(B * (H // 2) * (H // 2)) // 32) * 32
+            executed = 2.0 * tiles * 16 * C * N
+            out.append({"shape": name, "launches_per_step": count, "groupnorm_in_launch": bool(in_launch), "launch_us": sec * 1e6,
+                        "executed_gflop": executed / 1e9, "achieved": executed / sec / 1e12,
+                        "frac": executed / sec / 1e12 / FP32_PEAK_TFLOPS})
+            tot_f += count * executed
+            tot_t += count * sec
+            del x, w, wp, wu
+        except Exception as e:   # noqa: BLE001 -- secondary figures
+            log(f"roofline.variants: {name}: {type(e).__name__}: {e}")
+    fam = tot_f / tot_t / 1e12 / FP32_PEAK_TFLOPS if tot_t > 0 else None
+    return out, fam, tot_t * 1e6
+
+
+def time_b192(model, plan, tables, device, rank, steps=24):
     """Secondary figure at the batch the reference's sampler CLI defaults to (generate_model_samples.py:16: batch_size = 192):
-    `steps` timed reverse steps + the x3 decoder at B = 192, extrapolated like the headline value."""
+    `steps` timed reverse steps + the x3 decoder at B = 192, extrapolated like the headline value.  Rank-local on purpose: no
+    collective inside the guarded section, so a rank that fails here (out of memory, say) cannot leave the others in a barrier."""
     from ddk import ops
     B, C, S = 192, 8, 32
     try:
@@ -265,7 +327,7 @@ def time_b192(model, plan, tables, device, rank, fence, steps=24):
             x = ops.randn((B, S, S, C), device, seed=99, step=T_STEPS, stream_id=rank)
             plan.sample_nhwc(x, tables, T_STEPS - 1, T_STEPS - 20, seed=99, stream_id=rank, use_graph=True)
             img = model.rescaled_upsample(ops.nhwc_to_nchw(x))
-            fence()
+            torch.cuda.synchronize()
             t0 = time.perf_counter()
             plan.sample_nhwc(x, tables, T_STEPS - 1, T_STEPS - steps, seed=99, stream_id=rank, use_graph=True)
             torch.cuda.synchronize()
@@ -364,57 +426,118 @@ def train_step_ms(device, steps=5):
         return (time.perf_counter() - t0) / steps * 1e3
     ms_two = timed(xs)
     ms = timed([torch.cat(xs)])
-    # forward + input-gradient + weight-gradient passes of encoder, UNet (16x16 latents) and decoder, 2 micro-batches of 64
-    fwd = model.downsample.flops(64, 64, 64) + model.latent_model.flops(64, 16, 16) + model.upsample.flops(64, 16, 16)
-    gflop = 2 * 3 * fwd / 1e9
+
+    def gflops(batch, passes):
+        """(algorithmic, issued) GFLOP of `passes` forward + backward passes over `batch` samples each.  Algorithmic: 3 x 2 MAC of
+        every conv / projection / attention product (forward, input gradient, weight gradient).  Issued: the forward as the plan
+        dispatches it (ddk_unet_flops_executed: Winograd 3x3 convs issue 16/36 of their direct multiplies); the input gradient
+        priced like the forward (the gradient of a stride-1 3x3 conv is again a stride-1 3x3 conv, of dY, on the same kernels);
+        the weight gradient direct.  The encoder / decoder blocks run direct kernels throughout."""
+        unet, dn, up = model.latent_model, model.downsample, model.upsample
+        edge = dn.flops(batch, 64, 64) + up.flops(batch, 16, 16)
+        alg = passes * 3 * (edge + unet.flops(batch, 16, 16))
+        issued = passes * (3 * edge + 2 * unet.flops_executed(batch, 16, 16) + unet.flops(batch, 16, 16))
+        return alg / 1e9, issued / 1e9
+    alg1, iss1 = gflops(128, 1)
+    alg2, iss2 = gflops(64, 2)
     return ms, {"kernel": "one optimiser step of cfg3 (CelebA 64x64 dDDPM -downsample 2, batch 64 = 2 micro-batches): encoder + UNet + "
-                          "decoder forward and backward, clip, Adam, EMA",
-                "bound": "mfma", "algorithmic_gflop": gflop, "ms_per_step": ms, "achieved": gflop / ms, "peak": FP32_PEAK_TFLOPS,
-                "unit": "TFLOP/s", "frac": gflop / ms / FP32_PEAK_TFLOPS, "ms_per_step_two_passes": ms_two,
-                "frac_two_passes": gflop / ms_two / FP32_PEAK_TFLOPS,
-                "note": "algorithmic FLOPs = 2 micro-batches x 3 (forward, input gradient, weight gradient) x 2 MAC of every conv / "
-                        "projection / attention product over the measured step time (wall clock incl. the optimiser); the 3x3 forward and "
-                        "input-gradient convs of eligible shapes run as Winograd, so the FLOPs issued are lower than this.  ms_per_step: the "
-                        "two micro-batches as one pass over their 128 samples (the trainer's default; same gradient); "
-                        "ms_per_step_two_passes: the reference's pass-by-pass sequence"}
+                          "decoder forward and backward, clip, Adam, EMA -- schedule `merged`: the two micro-batches as ONE pass over "
+                          "their 128 samples (the product trainer's default where memory allows; same gradient, different RNG draw order "
+                          "and 2x activation memory vs the reference's trainer_ddpm.py:118-128); `two_passes` below is the reference's "
+                          "own pass-by-pass sequence",
+                "schedule": "merged", "bound": "mfma", "ms_per_step": ms, "executed_gflop": iss1, "achieved": iss1 / ms, "peak": FP32_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": iss1 / ms / FP32_PEAK_TFLOPS, "algorithmic_gflop": alg1, "algorithmic_equiv_tflops": alg1 / ms,
+                "algorithmic_frac": alg1 / ms / FP32_PEAK_TFLOPS,
+                "two_passes": {"schedule": "two_passes", "ms_per_step": ms_two, "executed_gflop": iss2, "achieved": iss2 / ms_two,
+                               "frac": iss2 / ms_two / FP32_PEAK_TFLOPS, "algorithmic_gflop": alg2,
+                               "algorithmic_frac": alg2 / ms_two / FP32_PEAK_TFLOPS},
+                "ms_per_step_two_passes": ms_two,
+                "note": "frac prices the MFMA / FMA FLOPs ISSUED (forward as dispatched by the plan, input gradient priced like the forward, "
+                        "weight gradient direct) over the measured step time (wall clock incl. the optimiser) against the fp32 peak; "
+                        "algorithmic_frac prices 2 micro-batches x 3 passes x 2 MAC of the direct algorithm on the same time (a statement "
+                        "about the algorithm, not the chip)"}
+
+
+def visible_gpus():
+    """GPUs this process may use, counted WITHOUT the HIP runtime (torch.cuda.device_count() falls back to hipGetDeviceCount when
+    amdsmi is missing, and that initialises HSA in the caller): GPU nodes of the KFD topology (`simd_count` > 0 in
+    /sys/class/kfd/kfd/topology/nodes/*/properties), narrowed by ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES
+    when one of them is set.  None when the topology cannot be read (the children then find out for themselves)."""
+    root = "/sys/class/kfd/kfd/topology/nodes"
+    if not os.path.exists(root) and not os.path.exists("/dev/kfd"):
+        return 0                     # no amdgpu compute driver in this system at all
+    try:
+        n = 0
+        for node in sorted(os.listdir(root)):
+            try:
+                with open(os.path.join(root, node, "properties")) as f:
+                    props = dict(ln.split()[:2] for ln in f if len(ln.split()) >= 2)
+            except OSError:
+                continue
+            if int(props.get("simd_count", "0")) > 0:
+                n += 1
+    except OSError:
+        return None
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
+EADDRINUSE_EXIT = 98      # a rank that could not bind / reach the rendezvous port leaves with this code; the parent picks another port
+
+
+def _make_child_preexec():
+    """The function a child runs between fork and exec, i.e. before the child's program (and any GPU call) starts: the kernel sends
+    the child SIGKILL the moment its parent dies, however the parent dies (SIGKILL included: no handler of the parent's is
+    involved).  libc is resolved HERE, in the parent, so that nothing is imported between fork and exec."""
+    import ctypes
+    libc = ctypes.CDLL(None, use_errno=True)
+    parent = os.getpid()
+    PR_SET_PDEATHSIG, SIGKILL = 1, 9
+
+    def preexec():
+        libc.prctl(PR_SET_PDEATHSIG, SIGKILL, 0, 0, 0)
+        if os.getppid() != parent:   # the parent died before the prctl took effect
+            os._exit(1)
+    return preexec
 
 
 def launch_ranks(args, argv):
     """`python bench.py --gpus N` with N > 1 and no launcher in front (WORLD_SIZE unset): start the N rank processes here.
 
-    This parent NEVER touches the GPU (no torch.cuda call that initialises HIP, no libddk load): it only counts devices, picks a
-    free rendezvous port, starts N fresh children of this file with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set (one process per
-    GPU, child r bound to cuda:r), relays rank 0's JSON line to stdout (everything else of the children goes to stderr) and exits
-    non-zero when any child fails or the job exceeds DDK_BENCH_TIMEOUT seconds -- the remaining children are then killed by the
-    exact process groups started here.  Nothing is ever re-exec'd."""
+    This parent NEVER touches the GPU: it does not import torch, it counts devices from the KFD topology in sysfs (visible_gpus),
+    picks a free rendezvous port, starts N fresh children of this file with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set (one
+    process per GPU, child r bound to cuda:r), relays rank 0's JSON line to stdout (everything else of the children goes to stderr)
+    and exits non-zero when any child fails or the job exceeds DDK_BENCH_TIMEOUT seconds (default 480: under the driver's 600 s
+    limit, so it is this parent that stops a stalled job, not a kill of the parent).  Nothing is ever re-exec'd.
+
+    No child outlives the parent: every child asks the kernel for SIGKILL on the parent's death (PR_SET_PDEATHSIG, set before
+    its program starts), and SIGTERM / SIGINT / SIGHUP to the parent kill the children's process groups before the parent
+    leaves with 128 + signal."""
     import signal
     import socket
     import subprocess
     import threading
     n = args.gpus
     same = bool(os.environ.get("DDK_BENCH_SAME_DEVICE"))
-    have = torch.cuda.device_count()           # counting devices does not initialise the GPU
-    if have < n and not same:
+    have = visible_gpus()
+    if have is not None and have < n and not same:
         log(f"bench.py: --gpus {n} but only {have} GPU(s) visible (one process per GPU over RCCL); "
             "DDK_BENCH_SAME_DEVICE=1 rehearses N ranks on cuda:0 over gloo")
         return 2
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    base = dict(os.environ, WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # the host driver only supports dmabuf IPC (RCCL between processes)
-    timeout = float(os.environ.get("DDK_BENCH_TIMEOUT", "1500"))
+    timeout = float(os.environ.get("DDK_BENCH_TIMEOUT", "480"))
     procs, lines = [], []
-    for r in range(n):
-        env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env, text=True,
-                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, start_new_session=True))
+    preexec = _make_child_preexec()
 
-    def relay():
-        for ln in procs[0].stdout:
-            lines.append(ln)
-    th = threading.Thread(target=relay, daemon=True)
-    th.start()
+    class Stopped(Exception):
+        pass
+
+    def on_signal(signum, _frame):
+        raise Stopped(signum)
+    for sg in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
+        signal.signal(sg, on_signal)
 
     def kill_all():
         for p in procs:
@@ -429,26 +552,63 @@ def launch_ranks(args, argv):
             except Exception:   # noqa: BLE001
                 pass
 
+    def start(port):
+        base = dict(os.environ, WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # the host driver only supports dmabuf IPC (RCCL between processes)
+        del procs[:]
+        del lines[:]
+        for r in range(n):
+            env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env, text=True,
+                                          stdout=subprocess.PIPE if r == 0 else sys.stderr, start_new_session=True,
+                                          preexec_fn=preexec))
+        out0 = procs[0].stdout
+
+        def relay():
+            for ln in out0:
+                lines.append(ln)
+        th = threading.Thread(target=relay, daemon=True)
+        th.start()
+        return th
+
+    def free_port():
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            return sk.getsockname()[1]
+
     deadline = time.monotonic() + timeout
-    rc = 0
+    rc, th = 0, None
     try:
-        while True:
-            codes = [p.poll() for p in procs]
-            bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
-            if bad:
-                log(f"bench.py: rank {bad[0][0]} exited with code {bad[0][1]}; stopping the other ranks")
-                rc = 1
+        for attempt in range(3):
+            th = start(free_port())
+            rc = 0
+            while True:
+                codes = [p.poll() for p in procs]
+                bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+                if bad:
+                    rc = EADDRINUSE_EXIT if any(c == EADDRINUSE_EXIT for _, c in bad) else 1
+                    log(f"bench.py: rank {bad[0][0]} exited with code {bad[0][1]}; stopping the other ranks")
+                    break
+                if all(c == 0 for c in codes):
+                    break
+                if time.monotonic() > deadline:
+                    log(f"bench.py: the {n}-rank job exceeded DDK_BENCH_TIMEOUT = {timeout:.0f} s; stopping it")
+                    rc = 3
+                    break
+                time.sleep(0.2)
+            if rc != EADDRINUSE_EXIT:
                 break
-            if all(c == 0 for c in codes):
-                break
-            if time.monotonic() > deadline:
-                log(f"bench.py: the {n}-rank job exceeded DDK_BENCH_TIMEOUT = {timeout:.0f} s; stopping it")
-                rc = 3
-                break
-            time.sleep(0.2)
+            kill_all()                      # the port chosen by bind-then-close was taken in between: once more on another one
+            log("bench.py: the rendezvous port was taken by another process; starting the ranks again on a new port")
+            rc = 1
+    except Stopped as e:
+        sg = int(e.args[0])
+        log(f"bench.py: signal {sg} received; stopping the {n} ranks")
+        rc = 128 + sg
     finally:
         kill_all()
-    th.join(timeout=10)
+    if th is not None:
+        th.join(timeout=10)
     out = [ln for ln in lines if ln.lstrip().startswith("{")]
     for ln in lines:
         if ln not in out:
@@ -561,7 +721,15 @@ def train_dp(args, rank, world, device, dist_on, fence):
         lat = S >> cfg["n_downsamples"]
         fwd = model.downsample.flops(B, S, S) + model.latent_model.flops(B, lat, lat) + model.upsample.flops(B, lat, lat)
     acc = trainer.gradient_accumulate_every
+    merged = bool(getattr(trainer, "merge_micro_batches", False)) and acc > 1
     gflop = acc * 3 * fwd / 1e9
+    if cfg["model"] == "ddpm":
+        fx = model.latent_model.flops_executed(B * acc, S, S) if merged else acc * model.latent_model.flops_executed(B, S, S)
+        issued = (2 * fx + acc * fwd) / 1e9
+    else:
+        edge = model.downsample.flops(B, S, S) + model.upsample.flops(B, lat, lat)
+        fx = model.latent_model.flops_executed(B * acc, lat, lat) if merged else acc * model.latent_model.flops_executed(B, lat, lat)
+        issued = (3 * acc * edge + 2 * fx + acc * model.latent_model.flops(B, lat, lat)) / 1e9
     info = rank_report(device, world, {"rank": rank, "device": str(device), "ms_per_step": own_ms * 1e3}) if dist_on else None
     if rank != 0:
         return
@@ -580,9 +748,14 @@ def train_dp(args, rank, world, device, dist_on, fence):
                       "allreduce_bus_gbps": (2 * (world - 1) / world * nbytes / t_ar / 1e9) if dist_on and world > 1 and t_ar > 0 else None,
                       "n_params": int(bucket.numel()), "graph_train": bool(trainer._graph)},
            "roofline_train": {"kernel": "one optimiser step: forward + input-gradient + weight-gradient passes of every conv / projection "
-                                        "/ attention product, clip, Adam, EMA", "bound": "mfma", "algorithmic_gflop": gflop,
-                              "achieved": gflop / (t_full * 1e3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                              "frac": gflop / (t_full * 1e3) / FP32_PEAK_TFLOPS, "per": "GPU"}}
+                                        "/ attention product, clip, Adam, EMA -- schedule `" + ("merged" if merged else "two_passes") + "`",
+                              "schedule": "merged" if merged else "two_passes", "bound": "mfma", "executed_gflop": issued,
+                              "achieved": issued / (t_full * 1e3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                              "frac": issued / (t_full * 1e3) / FP32_PEAK_TFLOPS, "algorithmic_gflop": gflop,
+                              "algorithmic_frac": gflop / (t_full * 1e3) / FP32_PEAK_TFLOPS, "per": "GPU",
+                              "note": "frac: FLOPs issued (forward as the plan dispatches it, input gradient priced like the forward, "
+                                      "weight gradient direct) / step time / fp32 peak; algorithmic_frac: the direct algorithm's FLOPs "
+                                      "on the same time"}}
     if info:
         out["rccl_world"], out["dist"] = info["rccl_world"], info
     print(json.dumps(out), flush=True)
@@ -610,17 +783,31 @@ def main():
         args.warmup = 2 if args.train_dp else 10
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
-        sys.exit(launch_ranks(args, sys.argv[1:]))     # the parent: no GPU call before or after this line
+        sys.exit(launch_ranks(args, sys.argv[1:]))     # the parent: torch is not even imported in this process
 
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     probe = os.environ.get("DDK_BENCH_LAUNCH_PROBE")
     if probe:
-        # launcher self-test (tests/test_host_logic.py, no GPU): a rank reports the environment it was started with and leaves;
-        # "fail<r>" makes rank r exit 7 while the others would run for a minute, "hang" makes every rank outlive the timeout
+        # launcher self-test (tests/test_host_logic.py, no GPU, torch never imported): a rank reports the environment it was started
+        # with and leaves; "fail<r>" makes rank r exit 7 while the others would run for a minute, "hang" makes every rank outlive the
+        # timeout, "pids" makes every rank leave its pid in DDK_BENCH_PROBE_DIR and stay for a minute (what survives the parent?),
+        # "eaddr" makes rank 0 report a taken rendezvous port on the job's first start only
+        pdir = os.environ.get("DDK_BENCH_PROBE_DIR", "")
         if probe == f"fail{rank}":
             sys.exit(7)
+        if probe == "pids":
+            with open(os.path.join(pdir, f"rank{rank}.pid"), "w") as f:
+                f.write(str(os.getpid()))
+            time.sleep(60)
+        if probe == "eaddr":
+            mark = os.path.join(pdir, "second_start")
+            if rank == 0 and not os.path.exists(mark):
+                open(mark, "w").close()
+                sys.exit(EADDRINUSE_EXIT)
+            if rank != 0 and not os.path.exists(mark):
+                time.sleep(60)
         if probe.startswith("fail") or probe == "hang":
             time.sleep(60)
         if rank == 0:
@@ -629,6 +816,7 @@ def main():
         else:
             print(f"probe rank {rank} of {world}", flush=True)      # relayed to stderr by the parent
         return
+    _import_torch()
     if world != args.gpus:
         log(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}; using WORLD_SIZE")
     same_device = bool(os.environ.get("DDK_BENCH_SAME_DEVICE"))
@@ -645,10 +833,16 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         # RCCL wants one device per rank: several ranks on cuda:0 can only rendezvous over gloo
         backend = os.environ.get("DDK_BENCH_BACKEND", "gloo" if (same_device and world > 1) else "nccl")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+        try:
+            if backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+            else:
+                dist.init_process_group(backend, rank=rank, world_size=world)
+        except Exception as e:   # noqa: BLE001
+            if "EADDRINUSE" in str(e) or "address already in use" in str(e).lower():
+                log(f"rank {rank}: rendezvous port {os.environ.get('MASTER_PORT')} is taken: {e}")
+                sys.exit(EADDRINUSE_EXIT)       # launch_ranks starts the job again on another port
+            raise
 
     def fence():
         torch.cuda.synchronize()
@@ -701,10 +895,32 @@ def main():
     def decode():
         return model.rescaled_upsample(ops.nhwc_to_nchw(x))
 
+    def settle_clock(min_s=0.3, max_s=4.0, seg=48, tol=0.005):
+        """Warm up by TIME, whatever --warmup says: the shader clock this chip holds under the step's load is reached only after a
+        few hundred ms (a 5-step warm-up left the 20 timed steps of the round-5 record at 2.336 GHz while its full chain ran at
+        2.393).  Runs segments of `seg` reverse steps, each bracketed by a clock probe, until at least `min_s` seconds have passed
+        AND two consecutive segments held the same clock within `tol` (or `max_s` is over).  Untimed; every rank does the same."""
+        t_start, prev, ghz, segs = time.perf_counter(), None, None, 0
+        while True:
+            cp = ops.ClockProbe(device)
+            cp.probe()
+            run_steps(seg)
+            cp.probe()
+            torch.cuda.synchronize()
+            ghz = cp.ghz()
+            segs += 1
+            dt = time.perf_counter() - t_start
+            if dt >= min_s and prev and ghz and abs(ghz / prev - 1) <= tol:
+                return {"seconds": dt, "segments": segs, "steps": segs * seg, "ghz_last": ghz, "ghz_before": prev, "settled": True}
+            if dt >= max_s:
+                return {"seconds": dt, "segments": segs, "steps": segs * seg, "ghz_last": ghz, "ghz_before": prev, "settled": False}
+            prev = ghz
+
     clk_steps, clk_chain = ops.ClockProbe(device), ops.ClockProbe(device)
     with torch.no_grad():
         run_steps(max(args.warmup, 1))
         decode()
+        settled = settle_clock()
         fence()
         clk_steps.probe()
         t0 = time.perf_counter()
@@ -738,7 +954,7 @@ def main():
 
     b192 = None
     if not args.no_b192 and not same_device:
-        b192 = time_b192(model, plan, tables, device, rank, fence)
+        b192 = time_b192(model, plan, tables, device, rank)
 
     dist_info = None
     if dist_on:
@@ -757,6 +973,7 @@ def main():
 
     if rank == 0:
         roof = time_conv_roofline(device)
+        roof["variants"], roof["family_frac"], roof["family_us_per_step"] = time_wino_variants(device, B)
         roof_hbm = time_hbm_rooflines(device)
         out = {
             "metric": "images/sec (T=1000 sampling), 256x256 dDDPM-x3",
@@ -769,6 +986,7 @@ def main():
                        "decode_ms": t_decode * 1e3, "hip_graph": model.use_graph,
                        "weights_broadcast_bytes": bcast_bytes,
                        "shader_clock_ghz_timed_steps": clk_steps.ghz(),
+                       "clock_warmup": settled,
                        "in_launch_groupnorm": plan._cluster},
             "roofline": roof,
             "roofline_cluster": time_conv_cluster_roofline(device),

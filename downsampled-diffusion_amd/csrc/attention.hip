@@ -160,7 +160,8 @@ constexpr int KC_K = 128, KC_BM = 64;
 constexpr int KC_W_FLOATS = 128 * KC_K, KC_A_FLOATS = KC_BM * KC_K;
 constexpr int KC_LDS_FLOATS = KC_W_FLOATS + 2 * KC_A_FLOATS + 2 * KC_BM + 64 + 64 + 8 * 64 + 8 * DH;
 
-#ifndef DDK_KVCTX_ABL
+#if !defined(DDK_TUNING) || !defined(DDK_KVCTX_ABL)     /* an ablation exists in the tuning build only: the product library cannot be built with one */
+#undef DDK_KVCTX_ABL
 #define DDK_KVCTX_ABL 0      // tuning experiments only (wrong results): 1 no exp pass, 2 no maximum phases, 4 no context MFMAs, 8 nothing behind the projection, 16 no LayerNorm statistics
 #endif
 struct KvCtxParams {

@@ -557,7 +557,7 @@ __global__ __launch_bounds__(1024) void conv3x3_gn_wlocal_kernel(const WLocalPar
 #pragma unroll
             for (int kk = 0; kk < 8; ++kk) {
                 const float av = reinterpret_cast<const float*>(&a[0])[kk];
-#ifdef DDK_WL_NO_MFMA     /* ablation (wrong results): how long does the transform take when the matrix pipe is idle? */
+#if defined(DDK_TUNING) && defined(DDK_WL_NO_MFMA)     /* ablation, tuning build only (wrong results): how long does the transform take when the matrix pipe is idle? */
                 acc[pp][0][0] += av * reinterpret_cast<const float*>(&bq[pp][0][0])[kk];
                 acc[pp][1][0] += av * reinterpret_cast<const float*>(&bq[pp][1][0])[kk];
 #else

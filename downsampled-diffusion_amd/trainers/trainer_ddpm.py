@@ -18,6 +18,11 @@ from .trainer import Trainer
 from .train_helpers import cycle
 
 
+def _is_oom(text):
+    t = (text or "").lower()
+    return "out of memory" in t or "outofmemory" in t or "hiperroroutofmemory" in t
+
+
 def _invalidate(model):
     for m in model.modules():
         if hasattr(m, "invalidate_plan"):
@@ -39,6 +44,8 @@ class TrainerDDPM(Trainer):
             self.val_batch = next(self.train_loader)[0][0].repeat(self.n_samples, 1, 1, 1).to(self.device)
         self.step = 0
         self._graph = None
+        self._merge = None              # merged micro-batches: None = not decided yet, then True / False (see _accumulate)
+        self._merge_proven = False
         self.gradient_accumulate_every = 2
         self.logging_every = 10000
         if self.use_ema:
@@ -108,6 +115,13 @@ class TrainerDDPM(Trainer):
         elif self.step % self.update_ema_every == 0:
             self.ema.update(self.model)
 
+    @property
+    def merge_micro_batches(self):
+        """True while the micro-batches of a step run as one merged pass (decided at the first step; see _accumulate)"""
+        if self._merge is None:
+            return bool(self.config.get('merge_micro_batches', True)) and self.gradient_accumulate_every > 1
+        return bool(self._merge)
+
     # ------------------------------------------------------------------ one optimiser step
     def _micro_batch(self, x=None, passes=None):
         """One forward + backward; `passes` = how many such passes make up the optimiser step (the objective enters the gradient
@@ -134,21 +148,47 @@ class TrainerDDPM(Trainer):
         # concatenation): the micro-batches of a step go through ONE forward + backward as one batch of acc x batch_size samples --
         # the same gradient up to fp32 summation order (tests/test_trainer_gpu.py), half the launches, kernels twice as full.
         # config['merge_micro_batches'] = False keeps the reference's pass-by-pass sequence (trainer_ddpm.py:118-128).
-        merged = bool(self.config.get('merge_micro_batches', True)) and acc > 1 and all(b.shape == batches[0].shape for b in batches)
+        #
+        # Memory: a merged pass holds the activations of acc x batch_size samples at once -- what accumulation exists to avoid
+        # (cfg4 -bs 32: 30.3 GiB instead of 15.2).  So the merge is an optimisation that must be able to fail: when the first merged
+        # pass (graph capture, or the first eager pass) runs out of device memory on ANY rank, every rank drops to the pass-by-pass
+        # sequence for the rest of the run.  config['merge_micro_batches']: True (default) = merge with that fall-back, False = never.
+        micro = batches
+        if self._merge is None:
+            self._merge = bool(self.config.get('merge_micro_batches', True)) and acc > 1
+        merged = self._merge and all(b.shape == micro[0].shape for b in micro)
         if merged:
-            batches = [torch.cat(batches)]
+            batches = [torch.cat(micro)]
         use_graph = self.config.get('graph_train', True) and str(self.device).startswith('cuda')
-        if use_graph and self._graph is None:
+
+        def capture(bs):
             from .graph_step import GraphedAccumulation
-            graph, err = None, None
             try:
-                graph = GraphedAccumulation(self.model, len(batches)).capture(batches)
+                return GraphedAccumulation(self.model, len(bs)).capture(bs), None
             except Exception as e:       # noqa: BLE001 -- e.g. a model whose forward synchronises with the host
-                err = f"{type(e).__name__}: {e}"
+                return None, f"{type(e).__name__}: {e}"
+
+        def unmerge(why):
+            print(f"[trainer] the merged pass over {acc} x {micro[0].shape[0]} samples ran out of device memory ({why}); "
+                  f"this run accumulates pass by pass (config['merge_micro_batches'] = False says so up front)")
+            self._merge = False
+            self.opt.zero_grad()
+            if str(self.device).startswith('cuda'):
+                torch.cuda.synchronize()
+                torch.cuda.empty_cache()
+
+        if use_graph and self._graph is None:
+            graph, err = capture(batches)
             # The outcome is agreed on by ALL ranks before anyone acts on it: a rank that raised (or went eager) alone would
             # leave the others parked in all_reduce_flat_ -- either every rank replays the graph, or every rank raises /
-            # runs eagerly.
+            # runs eagerly / drops the merge.
             ok, first_err = all_ranks_agree(err is None, err)
+            if not ok and merged and _is_oom(first_err):
+                del graph
+                unmerge(first_err)
+                merged, batches = False, micro
+                graph, err = capture(batches)
+                ok, first_err = all_ranks_agree(err is None, err)
             if ok:
                 self._graph = graph
             else:
@@ -166,12 +206,32 @@ class TrainerDDPM(Trainer):
                 and all(b.shape == s.shape for b, s in zip(batches, self._graph.static_x))):
             rows = self._graph.replay(batches)
         else:
-            rows = []
-            for x in batches:
-                obj, extra = self._micro_batch(x, passes=len(batches))
-                rec = [obj] if extra is None else [obj, extra['latent'].detach(), extra['recon'].detach()]
-                rows.append(torch.stack([r.reshape(()) for r in rec]))
-            rows = torch.stack(rows)
+            def eager(bs):
+                rows = []
+                for x in bs:
+                    obj, extra = self._micro_batch(x, passes=len(bs))
+                    rec = [obj] if extra is None else [obj, extra['latent'].detach(), extra['recon'].detach()]
+                    rows.append(torch.stack([r.reshape(()) for r in rec]))
+                return torch.stack(rows)
+            if merged and not self._merge_proven:
+                # the first eager merged pass of the run: its outcome (did it fit?) is agreed on by all ranks, as above
+                rows, err = None, None
+                try:
+                    rows = eager(batches)
+                except Exception as e:   # noqa: BLE001
+                    err = f"{type(e).__name__}: {e}"
+                ok, first_err = all_ranks_agree(err is None, err)
+                if ok:
+                    self._merge_proven = True
+                elif _is_oom(first_err):
+                    del rows
+                    unmerge(first_err)
+                    merged, batches = False, micro
+                    rows = eager(batches)
+                else:
+                    raise RuntimeError(f"the training pass failed: {first_err}")
+            else:
+                rows = eager(batches)
         # one row per micro-batch as the loggers expect; a merged pass reports the mean over all its samples in each
         return rows.expand(acc, -1) if merged else rows
 

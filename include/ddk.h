@@ -522,7 +522,9 @@ typedef struct ddk_wgrad_reduce_job {
     long long slab_stride;
     long long block0;        /* set by ddk_wgrad_reduce_jobs */
     int splits, N, ntaps, cx, c_real, cw, c_off, reserved;
-} ddk_wgrad_reduce_job;      /* Training at widths that are not multiples of 32 (blocks.py:75: GroupNorm(8, C) takes any C % 8 == 0): activations keep a pitch
+} ddk_wgrad_reduce_job;      /* 80 bytes */
+
+/* Training at widths that are not multiples of 32 (blocks.py:75: GroupNorm(8, C) takes any C % 8 == 0): activations keep a pitch
  * CP = pad32(C) whose channels [C, CP) are ZERO, so the conv kernels (forward, input gradient, weight gradient) run unchanged on
  * zero-padded weights and only the two normalisations see the real channel count.  GroupNorm + Mish (+ temb[b][c], temb_stride floats
  * per image) (+ Dropout(drop_p), mask = f(seed, layer, element)) (+ addend): training forward; backward: dx and part [4][B][C] = per
@@ -539,7 +541,7 @@ int ddk_chan_layernorm_generic(const float* x, const float* g, const float* b, f
                                ddk_stream_t s);
 int ddk_chan_layernorm_generic_bwd(const float* x, const float* g, const float* dy, const float* addend, float* dx, float* part,
                                    int max_parts, int* nparts_out, long long M, int CP, int C, float eps, ddk_stream_t s);
-/* 80 bytes */
+/* the deferred weight-gradient reduce (ddk_wgrad_reduce_job above) */
 int ddk_conv_wgrad_defer(int kind, const float* x, const float* dy, float* grad_w, float* grad_b, int B, int H, int W, int cx, int c_real,
                          int cw, int c_off, int N, void* workspace, size_t workspace_bytes, ddk_wgrad_reduce_job* job_out, ddk_stream_t s);
 int ddk_wgrad_reduce_jobs(const ddk_wgrad_reduce_job* jobs_host, int n, ddk_stream_t s);

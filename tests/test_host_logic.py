@@ -200,6 +200,99 @@ def test_bench_launcher_fails_loudly():
         assert p.returncode == 2 and "only 0 GPU(s) visible" in p.stderr
 
 
+def test_bench_launcher_default_timeout_is_under_the_drivers():
+    """the driver stops bench.py at 600 s: the launcher's own limit must come first, so that IT stops the ranks"""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    m = re.search(r'DDK_BENCH_TIMEOUT", "(\d+)"', src)
+    assert m and int(m.group(1)) <= 500
+
+
+def test_bench_launcher_parent_never_imports_torch(tmp_path):
+    """the parent of `--gpus N` counts devices from sysfs and starts children: it must not load torch (and with it HIP) at all"""
+    import subprocess
+    import sys
+    code = ("import sys, runpy; sys.argv = ['bench.py', '--gpus', '8', '--steps', '1']\n"
+            "import os; os.environ.update(DDK_BENCH_SAME_DEVICE='1', DDK_BENCH_LAUNCH_PROBE='1'); os.environ.pop('WORLD_SIZE', None)\n"
+            "try:\n    runpy.run_path(%r, run_name='__main__')\nexcept SystemExit as e:\n    rc = e.code\n"
+            "bad = [m for m in sys.modules if m == 'torch' or m.startswith('torch.')]\n"
+            "print('RC', rc, 'TORCH', len(bad), file=sys.stderr)") % os.path.join(ROOT, "bench.py")
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=180)
+    assert "RC 0 TORCH 0" in p.stderr, p.stderr[-2000:]
+    import json
+    line = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 8                                # the N = 8 launch itself, rehearsed with probe children
+    for r in range(1, 8):
+        assert f"probe rank {r} of 8" in p.stderr
+
+
+def _alive(pid):
+    try:
+        with open(f"/proc/{pid}/stat") as f:
+            return f.read().rsplit(")", 1)[1].split()[0] != "Z"      # a zombie nobody reaps holds no resource
+    except OSError:
+        return False
+
+
+@pytest.mark.parametrize("sig", ["SIGTERM", "SIGKILL", "SIGINT"])
+def test_bench_launcher_children_never_outlive_the_parent(tmp_path, sig):
+    """What the driver's timeout does to `bench.py --gpus 8`: SIGTERM (the parent's handler kills the children's process groups) or
+    SIGKILL (no handler runs: every child asked the kernel for SIGKILL on its parent's death before its program started).  Either
+    way no rank process is left behind to hold a GPU."""
+    import signal
+    import subprocess
+    import sys
+    import time
+    e = dict(os.environ, DDK_BENCH_SAME_DEVICE="1", DDK_BENCH_LAUNCH_PROBE="pids", DDK_BENCH_PROBE_DIR=str(tmp_path))
+    e.pop("WORLD_SIZE", None)
+    n = 8
+    parent = subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n)], env=e, stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True)
+    try:
+        t0 = time.monotonic()
+        files = [tmp_path / f"rank{r}.pid" for r in range(n)]
+        while not all(f.exists() and f.read_text().strip() for f in files):
+            assert time.monotonic() - t0 < 60 and parent.poll() is None, "the ranks did not start"
+            time.sleep(0.1)
+        pids = [int(f.read_text()) for f in files]
+        assert all(_alive(p) for p in pids)
+        parent.send_signal(getattr(signal, sig))
+        rc = parent.wait(timeout=40)
+        assert rc != 0
+        t1 = time.monotonic()
+        while any(_alive(p) for p in pids):
+            assert time.monotonic() - t1 < 10, f"rank processes survived the parent's {sig}: {[p for p in pids if _alive(p)]}"
+            time.sleep(0.05)
+    finally:
+        if parent.poll() is None:
+            parent.kill()
+        for f in tmp_path.glob("rank*.pid"):
+            try:
+                os.kill(int(f.read_text()), signal.SIGKILL)
+            except (OSError, ValueError):
+                pass
+
+
+def test_bench_launcher_retries_on_a_taken_rendezvous_port(tmp_path):
+    """the port is chosen by bind-then-close; when a rank reports it taken (exit 98) the job is started once more on another port"""
+    import json
+    p = _bench({"DDK_BENCH_SAME_DEVICE": "1", "DDK_BENCH_LAUNCH_PROBE": "eaddr", "DDK_BENCH_PROBE_DIR": str(tmp_path)}, "--gpus", "2")
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert "starting the ranks again on a new port" in p.stderr
+    assert json.loads(p.stdout.strip().splitlines()[-1])["n_gpus"] == 2
+
+
+def test_visible_gpus_counts_from_sysfs_without_the_runtime(monkeypatch):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    n = b.visible_gpus()
+    assert n is None or n >= 0
+    if n:
+        monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0")
+        assert b.visible_gpus() == 1
+
+
 def test_graph_owner_registers_and_unregisters_by_identity():
     """ddk.ops.graph_owner: while a capture runs, what captured launches address through device tables is appended to the capturing
     object's own list; lists are told apart by identity (two empty lists compare equal), nesting unwinds in order, and the

@@ -377,3 +377,73 @@ def test_trainer_merges_the_micro_batches_of_a_step(tmp_path, monkeypatch):
     assert torch.allclose(rows[True][0], rows[False].mean(dim=0), rtol=2e-5)
     scale = float(grads[False].abs().max())
     assert float((grads[True] - grads[False]).abs().max()) < 2e-4 * scale
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("graph", [True, False])
+def test_merged_pass_out_of_memory_falls_back_to_pass_by_pass(tmp_path, monkeypatch, graph):
+    """A merged pass holds acc x batch_size samples' activations at once -- what accumulation exists to avoid (advisor, round 5).  When
+    the first merged pass (graph capture, or the first eager pass) runs out of device memory the trainer drops to the reference's
+    pass-by-pass sequence for the rest of the run instead of failing: same gradient as a trainer that never merged."""
+    import trainers.trainer as T
+    import trainers.trainer_ddpm as TD
+    for mod in (T, TD):
+        monkeypatch.setattr(mod, "LOGGING_DIR", str(tmp_path) + "/", raising=True)
+    from trainers import setup_trainer
+    B = 4
+    base = dict(model="ddpm", dataset="cifar10", n_steps=1, batch_size=B, image_size=16, n_downsamples=0, lr=2e-4, unet_chan=32,
+                unet_dims=(1, 2, 2, 2), unet_dropout=0.0, T=1000, loss_type="simple", beta_schedule="linear", ema_decay=0.995,
+                loss_flat="sum", val_split=0, n_samples=4, graph_train=graph)
+    xs = [syn.synthetic_input((B, 3, 16, 16), f"oom.x{k}").to(DEV) for k in range(2)]
+    t_all = torch.tensor([3, 50, 99, 100, 640, 7, 999, 320], device=DEV)
+    eps_all = syn.synthetic_normal((2 * B, 3, 16, 16), "oom.eps").to(DEV)
+    grads, seen = {}, {}
+    for mode in ("never_merged", "merge_runs_out_of_memory"):
+        cfg = dict(base, merge_micro_batches=(mode != "never_merged"))
+        trainer, _ = setup_trainer(cfg, True, str(tmp_path), "unit", seed=0)
+        passes = []
+
+        def loader():
+            while True:
+                for x in xs:
+                    yield (x, 0)
+        trainer.train_loader = loader()
+        state = {"t": 0, "e": 0}
+        inner = trainer.model.forward
+
+        def forward(x, inner=inner, passes=passes, mode=mode):
+            passes.append(int(x.shape[0]))
+            if mode != "never_merged" and x.shape[0] == 2 * B:
+                raise torch.OutOfMemoryError("HIP out of memory. Tried to allocate 30.30 GiB (injected by the test)")
+            return inner(x)
+        trainer.model.forward = forward
+
+        def t_sample(n, state=state):
+            lo = state["t"] % (2 * B)
+            state["t"] += n
+            return t_all[lo:lo + n]
+
+        def randn_like(z, state=state):
+            if tuple(z.shape[1:]) != (3, 16, 16):
+                return orig(z)
+            lo = state["e"] % (2 * B)
+            state["e"] += z.shape[0]
+            return eps_all[lo:lo + z.shape[0]]
+        trainer.model.t_sample = t_sample
+        orig = torch.randn_like
+        torch.randn_like = randn_like
+        try:
+            trainer.model.train()
+            trainer.opt.zero_grad()
+            rows = trainer._accumulate().cpu()
+        finally:
+            torch.randn_like = orig
+        assert rows.shape[0] == 2 and torch.isfinite(rows).all()
+        grads[mode] = trainer.opt.fp.grad.detach().cpu().clone()
+        seen[mode] = passes
+        assert trainer.merge_micro_batches is False
+    assert 2 * B in seen["merge_runs_out_of_memory"] and 2 * B not in seen["never_merged"]
+    assert seen["merge_runs_out_of_memory"][-2:] == [B, B]
+    if not graph:           # a captured graph draws t / eps inside the replay: the eager pair is the one with injected draws
+        scale = float(grads["never_merged"].abs().max())
+        assert float((grads["merge_runs_out_of_memory"] - grads["never_merged"]).abs().max()) <= 1e-6 * scale
