@@ -895,7 +895,7 @@ def main():
     def decode():
         return model.rescaled_upsample(ops.nhwc_to_nchw(x))
 
-    def settle_clock(min_s=0.3, max_s=4.0, seg=48, tol=0.005):
+    def settle_clock(min_s=0.5, max_s=2.0, seg=96, tol=0.01):
         """Warm up by TIME, whatever --warmup says: the shader clock this chip holds under the step's load is reached only after a
         few hundred ms (a 5-step warm-up left the 20 timed steps of the round-5 record at 2.336 GHz while its full chain ran at
         2.393).  Runs segments of `seg` reverse steps, each bracketed by a clock probe, until at least `min_s` seconds have passed
