@@ -614,18 +614,19 @@ __global__ __launch_bounds__(1024) void conv3x3_gn_wlocal_kernel(const WLocalPar
 }
 
 // dst[n tile][tap][chunk][n block][k half][lane = kq * 16 + n][j] = w[o = 32 nt + 16 nb + n][i = 32 chunk + 8 kq + 4 half + j][tap]
+// (taps = 9: a 3x3 filter [O][I][3][3]; taps = 1: a 1x1 filter [O][I])
 __global__ __launch_bounds__(256) void pack_conv_weight_local_kernel(const float* __restrict__ w, float* __restrict__ dst, int O, int I,
-                                                                     int i_pad, long long total) {
+                                                                     int i_pad, long long total, int taps) {
     const int nch = i_pad >> 5;
     for (long long idx = blockIdx.x * 256LL + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
         const int j = (int)(idx & 3), lane = (int)((idx >> 2) & 63), half = (int)((idx >> 8) & 1), nb = (int)((idx >> 9) & 1);
         long long r = idx >> 10;
         const int chunk = (int)(r % nch); r /= nch;
-        const int tap = (int)(r % 9);
-        const int nt = (int)(r / 9);
+        const int tap = (int)(r % taps);
+        const int nt = (int)(r / taps);
         const int o = nt * 32 + nb * 16 + (lane & 15);
         const int i = chunk * 32 + (lane >> 4) * 8 + half * 4 + j;
-        dst[idx] = i < I ? w[((long long)o * I + i) * 9 + tap] : 0.f;
+        dst[idx] = i < I ? w[((long long)o * I + i) * taps + tap] : 0.f;
     }
 }
 
@@ -749,7 +750,18 @@ int ddk_pack_conv_weight_local(const float* w_oihw, float* dst, int O, int I, in
     const long long total = (long long)O * 9 * i_pad;
     const long long blocks = ceil_div(total, 256);
     hipLaunchKernelGGL(pack_conv_weight_local_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, as_stream(s), w_oihw,
-                       dst, O, I, i_pad, total);
+                       dst, O, I, i_pad, total, 9);
+    return check_launch("pack_conv_weight_local_kernel");
+}
+
+int ddk_pack_conv1x1_weight_local(const float* w_oi, float* dst, int O, int I, int i_pad, ddk_stream_t s) {
+    using namespace ddk;
+    DDK_REQUIRE(w_oi && dst && O > 0 && I > 0 && O % 32 == 0 && i_pad >= I && i_pad % 32 == 0,
+                "pack_conv1x1_weight_local: arguments (O % 32 == 0, i_pad % 32 == 0)");
+    const long long total = (long long)O * i_pad;
+    const long long blocks = ceil_div(total, 256);
+    hipLaunchKernelGGL(pack_conv_weight_local_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, as_stream(s), w_oi,
+                       dst, O, I, i_pad, total, 1);
     return check_launch("pack_conv_weight_local_kernel");
 }
 

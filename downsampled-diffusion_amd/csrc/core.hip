@@ -4,6 +4,7 @@
 #include <mutex>
 
 #include "ddk_internal.h"
+#include "level_chain.h"
 
 namespace ddk {
 static thread_local char g_err[512] = "";
@@ -31,6 +32,7 @@ int ensure_device_init() {
     DDK_TRY(conv_init_device());
     DDK_TRY(conv_wino_init_device());
     DDK_TRY(conv_gn_local_init_device());
+    DDK_TRY(level_chain_init_device());
     DDK_TRY(conv_first_init_device());
     DDK_TRY(conv1x1_ws_init_device());
     DDK_TRY(conv1x1_sm_init_device());

@@ -1,0 +1,487 @@
+// level_chain.hip -- the whole 4x4 level of the UNet in ONE persistent launch.
+//
+// Reference: models/unet/unet.py:83-101 (the level's module sequence: downs[-1] ResnetBlock x 2 + attention, mid_block1, mid_attn,
+// mid_block2, ups[0] ResnetBlock x 2 + attention), models/unet/blocks.py:74-84 (Block), :105-115 (ResnetBlock), :8-14, 50-71,
+// 116-134 (Residual(PreNorm(LinearAttention))).
+//
+// Why: at batch 32 a 4x4 map is 512 pixels.  Each of the level's 19 launches (12 conv3x3 + GroupNorm + Mish, one with a 512-channel
+// concat input, 3 x {to_qkv + attention core, to_out}, one 1x1 skip conv) did ~4-5 us of matrix work inside ~10 us: what stands
+// between two dependent launches is a kernel boundary (2.9 us at this geometry, tools/chain_hop.hip) plus the restaging of an image
+// that never leaves its eight workgroups.  Here the level is one launch: workgroup (image b, channel slice nt) walks the level's op
+// list; after an op it publishes its 16 x 32 slice (sc1 stores, drained, one arrival on the image's counter) and before the next
+// it waits for the image's eight arrivals and stages the 16 x C image (sc1 loads) -- the hand-off form of row 1 of
+// MI355X_MICROARCH.md's sc1 table, 1.8 us per hop instead of 2.9 (profiles/r06_chain_hop.txt).  The next op's first weight units,
+// affine and time shift are requested BEFORE the wait; the residual stream never goes through memory at all: thread (row, col)
+// of a workgroup produces the same output element in every op, so the ResnetBlock / attention residual is a register.
+//
+// Geometry: grid = 8 x min(B, 32) workgroups of 512 threads, block = image slot * 8 + slice, so that the 32 workgroups of a slice
+// share one XCD's L2 for that slice's filter (as in conv_local.hip); images beyond 32 are walked in rounds.  All workgroups of the
+// grid are resident at once on a whole, otherwise idle MI355X (<= 256 workgroups, one per CU: 96 KB of LDS); the waits are bounded
+// by wall time anyway, a give-up moves the caller's sticky fail word (ddk_unet_cluster_check) and is never silent.
+#include "level_chain.h"
+
+#include <atomic>
+#include <cstdlib>
+
+namespace ddk {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int LC_BIG = 12800;              // floats: image [17][cin + 4] (cin <= 512) | conv partials 8 x 16 x 36 | attention partials 8 x 16 x 100
+constexpr int LC_PP = 36;                  // conv partial row pitch
+constexpr int LC_QP = 100;                 // attention partial row pitch (96 columns + 4)
+constexpr int LC_RED = LC_BIG;             // 64
+constexpr int LC_TILE = LC_RED + 64;       // [16][36]: the output slice on its way to 16-byte stores
+constexpr int LC_KS = LC_TILE + 576;       // [16][32]
+constexpr int LC_VS = LC_KS + 512;         // [16][32]
+constexpr int LC_QS = LC_VS + 512;         // [16][33]
+constexpr int LC_CS = LC_QS + 528;         // [32][36]
+constexpr int LC_SMAX = LC_CS + 1152;      // [32]
+constexpr int LC_ROWSTAT = LC_SMAX + 32;   // [16][2]
+constexpr int LC_CFOLD = LC_ROWSTAT + 32;  // [192]
+constexpr int LC_MISC = LC_CFOLD + 192;    // [0] this workgroup gave up waiting
+constexpr int LC_FLOATS = LC_MISC + 4;
+
+size_t level_chain_lds_bytes() { return 96 * 1024; }     // > 80 KB: one workgroup per CU
+static_assert(LC_FLOATS * 4 <= 96 * 1024, "LDS carve-up");
+
+// ---- memory-side helpers: 16-byte sc1 loads (several in flight, ONE counted wait that owns their registers) and stores
+__device__ __forceinline__ void ld_sc1(f32x4& v, const float* p) { asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory"); }
+__device__ __forceinline__ void wait_vm(f32x4& a) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(a) :: "memory"); }
+__device__ __forceinline__ void wait_vm(f32x4& a, f32x4& b) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b) :: "memory"); }
+__device__ __forceinline__ void wait_vm(f32x4& a, f32x4& b, f32x4& c, f32x4& d) {
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) :: "memory");
+}
+__device__ __forceinline__ void st_sc1(float* p, f32x4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(v) : "memory"); }
+
+struct ChainCtx {
+    float* lds;
+    int tid, lane, wave, b, nt;
+    unsigned signals;            // signalling ops of this image so far (uniform)
+    float keep, keep2;
+};
+
+// every arrival of the image so far (8 per signalling op); bounded: 20 ms of wall time, then this workgroup stops waiting for good
+__device__ __forceinline__ void chain_wait(const ChainParams& p, ChainCtx& c) {
+    int* dead = reinterpret_cast<int*>(c.lds + LC_MISC);
+    if (c.tid == 0 && !*dead) {
+        const unsigned need = 8u * c.signals;
+        unsigned* cnt = p.cnt + c.b * 32;
+        if (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+            const long long t0 = __builtin_amdgcn_s_memrealtime();
+            while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+                __builtin_amdgcn_s_sleep(1);
+                if (__builtin_amdgcn_s_memrealtime() - t0 > 2000000LL) {       // 100 MHz ticks
+                    *dead = 1;
+                    atomicAdd(p.fail, 1u);
+                    break;
+                }
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// after the op's stores: every storing wave drains, the workgroup meets, ONE lane arrives for all of them
+__device__ __forceinline__ void chain_signal(const ChainParams& p, ChainCtx& c) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (c.tid == 0) __hip_atomic_fetch_add(p.cnt + c.b * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    ++c.signals;
+}
+
+// [16 rows][cin] of image b (src0 | src1 along the channels) -> LDS rows of pitch cin + 4; 512 threads, cin / 128 float4 each
+__device__ __forceinline__ void chain_stage(const ChainOp& o, ChainCtx& c, int cin, int pitch) {
+    const int q4 = cin >> 2;
+    auto addr = [&](int idx) -> const float* {
+        const int row = idx / q4, ch = (idx - row * q4) << 2;
+        const long long r = (long long)c.b * 16 + row;
+        return ch < o.c0 ? o.src0 + r * o.c0 + ch : o.src1 + r * o.c1 + (ch - o.c0);
+    };
+    auto put = [&](int idx, f32x4 v) {
+        const int row = idx / q4, ch = (idx - row * q4) << 2;
+        *reinterpret_cast<f32x4*>(c.lds + row * pitch + ch) = v;
+    };
+    if (cin == 512) {
+        f32x4 v0, v1, v2, v3;
+        ld_sc1(v0, addr(c.tid)); ld_sc1(v1, addr(c.tid + 512)); ld_sc1(v2, addr(c.tid + 1024)); ld_sc1(v3, addr(c.tid + 1536));
+        wait_vm(v0, v1, v2, v3);
+        put(c.tid, v0); put(c.tid + 512, v1); put(c.tid + 1024, v2); put(c.tid + 1536, v3);
+    } else if (cin == 256) {
+        f32x4 v0, v1;
+        ld_sc1(v0, addr(c.tid)); ld_sc1(v1, addr(c.tid + 512));
+        wait_vm(v0, v1);
+        put(c.tid, v0); put(c.tid + 512, v1);
+    } else {    // 128
+        f32x4 v0;
+        ld_sc1(v0, addr(c.tid));
+        wait_vm(v0);
+        put(c.tid, v0);
+    }
+    if (c.tid < q4) *reinterpret_cast<f32x4*>(c.lds + 16 * pitch + (c.tid << 2)) = f32x4{0.f, 0.f, 0.f, 0.f};   // the row out-of-image taps read
+}
+
+// this thread's output element y (row = tid / 32, col = tid % 32 of the workgroup's 16 x 32 slice) -> out, as 16-byte stores
+__device__ __forceinline__ void chain_store(const ChainOp& o, ChainCtx& c, float y, int n0) {
+    float* tile = c.lds + LC_TILE;
+    tile[(c.tid >> 5) * LC_PP + (c.tid & 31)] = y;
+    __syncthreads();
+    if (c.tid < 128) {
+        const int r = c.tid >> 3, c4 = (c.tid & 7) << 2;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(tile + r * LC_PP + c4);
+        float* dst = o.out + ((long long)c.b * 16 + r) * o.n_out + n0 + c4;
+        if (o.flags & CHF_SIGNAL) st_sc1(dst, v);
+        else *reinterpret_cast<f32x4*>(dst) = v;
+    }
+}
+
+// sum over the workgroup's 512 threads, the same value in every thread; `rd` = 8 floats nobody else touches until the next barrier
+__device__ __forceinline__ float chain_sum512(float s, float* rd, int lane, int wave) {
+    s = wave_sum(s);
+    if (lane == 0) rd[wave] = s;
+    __syncthreads();
+    float t = rd[0];
+#pragma unroll
+    for (int w = 1; w < 8; ++w) t += rd[w];
+    return t;
+}
+
+// CH_CONV3 / CH_CONV1.  The arithmetic of conv3x3_gn_local_kernel<16, 1, NU> (conv_local.hip): direct conv on v_mfma_f32_16x16x4_f32,
+// the 8 waves split k = taps x 32-channel chunks, weights straight from L2 into registers in MFMA operand order (three units in
+// flight), partial tiles meet in LDS, GroupNorm over the slice (32 channels x 16 pixels = one group) in two passes.
+// NU > 0: cin = 256 NU and 9 taps (compile-time taps, the nine source rows precomputed); NU = 0: generic (the 1x1 convs).
+template <int NU>
+__device__ __forceinline__ void chain_conv(const ChainParams& p, const ChainOp& o, ChainCtx& c) {
+    float* lds = c.lds;
+    const int tid = c.tid, lane = c.lane, wave = c.wave;
+    const int m = lane & 15, kq = lane >> 4;
+    const int n0 = c.nt << 5;
+    const int cin = o.c0 + o.c1, pitch = cin + 4, nch = cin >> 5;
+    const int taps = o.kind == CH_CONV3 ? 9 : 1;
+
+    // ---- what does not depend on the other workgroups: weights, affine, shift, bias -- requested before the wait
+    const float* wl = o.w + (size_t)c.nt * taps * nch * 1024 + lane * 4;
+    float4 bA[2][2], bB[2][2], bC[2][2];
+    int ltap = 0, lchunk = wave;
+    auto norm = [&](int& tap, int& chunk) {
+        while (chunk >= nch) { chunk -= nch; ++tap; }
+    };
+    norm(ltap, lchunk);
+    auto load_b = [&](float4 (&bq)[2][2]) {
+        const int unit = ltap < taps ? ltap * nch + lchunk : taps * nch - 1;
+        const float* wp = wl + (size_t)unit * 1024;
+        bq[0][0] = *reinterpret_cast<const float4*>(wp);
+        bq[0][1] = *reinterpret_cast<const float4*>(wp + 256);
+        bq[1][0] = *reinterpret_cast<const float4*>(wp + 512);
+        bq[1][1] = *reinterpret_cast<const float4*>(wp + 768);
+        lchunk += 8;
+        norm(ltap, lchunk);
+    };
+    load_b(bA);
+    load_b(bB);
+    load_b(bC);
+    const int col = tid & 31, row = tid >> 5;
+    const int ch = n0 + col;
+    float ga = 1.f, be = 0.f, sh = 0.f;
+    if (o.kind == CH_CONV3) { ga = o.gamma[ch]; be = o.beta[ch]; }
+    if (o.temb_off >= 0) {
+        const long long tr = p.temb_rows ? p.temb_rows[c.b] : c.b;
+        sh = p.temb[tr * p.temb_stride + o.temb_off + ch];
+    }
+    const float cb = o.bias ? o.bias[ch] : 0.f;
+    if (o.flags & CHF_KEEP_FROM_SRC) c.keep = o.src0[((long long)c.b * 16 + row) * o.c0 + ch];
+
+    if (o.flags & CHF_WAIT) chain_wait(p, c);
+    chain_stage(o, c, cin, pitch);
+    __syncthreads();
+
+    // ---- k loop
+    f32x4 acc[2];
+    acc[0] = acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int py = m >> 2, px = m & 3;
+    if constexpr (NU > 0) {
+        int a_tap[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int yy = py + t / 3 - 1, xx = px + t % 3 - 1;
+            const bool ok = (unsigned)yy < 4u && (unsigned)xx < 4u;
+            a_tap[t] = (ok ? yy * 4 + xx : 16) * pitch + kq * 8 + (wave << 5);
+        }
+        auto compute_at = [&](int t, int sub, const float4 (&bq)[2][2]) {
+            const float* ap = lds + a_tap[t] + sub * 256;
+            const float4 a0 = *reinterpret_cast<const float4*>(ap), a1 = *reinterpret_cast<const float4*>(ap + 4);
+            const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kk], reinterpret_cast<const float*>(&bq[0][0])[kk], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kk], reinterpret_cast<const float*>(&bq[1][0])[kk], acc[1], 0, 0, 0);
+            }
+        };
+#pragma unroll
+        for (int k = 0; k < 9 * NU; k += 3) {
+            compute_at(k / NU, k % NU, bA);
+            load_b(bA);
+            if (k + 1 < 9 * NU) compute_at((k + 1) / NU, (k + 1) % NU, bB);
+            load_b(bB);
+            if (k + 2 < 9 * NU) compute_at((k + 2) / NU, (k + 2) % NU, bC);
+            load_b(bC);
+        }
+    } else {
+        int ctap = 0, cchunk = wave;
+        norm(ctap, cchunk);
+        auto compute = [&](const float4 (&bq)[2][2]) {
+            int srow = m;
+            if (taps == 9) {
+                const int t3 = ctap / 3;
+                const int yy = py + t3 - 1, xx = px + ctap - t3 * 3 - 1;
+                srow = ((unsigned)yy < 4u && (unsigned)xx < 4u) ? yy * 4 + xx : 16;
+            }
+            const float* ap = lds + srow * pitch + (cchunk << 5) + kq * 8;
+            const float4 a0 = *reinterpret_cast<const float4*>(ap), a1 = *reinterpret_cast<const float4*>(ap + 4);
+            const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kk], reinterpret_cast<const float*>(&bq[0][0])[kk], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kk], reinterpret_cast<const float*>(&bq[1][0])[kk], acc[1], 0, 0, 0);
+            }
+            cchunk += 8;
+            norm(ctap, cchunk);
+        };
+        while (ctap < taps) {
+            compute(bA);
+            load_b(bA);
+            if (ctap < taps) compute(bB);
+            load_b(bB);
+            if (ctap < taps) compute(bC);
+            load_b(bC);
+        }
+    }
+
+    // ---- the 8 waves' partial tiles meet in LDS (the image is no longer needed)
+    __syncthreads();
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) lds[(wave * 16 + kq * 4 + r) * LC_PP + nb * 16 + m] = acc[nb][r];
+    __syncthreads();
+    float v = lds[row * LC_PP + col];
+#pragma unroll
+    for (int w = 1; w < 8; ++w) v += lds[(w * 16 + row) * LC_PP + col];
+    v += cb;
+
+    float y = v;
+    if (o.kind == CH_CONV3) {
+        // GroupNorm of the slice = one group of 32 channels x 16 pixels, two passes like torch's native_group_norm
+        float* red = lds + LC_RED;
+        const float mean = chain_sum512(v, red, lane, wave) * (1.0f / 512.0f);
+        const float d = v - mean;
+        const float var = chain_sum512(d * d, red + 8, lane, wave) * (1.0f / 512.0f);
+        const float rstd = 1.0f / sqrtf(var + p.gn_eps);
+        y = mish_f(d * rstd * ga + be) + sh;
+    }
+    if (o.flags & CHF_ADD_KEEP) y += c.keep;
+    if (o.flags & CHF_ADD_KEEP2) y += c.keep2;
+    if (o.flags & CHF_SAVE_KEEP) c.keep = y;
+    if (o.flags & CHF_SAVE_KEEP2) c.keep2 = y;
+    if (!(o.flags & CHF_NO_OUT)) chain_store(o, c, y, n0);
+    if (o.flags & CHF_SIGNAL) chain_signal(p, c);
+    else __syncthreads();
+}
+
+// CH_ATTN (blocks.py:116-134 behind PreNorm, :57-71): head h = nt < 4 of image b.  q | k | v of the head = LayerNorm-folded to_qkv
+// ([16 x C] x [C x 96], the 8 waves split the 32-channel chunks, weights in operand order: qkv_operand_pack_kernel), k soft-maxed
+// over the 16 pixels, ctx = k^T v, out = q ctx -- linattn_small_qkv_kernel's arithmetic on 512 threads.  o.gamma / o.beta: W g, W b.
+__device__ __forceinline__ void chain_attn(const ChainParams& p, const ChainOp& o, ChainCtx& c) {
+    float* lds = c.lds;
+    const int tid = c.tid, lane = c.lane, wave = c.wave;
+    if (c.nt < 4) {
+        const int h = c.nt;
+        const int m = lane & 15, kq = lane >> 4;
+        const int C = o.c0, pitch = C + 4, nch = C >> 5;
+        float* xs = lds;
+        float* ks = lds + LC_KS;
+        float* vs = lds + LC_VS;
+        float* qs = lds + LC_QS;
+        float* cs = lds + LC_CS;
+        float* smax = lds + LC_SMAX;
+        float* rowstat = lds + LC_ROWSTAT;
+        float* cfold = lds + LC_CFOLD;
+        const float* wl = o.w + (size_t)h * nch * 3072 + lane * 4;         // a chunk = 6 n blocks x 512 floats
+        float4 bq[6][2];
+        {
+            const int chunk = wave < nch ? wave : nch - 1;
+            const float* wp = wl + (size_t)chunk * 3072;
+#pragma unroll
+            for (int nb = 0; nb < 6; ++nb) {
+                bq[nb][0] = *reinterpret_cast<const float4*>(wp + nb * 512);
+                bq[nb][1] = *reinterpret_cast<const float4*>(wp + nb * 512 + 256);
+            }
+        }
+        if (tid < 192) {                                   // the fold vectors of this head's 96 columns (q | k | v)
+            const int n = tid % 96;
+            const int colw = (n >> 5) * 128 + h * 32 + (n & 31);
+            cfold[tid] = tid < 96 ? o.gamma[colw] : o.beta[colw];
+        }
+        if (o.flags & CHF_WAIT) chain_wait(p, c);
+        chain_stage(o, c, C, pitch);
+        __syncthreads();
+        {   // LayerNorm statistics of the 16 pixel rows: 32 threads per row, two passes over the resident row (biased variance, eps on the std)
+            const int row = tid >> 5, sub = tid & 31;
+            float s1 = 0.f;
+            for (int ch = sub * 4; ch < C; ch += 128) {
+                const float4 v = *reinterpret_cast<const float4*>(xs + row * pitch + ch);
+                s1 += (v.x + v.y) + (v.z + v.w);
+            }
+#pragma unroll
+            for (int of = 1; of < 32; of <<= 1) s1 += __shfl_xor(s1, of, 64);
+            const float inv_c = 1.0f / (float)C;
+            const float mean = s1 * inv_c;
+            float s2 = 0.f;
+            for (int ch = sub * 4; ch < C; ch += 128) {
+                const float4 v = *reinterpret_cast<const float4*>(xs + row * pitch + ch);
+                const float a0 = v.x - mean, a1 = v.y - mean, a2 = v.z - mean, a3 = v.w - mean;
+                s2 += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+            }
+#pragma unroll
+            for (int of = 1; of < 32; of <<= 1) s2 += __shfl_xor(s2, of, 64);
+            if (sub == 0) {
+                const float r = 1.0f / (sqrtf(s2 * inv_c) + p.ln_eps);
+                rowstat[2 * row] = r;
+                rowstat[2 * row + 1] = r * mean;
+            }
+        }
+        // ---- [16 x C] x [C x 96]: wave w takes chunks w, w + 8, ...
+        f32x4 acc[6];
+#pragma unroll
+        for (int nb = 0; nb < 6; ++nb) acc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int chunk = wave; chunk < nch; chunk += 8) {
+            const float* ap = xs + m * pitch + (chunk << 5) + kq * 8;
+            const float4 a0 = *reinterpret_cast<const float4*>(ap), a1 = *reinterpret_cast<const float4*>(ap + 4);
+            const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk)
+#pragma unroll
+                for (int nb = 0; nb < 6; ++nb)
+                    acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kk], reinterpret_cast<const float*>(&bq[nb][0])[kk], acc[nb], 0, 0, 0);
+            if (chunk + 8 < nch) {
+                const float* wp = wl + (size_t)(chunk + 8) * 3072;
+#pragma unroll
+                for (int nb = 0; nb < 6; ++nb) {
+                    bq[nb][0] = *reinterpret_cast<const float4*>(wp + nb * 512);
+                    bq[nb][1] = *reinterpret_cast<const float4*>(wp + nb * 512 + 256);
+                }
+            }
+        }
+        __syncthreads();                                    // image consumed, rowstat written
+#pragma unroll
+        for (int nb = 0; nb < 6; ++nb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) xs[(wave * 16 + kq * 4 + r) * LC_QP + nb * 16 + m] = acc[nb][r];
+        __syncthreads();
+        // ---- the 8 partials in fixed order + the folded LayerNorm -> q | k | v
+        for (int e = tid; e < 16 * 96; e += 512) {
+            const int row = e / 96, n = e - row * 96;
+            float s = xs[row * LC_QP + n];
+#pragma unroll
+            for (int w = 1; w < 8; ++w) s += xs[(w * 16 + row) * LC_QP + n];
+            const float v = rowstat[2 * row] * s - rowstat[2 * row + 1] * cfold[n] + cfold[96 + n];
+            const int sel = n >> 5, d = n & 31;
+            if (sel == 0) qs[row * 33 + d] = v;
+            else if (sel == 1) ks[row * 32 + d] = v;
+            else vs[row * 32 + d] = v;
+        }
+        __syncthreads();
+        // ---- softmax over the pixels (dim=-1 of the reference's [b, heads, c, n]), context, apply
+        if (tid < 32) {
+            float mx = ks[tid];
+#pragma unroll
+            for (int n = 1; n < 16; ++n) mx = fmaxf(mx, ks[n * 32 + tid]);
+            smax[tid] = mx;
+        }
+        __syncthreads();
+        ks[tid] = __expf(ks[tid] - smax[tid & 31]);
+        __syncthreads();
+        {
+            const int d = tid >> 4, e0 = (tid & 15) << 1;
+            float a0 = 0.f, a1 = 0.f, den = 0.f;
+#pragma unroll
+            for (int n = 0; n < 16; ++n) {
+                const float kd = ks[n * 32 + d];
+                a0 += kd * vs[n * 32 + e0];
+                a1 += kd * vs[n * 32 + e0 + 1];
+                den += kd;
+            }
+            const float inv = 1.0f / den;
+            cs[d * 36 + e0] = a0 * inv;
+            cs[d * 36 + e0 + 1] = a1 * inv;
+        }
+        __syncthreads();
+        const int n = tid >> 5, e = tid & 31;
+        float y = 0.f;
+#pragma unroll
+        for (int d = 0; d < 32; ++d) y += qs[n * 33 + d] * cs[d * 36 + e];
+        chain_store(o, c, y, h * 32);
+    }
+    if (o.flags & CHF_SIGNAL) chain_signal(p, c);
+    else __syncthreads();
+}
+
+__global__ __launch_bounds__(512) void level_chain_kernel(const ChainParams p) {
+    extern __shared__ __align__(16) float lds[];
+    ChainCtx c;
+    c.lds = lds;
+    c.tid = threadIdx.x;
+    c.lane = c.tid & 63;
+    c.wave = __builtin_amdgcn_readfirstlane(c.tid >> 6);
+    c.nt = blockIdx.x & 7;
+    if (c.tid == 0) *reinterpret_cast<int*>(lds + LC_MISC) = 0;
+    __syncthreads();
+    const int slots = gridDim.x >> 3;
+    for (int b = blockIdx.x >> 3; b < p.B; b += slots) {
+        c.b = b;
+        c.signals = 0;
+        c.keep = c.keep2 = 0.f;
+        for (int k = 0; k < p.n_ops; ++k) {
+            const ChainOp& o = p.op[k];
+            if (o.kind == CH_ATTN) chain_attn(p, o, c);
+            else if (o.kind == CH_CONV1) chain_conv<0>(p, o, c);
+            else if (o.c0 + o.c1 == 256) chain_conv<1>(p, o, c);
+            else if (o.c0 + o.c1 == 512) chain_conv<2>(p, o, c);
+            else chain_conv<0>(p, o, c);
+        }
+        // the image's last departure re-arms its counters for the next launch: every one of the eight has passed its last wait
+        if (c.tid == 0) {
+            const unsigned prev = __hip_atomic_fetch_add(p.done + b * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (prev == 7u) {
+                __hip_atomic_store(p.cnt + b * 32, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(p.done + b * 32, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+}
+
+bool level_chain_device_ok() { return conv_wino_cluster_device_ok(); }
+
+int level_chain_init_device() {
+    DDK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(level_chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    return DDK_OK;
+}
+
+int level_chain_launch(const ChainParams& p, hipStream_t st) {
+    DDK_REQUIRE(p.n_ops > 0 && p.n_ops <= CH_MAX_OPS && p.B > 0 && p.cnt && p.done && p.fail, "level_chain: arguments");
+    for (int k = 0; k < p.n_ops; ++k) {
+        const ChainOp& o = p.op[k];
+        const int cin = o.c0 + o.c1;
+        DDK_REQUIRE(o.src0 && o.w && aligned16(o.src0) && aligned16(o.src1) && aligned16(o.w) && aligned16(o.out), "level_chain: op pointers");
+        DDK_REQUIRE((cin == 128 || cin == 256 || cin == 512) && o.c0 % 4 == 0 && o.c1 % 4 == 0 && (o.c1 == 0 || o.src1), "level_chain: op channels");
+        DDK_REQUIRE((o.flags & CHF_NO_OUT) || o.out, "level_chain: op output");
+        if (o.kind == CH_ATTN) DDK_REQUIRE(o.c1 == 0 && o.n_out == 128 && o.gamma && o.beta, "level_chain: attention op");
+        else DDK_REQUIRE(o.n_out == 256 && (o.kind != CH_CONV3 || (o.gamma && o.beta)), "level_chain: conv op (8 slices of 32 channels)");
+    }
+    DDK_TRY(ensure_device_init());
+    const int slots = p.B < 32 ? p.B : 32;
+    hipLaunchKernelGGL(level_chain_kernel, dim3(8 * slots), dim3(512), level_chain_lds_bytes(), st, p);
+    return check_launch("level_chain_kernel");
+}
+
+}  // namespace ddk

@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "ddk_internal.h"
+#include "level_chain.h"
 
 namespace ddk {
 
@@ -25,7 +26,7 @@ constexpr float GN_EPS = 1e-5f, LN_EPS = 1e-5f;
 static inline int pad32(int c) { return (c + 31) / 32 * 32; }
 
 enum PackKind { PK_COPY = 0, PK_CONV = 1, PK_CONVT = 2, PK_LINEAR_T = 3, PK_WINO = 4, PK_LOCAL = 5, PK_WLOCAL = 6, PK_FIRST = 7, PK_CONVT_WINO = 8,
-                PK_ROWS = 9 /* [O][I] rows into rows of pitch ld */ };
+                PK_ROWS = 9 /* [O][I] rows into rows of pitch ld */, PK_LOCAL1 = 10 /* a 1x1 filter in conv_local.hip's operand order */ };
 
 struct Slot {
     std::string name;
@@ -49,6 +50,8 @@ struct ConvW {
     bool has_wwl = false;
     size_t wf = 0;          // conv_first.hip's operand-order copy (the network's first conv, C_in <= 8); has_wf
     bool has_wf = false;
+    size_t wl1 = 0;         // a 1x1 filter (to_out, res_conv) in conv_local.hip's operand order, one tap: the level chain's 1x1 ops
+    bool has_wl1 = false;
 };
 struct NormW { size_t g = 0, b = 0; int c_real = 0; };
 struct ResW {
@@ -104,6 +107,8 @@ struct ddk_unet {
     bool fold_down_reduce = false;           // Downsample conv's split-K slabs summed by the image-local ResnetBlock behind it (no reduce launch).
                                              // OFF by default: measured 6 us per step SLOWER (each of an image's eight workgroups re-sums the slabs:
                                              // +6.3 / +5.9 us on the two consumers against reduce launches of 5.2 / 4.9 us; tools/fold_ab.py)
+    bool level_chain = true;                 // the whole 4x4 level (ResnetBlocks + attention of downs[-1], mid, ups[0]) as ONE persistent launch
+                                             // (level_chain.hip) wherever the in-launch GroupNorm may run (its workgroups wait for each other too)
     bool attn_fold = true;                   // attention on maps with HW > 256, C = 128: q projection + apply + to_out as ONE per-image C x C conv
     // unet_chan % 8 == 0 but not % 32 (reference blocks.py:75 takes any GroupNorm(8, C)): every tensor keeps a pitch of pad32(C) channels
     // with zero padding, the convs run on the generic im2col kernels over zero-padded weights and the normalisations on their
@@ -153,6 +158,12 @@ struct ddk_unet {
             slots.push_back(Slot{prefix + "bias", cout, PK_COPY, c.b, 0, 0, 0, 0, 0, 0, 0});
         }
         if (generic) return c;                      // no Winograd / image-local / first-layer copies: the generic kernels only
+        if (k == 1 && bias && cout % 32 == 0 && c.cin_pad == cin && cin % 32 == 0) {
+            // to_out / res_conv: also in the operand order of the image-local kernels (level_chain.hip's 1x1 ops)
+            c.wl1 = alloc((size_t)cout * c.cin_pad);
+            c.has_wl1 = true;
+            slots.push_back(Slot{prefix + "weight", (long long)cout * cin, PK_LOCAL1, c.wl1, cout, cin, 1, 1, c.cin_pad, 0, 0});
+        }
         if (k == 3 && cout % 64 == 0) {
             // the same state_dict tensor feeds a second slot: its Winograd-domain form G g G^T for conv3x3_wino_kernel
             c.wu = alloc((size_t)16 * cout * c.cin_pad);
@@ -416,6 +427,13 @@ extern "C" int ddk_unet_set_option(ddk_unet* u, int option, int value) {
         u->attn_kvctx = value != 0;
         return DDK_OK;
     }
+    if (option == DDK_OPT_LEVEL_CHAIN) {
+        std::lock_guard<std::mutex> lock(u->mu);
+        if (!u->graphs.empty()) DDK_HIP(hipDeviceSynchronize());
+        drop_graphs(u);
+        u->level_chain = value != 0;
+        return DDK_OK;
+    }
     if (option == DDK_OPT_FOLD_DOWNSAMPLE_REDUCE) {
         std::lock_guard<std::mutex> lock(u->mu);
         if (!u->graphs.empty()) DDK_HIP(hipDeviceSynchronize());
@@ -512,6 +530,7 @@ extern "C" int ddk_unet_pack_slot(const ddk_unet* u, int slot, const float* cano
         case PK_LINEAR_T: rc = ddk_pack_linear_T(canonical, dst, sl.O, sl.I, sl.ld, sl.col0, s); break;
         case PK_WINO: rc = ddk_pack_conv_weight_wino(canonical, dst, sl.O, sl.I, sl.i_pad, s); break;
         case PK_LOCAL: rc = ddk_pack_conv_weight_local(canonical, dst, sl.O, sl.I, sl.i_pad, s); break;
+        case PK_LOCAL1: rc = ddk_pack_conv1x1_weight_local(canonical, dst, sl.O, sl.I, sl.i_pad, s); break;
         case PK_WLOCAL: rc = ddk_pack_conv_weight_wino_local(canonical, dst, sl.O, sl.I, sl.i_pad, s); break;
         case PK_FIRST: rc = ddk_pack_conv_weight_first(canonical, dst, sl.O, sl.I, s); break;
         case PK_CONVT_WINO: rc = ddk_pack_convT_weight_wino(canonical, dst, sl.I, sl.O, sl.i_pad, s); break;
@@ -530,12 +549,12 @@ namespace ddk {
 // Workspace carve-up (all offsets in floats, 16-byte aligned).
 struct Layout {
     size_t act = 0;      // one general activation buffer (max over layers of M*C)
-    size_t qkv = 0, o = 0, ctx = 0, splitk = 0, gn_ws = 0, cl = 0;
+    size_t qkv = 0, o = 0, ctx = 0, splitk = 0, gn_ws = 0, cl = 0, chain = 0;
     std::vector<size_t> skip;  // per level
     size_t xpad = 0, temb = 0, tact = 0;
     // offsets
     size_t off_A = 0, off_B = 0, off_C = 0, off_raw = 0, off_a1 = 0, off_res = 0, off_xn = 0, off_qkv = 0, off_o = 0, off_ctx = 0,
-           off_splitk = 0, off_gn = 0, off_xpad = 0, off_temb = 0, off_tact = 0, off_cl = 0;
+           off_splitk = 0, off_gn = 0, off_xpad = 0, off_temb = 0, off_tact = 0, off_cl = 0, off_chain = 0;
     std::vector<size_t> off_skip;
     size_t total = 0;
 };
@@ -563,8 +582,11 @@ static size_t conv3_ws_floats(const ConvW& cw, int B, int H, int W, int cin, int
 
 // counters of the cluster GroupNorm: fixed place (16 words per (image, n tile), N <= 512) so every layer re-arms the same words
 // ... and behind them one line for the sticky give-up count of this workspace (ddk_unet_cluster_check)
-static size_t cl_counter_floats(int B) { return (size_t)B * 8 * 16 + 16; }
+// ... and behind that the level chain's arrival and departure counters, one 128-byte line per image each
+static size_t cl_counter_floats(int B) { return (size_t)B * 8 * 16 + 16 + (size_t)B * 64; }
 static size_t cl_fail_offset(int B) { return (size_t)B * 8 * 16; }
+static size_t cl_chain_offset(int B) { return (size_t)B * 8 * 16 + 16; }
+constexpr int CHAIN_BUFS = 16;                // activations that cross workgroups inside the level chain, [B][16][256] each
 
 static void res_sizes(const ResW& r, int B, int H, int W, Layout& ly) {
     const size_t M = (size_t)B * H * W;
@@ -587,6 +609,21 @@ static void attn_sizes(const AttnW& a, int B, int H, int W, Layout& ly) {
     if (attn_kvctx_ok(B, H * W, a.c, HEADS)) upd(ly.splitk, attn_kvctx_workspace_bytes(B, H * W) / 4);
     upd(ly.splitk, conv_workspace_bytes(DDK_CONV1X1, B, H, W, a.c, 3 * HIDDEN) / 4);
     upd(ly.splitk, conv_workspace_bytes(DDK_CONV1X1, B, H, W, HIDDEN, a.c) / 4);
+}
+
+// The level chain (level_chain.hip) takes the last level when it is a 4x4 map of 256 channels whose neighbours are 256 wide too (cfg1,
+// cfg2, cfg4): ResnetBlocks without a skip conv on the way down and in the middle, one 512 -> 256 ResnetBlock on the way up.
+static bool level_chain_shape_ok(const ddk_unet& u, int H0, int W0) {
+    if (u.generic || u.L < 2) return false;
+    const int sh = u.L - 1;
+    if ((H0 >> sh) != 4 || (W0 >> sh) != 4 || (H0 & ((1 << sh) - 1)) || (W0 & ((1 << sh) - 1))) return false;
+    if (u.dimp[u.L] != 256 || u.dimp[u.L - 1] != 256 || GROUPS != 8) return false;
+    auto plain = [](const ResW& r) { return r.ci == 256 && r.co == 256 && !r.has_res && r.c1.has_wl && r.c2.has_wl && r.c1.has_bias && r.c2.has_bias; };
+    auto att = [](const AttnW& a) { return a.c == 256 && a.out.has_wl1 && a.out.has_bias; };
+    const ResW& u0 = u.up_res[0];
+    return plain(u.down_res[2 * sh]) && plain(u.down_res[2 * sh + 1]) && plain(u.mid1) && plain(u.mid2) && plain(u.up_res[1]) &&
+           att(u.down_attn[sh]) && att(u.mid_attn) && att(u.up_attn[0]) && u0.ci == 512 && u0.ci_pad == 512 && u0.co == 256 && u0.has_res &&
+           u0.res.has_wl1 && u0.res.has_bias && u0.c1.has_wl && u0.c2.has_wl && u0.c1.cin_pad == 512;
 }
 
 static Layout make_layout(const ddk_unet& u, int B, int H0, int W0) {
@@ -625,13 +662,14 @@ static Layout make_layout(const ddk_unet& u, int B, int H0, int W0) {
     ly.tact = al4((size_t)B * u.time_dim);
     ly.act = al4(ly.act); ly.qkv = al4(ly.qkv); ly.o = al4(ly.o); ly.ctx = al4(ly.ctx);
     ly.splitk = al4(ly.splitk); ly.gn_ws = al4(ly.gn_ws); ly.cl = al4(ly.cl);
+    if (level_chain_shape_ok(u, H0, W0)) ly.chain = (size_t)CHAIN_BUFS * B * 16 * 256;
 
     size_t off = 0;
     auto take = [&](size_t n) { const size_t o = off; off += n; return o; };
     ly.off_A = take(ly.act); ly.off_B = take(ly.act); ly.off_C = take(ly.act);
     ly.off_raw = take(ly.act); ly.off_a1 = take(ly.act); ly.off_res = take(ly.act); ly.off_xn = take(ly.act);
     ly.off_qkv = take(ly.qkv); ly.off_o = take(ly.o); ly.off_ctx = take(ly.ctx);
-    ly.off_splitk = take(ly.splitk); ly.off_gn = take(ly.gn_ws); ly.off_cl = take(ly.cl);
+    ly.off_splitk = take(ly.splitk); ly.off_gn = take(ly.gn_ws); ly.off_cl = take(ly.cl); ly.off_chain = take(ly.chain);
     ly.off_xpad = take(ly.xpad); ly.off_temb = take(ly.temb); ly.off_tact = take(ly.tact);
     ly.off_skip.resize(u.L);
     for (int l = 0; l < u.L; ++l) ly.off_skip[l] = take(ly.skip[l]);
@@ -900,6 +938,81 @@ static int run_attn(Ctx& c, const AttnW& a, const float* x, float* out, int H, i
     return run_conv(c, DDK_CONV1X1, a.out, o, HIDDEN, nullptr, 0, x, out, H, W, a.c);
 }
 
+// The last level as one persistent launch (level_chain.hip; unet.py:83-101 for that level): `in` = the Downsample conv's output,
+// `skip` receives the level's skip tensor (the down attention block's output, unet.py:87), `out` the up attention block's output.
+static bool level_chain_use(const Ctx& c, int H0, int W0) {
+    return c.allow_cluster && c.u.level_chain && c.ly.chain > 0 && level_chain_shape_ok(c.u, H0, W0) && level_chain_device_ok();
+}
+
+static int run_level_chain(Ctx& c, const float* in, float* skip, float* out) {
+    const ddk_unet& u = c.u;
+    const int sh = u.L - 1;
+    ChainParams p{};
+    int n = 0, e = 0;
+    const size_t per = (size_t)c.B * 16 * 256;
+    auto buf = [&](int i) { return c.W + c.ly.off_chain + (size_t)i * per; };
+    auto conv3 = [&](const ConvW& cw, const NormW& nw, const float* s0, int c0, const float* s1, int c1, int temb_off, int flags, float* o) {
+        ChainOp& op = p.op[n++];
+        op = ChainOp{s0, s1, c.P + cw.wl, c.P + cw.b, c.P + nw.g, c.P + nw.b, o, c0, c1, CH_CONV3, flags, temb_off, 256};
+    };
+    auto conv1 = [&](const ConvW& cw, const float* s0, int c0, const float* s1, int c1, int flags, float* o) {
+        ChainOp& op = p.op[n++];
+        op = ChainOp{s0, s1, c.P + cw.wl1, c.P + cw.b, nullptr, nullptr, o, c0, c1, CH_CONV1, flags, -1, 256};
+    };
+    auto attn = [&](const AttnW& a, const float* s0, float* o) {
+        ChainOp& op = p.op[n++];
+        op = ChainOp{s0, nullptr, c.P + a.qkv_op, nullptr, c.P + a.ln_c1, c.P + a.ln_c2, o, a.c, 0, CH_ATTN, CHF_WAIT | CHF_SIGNAL, -1, HIDDEN};
+    };
+    const int WS = CHF_WAIT | CHF_SIGNAL, RES = CHF_ADD_KEEP | CHF_SAVE_KEEP;
+    // a ResnetBlock without a skip conv (blocks.py:105-115): x enters as `keep`
+    auto res_plain = [&](const ResW& r, const float* x, bool external, float* o, bool last_signals = true) {
+        float* h = buf(e++);
+        conv3(r.c1, r.n1, x, 256, nullptr, 0, r.temb_off, external ? (CHF_SIGNAL | CHF_KEEP_FROM_SRC) : WS, h);
+        conv3(r.c2, r.n2, h, 256, nullptr, 0, -1, (last_signals ? WS : CHF_WAIT) | RES, o);
+    };
+    // Residual(PreNorm(LinearAttention)) (blocks.py:8-14, 63-71, 116-134): x is `keep`
+    auto attn_block = [&](const AttnW& a, const float* x, float* o, bool signals) {
+        float* heads = buf(e++);
+        attn(a, x, heads);
+        conv1(a.out, heads, HIDDEN, nullptr, 0, (signals ? WS : CHF_WAIT) | RES, o);
+    };
+    float* d0 = buf(e++);
+    res_plain(u.down_res[2 * sh], in, true, d0);
+    float* d1 = buf(e++);
+    res_plain(u.down_res[2 * sh + 1], d0, false, d1);
+    attn_block(u.down_attn[sh], d1, skip, true);
+    float* m1 = buf(e++);
+    res_plain(u.mid1, skip, false, m1);
+    float* ma = buf(e++);
+    attn_block(u.mid_attn, m1, ma, true);
+    float* m2 = buf(e++);
+    res_plain(u.mid2, ma, false, m2);
+    {   // ups[0][0]: cat(x, skip) -> 512 channels, res_conv is a 1x1 (its result lives in keep2)
+        const ResW& r = u.up_res[0];
+        conv1(r.res, m2, 256, skip, 256, CHF_WAIT | CHF_SAVE_KEEP2 | CHF_NO_OUT, nullptr);
+        float* h = buf(e++);
+        conv3(r.c1, r.n1, m2, 256, skip, 256, r.temb_off, CHF_SIGNAL, h);
+        float* u0 = buf(e++);
+        conv3(r.c2, r.n2, h, 256, nullptr, 0, -1, WS | CHF_ADD_KEEP2 | CHF_SAVE_KEEP, u0);
+        float* u1 = buf(e++);
+        res_plain(u.up_res[1], u0, false, u1);
+        attn_block(u.up_attn[0], u1, out, false);
+    }
+    if (n > CH_MAX_OPS || e > CHAIN_BUFS) return fail_arg("level_chain: internal op / buffer count");
+    p.n_ops = n;
+    p.B = c.B;
+    p.temb = c.temb;
+    p.temb_rows = c.temb_rows;
+    p.temb_stride = u.temb_total;
+    float* cl = c.W + c.ly.off_cl;
+    p.cnt = reinterpret_cast<unsigned*>(cl + cl_chain_offset(c.B));
+    p.done = p.cnt + (size_t)c.B * 32;
+    p.fail = reinterpret_cast<unsigned*>(cl + cl_fail_offset(c.B));
+    p.gn_eps = GN_EPS;
+    p.ln_eps = LN_EPS;
+    return level_chain_launch(p, c.st);
+}
+
 // What a reverse step of the sampler adds to a forward: the bookkeeping in front (t_cur[b] <- counter; counter -= 1) and the
 // update of x behind it (ddpm.py:203-227).  Both ride on the forward's own first / last kernel where the shape allows.
 struct StepArgs {
@@ -986,9 +1099,16 @@ static int forward_core(const ddk_unet& u, const float* P, const float* x, int64
     const float* cur = xpad;
     int cur_c = pad32(u.cfg.in_ch);
     AddendSlabs cur_ss;           // > 1 slab: `cur` is the split-K area a Downsample conv left for the next ResnetBlock to sum
+    const bool chained = level_chain_use(c, H0, W0);    // the last level (4x4 maps) as one persistent launch
     for (int l = 0; l < u.L; ++l) {
         float* skip = ws + ly.off_skip[l];
         const int co = u.dimp[l + 1];
+        if (chained && l == u.L - 1) {
+            // downs[-1] (2 ResnetBlocks + attention), mid_block1, mid_attn, mid_block2, ups[0] (2 ResnetBlocks + attention): 19 launches in one
+            DDK_TRY(run_level_chain(c, cur, skip, bufB));
+            cur_c = co;
+            break;
+        }
         if (l == 0 && fast0) {
             const ResW& r = u.down_res[0];
             DDK_TRY(conv_first(x, P + r.c1.wf, r.c1.has_bias ? P + r.c1.b : nullptr, raw, gnp, B, H, W, r.ci, r.co, GROUPS,
@@ -1029,7 +1149,8 @@ static int forward_core(const ddk_unet& u, const float* P, const float* x, int64
         DDK_TRY(run_attn(c, u.down_attn[l], bufC, skip, H, W));
         if (l < u.L - 1) {
             const int s2 = conv_splits(DDK_CONV3X3_S2, B, H, W, co, co);
-            if (u.fold_down_reduce && s2 > 1 && res_takes_slab_source(u, u.down_res[2 * l + 2], B, H / 2, W / 2, co)) {
+            if (u.fold_down_reduce && s2 > 1 && !(chained && l + 1 == u.L - 1) &&
+                res_takes_slab_source(u, u.down_res[2 * l + 2], B, H / 2, W / 2, co)) {
                 // the Downsample conv splits k and the ResnetBlock behind it is image-local (8x8 / 4x4 maps, no skip conv): the conv leaves
                 // its slabs in the split-K area and that block's two readers sum them -- no reduce launch, no reduced tensor
                 ddk_conv_args a{};
@@ -1057,17 +1178,21 @@ static int forward_core(const ddk_unet& u, const float* P, const float* x, int64
         }
         cur_c = co;
     }
-    DDK_TRY(run_res(c, u.mid1, cur, cur_c, nullptr, 0, bufB, H, W));
-    DDK_TRY(run_attn(c, u.mid_attn, bufB, bufC, H, W));
-    DDK_TRY(run_res(c, u.mid2, bufC, cur_c, nullptr, 0, bufA, H, W));
-    cur = bufA;
+    if (!chained) {
+        DDK_TRY(run_res(c, u.mid1, cur, cur_c, nullptr, 0, bufB, H, W));
+        DDK_TRY(run_attn(c, u.mid_attn, bufB, bufC, H, W));
+        DDK_TRY(run_res(c, u.mid2, bufC, cur_c, nullptr, 0, bufA, H, W));
+        cur = bufA;
+    }
     for (int i = 0; i < u.L - 1; ++i) {
         const int lvl = u.L - 1 - i;  // skips.pop(): the most recent skip first (unet.py:97)
         const float* skip = ws + ly.off_skip[lvl];
         const int dout = u.dimp[lvl + 1], din = u.dimp[lvl];
-        DDK_TRY(run_res(c, u.up_res[2 * i], cur, cur_c, skip, dout, bufB, H, W));
-        DDK_TRY(run_res(c, u.up_res[2 * i + 1], bufB, din, nullptr, 0, bufC, H, W));
-        DDK_TRY(run_attn(c, u.up_attn[i], bufC, bufB, H, W));
+        if (!(chained && i == 0)) {
+            DDK_TRY(run_res(c, u.up_res[2 * i], cur, cur_c, skip, dout, bufB, H, W));
+            DDK_TRY(run_res(c, u.up_res[2 * i + 1], bufB, din, nullptr, 0, bufC, H, W));
+            DDK_TRY(run_attn(c, u.up_attn[i], bufC, bufB, H, W));
+        }
         DDK_TRY(run_conv(c, DDK_CONVT4X4_S2, u.up_conv[i], bufB, din, nullptr, 0, nullptr, bufA, H, W, din));
         H *= 2; W *= 2;
         cur = bufA;

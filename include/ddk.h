@@ -136,6 +136,8 @@ int ddk_groupnorm_mish_slabs(const float* slabs, int nslab, long long slab_strid
  * the filter packed by ddk_pack_conv_weight_local (O*9*i_pad floats: the kernel's MFMA operand order, O % 32 == 0).
  * ddk_conv3x3_gn_mish_ok() != 0 when the shape is eligible. */
 int ddk_pack_conv_weight_local(const float* w_oihw, float* dst, int O, int I, int i_pad, ddk_stream_t s);
+/* the same operand order for a 1x1 filter [O][I][1][1] (one tap: O*i_pad floats) -- the 1x1 ops of the level chain (DDK_OPT_LEVEL_CHAIN) */
+int ddk_pack_conv1x1_weight_local(const float* w_oi, float* dst, int O, int I, int i_pad, ddk_stream_t s);
 int ddk_conv3x3_gn_mish_ok(int H, int W, int cin, int c0, int N, int groups);
 int ddk_conv3x3_gn_mish(const float* src0, int c0, const float* src1, int c1, const float* weight, const float* bias,
                         const float* gamma, const float* beta, const float* temb, int temb_stride, const float* addend,
@@ -353,6 +355,13 @@ int ddk_unet_forward(const ddk_unet* u, const void* packed, const float* x, cons
 /* DDK_OPT_ATTENTION_KV_CONTEXT (default 1): inside the folded attention block the k, v projection and the context run as one launch
  * (ddk_attention_kv_context) instead of a 1x1 conv that writes the kv tensor + the context kernel that reads it back. */
 #define DDK_OPT_ATTENTION_KV_CONTEXT 6
+/* DDK_OPT_LEVEL_CHAIN (default 1): where the last level of the UNet is a 4x4 map of 256 channels (unet_chan 128, dims (1,2,2,2) on 32x32
+ * inputs), its 19 launches -- the ResnetBlocks and attention blocks of downs[-1], mid and ups[0], reference models/unet/unet.py:83-101 --
+ * run as ONE persistent launch whose workgroups hand the 16-pixel images to each other in memory (csrc/level_chain.hip).  Like the
+ * in-launch GroupNorm it needs all its workgroups resident together, so it runs exactly where DDK_OPT_CLUSTER_GROUPNORM lets that one
+ * run (ddk_sampler_run; ddk_unet_forward with that option at 2), and a wait that times out moves the same sticky word
+ * (ddk_unet_cluster_check -> DDK_ERR_CLUSTER). */
+#define DDK_OPT_LEVEL_CHAIN 7
 int ddk_unet_set_option(ddk_unet* u, int option, int value);
 /* Waits for `s`, then reads and clears the sticky give-up count of the launches issued on `workspace` (a ddk_unet_forward or
  * ddk_sampler_run workspace of this shape): DDK_OK, or DDK_ERR_CLUSTER when any in-launch GroupNorm exchange timed out. */

@@ -512,3 +512,96 @@ def test_downsample_reduce_fold_option_gives_the_same_unet_bits():
         plan.set_option(plan.OPT_FOLD_DOWNSAMPLE_REDUCE, 1)
         y_on2 = net(x, t)
     assert torch.equal(y_on, y_off) and torch.equal(y_on, y_on2)
+
+
+def _chain_net(in_ch=8):
+    from helpers import det_state, unet_cfg
+    from models import Unet
+    cfg = unet_cfg(128, in_ch)
+    net = Unet(cfg)
+    net.load_state_dict(det_state({k: v.shape for k, v in net.state_dict().items()}))
+    return net.to(DEV).eval()
+
+
+@pytest.mark.parametrize("batch", [32, 5, 40])
+def test_level_chain_option_gives_the_same_unet(batch):
+    """plan option DDK_OPT_LEVEL_CHAIN (csrc/level_chain.hip): the 4x4 level of the full-width UNet -- 2 + 2 + 2 ResnetBlocks and three
+    attention blocks, reference unet.py:83-101 -- as ONE persistent launch whose workgroups hand the images to each other, against the
+    same level as 19 launches.  Same arithmetic up to summation order (<= 2e-5 of the output's max), not the same bits (the option
+    really switches paths), bit-stable from launch to launch (a stale hand-off would show), no wait timed out.  Batch 5: fewer
+    workgroups than CUs; batch 40: images walked in two rounds by the same workgroups."""
+    from ddk import ops
+    from utils import synthetic as syn
+    net = _chain_net()
+    x = syn.synthetic_normal((batch, 8, 32, 32), f"chain.x{batch}").to(DEV)
+    x2 = syn.synthetic_normal((batch, 8, 32, 32), f"chain.y{batch}").to(DEV)
+    t = (torch.arange(batch, device=DEV) * 23) % 1000
+    with torch.no_grad():
+        plan = net.plan()
+        y_plain = net(x, t)                                        # single forwards take neither in-launch path by default
+        plan.set_option(plan.OPT_CLUSTER_GROUPNORM, 2)             # ... with 2 they take both (and wait + check behind the call)
+        before = ops.cluster_timeouts()
+        y_on = net(x, t)
+        y_other = net(x2, t)                                       # different data through the same hand-off buffers
+        y_on2 = net(x, t)
+        plan.set_option(plan.OPT_LEVEL_CHAIN, 0)
+        y_off = net(x, t)
+        plan.set_option(plan.OPT_LEVEL_CHAIN, 1)
+        y_on3 = net(x, t)
+    assert plan._cluster == 2, "the in-launch paths were switched off by a failed check"
+    assert ops.cluster_timeouts() == before
+    assert torch.isfinite(y_on).all()
+    assert torch.equal(y_on, y_on2) and torch.equal(y_on, y_on3)
+    assert not torch.equal(y_on, y_other)
+    assert not torch.equal(y_on, y_off)
+    assert rel_err(y_on.cpu(), y_off.cpu()) < 2e-5
+    assert rel_err(y_on.cpu(), y_plain.cpu()) < 2e-5
+
+
+def test_level_chain_vs_oracle():
+    """the chained level inside the whole UNet against the CPU oracle (oracle/unet_ref.py, pinned to the reference by tests/golden):
+    in_ch 3 and 8 (cfg2 / cfg4 shapes), 1e-3 relative as BASELINE.json's north_star states it, measured ~5e-6"""
+    from oracle import unet_ref as U
+    from helpers import unet_cfg
+    from utils import synthetic as syn
+    for in_ch in (3, 8):
+        net = _chain_net(in_ch)
+        cfg = unet_cfg(128, in_ch)
+        x = syn.synthetic_normal((4, in_ch, 32, 32), f"chain.oracle{in_ch}")
+        t = torch.tensor([0, 17, 500, 999])
+        with torch.no_grad():
+            plan = net.plan()
+            plan.set_option(plan.OPT_CLUSTER_GROUPNORM, 2)
+            y = net(x.to(DEV), t.to(DEV)).cpu()
+            ref = U.unet_forward({k: v.cpu() for k, v in net.state_dict().items()}, cfg, x, t)
+        assert plan._cluster == 2
+        assert rel_err(y, ref) < 5e-5
+
+
+def test_level_chain_in_the_sampler_matches_the_unchained_chain():
+    """ddk_sampler_run (hipGraph replay, 16 steps per graph) with the level chain on (the default) vs off: 40 reverse steps from the
+    same x_T with the same Philox stream end within 1e-4 of each other, and the counters re-arm across replays (no timeout)."""
+    from ddk import ops
+    from models import DDPM
+    from helpers import ddpm_cfg
+    from utils import synthetic as syn
+    cfg = ddpm_cfg(128, 3, 32, T=1000)
+    from models import Unet
+    model = DDPM(cfg, Unet(cfg), "cuda", 3)
+    model.load_state_dict(syn.fill_state_dict(model.state_dict(), skip=syn.SCHEDULE_KEYS))
+    model = model.to(DEV).eval()
+    plan = model.latent_model.plan()
+    tables = model._tables()
+    outs = {}
+    before = ops.cluster_timeouts()
+    for chain in (1, 0):
+        plan.set_option(plan.OPT_LEVEL_CHAIN, chain)
+        x = ops.randn((8, 32, 32, 3), DEV, seed=77, step=1000, stream_id=0)
+        with torch.no_grad():
+            plan.sample_nhwc(x, tables, 999, 960, seed=77, stream_id=0, use_graph=True)
+        outs[chain] = x.clone()
+    plan.set_option(plan.OPT_LEVEL_CHAIN, 1)
+    assert plan._cluster >= 1 and ops.cluster_timeouts() == before
+    assert torch.isfinite(outs[1]).all()
+    assert not torch.equal(outs[0], outs[1])
+    assert float((outs[0] - outs[1]).abs().max()) < 1e-4 * float(outs[0].abs().max())
