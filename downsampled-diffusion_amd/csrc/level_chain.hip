@@ -54,11 +54,25 @@ __device__ __forceinline__ void wait_vm(f32x4& a, f32x4& b, f32x4& c, f32x4& d) 
 }
 __device__ __forceinline__ void st_sc1(float* p, f32x4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(v) : "memory"); }
 
+#ifdef DDK_TUNING
+// Diagnostic stamps (tuning build only): per op and watched workgroup (blocks 0, 100, 255), s_memrealtime ticks (10 ns) at
+// [0] op entry, [1] wait passed, [2] image staged, [3] k loop / projection done, [4] op left (after the signal).
+__device__ unsigned long long g_lc_stamps[3 * CH_MAX_OPS * 8];
+#define LC_STAMP(c, k, i)                                                                                                   \
+    do {                                                                                                                    \
+        if ((c).tid == 0 && (c).watch >= 0) g_lc_stamps[((c).watch * CH_MAX_OPS + (k)) * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+#else
+#define LC_STAMP(c, k, i) do { } while (0)
+#endif
+
 struct ChainCtx {
     float* lds;
     int tid, lane, wave, b, nt;
     unsigned signals;            // signalling ops of this image so far (uniform)
-    float keep, keep2;
+    float keep, keep2;           // the residual stream's / the skip conv's element of this thread (row tid / 32, column tid % 32 of the slice)
+    int slot, slots;             // image slot of this workgroup and slots in the grid (the 32 workgroups of a slice share an XCD)
+    int watch, k;                // tuning build: which stamp row this workgroup writes (-1: none), current op index
 };
 
 // every arrival of the image so far (8 per signalling op); bounded: 20 ms of wall time, then this workgroup stops waiting for good
@@ -82,12 +96,61 @@ __device__ __forceinline__ void chain_wait(const ChainParams& p, ChainCtx& c) {
     __syncthreads();
 }
 
-// after the op's stores: every storing wave drains, the workgroup meets, ONE lane arrives for all of them
-__device__ __forceinline__ void chain_signal(const ChainParams& p, ChainCtx& c) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (c.tid == 0) __hip_atomic_fetch_add(p.cnt + c.b * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    ++c.signals;
+// The NEXT op's filter slice into this XCD's L2 while this op runs (the level's filters are 33 MB, read once per step: without
+// this every op's k loop starts on far-memory latency -- the 512-channel conv ran at 13-16 us where its MFMAs need 8.4,
+// profiles/r06_chain_clock_v1.txt).  The 32 workgroups of a slice share the XCD: workgroup `slot` touches every slots-th part, one
+// dword per 128-byte line and thread.  The destination register stays reserved until chain_pf_retire (a load that lands in a
+// register the compiler has reused would corrupt it).
+__device__ __forceinline__ void chain_prefetch(const ChainOp& o, const ChainCtx& c, float& sink) {
+    const int cin = o.c0 + o.c1;
+    const float* base;
+    int lines;                                           // 128-byte lines of this workgroup's slice
+    if (o.kind == CH_ATTN) {
+        if (c.nt >= 4) return;
+        base = o.w + (size_t)c.nt * (cin >> 5) * 3072;
+        lines = (cin >> 5) * 3072 / 32;
+    } else {
+        const int taps = o.kind == CH_CONV3 ? 9 : 1;
+        base = o.w + (size_t)c.nt * taps * (cin >> 5) * 1024;
+        lines = taps * (cin >> 5) * 1024 / 32;
+    }
+    const int share = (lines + c.slots - 1) / c.slots;
+    const int line = c.slot * share + c.tid;
+    if (c.tid < share && line < lines) asm volatile("global_load_dword %0, %1, off" : "=v"(sink) : "v"(base + (size_t)line * 32) : "memory");
+}
+__device__ __forceinline__ void chain_pf_retire(float& sink) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(sink) :: "memory"); }
+
+// The end of an op.  Thread (row = tid / 32, col = tid % 32) holds output element y of the workgroup's 16 x 32 slice -- the same
+// element in every op, so the residuals are registers.  The four lanes of a quad hold four consecutive channels of one pixel: they
+// are gathered with three DPP moves (no LDS, no barrier) and every fourth lane stores 16 bytes.  Publishing: each wave drains its
+// OWN stores and counts itself in on an LDS word; the wave whose count completes the eight arrives on the image's counter for all
+// of them (MI355X_MICROARCH.md, hand-off table, row 1 with the LDS-counter form of its condition (3)) -- no workgroup barrier, the
+// waves run ahead into the next op's prologue as they finish.
+__device__ __forceinline__ void chain_finish(const ChainParams& p, const ChainOp& o, ChainCtx& c, float y, int n0) {
+    if (o.flags & CHF_ADD_KEEP) y += c.keep;
+    if (o.flags & CHF_ADD_KEEP2) y += c.keep2;
+    if (o.flags & CHF_SAVE_KEEP) c.keep = y;
+    if (o.flags & CHF_SAVE_KEEP2) c.keep2 = y;
+    if (!(o.flags & CHF_NO_OUT)) {
+        const int yb = __builtin_bit_cast(int, y);
+        const float y0 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, yb, 0x00, 0xF, 0xF, true));   // quad_perm [0,0,0,0]
+        const float y1 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, yb, 0x55, 0xF, 0xF, true));   // [1,1,1,1]
+        const float y2 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, yb, 0xAA, 0xF, 0xF, true));   // [2,2,2,2]
+        const float y3 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, yb, 0xFF, 0xF, 0xF, true));   // [3,3,3,3]
+        if ((c.lane & 3) == 0) {
+            float* dst = o.out + ((long long)c.b * 16 + (c.tid >> 5)) * o.n_out + n0 + (c.tid & 31);
+            const f32x4 v{y0, y1, y2, y3};
+            if (o.flags & CHF_SIGNAL) st_sc1(dst, v);
+            else *reinterpret_cast<f32x4*>(dst) = v;
+        }
+    }
+    if (o.flags & CHF_SIGNAL) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (c.lane == 0) {
+            unsigned* lcnt = reinterpret_cast<unsigned*>(c.lds + LC_MISC) + 1;
+            if ((atomicAdd(lcnt, 1u) & 7u) == 7u) __hip_atomic_fetch_add(p.cnt + c.b * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
 // [16 rows][cin] of image b (src0 | src1 along the channels) -> LDS rows of pitch cin + 4; 512 threads, cin / 128 float4 each
@@ -119,31 +182,6 @@ __device__ __forceinline__ void chain_stage(const ChainOp& o, ChainCtx& c, int c
         put(c.tid, v0);
     }
     if (c.tid < q4) *reinterpret_cast<f32x4*>(c.lds + 16 * pitch + (c.tid << 2)) = f32x4{0.f, 0.f, 0.f, 0.f};   // the row out-of-image taps read
-}
-
-// this thread's output element y (row = tid / 32, col = tid % 32 of the workgroup's 16 x 32 slice) -> out, as 16-byte stores
-__device__ __forceinline__ void chain_store(const ChainOp& o, ChainCtx& c, float y, int n0) {
-    float* tile = c.lds + LC_TILE;
-    tile[(c.tid >> 5) * LC_PP + (c.tid & 31)] = y;
-    __syncthreads();
-    if (c.tid < 128) {
-        const int r = c.tid >> 3, c4 = (c.tid & 7) << 2;
-        const f32x4 v = *reinterpret_cast<const f32x4*>(tile + r * LC_PP + c4);
-        float* dst = o.out + ((long long)c.b * 16 + r) * o.n_out + n0 + c4;
-        if (o.flags & CHF_SIGNAL) st_sc1(dst, v);
-        else *reinterpret_cast<f32x4*>(dst) = v;
-    }
-}
-
-// sum over the workgroup's 512 threads, the same value in every thread; `rd` = 8 floats nobody else touches until the next barrier
-__device__ __forceinline__ float chain_sum512(float s, float* rd, int lane, int wave) {
-    s = wave_sum(s);
-    if (lane == 0) rd[wave] = s;
-    __syncthreads();
-    float t = rd[0];
-#pragma unroll
-    for (int w = 1; w < 8; ++w) t += rd[w];
-    return t;
 }
 
 // CH_CONV3 / CH_CONV1.  The arithmetic of conv3x3_gn_local_kernel<16, 1, NU> (conv_local.hip): direct conv on v_mfma_f32_16x16x4_f32,
@@ -190,10 +228,17 @@ __device__ __forceinline__ void chain_conv(const ChainParams& p, const ChainOp& 
     }
     const float cb = o.bias ? o.bias[ch] : 0.f;
     if (o.flags & CHF_KEEP_FROM_SRC) c.keep = o.src0[((long long)c.b * 16 + row) * o.c0 + ch];
+    float pf = 0.f;
+    if (c.k + 1 < p.n_ops) chain_prefetch(p.op[c.k + 1], c, pf);
 
+    LC_STAMP(c, c.k, 0);
     if (o.flags & CHF_WAIT) chain_wait(p, c);
-    chain_stage(o, c, cin, pitch);
+    else __syncthreads();                 // a wave may still be reading the previous op's partial tiles: the image lands on them
+    LC_STAMP(c, c.k, 1);
+    chain_stage(o, c, cin, pitch);        // (its vmcnt(0) also retires the prefetch)
+    chain_pf_retire(pf);
     __syncthreads();
+    LC_STAMP(c, c.k, 2);
 
     // ---- k loop
     f32x4 acc[2];
@@ -258,6 +303,7 @@ __device__ __forceinline__ void chain_conv(const ChainParams& p, const ChainOp& 
     }
 
     // ---- the 8 waves' partial tiles meet in LDS (the image is no longer needed)
+    LC_STAMP(c, c.k, 3);
     __syncthreads();
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb)
@@ -268,24 +314,30 @@ __device__ __forceinline__ void chain_conv(const ChainParams& p, const ChainOp& 
 #pragma unroll
     for (int w = 1; w < 8; ++w) v += lds[(w * 16 + row) * LC_PP + col];
     v += cb;
-
     float y = v;
     if (o.kind == CH_CONV3) {
-        // GroupNorm of the slice = one group of 32 channels x 16 pixels, two passes like torch's native_group_norm
+        // GroupNorm of the slice = one group of 32 channels x 16 pixels.  Each wave: mean and M2 of its own 64 values (two passes inside
+        // the wave); the eight {mean, M2} records merge exactly (Chan et al.) behind ONE barrier.
         float* red = lds + LC_RED;
-        const float mean = chain_sum512(v, red, lane, wave) * (1.0f / 512.0f);
-        const float d = v - mean;
-        const float var = chain_sum512(d * d, red + 8, lane, wave) * (1.0f / 512.0f);
+        const float mw = wave_sum(v) * (1.0f / 64.0f);
+        const float dw = v - mw;
+        const float m2w = wave_sum(dw * dw);
+        if (lane == 0) { red[2 * wave] = mw; red[2 * wave + 1] = m2w; }
+        __syncthreads();
+        float msum = red[0], m2 = red[1];
+#pragma unroll
+        for (int w = 1; w < 8; ++w) { msum += red[2 * w]; m2 += red[2 * w + 1]; }
+        const float mean = msum * 0.125f;
+        float dev = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) { const float dm = red[2 * w] - mean; dev += dm * dm; }
+        const float var = (m2 + 64.0f * dev) * (1.0f / 512.0f);
         const float rstd = 1.0f / sqrtf(var + p.gn_eps);
-        y = mish_f(d * rstd * ga + be) + sh;
+        y = mish_f((v - mean) * rstd * ga + be) + sh;
     }
-    if (o.flags & CHF_ADD_KEEP) y += c.keep;
-    if (o.flags & CHF_ADD_KEEP2) y += c.keep2;
-    if (o.flags & CHF_SAVE_KEEP) c.keep = y;
-    if (o.flags & CHF_SAVE_KEEP2) c.keep2 = y;
-    if (!(o.flags & CHF_NO_OUT)) chain_store(o, c, y, n0);
-    if (o.flags & CHF_SIGNAL) chain_signal(p, c);
-    else __syncthreads();
+    chain_finish(p, o, c, y, n0);
+    if (o.flags & CHF_SIGNAL) ++c.signals;
+    LC_STAMP(c, c.k, 4);
 }
 
 // CH_ATTN (blocks.py:116-134 behind PreNorm, :57-71): head h = nt < 4 of image b.  q | k | v of the head = LayerNorm-folded to_qkv
@@ -294,6 +346,9 @@ __device__ __forceinline__ void chain_conv(const ChainParams& p, const ChainOp& 
 __device__ __forceinline__ void chain_attn(const ChainParams& p, const ChainOp& o, ChainCtx& c) {
     float* lds = c.lds;
     const int tid = c.tid, lane = c.lane, wave = c.wave;
+    float pf = 0.f, pf2 = 0.f;           // the to_out behind this op is short: warm the L2 for the conv behind it as well
+    if (c.k + 1 < p.n_ops) chain_prefetch(p.op[c.k + 1], c, pf);
+    if (c.k + 2 < p.n_ops) chain_prefetch(p.op[c.k + 2], c, pf2);
     if (c.nt < 4) {
         const int h = c.nt;
         const int m = lane & 15, kq = lane >> 4;
@@ -322,9 +377,15 @@ __device__ __forceinline__ void chain_attn(const ChainParams& p, const ChainOp& 
             const int colw = (n >> 5) * 128 + h * 32 + (n & 31);
             cfold[tid] = tid < 96 ? o.gamma[colw] : o.beta[colw];
         }
+        LC_STAMP(c, c.k, 0);
         if (o.flags & CHF_WAIT) chain_wait(p, c);
+        else __syncthreads();
+        LC_STAMP(c, c.k, 1);
         chain_stage(o, c, C, pitch);
+        chain_pf_retire(pf);
+        chain_pf_retire(pf2);
         __syncthreads();
+        LC_STAMP(c, c.k, 2);
         {   // LayerNorm statistics of the 16 pixel rows: 32 threads per row, two passes over the resident row (biased variance, eps on the std)
             const int row = tid >> 5, sub = tid & 31;
             float s1 = 0.f;
@@ -372,6 +433,7 @@ __device__ __forceinline__ void chain_attn(const ChainParams& p, const ChainOp& 
                 }
             }
         }
+        LC_STAMP(c, c.k, 3);
         __syncthreads();                                    // image consumed, rowstat written
 #pragma unroll
         for (int nb = 0; nb < 6; ++nb)
@@ -416,14 +478,20 @@ __device__ __forceinline__ void chain_attn(const ChainParams& p, const ChainOp& 
             cs[d * 36 + e0 + 1] = a1 * inv;
         }
         __syncthreads();
-        const int n = tid >> 5, e = tid & 31;
+        const int n = tid >> 5, e = tid & 31;      // out[n][e] = sum_d q[n][d] ctx[d][e]: the thread's own element, as in chain_conv
         float y = 0.f;
 #pragma unroll
         for (int d = 0; d < 32; ++d) y += qs[n * 33 + d] * cs[d * 36 + e];
-        chain_store(o, c, y, h * 32);
+        chain_finish(p, o, c, y, h * 32);
+    } else {
+        // heads are workgroups 0..3; 4..7 have nothing to compute here: they arrive at once (their arrival publishes nothing) and only
+        // warm their L2 for the ops behind
+        chain_pf_retire(pf);
+        chain_pf_retire(pf2);
+        if ((o.flags & CHF_SIGNAL) && tid == 0) __hip_atomic_fetch_add(p.cnt + c.b * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (o.flags & CHF_SIGNAL) chain_signal(p, c);
-    else __syncthreads();
+    if (o.flags & CHF_SIGNAL) ++c.signals;
+    LC_STAMP(c, c.k, 4);
 }
 
 __global__ __launch_bounds__(512) void level_chain_kernel(const ChainParams p) {
@@ -434,15 +502,20 @@ __global__ __launch_bounds__(512) void level_chain_kernel(const ChainParams p) {
     c.lane = c.tid & 63;
     c.wave = __builtin_amdgcn_readfirstlane(c.tid >> 6);
     c.nt = blockIdx.x & 7;
-    if (c.tid == 0) *reinterpret_cast<int*>(lds + LC_MISC) = 0;
+    c.watch = blockIdx.x == 0 ? 0 : blockIdx.x == 100 ? 1 : blockIdx.x == 255 ? 2 : -1;
+    c.k = 0;
+    if (c.tid == 0) { *reinterpret_cast<int*>(lds + LC_MISC) = 0; reinterpret_cast<unsigned*>(lds + LC_MISC)[1] = 0u; }
     __syncthreads();
     const int slots = gridDim.x >> 3;
+    c.slot = blockIdx.x >> 3;
+    c.slots = slots;
     for (int b = blockIdx.x >> 3; b < p.B; b += slots) {
         c.b = b;
         c.signals = 0;
         c.keep = c.keep2 = 0.f;
         for (int k = 0; k < p.n_ops; ++k) {
             const ChainOp& o = p.op[k];
+            c.k = k;
             if (o.kind == CH_ATTN) chain_attn(p, o, c);
             else if (o.kind == CH_CONV1) chain_conv<0>(p, o, c);
             else if (o.c0 + o.c1 == 256) chain_conv<1>(p, o, c);
@@ -450,6 +523,7 @@ __global__ __launch_bounds__(512) void level_chain_kernel(const ChainParams p) {
             else chain_conv<0>(p, o, c);
         }
         // the image's last departure re-arms its counters for the next launch: every one of the eight has passed its last wait
+        __syncthreads();              // (every wave has left the last op)
         if (c.tid == 0) {
             const unsigned prev = __hip_atomic_fetch_add(p.done + b * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (prev == 7u) {
@@ -485,3 +559,10 @@ int level_chain_launch(const ChainParams& p, hipStream_t st) {
 }
 
 }  // namespace ddk
+
+#ifdef DDK_TUNING
+extern "C" int ddk_debug_read_lc_stamps(unsigned long long* host_out) {   // tuning build only (not in include/ddk.h)
+    if (hipDeviceSynchronize() != hipSuccess) return -2;
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(ddk::g_lc_stamps), sizeof(unsigned long long) * 3 * ddk::CH_MAX_OPS * 8) == hipSuccess ? 0 : -2;
+}
+#endif
