@@ -19,9 +19,11 @@
 // grid are resident at once on a whole, otherwise idle MI355X (<= 256 workgroups, one per CU: 96 KB of LDS); the waits are bounded
 // by wall time anyway, a give-up moves the caller's sticky fail word (ddk_unet_cluster_check) and is never silent.
 #include "level_chain.h"
+#include "conv_common.h"
 
 #include <atomic>
 #include <cstdlib>
+#include <type_traits>
 
 namespace ddk {
 
@@ -39,18 +41,26 @@ constexpr int LC_CS = LC_QS + 528;         // [32][36]
 constexpr int LC_SMAX = LC_CS + 1152;      // [32]
 constexpr int LC_ROWSTAT = LC_SMAX + 32;   // [16][2]
 constexpr int LC_CFOLD = LC_ROWSTAT + 32;  // [192]
-constexpr int LC_MISC = LC_CFOLD + 192;    // [0] this workgroup gave up waiting
-constexpr int LC_FLOATS = LC_MISC + 4;
+constexpr int LC_MISC = LC_CFOLD + 192;    // [0] this workgroup gave up waiting, [1] waves counted in at the current publish
+constexpr int LC_PF = LC_MISC + 4;         // 256 floats nobody reads: where the L2 prefetch's LDS-DMA pieces land
+constexpr int LC_FLOATS = LC_PF + 256;
 
 size_t level_chain_lds_bytes() { return 96 * 1024; }     // > 80 KB: one workgroup per CU
 static_assert(LC_FLOATS * 4 <= 96 * 1024, "LDS carve-up");
 
-// ---- memory-side helpers: 16-byte sc1 loads (several in flight, ONE counted wait that owns their registers) and stores
-__device__ __forceinline__ void ld_sc1(f32x4& v, const float* p) { asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory"); }
-__device__ __forceinline__ void wait_vm(f32x4& a) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(a) :: "memory"); }
-__device__ __forceinline__ void wait_vm(f32x4& a, f32x4& b) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b) :: "memory"); }
-__device__ __forceinline__ void wait_vm(f32x4& a, f32x4& b, f32x4& c, f32x4& d) {
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) :: "memory");
+// ---- memory-side helpers: 16-byte sc1 loads -- issue and wait in ONE asm statement, so that no compiler-made copy can ever sit
+//      between a load and the wait that makes its destination valid -- and stores
+__device__ __forceinline__ void ld_sc1_x1(f32x4& a, const float* pa) {
+    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(a) : "v"(pa) : "memory");
+}
+__device__ __forceinline__ void ld_sc1_x2(f32x4& a, f32x4& b, const float* pa, const float* pb) {
+    asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %3, off sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(a), "=&v"(b) : "v"(pa), "v"(pb) : "memory");
+}
+__device__ __forceinline__ void ld_sc1_x4(f32x4& a, f32x4& b, f32x4& c, f32x4& d, const float* pa, const float* pb, const float* pc, const float* pd) {
+    asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %5, off sc1\n\tglobal_load_dwordx4 %2, %6, off sc1\n\t"
+                 "global_load_dwordx4 %3, %7, off sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d) : "v"(pa), "v"(pb), "v"(pc), "v"(pd) : "memory");
 }
 __device__ __forceinline__ void st_sc1(float* p, f32x4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(v) : "memory"); }
 
@@ -65,6 +75,22 @@ __device__ unsigned long long g_lc_stamps[3 * CH_MAX_OPS * 8];
 #else
 #define LC_STAMP(c, k, i) do { } while (0)
 #endif
+
+// Sum over the 64 lanes, the same value in every lane, on DPP + readlane (wave_sum's __shfl_xor steps compile to six dependent
+// ds_bpermute_b32, ~0.25 us per reduction on an otherwise idle CU; the op's tail runs two of them back to back)
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+    auto dpp_add = [](float x, auto ctrl) {
+        return x + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xF, 0xF, true));
+    };
+    v = dpp_add(v, std::integral_constant<int, 0xB1>{});     // quad_perm [1,0,3,2]
+    v = dpp_add(v, std::integral_constant<int, 0x4E>{});     // quad_perm [2,3,0,1]
+    v = dpp_add(v, std::integral_constant<int, 0x141>{});    // row_half_mirror
+    v = dpp_add(v, std::integral_constant<int, 0x140>{});    // row_mirror: every lane holds its 16-lane row's sum
+    const int b = __builtin_bit_cast(int, v);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
+    return (r0 + r1) + (r2 + r3);
+}
 
 struct ChainCtx {
     float* lds;
@@ -99,9 +125,11 @@ __device__ __forceinline__ void chain_wait(const ChainParams& p, ChainCtx& c) {
 // The NEXT op's filter slice into this XCD's L2 while this op runs (the level's filters are 33 MB, read once per step: without
 // this every op's k loop starts on far-memory latency -- the 512-channel conv ran at 13-16 us where its MFMAs need 8.4,
 // profiles/r06_chain_clock_v1.txt).  The 32 workgroups of a slice share the XCD: workgroup `slot` touches every slots-th part, one
-// dword per 128-byte line and thread.  The destination register stays reserved until chain_pf_retire (a load that lands in a
-// register the compiler has reused would corrupt it).
-__device__ __forceinline__ void chain_prefetch(const ChainOp& o, const ChainCtx& c, float& sink) {
+// 16-byte piece per 128-byte line and thread.  The pieces are LDS-DMA loads into a scratch kilobyte nobody reads: a load with a
+// register destination would have to keep that register reserved until it lands, and the compiler cannot be told (a first version
+// did that through an asm output operand; a register copy the compiler inserted behind the load freed the real destination, the
+// late data landed in an address register and the kernel faulted).
+__device__ __forceinline__ void chain_prefetch(const ChainOp& o, const ChainCtx& c) {
     const int cin = o.c0 + o.c1;
     const float* base;
     int lines;                                           // 128-byte lines of this workgroup's slice
@@ -115,10 +143,15 @@ __device__ __forceinline__ void chain_prefetch(const ChainOp& o, const ChainCtx&
         lines = taps * (cin >> 5) * 1024 / 32;
     }
     const int share = (lines + c.slots - 1) / c.slots;
-    const int line = c.slot * share + c.tid;
-    if (c.tid < share && line < lines) asm volatile("global_load_dword %0, %1, off" : "=v"(sink) : "v"(base + (size_t)line * 32) : "memory");
+    const int first = c.slot * share;
+    const int n = lines - first < share ? lines - first : share;      // this workgroup's lines: [first, first + n)
+    const unsigned dst = (unsigned)(size_t)(__attribute__((address_space(3))) float*)(c.lds + LC_PF);
+    for (int i = c.wave * 64; i < n; i += 512) {                      // wave-uniform trip count; lanes past the end re-touch the last line
+        int line = first + i + c.lane;
+        line = line < first + n ? line : first + n - 1;
+        lds_dma16(base + (size_t)line * 32, dst);
+    }
 }
-__device__ __forceinline__ void chain_pf_retire(float& sink) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(sink) :: "memory"); }
 
 // The end of an op.  Thread (row = tid / 32, col = tid % 32) holds output element y of the workgroup's 16 x 32 slice -- the same
 // element in every op, so the residuals are registers.  The four lanes of a quad hold four consecutive channels of one pixel: they
@@ -167,18 +200,15 @@ __device__ __forceinline__ void chain_stage(const ChainOp& o, ChainCtx& c, int c
     };
     if (cin == 512) {
         f32x4 v0, v1, v2, v3;
-        ld_sc1(v0, addr(c.tid)); ld_sc1(v1, addr(c.tid + 512)); ld_sc1(v2, addr(c.tid + 1024)); ld_sc1(v3, addr(c.tid + 1536));
-        wait_vm(v0, v1, v2, v3);
+        ld_sc1_x4(v0, v1, v2, v3, addr(c.tid), addr(c.tid + 512), addr(c.tid + 1024), addr(c.tid + 1536));
         put(c.tid, v0); put(c.tid + 512, v1); put(c.tid + 1024, v2); put(c.tid + 1536, v3);
     } else if (cin == 256) {
         f32x4 v0, v1;
-        ld_sc1(v0, addr(c.tid)); ld_sc1(v1, addr(c.tid + 512));
-        wait_vm(v0, v1);
+        ld_sc1_x2(v0, v1, addr(c.tid), addr(c.tid + 512));
         put(c.tid, v0); put(c.tid + 512, v1);
     } else {    // 128
         f32x4 v0;
-        ld_sc1(v0, addr(c.tid));
-        wait_vm(v0);
+        ld_sc1_x1(v0, addr(c.tid));
         put(c.tid, v0);
     }
     if (c.tid < q4) *reinterpret_cast<f32x4*>(c.lds + 16 * pitch + (c.tid << 2)) = f32x4{0.f, 0.f, 0.f, 0.f};   // the row out-of-image taps read
@@ -228,15 +258,13 @@ __device__ __forceinline__ void chain_conv(const ChainParams& p, const ChainOp& 
     }
     const float cb = o.bias ? o.bias[ch] : 0.f;
     if (o.flags & CHF_KEEP_FROM_SRC) c.keep = o.src0[((long long)c.b * 16 + row) * o.c0 + ch];
-    float pf = 0.f;
-    if (c.k + 1 < p.n_ops) chain_prefetch(p.op[c.k + 1], c, pf);
+    if (c.k + 1 < p.n_ops) chain_prefetch(p.op[c.k + 1], c);
 
     LC_STAMP(c, c.k, 0);
     if (o.flags & CHF_WAIT) chain_wait(p, c);
     else __syncthreads();                 // a wave may still be reading the previous op's partial tiles: the image lands on them
     LC_STAMP(c, c.k, 1);
-    chain_stage(o, c, cin, pitch);        // (its vmcnt(0) also retires the prefetch)
-    chain_pf_retire(pf);
+    chain_stage(o, c, cin, pitch);        // (its vmcnt(0) also drains the prefetch pieces)
     __syncthreads();
     LC_STAMP(c, c.k, 2);
 
@@ -319,9 +347,9 @@ __device__ __forceinline__ void chain_conv(const ChainParams& p, const ChainOp& 
         // GroupNorm of the slice = one group of 32 channels x 16 pixels.  Each wave: mean and M2 of its own 64 values (two passes inside
         // the wave); the eight {mean, M2} records merge exactly (Chan et al.) behind ONE barrier.
         float* red = lds + LC_RED;
-        const float mw = wave_sum(v) * (1.0f / 64.0f);
+        const float mw = wave_sum_dpp(v) * (1.0f / 64.0f);
         const float dw = v - mw;
-        const float m2w = wave_sum(dw * dw);
+        const float m2w = wave_sum_dpp(dw * dw);
         if (lane == 0) { red[2 * wave] = mw; red[2 * wave + 1] = m2w; }
         __syncthreads();
         float msum = red[0], m2 = red[1];
@@ -346,9 +374,9 @@ __device__ __forceinline__ void chain_conv(const ChainParams& p, const ChainOp& 
 __device__ __forceinline__ void chain_attn(const ChainParams& p, const ChainOp& o, ChainCtx& c) {
     float* lds = c.lds;
     const int tid = c.tid, lane = c.lane, wave = c.wave;
-    float pf = 0.f, pf2 = 0.f;           // the to_out behind this op is short: warm the L2 for the conv behind it as well
-    if (c.k + 1 < p.n_ops) chain_prefetch(p.op[c.k + 1], c, pf);
-    if (c.k + 2 < p.n_ops) chain_prefetch(p.op[c.k + 2], c, pf2);
+    // the to_out behind this op is short: warm the L2 for the conv behind it as well
+    if (c.k + 1 < p.n_ops) chain_prefetch(p.op[c.k + 1], c);
+    if (c.k + 2 < p.n_ops) chain_prefetch(p.op[c.k + 2], c);
     if (c.nt < 4) {
         const int h = c.nt;
         const int m = lane & 15, kq = lane >> 4;
@@ -382,8 +410,6 @@ __device__ __forceinline__ void chain_attn(const ChainParams& p, const ChainOp& 
         else __syncthreads();
         LC_STAMP(c, c.k, 1);
         chain_stage(o, c, C, pitch);
-        chain_pf_retire(pf);
-        chain_pf_retire(pf2);
         __syncthreads();
         LC_STAMP(c, c.k, 2);
         {   // LayerNorm statistics of the 16 pixel rows: 32 threads per row, two passes over the resident row (biased variance, eps on the std)
@@ -486,8 +512,6 @@ __device__ __forceinline__ void chain_attn(const ChainParams& p, const ChainOp& 
     } else {
         // heads are workgroups 0..3; 4..7 have nothing to compute here: they arrive at once (their arrival publishes nothing) and only
         // warm their L2 for the ops behind
-        chain_pf_retire(pf);
-        chain_pf_retire(pf2);
         if ((o.flags & CHF_SIGNAL) && tid == 0) __hip_atomic_fetch_add(p.cnt + c.b * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (o.flags & CHF_SIGNAL) ++c.signals;
@@ -513,6 +537,8 @@ __global__ __launch_bounds__(512) void level_chain_kernel(const ChainParams p) {
         c.b = b;
         c.signals = 0;
         c.keep = c.keep2 = 0.f;
+        // the first op's filter is cold too: its lines are requested now, the later part of its k loop hits L2 (retired at its stage)
+        chain_prefetch(p.op[0], c);
         for (int k = 0; k < p.n_ops; ++k) {
             const ChainOp& o = p.op[k];
             c.k = k;
