@@ -42,6 +42,7 @@ struct ChainParams {
     unsigned* fail;                 // sticky count of workgroups that gave up waiting (the caller's cluster check reads it)
     int n_ops, B, temb_stride;
     float gn_eps, ln_eps;
+    int hw;                         // pixels per image: 16 (4x4 maps: level_chain_kernel) or 64 (8x8 maps: level8_chain_kernel)
 };
 
 bool level_chain_device_ok();

@@ -97,13 +97,16 @@ struct ChainCtx {
     int tid, lane, wave, b, nt;
     unsigned signals;            // signalling ops of this image so far (uniform)
     float keep, keep2;           // the residual stream's / the skip conv's element of this thread (row tid / 32, column tid % 32 of the slice)
+    float* misc;                 // LDS: [0] this workgroup gave up waiting, [1] waves counted in at the current publish
+    unsigned pf_dst;             // LDS byte address of the scratch kilobyte the prefetch pieces land in
+    int nwaves, units3;          // waves in the workgroup; filter units per 32-channel chunk of a CH_CONV3 op (9 taps, or 16 Winograd positions)
     int slot, slots;             // image slot of this workgroup and slots in the grid (the 32 workgroups of a slice share an XCD)
     int watch, k;                // tuning build: which stamp row this workgroup writes (-1: none), current op index
 };
 
 // every arrival of the image so far (8 per signalling op); bounded: 20 ms of wall time, then this workgroup stops waiting for good
 __device__ __forceinline__ void chain_wait(const ChainParams& p, ChainCtx& c) {
-    int* dead = reinterpret_cast<int*>(c.lds + LC_MISC);
+    int* dead = reinterpret_cast<int*>(c.misc);
     if (c.tid == 0 && !*dead) {
         const unsigned need = 8u * c.signals;
         unsigned* cnt = p.cnt + c.b * 32;
@@ -138,18 +141,17 @@ __device__ __forceinline__ void chain_prefetch(const ChainOp& o, const ChainCtx&
         base = o.w + (size_t)c.nt * (cin >> 5) * 3072;
         lines = (cin >> 5) * 3072 / 32;
     } else {
-        const int taps = o.kind == CH_CONV3 ? 9 : 1;
+        const int taps = o.kind == CH_CONV3 ? c.units3 : 1;
         base = o.w + (size_t)c.nt * taps * (cin >> 5) * 1024;
         lines = taps * (cin >> 5) * 1024 / 32;
     }
     const int share = (lines + c.slots - 1) / c.slots;
     const int first = c.slot * share;
     const int n = lines - first < share ? lines - first : share;      // this workgroup's lines: [first, first + n)
-    const unsigned dst = (unsigned)(size_t)(__attribute__((address_space(3))) float*)(c.lds + LC_PF);
-    for (int i = c.wave * 64; i < n; i += 512) {                      // wave-uniform trip count; lanes past the end re-touch the last line
+    for (int i = c.wave * 64; i < n; i += c.nwaves * 64) {            // wave-uniform trip count; lanes past the end re-touch the last line
         int line = first + i + c.lane;
         line = line < first + n ? line : first + n - 1;
-        lds_dma16(base + (size_t)line * 32, dst);
+        lds_dma16(base + (size_t)line * 32, c.pf_dst);
     }
 }
 
@@ -180,7 +182,7 @@ __device__ __forceinline__ void chain_finish(const ChainParams& p, const ChainOp
     if (o.flags & CHF_SIGNAL) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (c.lane == 0) {
-            unsigned* lcnt = reinterpret_cast<unsigned*>(c.lds + LC_MISC) + 1;
+            unsigned* lcnt = reinterpret_cast<unsigned*>(c.misc) + 1;
             if ((atomicAdd(lcnt, 1u) & 7u) == 7u) __hip_atomic_fetch_add(p.cnt + c.b * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
@@ -510,8 +512,12 @@ __device__ __forceinline__ void chain_attn(const ChainParams& p, const ChainOp& 
         for (int d = 0; d < 32; ++d) y += qs[n * 33 + d] * cs[d * 36 + e];
         chain_finish(p, o, c, y, h * 32);
     } else {
-        // heads are workgroups 0..3; 4..7 have nothing to compute here: they arrive at once (their arrival publishes nothing) and only
-        // warm their L2 for the ops behind
+        // heads are workgroups 0..3; 4..7 have nothing to compute here and only warm their L2 for the ops behind.  They WAIT like the
+        // others before they arrive: the image's counter is one monotonic count of arrivals, and "8 x signalling ops so far" only means
+        // "everybody has published the previous op" if nobody can arrive for op k + 1 before every arrival of op k is in (a first version
+        // let them arrive at once: a reader could then pass its wait with one slice of the previous op still unpublished -- rare on the
+        // 4x4 maps, every first forward on the 8x8 ones)
+        if (o.flags & CHF_WAIT) chain_wait(p, c);
         if ((o.flags & CHF_SIGNAL) && tid == 0) __hip_atomic_fetch_add(p.cnt + c.b * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (o.flags & CHF_SIGNAL) ++c.signals;
@@ -526,6 +532,10 @@ __global__ __launch_bounds__(512) void level_chain_kernel(const ChainParams p) {
     c.lane = c.tid & 63;
     c.wave = __builtin_amdgcn_readfirstlane(c.tid >> 6);
     c.nt = blockIdx.x & 7;
+    c.misc = lds + LC_MISC;
+    c.pf_dst = (unsigned)(size_t)(__attribute__((address_space(3))) float*)(lds + LC_PF);
+    c.nwaves = 8;
+    c.units3 = 9;
     c.watch = blockIdx.x == 0 ? 0 : blockIdx.x == 100 ? 1 : blockIdx.x == 255 ? 2 : -1;
     c.k = 0;
     if (c.tid == 0) { *reinterpret_cast<int*>(lds + LC_MISC) = 0; reinterpret_cast<unsigned*>(lds + LC_MISC)[1] = 0u; }
@@ -560,31 +570,625 @@ __global__ __launch_bounds__(512) void level_chain_kernel(const ChainParams p) {
     }
 }
 
+// ===========================================================================================================================
+// The 8x8 levels (downs[-2] and ups[1] of the cfg4 UNet: 64 pixels x 256 channels per image) the same way, 1024 threads:
+// CH_CONV3 is conv3x3_gn_wlocal_kernel's arithmetic (conv_local.hip) -- Winograd F(2x2, 3x3), an image = 16 tiles = one M block of
+// v_mfma_f32_16x16x4_f32; eight TRANSFORM waves (8..15) build V = B^T d B of the next 32-channel chunk while eight MATRIX waves (0..7)
+// multiply positions 2w, 2w+1 of this one against U streamed from L2 in operand order (ddk_pack_conv_weight_wino_local), V
+// double-buffered, one LDS barrier per chunk -- with a 512-channel concat input walked as two staged halves.  CH_CONV1 / CH_ATTN:
+// direct products on the matrix waves.  Thread (tile tid / 32, channel tid % 32) of the matrix waves owns the 2 x 2 pixels of its
+// tile in every op: the residuals are four registers.
+constexpr int L8_P = 260;                      // image row pitch (256 channels per staged pass + 4)
+constexpr int L8_IMG = 65 * L8_P;              // rows 0..63 + the zero row out-of-image taps read; later: attention / 1x1 partial tiles
+constexpr int L8_VP = 36;
+constexpr int L8_VBUF = 16 * 16 * L8_VP;       // one V buffer [position][tile][36]
+constexpr int L8_V = L8_IMG;                   // two V buffers; later M [position][tile][36]; attention: k, v, q, ctx
+constexpr int L8_KS = L8_V;                    // [64][32]
+constexpr int L8_VS = L8_KS + 2048;            // [64][32]
+constexpr int L8_QS = L8_VS + 2048;            // [64][33]
+constexpr int L8_CS = L8_QS + 2112;            // [32][36]
+constexpr int L8_RED = L8_V + 2 * L8_VBUF;     // 64
+constexpr int L8_SMAX = L8_RED + 64;           // [8][32] partial maxima, [32] maxima
+constexpr int L8_ROWSTAT = L8_SMAX + 320;      // [64][2]
+constexpr int L8_CFOLD = L8_ROWSTAT + 128;     // [192]
+constexpr int L8_MISC = L8_CFOLD + 192;
+constexpr int L8_PF = L8_MISC + 4;
+constexpr int L8_FLOATS = L8_PF + 256;
+static_assert(L8_CS + 1152 <= L8_RED, "attention arrays fit the V buffers");
+static_assert(L8_FLOATS * 4 <= 160 * 1024, "LDS carve-up (8x8)");
+static_assert(2 * 64 * LC_QP <= L8_IMG && 8 * 64 * LC_PP <= 2 * L8_VBUF, "partial tiles fit");
+
+// [64 rows][ncols] of image b, channels [ch_lo, ch_lo + ncols) of (src0 | src1) -> LDS rows of pitch ncols + 4 (+ the zero row)
+__device__ __forceinline__ void c8_stage(const ChainOp& o, ChainCtx& c, int ch_lo, int ncols) {
+    const int q4 = ncols >> 2, pitch = ncols + 4;
+    auto addr = [&](int idx) -> const float* {
+        const int row = idx / q4, ch = ch_lo + ((idx - row * q4) << 2);
+        const long long r = (long long)c.b * 64 + row;
+        return ch < o.c0 ? o.src0 + r * o.c0 + ch : o.src1 + r * o.c1 + (ch - o.c0);
+    };
+    auto put = [&](int idx, f32x4 v) {
+        const int row = idx / q4, ch = (idx - row * q4) << 2;
+        *reinterpret_cast<f32x4*>(c.lds + row * pitch + ch) = v;
+    };
+    // two 16-byte pieces per thread and round (a 1024-thread workgroup leaves 128 registers per thread: four pieces and their
+    // addresses in flight next to the matrix waves' 64 filter registers spilled)
+    for (int r0 = 0; r0 < 64 * q4; r0 += 2048) {
+        f32x4 v0, v1;
+        ld_sc1_x2(v0, v1, addr(r0 + c.tid), addr(r0 + c.tid + 1024));
+        put(r0 + c.tid, v0); put(r0 + c.tid + 1024, v1);
+    }
+    if (c.tid < q4) *reinterpret_cast<f32x4*>(c.lds + 64 * pitch + (c.tid << 2)) = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
+struct C8Keep { float keep[4], keep2[4]; };
+
+// An op's thread indices pass through an empty asm: everything derived from them is recomputed inside the op.  Without it the
+// compiler hoists every op's loop-invariant address arithmetic (hundreds of per-thread LDS offsets) in front of the op loop and
+// spills it (200 registers of scratch at the 128 a 1024-thread workgroup leaves each thread).
+__device__ __forceinline__ int c8_fresh(int v) { asm volatile("" : "+v"(v)); return v; }
+
+// the end of an 8x8 op: matrix-wave thread (tile tt = tid / 32, channel col = tid % 32) holds y[k], k = 2 dy + dx of its tile's 2 x 2
+// pixels.  A quad's lanes hold four consecutive channels: sixteen DPP moves give every lane all of the quad's values, lane j of the
+// quad stores pixel j's four channels as 16 bytes.  Publishing as in chain_finish (waves 0..7 store and count themselves in).
+__device__ __forceinline__ void c8_finish(const ChainParams& p, const ChainOp& o, ChainCtx& c, C8Keep& kp, float (&y)[4], int n0) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (o.flags & CHF_ADD_KEEP) y[k] += kp.keep[k];
+        if (o.flags & CHF_ADD_KEEP2) y[k] += kp.keep2[k];
+        if (o.flags & CHF_SAVE_KEEP) kp.keep[k] = y[k];
+        if (o.flags & CHF_SAVE_KEEP2) kp.keep2[k] = y[k];
+    }
+    if (!(o.flags & CHF_NO_OUT)) {
+        float g[4][4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int yb = __builtin_bit_cast(int, y[k]);
+            g[k][0] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, yb, 0x00, 0xF, 0xF, true));
+            g[k][1] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, yb, 0x55, 0xF, 0xF, true));
+            g[k][2] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, yb, 0xAA, 0xF, 0xF, true));
+            g[k][3] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, yb, 0xFF, 0xF, 0xF, true));
+        }
+        const int j = c.lane & 3;
+        f32x4 v;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = j == 0 ? g[0][q] : j == 1 ? g[1][q] : j == 2 ? g[2][q] : g[3][q];
+        const int tt = c.tid >> 5, ty = tt >> 2, tx = tt & 3;
+        const int pix = (2 * ty + (j >> 1)) * 8 + 2 * tx + (j & 1);
+        float* dst = o.out + ((long long)c.b * 64 + pix) * o.n_out + n0 + ((c.tid & 31) & ~3);
+        if (o.flags & CHF_SIGNAL) st_sc1(dst, v);
+        else *reinterpret_cast<f32x4*>(dst) = v;
+    }
+    if (o.flags & CHF_SIGNAL) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (c.lane == 0) {
+            unsigned* lcnt = reinterpret_cast<unsigned*>(c.misc) + 1;
+            if ((atomicAdd(lcnt, 1u) & 7u) == 7u) __hip_atomic_fetch_add(p.cnt + c.b * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+__device__ __forceinline__ void c8_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// CH_CONV3 on an 8x8 map: Winograd, see the section header.  cin = 256, or 512 as two staged halves.
+__device__ __forceinline__ void c8_conv3(const ChainParams& p, const ChainOp& o, ChainCtx& c, C8Keep& kp) {
+    float* lds = c.lds;
+    const int tid = c.tid, lane = c.lane, wave = c.wave;
+    const int m = lane & 15, kq = lane >> 4;
+    const int n0 = c.nt << 5;
+    const int cin = o.c0 + o.c1, nch = cin >> 5, halves = cin >> 8;
+    float* V = lds + L8_V;
+    const bool matrix = wave < 8;
+
+    // ---- before the wait: the first two chunks' filter units (matrix waves), the tail's operands, the next op's filter into L2
+    const float* wl = o.w + ((size_t)c.nt * nch * 16 + 2 * (wave & 7)) * 1024 + lane * 4;
+    float4 bA[2][2][2], bB[2][2][2];            // [position of the pair][n block][k half]
+    auto load_b = [&](int chunk, float4 (&bq)[2][2][2]) {
+        chunk = chunk < nch ? chunk : nch - 1;  // past the end: harmless re-read, no load under a condition
+        const float* wp = wl + (size_t)chunk * 16 * 1024;
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp) {
+            bq[pp][0][0] = *reinterpret_cast<const float4*>(wp + pp * 1024);
+            bq[pp][0][1] = *reinterpret_cast<const float4*>(wp + pp * 1024 + 256);
+            bq[pp][1][0] = *reinterpret_cast<const float4*>(wp + pp * 1024 + 512);
+            bq[pp][1][1] = *reinterpret_cast<const float4*>(wp + pp * 1024 + 768);
+        }
+    };
+    const int tt = (tid >> 5) & 15, col = tid & 31, ch = n0 + col;
+    const int tty = tt >> 2, ttx = tt & 3;
+    float ga = 1.f, be = 0.f, sh = 0.f, cb = 0.f;
+    if (matrix) {
+        load_b(0, bA);
+        load_b(1, bB);
+        ga = o.gamma[ch]; be = o.beta[ch];
+        if (o.temb_off >= 0) {
+            const long long tr = p.temb_rows ? p.temb_rows[c.b] : c.b;
+            sh = p.temb[tr * p.temb_stride + o.temb_off + ch];
+        }
+        if (o.bias) cb = o.bias[ch];
+        if (o.flags & CHF_KEEP_FROM_SRC) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                kp.keep[k] = o.src0[((long long)c.b * 64 + (2 * tty + (k >> 1)) * 8 + 2 * ttx + (k & 1)) * o.c0 + ch];
+        }
+    }
+    if (c.k + 1 < p.n_ops) chain_prefetch(p.op[c.k + 1], c);
+
+    LC_STAMP(c, c.k, 0);
+    if (o.flags & CHF_WAIT) chain_wait(p, c);
+    else __syncthreads();
+    LC_STAMP(c, c.k, 1);
+
+    f32x4 acc[2][2];
+    acc[0][0] = acc[0][1] = acc[1][0] = acc[1][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // The two roles walk the same barriers (stage, one per chunk) in two separate loops: in one loop the register allocator would
+    // keep both roles' state alive in every wave (348 spilled registers at the 128 a 1024-thread workgroup leaves each thread).
+    if (!matrix) {
+        // transform waves: thread = (tile t2 / 32, position row i = (t2 / 8) % 4, channel quad t2 % 8) -- conv3x3_gn_wlocal_kernel's item
+        const int t2 = tid - 512;
+        const int ftt = (t2 >> 5) & 15, ri = (t2 >> 3) & 3, q4i = t2 & 7;
+        const int fty = ftt >> 2, ftx = ftt & 3;
+        const int row_a = ri == 0 ? 0 : ri == 2 ? 2 : 1, row_b = ri == 0 ? 2 : ri == 1 ? 2 : ri == 2 ? 1 : 3;
+        int poff[8];
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int yy = 2 * fty - 1 + (hh == 0 ? row_a : row_b), xx = 2 * ftx - 1 + j;
+                const bool ok = (unsigned)yy < 8u && (unsigned)xx < 8u;
+                poff[hh * 4 + j] = (ok ? yy * 8 + xx : 64) * L8_P + q4i * 4;
+            }
+        const int voff = (4 * ri * 16 + ftt) * L8_VP + q4i * 4;
+        const float sgn = ri == 1 ? 1.0f : -1.0f;
+        auto f4 = [](const float* q) { return *reinterpret_cast<const float4*>(q); };
+        auto sub4 = [](float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); };
+        auto add4 = [](float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); };
+        auto transform = [&](int lchunk, int buf) {       // lchunk: chunk inside the staged half
+            float4 r[4];
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                const float4 a = f4(lds + poff[x] + (lchunk << 5)), b = f4(lds + poff[4 + x] + (lchunk << 5));
+                r[x] = make_float4(fmaf(sgn, b.x, a.x), fmaf(sgn, b.y, a.y), fmaf(sgn, b.z, a.z), fmaf(sgn, b.w, a.w));
+            }
+            float* vb = V + buf * L8_VBUF + voff;
+            *reinterpret_cast<float4*>(vb + 0 * (16 * L8_VP)) = sub4(r[0], r[2]);
+            *reinterpret_cast<float4*>(vb + 1 * (16 * L8_VP)) = add4(r[1], r[2]);
+            *reinterpret_cast<float4*>(vb + 2 * (16 * L8_VP)) = sub4(r[2], r[1]);
+            *reinterpret_cast<float4*>(vb + 3 * (16 * L8_VP)) = sub4(r[1], r[3]);
+        };
+        for (int hf = 0; hf < halves; ++hf) {
+            if (hf > 0) __syncthreads();                   // every reader of the first half's image and V buffers is through
+            c8_stage(o, c, hf << 8, 256);
+            __syncthreads();
+            const int c0 = hf << 3;                        // first chunk of this half
+            __builtin_amdgcn_s_setprio(3);
+            transform(0, c0 & 1);
+#pragma unroll 1
+            for (int lc = 0; lc < 8; ++lc) {
+                c8_lds_barrier();                          // V[(c0 + lc) & 1] complete, the other buffer consumed
+                if (lc + 1 < 8) transform(lc + 1, (c0 + lc + 1) & 1);
+            }
+            __builtin_amdgcn_s_setprio(0);
+        }
+    } else {
+        auto chunk_mfma = [&](int chunk, const float4 (&bq)[2][2][2]) {
+            const float* vb = V + (chunk & 1) * L8_VBUF + ((2 * wave) * 16 + m) * L8_VP + kq * 8;
+#pragma unroll
+            for (int pp = 0; pp < 2; ++pp) {
+                const float4 a0 = *reinterpret_cast<const float4*>(vb + pp * (16 * L8_VP)), a1 = *reinterpret_cast<const float4*>(vb + pp * (16 * L8_VP) + 4);
+                const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) {
+                    acc[pp][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kk], reinterpret_cast<const float*>(&bq[pp][0][0])[kk], acc[pp][0], 0, 0, 0);
+                    acc[pp][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kk], reinterpret_cast<const float*>(&bq[pp][1][0])[kk], acc[pp][1], 0, 0, 0);
+                }
+            }
+        };
+        for (int hf = 0; hf < halves; ++hf) {
+            if (hf > 0) __syncthreads();
+            c8_stage(o, c, hf << 8, 256);
+            __syncthreads();
+            if (hf == 0) LC_STAMP(c, c.k, 2);
+            const int c0 = hf << 3;
+#pragma unroll 1
+            for (int lc = 0; lc < 8; lc += 2) {       // (not unrolled: with all eight chunks' loads hoisted the matrix waves spill)
+                c8_lds_barrier();
+                chunk_mfma(c0 + lc, bA);
+                load_b(c0 + lc + 2, bA);
+                c8_lds_barrier();
+                chunk_mfma(c0 + lc + 1, bB);
+                load_b(c0 + lc + 3, bB);
+            }
+        }
+    }
+    LC_STAMP(c, c.k, 3);
+
+    // ---- M[position][tile][n] of the 8 matrix waves into LDS (over the V buffers), output transform, GroupNorm, finish
+    __syncthreads();
+    if (matrix) {
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) V[((2 * wave + pp) * 16 + kq * 4 + r) * L8_VP + nb * 16 + m] = acc[pp][nb][r];
+    }
+    __syncthreads();
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    float* red = lds + L8_RED;
+    if (matrix) {
+        float mm[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) mm[k] = V[(k * 16 + tt) * L8_VP + col];
+        float t0[4], t1[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            t0[j] = (mm[0 + j] + mm[4 + j]) + mm[8 + j];
+            t1[j] = (mm[4 + j] - mm[8 + j]) - mm[12 + j];
+        }
+        v[0] = ((t0[0] + t0[1]) + t0[2]) + cb;
+        v[1] = ((t0[1] - t0[2]) - t0[3]) + cb;
+        v[2] = ((t1[0] + t1[1]) + t1[2]) + cb;
+        v[3] = ((t1[1] - t1[2]) - t1[3]) + cb;
+        // GroupNorm of the slice (32 channels x 64 pixels = the 8 matrix waves' 2048 values): per wave {mean, M2} of its 256, merged exactly
+        const float mw = wave_sum_dpp((v[0] + v[1]) + (v[2] + v[3])) * (1.0f / 256.0f);
+        float q = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) q += (v[k] - mw) * (v[k] - mw);
+        const float m2w = wave_sum_dpp(q);
+        if (lane == 0) { red[2 * wave] = mw; red[2 * wave + 1] = m2w; }
+    }
+    __syncthreads();
+    if (matrix) {
+        float msum = red[0], m2 = red[1];
+#pragma unroll
+        for (int w = 1; w < 8; ++w) { msum += red[2 * w]; m2 += red[2 * w + 1]; }
+        const float mean = msum * 0.125f;
+        float dev = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) { const float dm = red[2 * w] - mean; dev += dm * dm; }
+        const float var = (m2 + 256.0f * dev) * (1.0f / 2048.0f);
+        const float rstd = 1.0f / sqrtf(var + p.gn_eps);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = mish_f((v[k] - mean) * rstd * ga + be) + sh;
+        c8_finish(p, o, c, kp, v, n0);
+    }
+    if (o.flags & CHF_SIGNAL) ++c.signals;
+    LC_STAMP(c, c.k, 4);
+}
+
+// CH_CONV1 on an 8x8 map: [64 x cin] x [cin x 32] direct on the matrix waves, wave w = chunks w, w + 8, ...; four 16-row M blocks per
+// wave, partial tiles [wave][64][36] meet in the V buffers
+__device__ __forceinline__ void c8_conv1(const ChainParams& p, const ChainOp& o, ChainCtx& c, C8Keep& kp) {
+    float* lds = c.lds;
+    const int tid = c.tid, lane = c.lane, wave = c.wave;
+    const int m = lane & 15, kq = lane >> 4;
+    const int n0 = c.nt << 5;
+    const int cin = o.c0 + o.c1, nch = cin >> 5, halves = cin > 256 ? 2 : 1, hcols = cin > 256 ? 256 : cin, hch = hcols >> 5;
+    const bool matrix = wave < 8;
+    float* V = lds + L8_V;
+    const float* wl = o.w + (size_t)c.nt * nch * 1024 + lane * 4;
+    const int tt = (tid >> 5) & 15, col = tid & 31, ch = n0 + col;
+    float cb = 0.f;
+    if (matrix && o.bias) cb = o.bias[ch];
+    if (c.k + 1 < p.n_ops) chain_prefetch(p.op[c.k + 1], c);
+    LC_STAMP(c, c.k, 0);
+    if (o.flags & CHF_WAIT) chain_wait(p, c);
+    else __syncthreads();
+    LC_STAMP(c, c.k, 1);
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i][0] = acc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int hf = 0; hf < halves; ++hf) {
+        if (hf > 0) __syncthreads();
+        c8_stage(o, c, hf << 8, hcols);
+        __syncthreads();
+        if (hf == 0) LC_STAMP(c, c.k, 2);
+        if (matrix) {
+            const int pitch = hcols + 4;
+            for (int lc = wave; lc < hch; lc += 8) {
+                const float* wp = wl + (size_t)(hf * 8 + lc) * 1024;
+                const float4 b00 = *reinterpret_cast<const float4*>(wp), b01 = *reinterpret_cast<const float4*>(wp + 256);
+                const float4 b10 = *reinterpret_cast<const float4*>(wp + 512), b11 = *reinterpret_cast<const float4*>(wp + 768);
+                const float bv0[8] = {b00.x, b00.y, b00.z, b00.w, b01.x, b01.y, b01.z, b01.w};
+                const float bv1[8] = {b10.x, b10.y, b10.z, b10.w, b11.x, b11.y, b11.z, b11.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float* ap = lds + (i * 16 + m) * pitch + (lc << 5) + kq * 8;
+                    const float4 a0 = *reinterpret_cast<const float4*>(ap), a1 = *reinterpret_cast<const float4*>(ap + 4);
+                    const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+                    for (int kk = 0; kk < 8; ++kk) {
+                        acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kk], bv0[kk], acc[i][0], 0, 0, 0);
+                        acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kk], bv1[kk], acc[i][1], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    LC_STAMP(c, c.k, 3);
+    if (matrix) {     // the V buffers are free: nobody reads them in this op
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) V[(wave * 64 + i * 16 + kq * 4 + r) * LC_PP + nb * 16 + m] = acc[i][nb][r];
+    }
+    __syncthreads();
+    if (matrix) {
+        const int tty = tt >> 2, ttx = tt & 3;
+        float y[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int row = (2 * tty + (k >> 1)) * 8 + 2 * ttx + (k & 1);
+            float sacc = V[row * LC_PP + col];
+#pragma unroll
+            for (int w = 1; w < 8; ++w) sacc += V[(w * 64 + row) * LC_PP + col];
+            y[k] = sacc + cb;
+        }
+        c8_finish(p, o, c, kp, y, n0);
+    }
+    if (o.flags & CHF_SIGNAL) ++c.signals;
+    LC_STAMP(c, c.k, 4);
+}
+
+// CH_ATTN on an 8x8 map: head h = nt < 4.  Projection [64 x C] x [C x 96] on the matrix waves (wave w: M block w % 4, chunks of K half
+// w / 4), softmax over the 64 pixels, context, apply -- linattn_small_qkv_kernel<4>'s arithmetic on 1024 threads.
+__device__ __forceinline__ void c8_attn(const ChainParams& p, const ChainOp& o, ChainCtx& c, C8Keep& kp) {
+    float* lds = c.lds;
+    const int tid = c.tid, lane = c.lane, wave = c.wave;
+    if (c.k + 1 < p.n_ops) chain_prefetch(p.op[c.k + 1], c);
+    if (c.k + 2 < p.n_ops) chain_prefetch(p.op[c.k + 2], c);
+    if (c.nt < 4) {
+        const int h = c.nt;
+        const int m = lane & 15, kq = lane >> 4;
+        const int C = o.c0, nch = C >> 5;
+        const bool matrix = wave < 8;
+        float* xs = lds;
+        float* ks = lds + L8_KS;
+        float* vs = lds + L8_VS;
+        float* qs = lds + L8_QS;
+        float* cs = lds + L8_CS;
+        float* smax = lds + L8_SMAX;
+        float* rowstat = lds + L8_ROWSTAT;
+        float* cfold = lds + L8_CFOLD;
+        const float* wl = o.w + (size_t)h * nch * 3072 + lane * 4;
+        if (tid < 192) {
+            const int n = tid % 96;
+            const int colw = (n >> 5) * 128 + h * 32 + (n & 31);
+            cfold[tid] = tid < 96 ? o.gamma[colw] : o.beta[colw];
+        }
+        LC_STAMP(c, c.k, 0);
+        if (o.flags & CHF_WAIT) chain_wait(p, c);
+        else __syncthreads();
+        LC_STAMP(c, c.k, 1);
+        c8_stage(o, c, 0, C);
+        __syncthreads();
+        LC_STAMP(c, c.k, 2);
+        {   // LayerNorm statistics of the 64 pixel rows: 16 threads per row, two passes over the resident row
+            const int row = tid >> 4, sub = tid & 15;
+            float s1 = 0.f;
+            for (int chn = sub * 4; chn < C; chn += 64) {
+                const float4 v = *reinterpret_cast<const float4*>(xs + row * L8_P + chn);
+                s1 += (v.x + v.y) + (v.z + v.w);
+            }
+#pragma unroll
+            for (int of = 1; of < 16; of <<= 1) s1 += __shfl_xor(s1, of, 64);
+            const float inv_c = 1.0f / (float)C;
+            const float mean = s1 * inv_c;
+            float s2 = 0.f;
+            for (int chn = sub * 4; chn < C; chn += 64) {
+                const float4 v = *reinterpret_cast<const float4*>(xs + row * L8_P + chn);
+                const float a0 = v.x - mean, a1 = v.y - mean, a2 = v.z - mean, a3 = v.w - mean;
+                s2 += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+            }
+#pragma unroll
+            for (int of = 1; of < 16; of <<= 1) s2 += __shfl_xor(s2, of, 64);
+            if (sub == 0) {
+                const float r = 1.0f / (sqrtf(s2 * inv_c) + p.ln_eps);
+                rowstat[2 * row] = r;
+                rowstat[2 * row + 1] = r * mean;
+            }
+        }
+        f32x4 acc[6];
+#pragma unroll
+        for (int nb = 0; nb < 6; ++nb) acc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int mb = wave & 3, khalf = (wave >> 2) & 1;
+        if (matrix) {
+            for (int chunk = khalf; chunk < nch; chunk += 2) {
+                const float* wp = wl + (size_t)chunk * 3072;
+                const float* ap = xs + (mb * 16 + m) * L8_P + (chunk << 5) + kq * 8;
+                const float4 a0 = *reinterpret_cast<const float4*>(ap), a1 = *reinterpret_cast<const float4*>(ap + 4);
+                const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+                for (int nb = 0; nb < 6; ++nb) {
+                    const float4 b0 = *reinterpret_cast<const float4*>(wp + nb * 512), b1 = *reinterpret_cast<const float4*>(wp + nb * 512 + 256);
+                    const float bv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+                    for (int kk = 0; kk < 8; ++kk) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kk], bv[kk], acc[nb], 0, 0, 0);
+                    if (nb == 2) __builtin_amdgcn_sched_barrier(0);     // three n blocks' filter fragments in flight, not six
+                }
+            }
+        }
+        LC_STAMP(c, c.k, 3);
+        __syncthreads();                                    // image consumed, rowstat written
+        if (matrix) {
+#pragma unroll
+            for (int nb = 0; nb < 6; ++nb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) xs[(khalf * 64 + mb * 16 + kq * 4 + r) * LC_QP + nb * 16 + m] = acc[nb][r];
+        }
+        __syncthreads();
+        for (int e = tid; e < 64 * 96; e += 1024) {
+            const int row = e / 96, n = e - row * 96;
+            const float sacc = xs[row * LC_QP + n] + xs[(64 + row) * LC_QP + n];
+            const float v = rowstat[2 * row] * sacc - rowstat[2 * row + 1] * cfold[n] + cfold[96 + n];
+            const int sel = n >> 5, d = n & 31;
+            if (sel == 0) qs[row * 33 + d] = v;
+            else if (sel == 1) ks[row * 32 + d] = v;
+            else vs[row * 32 + d] = v;
+        }
+        __syncthreads();
+        if (tid < 256) {     // column maxima of k over the 64 pixels: 8 row groups, then 8 -> 1
+            const int d = tid & 31, ng = tid >> 5;
+            float mx = ks[(ng * 8) * 32 + d];
+#pragma unroll
+            for (int n = 1; n < 8; ++n) mx = fmaxf(mx, ks[(ng * 8 + n) * 32 + d]);
+            smax[ng * 32 + d] = mx;
+        }
+        __syncthreads();
+        if (tid < 32) {
+            float mx = smax[tid];
+#pragma unroll
+            for (int j = 1; j < 8; ++j) mx = fmaxf(mx, smax[j * 32 + tid]);
+            smax[256 + tid] = mx;
+        }
+        __syncthreads();
+        ks[tid] = __expf(ks[tid] - smax[256 + (tid & 31)]);
+        ks[tid + 1024] = __expf(ks[tid + 1024] - smax[256 + (tid & 31)]);
+        __syncthreads();
+        {   // ctx[d][e] = sum_n p[n][d] v[n][e] / sum_n p[n][d]: one output per thread
+            const int d = tid >> 5, e = tid & 31;
+            float a = 0.f, den = 0.f;
+#pragma unroll 4
+            for (int n = 0; n < 64; ++n) {
+                const float kd = ks[n * 32 + d];
+                a += kd * vs[n * 32 + e];
+                den += kd;
+            }
+            cs[d * 36 + e] = a * (1.0f / den);
+        }
+        __syncthreads();
+        if (matrix) {
+            const int tt = (tid >> 5) & 15, e = tid & 31;
+            const int tty = tt >> 2, ttx = tt & 3;
+            float y[4] = {0.f, 0.f, 0.f, 0.f};
+            const int r00 = (2 * tty) * 8 + 2 * ttx;
+#pragma unroll 4
+            for (int d = 0; d < 32; ++d) {
+                const float cv = cs[d * 36 + e];
+                y[0] += qs[r00 * 33 + d] * cv;
+                y[1] += qs[(r00 + 1) * 33 + d] * cv;
+                y[2] += qs[(r00 + 8) * 33 + d] * cv;
+                y[3] += qs[(r00 + 9) * 33 + d] * cv;
+            }
+            c8_finish(p, o, c, kp, y, h * 32);
+        }
+    } else {
+        if (o.flags & CHF_WAIT) chain_wait(p, c);        // see chain_attn: no arrival for this op before every arrival of the one before
+        if ((o.flags & CHF_SIGNAL) && tid == 0) __hip_atomic_fetch_add(p.cnt + c.b * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (o.flags & CHF_SIGNAL) ++c.signals;
+    LC_STAMP(c, c.k, 4);
+}
+
+__global__ __launch_bounds__(1024) void level8_chain_kernel(const ChainParams p) {
+    extern __shared__ __align__(16) float lds[];
+    ChainCtx c;
+    c.lds = lds;
+    c.tid = threadIdx.x;
+    c.lane = c.tid & 63;
+    c.wave = __builtin_amdgcn_readfirstlane(c.tid >> 6);
+    c.nt = blockIdx.x & 7;
+    c.misc = lds + L8_MISC;
+    c.pf_dst = (unsigned)(size_t)(__attribute__((address_space(3))) float*)(lds + L8_PF);
+    c.nwaves = 16;
+    c.units3 = 16;
+    c.watch = blockIdx.x == 0 ? 0 : blockIdx.x == 100 ? 1 : blockIdx.x == 255 ? 2 : -1;
+    c.k = 0;
+    c.keep = c.keep2 = 0.f;
+    if (c.tid == 0) { *reinterpret_cast<int*>(c.misc) = 0; reinterpret_cast<unsigned*>(c.misc)[1] = 0u; }
+    __syncthreads();
+    const int slots = gridDim.x >> 3;
+    c.slot = blockIdx.x >> 3;
+    c.slots = slots;
+    for (int b = blockIdx.x >> 3; b < p.B; b += slots) {
+        c.b = b;
+        c.signals = 0;
+        C8Keep kp;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) kp.keep[k] = kp.keep2[k] = 0.f;
+        chain_prefetch(p.op[0], c);
+        for (int k = 0; k < p.n_ops; ++k) {
+            const ChainOp& o = p.op[k];
+            c.k = k;
+            c.tid = c8_fresh(c.tid);
+            c.lane = c.tid & 63;
+            c.wave = __builtin_amdgcn_readfirstlane(c.tid >> 6);
+            if (o.kind == CH_ATTN) c8_attn(p, o, c, kp);
+            else if (o.kind == CH_CONV1) c8_conv1(p, o, c, kp);
+            else c8_conv3(p, o, c, kp);
+        }
+        __syncthreads();
+        if (c.tid == 0) {
+            const unsigned prev = __hip_atomic_fetch_add(p.done + b * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (prev == 7u) {
+                __hip_atomic_store(p.cnt + b * 32, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(p.done + b * 32, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+}
+
 bool level_chain_device_ok() { return conv_wino_cluster_device_ok(); }
 
 int level_chain_init_device() {
     DDK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(level_chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    DDK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(level8_chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     return DDK_OK;
 }
 
 int level_chain_launch(const ChainParams& p, hipStream_t st) {
-    DDK_REQUIRE(p.n_ops > 0 && p.n_ops <= CH_MAX_OPS && p.B > 0 && p.cnt && p.done && p.fail, "level_chain: arguments");
+    DDK_REQUIRE(p.n_ops > 0 && p.n_ops <= CH_MAX_OPS && p.B > 0 && p.cnt && p.done && p.fail && (p.hw == 16 || p.hw == 64), "level_chain: arguments");
     for (int k = 0; k < p.n_ops; ++k) {
         const ChainOp& o = p.op[k];
         const int cin = o.c0 + o.c1;
         DDK_REQUIRE(o.src0 && o.w && aligned16(o.src0) && aligned16(o.src1) && aligned16(o.w) && aligned16(o.out), "level_chain: op pointers");
         DDK_REQUIRE((cin == 128 || cin == 256 || cin == 512) && o.c0 % 4 == 0 && o.c1 % 4 == 0 && (o.c1 == 0 || o.src1), "level_chain: op channels");
+        if (p.hw == 64) {
+            DDK_REQUIRE(o.kind != CH_CONV3 || cin == 256 || (cin == 512 && o.c0 == 256), "level_chain: 8x8 conv3x3 takes 256 channels, or 256 + 256");
+            DDK_REQUIRE(o.kind != CH_CONV1 || cin == 128 || cin == 256 || (cin == 512 && o.c0 == 256), "level_chain: 8x8 conv1x1 channels");
+            DDK_REQUIRE(o.kind != CH_ATTN || cin == 256, "level_chain: 8x8 attention takes 256 channels");
+        }
         DDK_REQUIRE((o.flags & CHF_NO_OUT) || o.out, "level_chain: op output");
         if (o.kind == CH_ATTN) DDK_REQUIRE(o.c1 == 0 && o.n_out == 128 && o.gamma && o.beta, "level_chain: attention op");
         else DDK_REQUIRE(o.n_out == 256 && (o.kind != CH_CONV3 || (o.gamma && o.beta)), "level_chain: conv op (8 slices of 32 channels)");
     }
     DDK_TRY(ensure_device_init());
     const int slots = p.B < 32 ? p.B : 32;
+    if (p.hw == 64) {
+        hipLaunchKernelGGL(level8_chain_kernel, dim3(8 * slots), dim3(1024), (size_t)L8_FLOATS * 4, st, p);
+        return check_launch("level8_chain_kernel");
+    }
     hipLaunchKernelGGL(level_chain_kernel, dim3(8 * slots), dim3(512), level_chain_lds_bytes(), st, p);
     return check_launch("level_chain_kernel");
 }
 
 }  // namespace ddk
+
+// A level chain from a caller-made op list (tests/test_level_chain_gpu.py drives single ops and short chains of both kernels against
+// the stand-alone kernels they replace).  ops: n records laid out like ddk::ChainOp (7 pointers, 6 ints); counters: 64 * B + 16 zeroed
+// words of device memory ([B] arrivals, [B] departures, 32 words apart, then the give-up word).  Not part of the product surface.
+extern "C" int ddk_debug_level_chain(const void* ops, int n, int hw, int B, const float* temb, int temb_stride, void* counters, ddk_stream_t s) {
+    using namespace ddk;
+    DDK_REQUIRE(ops && n > 0 && n <= CH_MAX_OPS && counters, "debug_level_chain: arguments");
+    if (!level_chain_device_ok()) return fail_arg("debug_level_chain: needs a whole MI355X");
+    ChainParams p{};
+    const ChainOp* src = static_cast<const ChainOp*>(ops);
+    for (int i = 0; i < n; ++i) p.op[i] = src[i];
+    p.n_ops = n;
+    p.B = B;
+    p.hw = hw;
+    p.temb = temb;
+    p.temb_rows = nullptr;
+    p.temb_stride = temb_stride;
+    p.cnt = static_cast<unsigned*>(counters);
+    p.done = p.cnt + (size_t)B * 32;
+    p.fail = p.cnt + (size_t)B * 64;
+    p.gn_eps = 1e-5f;
+    p.ln_eps = 1e-5f;
+    return level_chain_launch(p, as_stream(s));
+}
 
 #ifdef DDK_TUNING
 extern "C" int ddk_debug_read_lc_stamps(unsigned long long* host_out) {   // tuning build only (not in include/ddk.h)

@@ -107,8 +107,9 @@ struct ddk_unet {
     bool fold_down_reduce = false;           // Downsample conv's split-K slabs summed by the image-local ResnetBlock behind it (no reduce launch).
                                              // OFF by default: measured 6 us per step SLOWER (each of an image's eight workgroups re-sums the slabs:
                                              // +6.3 / +5.9 us on the two consumers against reduce launches of 5.2 / 4.9 us; tools/fold_ab.py)
-    bool level_chain = true;                 // the whole 4x4 level (ResnetBlocks + attention of downs[-1], mid, ups[0]) as ONE persistent launch
-                                             // (level_chain.hip) wherever the in-launch GroupNorm may run (its workgroups wait for each other too)
+    int level_chain = 7;                     // bit 0: the whole 4x4 level (ResnetBlocks + attention of downs[-1], mid, ups[0]) as ONE persistent launch
+                                             // (level_chain.hip) wherever the in-launch GroupNorm may run (its workgroups wait for each other too);
+                                             // bits 1, 2: the two 8x8 levels (downs[-2]; ups[1]) likewise, one launch each
     bool attn_fold = true;                   // attention on maps with HW > 256, C = 128: q projection + apply + to_out as ONE per-image C x C conv
     // unet_chan % 8 == 0 but not % 32 (reference blocks.py:75 takes any GroupNorm(8, C)): every tensor keeps a pitch of pad32(C) channels
     // with zero padding, the convs run on the generic im2col kernels over zero-padded weights and the normalisations on their
@@ -175,7 +176,7 @@ struct ddk_unet {
             c.wl = alloc((size_t)9 * cout * c.cin_pad);
             c.has_wl = true;
             slots.push_back(Slot{prefix + "weight", (long long)cout * cin * k * k, PK_LOCAL, c.wl, cout, cin, k, k, c.cin_pad, 0, 0});
-            if (c.cin_pad <= 320) {
+            if (c.cin_pad <= 320 || c.cin_pad == 512) {     // (512: the 8x8 level chain walks the concat input as two staged halves)
                 c.wwl = alloc((size_t)16 * cout * c.cin_pad);
                 c.has_wwl = true;
                 slots.push_back(Slot{prefix + "weight", (long long)cout * cin * k * k, PK_WLOCAL, c.wwl, cout, cin, k, k, c.cin_pad, 0, 0});
@@ -431,7 +432,8 @@ extern "C" int ddk_unet_set_option(ddk_unet* u, int option, int value) {
         std::lock_guard<std::mutex> lock(u->mu);
         if (!u->graphs.empty()) DDK_HIP(hipDeviceSynchronize());
         drop_graphs(u);
-        u->level_chain = value != 0;
+        // 0 off, 1 all, 2: the 4x4 level only, 4: the 8x8 levels only, 8 / 16: only downs[-2] / only ups[1] of them (diagnostics)
+        u->level_chain = value == 1 ? 7 : value == 2 ? 1 : value == 4 ? 6 : value == 8 ? 2 : value == 16 ? 4 : value != 0 ? 7 : 0;
         return DDK_OK;
     }
     if (option == DDK_OPT_FOLD_DOWNSAMPLE_REDUCE) {
@@ -587,6 +589,7 @@ static size_t cl_counter_floats(int B) { return (size_t)B * 8 * 16 + 16 + (size_
 static size_t cl_fail_offset(int B) { return (size_t)B * 8 * 16; }
 static size_t cl_chain_offset(int B) { return (size_t)B * 8 * 16 + 16; }
 constexpr int CHAIN_BUFS = 16;                // activations that cross workgroups inside the level chain, [B][16][256] each
+constexpr int CHAIN8_BUFS = 5;                // ... inside an 8x8 chain, [B][64][256] each
 
 static void res_sizes(const ResW& r, int B, int H, int W, Layout& ly) {
     const size_t M = (size_t)B * H * W;
@@ -613,17 +616,31 @@ static void attn_sizes(const AttnW& a, int B, int H, int W, Layout& ly) {
 
 // The level chain (level_chain.hip) takes the last level when it is a 4x4 map of 256 channels whose neighbours are 256 wide too (cfg1,
 // cfg2, cfg4): ResnetBlocks without a skip conv on the way down and in the middle, one 512 -> 256 ResnetBlock on the way up.
+static bool chain_plain(const ResW& r, bool wino) {
+    return r.ci == 256 && r.co == 256 && !r.has_res && r.c1.has_bias && r.c2.has_bias && (wino ? r.c1.has_wwl && r.c2.has_wwl : r.c1.has_wl && r.c2.has_wl);
+}
+static bool chain_att(const AttnW& a) { return a.c == 256 && a.out.has_wl1 && a.out.has_bias; }
+static bool chain_cat(const ResW& r, bool wino) {
+    return r.ci == 512 && r.ci_pad == 512 && r.co == 256 && r.has_res && r.res.has_wl1 && r.res.has_bias && r.c1.cin_pad == 512 && r.c1.has_bias &&
+           r.c2.has_bias && (wino ? r.c1.has_wwl && r.c2.has_wwl : r.c1.has_wl && r.c2.has_wl);
+}
 static bool level_chain_shape_ok(const ddk_unet& u, int H0, int W0) {
     if (u.generic || u.L < 2) return false;
     const int sh = u.L - 1;
     if ((H0 >> sh) != 4 || (W0 >> sh) != 4 || (H0 & ((1 << sh) - 1)) || (W0 & ((1 << sh) - 1))) return false;
     if (u.dimp[u.L] != 256 || u.dimp[u.L - 1] != 256 || GROUPS != 8) return false;
-    auto plain = [](const ResW& r) { return r.ci == 256 && r.co == 256 && !r.has_res && r.c1.has_wl && r.c2.has_wl && r.c1.has_bias && r.c2.has_bias; };
-    auto att = [](const AttnW& a) { return a.c == 256 && a.out.has_wl1 && a.out.has_bias; };
-    const ResW& u0 = u.up_res[0];
-    return plain(u.down_res[2 * sh]) && plain(u.down_res[2 * sh + 1]) && plain(u.mid1) && plain(u.mid2) && plain(u.up_res[1]) &&
-           att(u.down_attn[sh]) && att(u.mid_attn) && att(u.up_attn[0]) && u0.ci == 512 && u0.ci_pad == 512 && u0.co == 256 && u0.has_res &&
-           u0.res.has_wl1 && u0.res.has_bias && u0.c1.has_wl && u0.c2.has_wl && u0.c1.cin_pad == 512;
+    return chain_plain(u.down_res[2 * sh], false) && chain_plain(u.down_res[2 * sh + 1], false) && chain_plain(u.mid1, false) &&
+           chain_plain(u.mid2, false) && chain_plain(u.up_res[1], false) && chain_att(u.down_attn[sh]) && chain_att(u.mid_attn) &&
+           chain_att(u.up_attn[0]) && chain_cat(u.up_res[0], false);
+}
+// ... and the level above it when that is an 8x8 map of 256 channels between 256-wide neighbours (cfg4: downs[2] and ups[1])
+static bool level8_chain_shape_ok(const ddk_unet& u, int H0, int W0) {
+    if (u.generic || u.L < 3) return false;
+    const int sh = u.L - 2;
+    if ((H0 >> sh) != 8 || (W0 >> sh) != 8 || (H0 & ((1 << sh) - 1)) || (W0 & ((1 << sh) - 1))) return false;
+    if (u.dimp[sh + 1] != 256 || u.dimp[sh] != 256 || u.dimp[sh + 2] != 256 || GROUPS != 8) return false;
+    return chain_plain(u.down_res[2 * sh], true) && chain_plain(u.down_res[2 * sh + 1], true) && chain_att(u.down_attn[sh]) &&
+           chain_cat(u.up_res[2], true) && chain_plain(u.up_res[3], true) && chain_att(u.up_attn[1]);
 }
 
 static Layout make_layout(const ddk_unet& u, int B, int H0, int W0) {
@@ -663,6 +680,7 @@ static Layout make_layout(const ddk_unet& u, int B, int H0, int W0) {
     ly.act = al4(ly.act); ly.qkv = al4(ly.qkv); ly.o = al4(ly.o); ly.ctx = al4(ly.ctx);
     ly.splitk = al4(ly.splitk); ly.gn_ws = al4(ly.gn_ws); ly.cl = al4(ly.cl);
     if (level_chain_shape_ok(u, H0, W0)) ly.chain = (size_t)CHAIN_BUFS * B * 16 * 256;
+    if (level8_chain_shape_ok(u, H0, W0)) upd(ly.chain, (size_t)CHAIN8_BUFS * B * 64 * 256);     // the chains run one after the other
 
     size_t off = 0;
     auto take = [&](size_t n) { const size_t o = off; off += n; return o; };
@@ -938,22 +956,27 @@ static int run_attn(Ctx& c, const AttnW& a, const float* x, float* out, int H, i
     return run_conv(c, DDK_CONV1X1, a.out, o, HIDDEN, nullptr, 0, x, out, H, W, a.c);
 }
 
-// The last level as one persistent launch (level_chain.hip; unet.py:83-101 for that level): `in` = the Downsample conv's output,
-// `skip` receives the level's skip tensor (the down attention block's output, unet.py:87), `out` the up attention block's output.
+// Levels as persistent launches (level_chain.hip; unet.py:83-101).  part 0: the last level whole -- downs[-1], mid, ups[0] -- on 4x4 maps:
+// `in` = the Downsample conv's output, `skip` receives the level's skip tensor (unet.py:87), `out` the up attention block's output.
+// part 1: downs[-2] on 8x8 maps (in -> skip).  part 2: ups[1] on 8x8 maps (cat(in, skip) -> out).
 static bool level_chain_use(const Ctx& c, int H0, int W0) {
-    return c.allow_cluster && c.u.level_chain && c.ly.chain > 0 && level_chain_shape_ok(c.u, H0, W0) && level_chain_device_ok();
+    return c.allow_cluster && (c.u.level_chain & 1) && c.ly.chain > 0 && level_chain_shape_ok(c.u, H0, W0) && level_chain_device_ok();
+}
+static bool level8_chain_use(const Ctx& c, int H0, int W0, int bit) {
+    return c.allow_cluster && (c.u.level_chain & bit) && c.ly.chain > 0 && level8_chain_shape_ok(c.u, H0, W0) && level_chain_device_ok();
 }
 
-static int run_level_chain(Ctx& c, const float* in, float* skip, float* out) {
+static int run_level_chain(Ctx& c, int part, const float* in, float* skip, float* out) {
     const ddk_unet& u = c.u;
-    const int sh = u.L - 1;
+    const int hw = part == 0 ? 16 : 64;
+    const bool wino = hw == 64;
     ChainParams p{};
     int n = 0, e = 0;
-    const size_t per = (size_t)c.B * 16 * 256;
+    const size_t per = (size_t)c.B * hw * 256;
     auto buf = [&](int i) { return c.W + c.ly.off_chain + (size_t)i * per; };
     auto conv3 = [&](const ConvW& cw, const NormW& nw, const float* s0, int c0, const float* s1, int c1, int temb_off, int flags, float* o) {
         ChainOp& op = p.op[n++];
-        op = ChainOp{s0, s1, c.P + cw.wl, c.P + cw.b, c.P + nw.g, c.P + nw.b, o, c0, c1, CH_CONV3, flags, temb_off, 256};
+        op = ChainOp{s0, s1, c.P + (wino ? cw.wwl : cw.wl), c.P + cw.b, c.P + nw.g, c.P + nw.b, o, c0, c1, CH_CONV3, flags, temb_off, 256};
     };
     auto conv1 = [&](const ConvW& cw, const float* s0, int c0, const float* s1, int c1, int flags, float* o) {
         ChainOp& op = p.op[n++];
@@ -965,10 +988,10 @@ static int run_level_chain(Ctx& c, const float* in, float* skip, float* out) {
     };
     const int WS = CHF_WAIT | CHF_SIGNAL, RES = CHF_ADD_KEEP | CHF_SAVE_KEEP;
     // a ResnetBlock without a skip conv (blocks.py:105-115): x enters as `keep`
-    auto res_plain = [&](const ResW& r, const float* x, bool external, float* o, bool last_signals = true) {
+    auto res_plain = [&](const ResW& r, const float* x, bool external, float* o) {
         float* h = buf(e++);
         conv3(r.c1, r.n1, x, 256, nullptr, 0, r.temb_off, external ? (CHF_SIGNAL | CHF_KEEP_FROM_SRC) : WS, h);
-        conv3(r.c2, r.n2, h, 256, nullptr, 0, -1, (last_signals ? WS : CHF_WAIT) | RES, o);
+        conv3(r.c2, r.n2, h, 256, nullptr, 0, -1, WS | RES, o);
     };
     // Residual(PreNorm(LinearAttention)) (blocks.py:8-14, 63-71, 116-134): x is `keep`
     auto attn_block = [&](const AttnW& a, const float* x, float* o, bool signals) {
@@ -976,31 +999,49 @@ static int run_level_chain(Ctx& c, const float* in, float* skip, float* out) {
         attn(a, x, heads);
         conv1(a.out, heads, HIDDEN, nullptr, 0, (signals ? WS : CHF_WAIT) | RES, o);
     };
-    float* d0 = buf(e++);
-    res_plain(u.down_res[2 * sh], in, true, d0);
-    float* d1 = buf(e++);
-    res_plain(u.down_res[2 * sh + 1], d0, false, d1);
-    attn_block(u.down_attn[sh], d1, skip, true);
-    float* m1 = buf(e++);
-    res_plain(u.mid1, skip, false, m1);
-    float* ma = buf(e++);
-    attn_block(u.mid_attn, m1, ma, true);
-    float* m2 = buf(e++);
-    res_plain(u.mid2, ma, false, m2);
-    {   // ups[0][0]: cat(x, skip) -> 512 channels, res_conv is a 1x1 (its result lives in keep2)
-        const ResW& r = u.up_res[0];
-        conv1(r.res, m2, 256, skip, 256, CHF_WAIT | CHF_SAVE_KEEP2 | CHF_NO_OUT, nullptr);
+    // a ResnetBlock on cat(x, skip) -> 512 channels, res_conv is a 1x1 (its result lives in keep2); x_external: x comes from another kernel
+    auto res_cat = [&](const ResW& r, const float* x, bool x_external, const float* sk, float* o) {
+        conv1(r.res, x, 256, sk, 256, (x_external ? 0 : CHF_WAIT) | CHF_SAVE_KEEP2 | CHF_NO_OUT, nullptr);
         float* h = buf(e++);
-        conv3(r.c1, r.n1, m2, 256, skip, 256, r.temb_off, CHF_SIGNAL, h);
+        conv3(r.c1, r.n1, x, 256, sk, 256, r.temb_off, CHF_SIGNAL, h);
+        conv3(r.c2, r.n2, h, 256, nullptr, 0, -1, WS | CHF_ADD_KEEP2 | CHF_SAVE_KEEP, o);
+    };
+    if (part == 0) {
+        const int sh = u.L - 1;
+        float* d0 = buf(e++);
+        res_plain(u.down_res[2 * sh], in, true, d0);
+        float* d1 = buf(e++);
+        res_plain(u.down_res[2 * sh + 1], d0, false, d1);
+        attn_block(u.down_attn[sh], d1, skip, true);
+        float* m1 = buf(e++);
+        res_plain(u.mid1, skip, false, m1);
+        float* ma = buf(e++);
+        attn_block(u.mid_attn, m1, ma, true);
+        float* m2 = buf(e++);
+        res_plain(u.mid2, ma, false, m2);
         float* u0 = buf(e++);
-        conv3(r.c2, r.n2, h, 256, nullptr, 0, -1, WS | CHF_ADD_KEEP2 | CHF_SAVE_KEEP, u0);
+        res_cat(u.up_res[0], m2, false, skip, u0);
         float* u1 = buf(e++);
         res_plain(u.up_res[1], u0, false, u1);
         attn_block(u.up_attn[0], u1, out, false);
+    } else if (part == 1) {
+        const int sh = u.L - 2;
+        float* d0 = buf(e++);
+        res_plain(u.down_res[2 * sh], in, true, d0);
+        float* d1 = buf(e++);
+        res_plain(u.down_res[2 * sh + 1], d0, false, d1);
+        attn_block(u.down_attn[sh], d1, skip, false);
+    } else {
+        float* u0 = buf(e++);
+        res_cat(u.up_res[2], in, true, skip, u0);
+        float* u1 = buf(e++);
+        res_plain(u.up_res[3], u0, false, u1);
+        attn_block(u.up_attn[1], u1, out, false);
     }
-    if (n > CH_MAX_OPS || e > CHAIN_BUFS) return fail_arg("level_chain: internal op / buffer count");
+    if (n > CH_MAX_OPS || e > (part == 0 ? CHAIN_BUFS : CHAIN8_BUFS)) return fail_arg("level_chain: internal op / buffer count");
     p.n_ops = n;
     p.B = c.B;
+    p.hw = hw;
     p.temb = c.temb;
     p.temb_rows = c.temb_rows;
     p.temb_stride = u.temb_total;
@@ -1100,16 +1141,22 @@ static int forward_core(const ddk_unet& u, const float* P, const float* x, int64
     int cur_c = pad32(u.cfg.in_ch);
     AddendSlabs cur_ss;           // > 1 slab: `cur` is the split-K area a Downsample conv left for the next ResnetBlock to sum
     const bool chained = level_chain_use(c, H0, W0);    // the last level (4x4 maps) as one persistent launch
+    const bool chained8 = level8_chain_use(c, H0, W0, 2);   // the level above it (8x8 maps): downs[-2] as one launch,
+    const bool chained8u = level8_chain_use(c, H0, W0, 4);  // ups[1] as another
     for (int l = 0; l < u.L; ++l) {
         float* skip = ws + ly.off_skip[l];
         const int co = u.dimp[l + 1];
         if (chained && l == u.L - 1) {
             // downs[-1] (2 ResnetBlocks + attention), mid_block1, mid_attn, mid_block2, ups[0] (2 ResnetBlocks + attention): 19 launches in one
-            DDK_TRY(run_level_chain(c, cur, skip, bufB));
+            DDK_TRY(run_level_chain(c, 0, cur, skip, bufB));
             cur_c = co;
             break;
         }
-        if (l == 0 && fast0) {
+        const bool level_chained = chained8 && l == u.L - 2 && cur_ss.n == 1;
+        if (level_chained) {
+            // downs[-2] on 8x8 maps (2 ResnetBlocks + attention): 7 launches in one
+            DDK_TRY(run_level_chain(c, 1, cur, skip, nullptr));
+        } else if (l == 0 && fast0) {
             const ResW& r = u.down_res[0];
             DDK_TRY(conv_first(x, P + r.c1.wf, r.c1.has_bias ? P + r.c1.b : nullptr, raw, gnp, B, H, W, r.ci, r.co, GROUPS,
                                step ? step->state : nullptr, step ? t : nullptr, st));
@@ -1145,11 +1192,13 @@ static int forward_core(const ddk_unet& u, const float* P, const float* x, int64
             DDK_TRY(run_res(c, u.down_res[2 * l], cur, cur_c, nullptr, 0, bufB, H, W, cur_ss));
             cur_ss = AddendSlabs();
         }
-        DDK_TRY(run_res(c, u.down_res[2 * l + 1], bufB, co, nullptr, 0, bufC, H, W));
-        DDK_TRY(run_attn(c, u.down_attn[l], bufC, skip, H, W));
+        if (!level_chained) {
+            DDK_TRY(run_res(c, u.down_res[2 * l + 1], bufB, co, nullptr, 0, bufC, H, W));
+            DDK_TRY(run_attn(c, u.down_attn[l], bufC, skip, H, W));
+        }
         if (l < u.L - 1) {
             const int s2 = conv_splits(DDK_CONV3X3_S2, B, H, W, co, co);
-            if (u.fold_down_reduce && s2 > 1 && !(chained && l + 1 == u.L - 1) &&
+            if (u.fold_down_reduce && s2 > 1 && !(chained && l + 1 == u.L - 1) && !(chained8 && l + 1 == u.L - 2) &&
                 res_takes_slab_source(u, u.down_res[2 * l + 2], B, H / 2, W / 2, co)) {
                 // the Downsample conv splits k and the ResnetBlock behind it is image-local (8x8 / 4x4 maps, no skip conv): the conv leaves
                 // its slabs in the split-K area and that block's two readers sum them -- no reduce launch, no reduced tensor
@@ -1188,7 +1237,10 @@ static int forward_core(const ddk_unet& u, const float* P, const float* x, int64
         const int lvl = u.L - 1 - i;  // skips.pop(): the most recent skip first (unet.py:97)
         const float* skip = ws + ly.off_skip[lvl];
         const int dout = u.dimp[lvl + 1], din = u.dimp[lvl];
-        if (!(chained && i == 0)) {
+        if (chained8u && i == 1) {
+            // ups[1] on 8x8 maps (ResnetBlock on the concat, ResnetBlock, attention): 9 launches in one
+            DDK_TRY(run_level_chain(c, 2, cur, const_cast<float*>(skip), bufB));
+        } else if (!(chained && i == 0)) {
             DDK_TRY(run_res(c, u.up_res[2 * i], cur, cur_c, skip, dout, bufB, H, W));
             DDK_TRY(run_res(c, u.up_res[2 * i + 1], bufB, din, nullptr, 0, bufC, H, W));
             DDK_TRY(run_attn(c, u.up_attn[i], bufC, bufB, H, W));
