@@ -67,7 +67,8 @@ __device__ __forceinline__ void st_sc1(float* p, f32x4 v) { asm volatile("global
 #ifdef DDK_TUNING
 // Diagnostic stamps (tuning build only): per op and watched workgroup (blocks 0, 100, 255), s_memrealtime ticks (10 ns) at
 // [0] op entry, [1] wait passed, [2] image staged, [3] k loop / projection done, [4] op left (after the signal).
-__device__ unsigned long long g_lc_stamps[3 * CH_MAX_OPS * 8];
+// Three launches per step share the buffer: the 4x4 chain (19 ops) writes rows 0..2, the 8x8 chains rows 3..5 (6 ops) and 6..8 (7 ops).
+__device__ unsigned long long g_lc_stamps[9 * CH_MAX_OPS * 8];
 #define LC_STAMP(c, k, i)                                                                                                   \
     do {                                                                                                                    \
         if ((c).tid == 0 && (c).watch >= 0) g_lc_stamps[((c).watch * CH_MAX_OPS + (k)) * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); \
@@ -1095,6 +1096,7 @@ __global__ __launch_bounds__(1024) void level8_chain_kernel(const ChainParams p)
     c.nwaves = 16;
     c.units3 = 16;
     c.watch = blockIdx.x == 0 ? 0 : blockIdx.x == 100 ? 1 : blockIdx.x == 255 ? 2 : -1;
+    if (c.watch >= 0) c.watch += p.n_ops == 6 ? 3 : 6;
     c.k = 0;
     c.keep = c.keep2 = 0.f;
     if (c.tid == 0) { *reinterpret_cast<int*>(c.misc) = 0; reinterpret_cast<unsigned*>(c.misc)[1] = 0u; }
@@ -1193,6 +1195,6 @@ extern "C" int ddk_debug_level_chain(const void* ops, int n, int hw, int B, cons
 #ifdef DDK_TUNING
 extern "C" int ddk_debug_read_lc_stamps(unsigned long long* host_out) {   // tuning build only (not in include/ddk.h)
     if (hipDeviceSynchronize() != hipSuccess) return -2;
-    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(ddk::g_lc_stamps), sizeof(unsigned long long) * 3 * ddk::CH_MAX_OPS * 8) == hipSuccess ? 0 : -2;
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(ddk::g_lc_stamps), sizeof(unsigned long long) * 9 * ddk::CH_MAX_OPS * 8) == hipSuccess ? 0 : -2;
 }
 #endif

@@ -107,9 +107,12 @@ struct ddk_unet {
     bool fold_down_reduce = false;           // Downsample conv's split-K slabs summed by the image-local ResnetBlock behind it (no reduce launch).
                                              // OFF by default: measured 6 us per step SLOWER (each of an image's eight workgroups re-sums the slabs:
                                              // +6.3 / +5.9 us on the two consumers against reduce launches of 5.2 / 4.9 us; tools/fold_ab.py)
-    int level_chain = 7;                     // bit 0: the whole 4x4 level (ResnetBlocks + attention of downs[-1], mid, ups[0]) as ONE persistent launch
+    int level_chain = 1;                     // bit 0: the whole 4x4 level (ResnetBlocks + attention of downs[-1], mid, ups[0]) as ONE persistent launch
                                              // (level_chain.hip) wherever the in-launch GroupNorm may run (its workgroups wait for each other too);
-                                             // bits 1, 2: the two 8x8 levels (downs[-2]; ups[1]) likewise, one launch each
+                                             // bits 1, 2: the two 8x8 levels (downs[-2]; ups[1]) likewise, one launch each -- built, tested,
+                                             // OFF by default: measured 100 us per step SLOWER (150 + 170 us against 104 + 125 for the 16
+                                             // launches: a hop moves a 64 KB image to each of 8 workgroups, 5 us of staging and 7 us of
+                                             // tail per op where the launches pay 2.9 + 2.4 + 2.0; profiles/r06_chain8_clock.txt, r06_chain8_ab.txt)
     bool attn_fold = true;                   // attention on maps with HW > 256, C = 128: q projection + apply + to_out as ONE per-image C x C conv
     // unet_chan % 8 == 0 but not % 32 (reference blocks.py:75 takes any GroupNorm(8, C)): every tensor keeps a pitch of pad32(C) channels
     // with zero padding, the convs run on the generic im2col kernels over zero-padded weights and the normalisations on their
@@ -432,8 +435,8 @@ extern "C" int ddk_unet_set_option(ddk_unet* u, int option, int value) {
         std::lock_guard<std::mutex> lock(u->mu);
         if (!u->graphs.empty()) DDK_HIP(hipDeviceSynchronize());
         drop_graphs(u);
-        // 0 off, 1 all, 2: the 4x4 level only, 4: the 8x8 levels only, 8 / 16: only downs[-2] / only ups[1] of them (diagnostics)
-        u->level_chain = value == 1 ? 7 : value == 2 ? 1 : value == 4 ? 6 : value == 8 ? 2 : value == 16 ? 4 : value != 0 ? 7 : 0;
+        // 0 off, 1 (default) / 2: the 4x4 level, 3: the 8x8 levels as well, 4: the 8x8 levels only, 8 / 16: only downs[-2] / only ups[1]
+        u->level_chain = value == 1 || value == 2 ? 1 : value == 3 ? 7 : value == 4 ? 6 : value == 8 ? 2 : value == 16 ? 4 : value != 0 ? 1 : 0;
         return DDK_OK;
     }
     if (option == DDK_OPT_FOLD_DOWNSAMPLE_REDUCE) {

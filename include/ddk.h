@@ -360,7 +360,8 @@ int ddk_unet_forward(const ddk_unet* u, const void* packed, const float* x, cons
  * run as ONE persistent launch whose workgroups hand the 16-pixel images to each other in memory (csrc/level_chain.hip).  Like the
  * in-launch GroupNorm it needs all its workgroups resident together, so it runs exactly where DDK_OPT_CLUSTER_GROUPNORM lets that one
  * run (ddk_sampler_run; ddk_unet_forward with that option at 2), and a wait that times out moves the same sticky word
- * (ddk_unet_cluster_check -> DDK_ERR_CLUSTER). */
+ * (ddk_unet_cluster_check -> DDK_ERR_CLUSTER).  Values: 0 off, 1 the 4x4 level (default), 3 also the two 8x8 levels (downs[-2], ups[1]: one
+ * launch each; built and tested, measured slower on MI355X at batch 32 -- a hop moves 64 KB per image and workgroup there), 4 only those. */
 #define DDK_OPT_LEVEL_CHAIN 7
 int ddk_unet_set_option(ddk_unet* u, int option, int value);
 /* Waits for `s`, then reads and clears the sticky give-up count of the launches issued on `workspace` (a ddk_unet_forward or

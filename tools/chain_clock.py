@@ -24,13 +24,18 @@ with torch.no_grad():
 torch.cuda.synchronize()
 lib = L.load()
 NOPS = 24
-buf = (C.c_ulonglong * (3 * NOPS * 8))()
+buf = (C.c_ulonglong * (9 * NOPS * 8))()
 lib.ddk_debug_read_lc_stamps.argtypes = [C.c_void_p]
 assert lib.ddk_debug_read_lc_stamps(buf) == 0
 names = ["d0.c1", "d0.c2", "d1.c1", "d1.c2", "d.attn", "d.out", "m1.c1", "m1.c2", "m.attn", "m.out", "m2.c1", "m2.c2", "u0.res", "u0.c1",
          "u0.c2", "u1.c1", "u1.c2", "u.attn", "u.out"]
-for w, blk in enumerate((0, 100, 255)):
-    print(f"workgroup {blk}: us per phase   wait   stage   loop   tail+signal | op total | since kernel entry")
+names8d = ["d0.c1", "d0.c2", "d1.c1", "d1.c2", "attn", "out"]
+names8u = ["u0.res", "u0.c1", "u0.c2", "u1.c1", "u1.c2", "attn", "out"]
+which = sys.argv[1] if len(sys.argv) > 1 else "4"
+base, names = {"4": (0, names), "8d": (3, names8d), "8u": (6, names8u)}[which]
+for w0, blk in enumerate((0, 100, 255)):
+    w = base + w0
+    print(f"chain {which} workgroup {blk}: us per phase   wait   stage   loop   tail+signal | op total | since kernel entry")
     t00 = buf[(w * NOPS) * 8]
     tot = [0.0] * 4
     for k, nm in enumerate(names):

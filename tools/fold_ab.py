@@ -11,6 +11,7 @@ from models import DownsampleDDPM, Unet
 from utils import synthetic as syn
 
 opt = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+vals = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0, 1]       # option values to alternate between
 dev = torch.device("cuda", 0)
 cfg = cfg4()
 model = DownsampleDDPM(cfg, Unet(cfg), "cuda", 3)
@@ -27,7 +28,7 @@ def run(k):
 
 with torch.no_grad():
     for rnd in range(3):
-        for val in (0, 1):
+        for val in vals:
             plan.set_option(opt, val)
             run(40)
             torch.cuda.synchronize()
