@@ -29,8 +29,6 @@ class ConvResBlock(nn.Module):
     def __init__(self, dim, in_channels, out_channels=None, upsample=False, downsample=False, dropout=0, residual=False):
         super().__init__()
         assert not (upsample and downsample), 'Does not make sense to both down- and upsample.'
-        if dropout:
-            raise DDKError("ConvResBlock: d_dropout > 0 is not supported by the HIP path (train.py:36 uses 0)")
         self.upsample, self.downsample, self.residual = upsample, downsample, residual
         self.c1 = get_1x1(in_channels, dim)
         self.c2 = get_3x3(dim, dim)
@@ -38,30 +36,54 @@ class ConvResBlock(nn.Module):
         self.c4 = get_1x1(dim, out_channels)
         self.drop = nn.Dropout2d(p=dropout)
         self._packed = _Packed()
+        self._mask_hook = None          # tests: callable (batch, channels, device) -> the Dropout2d mask to use (already scaled by 1 / (1 - p))
+
+    def channel_mask(self, batch, channels_padded, device):
+        """The nn.Dropout2d draw of one training forward (convblocks.py:106,121-124): [batch, channels] of {0, 1 / (1 - p)}, zero on the
+        padding channels of a d_chans that is not a multiple of 32."""
+        import torch
+        p, c = float(self.drop.p), self.c4.out_channels
+        if self._mask_hook is not None:
+            m = self._mask_hook(batch, c, device).to(device=device, dtype=torch.float32)
+        else:
+            m = (torch.rand((batch, c), device=device) >= p).to(torch.float32) / (1.0 - p)
+        if channels_padded != c:
+            full = m.new_zeros((batch, channels_padded))
+            full[:, :c] = m
+            m = full
+        return m
 
     def forward_nhwc(self, x):
-        mid = self.c1.out_channels
+        if self.training and self.drop.p > 0 and not x.requires_grad:
+            # a train-mode forward outside autograd (reference: model.train() + torch.no_grad()): the differentiable path has the dropout
+            from trainers.autograd_unet import _conv_res_block
+            import torch
+            with torch.no_grad():
+                return _conv_res_block(self, x)[0]
+        mid, outer = self.c1.out_channels, self.c1.in_channels
         mp = ops.pad32(mid)
-        if mp == mid:
+        if mp == mid and outer % 32 == 0:
             pk = lambda name, conv: self._packed.get(name, conv.weight, ops.pack_conv_weight)
             bs = lambda name, conv: conv.bias.detach()
         else:
             # d_chans / 2 is not a multiple of 32 (d_chans = 32, 96, ...): the block's inner tensors keep a pitch of pad32(mid) channels.
             # Output rows and bias entries beyond `mid` are zero, Mish(0) = 0, and the next conv's weights are zero on the padded
             # inputs (ddk_pack_conv_weight pads the input side itself): the padding stays exactly zero through the block.
+            # The same for d_chans itself (48, 16, ...): the block's input / output pitch is pad32(d_chans).
             def pad_o(w):
-                wp = ops.pack_conv_weight(w)
-                if w.shape[0] == mid:
-                    out = wp.new_zeros((mp,) + tuple(wp.shape[1:]))
-                    out[:mid] = wp
+                wp = ops.pack_conv_weight(w)                    # pads the input side to 32 itself
+                op = ops.pad32(w.shape[0])
+                if op != w.shape[0]:
+                    out = wp.new_zeros((op,) + tuple(wp.shape[1:]))
+                    out[:w.shape[0]] = wp
                     return out
                 return wp
             def pad_b(b):
-                out = b.new_zeros(mp)
-                out[:mid] = b
+                out = b.new_zeros(ops.pad32(b.shape[0]))
+                out[:b.shape[0]] = b
                 return out
             pk = lambda name, conv: self._packed.get(name, conv.weight, pad_o)
-            bs = lambda name, conv: self._packed.get(name + ".b", conv.bias, pad_b) if conv.out_channels == mid else conv.bias.detach()
+            bs = lambda name, conv: self._packed.get(name + ".b", conv.bias, pad_b)
         h = ops.conv(ops.CONV1X1, x, pk("c1", self.c1), bs("c1", self.c1), pre_mish=True, post_mish=True)
         h = ops.conv(ops.CONV3X3_S1, h, pk("c2", self.c2), bs("c2", self.c2), post_mish=True)
         h = ops.conv(ops.CONV3X3_S1, h, pk("c3", self.c3), bs("c3", self.c3), post_mish=True)
@@ -82,9 +104,9 @@ class ConvResNet(nn.Module):
 
     def __init__(self, dim, in_channels, out_channels, n_downsamples=1, upsample=False, dropout=0, n_blocks=1):
         super().__init__()
-        if dim % 32 != 0 or dim <= 0:
-            raise DDKError("ConvResNet: d_chans must be a multiple of 32 for the HIP conv kernels (train.py:37 uses 64); training "
-                           "additionally needs a multiple of 64")
+        if dim % 2 != 0 or dim <= 0:
+            raise DDKError("ConvResNet: d_chans must be a positive even number (its blocks are d_chans / 2 wide, convblocks.py:147); "
+                           "multiples of 64 take the tuned kernels (train.py:37 uses 64), other widths run on zero-padded channel pitches")
         layers = [get_1x1(in_channels, dim)]
         for _ in range(n_downsamples):
             layers.append(ConvResBlock(int(dim / 2), dim, dim, upsample, not upsample, dropout, residual=True))
@@ -118,11 +140,32 @@ class ConvResNet(nn.Module):
     def forward_nhwc(self, x, final_tanh=False):
         """x [B,H,W,pad32(in_channels)] -> [B,H',W',out_channels]; optional fused-after tanh (dddpm.py:99,110)."""
         first, last = self.conv[0], self.conv[-1]
-        w0 = self._packed.get("first", first.weight, ops.pack_conv_weight)
-        h = ops.conv(ops.CONV1X1, x, w0, first.bias.detach())
+        dp = ops.pad32(self.dim)
+        if dp == self.dim:
+            w0 = self._packed.get("first", first.weight, ops.pack_conv_weight)
+            b0, wl = first.bias.detach(), last.weight.detach().contiguous()
+        else:
+            # d_chans not a multiple of 32: the trunk keeps a pitch of pad32(d_chans) channels, zero beyond d_chans
+            def pad_first(w):
+                wp = ops.pack_conv_weight(w)
+                out = wp.new_zeros((dp,) + tuple(wp.shape[1:]))
+                out[:self.dim] = wp
+                return out
+            def pad_bias(b):
+                out = b.new_zeros(dp)
+                out[:self.dim] = b
+                return out
+            def pad_last(w):
+                out = w.new_zeros((w.shape[0], dp) + tuple(w.shape[2:]))
+                out[:, :self.dim] = w
+                return out.contiguous()
+            w0 = self._packed.get("first", first.weight, pad_first)
+            b0 = self._packed.get("first.b", first.bias, pad_bias)
+            wl = self._packed.get("last", last.weight, pad_last)
+        h = ops.conv(ops.CONV1X1, x, w0, b0)
         for blk in list(self.conv)[1:-1]:
             h = blk.forward_nhwc(h)
-        out = ops.conv1x1_small_n(h, last.weight.detach().contiguous(), last.bias.detach())
+        out = ops.conv1x1_small_n(h, wl, last.bias.detach())
         return ops.tanh(out) if final_tanh else out
 
     def forward(self, x):

@@ -219,22 +219,31 @@ def _conv_res_block(blk, x, a=None, want_next_act=False):
     (`a`, written by its c4 epilogue: want_next_act, for a block that neither pools nor upsamples).  -> (out, Mish(out) or None)"""
     if a is None:
         a = ops.mish(x.detach())
-    hand = AG.GradHandoff() if blk.residual else None      # the skip's gradient rides on c1's input-gradient conv (no 17-67 MB add launch)
-    w1, b1, w2, b2, w3, b3, w4 = blk.c1.weight, blk.c1.bias, blk.c2.weight, blk.c2.bias, blk.c3.weight, blk.c3.bias, blk.c4.weight
-    inner = w1.shape[0]
-    if inner % 32:
-        # d_chans / 2 = 16, 48, ...: the block's inner tensors keep a pitch of pad32(inner) channels (zero weight rows and bias entries
-        # keep the padding exactly zero through Mish and both 3x3 convs); the kernels see zero-padded copies of the parameters
-        w1, b1 = AG.pad_param(w1, out_real=True), AG.pad_param(b1, out_real=True)
+    drop_p = float(blk.drop.p) if blk.training else 0.0
+    hand = AG.GradHandoff() if (blk.residual and drop_p == 0.0) else None   # the skip's gradient rides on c1's input-gradient conv (no 17-67 MB add launch)
+    w1, b1, w2, b2, w3, b3, w4, b4 = blk.c1.weight, blk.c1.bias, blk.c2.weight, blk.c2.bias, blk.c3.weight, blk.c3.bias, blk.c4.weight, blk.c4.bias
+    inner, outer = w1.shape[0], w1.shape[1]
+    if inner % 32 or outer % 32:
+        # d_chans = 48, 16, ... / d_chans / 2 = 16, 48, ...: tensors keep a pitch of pad32(channels) (zero weight rows and bias entries keep
+        # the padding exactly zero through Mish, the convs and the residual add); the kernels see zero-padded copies of the parameters
+        w1, b1 = AG.pad_param(w1, out_real=True, in_real=[outer]), AG.pad_param(b1, out_real=True)
         w2, b2 = AG.pad_param(w2, out_real=True, in_real=[inner]), AG.pad_param(b2, out_real=True)
         w3, b3 = AG.pad_param(w3, out_real=True, in_real=[inner]), AG.pad_param(b3, out_real=True)
-        w4 = AG.pad_param(w4, in_real=[inner])
+        w4, b4 = AG.pad_param(w4, out_real=True, in_real=[inner]), AG.pad_param(b4, out_real=True)
     h, a = AG.preact_conv(ops.CONV1X1, x, a, w1, b1, handoff=hand)
     h, a = AG.preact_conv(ops.CONV3X3_S1, h, a, w2, b2)
     h, a = AG.preact_conv(ops.CONV3X3_S1, h, a, w3, b3)
-    hand_over = want_next_act and not (blk.upsample or blk.downsample)
-    out, a_next = AG.preact_conv(ops.CONV1X1, h, a, w4, blk.c4.bias, resid=x if blk.residual else None, want_act=hand_over,
-                                 handoff=hand)
+    if drop_p > 0.0:
+        # nn.Dropout2d on c4's output (convblocks.py:106,121-124): whole channels of a sample are zeroed with probability p, the others scaled
+        # by 1 / (1 - p), BEFORE the residual.  train.py:36 uses d_dropout = 0, so this path is plain: c4 without its fused residual, the
+        # mask as one broadcast multiply (torch elementwise kernels; autograd differentiates it), the residual as an add.
+        x_hat, _ = AG.preact_conv(ops.CONV1X1, h, a, w4, b4, resid=None, want_act=False, handoff=None)
+        mask = blk.channel_mask(x_hat.shape[0], x_hat.shape[-1], x_hat.device)
+        x_hat = x_hat * mask[:, None, None, :]
+        out, a_next = (x + x_hat if blk.residual else x_hat), None
+    else:
+        hand_over = want_next_act and not (blk.upsample or blk.downsample)
+        out, a_next = AG.preact_conv(ops.CONV1X1, h, a, w4, b4, resid=x if blk.residual else None, want_act=hand_over, handoff=hand)
     if blk.upsample:
         out = AG.UpNearest2Fn.apply(out)
     elif blk.downsample:
@@ -244,17 +253,19 @@ def _conv_res_block(blk, x, a=None, want_next_act=False):
 
 def resnet_forward_autograd(net, x_nchw, final_tanh):
     """ConvResNet (dDDPM encoder / decoder) on an NCHW tensor -> NCHW, differentiable."""
-    if net.dim % 32 != 0:
-        from ddk.lib import DDKError
-        raise DDKError(f"d_chans={net.dim}: the HIP path needs d_chans % 32 == 0")
     h = AG.NchwToNhwcFn.apply(x_nchw.contiguous().float(), ops.pad32(x_nchw.shape[1]))
     first, last = net.conv[0], net.conv[-1]
-    h = AG.conv(ops.CONV1X1, h, first.weight, first.bias)
+    wf, bf, wl = first.weight, first.bias, last.weight
+    if net.dim % 32:
+        # d_chans that is not a multiple of 32 (convblocks.py:133-159 takes any): the trunk keeps a pitch of pad32(d_chans) channels
+        wf, bf = AG.pad_param(wf, out_real=True), AG.pad_param(bf, out_real=True)
+        wl = AG.pad_param(wl, in_real=[net.dim])
+    h = AG.conv(ops.CONV1X1, h, wf, bf)
     blocks = list(net.conv)[1:-1]
     a = None
     for k, blk in enumerate(blocks):
         h, a = _conv_res_block(blk, h, a, want_next_act=k + 1 < len(blocks))
-    out = AG.SmallNConvFn.apply(h, last.weight, last.bias)
+    out = AG.SmallNConvFn.apply(h, wl, last.bias)
     if final_tanh:
         out = AG.TanhFn.apply(out)
     return AG.NhwcToNchwFn.apply(out, out.shape[-1])

@@ -11,15 +11,18 @@ from .diffusion_ref import loss_ddpm, predict_x_from_eps, q_sample
 from .unet_ref import mish, unet_forward
 
 
-def conv_res_block(sd, pre, x, mode):
-    """convblocks.py:112-130: Mish->1x1->Mish->3x3->Mish->3x3->Mish->1x1, +x, then resample.
+def conv_res_block(sd, pre, x, mode, mask=None):
+    """convblocks.py:112-130: Mish->1x1->Mish->3x3->Mish->3x3->Mish->1x1, Dropout2d, +x, then resample.
 
-    mode: 'down' (avg_pool2d 2), 'up' (nearest x2) or None.  Dropout2d(p=0) is identity.
+    mode: 'down' (avg_pool2d 2), 'up' (nearest x2) or None.  mask: None = Dropout2d(p=0) / eval mode (identity); else the
+    nn.Dropout2d draw of convblocks.py:121-124 restated with an injected mask [B, C] of {0, 1 / (1 - p)} (whole channels of a sample).
     """
     h = F.conv2d(mish(x), sd[pre + "c1.weight"], sd[pre + "c1.bias"])
     h = F.conv2d(mish(h), sd[pre + "c2.weight"], sd[pre + "c2.bias"], padding=1)
     h = F.conv2d(mish(h), sd[pre + "c3.weight"], sd[pre + "c3.bias"], padding=1)
     h = F.conv2d(mish(h), sd[pre + "c4.weight"], sd[pre + "c4.bias"])
+    if mask is not None:
+        h = h * mask[:, :, None, None]
     out = x + h
     if mode == "up":
         out = F.interpolate(out, scale_factor=2)
@@ -28,28 +31,30 @@ def conv_res_block(sd, pre, x, mode):
     return out
 
 
-def conv_res_net(sd, pre, x, n_levels, n_blocks, upsample):
-    """convblocks.py:133-159: 1x1 explode, per level [resampling block + (n_blocks-1) plain], 1x1 condense."""
+def conv_res_net(sd, pre, x, n_levels, n_blocks, upsample, masks=None):
+    """convblocks.py:133-159: 1x1 explode, per level [resampling block + (n_blocks-1) plain], 1x1 condense.
+    masks: {block key prefix: Dropout2d mask} for train-mode parity with injected draws (see conv_res_block)."""
+    masks = masks or {}
     x = F.conv2d(x, sd[pre + "conv.0.weight"], sd[pre + "conv.0.bias"])
     i = 1
     for _ in range(n_levels):
-        x = conv_res_block(sd, f"{pre}conv.{i}.", x, "up" if upsample else "down")
+        x = conv_res_block(sd, f"{pre}conv.{i}.", x, "up" if upsample else "down", masks.get(f"{pre}conv.{i}."))
         i += 1
         for _ in range(n_blocks - 1):
-            x = conv_res_block(sd, f"{pre}conv.{i}.", x, None)
+            x = conv_res_block(sd, f"{pre}conv.{i}.", x, None, masks.get(f"{pre}conv.{i}."))
             i += 1
     return F.conv2d(x, sd[f"{pre}conv.{i}.weight"], sd[f"{pre}conv.{i}.bias"])
 
 
-def rescaled_downsample(sd, cfg, x):
+def rescaled_downsample(sd, cfg, x, masks=None):
     """dddpm.py:92-101: z = tanh(downsample(x)) when force_latent."""
-    z = conv_res_net(sd, "downsample.", x, cfg["n_downsamples"], cfg["d_n_blocks"], False)
+    z = conv_res_net(sd, "downsample.", x, cfg["n_downsamples"], cfg["d_n_blocks"], False, masks)
     return torch.tanh(z) if cfg["force_latent"] else z
 
 
-def rescaled_upsample(sd, cfg, z):
+def rescaled_upsample(sd, cfg, z, masks=None):
     """dddpm.py:103-112."""
-    x = conv_res_net(sd, "upsample.", z, cfg["n_downsamples"], cfg["u_n_blocks"], True)
+    x = conv_res_net(sd, "upsample.", z, cfg["n_downsamples"], cfg["u_n_blocks"], True, masks)
     return torch.tanh(x) if cfg["force_latent"] else x
 
 

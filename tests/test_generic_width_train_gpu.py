@@ -147,15 +147,17 @@ def test_unet_generic_width_dropout_trains(tmp_path):
     assert not torch.equal(p0, trainer.opt.fp.flat) and bool(torch.isfinite(trainer.opt.fp.flat).all())
 
 
-@pytest.mark.parametrize("d_chans", [32, 96])
-def test_resampler_training_at_d_chans_not_a_multiple_of_64(d_chans):
+@pytest.mark.parametrize("d_chans,d_dropout", [(32, 0.0), (96, 0.0), (48, 0.0), (16, 0.0), (48, 0.1), (64, 0.25)])
+def test_resampler_training_at_d_chans_not_a_multiple_of_64(d_chans, d_dropout):
     """the dDDPM encoder / decoder (ConvResNet, convblocks.py:92-159) in training at d_chans = 32 / 96 -- inner widths 16 / 48 on a
-    zero-padded pitch: outputs and gradients (input, first / inner / last conv parameters) vs torch-CPU autograd through
-    oracle.resampler_ref"""
+    zero-padded pitch --, at d_chans = 48 / 16 -- the trunk itself on a padded pitch (any even d_chans, convblocks.py:133-159) --
+    and with d_dropout > 0 (nn.Dropout2d on c4's output, convblocks.py:106,121-124; the draws injected on both sides): outputs and
+    gradients (input, first / inner / last conv parameters) vs torch-CPU autograd through oracle.resampler_ref"""
     from helpers import dddpm_cfg
     from models import DownsampleDDPMAutoencoder, Unet
     cfg = dddpm_cfg(32, 32, 2)
     cfg["d_chans"] = d_chans
+    cfg["d_dropout"] = d_dropout
     model = DownsampleDDPMAutoencoder(cfg, Unet(cfg), DEV, 3)
     sd = syn.fill_state_dict(model.state_dict(), 17, skip=syn.SCHEDULE_KEYS)
     model.load_state_dict(sd)
@@ -170,9 +172,20 @@ def test_resampler_training_at_d_chans_not_a_multiple_of_64(d_chans):
     ref = {k: v.clone() for k, v in sd.items()}
     for k in probe:
         ref[k].requires_grad_(True)
+    masks = None
+    if d_dropout > 0:
+        # one Dropout2d draw per ConvResBlock, the same on both sides: [B, d_chans] of {0, 1 / (1 - p)}
+        masks = {}
+        g = torch.Generator().manual_seed(5)
+        for name, net in (("downsample.", model.downsample), ("upsample.", model.upsample)):
+            for i, blk in enumerate(list(net.conv)[1:-1], start=1):
+                m = (torch.rand((2, d_chans), generator=g) >= d_dropout).float() / (1.0 - d_dropout)
+                masks[f"{name}conv.{i}."] = m
+                blk._mask_hook = (lambda mm: (lambda b, c, dev: mm))(m)
+        assert any(float((m == 0).float().mean()) > 0 for m in masks.values())
     xr = x.clone().requires_grad_(True)
-    zr = R.rescaled_downsample(ref, cfg, xr)
-    xo_r = R.rescaled_upsample(ref, cfg, zr)
+    zr = R.rescaled_downsample(ref, cfg, xr, masks)
+    xo_r = R.rescaled_upsample(ref, cfg, zr, masks)
     ((zr * wz).sum() + (xo_r * wx).sum()).backward()
     xd = x.to(DEV).requires_grad_(True)
     z = model.rescaled_downsample(xd)
@@ -183,3 +196,29 @@ def test_resampler_training_at_d_chans_not_a_multiple_of_64(d_chans):
     assert rel_err(xd.grad.cpu(), xr.grad) < 2e-4
     for k in probe:
         assert rel_err(params[k].grad.cpu(), ref[k].grad) < 2e-4, k
+    # eval mode: Dropout2d is the identity, the sampler's decode path (forward_nhwc) == the oracle without masks
+    model.eval()
+    with torch.no_grad():
+        z_e = model.rescaled_downsample(x.to(DEV))
+        x_e = model.rescaled_upsample(z_e)
+        z_ref = R.rescaled_downsample(sd, cfg, x)
+        assert rel_err(z_e.cpu(), z_ref) < 2e-5 and rel_err(x_e.cpu(), R.rescaled_upsample(sd, cfg, z_ref)) < 2e-5
+
+
+def test_resampler_dropout_draws_whole_channels(monkeypatch):
+    """d_dropout > 0 without injected draws: in training a ConvResBlock zeroes whole (sample, channel) planes of c4's output with
+    probability p and scales the rest by 1 / (1 - p) (nn.Dropout2d, convblocks.py:106,121-124); two forwards draw different masks"""
+    from models.downsampled.convblocks import ConvResBlock
+    blk = ConvResBlock(32, 64, 64, dropout=0.5, residual=False).to(DEV).train()
+    x = torch.randn(16, 64, 8, 8, device=DEV)
+    with torch.no_grad():
+        y1, y2 = blk(x), blk(x)
+        blk.eval()
+        y0 = blk(x)
+    dead1 = (y1.abs().amax(dim=(2, 3)) == 0)
+    frac = float(dead1.float().mean())
+    assert 0.3 < frac < 0.7
+    keep = ~dead1
+    assert torch.allclose(y1.permute(0, 2, 3, 1)[keep[:, None, None, :].expand(16, 8, 8, 64)],
+                          2.0 * y0.permute(0, 2, 3, 1)[keep[:, None, None, :].expand(16, 8, 8, 64)], rtol=1e-5, atol=1e-6)
+    assert not torch.equal(dead1, (y2.abs().amax(dim=(2, 3)) == 0))
