@@ -18,6 +18,8 @@
 //   (quad -> 32 lanes -> 4 waves -> quads of the group: one pass, no cancellation), the format gn_apply_parts_kernel consumes.
 //   In the sampler the workgroup 0 also does the step's bookkeeping (t_cur[b] <- counter; counter -= 1): it is the first kernel
 //   of a reverse step, so the separate prepare / pad kernel disappears.
+#include <type_traits>
+
 #include "conv_common.h"
 
 namespace ddk {
@@ -33,6 +35,17 @@ struct FirstParams {
     int64_t* counter;      // sampler bookkeeping (nullptr outside the sampler)
     int64_t* t_cur;
     int B;
+    // FUSE: GroupNorm + Mish + time shift finished inside the launch (the image's tiles exchange their statistics); out = the activation
+    const float* gamma;
+    const float* beta;
+    const float* temb;             // [rows][temb_stride] or null
+    const long long* temb_rows;    // row of image b, or null: row b
+    int temb_stride;
+    float eps;
+    unsigned long long* cl_rec;    // [tile][16] records {mean, M2} per group, 8 bytes each
+    unsigned* cl_cnt;              // [image][8 * 16]: word 0 arrivals, word 1 departures (re-armed by the last one out)
+    unsigned* cl_fail;
+    int tpi;                       // tiles (workgroups) per image
 };
 
 // dst[(nb*K2 + s)*64 + l] = w[n = nb*32 + (l & 31)][k = 2s + (l >> 5)],  k = tap*I + c  <-  OIHW w[n][c][tap]
@@ -59,7 +72,15 @@ __device__ __forceinline__ float dpp_partner(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
 }
 
-template <int CIN>
+constexpr unsigned long long FIRST_TIMEOUT_TICKS = 2000000ull;   // 20 ms of the 100 MHz s_memrealtime clock
+
+// FUSE (round 6): the Block's GroupNorm + Mish + time shift in the same launch.  A 128-pixel tile's statistics cannot normalise it --
+// the group spans the image's HW / 128 tiles -- so the workgroups of an image (consecutive block ids, dispatched together) exchange
+// their per-group {mean, M2} records exactly as conv3x3_wino2_kernel<.., true> does (row 1 of MI355X_MICROARCH.md's sc1 table: 8-byte
+// sc1 record stores by wave 0, drained, one arrival; one lane polls; workgroup barrier; sc1 loads), keep their 128 x N outputs in
+// registers meanwhile, and store the ACTIVATION: the raw tensor (16.8 MB at cfg4) is never written or re-read and the
+// gn_apply_parts_kernel launch behind this kernel disappears (14.6 + 10.1 us -> one launch).  N = 128 only (two channel blocks per wave).
+template <int CIN, bool FUSE = false>
 __global__ __launch_bounds__(512) void conv_first_kernel(const FirstParams p) {
     constexpr int K = 9 * CIN, K2 = (K + 1) / 2;
     constexpr int XS = CIN | 1;                      // LDS pixel stride of the staged input: odd -> conflict-free 4-byte gathers
@@ -123,7 +144,12 @@ __global__ __launch_bounds__(512) void conv_first_kernel(const FirstParams p) {
     }
 
     const long long orow = (long long)g * p.N;
-    for (int nb = par; nb < p.NB; nb += 2) {
+    float4 vk[2][4];             // FUSE: this wave's two channel blocks stay in registers until the image's statistics are known
+    (void)vk;
+    // (FUSE: exactly two channel blocks per wave, a compile-time trip count -- vk must be indexed by constants to stay in registers)
+    auto block = [&](int nb, auto itc) {
+        constexpr int it = decltype(itc)::value;
+        (void)it;
         f32x16 acc;
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] = 0.f;
@@ -137,9 +163,10 @@ __global__ __launch_bounds__(512) void conv_first_kernel(const FirstParams p) {
         for (int q = 0; q < 4; ++q) {
             const float4 bb = *reinterpret_cast<const float4*>(bl + cb + 8 * q);
             v[q] = make_float4(acc[4 * q] + bb.x, acc[4 * q + 1] + bb.y, acc[4 * q + 2] + bb.z, acc[4 * q + 3] + bb.w);
-            *reinterpret_cast<float4*>(p.out + orow + cb + 8 * q) = v[q];
+            if constexpr (!FUSE) *reinterpret_cast<float4*>(p.out + orow + cb + 8 * q) = v[q];
+            else vk[it][q] = v[q];
         }
-        if (p.gn_part) {
+        if (FUSE || p.gn_part) {
             // {mean, M2} of each quad, then merged over the 32 lanes that hold the same channels (equal counts at every level);
             // the four quads' trees run side by side
             float m[4], m2[4];
@@ -180,9 +207,17 @@ __global__ __launch_bounds__(512) void conv_first_kernel(const FirstParams p) {
                 for (int q = 0; q < 4; ++q) qs[pg * (p.N >> 2) + ((cb + 8 * q) >> 2)] = make_float2(m[q], m2[q]);
             }
         }
+    };
+    if constexpr (FUSE) {
+        block(par, std::integral_constant<int, 0>{});
+        block(par + 2, std::integral_constant<int, 1>{});
+    } else {
+        for (int nb = par; nb < p.NB; nb += 2) block(nb, std::integral_constant<int, 0>{});
     }
-    if (p.gn_part) {
+    if (FUSE || p.gn_part) {
         __syncthreads();
+        float2* ts = qs;                  // FUSE: [groups] merged {mean, rstd} of the image, over the quad records once they are consumed
+        float gmean = 0.f, gm2 = 0.f;
         if (tid < p.groups) {
             // fixed order: pixel groups, then the group's quads (Chan et al., unequal counts)
             const int qpg = p.cpg >> 2, q0 = tid * qpg;
@@ -196,7 +231,84 @@ __global__ __launch_bounds__(512) void conv_first_kernel(const FirstParams p) {
                     m2 += t.y + d * d * (n * ni / tot);
                     n = tot;
                 }
-            p.gn_part[(long long)blockIdx.x * p.groups + tid] = make_float2(mean, m2);
+            if constexpr (!FUSE) p.gn_part[(long long)blockIdx.x * p.groups + tid] = make_float2(mean, m2);
+            gmean = mean;
+            gm2 = m2;
+        }
+        if constexpr (FUSE) {
+            int* gave_up = reinterpret_cast<int*>(bl);       // the bias is consumed: its first word carries this workgroup's give-up flag
+            unsigned* cnt = p.cl_cnt + (size_t)bimg * 8 * 16;
+            if (tid < p.groups) {
+                const unsigned long long bits = (unsigned long long)__float_as_uint(gmean) | ((unsigned long long)__float_as_uint(gm2) << 32);
+                __hip_atomic_store(p.cl_rec + (size_t)blockIdx.x * 16 + tid, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (wave == 0) {              // every record was stored by this wave (groups <= 64): drain, ONE arrival, one lane polls
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0) {
+                    *gave_up = 0;
+                    __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)p.tpi) {
+                        const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();
+                        for (;;) {
+                            __builtin_amdgcn_s_sleep(2);
+                            if (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)p.tpi) break;
+                            if (__builtin_amdgcn_s_memrealtime() - t_begin > FIRST_TIMEOUT_TICKS) {
+                                if (p.cl_fail) __hip_atomic_fetch_add(p.cl_fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                *gave_up = 1;
+                                break;
+                            }
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            if (tid < p.groups) {
+                // the image's tiles of this group, equal counts: mean of means, M2 = sum M2_i + n_i sum (mean_i - mean)^2
+                const unsigned long long* r0 = p.cl_rec + (size_t)bimg * p.tpi * 16 + tid;
+                float rm[8], rq[8], ms = 0.f;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    rm[i] = rq[i] = 0.f;
+                    if (i < p.tpi) {
+                        const unsigned long long bits = __hip_atomic_load(r0 + (size_t)i * 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        rm[i] = __uint_as_float((unsigned)bits);
+                        rq[i] = __uint_as_float((unsigned)(bits >> 32));
+                        ms += rm[i];
+                    }
+                }
+                const float mean = *gave_up ? __builtin_nanf("") : ms / (float)p.tpi;
+                float m2 = 0.f, d2 = 0.f;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) if (i < p.tpi) { m2 += rq[i]; d2 += (rm[i] - mean) * (rm[i] - mean); }
+                const float n_i = 128.0f * (float)p.cpg;
+                ts[tid] = make_float2(mean, 1.0f / sqrtf((m2 + n_i * d2) / ((float)p.tpi * n_i) + p.eps));
+            }
+            if (tid == 0) {               // departure: the last one out re-arms the image's counters for the next launch
+                const unsigned old = __hip_atomic_fetch_add(cnt + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (old == (unsigned)p.tpi - 1u) {
+                    __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(cnt + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            __syncthreads();
+            const float* trow = nullptr;
+            if (p.temb) trow = p.temb + (p.temb_rows ? p.temb_rows[bimg] : (long long)bimg) * p.temb_stride;
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int cb = (par + 2 * it) * 32 + 4 * h;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int ch = cb + 8 * q;
+                    const float2 st = ts[ch / p.cpg];
+                    const float4 ga = *reinterpret_cast<const float4*>(p.gamma + ch), be = *reinterpret_cast<const float4*>(p.beta + ch);
+                    float4 sh = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (trow) sh = *reinterpret_cast<const float4*>(trow + ch);
+                    const float4 v = vk[it][q];
+                    *reinterpret_cast<float4*>(p.out + orow + ch) =
+                        make_float4(mish_f((v.x - st.x) * st.y * ga.x + be.x) + sh.x, mish_f((v.y - st.x) * st.y * ga.y + be.y) + sh.y,
+                                    mish_f((v.z - st.x) * st.y * ga.z + be.z) + sh.z, mish_f((v.w - st.x) * st.y * ga.w + be.w) + sh.w);
+                }
+            }
         }
     }
 }
@@ -218,10 +330,45 @@ bool conv_first_ok(int cin, int N, int H, int W, int groups) {
 #define FIRST_CASES(X) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8)
 
 int conv_first_init_device() {
-#define X(C) DDK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_first_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+#define X(C) DDK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_first_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)); \
+             DDK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_first_kernel<C, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     FIRST_CASES(X)
 #undef X
     return DDK_OK;
+}
+
+// the first Block whole (conv + GroupNorm + Mish + time shift) in one launch: N = 128, at most 8 tiles of 128 pixels per image
+bool conv_first_gn_ok(int cin, int N, int H, int W, int groups) {
+    return conv_first_ok(cin, N, H, W, groups) && N == 128 && (long long)H * W / 128 <= 8 && groups <= 16;
+}
+size_t conv_first_gn_ws_floats(int B, int H, int W) { return (size_t)B * ((size_t)H * W / 128) * 32; }    // 16 eight-byte records per tile
+
+int conv_first_gn(const float* x, const float* wp, const float* bias, const float* gamma, const float* beta, const float* temb,
+                  int temb_stride, const long long* temb_rows, float eps, float* out, int B, int H, int W, int cin, int N, int groups,
+                  float* records, unsigned* counters, unsigned* fail, int64_t* counter, int64_t* t_cur, hipStream_t st) {
+    DDK_REQUIRE(x && wp && out && gamma && beta && records && counters && B > 0, "conv_first_gn: null pointer / B");
+    DDK_REQUIRE(conv_first_gn_ok(cin, N, H, W, groups), "conv_first_gn: needs conv_first's shape with N == 128 and H*W <= 1024");
+    DDK_REQUIRE(aligned16(wp) && aligned16(out) && aligned16(bias) && aligned16(gamma) && aligned16(beta) && aligned16(temb) &&
+                    (temb_stride & 3) == 0 && (reinterpret_cast<uintptr_t>(records) & 7u) == 0 && (reinterpret_cast<uintptr_t>(x) & 3u) == 0,
+                "conv_first_gn: alignment");
+    DDK_REQUIRE((long long)B * H * W * 8 < (1ll << 31), "conv_first_gn: B*H*W too large for 32-bit pixel offsets");
+    DDK_REQUIRE((counter == nullptr) == (t_cur == nullptr), "conv_first_gn: counter and t_cur go together");
+    FirstParams p{};
+    p.x = x; p.wp = wp; p.bias = bias; p.out = out; p.gn_part = nullptr;
+    p.H = H; p.W = W; p.HW = H * W; p.N = N; p.NB = N / 32;
+    p.groups = groups; p.cpg = N / groups;
+    p.counter = counter; p.t_cur = t_cur; p.B = B;
+    p.gamma = gamma; p.beta = beta; p.temb = temb; p.temb_rows = temb_rows; p.temb_stride = temb_stride; p.eps = eps;
+    p.cl_rec = reinterpret_cast<unsigned long long*>(records); p.cl_cnt = counters; p.cl_fail = fail; p.tpi = H * W / 128;
+    const dim3 grid((unsigned)((long long)B * H * W / 128));
+    const size_t lds = first_lds_bytes(cin, N, W);
+    switch (cin) {
+#define X(C) case C: hipLaunchKernelGGL((conv_first_kernel<C, true>), grid, dim3(512), lds, st, p); break;
+        FIRST_CASES(X)
+#undef X
+        default: return fail_arg("conv_first_gn: C_in");
+    }
+    return check_launch("conv_first_kernel<FUSE>");
 }
 
 int conv_first(const float* x, const float* wp, const float* bias, float* out, float* gn_partials, int B, int H, int W, int cin, int N,

@@ -185,6 +185,13 @@ bool conv_first_ok(int cin, int N, int H, int W, int groups);
 int conv_first(const float* x, const float* wp, const float* bias, float* out, float* gn_partials, int B, int H, int W, int cin, int N,
                int groups, int64_t* counter, int64_t* t_cur, hipStream_t st);
 int conv_first_init_device();
+// ... with the Block's GroupNorm + Mish + time shift finished in the same launch (the image's tiles exchange their statistics):
+// records = conv_first_gn_ws_floats() floats, counters = [B][8 * 16] zeroed words that re-arm themselves, fail = sticky give-up count
+bool conv_first_gn_ok(int cin, int N, int H, int W, int groups);
+size_t conv_first_gn_ws_floats(int B, int H, int W);
+int conv_first_gn(const float* x, const float* wp, const float* bias, const float* gamma, const float* beta, const float* temb,
+                  int temb_stride, const long long* temb_rows, float eps, float* out, int B, int H, int W, int cin, int N, int groups,
+                  float* records, unsigned* counters, unsigned* fail, int64_t* counter, int64_t* t_cur, hipStream_t st);
 // conv1x1_ws.hip: 1x1 conv with 128 input channels on a large map as a weights-stationary, pixel-streaming GEMM
 // (w = the packed 1x1 weight [N][128]; ln as in conv_forward)
 // conv1x1_sm.hip: 1x1 conv + bias + residual on small maps (32x32 tiles, the four waves split K, no ring)

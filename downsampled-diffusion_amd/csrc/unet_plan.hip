@@ -107,6 +107,8 @@ struct ddk_unet {
     bool fold_down_reduce = false;           // Downsample conv's split-K slabs summed by the image-local ResnetBlock behind it (no reduce launch).
                                              // OFF by default: measured 6 us per step SLOWER (each of an image's eight workgroups re-sums the slabs:
                                              // +6.3 / +5.9 us on the two consumers against reduce launches of 5.2 / 4.9 us; tools/fold_ab.py)
+    bool first_gn = true;                    // the first Block's GroupNorm + Mish + shift inside conv_first_kernel's launch (DDK_OPT_FIRST_GROUPNORM),
+                                             // wherever the in-launch GroupNorm of the Winograd convs may run
     int level_chain = 1;                     // bit 0: the whole 4x4 level (ResnetBlocks + attention of downs[-1], mid, ups[0]) as ONE persistent launch
                                              // (level_chain.hip) wherever the in-launch GroupNorm may run (its workgroups wait for each other too);
                                              // bits 1, 2: the two 8x8 levels (downs[-2]; ups[1]) likewise, one launch each -- built, tested,
@@ -431,6 +433,13 @@ extern "C" int ddk_unet_set_option(ddk_unet* u, int option, int value) {
         u->attn_kvctx = value != 0;
         return DDK_OK;
     }
+    if (option == DDK_OPT_FIRST_GROUPNORM) {
+        std::lock_guard<std::mutex> lock(u->mu);
+        if (!u->graphs.empty()) DDK_HIP(hipDeviceSynchronize());
+        drop_graphs(u);
+        u->first_gn = value != 0;
+        return DDK_OK;
+    }
     if (option == DDK_OPT_LEVEL_CHAIN) {
         std::lock_guard<std::mutex> lock(u->mu);
         if (!u->graphs.empty()) DDK_HIP(hipDeviceSynchronize());
@@ -603,6 +612,7 @@ static void res_sizes(const ResW& r, int B, int H, int W, Layout& ly) {
     upd(ly.gn_ws, groupnorm_workspace_bytes(B, H * W, r.co, GROUPS) / 4);
     upd(ly.gn_ws, (size_t)2 * GROUPS * (M / 128 + 1));      // {mean, M2} partials the Winograd conv leaves for GroupNorm
     upd(ly.cl, cl_counter_floats(B) + conv_wino_cluster_ws_floats(B, H, W, r.co));   // cluster GroupNorm: counters, then records
+    if (H * W % 128 == 0 && H * W / 128 <= 8) upd(ly.cl, cl_counter_floats(B) + conv_first_gn_ws_floats(B, H, W));   // ... of the first Block
 }
 
 static void attn_sizes(const AttnW& a, int B, int H, int W, Layout& ly) {
@@ -1161,10 +1171,21 @@ static int forward_core(const ddk_unet& u, const float* P, const float* x, int64
             DDK_TRY(run_level_chain(c, 1, cur, skip, nullptr));
         } else if (l == 0 && fast0) {
             const ResW& r = u.down_res[0];
-            DDK_TRY(conv_first(x, P + r.c1.wf, r.c1.has_bias ? P + r.c1.b : nullptr, raw, gnp, B, H, W, r.ci, r.co, GROUPS,
-                               step ? step->state : nullptr, step ? t : nullptr, st));
-            DDK_TRY(groupnorm_mish_parts(raw, gnp, H * W / 128, P + r.n1.g, P + r.n1.b, c.temb + r.temb_off, u.temb_total, nullptr, a1, B,
-                                         H * W, r.co, GROUPS, GN_EPS, st, c.temb_rows));
+            if (c.allow_cluster && u.first_gn && conv_wino_cluster_device_ok() && conv_first_gn_ok(r.ci, r.co, H, W, GROUPS) &&
+                c.n_cluster < u.cluster_limit) {
+                // round 6: the first Block's GroupNorm + Mish + shift inside the conv's launch (the image's 8 tiles exchange their statistics):
+                // no raw tensor, no GroupNorm-apply launch
+                float* cl = ws + ly.off_cl;
+                DDK_TRY(conv_first_gn(x, P + r.c1.wf, r.c1.has_bias ? P + r.c1.b : nullptr, P + r.n1.g, P + r.n1.b, c.temb + r.temb_off,
+                                      u.temb_total, c.temb_rows, GN_EPS, a1, B, H, W, r.ci, r.co, GROUPS, cl + cl_counter_floats(B),
+                                      reinterpret_cast<unsigned*>(cl), reinterpret_cast<unsigned*>(cl + cl_fail_offset(B)),
+                                      step ? step->state : nullptr, step ? t : nullptr, st));
+            } else {
+                DDK_TRY(conv_first(x, P + r.c1.wf, r.c1.has_bias ? P + r.c1.b : nullptr, raw, gnp, B, H, W, r.ci, r.co, GROUPS,
+                                   step ? step->state : nullptr, step ? t : nullptr, st));
+                DDK_TRY(groupnorm_mish_parts(raw, gnp, H * W / 128, P + r.n1.g, P + r.n1.b, c.temb + r.temb_off, u.temb_total, nullptr, a1, B,
+                                             H * W, r.co, GROUPS, GN_EPS, st, c.temb_rows));
+            }
             ddk_conv_args a{};
             a.kind = DDK_CONV3X3_S1;
             a.src0 = a1; a.c0 = r.co;

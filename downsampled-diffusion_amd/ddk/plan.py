@@ -103,6 +103,7 @@ class UnetPlan:
     OPT_FOLD_DOWNSAMPLE_REDUCE = 5
     OPT_ATTENTION_KV_CONTEXT = 6
     OPT_LEVEL_CHAIN = 7
+    OPT_FIRST_GROUPNORM = 8
 
     def set_option(self, option, value):
         """ddk_unet_set_option: e.g. (OPT_CLUSTER_GROUPNORM, 0) keeps conv + GroupNorm-apply as two launches

@@ -363,6 +363,10 @@ int ddk_unet_forward(const ddk_unet* u, const void* packed, const float* x, cons
  * (ddk_unet_cluster_check -> DDK_ERR_CLUSTER).  Values: 0 off, 1 the 4x4 level (default), 3 also the two 8x8 levels (downs[-2], ups[1]: one
  * launch each; built and tested, measured slower on MI355X at batch 32 -- a hop moves 64 KB per image and workgroup there), 4 only those. */
 #define DDK_OPT_LEVEL_CHAIN 7
+/* DDK_OPT_FIRST_GROUPNORM (default 1): the network's first Block (conv on the <= 8-channel input, reference models/unet/blocks.py:74-84)
+ * finishes its GroupNorm + Mish + time shift inside the conv's own launch -- the eight 128-pixel tiles of an image exchange their statistics
+ * as the Winograd convs of DDK_OPT_CLUSTER_GROUPNORM do -- wherever that option lets the exchange run; 0 keeps conv + GroupNorm-apply. */
+#define DDK_OPT_FIRST_GROUPNORM 8
 int ddk_unet_set_option(ddk_unet* u, int option, int value);
 /* Waits for `s`, then reads and clears the sticky give-up count of the launches issued on `workspace` (a ddk_unet_forward or
  * ddk_sampler_run workspace of this shape): DDK_OK, or DDK_ERR_CLUSTER when any in-launch GroupNorm exchange timed out. */

@@ -608,3 +608,29 @@ def test_level_chain_in_the_sampler_matches_the_unchained_chain():
     assert torch.isfinite(outs[1]).all()
     assert not torch.equal(outs[0], outs[1])
     assert float((outs[0] - outs[1]).abs().max()) < 1e-4 * float(outs[0].abs().max())
+
+
+@pytest.mark.parametrize("in_ch,batch", [(8, 32), (3, 5), (1, 40)])
+def test_first_block_groupnorm_in_launch_option_gives_the_same_unet(in_ch, batch):
+    """plan option DDK_OPT_FIRST_GROUPNORM (conv_first_kernel<C, true>): the first Block's GroupNorm + Mish + time shift finished inside
+    the conv's launch (the eight 128-pixel tiles of an image exchange their statistics) against conv + GroupNorm-apply: <= 2e-5 of
+    the output's max, not the same bits, bit-stable across launches with other data in between, no wait timed out (blocks.py:74-84)"""
+    from ddk import ops
+    from utils import synthetic as syn
+    net = _chain_net(in_ch)
+    x = syn.synthetic_normal((batch, in_ch, 32, 32), f"firstgn.x{batch}").to(DEV)
+    x2 = syn.synthetic_normal((batch, in_ch, 32, 32), f"firstgn.y{batch}").to(DEV)
+    t = (torch.arange(batch, device=DEV) * 37) % 1000
+    with torch.no_grad():
+        plan = net.plan()
+        plan.set_option(plan.OPT_CLUSTER_GROUPNORM, 2)
+        before = ops.cluster_timeouts()
+        y_on = net(x, t)
+        y_other = net(x2, t)
+        y_on2 = net(x, t)
+        plan.set_option(plan.OPT_FIRST_GROUPNORM, 0)
+        y_off = net(x, t)
+        plan.set_option(plan.OPT_FIRST_GROUPNORM, 1)
+    assert plan._cluster == 2 and ops.cluster_timeouts() == before
+    assert torch.isfinite(y_on).all() and torch.equal(y_on, y_on2) and not torch.equal(y_on, y_other)
+    assert rel_err(y_on.cpu(), y_off.cpu()) < 2e-5
