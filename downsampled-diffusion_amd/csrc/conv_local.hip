@@ -630,6 +630,27 @@ __global__ __launch_bounds__(256) void pack_conv_weight_local_kernel(const float
     }
 }
 
+// ConvTranspose2d(4, stride 2, padding 1) filter w_T [I][O][4][4] in the operand order of the level chain's CH_UPT op (level_chain.hip):
+// dst[n tile][phase = 2 py + px][tap = 2 ty + tx][chunk][n block][k half][lane][j] = w_T[i][o][ky][kx] with (o, i) decoded as above and
+// ky = py == 0 ? (ty == 0 ? 1 : 3) : (ty == 0 ? 0 : 2) (the input row offsets 0, -1 / +1, 0 of chain_upt), kx likewise from (px, tx)
+__global__ __launch_bounds__(256) void pack_convT_weight_local_kernel(const float* __restrict__ w, float* __restrict__ dst, int I, int O,
+                                                                      long long total) {
+    const int nch = I >> 5;
+    for (long long idx = blockIdx.x * 256LL + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int j = (int)(idx & 3), lane = (int)((idx >> 2) & 63), half = (int)((idx >> 8) & 1), nb = (int)((idx >> 9) & 1);
+        long long r = idx >> 10;
+        const int chunk = (int)(r % nch); r /= nch;
+        const int tp = (int)(r & 3); r >>= 2;
+        const int ph = (int)(r & 3);
+        const int nt = (int)(r >> 2);
+        const int o = nt * 32 + nb * 16 + (lane & 15);
+        const int i = chunk * 32 + (lane >> 4) * 8 + half * 4 + j;
+        const int py = ph >> 1, px = ph & 1, ty = tp >> 1, tx = tp & 1;
+        const int ky = py == 0 ? (ty == 0 ? 1 : 3) : (ty == 0 ? 0 : 2), kx = px == 0 ? (tx == 0 ? 1 : 3) : (tx == 0 ? 0 : 2);
+        dst[idx] = w[(((long long)i * O + o) * 4 + ky) * 4 + kx];
+    }
+}
+
 // Winograd-domain filter U = G g G^T in the operand order of conv3x3_gn_wlocal_kernel:
 // dst[n tile][chunk][position][n block][k half][lane][j], same (o, i) decoding as above.  G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
 __global__ __launch_bounds__(256) void pack_conv_weight_wlocal_kernel(const float* __restrict__ w, float* __restrict__ dst, int O, int I,
@@ -752,6 +773,16 @@ int ddk_pack_conv_weight_local(const float* w_oihw, float* dst, int O, int I, in
     hipLaunchKernelGGL(pack_conv_weight_local_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, as_stream(s), w_oihw,
                        dst, O, I, i_pad, total, 9);
     return check_launch("pack_conv_weight_local_kernel");
+}
+
+int ddk_pack_convT_weight_local(const float* w_iohw, float* dst, int I, int O, ddk_stream_t s) {
+    using namespace ddk;
+    DDK_REQUIRE(w_iohw && dst && I > 0 && O > 0 && O % 32 == 0 && I % 32 == 0, "pack_convT_weight_local: arguments (I % 32 == 0, O % 32 == 0)");
+    const long long total = (long long)O * 16 * I;
+    const long long blocks = ceil_div(total, 256);
+    hipLaunchKernelGGL(pack_convT_weight_local_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, as_stream(s), w_iohw,
+                       dst, I, O, total);
+    return check_launch("pack_convT_weight_local_kernel");
 }
 
 int ddk_pack_conv1x1_weight_local(const float* w_oi, float* dst, int O, int I, int i_pad, ddk_stream_t s) {

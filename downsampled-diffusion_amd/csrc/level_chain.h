@@ -9,7 +9,8 @@ constexpr int CH_MAX_OPS = 24;
 enum ChainKind {
     CH_CONV3 = 0,   // conv3x3(pad 1) + bias -> GroupNorm(32 channels = this workgroup's slice) -> Mish (+ time shift) (+ kept residual)
     CH_CONV1 = 1,   // conv1x1 + bias (+ kept residual)
-    CH_ATTN = 2     // LayerNorm-folded to_qkv of one head + softmax_n(k) + context + apply (workgroups 0..3 of the image; 4..7 pass)
+    CH_ATTN = 2,    // LayerNorm-folded to_qkv of one head + softmax_n(k) + context + apply (workgroups 0..3 of the image; 4..7 pass)
+    CH_UPT = 3      // ConvTranspose2d(4, stride 2, padding 1) + bias, 4x4 -> 8x8 (blocks.py:32-38): four output phases of 2 x 2 taps each
 };
 enum ChainFlag {
     CHF_WAIT = 1,           // the sources were written in this launch by the image's other workgroups: wait for every signal so far
@@ -19,7 +20,9 @@ enum ChainFlag {
     CHF_ADD_KEEP2 = 16,     // y += keep2     (the 1x1 skip conv of a ResnetBlock whose channel count changes)
     CHF_SAVE_KEEP2 = 32,    // keep2 = y
     CHF_KEEP_FROM_SRC = 64, // keep = src0's element at this thread's output position (the chain's external input)
-    CHF_NO_OUT = 128        // nothing is stored (the result only lives in keep2)
+    CHF_NO_OUT = 128,       // nothing is stored (the result only lives in keep2)
+    CHF_NO_GN = 256,        // CH_CONV3 without the GroupNorm + Mish behind it: a plain conv3x3 + bias
+    CHF_DOWN = 512          // CH_CONV3 with stride 2 (blocks.py:41-47): the source is the 8x8 map [B][64][c0], the output the 4x4 one
 };
 
 struct ChainOp {

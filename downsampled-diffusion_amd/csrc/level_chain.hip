@@ -24,12 +24,14 @@
 #include <atomic>
 #include <cstdlib>
 #include <type_traits>
+#include <utility>
 
 namespace ddk {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int LC_BIG = 12800;              // floats: image [17][cin + 4] (cin <= 512) | conv partials 8 x 16 x 36 | attention partials 8 x 16 x 100
+constexpr int LC_BIG = 18432;              // floats: image [17][cin + 4] (cin <= 512) or the 8x8 source of a stride-2 conv [65][260] | conv partials
+                                           // 8 x 16 x 36 (transpose conv: 8 x 64 x 36) | attention partials 8 x 16 x 100
 constexpr int LC_PP = 36;                  // conv partial row pitch
 constexpr int LC_QP = 100;                 // attention partial row pitch (96 columns + 4)
 constexpr int LC_RED = LC_BIG;             // 64
@@ -45,8 +47,8 @@ constexpr int LC_MISC = LC_CFOLD + 192;    // [0] this workgroup gave up waiting
 constexpr int LC_PF = LC_MISC + 4;         // 256 floats nobody reads: where the L2 prefetch's LDS-DMA pieces land
 constexpr int LC_FLOATS = LC_PF + 256;
 
-size_t level_chain_lds_bytes() { return 96 * 1024; }     // > 80 KB: one workgroup per CU
-static_assert(LC_FLOATS * 4 <= 96 * 1024, "LDS carve-up");
+size_t level_chain_lds_bytes() { return 100 * 1024; }    // > 80 KB: one workgroup per CU
+static_assert(LC_FLOATS * 4 <= 100 * 1024, "LDS carve-up");
 
 // ---- memory-side helpers: 16-byte sc1 loads -- issue and wait in ONE asm statement, so that no compiler-made copy can ever sit
 //      between a load and the wait that makes its destination valid -- and stores
@@ -92,6 +94,11 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {
     const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
     return (r0 + r1) + (r2 + r3);
 }
+
+template <int... I, class F>
+__device__ __forceinline__ void static_for_lc_impl(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for_lc(F&& f) { static_for_lc_impl(std::make_integer_sequence<int, N>{}, f); }
 
 struct ChainCtx {
     float* lds;
@@ -142,7 +149,7 @@ __device__ __forceinline__ void chain_prefetch(const ChainOp& o, const ChainCtx&
         base = o.w + (size_t)c.nt * (cin >> 5) * 3072;
         lines = (cin >> 5) * 3072 / 32;
     } else {
-        const int taps = o.kind == CH_CONV3 ? c.units3 : 1;
+        const int taps = o.kind == CH_CONV3 ? c.units3 : o.kind == CH_UPT ? 16 : 1;
         base = o.w + (size_t)c.nt * taps * (cin >> 5) * 1024;
         lines = taps * (cin >> 5) * 1024 / 32;
     }
@@ -217,6 +224,20 @@ __device__ __forceinline__ void chain_stage(const ChainOp& o, ChainCtx& c, int c
     if (c.tid < q4) *reinterpret_cast<f32x4*>(c.lds + 16 * pitch + (c.tid << 2)) = f32x4{0.f, 0.f, 0.f, 0.f};   // the row out-of-image taps read
 }
 
+// the 8x8 source map of a stride-2 conv: [64 rows][256] of image b -> LDS rows of pitch 260, row 64 = zeros; 8 x 16 bytes per thread
+__device__ __forceinline__ void chain_stage64(const ChainOp& o, ChainCtx& c) {
+    const float* src = o.src0 + (long long)c.b * 64 * 256;
+#pragma unroll
+    for (int r0 = 0; r0 < 4096; r0 += 2048) {
+        f32x4 v0, v1, v2, v3;
+        ld_sc1_x4(v0, v1, v2, v3, src + (size_t)(r0 + c.tid) * 4, src + (size_t)(r0 + c.tid + 512) * 4, src + (size_t)(r0 + c.tid + 1024) * 4,
+                  src + (size_t)(r0 + c.tid + 1536) * 4);
+        auto put = [&](int idx, f32x4 v) { *reinterpret_cast<f32x4*>(c.lds + (idx >> 6) * 260 + ((idx & 63) << 2)) = v; };
+        put(r0 + c.tid, v0); put(r0 + c.tid + 512, v1); put(r0 + c.tid + 1024, v2); put(r0 + c.tid + 1536, v3);
+    }
+    if (c.tid < 64) *reinterpret_cast<f32x4*>(c.lds + 64 * 260 + (c.tid << 2)) = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
 // CH_CONV3 / CH_CONV1.  The arithmetic of conv3x3_gn_local_kernel<16, 1, NU> (conv_local.hip): direct conv on v_mfma_f32_16x16x4_f32,
 // the 8 waves split k = taps x 32-channel chunks, weights straight from L2 into registers in MFMA operand order (three units in
 // flight), partial tiles meet in LDS, GroupNorm over the slice (32 channels x 16 pixels = one group) in two passes.
@@ -254,7 +275,7 @@ __device__ __forceinline__ void chain_conv(const ChainParams& p, const ChainOp& 
     const int col = tid & 31, row = tid >> 5;
     const int ch = n0 + col;
     float ga = 1.f, be = 0.f, sh = 0.f;
-    if (o.kind == CH_CONV3) { ga = o.gamma[ch]; be = o.beta[ch]; }
+    if (o.kind == CH_CONV3 && !(o.flags & CHF_NO_GN)) { ga = o.gamma[ch]; be = o.beta[ch]; }
     if (o.temb_off >= 0) {
         const long long tr = p.temb_rows ? p.temb_rows[c.b] : c.b;
         sh = p.temb[tr * p.temb_stride + o.temb_off + ch];
@@ -262,12 +283,14 @@ __device__ __forceinline__ void chain_conv(const ChainParams& p, const ChainOp& 
     const float cb = o.bias ? o.bias[ch] : 0.f;
     if (o.flags & CHF_KEEP_FROM_SRC) c.keep = o.src0[((long long)c.b * 16 + row) * o.c0 + ch];
     if (c.k + 1 < p.n_ops) chain_prefetch(p.op[c.k + 1], c);
+    const bool down = NU == 1 && (o.flags & CHF_DOWN);      // stride 2: the source is the 8x8 map
 
     LC_STAMP(c, c.k, 0);
     if (o.flags & CHF_WAIT) chain_wait(p, c);
     else __syncthreads();                 // a wave may still be reading the previous op's partial tiles: the image lands on them
     LC_STAMP(c, c.k, 1);
-    chain_stage(o, c, cin, pitch);        // (its vmcnt(0) also drains the prefetch pieces)
+    if (down) chain_stage64(o, c);
+    else chain_stage(o, c, cin, pitch);   // (its vmcnt(0) also drains the prefetch pieces)
     __syncthreads();
     LC_STAMP(c, c.k, 2);
 
@@ -279,9 +302,15 @@ __device__ __forceinline__ void chain_conv(const ChainParams& p, const ChainOp& 
         int a_tap[9];
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
-            const int yy = py + t / 3 - 1, xx = px + t % 3 - 1;
-            const bool ok = (unsigned)yy < 4u && (unsigned)xx < 4u;
-            a_tap[t] = (ok ? yy * 4 + xx : 16) * pitch + kq * 8 + (wave << 5);
+            if (down) {                   // output pixel (py, px) of the 4x4 map reads input pixel (2 py + dy, 2 px + dx) of the 8x8 one
+                const int yy = 2 * py + t / 3 - 1, xx = 2 * px + t % 3 - 1;
+                const bool ok = (unsigned)yy < 8u && (unsigned)xx < 8u;
+                a_tap[t] = (ok ? yy * 8 + xx : 64) * pitch + kq * 8 + (wave << 5);
+            } else {
+                const int yy = py + t / 3 - 1, xx = px + t % 3 - 1;
+                const bool ok = (unsigned)yy < 4u && (unsigned)xx < 4u;
+                a_tap[t] = (ok ? yy * 4 + xx : 16) * pitch + kq * 8 + (wave << 5);
+            }
         }
         auto compute_at = [&](int t, int sub, const float4 (&bq)[2][2]) {
             const float* ap = lds + a_tap[t] + sub * 256;
@@ -346,7 +375,7 @@ __device__ __forceinline__ void chain_conv(const ChainParams& p, const ChainOp& 
     for (int w = 1; w < 8; ++w) v += lds[(w * 16 + row) * LC_PP + col];
     v += cb;
     float y = v;
-    if (o.kind == CH_CONV3) {
+    if (o.kind == CH_CONV3 && !(o.flags & CHF_NO_GN)) {
         // GroupNorm of the slice = one group of 32 channels x 16 pixels.  Each wave: mean and M2 of its own 64 values (two passes inside
         // the wave); the eight {mean, M2} records merge exactly (Chan et al.) behind ONE barrier.
         float* red = lds + LC_RED;
@@ -368,6 +397,116 @@ __device__ __forceinline__ void chain_conv(const ChainParams& p, const ChainOp& 
     }
     chain_finish(p, o, c, y, n0);
     if (o.flags & CHF_SIGNAL) ++c.signals;
+    LC_STAMP(c, c.k, 4);
+}
+
+// CH_UPT: ConvTranspose2d(C, C, 4, stride 2, padding 1) + bias on the 4x4 map -> 8x8 (blocks.py:32-38).  out[2y + py][2x + px] only gets
+// input rows y + dy with ky = 2y + py + 1 - 2 (y + dy) in [0, 4): py = 0 -> (dy 0, ky 1), (dy -1, ky 3); py = 1 -> (dy +1, ky 0), (dy 0, ky 2)
+// -- and the same along x: four output phases, each a 2 x 2-tap stride-1 conv of the 4x4 map = a [16 x 4 C] x [4 C x 32] product per
+// workgroup.  Wave w takes chunk w of every (phase, tap): 16 units of 16 MFMAs; filter in operand order [slice][phase][tap][chunk][1024]
+// (ddk_pack_convT_weight_local).  Thread (pixel, channel) ends up with the pixel's four phase outputs = a 2 x 2 block of the 8x8 map.
+__device__ __forceinline__ void chain_upt(const ChainParams& p, const ChainOp& o, ChainCtx& c) {
+    float* lds = c.lds;
+    const int tid = c.tid, lane = c.lane, wave = c.wave;
+    const int m = lane & 15, kq = lane >> 4;
+    const int n0 = c.nt << 5;
+    const int cin = o.c0, pitch = cin + 4, nch = cin >> 5;          // cin = 256: 8 chunks = one per wave
+    const float* wl = o.w + ((size_t)c.nt * 16 * nch + wave) * 1024 + lane * 4;      // unit u = (phase * 4 + tap) * nch + chunk
+    float4 bA[2][2], bB[2][2], bC[2][2];
+    int lu = 0;
+    auto load_b = [&](float4 (&bq)[2][2]) {
+        const float* wp = wl + (size_t)(lu < 16 ? lu : 15) * nch * 1024;
+        bq[0][0] = *reinterpret_cast<const float4*>(wp);
+        bq[0][1] = *reinterpret_cast<const float4*>(wp + 256);
+        bq[1][0] = *reinterpret_cast<const float4*>(wp + 512);
+        bq[1][1] = *reinterpret_cast<const float4*>(wp + 768);
+        ++lu;
+    };
+    load_b(bA);
+    load_b(bB);
+    load_b(bC);
+    const int col = tid & 31, row = tid >> 5;
+    const float cb = o.bias ? o.bias[n0 + col] : 0.f;
+    if (c.k + 1 < p.n_ops) chain_prefetch(p.op[c.k + 1], c);
+    LC_STAMP(c, c.k, 0);
+    if (o.flags & CHF_WAIT) chain_wait(p, c);
+    else __syncthreads();
+    LC_STAMP(c, c.k, 1);
+    chain_stage(o, c, cin, pitch);
+    __syncthreads();
+    LC_STAMP(c, c.k, 2);
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int ph = 0; ph < 4; ++ph) acc[ph][0] = acc[ph][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int y = m >> 2, x = m & 3;
+    auto unit = [&](auto phc, auto tpc, const float4 (&bq)[2][2]) {
+        constexpr int ph = decltype(phc)::value, tp = decltype(tpc)::value;
+        constexpr int pyy = ph >> 1, pxx = ph & 1, ty = tp >> 1, tx = tp & 1;
+        constexpr int dy = pyy == 0 ? (ty == 0 ? 0 : -1) : (ty == 0 ? 1 : 0);
+        constexpr int dx = pxx == 0 ? (tx == 0 ? 0 : -1) : (tx == 0 ? 1 : 0);
+        const int yy = y + dy, xx = x + dx;
+        const bool ok = (unsigned)yy < 4u && (unsigned)xx < 4u;
+        const float* ap = lds + (ok ? yy * 4 + xx : 16) * pitch + (wave << 5) + kq * 8;
+        const float4 a0 = *reinterpret_cast<const float4*>(ap), a1 = *reinterpret_cast<const float4*>(ap + 4);
+        const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            acc[ph][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kk], reinterpret_cast<const float*>(&bq[0][0])[kk], acc[ph][0], 0, 0, 0);
+            acc[ph][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kk], reinterpret_cast<const float*>(&bq[1][0])[kk], acc[ph][1], 0, 0, 0);
+        }
+    };
+    static_for_lc<16>([&](auto uc) {
+        constexpr int u = decltype(uc)::value;
+        using PH = std::integral_constant<int, u / 4>;
+        using TP = std::integral_constant<int, u % 4>;
+        if constexpr (u % 3 == 0) { unit(PH{}, TP{}, bA); load_b(bA); }
+        else if constexpr (u % 3 == 1) { unit(PH{}, TP{}, bB); load_b(bB); }
+        else { unit(PH{}, TP{}, bC); load_b(bC); }
+    });
+    LC_STAMP(c, c.k, 3);
+    __syncthreads();
+#pragma unroll
+    for (int ph = 0; ph < 4; ++ph)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) lds[((wave * 4 + ph) * 16 + kq * 4 + r) * LC_PP + nb * 16 + m] = acc[ph][nb][r];
+    __syncthreads();
+    float yv[4];
+#pragma unroll
+    for (int ph = 0; ph < 4; ++ph) {
+        float s = lds[(ph * 16 + row) * LC_PP + col];
+#pragma unroll
+        for (int w = 1; w < 8; ++w) s += lds[((w * 4 + ph) * 16 + row) * LC_PP + col];
+        yv[ph] = s + cb;
+    }
+    {   // the four lanes of a quad hold four consecutive channels: lane j stores phase j's pixel as 16 bytes
+        float g[4][4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int yb = __builtin_bit_cast(int, yv[k]);
+            g[k][0] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, yb, 0x00, 0xF, 0xF, true));
+            g[k][1] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, yb, 0x55, 0xF, 0xF, true));
+            g[k][2] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, yb, 0xAA, 0xF, 0xF, true));
+            g[k][3] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, yb, 0xFF, 0xF, 0xF, true));
+        }
+        const int j = lane & 3;
+        f32x4 v;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = j == 0 ? g[0][q] : j == 1 ? g[1][q] : j == 2 ? g[2][q] : g[3][q];
+        const int oy = 2 * (row >> 2) + (j >> 1), ox = 2 * (row & 3) + (j & 1);
+        float* dst = o.out + ((long long)c.b * 64 + oy * 8 + ox) * o.n_out + n0 + (col & ~3);
+        if (o.flags & CHF_SIGNAL) st_sc1(dst, v);
+        else *reinterpret_cast<f32x4*>(dst) = v;
+    }
+    if (o.flags & CHF_SIGNAL) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) {
+            unsigned* lcnt = reinterpret_cast<unsigned*>(c.misc) + 1;
+            if ((atomicAdd(lcnt, 1u) & 7u) == 7u) __hip_atomic_fetch_add(p.cnt + c.b * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        ++c.signals;
+    }
     LC_STAMP(c, c.k, 4);
 }
 
@@ -554,6 +693,7 @@ __global__ __launch_bounds__(512) void level_chain_kernel(const ChainParams p) {
             const ChainOp& o = p.op[k];
             c.k = k;
             if (o.kind == CH_ATTN) chain_attn(p, o, c);
+            else if (o.kind == CH_UPT) chain_upt(p, o, c);
             else if (o.kind == CH_CONV1) chain_conv<0>(p, o, c);
             else if (o.c0 + o.c1 == 256) chain_conv<1>(p, o, c);
             else if (o.c0 + o.c1 == 512) chain_conv<2>(p, o, c);
@@ -1154,7 +1294,9 @@ int level_chain_launch(const ChainParams& p, hipStream_t st) {
         }
         DDK_REQUIRE((o.flags & CHF_NO_OUT) || o.out, "level_chain: op output");
         if (o.kind == CH_ATTN) DDK_REQUIRE(o.c1 == 0 && o.n_out == 128 && o.gamma && o.beta, "level_chain: attention op");
-        else DDK_REQUIRE(o.n_out == 256 && (o.kind != CH_CONV3 || (o.gamma && o.beta)), "level_chain: conv op (8 slices of 32 channels)");
+        else DDK_REQUIRE(o.n_out == 256 && (o.kind != CH_CONV3 || (o.flags & CHF_NO_GN) || (o.gamma && o.beta)), "level_chain: conv op (8 slices of 32 channels)");
+        if (o.flags & CHF_DOWN) DDK_REQUIRE(p.hw == 16 && o.kind == CH_CONV3 && cin == 256 && o.c1 == 0, "level_chain: stride-2 conv (4x4 chain, 256 channels)");
+        if (o.kind == CH_UPT) DDK_REQUIRE(p.hw == 16 && cin == 256 && o.c1 == 0, "level_chain: transpose conv (4x4 chain, 256 channels)");
     }
     DDK_TRY(ensure_device_init());
     const int slots = p.B < 32 ? p.B : 32;

@@ -26,7 +26,8 @@ constexpr float GN_EPS = 1e-5f, LN_EPS = 1e-5f;
 static inline int pad32(int c) { return (c + 31) / 32 * 32; }
 
 enum PackKind { PK_COPY = 0, PK_CONV = 1, PK_CONVT = 2, PK_LINEAR_T = 3, PK_WINO = 4, PK_LOCAL = 5, PK_WLOCAL = 6, PK_FIRST = 7, PK_CONVT_WINO = 8,
-                PK_ROWS = 9 /* [O][I] rows into rows of pitch ld */, PK_LOCAL1 = 10 /* a 1x1 filter in conv_local.hip's operand order */ };
+                PK_ROWS = 9 /* [O][I] rows into rows of pitch ld */, PK_LOCAL1 = 10 /* a 1x1 filter in conv_local.hip's operand order */,
+                PK_CONVT_LOCAL = 11 /* a transpose-conv filter in the level chain's operand order */ };
 
 struct Slot {
     std::string name;
@@ -52,6 +53,8 @@ struct ConvW {
     bool has_wf = false;
     size_t wl1 = 0;         // a 1x1 filter (to_out, res_conv) in conv_local.hip's operand order, one tap: the level chain's 1x1 ops
     bool has_wl1 = false;
+    size_t wtl = 0;         // a transpose-conv filter in the level chain's operand order (CH_UPT); has_wtl
+    bool has_wtl = false;
 };
 struct NormW { size_t g = 0, b = 0; int c_real = 0; };
 struct ResW {
@@ -109,8 +112,10 @@ struct ddk_unet {
                                              // +6.3 / +5.9 us on the two consumers against reduce launches of 5.2 / 4.9 us; tools/fold_ab.py)
     bool first_gn = true;                    // the first Block's GroupNorm + Mish + shift inside conv_first_kernel's launch (DDK_OPT_FIRST_GROUPNORM),
                                              // wherever the in-launch GroupNorm of the Winograd convs may run
-    int level_chain = 1;                     // bit 0: the whole 4x4 level (ResnetBlocks + attention of downs[-1], mid, ups[0]) as ONE persistent launch
+    int level_chain = 9;                     // bit 0: the whole 4x4 level (ResnetBlocks + attention of downs[-1], mid, ups[0]) as ONE persistent launch
                                              // (level_chain.hip) wherever the in-launch GroupNorm may run (its workgroups wait for each other too);
+                                             // bit 3: ... with the Downsample conv in front of it and the Upsample transpose conv behind it inside
+                                             // the same launch (8x8 -> 4x4 -> ... -> 4x4 -> 8x8: two igemm + slab-reduce pairs less);
                                              // bits 1, 2: the two 8x8 levels (downs[-2]; ups[1]) likewise, one launch each -- built, tested,
                                              // OFF by default: measured 100 us per step SLOWER (150 + 170 us against 104 + 125 for the 16
                                              // launches: a hop moves a 64 KB image to each of 8 workgroups, 5 us of staging and 7 us of
@@ -150,7 +155,7 @@ struct ddk_unet {
         slots.push_back(Slot{name, n, PK_COPY, off, 0, 0, 0, 0, 0, 0, 0});
     }
     // split > 0: the cin input channels are the concat of two sources of `split` and cin - split channels, each padded to 32 on its own
-    ConvW add_conv(const std::string& prefix, int cout, int cin, int k, bool bias, bool gn_follows = false, int split = 0) {
+    ConvW add_conv(const std::string& prefix, int cout, int cin, int k, bool bias, bool gn_follows = false, int split = 0, bool local = false) {
         ConvW c;
         c.cin = cin; c.cin_pad = split > 0 ? pad32(split) + pad32(cin - split) : pad32(cin); c.cout = cout;
         const int cout_rows = pad32(cout);          // rows beyond cout stay zero (the arena is zero-filled): N as the kernels see it
@@ -176,12 +181,13 @@ struct ddk_unet {
             c.has_wu = true;
             slots.push_back(Slot{prefix + "weight", (long long)cout * cin * k * k, PK_WINO, c.wu, cout, cin, k, k, c.cin_pad, 0, 0});
         }
-        if (k == 3 && gn_follows && cout % 32 == 0) {
-            // and a third for the one-launch conv + GroupNorm kernel of the 4x4 maps (its MFMA operand order)
+        if (k == 3 && (gn_follows || local) && cout % 32 == 0) {
+            // and a third for the one-launch conv + GroupNorm kernel of the 4x4 maps (its MFMA operand order; `local`: the Downsample conv
+            // the level chain absorbs)
             c.wl = alloc((size_t)9 * cout * c.cin_pad);
             c.has_wl = true;
             slots.push_back(Slot{prefix + "weight", (long long)cout * cin * k * k, PK_LOCAL, c.wl, cout, cin, k, k, c.cin_pad, 0, 0});
-            if (c.cin_pad <= 320 || c.cin_pad == 512) {     // (512: the 8x8 level chain walks the concat input as two staged halves)
+            if (gn_follows && (c.cin_pad <= 320 || c.cin_pad == 512)) {     // (512: the 8x8 level chain walks the concat input as two staged halves)
                 c.wwl = alloc((size_t)16 * cout * c.cin_pad);
                 c.has_wwl = true;
                 slots.push_back(Slot{prefix + "weight", (long long)cout * cin * k * k, PK_WLOCAL, c.wwl, cout, cin, k, k, c.cin_pad, 0, 0});
@@ -189,7 +195,7 @@ struct ddk_unet {
         }
         return c;
     }
-    ConvW add_convT(const std::string& prefix, int ch) {
+    ConvW add_convT(const std::string& prefix, int ch, bool local = false) {
         ConvW c;
         c.cin = ch; c.cin_pad = pad32(ch); c.cout = ch;
         c.w = alloc((size_t)16 * pad32(ch) * pad32(ch));
@@ -197,6 +203,12 @@ struct ddk_unet {
         c.has_bias = true;
         c.b = alloc((size_t)pad32(ch));
         slots.push_back(Slot{prefix + "bias", ch, PK_COPY, c.b, 0, 0, 0, 0, 0, 0, 0});
+        if (local && ch % 32 == 0 && !generic) {
+            // ... in the level chain's operand order (four phases x 2 x 2 taps: level_chain.hip, CH_UPT)
+            c.wtl = alloc((size_t)16 * ch * ch);
+            c.has_wtl = true;
+            slots.push_back(Slot{prefix + "weight", (long long)16 * ch * ch, PK_CONVT_LOCAL, c.wtl, ch, ch, 4, 4, ch, 0, 0});
+        }
         if (ch % 128 == 0) {
             // the same tensor's Winograd F(2x2, 2x2) form, four phases x 9 positions (conv_winoT_kernel.inc)
             c.wu = alloc((size_t)36 * ch * ch);
@@ -325,7 +337,7 @@ extern "C" ddk_unet* ddk_unet_create(const ddk_unet_config* cfg) {
         }
         u->down_res.push_back(u->add_res(p + "1.", co, co, cur));
         u->down_attn.push_back(u->add_attn(p + "2.", co));
-        if (l < u->L - 1) u->down_conv.push_back(u->add_conv(p + "3.conv.", co, co, 3, true));
+        if (l < u->L - 1) u->down_conv.push_back(u->add_conv(p + "3.conv.", co, co, 3, true, false, 0, /*local=*/l == u->L - 2));
     }
     const int mid = u->dims[u->L];
     u->mid1 = u->add_res("mid_block1.", mid, mid, cur);
@@ -337,7 +349,7 @@ extern "C" ddk_unet* ddk_unet_create(const ddk_unet_config* cfg) {
         u->up_res.push_back(u->add_res(p + "0.", 2 * dout, din, cur, dout));
         u->up_res.push_back(u->add_res(p + "1.", din, din, cur));
         u->up_attn.push_back(u->add_attn(p + "2.", din));
-        u->up_conv.push_back(u->add_convT(p + "3.conv.", din));
+        u->up_conv.push_back(u->add_convT(p + "3.conv.", din, /*local=*/i == 0));
     }
     u->final_conv = u->add_conv("final_conv.0.block.0.", cfg->chan, cfg->chan, 3, true, true);
     u->final_norm = u->add_norm("final_conv.0.block.1.weight", "final_conv.0.block.1.bias", cfg->chan);
@@ -444,8 +456,9 @@ extern "C" int ddk_unet_set_option(ddk_unet* u, int option, int value) {
         std::lock_guard<std::mutex> lock(u->mu);
         if (!u->graphs.empty()) DDK_HIP(hipDeviceSynchronize());
         drop_graphs(u);
-        // 0 off, 1 (default) / 2: the 4x4 level, 3: the 8x8 levels as well, 4: the 8x8 levels only, 8 / 16: only downs[-2] / only ups[1]
-        u->level_chain = value == 1 || value == 2 ? 1 : value == 3 ? 7 : value == 4 ? 6 : value == 8 ? 2 : value == 16 ? 4 : value != 0 ? 1 : 0;
+        // 0 off, 1 (default): the 4x4 level with its Downsample / Upsample convs, 2: the 4x4 level alone, 3: the 8x8 levels as well,
+        // 4: the 8x8 levels only, 8 / 16: only downs[-2] / only ups[1]
+        u->level_chain = value == 1 ? 9 : value == 2 ? 1 : value == 3 ? 15 : value == 4 ? 6 : value == 8 ? 2 : value == 16 ? 4 : value != 0 ? 9 : 0;
         return DDK_OK;
     }
     if (option == DDK_OPT_FOLD_DOWNSAMPLE_REDUCE) {
@@ -545,6 +558,7 @@ extern "C" int ddk_unet_pack_slot(const ddk_unet* u, int slot, const float* cano
         case PK_WINO: rc = ddk_pack_conv_weight_wino(canonical, dst, sl.O, sl.I, sl.i_pad, s); break;
         case PK_LOCAL: rc = ddk_pack_conv_weight_local(canonical, dst, sl.O, sl.I, sl.i_pad, s); break;
         case PK_LOCAL1: rc = ddk_pack_conv1x1_weight_local(canonical, dst, sl.O, sl.I, sl.i_pad, s); break;
+        case PK_CONVT_LOCAL: rc = ddk_pack_convT_weight_local(canonical, dst, sl.I, sl.O, s); break;
         case PK_WLOCAL: rc = ddk_pack_conv_weight_wino_local(canonical, dst, sl.O, sl.I, sl.i_pad, s); break;
         case PK_FIRST: rc = ddk_pack_conv_weight_first(canonical, dst, sl.O, sl.I, s); break;
         case PK_CONVT_WINO: rc = ddk_pack_convT_weight_wino(canonical, dst, sl.I, sl.O, sl.i_pad, s); break;
@@ -600,7 +614,7 @@ static size_t conv3_ws_floats(const ConvW& cw, int B, int H, int W, int cin, int
 static size_t cl_counter_floats(int B) { return (size_t)B * 8 * 16 + 16 + (size_t)B * 64; }
 static size_t cl_fail_offset(int B) { return (size_t)B * 8 * 16; }
 static size_t cl_chain_offset(int B) { return (size_t)B * 8 * 16 + 16; }
-constexpr int CHAIN_BUFS = 16;                // activations that cross workgroups inside the level chain, [B][16][256] each
+constexpr int CHAIN_BUFS = 18;                // activations that cross workgroups inside the level chain, [B][16][256] each
 constexpr int CHAIN8_BUFS = 5;                // ... inside an 8x8 chain, [B][64][256] each
 
 static void res_sizes(const ResW& r, int B, int H, int W, Layout& ly) {
@@ -979,7 +993,9 @@ static bool level8_chain_use(const Ctx& c, int H0, int W0, int bit) {
     return c.allow_cluster && (c.u.level_chain & bit) && c.ly.chain > 0 && level8_chain_shape_ok(c.u, H0, W0) && level_chain_device_ok();
 }
 
-static int run_level_chain(Ctx& c, int part, const float* in, float* skip, float* out) {
+// down_src != null (part 0): `in` is not used -- the chain starts with the Downsample conv on the 8x8 map down_src (blocks.py:41-47);
+// up_out != null (part 0): the chain ends with the Upsample transpose conv (blocks.py:32-38) into the 8x8 map up_out, `out` is not used
+static int run_level_chain(Ctx& c, int part, const float* in, float* skip, float* out, const float* down_src = nullptr, float* up_out = nullptr) {
     const ddk_unet& u = c.u;
     const int hw = part == 0 ? 16 : 64;
     const bool wino = hw == 64;
@@ -1021,8 +1037,16 @@ static int run_level_chain(Ctx& c, int part, const float* in, float* skip, float
     };
     if (part == 0) {
         const int sh = u.L - 1;
+        if (down_src) {
+            const ConvW& dc = u.down_conv[sh - 1];
+            float* dn = buf(e++);
+            ChainOp& op = p.op[n++];
+            op = ChainOp{down_src, nullptr, c.P + dc.wl, c.P + dc.b, nullptr, nullptr, dn, 256, 0, CH_CONV3,
+                         CHF_DOWN | CHF_NO_GN | CHF_SIGNAL | CHF_SAVE_KEEP, -1, 256};
+            in = dn;
+        }
         float* d0 = buf(e++);
-        res_plain(u.down_res[2 * sh], in, true, d0);
+        res_plain(u.down_res[2 * sh], in, down_src == nullptr, d0);
         float* d1 = buf(e++);
         res_plain(u.down_res[2 * sh + 1], d0, false, d1);
         attn_block(u.down_attn[sh], d1, skip, true);
@@ -1036,7 +1060,15 @@ static int run_level_chain(Ctx& c, int part, const float* in, float* skip, float
         res_cat(u.up_res[0], m2, false, skip, u0);
         float* u1 = buf(e++);
         res_plain(u.up_res[1], u0, false, u1);
-        attn_block(u.up_attn[0], u1, out, false);
+        if (up_out) {
+            float* ua = buf(e++);
+            attn_block(u.up_attn[0], u1, ua, true);
+            const ConvW& uc = u.up_conv[0];
+            ChainOp& op = p.op[n++];
+            op = ChainOp{ua, nullptr, c.P + uc.wtl, c.P + uc.b, nullptr, nullptr, up_out, 256, 0, CH_UPT, CHF_WAIT, -1, 256};
+        } else {
+            attn_block(u.up_attn[0], u1, out, false);
+        }
     } else if (part == 1) {
         const int sh = u.L - 2;
         float* d0 = buf(e++);
@@ -1154,14 +1186,17 @@ static int forward_core(const ddk_unet& u, const float* P, const float* x, int64
     int cur_c = pad32(u.cfg.in_ch);
     AddendSlabs cur_ss;           // > 1 slab: `cur` is the split-K area a Downsample conv left for the next ResnetBlock to sum
     const bool chained = level_chain_use(c, H0, W0);    // the last level (4x4 maps) as one persistent launch
+    const bool chain_edges = chained && (u.level_chain & 8) && u.L >= 2 && u.down_conv[u.L - 2].has_wl && u.down_conv[u.L - 2].has_bias &&
+                             u.up_conv[0].has_wtl && u.up_conv[0].cin == 256 && u.down_conv[u.L - 2].cin == 256;
     const bool chained8 = level8_chain_use(c, H0, W0, 2);   // the level above it (8x8 maps): downs[-2] as one launch,
     const bool chained8u = level8_chain_use(c, H0, W0, 4);  // ups[1] as another
     for (int l = 0; l < u.L; ++l) {
         float* skip = ws + ly.off_skip[l];
         const int co = u.dimp[l + 1];
         if (chained && l == u.L - 1) {
-            // downs[-1] (2 ResnetBlocks + attention), mid_block1, mid_attn, mid_block2, ups[0] (2 ResnetBlocks + attention): 19 launches in one
-            DDK_TRY(run_level_chain(c, 0, cur, skip, bufB));
+            // downs[-1] (2 ResnetBlocks + attention), mid_block1, mid_attn, mid_block2, ups[0] (2 ResnetBlocks + attention): 19 launches in one;
+            // with the Downsample conv in front and the Upsample transpose conv behind (chain_edges): 23 in one
+            DDK_TRY(run_level_chain(c, 0, cur, skip, bufB, chain_edges ? ws + ly.off_skip[l - 1] : nullptr, chain_edges ? bufA : nullptr));
             cur_c = co;
             break;
         }
@@ -1220,7 +1255,10 @@ static int forward_core(const ddk_unet& u, const float* P, const float* x, int64
             DDK_TRY(run_res(c, u.down_res[2 * l + 1], bufB, co, nullptr, 0, bufC, H, W));
             DDK_TRY(run_attn(c, u.down_attn[l], bufC, skip, H, W));
         }
-        if (l < u.L - 1) {
+        if (l < u.L - 1 && chain_edges && l + 1 == u.L - 1) {
+            H /= 2; W /= 2;               // the level chain runs this Downsample conv itself, from `skip`
+            cur = skip;
+        } else if (l < u.L - 1) {
             const int s2 = conv_splits(DDK_CONV3X3_S2, B, H, W, co, co);
             if (u.fold_down_reduce && s2 > 1 && !(chained && l + 1 == u.L - 1) && !(chained8 && l + 1 == u.L - 2) &&
                 res_takes_slab_source(u, u.down_res[2 * l + 2], B, H / 2, W / 2, co)) {
@@ -1269,7 +1307,8 @@ static int forward_core(const ddk_unet& u, const float* P, const float* x, int64
             DDK_TRY(run_res(c, u.up_res[2 * i + 1], bufB, din, nullptr, 0, bufC, H, W));
             DDK_TRY(run_attn(c, u.up_attn[i], bufC, bufB, H, W));
         }
-        DDK_TRY(run_conv(c, DDK_CONVT4X4_S2, u.up_conv[i], bufB, din, nullptr, 0, nullptr, bufA, H, W, din));
+        if (!(chain_edges && i == 0))     // (the level chain has written this transpose conv's output into bufA itself)
+            DDK_TRY(run_conv(c, DDK_CONVT4X4_S2, u.up_conv[i], bufB, din, nullptr, 0, nullptr, bufA, H, W, din));
         H *= 2; W *= 2;
         cur = bufA;
         cur_c = din;

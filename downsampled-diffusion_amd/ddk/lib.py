@@ -98,6 +98,7 @@ SIGNATURES = {
     "ddk_final_tail": (_I, [_P, _P, _I, _P, _P, _F, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_uint64, C.c_uint32, _I, _I, _I, _I, _P]),
     "ddk_pack_conv_weight_local": (_I, [_P, _P, _I, _I, _I, _P]),
     "ddk_pack_conv1x1_weight_local": (_I, [_P, _P, _I, _I, _I, _P]),
+    "ddk_pack_convT_weight_local": (_I, [_P, _P, _I, _I, _P]),
     "ddk_pack_conv_weight_wino_local": (_I, [_P, _P, _I, _I, _I, _P]),
     "ddk_conv3x3_gn_mish_wino_ok": (_I, [_I, _I, _I, _I, _I, _I]),
     "ddk_conv3x3_gn_mish_wino": (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _F, _P]),

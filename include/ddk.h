@@ -138,6 +138,9 @@ int ddk_groupnorm_mish_slabs(const float* slabs, int nslab, long long slab_strid
 int ddk_pack_conv_weight_local(const float* w_oihw, float* dst, int O, int I, int i_pad, ddk_stream_t s);
 /* the same operand order for a 1x1 filter [O][I][1][1] (one tap: O*i_pad floats) -- the 1x1 ops of the level chain (DDK_OPT_LEVEL_CHAIN) */
 int ddk_pack_conv1x1_weight_local(const float* w_oi, float* dst, int O, int I, int i_pad, ddk_stream_t s);
+/* ... and for a ConvTranspose2d(4, stride 2, padding 1) filter [I][O][4][4] (O*16*I floats: four output phases of 2 x 2 taps each) -- the
+ * transpose-conv op that ends the level chain (reference models/unet/blocks.py:32-38) */
+int ddk_pack_convT_weight_local(const float* w_iohw, float* dst, int I, int O, ddk_stream_t s);
 int ddk_conv3x3_gn_mish_ok(int H, int W, int cin, int c0, int N, int groups);
 int ddk_conv3x3_gn_mish(const float* src0, int c0, const float* src1, int c1, const float* weight, const float* bias,
                         const float* gamma, const float* beta, const float* temb, int temb_stride, const float* addend,

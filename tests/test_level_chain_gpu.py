@@ -186,3 +186,34 @@ def test_chain_resnet_block_pair(hw, B):
         assert rel_err(bufs[3].permute(0, 3, 1, 2).cpu(), r2.cpu()) < 5e-5
         outs.append(bufs[3].clone())
     assert torch.equal(outs[0], outs[2]) and not torch.equal(outs[0], outs[1])
+
+
+DOWN, NO_GN = 512, 256
+UPT = 3
+
+
+@pytest.mark.parametrize("B", [4, 33])
+def test_chain_downsample_and_transpose_conv_ops(B):
+    """the level chain's edges: the Downsample conv (3x3, stride 2, padding 1: 8x8 -> 4x4, blocks.py:41-47) as its first op, handed to a
+    conv3x3 + GroupNorm op with the residual kept from it, and the Upsample transpose conv (4x4, stride 2, padding 1: 4x4 -> 8x8,
+    blocks.py:32-38) as its last -- against torch's conv2d / conv_transpose2d in fp64"""
+    x = gen((B, 256, 8, 8), 91)
+    wd, bd = gen((256, 256, 3, 3), 92, (256 * 9) ** -0.5), gen((256,), 93, 0.1)
+    wc, bc, g, be = gen((256, 256, 3, 3), 94, (256 * 9) ** -0.5), gen((256,), 95, 0.1), 1 + gen((256,), 96, 0.1), gen((256,), 97, 0.1)
+    wt, bt = gen((256, 256, 4, 4), 98, (256 * 4) ** -0.5), gen((256,), 99, 0.1)          # ConvTranspose2d weight: [in][out][4][4]
+    wdp, wcp = ops.pack_conv_weight_local(wd), ops.pack_conv_weight_local(wc)
+    wtp = torch.empty(256 * 16 * 256, device=DEV)
+    L.check(L.load().ddk_pack_convT_weight_local(L.ptr(wt.contiguous()), L.ptr(wtp), 256, 256, L.stream()), "pack_convT_weight_local")
+    xin = nhwc(x)
+    d = torch.empty((B, 4, 4, 256), device=DEV)
+    h = torch.empty((B, 4, 4, 256), device=DEV)
+    up = torch.empty((B, 8, 8, 256), device=DEV)
+    run_chain([ChainOp(_p(xin), None, _p(wdp), _p(bd), None, None, _p(d), 256, 0, CONV3, DOWN | NO_GN | SIGNAL | SAVE_KEEP, -1, 256),
+               ChainOp(_p(d), None, _p(wcp), _p(bc), _p(g), _p(be), _p(h), 256, 0, CONV3, WAIT | SIGNAL | ADD_KEEP, -1, 256),
+               ChainOp(_p(h), None, _p(wtp), _p(bt), None, None, _p(up), 256, 0, UPT, WAIT, -1, 256)], 16, B)
+    d_ref = F.conv2d(x.double(), wd.double(), bd.double(), stride=2, padding=1)
+    h_ref = block_ref(d_ref, wc, bc, g, be) + d_ref
+    up_ref = F.conv_transpose2d(h_ref, wt.double(), bt.double(), stride=2, padding=1)
+    assert rel_err(d.permute(0, 3, 1, 2).cpu(), d_ref.cpu()) < 2e-5
+    assert rel_err(h.permute(0, 3, 1, 2).cpu(), h_ref.cpu()) < 3e-5
+    assert rel_err(up.permute(0, 3, 1, 2).cpu(), up_ref.cpu()) < 3e-5

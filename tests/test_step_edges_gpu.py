@@ -523,12 +523,13 @@ def _chain_net(in_ch=8):
     return net.to(DEV).eval()
 
 
-@pytest.mark.parametrize("mode", [1, 3, 4, 8, 16])
+@pytest.mark.parametrize("mode", [1, 2, 3, 4, 8, 16])
 @pytest.mark.parametrize("batch", [32, 5, 40])
 def test_level_chain_option_gives_the_same_unet(batch, mode):
     """plan option DDK_OPT_LEVEL_CHAIN (csrc/level_chain.hip): the 4x4 level of the full-width UNet -- 2 + 2 + 2 ResnetBlocks and three
     attention blocks, reference unet.py:83-101 -- as ONE persistent launch whose workgroups hand the images to each other, against the
-    same level as 19 launches (mode 1, the default); the 8x8 levels -- downs[2], ups[1] -- as one launch each against 7 + 9 (mode 4;
+    same level as 19 launches (mode 2; mode 1, the default: with the Downsample conv in front and the Upsample transpose conv behind
+    inside the launch as well, 23 launches); the 8x8 levels -- downs[2], ups[1] -- as one launch each against 7 + 9 (mode 4;
     8 / 16: one of them); all three (mode 3).  Same arithmetic up to summation order (<= 2e-5 of the output's max), not the same bits (the option
     really switches paths), bit-stable from launch to launch (a stale hand-off would show), no wait timed out.  Batch 5: fewer
     workgroups than CUs; batch 40: images walked in two rounds by the same workgroups."""
