@@ -45,7 +45,7 @@ WINO_PMC = "r04_wino_pmc.json"      # committed counter summary of the timed Win
 CLUSTER_PMC = "r04_wino_cluster32_pmc.json"   # ... of its in-launch-GroupNorm variant (three launches per step at 32x32)
 WINO_SRC = "downsampled-diffusion_amd/csrc/conv_wino.hip+downsampled-diffusion_amd/csrc/conv_wino2_kernel.inc"   # what its hash covers
 HBM_PMC = "r05_gn_pmc.json"         # ... of the GroupNorm-apply kernel (FETCH_SIZE / WRITE_SIZE passes)
-LOCAL_PMC = "r05_wlocal8_pmc.json"  # ... of the image-local conv + GroupNorm kernel (8x8 maps)
+LOCAL_PMC = "r06_wlocal8_pmc.json"  # ... of the image-local conv + GroupNorm kernel (8x8 maps)
 STREAM_PMC = "r04_stream_pmc.json"  # ... of the streaming 1x1 conv of the dDDPM encoder / decoder blocks
 
 
@@ -175,6 +175,118 @@ def time_local_roofline(device):
                 traffic=pm["traffic_bytes_per_launch"] if pm else None, traffic_source=src,
                 mfma_busy=pm["mfma_busy"] if pm else None, mfma_busy_source=src, launch_us=sec * 1e6, executed_gflop=executed / 1e9,
                 algorithmic_gflop=2.0 * B * H * H * 9 * C * N / 1e9)
+
+
+CHAIN_PMC = "r06_chain4_pmc.json"  # ... of the persistent 4x4-level kernel (csrc/level_chain.hip)
+
+
+def time_chain_roofline(device, B=32):
+    """The persistent 4x4-level kernel (csrc/level_chain.hip, `level_chain_kernel`): ONE launch walks the level's 23 ops -- the Downsample
+    conv 8x8 -> 4x4, 2 + 2 + 2 ResnetBlocks (12 conv3x3 + GroupNorm + Mish, one on a 512-channel concat, and its 1x1 skip conv), three
+    attention blocks (LayerNorm-folded to_qkv + attention core per head, then to_out), the Upsample transpose conv 4x4 -> 8x8 -- for
+    `B` images on 8 x B workgroups that hand the 16-pixel images to each other through memory.  Timed live at the cfg4 shape (256
+    channels) on synthetic weights through the library's op-list entry (ddk_debug_level_chain: the same kernel, the same op list as
+    unet_plan.hip builds); priced on the MFMA FLOPs it ISSUES (direct products, padding taps included) against the fp32 MFMA peak."""
+    import ctypes as C
+    from ddk import lib, ops
+    L = lib.load()
+
+    class Op(C.Structure):
+        _fields_ = [("src0", C.c_void_p), ("src1", C.c_void_p), ("w", C.c_void_p), ("bias", C.c_void_p), ("gamma", C.c_void_p),
+                    ("beta", C.c_void_p), ("out", C.c_void_p), ("c0", C.c_int), ("c1", C.c_int), ("kind", C.c_int), ("flags", C.c_int),
+                    ("temb_off", C.c_int), ("n_out", C.c_int)]
+    CONV3, CONV1, ATTN, UPT = 0, 1, 2, 3
+    WAIT, SIGNAL, ADDK, SAVEK, ADDK2, SAVEK2, NO_OUT, NO_GN, DOWN = 1, 2, 4, 8, 16, 32, 128, 256, 512
+    g = torch.Generator(device="cpu").manual_seed(11)
+    keep = []
+
+    def t(*shape, scale=1.0):
+        v = (torch.randn(*shape, generator=g) * scale).to(device)
+        keep.append(v)
+        return v
+
+    def buf(hw=16, c=256):
+        v = torch.empty((B, hw, c), device=device)
+        keep.append(v)
+        return v
+    p = lambda v: None if v is None else v.data_ptr()   # noqa: E731
+    temb = t(B, 6 * 256)
+    opsl, flop = [], 0.0
+
+    def conv3(src, src1, cin, temb_off, flags, out, down=False):
+        nonlocal flop
+        w = ops.pack_conv_weight_local(t(256, cin, 3, 3, scale=(cin * 9) ** -0.5))
+        keep.append(w)
+        opsl.append(Op(p(src), p(src1), p(w), p(t(256, scale=0.1)), p(1 + t(256, scale=0.1)), p(t(256, scale=0.1)), p(out), min(cin, 256),
+                       cin - min(cin, 256), CONV3, flags | (DOWN | NO_GN if down else 0), temb_off, 256))
+        flop += 2.0 * B * 16 * 9 * cin * 256
+
+    def conv1(src, src1, cin, flags, out):
+        nonlocal flop
+        w = torch.empty(256 * cin, device=device)
+        wc = t(256, cin, scale=cin ** -0.5)
+        lib.check(L.ddk_pack_conv1x1_weight_local(lib.ptr(wc), lib.ptr(w), 256, cin, cin, lib.stream()), "pack1")
+        keep.append(w)
+        opsl.append(Op(p(src), p(src1), p(w), p(t(256, scale=0.1)), None, None, p(out), min(cin, 256), cin - min(cin, 256), CONV1, flags, -1, 256))
+        flop += 2.0 * B * 16 * cin * 256
+
+    def attn_block(src, out, signals):
+        nonlocal flop
+        lnw = t(384, 256, scale=256 ** -0.5)
+        wop = torch.empty_like(lnw)
+        lib.check(L.ddk_pack_qkv_operand(lib.ptr(lnw), lib.ptr(wop), 4, 256, lib.stream()), "pack_qkv_operand")
+        keep.append(wop)
+        heads = buf(16, 128)
+        opsl.append(Op(p(src), None, p(wop), None, p(t(384)), p(t(384)), p(heads), 256, 0, ATTN, WAIT | SIGNAL, -1, 128))
+        flop += 2.0 * B * 16 * 256 * 384 + 2 * 2.0 * B * 4 * 16 * 32 * 32
+        conv1(heads, None, 128, (WAIT | SIGNAL if signals else WAIT) | ADDK | SAVEK, out)
+
+    def res_plain(src, temb_off, out):
+        h = buf()
+        conv3(src, None, 256, temb_off, WAIT | SIGNAL, h)
+        conv3(h, None, 256, -1, WAIT | SIGNAL | ADDK | SAVEK, out)
+    x8 = t(B, 64, 256)
+    dn, d0, d1, skip, m1, ma, m2, u0, u1, ua = (buf() for _ in range(10))
+    up = buf(64, 256)
+    conv3(x8, None, 256, -1, SIGNAL | SAVEK, dn, down=True)
+    res_plain(dn, 0, d0)
+    res_plain(d0, 256, d1)
+    attn_block(d1, skip, True)
+    res_plain(skip, 512, m1)
+    attn_block(m1, ma, True)
+    res_plain(ma, 768, m2)
+    conv1(m2, skip, 512, WAIT | SAVEK2 | NO_OUT, None)
+    h = buf()
+    conv3(m2, skip, 512, 1024, SIGNAL, h)
+    conv3(h, None, 256, -1, WAIT | SIGNAL | ADDK2 | SAVEK, u0)
+    res_plain(u0, 1280, u1)
+    attn_block(u1, ua, True)
+    wt = t(256, 256, 4, 4, scale=(256 * 4) ** -0.5)
+    wtp = torch.empty(256 * 16 * 256, device=device)
+    lib.check(L.ddk_pack_convT_weight_local(lib.ptr(wt), lib.ptr(wtp), 256, 256, lib.stream()), "pack_convT_weight_local")
+    opsl.append(Op(p(ua), None, p(wtp), p(t(256, scale=0.1)), None, None, p(up), 256, 0, UPT, WAIT, -1, 256))
+    flop += 2.0 * B * 16 * 4 * 4 * 256 * 256
+    arr = (Op * len(opsl))(*opsl)
+    cnt = torch.zeros(64 * B + 16, device=device, dtype=torch.int32)
+    L.ddk_debug_level_chain.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    L.ddk_debug_level_chain.restype = C.c_int
+
+    def fn():
+        lib.check(L.ddk_debug_level_chain(C.cast(arr, C.c_void_p), len(opsl), 16, B, temb.data_ptr(), temb.shape[1], cnt.data_ptr(), lib.stream()),
+                  "debug_level_chain")
+    fn()
+    torch.cuda.synchronize()
+    sec = graph_kernel_seconds(device, fn, n=20, reps=3)
+    torch.cuda.synchronize()
+    if int(cnt[64 * B]) != 0 or not bool(torch.isfinite(up).all()):
+        raise RuntimeError("level chain: a hand-off wait timed out during the timed launches (GPU shared?)")
+    pm = _profile_json(CHAIN_PMC, "downsampled-diffusion_amd/csrc/level_chain.hip")
+    src = f"profiles/{CHAIN_PMC} (rocprofv3 --pmc, separate passes, the kernel inside the whole UNet forward)" if pm else None
+    return dict(kernel=f"level_chain_kernel: the whole 4x4 level of the cfg4 UNet ({len(opsl)} ops: Downsample conv, 12 conv3x3 + GroupNorm + Mish, "
+                       "1x1 skip conv, 3 attention blocks, Upsample transpose conv) in ONE persistent launch, B=32 (replaces 23 launches)",
+                bound="mfma", achieved=flop / sec / 1e12, peak=FP32_PEAK_TFLOPS, unit="TFLOP/s", frac=flop / sec / 1e12 / FP32_PEAK_TFLOPS,
+                traffic=pm["traffic_bytes_per_launch"] if pm else None, traffic_source=src,
+                mfma_busy=pm["mfma_busy"] if pm else None, mfma_busy_source=src, launch_us=sec * 1e6, executed_gflop=flop / 1e9, ops=len(opsl))
 
 
 def time_hbm_rooflines(device):
@@ -999,6 +1111,11 @@ def main():
             "roofline_hbm": roof_hbm,
             "roofline_local": time_local_roofline(device),
         }
+        try:
+            out["roofline_chain"] = time_chain_roofline(device)
+        except Exception as e:   # noqa: BLE001 -- secondary figure
+            out["roofline_chain"] = None
+            log(f"roofline_chain: {type(e).__name__}: {e}")
         if full_chain_s is not None:
             vfc = B * world / full_chain_s
             out["value_full_chain"] = vfc

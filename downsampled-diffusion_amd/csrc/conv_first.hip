@@ -93,11 +93,16 @@ __global__ __launch_bounds__(512) void conv_first_kernel(const FirstParams p) {
     const int pg = wave & 3, par = wave >> 2;        // 8 waves: pixel group (32 pixels) x parity of the channel blocks it multiplies --
     const int pl = lane & 31, h = lane >> 5;         // the two waves of a SIMD alternate between their MFMA run and their epilogue
 
+    // FUSE in the sampler: every workgroup needs the step's t (the time shift's row) and t_cur is only being written by workgroup 0 of
+    // this very launch -- so each reads the counter itself, and nobody decrements it during this kernel (the step's last kernel does)
+    const int64_t t_step = (FUSE && p.counter) ? *p.counter : 0;
     if (p.counter && blockIdx.x == 0) {          // first kernel of a reverse step: nobody else touches the counter now
         const int64_t v = *p.counter;
         for (int b = tid; b < p.B; b += 512) p.t_cur[b] = v;
-        __syncthreads();
-        if (tid == 0) *p.counter = v - 1;
+        if constexpr (!FUSE) {
+            __syncthreads();
+            if (tid == 0) *p.counter = v - 1;
+        }
     }
     // In row-major order the 3x3 neighbourhoods of 128 consecutive pixels of an image are ONE contiguous pixel range,
     // [first - W - 1, first + 128 + W + 1): staged once, coalesced; what falls outside the image is zero (and masked anyway).
@@ -292,7 +297,7 @@ __global__ __launch_bounds__(512) void conv_first_kernel(const FirstParams p) {
             }
             __syncthreads();
             const float* trow = nullptr;
-            if (p.temb) trow = p.temb + (p.temb_rows ? p.temb_rows[bimg] : (long long)bimg) * p.temb_stride;
+            if (p.temb) trow = p.temb + (p.counter ? (long long)t_step : p.temb_rows ? p.temb_rows[bimg] : (long long)bimg) * p.temb_stride;
 #pragma unroll
             for (int it = 0; it < 2; ++it) {
                 const int cb = (par + 2 * it) * 32 + 4 * h;

@@ -192,6 +192,8 @@ size_t conv_first_gn_ws_floats(int B, int H, int W);
 int conv_first_gn(const float* x, const float* wp, const float* bias, const float* gamma, const float* beta, const float* temb,
                   int temb_stride, const long long* temb_rows, float eps, float* out, int B, int H, int W, int cin, int N, int groups,
                   float* records, unsigned* counters, unsigned* fail, int64_t* counter, int64_t* t_cur, hipStream_t st);
+// (in the sampler this kernel reads the step counter in EVERY workgroup -- the time shift's row -- so it must not decrement it: the
+//  step's last kernel does, final_tail / p_sample_update with dec_counter)
 // conv1x1_ws.hip: 1x1 conv with 128 input channels on a large map as a weights-stationary, pixel-streaming GEMM
 // (w = the packed 1x1 weight [N][128]; ln as in conv_forward)
 // conv1x1_sm.hip: 1x1 conv + bias + residual on small maps (32x32 tiles, the four waves split K, no ring)
@@ -282,13 +284,14 @@ int conv1x1_small_n(const float* x, const float* w, const float* bias, float* ou
 int p_sample_update(float* x, const float* eps_hat, const float* noise, long long noise_step_stride, int t_first,
                     const int64_t* t, const float* c_recip, const float* c_recipm1, const float* c1, const float* c2,
                     const float* sigma, int B, long long per, uint64_t seed, uint32_t stream_id, hipStream_t st,
-                    const int64_t* chain_state = nullptr);
+                    const int64_t* chain_state = nullptr, int64_t* dec_counter = nullptr);
 int randn(float* out, long long n, uint64_t seed, uint32_t step, uint32_t stream_id, hipStream_t st);
 // GroupNorm (from conv partials) + Mish + 1x1 projection to n_out <= 8 channels (+ the reverse-step update of x) in one launch
 bool final_tail_ok(int HW, int C, int groups, int n_out, int np);
 int final_tail(const float* raw, const float* part, int np, const float* gamma, const float* beta, float eps, const float* w,
                const float* bias, int n_out, float* eps_out, float* x, const float* noise, long long noise_step_stride, int t_first,
                const int64_t* t, const float* c_recip, const float* c_recipm1, const float* c1, const float* c2, const float* sigma,
-               const int64_t* chain_state, uint64_t seed, uint32_t stream_id, int B, int HW, int C, int groups, hipStream_t st);
+               const int64_t* chain_state, uint64_t seed, uint32_t stream_id, int B, int HW, int C, int groups, hipStream_t st,
+               int64_t* dec_counter = nullptr);     // dec_counter: the sampler's step counter, decremented by this (last) kernel of the step
 
 }  // namespace ddk

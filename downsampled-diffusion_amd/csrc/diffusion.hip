@@ -93,7 +93,9 @@ __global__ __launch_bounds__(256) void p_sample_kernel(float* __restrict__ x, co
                                                        const float* __restrict__ c_recip, const float* __restrict__ c_recipm1,
                                                        const float* __restrict__ c1, const float* __restrict__ c2,
                                                        const float* __restrict__ sigma, long long per4, long long total4,
-                                                       uint64_t seed, uint32_t stream, const int64_t* __restrict__ chain_state) {
+                                                       uint64_t seed, uint32_t stream, const int64_t* __restrict__ chain_state,
+                                                       int64_t* dec_counter) {
+    if (dec_counter && blockIdx.x == 0 && threadIdx.x == 0) *dec_counter -= 1;     // the step counter, by the step's last kernel (see final_tail)
     if (chain_state) {   // sampler: the Philox key lives in device memory, so one captured graph serves every seed
         seed = (uint64_t)chain_state[1];
         stream = (uint32_t)chain_state[2];
@@ -143,6 +145,7 @@ struct TailParams {
     uint32_t stream;
     int np, HW, C, cpg, n_out;
     float eps;
+    int64_t* dec_counter;         // the step counter, decremented HERE (the step's last kernel) when the first kernel left it alone, or null
 };
 
 template <int LPP, int VPL>
@@ -157,6 +160,7 @@ __global__ __launch_bounds__(1024) void final_tail_kernel(const TailParams p) {
     const int b = blockIdx.x / p.np, tile = blockIdx.x - b * p.np;
     const int G = p.C / p.cpg;
     const long long pix0 = (long long)b * p.HW + tile * 128;
+    if (p.dec_counter && blockIdx.x == 0 && tid == 0) *p.dec_counter -= 1;     // nobody reads the counter in this kernel (t comes from t_cur)
     // every pixel this wave will touch is requested up front, before the statistics are merged: one latency, not NIT
     float4 v[NIT][VPL];
 #pragma unroll
@@ -270,7 +274,8 @@ bool final_tail_ok(int HW, int C, int groups, int n_out, int np) {
 int final_tail(const float* raw, const float* part, int np, const float* gamma, const float* beta, float eps, const float* w,
                const float* bias, int n_out, float* eps_out, float* x, const float* noise, long long noise_step_stride, int t_first,
                const int64_t* t, const float* c_recip, const float* c_recipm1, const float* c1, const float* c2, const float* sigma,
-               const int64_t* chain_state, uint64_t seed, uint32_t stream_id, int B, int HW, int C, int groups, hipStream_t st) {
+               const int64_t* chain_state, uint64_t seed, uint32_t stream_id, int B, int HW, int C, int groups, hipStream_t st,
+               int64_t* dec_counter) {
     DDK_REQUIRE(raw && part && gamma && beta && w && (eps_out || x) && B > 0, "final_tail: null pointer");
     DDK_REQUIRE(final_tail_ok(HW, C, groups, n_out, np), "final_tail: needs C in {32,64,128,256}, n_out <= 8, H*W == tiles * 128");
     DDK_REQUIRE(aligned16(raw) && aligned16(gamma) && aligned16(beta) && aligned16(w) && aligned16(eps_out) && aligned16(x) &&
@@ -282,6 +287,7 @@ int final_tail(const float* raw, const float* part, int np, const float* gamma, 
     p.c_recip = c_recip; p.c_recipm1 = c_recipm1; p.c1 = c1; p.c2 = c2; p.sigma = sigma; p.chain_state = chain_state;
     p.seed = seed; p.stream = stream_id;
     p.np = np; p.HW = HW; p.C = C; p.cpg = C / groups; p.n_out = n_out; p.eps = eps;
+    p.dec_counter = dec_counter;
     const dim3 grid((unsigned)(B * np));
     if (C == 32) hipLaunchKernelGGL((final_tail_kernel<8, 1>), grid, dim3(1024), 0, st, p);
     else if (C == 64) hipLaunchKernelGGL((final_tail_kernel<16, 1>), grid, dim3(1024), 0, st, p);
@@ -393,13 +399,13 @@ static int vlb_slices(int B, long long per) {
 int p_sample_update(float* x, const float* eps_hat, const float* noise, long long noise_step_stride, int t_first,
                     const int64_t* t, const float* c_recip, const float* c_recipm1, const float* c1, const float* c2,
                     const float* sigma, int B, long long per, uint64_t seed, uint32_t stream_id, hipStream_t st,
-                    const int64_t* chain_state) {
+                    const int64_t* chain_state, int64_t* dec_counter) {
     DDK_REQUIRE(x && eps_hat && t && c_recip && c_recipm1 && c1 && c2 && sigma, "p_sample_update: null pointer");
     DDK_REQUIRE(B > 0 && per > 0 && per % 4 == 0, "p_sample_update: per-sample element count must be a multiple of 4");
     DDK_REQUIRE(aligned16(x) && aligned16(eps_hat) && aligned16(noise) && noise_step_stride % 4 == 0, "p_sample_update: alignment");
     const long long total4 = B * per / 4;
     hipLaunchKernelGGL(p_sample_kernel, dim3(grid1d(total4)), dim3(256), 0, st, x, eps_hat, noise, noise_step_stride, t_first, t,
-                       c_recip, c_recipm1, c1, c2, sigma, per / 4, total4, seed, stream_id, chain_state);
+                       c_recip, c_recipm1, c1, c2, sigma, per / 4, total4, seed, stream_id, chain_state, dec_counter);
     return check_launch("p_sample_kernel");
 }
 

@@ -1185,6 +1185,11 @@ static int forward_core(const ddk_unet& u, const float* P, const float* x, int64
     const float* cur = xpad;
     int cur_c = pad32(u.cfg.in_ch);
     AddendSlabs cur_ss;           // > 1 slab: `cur` is the split-K area a Downsample conv left for the next ResnetBlock to sum
+    // the first Block with its GroupNorm in the conv's launch: in the sampler that kernel leaves the step counter alone (every workgroup of
+    // it reads the counter) and the step's LAST kernel decrements it (dec_counter below)
+    const bool first_fused = fast0 && c.allow_cluster && u.first_gn && conv_wino_cluster_device_ok() &&
+                             conv_first_gn_ok(u.down_res[0].ci, u.down_res[0].co, H0, W0, GROUPS) && u.cluster_limit > 0;
+    int64_t* dec_counter = (first_fused && step) ? step->state : nullptr;
     const bool chained = level_chain_use(c, H0, W0);    // the last level (4x4 maps) as one persistent launch
     const bool chain_edges = chained && (u.level_chain & 8) && u.L >= 2 && u.down_conv[u.L - 2].has_wl && u.down_conv[u.L - 2].has_bias &&
                              u.up_conv[0].has_wtl && u.up_conv[0].cin == 256 && u.down_conv[u.L - 2].cin == 256;
@@ -1206,8 +1211,7 @@ static int forward_core(const ddk_unet& u, const float* P, const float* x, int64
             DDK_TRY(run_level_chain(c, 1, cur, skip, nullptr));
         } else if (l == 0 && fast0) {
             const ResW& r = u.down_res[0];
-            if (c.allow_cluster && u.first_gn && conv_wino_cluster_device_ok() && conv_first_gn_ok(r.ci, r.co, H, W, GROUPS) &&
-                c.n_cluster < u.cluster_limit) {
+            if (first_fused) {
                 // round 6: the first Block's GroupNorm + Mish + shift inside the conv's launch (the image's 8 tiles exchange their statistics):
                 // no raw tensor, no GroupNorm-apply launch
                 float* cl = ws + ly.off_cl;
@@ -1332,7 +1336,7 @@ static int forward_core(const ddk_unet& u, const float* P, const float* x, int64
         if (step)
             return final_tail(raw, gnp, npf, P + u.final_norm.g, P + u.final_norm.b, GN_EPS, P + u.final_w, P + u.final_b, n_out, nullptr,
                               step->x, step->noise, step->noise_step_stride, step->t_first, t, step->c_recip, step->c_recipm1, step->c1,
-                              step->c2, step->sigma, step->state, 0, 0, B, H * W, chan, GROUPS, st);
+                              step->c2, step->sigma, step->state, 0, 0, B, H * W, chan, GROUPS, st, dec_counter);
         return final_tail(raw, gnp, npf, P + u.final_norm.g, P + u.final_norm.b, GN_EPS, P + u.final_w, P + u.final_b, n_out, out, nullptr,
                           nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, B, H * W, chan, GROUPS, st);
     }
@@ -1341,7 +1345,7 @@ static int forward_core(const ddk_unet& u, const float* P, const float* x, int64
     DDK_TRY(conv1x1_small_n(a1, P + u.final_w, P + u.final_b, eps_hat, (long long)B * H * W, chan, n_out, st));
     if (!step) return DDK_OK;
     return p_sample_update(step->x, eps_hat, step->noise, step->noise_step_stride, step->t_first, t, step->c_recip, step->c_recipm1,
-                           step->c1, step->c2, step->sigma, B, step->per, 0, 0, st, step->state);
+                           step->c1, step->c2, step->sigma, B, step->per, 0, 0, st, step->state, dec_counter);
 }
 
 static int check_shape(const ddk_unet* u, int B, int H, int W) {

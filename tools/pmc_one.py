@@ -106,6 +106,20 @@ elif case == "cluster16":
     wu, b = ops.pack_conv_weight_wino(w), torch.zeros(256, device=dev)
     gam, bet, temb = torch.ones(256, device=dev), torch.zeros(256, device=dev), torch.randn(B, 256, device=dev)
     fn = lambda: ops.conv3x3_gn_mish_cluster(x, wu, b, gam, bet, temb=temb, check=False)
+elif case == "unet":           # the whole cfg4 UNet forward, in-launch paths on: counters of kernels that only exist inside it (level_chain_kernel)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import det_state, unet_cfg
+    from models import Unet
+    cfg = unet_cfg(128, 8)
+    net = Unet(cfg)
+    net.load_state_dict(det_state({k: v.shape for k, v in net.state_dict().items()}))
+    net = net.to(dev).eval()
+    xin = torch.randn(B, 8, 32, 32, device=dev)
+    tt = (torch.arange(B, device=dev) * 31) % 1000
+    net.plan().set_option(net.plan().OPT_CLUSTER_GROUPNORM, 2)
+    def fn():
+        with torch.no_grad():
+            return net(xin, tt)
 else:
     raise SystemExit(f"unknown case {case}")
 for _ in range(20):
