@@ -517,12 +517,14 @@ class ClockProbe:
         L.check(L.load().ddk_debug_clock_probe(buf.data_ptr(), self.n, L.stream()), "debug_clock_probe")
 
     def ghz(self):
+        """Median over the workgroups whose two records come from the same XCC (workgroup i of both probe launches: the same dispatch
+        slot) of d(s_memtime) / d(s_memrealtime).  Pairing records of different workgroups of an XCC (rounds 4-5 took the first record
+        per XCC of each probe) mixes counters that are a constant apart: invisible over a second, 30 % off over 25 ms."""
         a, b = self.a.cpu().numpy(), self.b.cpu().numpy()
         rates = []
-        for xcc in set(int(v) for v in a[:, 0]):
-            ra, rb = a[a[:, 0] == xcc], b[b[:, 0] == xcc]
-            if len(ra) and len(rb):
-                dc, dt = int(rb[0, 1]) - int(ra[0, 1]), int(rb[0, 2]) - int(ra[0, 2])
+        for i in range(min(len(a), len(b))):
+            if int(a[i, 3]) == 1 and int(b[i, 3]) == 1 and int(a[i, 0]) == int(b[i, 0]):
+                dc, dt = int(b[i, 1]) - int(a[i, 1]), int(b[i, 2]) - int(a[i, 2])
                 if dt > 0 and dc > 0:
                     rates.append(dc / dt * 0.1)        # cycles per 10 ns tick -> GHz
         rates.sort()

@@ -27,8 +27,8 @@ NOPS = 24
 buf = (C.c_ulonglong * (9 * NOPS * 8))()
 lib.ddk_debug_read_lc_stamps.argtypes = [C.c_void_p]
 assert lib.ddk_debug_read_lc_stamps(buf) == 0
-names = ["d0.c1", "d0.c2", "d1.c1", "d1.c2", "d.attn", "d.out", "m1.c1", "m1.c2", "m.attn", "m.out", "m2.c1", "m2.c2", "u0.res", "u0.c1",
-         "u0.c2", "u1.c1", "u1.c2", "u.attn", "u.out"]
+names = ["down", "d0.c1", "d0.c2", "d1.c1", "d1.c2", "d.attn", "d.out", "m1.c1", "m1.c2", "m.attn", "m.out", "m2.c1", "m2.c2", "u0.res", "u0.c1",
+         "u0.c2", "u1.c1", "u1.c2", "u.attn", "u.out", "upT"]
 names8d = ["d0.c1", "d0.c2", "d1.c1", "d1.c2", "attn", "out"]
 names8u = ["u0.res", "u0.c1", "u0.c2", "u1.c1", "u1.c2", "attn", "out"]
 which = sys.argv[1] if len(sys.argv) > 1 else "4"
