@@ -120,6 +120,11 @@ struct ddk_unet {
                                              // OFF by default: measured 100 us per step SLOWER (150 + 170 us against 104 + 125 for the 16
                                              // launches: a hop moves a 64 KB image to each of 8 workgroups, 5 us of staging and 7 us of
                                              // tail per op where the launches pay 2.9 + 2.4 + 2.0; profiles/r06_chain8_clock.txt, r06_chain8_ab.txt)
+    int level_chain_max_batch = 32;          // the chain walks images in rounds of 32 (one workgroup per CU): measured at cfg4 it wins up to ONE round
+                                             // (batch 16: 0.984 -> 0.947 ms, 32: 1.282 -> 1.232) and loses from the second on (48: 2.084 -> 2.142,
+                                             // 64: 2.071 -> 2.095, 192: 5.753 -> 5.976; tools/chain_batch_ab.py) -- the launches it replaces amortise
+                                             // their boundaries over the larger batch, the chain's hops do not (diagnostic option 10 moves the limit)
+    int attn_fold_min_hw = 256;              // ... on maps with MORE pixels than this (diagnostic option 9: 255 lets the 16x16, C = 128 site take it)
     bool attn_fold = true;                   // attention on maps with HW > 256, C = 128: q projection + apply + to_out as ONE per-image C x C conv
     // unet_chan % 8 == 0 but not % 32 (reference blocks.py:75 takes any GroupNorm(8, C)): every tensor keeps a pitch of pad32(C) channels
     // with zero padding, the convs run on the generic im2col kernels over zero-padded weights and the normalisations on their
@@ -466,6 +471,20 @@ extern "C" int ddk_unet_set_option(ddk_unet* u, int option, int value) {
         if (!u->graphs.empty()) DDK_HIP(hipDeviceSynchronize());
         drop_graphs(u);
         u->fold_down_reduce = value != 0;
+        return DDK_OK;
+    }
+    if (option == 10) {  // diagnostic (not in ddk.h): largest batch the level chain takes
+        std::lock_guard<std::mutex> lock(u->mu);
+        if (!u->graphs.empty()) DDK_HIP(hipDeviceSynchronize());
+        drop_graphs(u);
+        u->level_chain_max_batch = value;
+        return DDK_OK;
+    }
+    if (option == 9) {   // diagnostic (not in ddk.h): the folded attention block from this many pixels up
+        std::lock_guard<std::mutex> lock(u->mu);
+        if (!u->graphs.empty()) DDK_HIP(hipDeviceSynchronize());
+        drop_graphs(u);
+        u->attn_fold_min_hw = value;
         return DDK_OK;
     }
     if (option == 2) {   // diagnostic (not in ddk.h): cap on the cluster launches per forward
@@ -909,7 +928,7 @@ static int run_res(Ctx& c, const ResW& r, const float* src0, int c0, const float
 // The folded form of the attention block (attention.hip, attn_fold_kernel): maps with many more pixels than channels, C = 128
 static bool attn_fold_eligible(const ddk_unet& u, const AttnW& a, int B, int H, int W) {
     const long long M = (long long)B * H * W;
-    return u.attn_fold && H * W > 256 && (H * W) % 64 == 0 && attn_fold_ok(a.c, HEADS) && conv1x1_ws_ok(M, a.c, a.c) &&
+    return u.attn_fold && H * W > u.attn_fold_min_hw && (H * W) % 64 == 0 && attn_fold_ok(a.c, HEADS) && conv1x1_ws_ok(M, a.c, a.c) &&
            conv_ln_fold_ok(B, H, W, a.c, 2 * HIDDEN) && B <= 256;
 }
 
@@ -987,10 +1006,11 @@ static int run_attn(Ctx& c, const AttnW& a, const float* x, float* out, int H, i
 // `in` = the Downsample conv's output, `skip` receives the level's skip tensor (unet.py:87), `out` the up attention block's output.
 // part 1: downs[-2] on 8x8 maps (in -> skip).  part 2: ups[1] on 8x8 maps (cat(in, skip) -> out).
 static bool level_chain_use(const Ctx& c, int H0, int W0) {
-    return c.allow_cluster && (c.u.level_chain & 1) && c.ly.chain > 0 && level_chain_shape_ok(c.u, H0, W0) && level_chain_device_ok();
+    return c.allow_cluster && (c.u.level_chain & 1) && c.B <= c.u.level_chain_max_batch && c.ly.chain > 0 && level_chain_shape_ok(c.u, H0, W0) &&
+           level_chain_device_ok();
 }
 static bool level8_chain_use(const Ctx& c, int H0, int W0, int bit) {
-    return c.allow_cluster && (c.u.level_chain & bit) && c.ly.chain > 0 && level8_chain_shape_ok(c.u, H0, W0) && level_chain_device_ok();
+    return c.allow_cluster && (c.u.level_chain & bit) && c.B <= c.u.level_chain_max_batch && c.ly.chain > 0 && level8_chain_shape_ok(c.u, H0, W0) && level_chain_device_ok();
 }
 
 // down_src != null (part 0): `in` is not used -- the chain starts with the Downsample conv on the 8x8 map down_src (blocks.py:41-47);

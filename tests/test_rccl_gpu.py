@@ -72,6 +72,18 @@ def test_bench_gpus_2_launches_two_ranks_itself(tmp_path):
     assert "cpu_baseline" not in line and line["value"] > 1
 
 
+def test_bench_gpus_4_launches_four_ranks_itself(tmp_path):
+    """the same with FOUR ranks sharing cuda:0 -- the widest world the one-GPU box admits next to the test process (its guard allows six
+    GPU processes per user; the N = 8 launch itself is rehearsed with probe children in tests/test_host_logic.py): four rank records,
+    one JSON line, `world == 4`"""
+    line = _bench_unaided(tmp_path, "--gpus", "4", "--steps", "4", "--warmup", "1", "--no-full-chain")
+    assert line["n_gpus"] == 4 and line["dist"]["world"] == 4 and line["dist"]["backend"] == "gloo"
+    ranks = line["dist"]["ranks"]
+    assert [r["rank"] for r in ranks] == [0, 1, 2, 3] and all(r["ms_per_step"] > 0 for r in ranks)
+    assert line["config"]["global_batch"] == 128 and line["config"]["in_launch_groupnorm_per_rank"] == [0, 0, 0, 0]
+    assert line["value"] > 1
+
+
 def test_bench_train_dp_two_ranks(tmp_path):
     """`python bench.py --gpus 2 --train-dp` unaided: the cfg5 optimiser step (2 micro-batches of 8 images of 256x256 per rank) through
     trainers.setup_trainer / TrainerDDPM.optimizer_step with the C2 all-reduce of the 89 MB gradient bucket between two ranks."""

@@ -544,6 +544,7 @@ def test_level_chain_option_gives_the_same_unet(batch, mode):
         y_plain = net(x, t)                                        # single forwards take neither in-launch path by default
         plan.set_option(plan.OPT_CLUSTER_GROUPNORM, 2)             # ... with 2 they take both (and wait + check behind the call)
         plan.set_option(plan.OPT_LEVEL_CHAIN, mode)
+        plan.set_option(10, 1 << 20)                               # diagnostic: the chain at any batch (by default only up to one round of 32 images)
         before = ops.cluster_timeouts()
         y_on = net(x, t)
         y_other = net(x2, t)                                       # different data through the same hand-off buffers
