@@ -879,6 +879,9 @@ __global__ __launch_bounds__(256) void conv1x1_small_n_bwd_kernel(const float* _
                                                                   float* __restrict__ part, long long M, int C, int n_out) {
     constexpr int PPW = 64 / LPP;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, sub = lane % LPP;
+    // cb: the LPP * VPL * 4 channels of this trip.  Every listed width is one trip; other multiples of 32 (padded generic widths:
+    // 224, 288, 352, ...) walk the pixels once per 32 channels -- the products are per channel, so the result does not depend on it
+    for (int cb = 0; cb < C; cb += LPP * VPL * 4) {
     float4 dw[NOUT_MAX][VPL];
     float dbv[NOUT_MAX];
 #pragma unroll
@@ -902,7 +905,7 @@ __global__ __launch_bounds__(256) void conv1x1_small_n_bwd_kernel(const float* _
             const bool ok = pix[u] < M;
 #pragma unroll
             for (int i = 0; i < VPL; ++i)
-                av[u][i] = ok ? *reinterpret_cast<const float4*>(a + pix[u] * C + (sub + i * LPP) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                av[u][i] = ok ? *reinterpret_cast<const float4*>(a + pix[u] * C + cb + (sub + i * LPP) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
             for (int co = 0; co < NOUT_MAX; ++co) g[u][co] = (ok && co < n_out) ? dy[pix[u] * n_out + co] : 0.f;
         }
@@ -918,7 +921,7 @@ __global__ __launch_bounds__(256) void conv1x1_small_n_bwd_kernel(const float* _
                     if (sub == 0) dbv[co] += gg;
 #pragma unroll
                     for (int i = 0; i < VPL; ++i) {
-                        const float4 ww = *reinterpret_cast<const float4*>(w + (long long)co * C + (sub + i * LPP) * 4);
+                        const float4 ww = *reinterpret_cast<const float4*>(w + (long long)co * C + cb + (sub + i * LPP) * 4);
                         r[i].x += gg * ww.x; r[i].y += gg * ww.y; r[i].z += gg * ww.z; r[i].w += gg * ww.w;
                         dw[co][i].x += gg * av[u][i].x; dw[co][i].y += gg * av[u][i].y; dw[co][i].z += gg * av[u][i].z;
                         dw[co][i].w += gg * av[u][i].w;
@@ -927,7 +930,7 @@ __global__ __launch_bounds__(256) void conv1x1_small_n_bwd_kernel(const float* _
             }
             if (pix[u] < M)
 #pragma unroll
-                for (int i = 0; i < VPL; ++i) *reinterpret_cast<float4*>(da + pix[u] * C + (sub + i * LPP) * 4) = r[i];
+                for (int i = 0; i < VPL; ++i) *reinterpret_cast<float4*>(da + pix[u] * C + cb + (sub + i * LPP) * 4) = r[i];
         }
     }
     // fold the PPW pixel slots of the wave by xor shuffles over lane bits >= log2(LPP); one partial row per wave
@@ -942,12 +945,13 @@ __global__ __launch_bounds__(256) void conv1x1_small_n_bwd_kernel(const float* _
                 for (int o = LPP; o < 64; o <<= 1) {
                     t.x += __shfl_xor(t.x, o, 64); t.y += __shfl_xor(t.y, o, 64); t.z += __shfl_xor(t.z, o, 64); t.w += __shfl_xor(t.w, o, 64);
                 }
-                if (lane < LPP) *reinterpret_cast<float4*>(prow + (long long)co * C + (sub + i * LPP) * 4) = t;
+                if (lane < LPP) *reinterpret_cast<float4*>(prow + (long long)co * C + cb + (sub + i * LPP) * 4) = t;
             }
             float tb = dbv[co];
             for (int o = 1; o < 64; o <<= 1) tb += __shfl_xor(tb, o, 64);
-            if (lane == 0) prow[(long long)n_out * C + co] = tb;
+            if (lane == 0 && cb == 0) prow[(long long)n_out * C + co] = tb;
         }
+    }
     }
 }
 
@@ -1174,16 +1178,18 @@ __global__ __launch_bounds__(256) void gn_generic_train_kernel(const float* __re
 }
 
 // Channel LayerNorm backward over the C real channels of CP-pitched rows (the arithmetic of chan_layernorm_bwd_kernel): one wave
-// per pixel, a lane owns channels lane, lane + 64, ... (C <= 512); per-workgroup partial rows of dg, db.
+// per pixel, a lane owns channels lane, lane + 64, ... (CP <= 512: unet_create admits no level wider than 512 channels); per-workgroup
+// partial rows of dg, db.
+template <int NS = 8>
 __global__ __launch_bounds__(256) void chan_layernorm_generic_bwd_kernel(const float* __restrict__ x, const float* __restrict__ g,
                                                                          const float* __restrict__ dy, const float* __restrict__ addend,
                                                                          float* __restrict__ dx, float* __restrict__ part /* [2][grid][C] */,
                                                                          long long M, int CP, int C, float eps) {
-    __shared__ float acc[4][2][512];
+    __shared__ float acc[4][2][64 * NS];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    float sg[8], sb[8];
+    float sg[NS], sb[NS];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) sg[i] = sb[i] = 0.f;
+    for (int i = 0; i < NS; ++i) sg[i] = sb[i] = 0.f;
     for (long long pix = blockIdx.x * 4LL + wid; pix < M; pix += (long long)gridDim.x * 4) {
         const float* xr = x + pix * CP;
         const float* dr = dy + pix * CP;
@@ -1199,7 +1205,7 @@ __global__ __launch_bounds__(256) void chan_layernorm_generic_bwd_kernel(const f
         const float sigma = sqrtf(q / (float)C), sden = sigma + eps, inv_s = 1.0f / sden;
         const float k1 = t1 / (float)C * inv_s, k2 = t2 / ((float)C * sigma * sden * sden);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < NS; ++i) {
             const int c = lane + 64 * i;
             if (c < CP) {
                 float rv = 0.f;
@@ -1215,7 +1221,7 @@ __global__ __launch_bounds__(256) void chan_layernorm_generic_bwd_kernel(const f
         }
     }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { acc[wid][0][lane + 64 * i] = sg[i]; acc[wid][1][lane + 64 * i] = sb[i]; }
+    for (int i = 0; i < NS; ++i) { acc[wid][0][lane + 64 * i] = sg[i]; acc[wid][1][lane + 64 * i] = sb[i]; }
     __syncthreads();
     for (int c = threadIdx.x; c < C; c += 256) {
         part[(long long)blockIdx.x * C + c] = (acc[0][0][c] + acc[1][0][c]) + (acc[2][0][c] + acc[3][0][c]);
@@ -1365,12 +1371,12 @@ int ddk_chan_layernorm_generic(const float* x, const float* g, const float* b, f
 int ddk_chan_layernorm_generic_bwd(const float* x, const float* g, const float* dy, const float* addend, float* dx, float* part,
                                    int max_parts, int* nparts_out, long long M, int CP, int C, float eps, ddk_stream_t s) {
     DDK_REQUIRE(x && g && dy && dx && part && nparts_out && M > 0 && max_parts > 0 && C > 0 && C <= 512 && CP >= C && CP <= 512,
-                "layernorm_generic_bwd: arguments");
+                "layernorm_generic_bwd: arguments (pitch <= 512, the widest level unet_create admits)");
     long long blocks = ceil_div(M, 4);
     if (blocks > max_parts) blocks = max_parts;
     if (blocks > 512) blocks = 512;
     *nparts_out = (int)blocks;
-    hipLaunchKernelGGL(chan_layernorm_generic_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(s), x, g, dy, addend, dx, part, M,
+    hipLaunchKernelGGL(chan_layernorm_generic_bwd_kernel<8>, dim3((unsigned)blocks), dim3(256), 0, as_stream(s), x, g, dy, addend, dx, part, M,
                        CP, C, eps);
     return check_launch("chan_layernorm_generic_bwd_kernel");
 }
@@ -1678,8 +1684,9 @@ int ddk_conv1x1_small_n_bwd(const float* a, const float* w, const float* dy, flo
         case 512: CB(64, 2);
         default: break;
     }
+    if (C > 0 && C % 32 == 0) CB(8, 1);     // any other padded width: 32 channels per trip over the pixels
 #undef CB
-    return fail_arg("conv1x1_small_n_bwd: unsupported channel count (32, 64, 96, 128, 160, 192, 256, 320, 384, 512)");
+    return fail_arg("conv1x1_small_n_bwd: the channel count must be a multiple of 32");
 }
 
 /* C = op(A) op(B) for the tiny time-embedding matrices; see small_gemm_kernel for the modes */

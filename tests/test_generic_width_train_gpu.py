@@ -91,12 +91,29 @@ def test_chan_layernorm_generic_fwd_bwd(ops, M, C):
     assert rel_err(gd.grad.cpu(), gr.grad) < 2e-5 and rel_err(bd.grad.cpu(), br.grad) < 2e-5
 
 
-@pytest.mark.parametrize("chan,cin,size", [(24, 3, 16), (40, 8, 16)])
-def test_unet_training_at_widths_that_are_not_multiples_of_32(chan, cin, size):
-    """forward, input gradient and parameter gradients of every layer kind of the full UNet (4 levels, attention at every level) at
-    unet_chan = 24 / 40 against torch-CPU autograd through oracle.unet_ref (reference models/unet/unet.py:74-104)"""
+@pytest.mark.parametrize("C", [32, 96, 224, 288, 352, 416, 448, 480, 512])
+@pytest.mark.parametrize("n_out", [3, 8])
+def test_small_n_conv1x1_backward_at_every_padded_width(ops, C, n_out):
+    """final_conv.1's backward (da, dw, db) at every multiple of 32 a padded generic width can give -- 224 (unet_chan 200..224),
+    288, 352, ... take the 32-channels-per-trip form of the kernel; against the plain products in float64"""
+    g = torch.Generator().manual_seed(C * 10 + n_out)
+    M = 2 * 13 * 11
+    a = torch.randn(M, C, generator=g)
+    w = torch.randn(n_out, C, generator=g) * C ** -0.5
+    dy = torch.randn(M, n_out, generator=g)
+    da, dw, db = ops.conv1x1_small_n_bwd(a.to(DEV), w.to(DEV), dy.to(DEV))
+    assert rel_err(da.cpu(), (dy.double() @ w.double()).float()) < 1e-5
+    assert rel_err(dw.cpu(), (dy.double().t() @ a.double()).float()) < 1e-5
+    assert rel_err(db.cpu(), dy.double().sum(0).float()) < 1e-5
+
+
+@pytest.mark.parametrize("chan,cin,size,dims", [(24, 3, 16, (1, 2, 2, 2)), (40, 8, 16, (1, 2, 2, 2)), (200, 3, 8, (1, 2))])
+def test_unet_training_at_widths_that_are_not_multiples_of_32(chan, cin, size, dims):
+    """forward, input gradient and parameter gradients of every layer kind of the full UNet (attention at every level) at
+    unet_chan = 24 / 40 (4 levels) and 200 (levels of 200 and 400 channels: pitches 224 and 416) against torch-CPU autograd through
+    oracle.unet_ref (reference models/unet/unet.py:74-104)"""
     from models import Unet
-    cfg = dict(unet_chan=chan, unet_in=cin, unet_dims=(1, 2, 2, 2), unet_dropout=0.0)
+    cfg = dict(unet_chan=chan, unet_in=cin, unet_dims=dims, unet_dropout=0.0)
     model = Unet(cfg)
     sd = syn.fill_state_dict(model.state_dict(), 91)
     model.load_state_dict(sd)
@@ -108,6 +125,8 @@ def test_unet_training_at_widths_that_are_not_multiples_of_32(chan, cin, size):
              "downs.1.2.fn.fn.to_qkv.weight", "downs.1.2.fn.fn.to_out.bias", "downs.1.2.fn.norm.g", "downs.0.3.conv.weight", "mid_block1.block2.block.1.bias",
              "ups.0.0.block1.block.0.weight", "ups.0.0.res_conv.weight", "ups.1.3.conv.weight", "ups.2.1.block2.block.0.weight",
              "final_conv.0.block.0.weight", "final_conv.1.weight", "time_mlp.1.weight", "downs.2.1.mlp.1.bias", "ups.1.0.mlp.1.weight"]
+    probe = [k for k in probe if k in sd]            # the two-level case has no downs.2 / ups.1 / ups.2
+    assert len(probe) >= 10
     ref_sd = {k: v.clone() for k, v in sd.items()}
     for k in probe:
         ref_sd[k].requires_grad_(True)
@@ -147,7 +166,7 @@ def test_unet_generic_width_dropout_trains(tmp_path):
     assert not torch.equal(p0, trainer.opt.fp.flat) and bool(torch.isfinite(trainer.opt.fp.flat).all())
 
 
-@pytest.mark.parametrize("d_chans,d_dropout", [(32, 0.0), (96, 0.0), (48, 0.0), (16, 0.0), (48, 0.1), (64, 0.25)])
+@pytest.mark.parametrize("d_chans,d_dropout", [(32, 0.0), (96, 0.0), (48, 0.0), (16, 0.0), (224, 0.0), (48, 0.1), (64, 0.25)])
 def test_resampler_training_at_d_chans_not_a_multiple_of_64(d_chans, d_dropout):
     """the dDDPM encoder / decoder (ConvResNet, convblocks.py:92-159) in training at d_chans = 32 / 96 -- inner widths 16 / 48 on a
     zero-padded pitch --, at d_chans = 48 / 16 -- the trunk itself on a padded pitch (any even d_chans, convblocks.py:133-159) --
