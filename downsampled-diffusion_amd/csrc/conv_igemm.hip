@@ -1357,7 +1357,7 @@ int conv_forward(const ddk_conv_args& a, hipStream_t st, const ConvLnFold* ln, c
         const int ws = conv_wino_splits(a.B, a.H, a.W, a.c0 + a.c1, a.N);
         const long long slab = (long long)a.B * a.H * a.W * a.N;
         if (ws > 1) {
-            const size_t need = (size_t)ws * slab * sizeof(float);
+            const size_t need = (size_t)(fuse ? ws - 1 : ws) * slab * sizeof(float);    // fuse: only the partners' partial tiles
             if (!a.workspace || a.workspace_bytes < need) {
                 set_error("conv(wino): split-K workspace too small (%zu < %zu)", a.workspace_bytes, need);
                 return DDK_ERR_WORKSPACE;
@@ -1366,7 +1366,7 @@ int conv_forward(const ddk_conv_args& a, hipStream_t st, const ConvLnFold* ln, c
         }
         DDK_REQUIRE((long long)a.B * a.H * a.W * (a.c0 > a.c1 ? a.c0 : a.c1) * 4 < (1LL << 31), "conv(wino): a source of 2 GiB or more");
         DDK_TRY(conv_wino_forward(a, ws, st, fuse));
-        if (ws > 1 && !a.defer_reduce) {
+        if (ws > 1 && !a.defer_reduce && !fuse) {      // (fuse: the tiles' first workgroups have summed their partners in the launch)
             const long long n4 = slab / 4;
             const int blocks = (int)(ceil_div(n4, 256) < 2048 ? ceil_div(n4, 256) : 2048);
             hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, static_cast<const float*>(a.workspace), ws, slab, a.bias,
@@ -1383,7 +1383,7 @@ int conv_forward(const ddk_conv_args& a, hipStream_t st, const ConvLnFold* ln, c
         const int ws = convT_wino_splits(a.B, a.H, a.W, a.c0, a.N);
         const long long slab = (long long)a.B * g.Ho * g.Wo * a.N;
         if (ws > 1) {
-            const size_t need = (size_t)ws * slab * sizeof(float);
+            const size_t need = (size_t)(fuse ? ws - 1 : ws) * slab * sizeof(float);    // fuse: only the partners' partial tiles
             if (!a.workspace || a.workspace_bytes < need) {
                 set_error("conv(winoT): split-K workspace too small (%zu < %zu)", a.workspace_bytes, need);
                 return DDK_ERR_WORKSPACE;
@@ -1392,7 +1392,7 @@ int conv_forward(const ddk_conv_args& a, hipStream_t st, const ConvLnFold* ln, c
         }
         DDK_REQUIRE((long long)a.B * a.H * a.W * a.c0 * 4 < (1LL << 31), "conv(winoT): a source of 2 GiB or more");
         DDK_TRY(convT_wino_forward(a, ws, st));
-        if (ws > 1 && !a.defer_reduce) {
+        if (ws > 1 && !a.defer_reduce && !fuse) {      // (fuse: the tiles' first workgroups have summed their partners in the launch)
             const long long n4 = slab / 4;
             const int blocks = (int)(ceil_div(n4, 256) < 2048 ? ceil_div(n4, 256) : 2048);
             hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, static_cast<const float*>(a.workspace), ws, slab, a.bias,

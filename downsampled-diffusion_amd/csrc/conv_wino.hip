@@ -66,6 +66,8 @@ struct WinoParams {
     unsigned* cl_cnt;              // [image][n tile][16]: [0] arrivals, [1] departures (self-resetting)
     unsigned* cl_fail;             // workgroups of launches on THIS workspace that gave up waiting (sticky; ddk_unet_cluster_check)
     int cl_np;                     // m tiles per image = workgroups per cluster
+    float* cl_slab;                // CL with splits > 1: [splits - 1][B H W N] partial tiles of the workgroups split >= 1
+    unsigned* cl_pair;             // ... and [m tile][n tile][16] arrival counters of those workgroups (zero between launches)
     const float* r1_x;             // optional addend of the in-launch GroupNorm: a 1x1 conv of this narrow tensor [pixels][r1_cin] ...
     const float* r1_w;             // ... with weight rows [N][r1_ld] and bias r1_b [N] (WinoGnFuse::res_*)
     const float* r1_b;
@@ -115,6 +117,26 @@ __device__ __forceinline__ void buf_load16(f32x4& d, unsigned voff, const i32x4&
 }
 
 __device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+// 16-byte sc1 store, and four 16-byte sc1 loads issued and waited for in ONE asm statement (no compiler-made copy of a register a
+// load is still writing): the hand-off of a partial tile between the workgroups that split a conv's channel chunks (CL variant)
+typedef float wino_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void st_sc1_f4(float* p, float4 v) {
+    const wino_f32x4 t = {v.x, v.y, v.z, v.w};
+    // s_nop 1: a store of more than 8 bytes reads its upper data registers a cycle or two after issue, and the compiler's hazard
+    // recogniser does not know this asm is a store -- without the wait states it may (and did) place the next address computation in them
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(t) : "memory");
+}
+__device__ __forceinline__ void ld_sc1_f4x4(float4& a, float4& b, float4& c, float4& d, const float* pa, const float* pb, const float* pc,
+                                            const float* pd) {
+    wino_f32x4 x, y, z, w;
+    asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %5, off sc1\n\tglobal_load_dwordx4 %2, %6, off sc1\n\t"
+                 "global_load_dwordx4 %3, %7, off sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(x), "=&v"(y), "=&v"(z), "=&v"(w)
+                 : "v"(pa), "v"(pb), "v"(pc), "v"(pd)
+                 : "memory");
+    a = make_float4(x.x, x.y, x.z, x.w); b = make_float4(y.x, y.y, y.z, y.w);
+    c = make_float4(z.x, z.y, z.z, z.w); d = make_float4(w.x, w.y, w.z, w.w);
+}
 __device__ __forceinline__ float4 f4sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
 
 // Diagnostic stamps (DBG = 1, tuning build only): per workgroup {entry, loop start, loop end, end} in 100 MHz ticks and the
@@ -642,12 +664,15 @@ int conv_wino_splits(int B, int H, int W, int cin, int N) {
 
 // Can the kernel emit GroupNorm partials for this shape?  One pass (no channel-chunk split), every m tile full and inside one
 // image, whole groups inside an n tile, and few enough tiles per image that the consumer's merge stays trivial.
-int conv_wino_stats_parts(int B, int H, int W, int cin, int N, int groups) {
+static int wino_stats_shape_parts(int B, int H, int W, int cin, int N, int groups) {     // ... whatever the channel-chunk split
     if (!conv_wino_ok(DDK_CONV3X3_S1, H, W, cin, N) || groups <= 0 || N % groups) return 0;
     const int cpg = N / groups, tpi = (H / 2) * (W / 2), nt_w = wino_nt(wino_variant(B, H, W, N));
     if (cpg % 4 || nt_w % cpg || nt_w / cpg > 8 || tpi % WBT || tpi / WBT > 32) return 0;
-    if (conv_wino_splits(B, H, W, cin, N) != 1) return 0;
     return tpi / WBT;
+}
+int conv_wino_stats_parts(int B, int H, int W, int cin, int N, int groups) {
+    if (conv_wino_splits(B, H, W, cin, N) != 1) return 0;
+    return wino_stats_shape_parts(B, H, W, cin, N, groups);
 }
 
 // ---- transpose conv (conv_winoT_kernel.inc)
@@ -737,6 +762,27 @@ int conv_wino_cluster_np(int B, int H, int W, int cin, int N, int groups) {
     if (run % (np * nt) || per_round % (np * nt)) return 0;      // runs and rounds begin on cluster boundaries
     return np;
 }
+// ... and the shapes whose channel chunks are split over several workgroups (too few tiles for 256 workgroups otherwise): workgroup
+// `split 0` of a tile collects its partners' partial tiles in the launch, then takes part in the exchange above.  Everything must be
+// resident at once: at most 256 workgroups in all (one dispatch round), on the 8-matrix-wave kernels.  Returns np, *splits_out = splits.
+int conv_wino_cluster_split_np(int B, int H, int W, int cin, int N, int groups, int* splits_out) {
+    if (!conv_wino_ok(DDK_CONV3X3_S1, H, W, cin, N)) return 0;
+    const int splits = conv_wino_splits(B, H, W, cin, N);
+    if (splits_out) *splits_out = splits;
+    if (splits <= 1 || splits > 4) return 0;
+    const int np = wino_stats_shape_parts(B, H, W, cin, N, groups);
+    if (np <= 0 || np > 8) return 0;
+    const int variant = wino_variant(B, H, W, N);
+    if (variant != WINO_V_D) return 0;                           // the 64-channel tile: the only one with such shapes
+    const int nt_w = wino_nt(variant);
+    if (N / groups > 32 || nt_w % (N / groups) || nt_w / (N / groups) > 8) return 0;
+    const long long mt = (long long)B * np, nt = N / nt_w;
+    if (mt * nt * splits > 256) return 0;
+    return np;
+}
+size_t conv_wino_cluster_pair_words(int B, int H, int W, int N) {      // pair counters of the split form: 16 words per (m tile, n tile)
+    return (size_t)ceil_div((long long)B * (H / 2) * (W / 2), WBT) * (size_t)(N / WBN) * 16;
+}
 size_t conv_wino_cluster_ws_floats(int B, int H, int W, int N) {
     const long long mt = (long long)B * (H / 2) * (W / 2) / WBT, nt = N / WBN;      // sized for the narrow tile: enough for either
     return (size_t)(mt * nt * 32 + (long long)B * nt * 16);
@@ -767,8 +813,15 @@ bool conv_wino_variant_new(int B, int H, int W, int N) { return wino_variant(B, 
 int conv_wino_forward(const ddk_conv_args& a, int splits, hipStream_t st, const WinoGnFuse* fuse) {
     WinoParams p{};
     if (fuse) {
-        const int np = conv_wino_cluster_np(a.B, a.H, a.W, a.c0 + a.c1, a.N, fuse->groups);
-        DDK_REQUIRE(np > 0 && splits == 1 && !a.post_mish && !a.gn_partials, "conv(wino): shape not eligible for the in-launch GroupNorm");
+        const int np = splits == 1 ? conv_wino_cluster_np(a.B, a.H, a.W, a.c0 + a.c1, a.N, fuse->groups)
+                                   : conv_wino_cluster_split_np(a.B, a.H, a.W, a.c0 + a.c1, a.N, fuse->groups, nullptr);
+        DDK_REQUIRE(np > 0 && !a.post_mish && !a.gn_partials, "conv(wino): shape not eligible for the in-launch GroupNorm");
+        if (splits > 1) {
+            DDK_REQUIRE(fuse->pairs && a.workspace && aligned16(a.workspace) && !fuse->res_x,
+                        "conv(wino, cluster): a split shape needs pair counters and the slab workspace");
+            p.cl_slab = static_cast<float*>(a.workspace);
+            p.cl_pair = fuse->pairs;
+        }
         DDK_REQUIRE(fuse->gamma && fuse->beta && fuse->records && fuse->counters && aligned16(fuse->gamma) && aligned16(fuse->beta) &&
                         aligned16(fuse->temb) && fuse->temb_stride % 4 == 0 && aligned16(fuse->records) && aligned16(fuse->counters),
                     "conv(wino): in-launch GroupNorm arguments");
@@ -803,7 +856,7 @@ int conv_wino_forward(const ddk_conv_args& a, int splits, hipStream_t st, const 
     p.post_mish = a.post_mish;
     p.dTW = make_fastdiv_u((unsigned)p.TW);
     p.dTH = make_fastdiv_u((unsigned)p.TH);
-    if (p.splits > 1) p.out = static_cast<float*>(a.workspace);
+    if (p.splits > 1 && !fuse) p.out = static_cast<float*>(a.workspace);
     const int variant = wino_variant(a.B, a.H, a.W, a.N);
     if (variant != WINO_V_OLD) {
         dim3 grid2((unsigned)ceil_div(p.tiles, WBT), (unsigned)(a.N / wino_nt(variant)), (unsigned)p.splits);
@@ -934,11 +987,20 @@ extern "C" int ddk_conv_wino_splits(int B, int H, int W, int cin, int N) {
  * 16x16): see WinoGnFuse / the CL variant above. */
 extern "C" int ddk_conv3x3_gn_mish_cluster_ok(int B, int H, int W, int cin, int N, int groups) {
     if (!ddk::conv_wino_cluster_device_ok()) return 0;
-    return ddk::conv_wino_cluster_np(B, H, W, cin, N, groups);
+    const int np = ddk::conv_wino_cluster_np(B, H, W, cin, N, groups);
+    return np > 0 ? np : ddk::conv_wino_cluster_split_np(B, H, W, cin, N, groups, nullptr);
 }
 extern "C" size_t ddk_conv3x3_gn_mish_cluster_workspace_bytes(int B, int H, int W, int N) {
     if (B <= 0 || H <= 0 || W <= 0 || N <= 0 || N % ddk::WBN) return 0;
     return ((size_t)B * 8 * 16 + 16 + ddk::conv_wino_cluster_ws_floats(B, H, W, N)) * sizeof(float);
+}
+/* a shape whose channel chunks are split over workgroups (ddk_conv_wino_splits() > 1) needs the pair counters and (splits - 1) slabs
+ * of partial tiles behind that: the whole workspace in bytes, or 0 when the shape is not of that kind */
+extern "C" size_t ddk_conv3x3_gn_mish_cluster_split_workspace_bytes(int B, int H, int W, int cin, int N, int groups) {
+    int splits = 1;
+    if (ddk::conv_wino_cluster_split_np(B, H, W, cin, N, groups, &splits) <= 0) return 0;
+    return ddk_conv3x3_gn_mish_cluster_workspace_bytes(B, H, W, N) +
+           (ddk::conv_wino_cluster_pair_words(B, H, W, N) + (size_t)(splits - 1) * B * H * W * N) * sizeof(float);
 }
 extern "C" int ddk_conv3x3_gn_mish_cluster_check(void* workspace, int B, ddk_stream_t s) {
     using namespace ddk;
@@ -969,13 +1031,16 @@ extern "C" int ddk_conv3x3_gn_mish_cluster(const float* src0, int c0, const floa
                                            size_t workspace_bytes, ddk_stream_t s) {
     using namespace ddk;
     DDK_REQUIRE(src0 && weight_wino && gamma && beta && out && workspace, "conv3x3_gn_mish_cluster: null pointer");
-    DDK_REQUIRE(conv_wino_cluster_device_ok() && conv_wino_cluster_np(B, H, W, c0 + c1, N, groups) > 0,
+    DDK_REQUIRE(conv_wino_cluster_device_ok() && ddk_conv3x3_gn_mish_cluster_ok(B, H, W, c0 + c1, N, groups) > 0,
                 "conv3x3_gn_mish_cluster: shape or device not eligible (ddk_conv3x3_gn_mish_cluster_ok)");
-    DDK_REQUIRE(workspace_bytes >= ddk_conv3x3_gn_mish_cluster_workspace_bytes(B, H, W, N) && aligned16(workspace),
-                "conv3x3_gn_mish_cluster: workspace");
+    const size_t plain_bytes = ddk_conv3x3_gn_mish_cluster_workspace_bytes(B, H, W, N);
+    const size_t split_bytes = ddk_conv3x3_gn_mish_cluster_split_workspace_bytes(B, H, W, c0 + c1, N, groups);
+    DDK_REQUIRE(workspace_bytes >= (split_bytes ? split_bytes : plain_bytes) && aligned16(workspace), "conv3x3_gn_mish_cluster: workspace");
     float* ws = static_cast<float*>(workspace);
     // counters + the sticky give-up word behind them: zeroed per call here (a plan zeroes them once per forward / chain)
     DDK_HIP(hipMemsetAsync(ws, 0, ((size_t)B * 8 * 16 + 16) * sizeof(float), as_stream(s)));
+    float* pairs = ws + plain_bytes / sizeof(float);
+    if (split_bytes) DDK_HIP(hipMemsetAsync(pairs, 0, conv_wino_cluster_pair_words(B, H, W, N) * sizeof(float), as_stream(s)));
     ddk_conv_args a{};
     a.kind = DDK_CONV3X3_S1;
     a.src0 = src0; a.src1 = src1; a.c0 = c0; a.c1 = c1;
@@ -985,8 +1050,13 @@ extern "C" int ddk_conv3x3_gn_mish_cluster(const float* src0, int c0, const floa
     a.resid = addend;
     a.out = out;
     a.B = B; a.H = H; a.W = W; a.N = N;
-    const WinoGnFuse f{gamma, beta, temb, nullptr, temb_stride, eps, groups, ws + (size_t)B * 8 * 16 + 16, reinterpret_cast<unsigned*>(ws),
-                       reinterpret_cast<unsigned*>(ws + (size_t)B * 8 * 16)};
+    WinoGnFuse f{gamma, beta, temb, nullptr, temb_stride, eps, groups, ws + (size_t)B * 8 * 16 + 16, reinterpret_cast<unsigned*>(ws),
+                 reinterpret_cast<unsigned*>(ws + (size_t)B * 8 * 16)};
+    if (split_bytes) {
+        f.pairs = reinterpret_cast<unsigned*>(pairs);
+        a.workspace = pairs + conv_wino_cluster_pair_words(B, H, W, N);
+        a.workspace_bytes = split_bytes - plain_bytes - conv_wino_cluster_pair_words(B, H, W, N) * sizeof(float);
+    }
     return conv_forward(a, as_stream(s), nullptr, &f);
 }
 

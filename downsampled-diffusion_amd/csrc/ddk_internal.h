@@ -154,6 +154,8 @@ struct WinoGnFuse {
     float* records;
     unsigned* counters;
     unsigned* fail;         // sticky count of workgroups that gave up waiting (may be null)
+    unsigned* pairs = nullptr;   // shapes whose channel chunks are split (conv_wino_cluster_split_np): conv_wino_cluster_pair_words() zeroed
+                                 // words; the partial tiles go through ddk_conv_args::workspace ((splits - 1) slabs)
     // optional: the addend is a 1x1 conv of a narrow tensor, evaluated in the epilogue (the first ResnetBlock's res_conv of the
     // <= 8-channel input, blocks.py:103,115): res_x [B*H*W][res_cin], res_w [N][res_ld] (first res_cin entries of a row), res_b [N] or null
     const float* res_x = nullptr;
@@ -169,6 +171,8 @@ bool conv_wino_ok(int kind, int H, int W, int cin, int N);
 int conv_wino_splits(int B, int H, int W, int cin, int N);
 int conv_wino_forward(const ddk_conv_args& a, int splits, hipStream_t st, const WinoGnFuse* fuse = nullptr);
 int conv_wino_cluster_np(int B, int H, int W, int cin, int N, int groups);    // m tiles per image when eligible, else 0
+int conv_wino_cluster_split_np(int B, int H, int W, int cin, int N, int groups, int* splits_out);   // the same for k-split shapes
+size_t conv_wino_cluster_pair_words(int B, int H, int W, int N);
 bool conv_wino_variant_new(int B, int H, int W, int N);   // the shape runs on the 8-matrix-wave kernels (they carry the 1x1 addend)
 bool conv_wino_cluster_device_ok();     // a whole MI355X (256 CUs, 8 XCDs, no CU mask): the only place a cluster is co-resident
 size_t conv_wino_cluster_ws_floats(int B, int H, int W, int N);

@@ -64,7 +64,9 @@ __device__ __forceinline__ void ld_sc1_x4(f32x4& a, f32x4& b, f32x4& c, f32x4& d
                  "global_load_dwordx4 %3, %7, off sc1\n\ts_waitcnt vmcnt(0)"
                  : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d) : "v"(pa), "v"(pb), "v"(pc), "v"(pd) : "memory");
 }
-__device__ __forceinline__ void st_sc1(float* p, f32x4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(v) : "memory"); }
+// (s_nop 1: a store of more than 8 bytes reads its upper data registers up to two cycles after issue; the compiler's hazard recogniser does
+//  not see through the asm, so the wait states that keep a following VALU write out of those registers are spelled out here)
+__device__ __forceinline__ void st_sc1(float* p, f32x4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(v) : "memory"); }
 
 #ifdef DDK_TUNING
 // Diagnostic stamps (tuning build only): per op and watched workgroup (blocks 0, 100, 255), s_memrealtime ticks (10 ns) at

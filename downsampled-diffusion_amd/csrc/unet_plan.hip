@@ -106,6 +106,8 @@ struct ddk_unet {
                                              // sync point), 2 in ddk_unet_forward too
     int cluster_limit = 1 << 30;             // diagnostic: only the first so many eligible launches of a forward take that path
     int cluster_np_max = 8;                  // largest cluster (workgroups per image and n tile) that takes the path
+    bool cluster_split = true;               // ... also on shapes whose channel chunks are split over 2-4 workgroups (conv_wino_cluster_split_np):
+                                             // a tile's first workgroup sums its partners' partial tiles in the launch (diagnostic option 11)
     bool attn_kvctx = true;                  // folded attention block: k, v projection + context in one launch (no kv tensor)
     bool fold_down_reduce = false;           // Downsample conv's split-K slabs summed by the image-local ResnetBlock behind it (no reduce launch).
                                              // OFF by default: measured 6 us per step SLOWER (each of an image's eight workgroups re-sums the slabs:
@@ -499,6 +501,13 @@ extern "C" int ddk_unet_set_option(ddk_unet* u, int option, int value) {
         u->cluster_np_max = value;
         return DDK_OK;
     }
+    if (option == 11) {  // diagnostic (not in ddk.h): the in-launch GroupNorm on channel-chunk-split shapes
+        std::lock_guard<std::mutex> lock(u->mu);
+        if (!u->graphs.empty()) DDK_HIP(hipDeviceSynchronize());
+        drop_graphs(u);
+        u->cluster_split = value != 0;
+        return DDK_OK;
+    }
     return fail_arg("unet_set_option: unknown option");
 }
 extern "C" unsigned ddk_debug_cluster_timeouts(void) { return ddk::conv_wino_cluster_timeouts(); }
@@ -630,9 +639,12 @@ static size_t conv3_ws_floats(const ConvW& cw, int B, int H, int W, int cin, int
 // counters of the cluster GroupNorm: fixed place (16 words per (image, n tile), N <= 512) so every layer re-arms the same words
 // ... and behind them one line for the sticky give-up count of this workspace (ddk_unet_cluster_check)
 // ... and behind that the level chain's arrival and departure counters, one 128-byte line per image each
-static size_t cl_counter_floats(int B) { return (size_t)B * 8 * 16 + 16 + (size_t)B * 64; }
+// ... and the pair counters of the channel-chunk-split in-launch GroupNorm: <= 128 (m tile, n tile) pairs (256 workgroups, >= 2 splits)
+constexpr size_t CL_PAIR_WORDS = 128 * 16;
+static size_t cl_counter_floats(int B) { return (size_t)B * 8 * 16 + 16 + (size_t)B * 64 + CL_PAIR_WORDS; }
 static size_t cl_fail_offset(int B) { return (size_t)B * 8 * 16; }
 static size_t cl_chain_offset(int B) { return (size_t)B * 8 * 16 + 16; }
+static size_t cl_pair_offset(int B) { return (size_t)B * 8 * 16 + 16 + (size_t)B * 64; }
 constexpr int CHAIN_BUFS = 18;                // activations that cross workgroups inside the level chain, [B][16][256] each
 constexpr int CHAIN8_BUFS = 5;                // ... inside an 8x8 chain, [B][64][256] each
 
@@ -830,6 +842,30 @@ static int run_conv_gn(Ctx& c, const ConvW& cw, const float* src0, int c0, const
         float* cl = c.W + c.ly.off_cl;
         const WinoGnFuse f{c.P + n.g, c.P + n.b, temb, c.temb_rows, c.u.temb_total, GN_EPS, GROUPS, cl + cl_counter_floats(c.B),
                            reinterpret_cast<unsigned*>(cl), reinterpret_cast<unsigned*>(cl + cl_fail_offset(c.B))};
+        return conv_forward(a, c.st, nullptr, &f);
+    }
+    int cls_splits = 1;
+    const int cls_np = c.allow_cluster && c.u.cluster_split && cw.has_wu && conv_wino_cluster_device_ok()
+                           ? conv_wino_cluster_split_np(c.B, H, W, c0 + c1, N, GROUPS, &cls_splits) : 0;
+    if (cls_np > 0 && cls_np <= c.u.cluster_np_max && (size_t)cls_splits * c.B * H * W * N <= c.ly.splitk &&
+        conv_wino_cluster_pair_words(c.B, H, W, N) <= CL_PAIR_WORDS && c.n_cluster++ < c.u.cluster_limit) {
+        // the same on a shape whose channel chunks are split over workgroups (16x16 maps of 64-channel tiles at batch 32): a tile's first
+        // workgroup sums its partners' partial tiles in the launch -- no slabs left for a GroupNorm launch to sum, no GroupNorm launch
+        ddk_conv_args a{};
+        a.kind = DDK_CONV3X3_S1;
+        a.src0 = src0; a.src1 = src1; a.c0 = c0; a.c1 = c1;
+        a.weight = c.P + cw.w;
+        a.weight_wino = c.P + cw.wu;
+        a.bias = cw.has_bias ? c.P + cw.b : nullptr;
+        a.resid = addend;
+        a.out = out;
+        a.B = c.B; a.H = H; a.W = W; a.N = N;
+        a.workspace = c.W + c.ly.off_splitk;
+        a.workspace_bytes = c.ly.splitk * sizeof(float);
+        float* cl = c.W + c.ly.off_cl;
+        WinoGnFuse f{c.P + n.g, c.P + n.b, temb, c.temb_rows, c.u.temb_total, GN_EPS, GROUPS, cl + cl_counter_floats(c.B),
+                     reinterpret_cast<unsigned*>(cl), reinterpret_cast<unsigned*>(cl + cl_fail_offset(c.B))};
+        f.pairs = reinterpret_cast<unsigned*>(cl + cl_pair_offset(c.B));
         return conv_forward(a, c.st, nullptr, &f);
     }
     const int np = cw.has_wu ? conv_wino_stats_parts(c.B, H, W, c0 + c1, N, GROUPS) : 0;

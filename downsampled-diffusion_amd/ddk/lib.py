@@ -149,6 +149,7 @@ SIGNATURES = {
     "ddk_unet_forward": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P, _SZ, _P]),
     "ddk_conv3x3_gn_mish_cluster_ok": (_I, [_I, _I, _I, _I, _I, _I]),
     "ddk_conv3x3_gn_mish_cluster_workspace_bytes": (_SZ, [_I, _I, _I, _I]),
+    "ddk_conv3x3_gn_mish_cluster_split_workspace_bytes": (_SZ, [_I, _I, _I, _I, _I, _I]),
     "ddk_conv3x3_gn_mish_cluster": (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _F, _P, _SZ, _P]),
     "ddk_unet_set_option": (_I, [_P, _I, _I]),
     "ddk_debug_cluster_timeouts": (C.c_uint, []),

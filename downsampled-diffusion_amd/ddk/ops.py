@@ -479,7 +479,8 @@ def conv3x3_gn_mish_cluster(x, w_wino, bias, gamma, beta, x2=None, temb=None, ad
     lib = L.load()
     if lib.ddk_conv3x3_gn_mish_cluster_ok(b, h, w_, c0 + c1, n, groups) <= 0:
         raise L.DDKError(f"conv3x3_gn_mish_cluster: shape {tuple(x.shape)} (+{c1}) -> {n} not eligible")
-    nbytes = lib.ddk_conv3x3_gn_mish_cluster_workspace_bytes(b, h, w_, n)
+    nbytes = max(lib.ddk_conv3x3_gn_mish_cluster_workspace_bytes(b, h, w_, n),
+                 lib.ddk_conv3x3_gn_mish_cluster_split_workspace_bytes(b, h, w_, c0 + c1, n, groups))      # (the k-split kind of shape)
     ws = _ws(x.device, nbytes, "cluster")
     out = torch.empty((b, h, w_, n), device=x.device, dtype=torch.float32)
     stride = temb.stride(0) if temb is not None else 0

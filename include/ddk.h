@@ -203,6 +203,11 @@ int ddk_conv3x3_gn_mish_slabs(const float* src, int src_slabs, long long src_str
 int ddk_conv3x3_gn_mish_cluster_ok(int B, int H, int W, int cin, int N, int groups);
 int ddk_conv3x3_gn_mish_cluster_check(void* workspace, int B, ddk_stream_t s);
 size_t ddk_conv3x3_gn_mish_cluster_workspace_bytes(int B, int H, int W, int N);
+/* _ok() also admits the shapes whose channel chunks the Winograd conv splits over 2-4 workgroups (ddk_conv_wino_splits() > 1; 16x16 maps
+ * of 64-channel tiles at batch 32) when all of them make one dispatch round (<= 256): a tile's first workgroup sums its partners'
+ * partial tiles inside the launch, then takes part in the exchange -- no slabs for a GroupNorm launch to sum.  Such a shape needs a larger
+ * workspace (pair counters + splits - 1 slabs): _split_workspace_bytes() gives the whole size, or 0 for a shape of the plain kind. */
+size_t ddk_conv3x3_gn_mish_cluster_split_workspace_bytes(int B, int H, int W, int cin, int N, int groups);
 int ddk_conv3x3_gn_mish_cluster(const float* src0, int c0, const float* src1, int c1, const float* weight_wino, const float* bias,
                                 const float* gamma, const float* beta, const float* temb, int temb_stride, const float* addend,
                                 float* out, int B, int H, int W, int N, int groups, float eps, void* workspace, size_t workspace_bytes,

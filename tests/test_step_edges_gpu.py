@@ -217,6 +217,47 @@ def test_conv3x3_gn_mish_cluster(ops, B, H, W, c0, c1, N):
     assert ops.cluster_timeouts() == before
 
 
+@pytest.mark.parametrize("B,H,W,c0,c1,N", [(32, 16, 16, 128, 0, 128), (32, 16, 16, 256, 256, 128), (16, 16, 16, 128, 0, 128),
+                                           (8, 32, 32, 64, 0, 64)])
+def test_conv3x3_gn_mish_cluster_on_k_split_shapes(ops, B, H, W, c0, c1, N):
+    """the same ONE launch on shapes whose channel chunks the Winograd conv splits over 2-4 workgroups (cfg4's 16x16 up level): a tile's
+    first workgroup sums its partners' partial tiles inside the launch, then the image's tiles exchange statistics as above.
+    == conv (slabs + reduce launch) followed by the GroupNorm launch within 2e-6 (the k sum's order differs), == torch within 2e-5;
+    bit-stable run to run; counters re-arm; nothing timed out"""
+    cin = c0 + c1
+    lib = ops.L.load()
+    if lib.ddk_conv3x3_gn_mish_cluster_ok(B, H, W, cin, N, 8) <= 0:
+        pytest.skip("shape / device not eligible")
+    assert lib.ddk_conv_wino_splits(B, H, W, cin, N) > 1 and lib.ddk_conv3x3_gn_mish_cluster_split_workspace_bytes(B, H, W, cin, N, 8) > 0
+    x = rnd(B, cin, H, W, seed=61)
+    w = rnd(N, cin, 3, 3, seed=62, scale=(cin * 9) ** -0.5)
+    b = rnd(N, seed=63)
+    gamma, beta, temb = 1 + 0.1 * rnd(N, seed=64), 0.1 * rnd(N, seed=65), rnd(B, N, seed=66)
+    add = rnd(B, N, H, W, seed=67)
+    xh = to_nhwc(x).to(DEV)
+    x0, x1 = (xh[..., :c0].contiguous(), xh[..., c0:].contiguous()) if c1 else (xh, None)
+    wu, wp = ops.pack_conv_weight_wino(w.to(DEV)), ops.pack_conv_weight(w.to(DEV))
+    g, be, te, ad = gamma.to(DEV), beta.to(DEV), temb.to(DEV), to_nhwc(add).to(DEV)
+    before = ops.cluster_timeouts()
+    out = ops.conv3x3_gn_mish_cluster(x0, wu, b.to(DEV), g, be, x2=x1, temb=te, addend=ad)
+    out2 = ops.conv3x3_gn_mish_cluster(x0, wu, b.to(DEV), g, be, x2=x1, temb=te, addend=ad)
+    torch.cuda.synchronize()
+    assert ops.cluster_timeouts() == before
+    assert torch.equal(out, out2)
+    raw = ops.conv(ops.CONV3X3_S1, x0, wp, b.to(DEV), x2=x1, w_wino=wu)
+    two = ops.groupnorm_mish(raw, g, be, temb=te, addend=ad)
+    assert rel_err(out.cpu(), two.cpu()) < 2e-6
+    want = gn_mish(F.conv2d(x, w, b, padding=1), gamma, beta) + temb[:, :, None, None] + add
+    assert rel_err(to_nchw(out.cpu()), want) < 2e-5
+    for k in range(3):        # different inputs through the same pair counters / slabs / records: a stale partial tile would show
+        xk = (xh * (k + 2.0)).contiguous()
+        xk0, xk1 = (xk[..., :c0].contiguous(), xk[..., c0:].contiguous()) if c1 else (xk, None)
+        ok = ops.conv3x3_gn_mish_cluster(xk0, wu, b.to(DEV), g, be, x2=xk1)
+        rk = ops.conv(ops.CONV3X3_S1, xk0, wp, b.to(DEV), x2=xk1, w_wino=wu)
+        assert rel_err(ok.cpu(), ops.groupnorm_mish(rk, g, be).cpu()) < 2e-6
+    assert ops.cluster_timeouts() == before
+
+
 def test_cluster_groupnorm_option_gives_identical_unet():
     """The plan with GroupNorm finished inside the conv launches == the plan with the conv + GroupNorm-apply pairs (<= 2e-5 of the
     output's max: the two differ in FMA contraction of the residual add only), and is bit-stable run to run"""
