@@ -384,8 +384,8 @@ WINO_STEP_SHAPES = (          # every conv3x3_wino2_kernel launch of one cfg4 re
     ("128->256 @16x16 + GroupNorm in the launch", 16, 128, 256, 1, True),
     ("256->256 @16x16 + GroupNorm in the launch", 16, 256, 256, 3, True),
     ("512->256 @8x8 (k split, slabs summed by the GroupNorm launch behind it)", 8, 512, 256, 1, False),
-    ("512->128 @16x16 (k split)", 16, 512, 128, 1, False),
-    ("128->128 @16x16 (k split)", 16, 128, 128, 3, False),
+    ("512->128 @16x16 (k split over two workgroups, partner tile summed + GroupNorm in the launch)", 16, 512, 128, 1, True),
+    ("128->128 @16x16 (k split over two workgroups, partner tile summed + GroupNorm in the launch)", 16, 128, 128, 3, True),
     ("128->128 @32x32", 32, 128, 128, 1, False),
 )
 
