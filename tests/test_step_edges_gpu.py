@@ -287,20 +287,24 @@ def test_cluster_groupnorm_option_gives_identical_unet():
     assert rel_err(y_on.cpu(), y_off.cpu()) < 2e-5
 
 
-def test_cluster_groupnorm_next_to_a_foreign_kernel_is_never_silently_wrong(ops):
+@pytest.mark.parametrize("C,N", [(256, 256), (128, 128)])
+def test_cluster_groupnorm_next_to_a_foreign_kernel_is_never_silently_wrong(ops, C, N):
     """A long-running kernel on ANOTHER stream holds most CUs (through its LDS footprint) while cluster launches run: the
     co-residency the exchange assumes does not hold.  Allowed outcomes: the correct tensor, or a raised error (the bounded
     wait gave up: NaN tiles + sticky counter) -- never a finite wrong tensor.  And the counters re-arm: the next launch on an
-    idle GPU is correct again."""
-    B, H, W, C, N = 32, 16, 16, 256, 256
+    idle GPU is correct again.  (128 -> 128: the k-split form, whose first workgroups also wait for their partners' partial tiles.)"""
+    B, H, W = 32, 16, 16
     if ops.L.load().ddk_conv3x3_gn_mish_cluster_ok(B, H, W, C, N, 8) <= 0:
         pytest.skip("device / shape not eligible")
     x = to_nhwc(rnd(B, C, H, W, seed=51)).to(DEV)
     w = rnd(N, C, 3, 3, seed=52, scale=(C * 9) ** -0.5).to(DEV)
     b, gamma, beta = rnd(N, seed=53).to(DEV), (1 + 0.1 * rnd(N, seed=54)).to(DEV), (0.1 * rnd(N, seed=55)).to(DEV)
     wu = ops.pack_conv_weight_wino(w)
-    raw, part, tiles = ops.conv_with_gn_partials(x, ops.pack_conv_weight(w), b, wu)
-    want = ops.groupnorm_mish_from_partials(raw, part, tiles, gamma, beta)
+    if ops.L.load().ddk_conv_wino_splits(B, H, W, C, N) > 1:
+        want = ops.groupnorm_mish(ops.conv(ops.CONV3X3_S1, x, ops.pack_conv_weight(w), b, w_wino=wu), gamma, beta)
+    else:
+        raw, part, tiles = ops.conv_with_gn_partials(x, ops.pack_conv_weight(w), b, wu)
+        want = ops.groupnorm_mish_from_partials(raw, part, tiles, gamma, beta)
     torch.cuda.synchronize()
     lib = ops.L.load()
     side = torch.cuda.Stream(device=DEV)
@@ -310,7 +314,7 @@ def test_cluster_groupnorm_next_to_a_foreign_kernel_is_never_silently_wrong(ops)
         ops.L.check(lib.ddk_debug_occupy(filler_wgs, 100 * 1024, 60000, side.cuda_stream), "debug_occupy")
         try:
             out = ops.conv3x3_gn_mish_cluster(x, wu, b, gamma, beta)           # check=True: waits, raises on a give-up
-            assert rel_err(out.cpu(), want.cpu()) < 1e-6
+            assert rel_err(out.cpu(), want.cpu()) < 2e-6
             outcomes.append("correct")
         except ops.L.DDKError as e:
             assert "gave up" in str(e)
@@ -318,7 +322,7 @@ def test_cluster_groupnorm_next_to_a_foreign_kernel_is_never_silently_wrong(ops)
         side.synchronize()
     # idle again: the same records / counters serve a correct launch (they re-armed, or the wrapper zeroed them)
     out = ops.conv3x3_gn_mish_cluster(x, wu, b, gamma, beta)
-    assert rel_err(out.cpu(), want.cpu()) < 1e-6
+    assert rel_err(out.cpu(), want.cpu()) < 2e-6
     print("outcomes next to the foreign kernel:", outcomes)
 
 
