@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Launch ONE kernel of the reverse step, at its cfg4 shape, 20 times -- the program rocprofv3 counter passes run
 (`rocprofv3 --kernel-trace --pmc ... -- python3 tools/pmc_one.py <case>`; counters and --stats in separate passes).
-cases: wino (conv3x3 128->128 @32x32 B=32, Winograd), gn (GroupNorm-apply from partials, 32x32x32x128), local4 (conv+GroupNorm+Mish
+cases: cls16 (the k-split in-launch GroupNorm conv of the 16x16 up level), wino (conv3x3 128->128 @32x32 B=32, Winograd), gn (GroupNorm-apply from partials, 32x32x32x128), local4 (conv+GroupNorm+Mish
 one launch, 256->256 @4x4), wlocal8 (the same @8x8, Winograd form), first (conv_first 8->128 @32x32), tail (final_tail_kernel),
 cluster16 (conv3x3 256->256 @16x16 with GroupNorm finished in the launch), ws (to_out 1x1 128->128 + bias + residual @32x32,
 weights-stationary kernel), fold (attn_fold_kernel), halo32 (wgrad3x3_halo32_kernel), gnbig (gn_apply_kernel on the 256x256 tensor),
@@ -105,6 +105,11 @@ elif case == "cluster16":
     x, w = torch.randn(B, 16, 16, 256, device=dev), rw(256, 256)
     wu, b = ops.pack_conv_weight_wino(w), torch.zeros(256, device=dev)
     gam, bet, temb = torch.ones(256, device=dev), torch.zeros(256, device=dev), torch.randn(B, 256, device=dev)
+    fn = lambda: ops.conv3x3_gn_mish_cluster(x, wu, b, gam, bet, temb=temb, check=False)
+elif case == "cls16":          # conv3x3 128->128 @16x16, k split over two workgroups per tile, partner tile summed + GroupNorm in the launch (round 6)
+    x, w = torch.randn(B, 16, 16, 128, device=dev), rw(128, 128)
+    wu, b = ops.pack_conv_weight_wino(w), torch.zeros(128, device=dev)
+    gam, bet, temb = torch.ones(128, device=dev), torch.zeros(128, device=dev), torch.randn(B, 128, device=dev)
     fn = lambda: ops.conv3x3_gn_mish_cluster(x, wu, b, gam, bet, temb=temb, check=False)
 elif case == "unet":           # the whole cfg4 UNet forward, in-launch paths on: counters of kernels that only exist inside it (level_chain_kernel)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
