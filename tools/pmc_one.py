@@ -75,6 +75,10 @@ elif case == "halo32":         # narrow weight gradient: 3x3 32->32 on 64 x 64 x
     x, dy = torch.randn(64, 64, 64, 32, device=dev), torch.randn(64, 64, 64, 32, device=dev)
     gw = torch.zeros(32, 32, 3, 3, device=dev)
     fn = lambda: ops.conv_wgrad_(ops.CONV3X3_S1, x, dy, gw, c_real=32, cw=32, c_off=0)
+elif case == "wgrad64":        # weight gradient of a 3x3 conv 256->256 on 128 x 4 x 4 pixels (cfg3 merged pass, 4x4 level): wgrad_kernel<64, 64, 2, 2>
+    x, dy = torch.randn(128, 4, 4, 256, device=dev), torch.randn(128, 4, 4, 256, device=dev)
+    gw = torch.zeros(256, 256, 3, 3, device=dev)
+    fn = lambda: ops.conv_wgrad_(ops.CONV3X3_S1, x, dy, gw, c_real=256, cw=256, c_off=0)
 elif case == "gnbig":          # large-slab GroupNorm apply pass: 8 x 256 x 256 x 128 (cfg5 top level)
     x = torch.randn(8, 256, 256, 128, device=dev)
     gam, bet, temb = torch.ones(128, device=dev), torch.zeros(128, device=dev), torch.randn(8, 128, device=dev)
