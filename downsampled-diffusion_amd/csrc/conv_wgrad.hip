@@ -559,6 +559,15 @@ static WgChoice wgrad_choice(int N, int cx, int ntaps, long long M) {
     if (s > max_s) s = max_s;
     if (s > 256) s = 256;
     if (s < 1) s = 1;
+    // Round 6 (profiles/r06_wgrad64_pmc.json: 576 workgroups = 2.25 per CU, so the CUs with three set the time at 0.75 of the fill):
+    // among this and the next few split counts take the one whose workgroup count fills whole multiples of the 256 CUs best
+    if (waves == 4 && tiles * s > 256) {
+        auto fill = [&](long long ss) { const long long w = tiles * ss; return (double)w / (double)(ceil_div(w, 256) * 256); };
+        long long best = s;
+        for (long long cand = s + 1; cand <= s + 4 && cand <= max_s && cand <= 256; ++cand)
+            if (fill(cand) > fill(best) + 0.04) best = cand;
+        s = best;
+    }
     c.rows_per = (int)(ceil_div(ceil_div(M, s), 32) * 32);
     c.splits = (int)ceil_div(M, c.rows_per);
     return c;
