@@ -184,6 +184,24 @@ __global__ __launch_bounds__(1024) void final_tail_kernel(const TailParams p) {
     const bool h2 = sub & (LPP / 2), h4 = sub & (LPP / 4), h8 = sub & (LPP / 8);
     const int my_co = (h2 ? 4 : 0) + (h4 ? 2 : 0) + (h8 ? 1 : 0);
     const float my_bias = (p.bias && my_co < p.n_out) ? p.bias[my_co] : 0.f;
+    // ... including phase 2's operands of the threads that have one (128 * n_out / 4 <= 256 float4 per tile): the latent, the schedule
+    // scalars and the noise draw depend on nothing computed here -- one memory latency and the Philox rounds less behind the last barrier
+    const int cnt4 = 128 * p.n_out / 4;
+    const long long e4 = pix0 * p.n_out / 4;          // host: (128 * n_out) % 4 == 0
+    float4 xv0 = make_float4(0.f, 0.f, 0.f, 0.f), zv0 = xv0;
+    float cr = 0.f, crm1 = 0.f, a1 = 0.f, a2 = 0.f, sg = 0.f;
+    int64_t tb = 0;
+    if (p.x && tid < cnt4) {
+        const uint64_t seed = p.chain_state ? (uint64_t)p.chain_state[1] : p.seed;
+        const uint32_t stream = p.chain_state ? (uint32_t)p.chain_state[2] : p.stream;
+        tb = p.t[b];
+        cr = p.c_recip[tb]; crm1 = p.c_recipm1[tb]; a1 = p.c1[tb]; a2 = p.c2[tb];
+        sg = tb > 0 ? p.sigma[tb] : 0.0f;
+        const long long i = e4 + tid;
+        xv0 = reinterpret_cast<const float4*>(p.x)[i];
+        zv0 = p.noise ? reinterpret_cast<const float4*>(p.noise + (long long)(p.t_first - tb) * p.noise_step_stride)[i]
+                      : philox_normal4((unsigned long long)i, (uint32_t)tb, stream, seed);
+    }
     __syncthreads();
     if (tid < G) {          // the same fixed-order merge as gn_apply_parts_kernel
         float ms = 0.f;
@@ -238,28 +256,17 @@ __global__ __launch_bounds__(1024) void final_tail_kernel(const TailParams p) {
         if ((sub & (LPP / 8 - 1)) == 0 && my_co < p.n_out) es[lp * p.n_out + my_co] = r + my_bias;
     }
     __syncthreads();
-    // phase 2: the tile's 128 * n_out elements, contiguous in the NHWC latent
-    const int cnt4 = 128 * p.n_out / 4;
-    const long long e4 = pix0 * p.n_out / 4;          // host: (128 * n_out) % 4 == 0
-    if (p.eps_out)
-        for (int q = tid; q < cnt4; q += 1024) reinterpret_cast<float4*>(p.eps_out)[e4 + q] = reinterpret_cast<const float4*>(es)[q];
-    if (p.x) {
-        const uint64_t seed = p.chain_state ? (uint64_t)p.chain_state[1] : p.seed;
-        const uint32_t stream = p.chain_state ? (uint32_t)p.chain_state[2] : p.stream;
-        const int64_t tb = p.t[b];
-        const float cr = p.c_recip[tb], crm1 = p.c_recipm1[tb], a1 = p.c1[tb], a2 = p.c2[tb];
-        const float sg = tb > 0 ? p.sigma[tb] : 0.0f;
-        for (int q = tid; q < cnt4; q += 1024) {
-            const long long i = e4 + q;
-            const float4 xv = reinterpret_cast<const float4*>(p.x)[i], ev = reinterpret_cast<const float4*>(es)[q];
-            const float4 zv = p.noise ? reinterpret_cast<const float4*>(p.noise + (long long)(p.t_first - tb) * p.noise_step_stride)[i]
-                                      : philox_normal4((unsigned long long)i, (uint32_t)tb, stream, seed);
+    // phase 2: the tile's 128 * n_out elements, contiguous in the NHWC latent (cnt4 <= 256: at most one float4 per thread)
+    if (tid < cnt4) {
+        const float4 ev = reinterpret_cast<const float4*>(es)[tid];
+        if (p.eps_out) reinterpret_cast<float4*>(p.eps_out)[e4 + tid] = ev;
+        if (p.x) {
             float4 o;
-            o.x = p_step(xv.x, ev.x, zv.x, cr, crm1, a1, a2, sg);
-            o.y = p_step(xv.y, ev.y, zv.y, cr, crm1, a1, a2, sg);
-            o.z = p_step(xv.z, ev.z, zv.z, cr, crm1, a1, a2, sg);
-            o.w = p_step(xv.w, ev.w, zv.w, cr, crm1, a1, a2, sg);
-            reinterpret_cast<float4*>(p.x)[i] = o;
+            o.x = p_step(xv0.x, ev.x, zv0.x, cr, crm1, a1, a2, sg);
+            o.y = p_step(xv0.y, ev.y, zv0.y, cr, crm1, a1, a2, sg);
+            o.z = p_step(xv0.z, ev.z, zv0.z, cr, crm1, a1, a2, sg);
+            o.w = p_step(xv0.w, ev.w, zv0.w, cr, crm1, a1, a2, sg);
+            reinterpret_cast<float4*>(p.x)[e4 + tid] = o;
         }
     }
 }
